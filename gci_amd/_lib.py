@@ -1,0 +1,98 @@
+"""ctypes binding of libgci_hip.so (include/gci_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at load, and
+creating a context without an MI355X raises GciError.  (The CPU oracle lives under oracle/
+and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgci_hip.so")
+
+GCI_OK, GCI_E_INVALID, GCI_E_HIP, GCI_E_NO_NM, GCI_E_ZERO_DIV = 0, -1, -2, -3, -4
+GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, GCI_E_NO_LAYOUT = -5, -6, -7, -8, -9, -10
+GCI_TILE = 4096
+GCI_MAX_JOIN_FILES = 16
+REC_PASS, REC_HQ = 1, 2
+PROF_COUNT = 13
+PROF_DEPTH_SCAN = 5
+
+
+class GciError(RuntimeError):
+    def __init__(self, status: int, msg: str, rec: int = -1):
+        super().__init__(msg)
+        self.status, self.rec = status, rec
+
+
+class JoinFile(ctypes.Structure):
+    _fields_ = [("d_recs", c_void_p), ("n_recs", c_uint32), ("name_delta", c_uint32),
+                ("d_name_base", c_void_p), ("d_name_off", c_void_p)]
+
+
+class Window(ctypes.Structure):
+    _fields_ = [("begin", c_int64), ("end", c_int64)]
+
+
+# every symbol include/gci_hip.h declares: (name, restype, argtypes)
+EXPORTS = [
+    ("gci_abi_version", c_int, []),
+    ("gci_ctx_create", c_int, [c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    ("gci_ctx_destroy", c_int, [c_void_p]),
+    ("gci_sync", c_int, [c_void_p]),
+    ("gci_strerror", c_char_p, [c_int]),
+    ("gci_last_error", c_char_p, [c_void_p]),
+    ("gci_malloc", c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    ("gci_free", c_int, [c_void_p, c_void_p]),
+    ("gci_memcpy_h2d", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("gci_memcpy_d2h", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    ("gci_memset", c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    ("gci_profile_enable", c_int, [c_void_p, c_int]),
+    ("gci_profile_read", c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_uint64), c_int]),
+    ("gci_profile_name", c_char_p, [c_int]),
+    ("gci_layout_set", c_int, [c_void_p, c_int32, c_void_p]),
+    ("gci_layout_total", c_int64, [c_void_p]),
+    ("gci_layout_offsets", c_int, [c_void_p, c_void_p]),
+    ("gci_bam_filter", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_int32, c_int, c_int,
+                               c_double, c_double, c_uint32, c_void_p, c_void_p]),
+    ("gci_decode_status", c_int, [c_uint64, POINTER(c_uint32)]),
+    ("gci_name_hash", c_uint64, [c_void_p, c_uint32]),
+    ("gci_pack_names", c_int, [c_void_p, POINTER(JoinFile), c_void_p, c_uint64, c_void_p]),
+    ("gci_name_join", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
+                              c_void_p]),
+    ("gci_depth_build", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_int, c_void_p]),
+    ("gci_gap_mask", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
+    ("gci_max2", c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("gci_issue_scan", c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_uint32, c_void_p]),
+    ("gci_issue_scan_windows", c_int, [c_void_p, c_void_p, POINTER(Window), c_uint32, c_double, c_double, c_void_p,
+                                       c_uint32, c_void_p]),
+    ("gci_depth_text_size", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("gci_depth_text_write", c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
+    ("gci_depth_sum", c_int, [c_void_p, c_void_p, c_void_p]),
+]
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library and bind every export; raises if the .so or a symbol is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GciError(GCI_E_INVALID, "libgci_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, res, args in EXPORTS:
+            fn = getattr(lib, name)           # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if lib.gci_abi_version() != 1:
+            raise GciError(GCI_E_INVALID, "libgci_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def name_hash(name: bytes) -> int:
+    return int(load().gci_name_hash(name, len(name)))

@@ -1,0 +1,39 @@
+"""Build libgci_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(CSRC, "libgci_hip.so")
+SOURCES = [os.path.join(CSRC, "gci_hip.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, "gci_common.h"), os.path.join(_HERE, "..", "include", "gci_hip.h")]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fno-fast-math", "-ffp-contract=off", "-Wall", "-o", LIB] + SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

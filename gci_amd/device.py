@@ -1,0 +1,297 @@
+"""Device side of the path: one `Engine` per GPU wrapping a gci_ctx (include/gci_hip.h).
+
+torch is plumbing only: it owns the HBM buffers and the stream; every per-record and per-base
+operation is a hand-written gfx950 kernel reached through the C ABI.  Nothing here computes on
+the CPU; a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GciError, JoinFile, Window
+
+REC_DTYPE = np.dtype([("name_hash", "<u8"), ("contig", "<i4"), ("start", "<i4"), ("end", "<i4"), ("qlen", "<i4"),
+                      ("rec_idx", "<u4"), ("mapq", "u1"), ("flags", "u1"), ("name_len", "<u2")])
+assert REC_DTYPE.itemsize == 32
+IVL_DTYPE = np.dtype([("contig", "<i4"), ("start", "<i4"), ("end", "<i4"), ("pad", "<i4")])
+
+_M64 = (1 << 64) - 1
+
+
+def name_hash_np(names: Sequence[bytes]) -> np.ndarray:
+    """Vectorised twin of gci_name_hash (gci_amd/csrc/gci_common.h) for host-built records."""
+    n = len(names)
+    lens = np.fromiter((len(x) for x in names), dtype=np.int64, count=n)
+    width = int(((lens.max() if n else 0) + 7) // 8 * 8) or 8
+    buf = np.zeros((n, width), dtype=np.uint8)
+    for i, x in enumerate(names):
+        buf[i, :len(x)] = np.frombuffer(x, dtype=np.uint8)
+    words = buf.view("<u8")
+
+    def mix(x):
+        x = x ^ (x >> np.uint64(30))
+        x = x * np.uint64(0xbf58476d1ce4e5b9)
+        x = x ^ (x >> np.uint64(27))
+        x = x * np.uint64(0x94d049bb133111eb)
+        return x ^ (x >> np.uint64(31))
+
+    acc = np.zeros(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for k in range(width // 8):
+            use = (k * 8) < lens
+            key = np.uint64((0x9E3779B97F4A7C15 * (k + 1)) & _M64)
+            acc = acc + np.where(use, mix(words[:, k] ^ key), np.uint64(0))
+        return mix(acc ^ (lens.astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)))
+
+
+@dataclass
+class JoinInput:
+    """One file of the join: compact records on the device + where its name bytes are."""
+    recs: torch.Tensor            # uint8 [n, 32]
+    name_base: torch.Tensor       # uint8 blob (BAM: the inflated stream)
+    name_off: torch.Tensor        # int64 [*], indexed by rec_idx
+    name_delta: int               # 36 for BAM records, 0 for a names blob
+
+
+class Engine:
+    """A gci_ctx bound to torch's current stream on `device`."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise GciError(_lib.GCI_E_HIP, "no MI355X visible: the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = ctypes.c_void_p()
+        st = self.lib.gci_ctx_create(device, ctypes.c_void_p(self.stream.cuda_stream), 0, ctypes.byref(h))
+        if st != 0:
+            raise GciError(st, "gci_ctx_create: %s" % self.lib.gci_strerror(st).decode())
+        self.ctx = h
+        self.lengths: List[int] = []
+        self.offsets: List[int] = []
+        self.total = 0
+        self._status = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.gci_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def _chk(self, st: int, what: str) -> None:
+        if st != 0:
+            detail = self.lib.gci_last_error(self.ctx).decode() if st == _lib.GCI_E_HIP else ""
+            raise GciError(st, "%s: %s %s" % (what, self.lib.gci_strerror(st).decode(), detail))
+
+    def sync(self) -> None:
+        self._chk(self.lib.gci_sync(self.ctx), "gci_sync")
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def to_device(self, a: np.ndarray) -> torch.Tensor:
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        elif a.dtype == np.uint32:
+            a = a.view(np.int32)
+        return torch.from_numpy(a).to(self.device)
+
+    # ---- per-kernel HIP-event timing (library side, on the ctx stream) -------------------------
+    def profile_enable(self, mask: int) -> None:
+        self._chk(self.lib.gci_profile_enable(self.ctx, int(mask)), "gci_profile_enable")
+
+    def profile_read(self, reset: bool = True) -> Dict[str, Tuple[float, int]]:
+        """-> {kernel name: (total ms, launches)} accumulated since the last reset."""
+        out = {}
+        for k in range(_lib.PROF_COUNT):
+            ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
+            self._chk(self.lib.gci_profile_read(self.ctx, k, ctypes.byref(ms), ctypes.byref(n), int(reset)),
+                      "gci_profile_read")
+            if n.value:
+                out[self.lib.gci_profile_name(k).decode()] = (ms.value, int(n.value))
+        return out
+
+    # ---- layout ------------------------------------------------------------------------------
+    def set_layout(self, lengths: Sequence[int]) -> List[int]:
+        arr = np.asarray(lengths, dtype=np.int64)
+        self._chk(self.lib.gci_layout_set(self.ctx, arr.shape[0], arr.ctypes.data_as(ctypes.c_void_p)), "gci_layout_set")
+        self.lengths = [int(x) for x in arr]
+        offs = np.zeros(arr.shape[0], dtype=np.int64)
+        self._chk(self.lib.gci_layout_offsets(self.ctx, offs.ctypes.data_as(ctypes.c_void_p)), "gci_layout_offsets")
+        self.offsets = [int(x) for x in offs]
+        self.total = int(self.lib.gci_layout_total(self.ctx))
+        return self.offsets
+
+    def new_track(self) -> torch.Tensor:
+        return torch.empty(max(self.total, 1), dtype=torch.int32, device=self.device)
+
+    # ---- R1 ----------------------------------------------------------------------------------
+    def bam_filter(self, d_bam: torch.Tensor, d_rec_off: torch.Tensor, d_ref_sel: torch.Tensor, map_qual: int,
+                   mq_cutoff: int, clip_percent: float, iden_percent: float, out: Optional[torch.Tensor] = None,
+                   check: bool = True, rec_idx_base: int = 0) -> torch.Tensor:
+        n = int(d_rec_off.shape[0])
+        if out is None:
+            out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+        st = self.lib.gci_bam_filter(self.ctx, self._p(d_bam), int(d_bam.shape[0]), self._p(d_rec_off), n,
+                                     self._p(d_ref_sel), int(d_ref_sel.shape[0]), int(map_qual), int(mq_cutoff),
+                                     float(clip_percent), float(iden_percent), int(rec_idx_base), self._p(out),
+                                     self._p(self._status))
+        self._chk(st, "gci_bam_filter")
+        if check:
+            self.check_status("gci_bam_filter")
+        return out[:n]
+
+    def check_status(self, what: str) -> None:
+        w = int(self._status.item()) & _M64
+        rec = ctypes.c_uint32(0)
+        st = self.lib.gci_decode_status(w, ctypes.byref(rec))
+        if st != 0:
+            raise GciError(st, "%s: %s (record %d)" % (what, self.lib.gci_strerror(st).decode(), rec.value),
+                           rec=int(rec.value))
+
+    # ---- R5 ----------------------------------------------------------------------------------
+    def _join_files(self, files: Sequence[JoinInput]):
+        arr = (JoinFile * len(files))()
+        for i, f in enumerate(files):
+            arr[i].d_recs = f.recs.data_ptr()
+            arr[i].n_recs = int(f.recs.shape[0])
+            arr[i].name_delta = int(f.name_delta)
+            arr[i].d_name_base = f.name_base.data_ptr()
+            arr[i].d_name_off = f.name_off.data_ptr()
+        return arr
+
+    def name_join(self, files: Sequence[JoinInput], ovlp_percent: float, contig_map: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None, check: bool = True
+                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (intervals int32 [cap, 4], device count).  With check=True the count is read back,
+        capacity is grown if needed and the record-level status is raised."""
+        total = sum(int(f.recs.shape[0]) for f in files)
+        if out is None:
+            out = torch.empty((max(total, 1), 4), dtype=torch.int32, device=self.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        arr = self._join_files(files)
+        while True:
+            st = self.lib.gci_name_join(self.ctx, arr, len(files), float(ovlp_percent), self._p(contig_map),
+                                        self._p(out), int(out.shape[0]), self._p(count), self._p(self._status))
+            self._chk(st, "gci_name_join")
+            if not check:
+                return out, count
+            self.check_status("gci_name_join")
+            n = int(count.item())
+            if n <= out.shape[0]:
+                return out, count
+            out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+
+    def pack_names(self, f: JoinInput) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = int(f.recs.shape[0])
+        off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        arr = self._join_files([f])
+        self._chk(self.lib.gci_pack_names(self.ctx, arr, None, 0, self._p(off)), "gci_pack_names(size)")
+        total = int(off[n].item())
+        blob = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.gci_pack_names(self.ctx, arr, self._p(blob), total, self._p(off)), "gci_pack_names")
+        return blob[:total], off
+
+    # ---- R6 / R8 / R9 / R15 --------------------------------------------------------------------
+    def depth_build(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
+                    max_n: Optional[int] = None) -> torch.Tensor:
+        n = int(ivl.shape[0]) if max_n is None else int(max_n)
+        st = self.lib.gci_depth_build(self.ctx, self._p(ivl) if n else None, self._p(count), n, int(flank),
+                                      self._p(track))
+        self._chk(st, "gci_depth_build")
+        return track
+
+    def gap_mask(self, track: torch.Tensor, gaps: torch.Tensor) -> torch.Tensor:
+        n = int(gaps.shape[0])
+        if n:
+            self._chk(self.lib.gci_gap_mask(self.ctx, self._p(track), self._p(gaps), n), "gci_gap_mask")
+        return track
+
+    def max2(self, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = self.new_track()
+        self._chk(self.lib.gci_max2(self.ctx, self._p(a), self._p(b), self._p(out)), "gci_max2")
+        return out
+
+    def depth_sum(self, track: torch.Tensor) -> np.ndarray:
+        sums = torch.zeros(max(len(self.lengths), 1), dtype=torch.int64, device=self.device)
+        self._chk(self.lib.gci_depth_sum(self.ctx, self._p(track), self._p(sums)), "gci_depth_sum")
+        return sums.cpu().numpy()[:len(self.lengths)]
+
+    # ---- R10 ---------------------------------------------------------------------------------
+    @staticmethod
+    def _keys_to_runs(keys: np.ndarray, n_windows: int) -> List[np.ndarray]:
+        """Sorted boundary keys -> per window int64 [k, 2] of (rel start, rel end)."""
+        keys = np.sort(keys.astype(np.uint64))
+        win = (keys >> np.uint64(33)).astype(np.int64)
+        rel = ((keys >> np.uint64(1)) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        is_end = (keys & np.uint64(1)).astype(bool)
+        out = []
+        bounds = np.searchsorted(win, np.arange(n_windows + 1))
+        for w in range(n_windows):
+            a, b = bounds[w], bounds[w + 1]
+            r, e = rel[a:b], is_end[a:b]
+            if ((b - a) & 1) or e[0::2].any() or not e[1::2].all():
+                raise GciError(_lib.GCI_E_INVALID, "issue scan produced unpaired run boundaries")
+            out.append(np.stack([r[0::2], r[1::2]], axis=1) if b > a else np.zeros((0, 2), dtype=np.int64))
+        return out
+
+    def _scan(self, call, n_windows: int) -> List[np.ndarray]:
+        cap = 1 << 16
+        while True:
+            keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            call(keys, cap)
+            n = int(self._count.item())
+            if n <= cap:
+                return self._keys_to_runs(keys[:n].cpu().numpy().view(np.uint64), n_windows)
+            cap = n
+
+    def issue_scan(self, track: torch.Tensor, lo: float, hi: float, flank: int) -> List[np.ndarray]:
+        """Raw maximal runs of lo < depth <= hi inside [flank, L - flank) of every contig, as
+        positions relative to the window start (add `flank` for contig coordinates)."""
+        def call(keys, cap):
+            self._chk(self.lib.gci_issue_scan(self.ctx, self._p(track), float(lo), float(hi), int(flank),
+                                              self._p(keys), cap, self._p(self._count)), "gci_issue_scan")
+        return self._scan(call, len(self.lengths))
+
+    def issue_scan_windows(self, track: torch.Tensor, windows: Sequence[Tuple[int, int]], lo: float, hi: float
+                           ) -> List[np.ndarray]:
+        arr = (Window * max(len(windows), 1))()
+        for i, (a, b) in enumerate(windows):
+            arr[i].begin, arr[i].end = int(a), int(b)
+
+        def call(keys, cap):
+            self._chk(self.lib.gci_issue_scan_windows(self.ctx, self._p(track), arr, len(windows), float(lo), float(hi),
+                                                      self._p(keys), cap, self._p(self._count)),
+                      "gci_issue_scan_windows")
+        return self._scan(call, len(windows))
+
+    # ---- R7 ----------------------------------------------------------------------------------
+    def depth_text(self, track: torch.Tensor, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, np.ndarray]:
+        """-> (uint8 text of all contigs back to back, int64 [n_contigs + 1] byte offsets)."""
+        n = len(self.lengths)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        self._chk(self.lib.gci_depth_text_size(self.ctx, self._p(track), self._p(offs)), "gci_depth_text_size")
+        h = offs.cpu().numpy()
+        total = int(h[n])
+        if out is None or out.shape[0] < total:
+            out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.gci_depth_text_write(self.ctx, self._p(track), self._p(out), total), "gci_depth_text_write")
+        return out[:total], h

@@ -1,0 +1,417 @@
+"""Host-side mirror of the reference's hot-path functions, driving the HIP kernels.
+
+Same names, argument meaning, outputs and error behaviour as /root/reference/GCI.py so that a
+maintainer (and the parity tests) can read one against the other:
+
+    get_Ns_ref            GCI.py:18-46      filter                  GCI.py:172-312
+    merge_gaps_depths     GCI.py:315-329    merge_two_type_depth    GCI.py:332-353
+    collapse_depth_range  GCI.py:356-390    merge_depth             GCI.py:393-419
+    compute_index         GCI.py:522-657    GCI                     GCI.py:897-1028
+
+What differs is where the work happens: `depths` is a `DepthTracks` object whose per-base
+data lives in HBM as one int32 buffer for all contigs; records are decoded and filtered, names
+joined, depth built, masked, merged, scanned and rendered to text by gfx950 kernels
+(gci_amd/csrc/gci_hip.hip).  The host parses containers (BGZF, PAF, FASTA), does the tiny
+interval algebra (gci_amd/score.py) and writes files.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+
+from . import score
+from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
+from ._lib import GciError, REC_HQ, REC_PASS
+from .formats import bam as bamfmt
+from .formats import depthfile, fasta
+
+_ENGINE: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = Engine(int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.device_count() > 1 else 0)
+    return _ENGINE
+
+
+def _slice_bound(v: int, L: int) -> int:
+    if v < 0:
+        return max(v + L, 0)
+    return min(v, L)
+
+
+class DepthTracks:
+    """The reference's `depths` dict (contig -> per-base array), resident in HBM."""
+
+    def __init__(self, engine: Engine, targets_length: Dict[str, int], track: torch.Tensor):
+        self.engine = engine
+        self.targets_length = dict(targets_length)
+        self.targets = list(targets_length.keys())
+        self.lengths = [int(targets_length[t]) for t in self.targets]
+        self.track = track
+
+    def _bind(self) -> None:
+        if self.engine.lengths != self.lengths:
+            self.engine.set_layout(self.lengths)
+
+    def keys(self):
+        return self.targets_length.keys()
+
+    def __contains__(self, t) -> bool:
+        return t in self.targets_length
+
+    def __len__(self) -> int:
+        return len(self.targets)
+
+    def __getitem__(self, target: str) -> np.ndarray:
+        """Host copy of one contig (int64, as the reference's arrays are)."""
+        self._bind()
+        c = self.targets.index(target)
+        o = self.engine.offsets[c]
+        return self.track[o:o + self.lengths[c]].cpu().numpy().astype(np.int64)
+
+    def to_host(self) -> Dict[str, np.ndarray]:
+        return {t: self[t] for t in self.targets}
+
+    def sums(self) -> np.ndarray:
+        self._bind()
+        return self.engine.depth_sum(self.track)
+
+    def mean(self) -> float:
+        """np.mean over the concatenation of all contigs (GCI.py:862-868): integers, so exact."""
+        return float(int(self.sums().sum())) / float(sum(self.lengths))
+
+
+# ==============================================================================================
+# gaps
+# ==============================================================================================
+
+def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
+    _, ns_bed = fasta.n_runs(reference)
+    if len(ns_bed) > 0:
+        path = f"{directory}/{prefix}.gaps.bed"
+        if os.path.exists(path) and force == False:  # noqa: E712
+            sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+        with open(path, "w") as f:
+            for target, segments in ns_bed.items():
+                for a, b in segments:
+                    f.write(f"{target}\t{a}\t{b}\n")
+        return ns_bed, path
+    return None, None
+
+
+def merge_gaps_depths(depths: DepthTracks = None, Ns_bed=None) -> DepthTracks:
+    if Ns_bed is not None:
+        rows = [(depths.targets.index(t), a, b, 0) for t, segs in Ns_bed.items() if t in depths for a, b in segs]
+        if rows:
+            depths._bind()
+            gaps = depths.engine.to_device(np.asarray(rows, dtype=np.int32).reshape(-1, 4))
+            depths.engine.gap_mask(depths.track, gaps)
+    return depths
+
+
+# ==============================================================================================
+# PAF path (host; SURVEY.md R3 -- GPU tokeniser is a "next" row)
+# ==============================================================================================
+
+def _merge_span(pairs: List[Tuple[int, int]]) -> Tuple[int, int, int]:
+    """Union of closed-touching blocks: (covered length, start, end of the longest merged block,
+    the leftmost one on ties)."""
+    pairs = sorted(pairs)
+    covered = 0
+    best = (-1, 0, 0)
+    lo, hi = pairs[0]
+    for a, b in pairs[1:] + [(None, None)]:
+        if a is not None and hi >= a:
+            hi = max(hi, b)
+            continue
+        covered += hi - lo
+        if hi - lo > best[0]:
+            best = (hi - lo, lo, hi)
+        if a is not None:
+            lo, hi = a, b
+    return covered, best[1], best[2]
+
+
+def paf_filter(paf_files: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int, iden_percent: float
+               ) -> Tuple[List[Dict[str, Tuple[str, int, int, int]]], Set[str]]:
+    """GCI.py:211-254.  Block lists accumulate ACROSS files (the reference creates `synteny` once,
+    before the per-file loop), so file i re-emits every query seen in files < i."""
+    tset = set(targets)
+    high_qual: Set[str] = set()
+    blocks: Dict[str, Dict[str, list]] = {}
+    per_file: List[Dict[str, Tuple[str, int, int, int]]] = []
+    for path in paf_files:
+        with open(path, "r") as f:
+            for line in f:
+                col = line.strip().split("\t")
+                if col[5] not in tset:
+                    continue
+                qlen, qs, qe, ts, te = int(col[1]), int(col[2]), int(col[3]), int(col[7]), int(col[8])
+                nmatch, alnlen, mapq = int(col[9]), int(col[10]), int(col[11])
+                identity = nmatch / alnlen
+                if mapq >= map_qual and identity >= iden_percent:
+                    blocks.setdefault(col[0], {}).setdefault(col[5], []).append((qlen, qs, qe, ts, te, identity))
+                    if mapq >= mq_cutoff:
+                        high_qual.add(col[0])
+        emitted: Dict[str, Tuple[str, int, int, int]] = {}
+        for query, by_target in blocks.items():
+            best_key, best_val = None, None
+            for target, alns in by_target.items():
+                covered, _, _ = _merge_span([(a[1], a[2]) for a in alns])
+                qlen = alns[0][0]
+                total = 0
+                for a in alns:                       # file-order f64 accumulation, as sum() does
+                    total = total + a[5]
+                rank = (total / len(alns) * (covered / qlen), target)
+                if best_key is None or rank > best_key:
+                    _, s, e = _merge_span([(a[3], a[4]) for a in alns])
+                    best_key, best_val = rank, (target, s, e, qlen)
+            emitted[query] = best_val
+        per_file.append(emitted)
+    return per_file, high_qual
+
+
+# ==============================================================================================
+# filter
+# ==============================================================================================
+
+def _paf_join_input(engine: Engine, d: Dict[str, Tuple[str, int, int, int]], high_qual: Set[str],
+                    tindex: Dict[str, int]) -> JoinInput:
+    names = [q.encode() for q in d.keys()]
+    n = len(names)
+    recs = np.zeros(n, dtype=REC_DTYPE)
+    if n:
+        recs["name_hash"] = name_hash_np(names)
+        vals = list(d.values())
+        recs["contig"] = [tindex[v[0]] for v in vals]
+        for fld, k in (("start", 1), ("end", 2), ("qlen", 3)):
+            col = np.asarray([v[k] for v in vals], dtype=np.int64)
+            if (col > 0x7FFFFFFF).any() or (col < -0x80000000).any():
+                raise GciError(-1, "PAF coordinate does not fit int32")
+            recs[fld] = col
+        recs["rec_idx"] = np.arange(n)
+        recs["flags"] = [REC_PASS | (REC_HQ if q in high_qual else 0) for q in d.keys()]
+        recs["name_len"] = [len(x) for x in names]
+    lens = np.fromiter((len(x) for x in names), dtype=np.int64, count=n)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    blob = np.frombuffer(b"".join(names) or b"\x00", dtype=np.uint8)
+    return JoinInput(engine.to_device(recs.view(np.uint8).reshape(n, 32) if n else np.zeros((0, 32), np.uint8)),
+                     engine.to_device(blob), engine.to_device(off), 0)
+
+
+def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
+    """Inflate (host threads), find record boundaries (the one serial step), upload."""
+    stream, hdr, offs = bamfmt.read_bam(path, threads=threads)
+    return engine.to_device(stream), engine.to_device(offs), hdr
+
+
+def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, iden_percent=0.9,  # noqa: A001
+           clip_percent=0.1, ovlp_percent=0.9, flank_len=15, directory=".", force=False, log_reads_type="",
+           chrs_list=[], threads=1, engine: Optional[Engine] = None, write=True):
+    """Filter the PAF and BAM file(s), build the per-base depth in HBM and write
+    `{prefix}.depth.gz`.  Returns (depths, targets_length) like the reference."""
+    engine = engine or default_engine()
+    if write and os.path.exists(f"{directory}/{prefix}.depth.gz") and force == False:  # noqa: E712
+        sys.exit(f'ERROR!!! The file "{directory}/{prefix}.depth.gz" exists\nPlease use "-f" or "--force" to rewrite')
+    print(f"Filtering {log_reads_type} alignment files ...")
+
+    first = bamfmt.read_header(bam_files[0])
+    pairs = [(r, l) for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)]
+    targets_length = {r: l for r, l in pairs}
+    targets = list(targets_length.keys())
+    tindex = {t: i for i, t in enumerate(targets)}
+    engine.set_layout([targets_length[t] for t in targets])
+
+    inputs: List[JoinInput] = []
+    high_qual: Set[str] = set()
+    if len(paf_files) != 0:
+        paf_dicts, high_qual = paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
+        inputs += [_paf_join_input(engine, d, high_qual, tindex) for d in paf_dicts]
+    keep_alive = []
+    for path in bam_files:
+        d_bam, d_off, hdr = load_bam_to_device(engine, path, threads)
+        for t in targets:
+            if t not in hdr.references:
+                raise ValueError(f"invalid contig `{t}`")          # what pysam's fetch() raises
+        ref_sel = engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
+        try:
+            recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
+        except GciError as e:
+            _reraise_like_reference(e)
+        inputs.append(JoinInput(recs, d_bam, d_off, 36))
+        keep_alive.append((d_bam, d_off))
+    try:
+        ivl, count = engine.name_join(inputs, ovlp_percent)
+    except GciError as e:
+        _reraise_like_reference(e)
+    track = engine.new_track()
+    engine.depth_build(ivl, count, flank_len, track)
+    depths = DepthTracks(engine, targets_length, track)
+
+    print(f"Filtering {log_reads_type} alignment files done!!!")
+    if write:
+        print(f'Writing depths into "{directory}/{prefix}.depth.gz" ...')
+        write_depth(directory, prefix, depths, threads)
+        print("Writing depths done!!!\n\n")
+    return depths, targets_length
+
+
+def _reraise_like_reference(e: GciError):
+    from . import _lib
+    if e.status == _lib.GCI_E_NO_NM:
+        raise KeyError("tag 'NM' not present") from e
+    if e.status == _lib.GCI_E_ZERO_DIV:
+        raise ZeroDivisionError("division by zero") from e
+    raise e
+
+
+def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads=1) -> None:
+    """`{directory}/{prefix}.depth.gz`: '>contig' line then one decimal per line (GCI.py:99-143).
+    Text is rendered on the GPU; the host only frames it as gzip members."""
+    depths._bind()
+    text, offs = depths.engine.depth_text(depths.track)
+    host = text.cpu().numpy()
+    mv = memoryview(host)
+    pieces = ((t, mv[int(offs[c]):int(offs[c + 1])]) for c, t in enumerate(depths.targets))
+    path = f"{directory}/{prefix}.depth.gz"
+    if os.path.exists(path):
+        os.remove(path)
+    depthfile.write_depth_gz(path, pieces, level=1, threads=max(1, threads))
+
+
+def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTracks = None, prefix="GCI_two_type",
+                         directory=".", force=False, threads=1, write=True) -> DepthTracks:
+    print("Merging HiFi and ONT depth file ...")
+    if write and os.path.exists(f"{directory}/{prefix}.depth.gz") and force == False:  # noqa: E712
+        sys.exit(f'ERROR!!! The file "{directory}/{prefix}.depth.gz" exists\nPlease use "-f" or "--force" to rewrite')
+    hifi_depths._bind()
+    if nano_depths.targets != hifi_depths.targets or nano_depths.lengths != hifi_depths.lengths:
+        # the reference indexes nano by the HiFi dict's keys; GCI() has already checked both headers agree
+        raise KeyError("HiFi and ONT depth tracks cover different contigs")
+    merged = DepthTracks(hifi_depths.engine, hifi_depths.targets_length,
+                         hifi_depths.engine.max2(hifi_depths.track, nano_depths.track))
+    if write:
+        write_depth(directory, prefix, merged, threads)
+    print("Merging HiFi and ONT depth file done!!!\n\n")
+    return merged
+
+
+# ==============================================================================================
+# issue scan
+# ==============================================================================================
+
+def _issues_from_runs(runs: np.ndarray, n_slice: int, chr_len: int, flank_len: int, start_pos: int
+                      ) -> List[Tuple[int, int]]:
+    """Apply the reference's closing rules (GCI.py:380-388) to raw maximal runs given relative to
+    the scanned slice: a run that ends at an out-of-range base at relative index i is reported
+    only if i > flank_len; a run reaching the last scanned base is reported iff that base has
+    relative index chr_len - 2 * flank_len - 1."""
+    out: List[Tuple[int, int]] = []
+    for rs, re_ in runs.tolist():
+        if re_ == n_slice:
+            if n_slice - 1 != chr_len - 2 * flank_len - 1:
+                continue
+        elif not (re_ > flank_len):
+            continue
+        out.append((rs + flank_len + start_pos, re_ + flank_len + start_pos))
+    return out
+
+
+def collapse_depth_range(depths: DepthTracks = None, leftmost=-1, rightmost=0, flank_len=15, start_pos=0
+                         ) -> Dict[str, List[Tuple[int, int]]]:
+    depths._bind()
+    runs = depths.engine.issue_scan(depths.track, leftmost, rightmost, flank_len)
+    out = {}
+    for c, t in enumerate(depths.targets):
+        L = depths.lengths[c]
+        a, b = _slice_bound(flank_len, L), _slice_bound(L - flank_len, L)
+        out[t] = _issues_from_runs(runs[c], max(0, b - a), L, flank_len, start_pos)
+    return out
+
+
+def collapse_region(depths: DepthTracks, target: str, start: int, end: int, leftmost, rightmost
+                    ) -> List[Tuple[int, int]]:
+    """collapse_depth_range({target: depths[target][start:end]}, leftmost, rightmost, 0, start)."""
+    return collapse_regions(depths, [(target, start, end)], leftmost, rightmost)[0]
+
+
+def collapse_regions(depths: DepthTracks, regions: Sequence[Tuple[str, int, int]], leftmost, rightmost
+                     ) -> List[List[Tuple[int, int]]]:
+    depths._bind()
+    wins, meta = [], []
+    for target, start, end in regions:
+        c = depths.targets.index(target)
+        L = depths.lengths[c]
+        a, b = _slice_bound(start, L), _slice_bound(end, L)
+        b = max(a, b)
+        o = depths.engine.offsets[c]
+        wins.append((o + a, o + b))
+        meta.append((b - a, start))
+    runs = depths.engine.issue_scan_windows(depths.track, wins, leftmost, rightmost)
+    return [_issues_from_runs(r, n, n, 0, sp) for r, (n, sp) in zip(runs, meta)]
+
+
+def merge_depth(depths: DepthTracks = None, prefix="GCI", threshold=0, flank_len=15, directory=".", force=False,
+                log_reads_type=""):
+    print(f"Getting {log_reads_type} issues bed file detected by GCI ...")
+    path = f"{directory}/{prefix}.{threshold}.depth.bed"
+    if os.path.exists(path) and force == False:  # noqa: E712
+        sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+    merged = collapse_depth_range(depths, -1, threshold, flank_len, 0)
+    with open(path, "w") as f:
+        for target, segments in merged.items():
+            for s, e in segments:
+                f.write(f"{target}\t{s}\t{e}\n")
+    print(f"Getting {log_reads_type} issues bed file done!!!\n\n")
+    return merged
+
+
+# ==============================================================================================
+# score files
+# ==============================================================================================
+
+complement_merged_depth = score.complement_merged_depth
+compute_n50 = score.compute_n50
+merge_merged_depth_bed = score.merge_merged_depth_bed
+
+
+def compute_index(targets_length={}, prefix="GCI", directory=".", force=False, merged_depths_bed_list=[],
+                  type_list=[], flank_len=15, dist_percent=0.005, regions_bed={}, depths_list=[], threshold=0,
+                  chrs_list=[]):
+    gci_path = f"{directory}/{prefix}.gci"
+    if os.path.exists(gci_path) and force == False:  # noqa: E712
+        sys.exit(f'ERROR!!! The file "{gci_path}" exists\nPlease use "-f" or "--force" to rewrite')
+    with open(gci_path, "w"):
+        pass
+    reg_path = f"{directory}/{prefix}.regions.gci"
+    if len(regions_bed) > 0:
+        if os.path.exists(reg_path) and force == False:  # noqa: E712
+            sys.exit(f'ERROR!!! The file "{reg_path}" exists\nPlease use "-f" or "--force" to rewrite')
+    print("Computing Theoretical minimum N50 and contigs number ...")
+    print("Computing Theoretical minimum N50 and contigs number done!!!")
+    for t in type_list:
+        print(f"Computing Curated N50 and contigs number for {t} ...")
+        print(f"Computing Curated N50 and contigs number for {t} done!!!")
+        print(f"Writing results to {gci_path} ...")
+        print(f"Writing results to {gci_path} done!!!\n\n")
+    with open(gci_path, "w") as f:
+        f.write(score.index_text(targets_length, merged_depths_bed_list, type_list, flank_len, dist_percent, chrs_list))
+    if len(regions_bed) > 0:
+        print("Computing GCI scores for regions ...")
+        flat = [(t, s, e) for t, segs in regions_bed.items() for s, e in segs]
+        per_track = [collapse_regions(d, flat, -1, threshold) for d in depths_list]
+        lookup = {(i, r): per_track[i][k] for i in range(len(depths_list)) for k, r in enumerate(flat)}
+        text = score.regions_text(regions_bed, type_list, len(depths_list),
+                                  lambda i, t, s, e: lookup[(i, (t, s, e))], dist_percent,
+                                  warn=lambda m: print(m, file=sys.stderr))
+        with open(reg_path, "w") as f:
+            f.write(text)
+        print("Computing GCI scores for regions done!!!\n\n")

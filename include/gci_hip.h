@@ -1,0 +1,202 @@
+/*
+ * gci_hip.h -- C ABI of libgci_hip.so: the MI355X (gfx950) implementation of GCI's
+ * alignment-filter -> per-base-depth -> issue-scan hot path.
+ *
+ * The reference (yeeus/GCI, a single pure-Python file) has no FFI; the seams below are the
+ * function seams of its hot path, one export per seam so each is parity-testable against
+ * the matching reference function (citations are into /root/reference/GCI.py):
+ *
+ *   gci_bam_filter      read_sam                      GCI.py:146-169  (+ fan-out 257-270)
+ *   gci_name_join       filter(), cross-file join     GCI.py:272-301  (+ dict "last wins" 166, 269)
+ *   gci_depth_build     filter(), slice += 1          GCI.py:201-208, 302-306
+ *   gci_gap_mask        merge_gaps_depths             GCI.py:315-329
+ *   gci_max2            merge_two_type_depth          GCI.py:350
+ *   gci_issue_scan*     collapse_depth_range          GCI.py:356-390
+ *   gci_depth_text_*    write_depth (text body)       GCI.py:110-117
+ *   gci_depth_sum       np.mean numerator             GCI.py:862-868
+ *
+ * Conventions
+ *   - every export returns int: GCI_OK (0) or a negative gci_status; nothing throws, exits,
+ *     prints or touches files;
+ *   - the caller owns every buffer (torch / hipMalloc / gci_malloc); the library owns only
+ *     the scratch inside its gci_ctx;
+ *   - pointers named d_* are DEVICE pointers, h_* are HOST pointers;
+ *   - all work is enqueued on the ctx stream and is asynchronous unless stated; gci_sync()
+ *     waits for it.  A ctx is not thread-safe; distinct ctxs are independent;
+ *   - plain C structs with fixed layout, little endian.
+ *
+ * Track layout ("depth track"): one int32 per base, all selected contigs in ONE buffer.
+ * Contig c starts at element gci_layout_offsets()[c], a multiple of GCI_TILE (4096 elements,
+ * 16 KiB), so tiles never straddle contigs and every vector access is 16-byte aligned.
+ * Elements between the end of a contig and the next multiple of GCI_TILE are padding (always 0).
+ */
+#ifndef GCI_HIP_H
+#define GCI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCI_ABI_VERSION 1
+#define GCI_TILE 4096          /* elements per tile of a depth track */
+#define GCI_MAX_JOIN_FILES 16
+
+typedef enum gci_status {
+    GCI_OK = 0,
+    GCI_E_INVALID = -1,        /* bad argument */
+    GCI_E_HIP = -2,            /* a HIP runtime call failed: see gci_last_error() */
+    GCI_E_NO_NM = -3,          /* a record that reaches GCI.py:163 has no NM tag (reference: KeyError) */
+    GCI_E_ZERO_DIV = -4,       /* zero denominator at GCI.py:165 / 292 (reference: ZeroDivisionError) */
+    GCI_E_BAD_NM_TYPE = -5,    /* NM tag present but not an integer type */
+    GCI_E_NO_END = -6,         /* reference_end would be None (n_cigar_op == 0) */
+    GCI_E_MALFORMED = -7,      /* record runs past the end of the stream */
+    GCI_E_CAPACITY = -8,       /* output buffer too small: grow and call again */
+    GCI_E_NOMEM = -9,
+    GCI_E_NO_LAYOUT = -10      /* gci_layout_set() has not been called */
+} gci_status;
+
+/* Compact alignment record: what read_sam keeps per record (GCI.py:166-168), 32 bytes. */
+typedef struct gci_rec {
+    uint64_t name_hash;        /* gci_name_hash() of the query name */
+    int32_t contig;            /* index among the SELECTED contigs (not the BAM refID), -1 if none */
+    int32_t start;             /* reference_start */
+    int32_t end;               /* reference_end */
+    int32_t qlen;              /* query_length */
+    uint32_t rec_idx;          /* index of the record in its file (order = file order) */
+    uint8_t mapq;
+    uint8_t flags;             /* GCI_REC_PASS | GCI_REC_HQ */
+    uint16_t name_len;         /* bytes, without NUL */
+} gci_rec;
+#define GCI_REC_PASS 1u        /* record reaches GCI.py:166 */
+#define GCI_REC_HQ 2u          /* ... and mapq >= mq_cutoff (GCI.py:167) */
+
+/* Interval on a selected contig, 16 bytes. */
+typedef struct gci_ivl {
+    int32_t contig;
+    int32_t start;
+    int32_t end;
+    int32_t pad;
+} gci_ivl;
+
+/* One input of the join: compact records + where the query-name bytes of record i live:
+ * d_name_base + d_name_off[recs[i].rec_idx] + name_delta  (BAM: base = the inflated stream,
+ * off = record offsets, delta = 36;  PAF: base = a names blob, off = blob offsets, delta = 0). */
+typedef struct gci_join_file {
+    const gci_rec* d_recs;
+    uint32_t n_recs;
+    uint32_t name_delta;
+    const uint8_t* d_name_base;
+    const uint64_t* d_name_off;
+} gci_join_file;
+
+/* Scan window over a track, in flat element coordinates of the track buffer. */
+typedef struct gci_window {
+    int64_t begin;
+    int64_t end;
+} gci_window;
+
+typedef struct gci_ctx gci_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int gci_abi_version(void);
+/* own_stream == 0: enqueue on `stream`, a hipStream_t of the caller (e.g. torch's current stream;
+ * NULL is the device's default stream).  own_stream != 0: `stream` is ignored and the ctx creates
+ * (and later destroys) a non-blocking stream of its own. */
+int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx** out);
+int gci_ctx_destroy(gci_ctx* ctx);
+int gci_sync(gci_ctx* ctx);
+const char* gci_strerror(int status);
+const char* gci_last_error(gci_ctx* ctx);
+/* Convenience for hosts without a device allocator of their own (cgo, JNI ...). */
+int gci_malloc(gci_ctx* ctx, size_t bytes, void** d_out);
+int gci_free(gci_ctx* ctx, void* d_ptr);
+int gci_memcpy_h2d(gci_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* synchronous */
+int gci_memcpy_d2h(gci_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
+int gci_memset(gci_ctx* ctx, void* d_dst, int byte, size_t bytes);                /* async */
+
+/* ---- optional per-kernel timing with HIP events on the ctx stream ------------------------------
+ * gci_profile_enable(mask): bit k enables an event pair around every launch of kernel id k.
+ * gci_profile_read(): synchronises, folds finished event pairs in and returns the accumulated
+ * milliseconds / launch count of one kernel id (reset != 0 clears that id afterwards). */
+enum {
+    GCI_PROF_BAM_FILTER = 0, GCI_PROF_JOIN_INSERT, GCI_PROF_JOIN_FOLD, GCI_PROF_DEPTH_DIFF, GCI_PROF_SCAN_TILES,
+    GCI_PROF_DEPTH_SCAN, GCI_PROF_GAP_MASK, GCI_PROF_MAX2, GCI_PROF_ISSUE_SCAN, GCI_PROF_TEXT_COUNT,
+    GCI_PROF_TEXT_WRITE, GCI_PROF_DEPTH_SUM, GCI_PROF_MEMSET, GCI_PROF_COUNT
+};
+int gci_profile_enable(gci_ctx* ctx, int mask);
+int gci_profile_read(gci_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, int reset);
+const char* gci_profile_name(int kernel_id);
+
+/* ---- layout (GCI.py:201-208: contig table of the first BAM, optionally restricted by --chrs) */
+int gci_layout_set(gci_ctx* ctx, int32_t n_contigs, const int64_t* h_lengths);
+int64_t gci_layout_total(gci_ctx* ctx);                    /* elements of one track buffer */
+int gci_layout_offsets(gci_ctx* ctx, int64_t* h_offsets);  /* n_contigs entries */
+
+/* ---- R1: record filter ---------------------------------------------------------------------
+ * d_bam: inflated BAM stream; d_rec_off[i]: byte offset of record i's block_size word;
+ * d_ref_sel[refID]: index among the selected contigs or -1.  Writes one gci_rec per input
+ * record (flags == 0 for filtered records); out[i].rec_idx = rec_idx_base + i (a rank that
+ * decodes a slice of a file passes the slice's first record index).  *d_status (uint64, device) receives
+ * min over failing records of (rec_idx << 8 | -status), or UINT64_MAX if none failed;
+ * decode with gci_decode_status(). */
+int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
+                   uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                   double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                   uint64_t* d_status);
+int gci_decode_status(uint64_t status_word, uint32_t* rec_idx);   /* -> gci_status */
+/* The name hash K1 uses, for hosts that build gci_rec themselves (PAF path). */
+uint64_t gci_name_hash(const uint8_t* h_name, uint32_t len);
+/* Pack the query names of `n` records into a dense blob (multi-GPU exchange):
+ * d_out_off[i] = byte offset of name i (exclusive scan of name_len), d_out_off[n] = total. */
+int gci_pack_names(gci_ctx* ctx, const gci_join_file* h_file, uint8_t* d_out_names, uint64_t cap,
+                   uint64_t* d_out_off);
+
+/* ---- R5: cross-file join --------------------------------------------------------------------
+ * h_files in reference order (PAF files, then BAM files, each in command-line order).
+ * One file: the dict semantics of GCI.py:166/269 only (a repeated name keeps its LAST record).
+ * d_contig_map (nullable): remaps rec.contig -> output contig, entries < 0 drop the interval
+ * (multi-GPU: keep only the contigs this rank owns).  Output order is unspecified.
+ * *d_n_out may exceed cap: then nothing beyond cap was written, grow and retry. */
+int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
+                  const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                  uint64_t* d_status);
+
+/* ---- R6: depth build ------------------------------------------------------------------------
+ * depth[c][start+flank : end-flank+1] += 1 with Python/NumPy slice semantics, for n intervals
+ * (n read from *d_n if d_n != NULL, clamped to max_n).  Overwrites the whole track. */
+int gci_depth_build(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, int flank,
+                    int32_t* d_depth);
+
+/* ---- R8 / R9 -------------------------------------------------------------------------------- */
+int gci_gap_mask(gci_ctx* ctx, int32_t* d_depth, const gci_ivl* d_gaps, uint32_t n_gaps);
+int gci_max2(gci_ctx* ctx, const int32_t* d_a, const int32_t* d_b, int32_t* d_out);
+
+/* ---- R10: issue scan ------------------------------------------------------------------------
+ * Finds every maximal run of `lo < depth <= hi` inside each window.  Emits unordered 64-bit
+ * keys  (window << 33) | (rel << 1) | is_end,  rel = run start - window.begin for a start key,
+ * run end (exclusive) - window.begin for an end key; sorted ascending they read
+ * start,end,start,end... per window.  The reference's `i > flank_len` drop rule and
+ * coordinate shifts are applied by the host.  gci_issue_scan uses one window per contig:
+ * [flank, L - flank). */
+int gci_issue_scan(gci_ctx* ctx, const int32_t* d_depth, double lo, double hi, int flank,
+                   uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys);
+int gci_issue_scan_windows(gci_ctx* ctx, const int32_t* d_depth, const gci_window* h_windows,
+                           uint32_t n_windows, double lo, double hi, uint64_t* d_keys, uint32_t cap,
+                           uint32_t* d_n_keys);
+
+/* ---- R7: depth text -------------------------------------------------------------------------
+ * size: d_contig_off[c] = byte offset of contig c's lines in the text, d_contig_off[n_contigs] =
+ * total bytes (no '>' lines: the host writes those).  write: fills d_out (cap >= total). */
+int gci_depth_text_size(gci_ctx* ctx, const int32_t* d_depth, uint64_t* d_contig_off);
+int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_t* d_out, uint64_t cap);
+
+/* ---- R15 ------------------------------------------------------------------------------------ */
+int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums /* n_contigs */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCI_HIP_H */

@@ -1,0 +1,210 @@
+"""GPU parity, seam by seam: each C-ABI export against the oracle's restatement of the matching
+reference function on the same seeded inputs (bit-exact: everything here is integer work or an
+IEEE f64 comparison)."""
+import numpy as np
+import pytest
+import torch
+
+from gci_amd import synth
+from gci_amd.device import JoinInput, REC_DTYPE, name_hash_np
+from gci_amd import pipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _recs_np(t):
+    return t.cpu().numpy().reshape(-1).view(REC_DTYPE)
+
+
+def _filter_case(engine, oracle, rs, targets=None, mq=30, cut=50, cp=0.1, ip=0.9):
+    stream, offs = synth.to_bam_stream(rs)
+    refs = [n for n, _ in rs.contigs]
+    targets = targets or refs
+    tindex = {t: i for i, t in enumerate(targets)}
+    ref_sel = np.array([tindex.get(r, -1) for r in refs], dtype=np.int32)
+    want = oracle.bam_filter_arrays(stream, offs, ref_sel, mq, cut, cp, ip)
+    d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+    got = _recs_np(engine.bam_filter(d_bam, d_off, engine.to_device(ref_sel), mq, cut, cp, ip))
+    p = want["passed"].astype(bool)
+    assert np.array_equal((got["flags"] & 1).astype(bool), p)
+    assert np.array_equal(((got["flags"] & 2) != 0), want["hq"].astype(bool))
+    for f in ("contig", "start", "end", "qlen"):
+        assert np.array_equal(got[f][p], want[f][p]), f
+    assert np.array_equal(got["name_len"][p], want["name_len"][p])
+    names = [bytes(stream[int(o):int(o) + int(n)]) for o, n in zip(want["name_off"][p], want["name_len"][p])]
+    assert np.array_equal(got["name_hash"][p], name_hash_np(names))
+    assert np.array_equal(got["rec_idx"], np.arange(len(rs)))
+    return stream, offs, d_bam, d_off, got, p.sum()
+
+
+@pytest.mark.parametrize("kind,seed,cov", [("hifi", 11, 20), ("hifi", 12, 20), ("ont", 13, 15)])
+def test_bam_filter_matches_oracle(engine, oracle, kind, seed, cov):
+    rs = synth.simulate_reads((("a", 1_500_000), ("b", 700_000), ("c", 40_000)), cov, kind, seed=seed,
+                              long_cigar_frac=0.01 if kind == "ont" else 0.0)
+    *_, n_pass = _filter_case(engine, oracle, rs)
+    assert n_pass > 100
+    # --chrs restriction and non-default thresholds
+    _filter_case(engine, oracle, rs, targets=["b"], mq=20, cut=40, cp=0.02, ip=0.995)
+
+
+def _dicts_from(oracle, rs, targets, **kw):
+    stream, offs = synth.to_bam_stream(rs)
+    refs = [n for n, _ in rs.contigs]
+    return oracle.bam_file_dict(stream, offs, refs, targets, 30, 50, 0.1, 0.9), (stream, offs)
+
+
+def _join_gpu(engine, sets, targets, ovlp=0.9):
+    inputs = []
+    tindex = {t: i for i, t in enumerate(targets)}
+    for rs in sets:
+        stream, offs = synth.to_bam_stream(rs)
+        refs = [n for n, _ in rs.contigs]
+        ref_sel = engine.to_device(np.array([tindex.get(r, -1) for r in refs], dtype=np.int32))
+        d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+        recs = engine.bam_filter(d_bam, d_off, ref_sel, 30, 50, 0.1, 0.9)
+        inputs.append(JoinInput(recs, d_bam, d_off, 36))
+    ivl, cnt = engine.name_join(inputs, ovlp)
+    n = int(cnt.item())
+    return sorted(map(tuple, ivl[:n, :3].cpu().numpy().tolist()))
+
+
+@pytest.mark.parametrize("n_files", [1, 2, 3])
+def test_name_join_matches_oracle(engine, oracle, n_files):
+    contigs = (("a", 900_000), ("b", 500_000))
+    targets = ["a", "b"]
+    base = synth.simulate_reads(contigs, 25, "hifi", seed=21)
+    sets = [base] + [synth.perturb(base, 100 + k) for k in range(1, n_files)]
+    if n_files == 1:
+        # repeated names inside one file: the dict keeps the last record
+        dup = base.take(np.arange(0, len(base), 7))
+        dup.pos[:] = np.minimum(dup.pos + 1234, 400_000)
+        dup.mapq[:] = 60
+        sets = [synth.ReadSet.sorted(_concat(base, dup))]
+    files, hq = [], set()
+    for rs in sets:
+        (d, h), _ = _dicts_from(oracle, rs, targets)
+        files.append(d)
+        hq |= h
+    want = oracle.name_join(files, hq, 0.9)
+    tindex = {"a": 0, "b": 1}
+    want = sorted((tindex[v[0]], v[1], v[2]) for v in want.values())
+    got = _join_gpu(engine, sets, targets)
+    assert got == want
+    assert len(want) > 100
+
+
+def _concat(a, b):
+    from dataclasses import replace
+    off = np.concatenate([a.cigar_off, a.cigar_off[-1] + b.cigar_off[1:]])
+    w = max(a.names.dtype.itemsize, b.names.dtype.itemsize)
+    return replace(a, ref_id=np.concatenate([a.ref_id, b.ref_id]), pos=np.concatenate([a.pos, b.pos]),
+                   mapq=np.concatenate([a.mapq, b.mapq]), flag=np.concatenate([a.flag, b.flag]),
+                   l_seq=np.concatenate([a.l_seq, b.l_seq]), nm=np.concatenate([a.nm, b.nm]),
+                   nm_last=np.concatenate([a.nm_last, b.nm_last]),
+                   names=np.concatenate([a.names.astype("S%d" % w), b.names.astype("S%d" % w)]),
+                   cigar=np.concatenate([a.cigar, b.cigar]), cigar_off=off)
+
+
+def test_depth_build_slice_semantics(engine, oracle):
+    rng = np.random.default_rng(5)
+    lengths = {"x": 10_000, "y": 4096, "z": 4097, "w": 50, "v": 123_457}
+    targets = list(lengths)
+    engine.set_layout([lengths[t] for t in targets])
+    ivls = []
+    for c, t in enumerate(targets):
+        L = lengths[t]
+        for _ in range(400):
+            s = int(rng.integers(0, L))
+            e = int(min(L + 40, s + rng.integers(1, max(2, L // 3))))
+            ivls.append((c, s, e))
+    # NumPy negative-stop wrap (e <= fl - 2), empty slices, reads hanging over the end
+    ivls += [(3, 0, 10), (3, 0, 13), (3, 0, 14), (3, 20, 25), (0, 9_990, 10_050), (1, 0, 4096), (2, 4090, 4097)]
+    for fl in (15, 0, 3):
+        want = oracle.depth_build_py([(targets[c], s, e) for c, s, e in ivls], lengths, fl)
+        d = engine.to_device(np.array([(c, s, e, 0) for c, s, e in ivls], dtype=np.int32))
+        track = engine.new_track()
+        engine.depth_build(d, None, fl, track)
+        tr = pipeline.DepthTracks(engine, lengths, track)
+        for t in targets:
+            assert np.array_equal(tr[t], want[t]), (t, fl)
+        # padding between contigs stays zero
+        assert int(track.sum().item()) == sum(int(v.sum()) for v in want.values())
+        assert np.array_equal(tr.sums(), np.array([want[t].sum() for t in targets]))
+
+
+def _random_depth(rng, L):
+    d = rng.poisson(3.0, L).astype(np.int64)
+    for _ in range(max(3, L // 5000)):
+        a = int(rng.integers(0, L))
+        d[a:a + int(rng.integers(1, 400))] = 0
+    d[:int(rng.integers(0, 40))] = 0
+    d[L - int(rng.integers(1, 40)):] = 0
+    return d
+
+
+def _upload_depths(engine, depths):
+    targets = list(depths)
+    lengths = {t: int(depths[t].shape[0]) for t in targets}
+    offs = engine.set_layout([lengths[t] for t in targets])
+    flat = np.zeros(max(engine.total, 1), dtype=np.int32)
+    for o, t in zip(offs, targets):
+        flat[o:o + lengths[t]] = depths[t]
+    return pipeline.DepthTracks(engine, lengths, engine.to_device(flat))
+
+
+@pytest.mark.parametrize("flank,threshold", [(15, 0), (0, 0), (2, 1), (40, 2)])
+def test_issue_scan_matches_oracle(engine, oracle, flank, threshold):
+    rng = np.random.default_rng(7 + flank)
+    depths = {"a": _random_depth(rng, 200_001), "b": _random_depth(rng, 4096), "c": _random_depth(rng, 8193),
+              "tiny": np.zeros(20, dtype=np.int64), "one": np.zeros(2 * flank + 1, dtype=np.int64),
+              "full": np.full(5000, 9, dtype=np.int64), "zero": np.zeros(12_345, dtype=np.int64)}
+    tr = _upload_depths(engine, depths)
+    got = pipeline.collapse_depth_range(tr, -1, threshold, flank, 0)
+    want = oracle.collapse_depth_range(depths, -1, threshold, flank, 0)
+    assert got == want
+    assert sum(len(v) for v in want.values()) > 10
+
+
+def test_issue_scan_kats(engine, oracle):
+    """SURVEY.md R10 known answers, produced by the reference's collapse_depth_range."""
+    cases = [([0] * 10, 2, 0, [(2, 8)]), ([0, 0, 0, 0, 5, 5, 5, 5, 0, 0], 2, 0, []),
+             ([0, 0, 0, 0, 0, 5, 5, 5, 0, 0], 2, 0, [(2, 5)]), ([0, 0, 5, 5, 5, 5, 5, 0, 0, 0], 2, 0, [(7, 8)]),
+             ([0, 3, 0, 0, 3, 0], 0, 100, [(100, 101), (102, 104), (105, 106)])]
+    for d, fl, sp, want in cases:
+        tr = _upload_depths(engine, {"k": np.array(d, dtype=np.int64)})
+        assert pipeline.collapse_depth_range(tr, -1, 0, fl, sp)["k"] == want
+        assert oracle.collapse_contig(np.array(d), -1, 0, fl, sp) == want
+
+
+def test_regions_scan(engine, oracle):
+    rng = np.random.default_rng(3)
+    depths = {"a": _random_depth(rng, 50_000), "b": _random_depth(rng, 9_000)}
+    tr = _upload_depths(engine, depths)
+    regions = [("a", 0, 50_000), ("a", 100, 20_000), ("b", 4000, 9500), ("a", 4095, 4097), ("b", 10, 10),
+               ("a", 30_000, 20_000), ("a", -500, 50_000)]
+    got = pipeline.collapse_regions(tr, regions, -1, 0)
+    for (t, s, e), g in zip(regions, got):
+        assert g == oracle.collapse_contig(depths[t][s:e], -1, 0, 0, s), (t, s, e)
+
+
+def test_gap_mask_max2_text(engine, oracle):
+    rng = np.random.default_rng(9)
+    h = {"a": rng.poisson(30, 70_001).astype(np.int64), "b": rng.integers(0, 120_000, 5000).astype(np.int64),
+         "c": np.array([0, 9, 10, 99, 100, 999, 1000, 9999, 10000, 2**31 - 1], dtype=np.int64)}
+    n = {k: rng.poisson(25, v.shape[0]).astype(np.int64) for k, v in h.items()}
+    th, tn = _upload_depths(engine, h), _upload_depths(engine, n)
+    two = pipeline.merge_two_type_depth(th, tn, write=False)
+    want2 = oracle.max2(h, n)
+    for k in h:
+        assert np.array_equal(two[k], want2[k])
+    gaps = {"a": [(10, 500), (69_990, 80_000), (-20, -5)], "b": [(0, 1)], "nope": [(1, 2)]}
+    pipeline.merge_gaps_depths(two, gaps)
+    oracle.merge_gaps_depths(want2, gaps)
+    for k in h:
+        assert np.array_equal(two[k], want2[k])
+    text, offs = engine.depth_text(two.track)
+    host = text.cpu().numpy().tobytes()
+    want_text = b"".join(oracle.depth_text_contig(want2[k]) for k in h)
+    assert host == want_text
+    assert [int(x) for x in offs] == list(np.cumsum([0] + [len(oracle.depth_text_contig(want2[k])) for k in h]))
+    assert two.mean() == oracle.mean_depth(want2)
