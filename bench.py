@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned Gbases/s through the filter+depth pipeline (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic alignments whose inflated BAM
+bytes are already resident in HBM:
+
+    K1 record filter -> [N>1: RCCL all-gather of compact records + names] -> K3 name join
+    -> K4/K5 depth build -> K8 issue scan -> K10 depth text (size + write) -> per-contig sums
+    -> [N>1: RCCL all-reduce of the int64 totals]
+
+Workload at N=1: BASELINE.json configs[1] -- CHM13 chr19 (61,707,364 bp), one 40x HiFi BAM.
+At N>1 (weak scaling) every rank owns one chr19-sized contig of an N-contig assembly and the
+records of that contig; results are identical to a single-GPU run over the same N contigs.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CHR19_LEN = 61_707_364
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="per-rank contig length (default chr19)")
+    ap.add_argument("--coverage", type=float, default=40.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel HIP-event table to stderr")
+    return ap.parse_args()
+
+
+class Workload:
+    """Per-rank resident inputs + preallocated outputs for one step."""
+
+    def __init__(self, eng, rank, world, contig_len, coverage):
+        import torch
+        from gci_amd import synth
+        self.torch = torch
+        self.eng, self.rank, self.world = eng, rank, world
+        names = ["chr19"] if world == 1 else ["chr19_%d" % r for r in range(world)]
+        self.contigs = tuple((n, contig_len) for n in names)
+        # this rank's slice of the BAM: the records of its own contig
+        own = ((names[rank], contig_len),)
+        rs = synth.simulate_reads(own, coverage, "hifi", seed=synth.seed_for(2, rank))
+        self.aligned_bases = rs.aligned_bases()
+        self.n_rec = len(rs)
+        # the BAM header lists all N contigs; refID of this rank's records = rank
+        rs.ref_id[:] = rank
+        rs.contigs = self.contigs
+        stream, offs = synth.to_bam_stream(rs)
+        self.stream_bytes = int(stream.shape[0])
+        self.host_stream, self.host_offs = (stream, offs) if rank == 0 and world == 1 else (None, None)
+        self.d_bam = eng.to_device(stream)
+        self.d_off = eng.to_device(offs)
+        del stream
+        self.ref_sel = eng.to_device(np.arange(world, dtype=np.int32))
+        eng.set_layout([contig_len])                       # local track: the contig this rank owns
+        cmap = np.full(world, -1, dtype=np.int32)
+        cmap[rank] = 0
+        self.contig_map = eng.to_device(cmap) if world > 1 else None
+        dev = eng.device
+        self.recs = torch.empty((self.n_rec, 32), dtype=torch.uint8, device=dev)
+        self.track = eng.new_track()
+        self.ivl = torch.empty((self.n_rec * (world if world > 1 else 1), 4), dtype=torch.int32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.keys = torch.empty(1 << 16, dtype=torch.int64, device=dev)
+        self.nkeys = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.text_off = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.sums = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.totals = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.status = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.text = None
+        self.rec_base = 0
+        if world > 1:
+            self._setup_exchange()
+
+    # ---- multi-GPU: every rank needs every record's (hash, interval, name) for the join ----------
+    def _setup_exchange(self):
+        import torch.distributed as dist
+        torch = self.torch
+        dev = self.eng.device
+        n = torch.tensor([self.n_rec], dtype=torch.int64, device=dev)
+        alln = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(alln, n)
+        self.all_n = [int(x.item()) for x in alln]
+        self.max_n = max(self.all_n)
+        self.rec_base = self.rank * self.max_n
+        self.recs = torch.zeros((self.max_n, 32), dtype=torch.uint8, device=dev)       # padded send buffer
+        self.g_recs = torch.zeros((self.world * self.max_n, 32), dtype=torch.uint8, device=dev)
+        self.name_cap = self.max_n * 48
+        self.names = torch.zeros(self.name_cap, dtype=torch.uint8, device=dev)
+        self.name_off = torch.zeros(self.max_n + 1, dtype=torch.int64, device=dev)
+        self.g_names = torch.zeros(self.world * self.name_cap, dtype=torch.uint8, device=dev)
+        self.g_name_off = torch.zeros(self.world * (self.max_n + 1), dtype=torch.int64, device=dev)
+        # offsets into the gathered blob: chunk r starts at r * name_cap
+        self.chunk_base = (torch.arange(self.world, device=dev, dtype=torch.int64) * self.name_cap
+                           ).repeat_interleave(self.max_n + 1)
+        self.g_name_index = torch.zeros(self.world * self.max_n, dtype=torch.int64, device=dev)
+        self.ivl = torch.empty((self.world * self.max_n, 4), dtype=torch.int32, device=dev)
+
+    def _p(self, t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def step(self):
+        eng, lib, ctx = self.eng, self.eng.lib, self.eng.ctx
+        from gci_amd._lib import JoinFile
+        chk = eng._chk
+        chk(lib.gci_bam_filter(ctx, self._p(self.d_bam), self.stream_bytes, self._p(self.d_off), self.n_rec,
+                               self._p(self.ref_sel), self.world, 30, 50, 0.1, 0.9, self.rec_base, self._p(self.recs),
+                               self._p(self.status[0:1])), "gci_bam_filter")
+        jf = (JoinFile * 1)()
+        if self.world == 1:
+            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
+            jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
+        else:
+            import torch.distributed as dist
+            # names of the local records as a dense blob, then exchange records + names
+            loc = (JoinFile * 1)()
+            loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
+            loc[0].d_name_base = self.d_bam.data_ptr()
+            # rec_idx is global (rec_base + i): index the local offset table through a shifted base pointer
+            loc[0].d_name_off = self.d_off.data_ptr() - 8 * self.rec_base
+            chk(lib.gci_pack_names(ctx, loc, self._p(self.names), self.name_cap, self._p(self.name_off)),
+                "gci_pack_names")
+            dist.all_gather_into_tensor(self.g_recs, self.recs)
+            dist.all_gather_into_tensor(self.g_names, self.names)
+            dist.all_gather_into_tensor(self.g_name_off, self.name_off)
+            goff = self.g_name_off + self.chunk_base
+            # name offset table indexed by global rec_idx = r * max_n + i
+            self.g_name_index = goff.view(self.world, self.max_n + 1)[:, :self.max_n].reshape(-1).contiguous()
+            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.g_recs.data_ptr(), self.world * self.max_n, 0
+            jf[0].d_name_base, jf[0].d_name_off = self.g_names.data_ptr(), self.g_name_index.data_ptr()
+        chk(lib.gci_name_join(ctx, jf, 1, 0.9, self._p(self.contig_map), self._p(self.ivl), int(self.ivl.shape[0]),
+                              self._p(self.count), self._p(self.status[1:2])), "gci_name_join")
+        chk(lib.gci_depth_build(ctx, self._p(self.ivl), self._p(self.count), int(self.ivl.shape[0]), 15,
+                                self._p(self.track)), "gci_depth_build")
+        chk(lib.gci_issue_scan(ctx, self._p(self.track), -1.0, 0.0, 15, self._p(self.keys), int(self.keys.shape[0]),
+                               self._p(self.nkeys)), "gci_issue_scan")
+        chk(lib.gci_depth_text_size(ctx, self._p(self.track), self._p(self.text_off)), "gci_depth_text_size")
+        if self.text is None:                              # first (warm-up) call sizes the text buffer
+            total = int(self.text_off[1].item())
+            self.text = self.torch.empty(total + (total >> 4) + 4096, dtype=self.torch.uint8, device=eng.device)
+        chk(lib.gci_depth_text_write(ctx, self._p(self.track), self._p(self.text), int(self.text.shape[0])),
+            "gci_depth_text_write")
+        chk(lib.gci_depth_sum(ctx, self._p(self.track), self._p(self.sums)), "gci_depth_sum")
+        if self.world > 1:
+            import torch.distributed as dist
+            self.totals[0] = self.sums[0]
+            self.totals[1] = self.contigs[self.rank][1]
+            dist.all_reduce(self.totals, op=dist.ReduceOp.SUM)      # global mean depth = totals[0] / totals[1]
+
+    def check(self):
+        """Record-level status of the last step + issue-key capacity."""
+        from gci_amd._lib import GciError
+        for w, what in zip(self.status.cpu().numpy().view(np.uint64).tolist(), ("gci_bam_filter", "gci_name_join")):
+            rec = ctypes.c_uint32(0)
+            st = self.eng.lib.gci_decode_status(w, ctypes.byref(rec))
+            if st != 0:
+                raise GciError(st, "%s failed on record %d" % (what, rec.value))
+        if int(self.nkeys.item()) > self.keys.shape[0] or int(self.count.item()) > self.ivl.shape[0]:
+            raise GciError(-8, "bench output buffers too small")
+
+
+def cpu_baseline(w: Workload):
+    """The oracle's single-thread C/Python restatement of the same step on the same chr19 input,
+    timed on this host: filter -> dict -> slice-add depth -> run scan -> text -> sum."""
+    from oracle import gci_oracle as O
+    O.build()
+    refs = [n for n, _ in w.contigs]
+    tl = dict(w.contigs)
+    t0 = time.perf_counter()
+    d, hq = O.bam_file_dict(w.host_stream, w.host_offs, refs, refs, 30, 50, 0.1, 0.9)
+    file1 = O.name_join([d], hq, 0.9)
+    depths = O.depth_build(file1, tl, 15)
+    bed = O.collapse_depth_range(depths, -1, 0, 15, 0)
+    text = O.depth_text(depths)
+    mean = O.mean_depth(depths)
+    dt = time.perf_counter() - t0
+    return dt, depths, bed, text, mean
+
+
+def main():
+    args = parse_args()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gci_amd.build import build_hip, needs_build
+    if needs_build():
+        if local_rank == 0:
+            build_hip()
+        if world > 1:
+            dist.barrier()
+    from gci_amd import _lib
+    from gci_amd.device import Engine
+    eng = Engine(local_rank)
+    w = Workload(eng, rank, world, args.contig_len, args.coverage)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        w.step()
+    fence()
+    w.check()
+
+    eng.profile_enable(1 << _lib.PROF_DEPTH_SCAN)          # HIP events around the dominant kernel only
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    eng.profile_enable(0)
+    w.check()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ab = torch.tensor([w.aligned_bases], dtype=torch.int64, device=eng.device)
+        dist.all_reduce(ab, op=dist.ReduceOp.SUM)
+        aligned_total = int(ab.item())
+    else:
+        aligned_total = w.aligned_bases
+
+    scan_ms, scan_n = prof.get("k_depth_scan", (0.0, 0))
+    scan_avg_ms = scan_ms / max(1, scan_n)
+    algo_bytes = 8.0 * args.contig_len                     # K5: 4 B read + 4 B write per base
+    achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+
+    breakdown = None
+    if args.breakdown or True:
+        eng.profile_enable((1 << _lib.PROF_COUNT) - 1)
+        for _ in range(3):
+            w.step()
+        breakdown = {k: round(ms / n * 1e3, 2) for k, (ms, n) in eng.profile_read(reset=True).items()}   # us / launch
+        eng.profile_enable(0)
+
+    out = {
+        "metric": "aligned Gbases/s through filter+depth pipeline (CHM13, 40x HiFi)",
+        "value": aligned_total * args.steps / dt / 1e9,
+        "unit": "Gbases/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": "CHM13 chr19 (%d bp) x %d contig(s), one %gx HiFi BAM, filter -> join -> depth -> "
+                               "issue scan -> depth text" % (args.contig_len, world, args.coverage),
+                   "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
+                   "inflated_bam_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_depth_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
+        "kernel_us_per_launch": breakdown,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cdt, depths, bed, text, mean = cpu_baseline(w)
+        out["cpu_baseline"] = {"value": w.aligned_bases / cdt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+                               "sample": "one full step (all %d records, %d bp) through oracle/gci_oracle.{c,py}, "
+                                         "%.1f s" % (w.n_rec, args.contig_len, cdt)}
+        # the timed GPU result must equal the oracle's on the full-size input
+        from gci_amd import pipeline
+        tr = pipeline.DepthTracks(eng, dict(w.contigs), w.track)
+        ok = np.array_equal(tr["chr19"], depths["chr19"])
+        ok = ok and pipeline.collapse_depth_range(tr, -1, 0, 15, 0) == bed
+        n_text = int(w.text_off[1].item())
+        ok = ok and (b">chr19\n" + w.text[:n_text].cpu().numpy().tobytes()) == text
+        ok = ok and tr.mean() == mean
+        out["parity_vs_oracle_full_size"] = bool(ok)
+        if not ok:
+            print(json.dumps(out))
+            sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")
+    elif world == 1:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
