@@ -62,6 +62,7 @@ class Workload:
         rs = synth.simulate_reads(own, coverage, "hifi", seed=synth.seed_for(2, rank))
         self.aligned_bases = rs.aligned_bases()
         self.n_rec = len(rs)
+        self.name_bytes = int(np.char.str_len(rs.names).sum())
         # the BAM header lists all N contigs; refID of this rank's records = rank
         rs.ref_id[:] = rank
         rs.contigs = self.contigs
@@ -94,27 +95,11 @@ class Workload:
 
     # ---- multi-GPU: every rank needs every record's (hash, interval, name) for the join ----------
     def _setup_exchange(self):
-        import torch.distributed as dist
-        torch = self.torch
-        dev = self.eng.device
-        n = torch.tensor([self.n_rec], dtype=torch.int64, device=dev)
-        alln = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(alln, n)
-        self.all_n = [int(x.item()) for x in alln]
-        self.max_n = max(self.all_n)
-        self.rec_base = self.rank * self.max_n
-        self.recs = torch.zeros((self.max_n, 32), dtype=torch.uint8, device=dev)       # padded send buffer
-        self.g_recs = torch.zeros((self.world * self.max_n, 32), dtype=torch.uint8, device=dev)
-        self.name_cap = self.max_n * 48
-        self.names = torch.zeros(self.name_cap, dtype=torch.uint8, device=dev)
-        self.name_off = torch.zeros(self.max_n + 1, dtype=torch.int64, device=dev)
-        self.g_names = torch.zeros(self.world * self.name_cap, dtype=torch.uint8, device=dev)
-        self.g_name_off = torch.zeros(self.world * (self.max_n + 1), dtype=torch.int64, device=dev)
-        # offsets into the gathered blob: chunk r starts at r * name_cap
-        self.chunk_base = (torch.arange(self.world, device=dev, dtype=torch.int64) * self.name_cap
-                           ).repeat_interleave(self.max_n + 1)
-        self.g_name_index = torch.zeros(self.world * self.max_n, dtype=torch.int64, device=dev)
-        self.ivl = torch.empty((self.world * self.max_n, 4), dtype=torch.int32, device=dev)
+        from gci_amd import shard
+        self.ex = shard.RecordExchange(self.n_rec, self.name_bytes, self.eng.device)
+        self.rec_base = self.ex.rec_idx_base
+        self.recs = self.ex.send_recs                       # K1 writes straight into the send buffer
+        self.ivl = self.torch.empty((self.world * self.ex.max_n, 4), dtype=self.torch.int32, device=self.eng.device)
 
     def _p(self, t):
         return ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -131,23 +116,19 @@ class Workload:
             jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
             jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
         else:
-            import torch.distributed as dist
             # names of the local records as a dense blob, then exchange records + names
+            ex = self.ex
             loc = (JoinFile * 1)()
             loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
             loc[0].d_name_base = self.d_bam.data_ptr()
             # rec_idx is global (rec_base + i): index the local offset table through a shifted base pointer
             loc[0].d_name_off = self.d_off.data_ptr() - 8 * self.rec_base
-            chk(lib.gci_pack_names(ctx, loc, self._p(self.names), self.name_cap, self._p(self.name_off)),
+            chk(lib.gci_pack_names(ctx, loc, self._p(ex.send_names), ex.name_cap, self._p(ex.send_off)),
                 "gci_pack_names")
-            dist.all_gather_into_tensor(self.g_recs, self.recs)
-            dist.all_gather_into_tensor(self.g_names, self.names)
-            dist.all_gather_into_tensor(self.g_name_off, self.name_off)
-            goff = self.g_name_off + self.chunk_base
-            # name offset table indexed by global rec_idx = r * max_n + i
-            self.g_name_index = goff.view(self.world, self.max_n + 1)[:, :self.max_n].reshape(-1).contiguous()
-            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.g_recs.data_ptr(), self.world * self.max_n, 0
-            jf[0].d_name_base, jf[0].d_name_off = self.g_names.data_ptr(), self.g_name_index.data_ptr()
+            g = ex.gather()
+            self._g = g                                     # keep the index tensor alive until the join ran
+            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = g.recs.data_ptr(), self.world * g.max_n, 0
+            jf[0].d_name_base, jf[0].d_name_off = g.names.data_ptr(), g.name_index.data_ptr()
         chk(lib.gci_name_join(ctx, jf, 1, 0.9, self._p(self.contig_map), self._p(self.ivl), int(self.ivl.shape[0]),
                               self._p(self.count), self._p(self.status[1:2])), "gci_name_join")
         chk(lib.gci_depth_build(ctx, self._p(self.ivl), self._p(self.count), int(self.ivl.shape[0]), 15,
@@ -260,7 +241,7 @@ def main():
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
 
     breakdown = None
-    if args.breakdown or True:
+    if True:
         eng.profile_enable((1 << _lib.PROF_COUNT) - 1)
         for _ in range(3):
             w.step()

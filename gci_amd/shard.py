@@ -1,0 +1,110 @@
+"""Multi-GPU sharding of the path: one process per GPU, contigs sharded, ONE real
+exchange step.
+
+* Depth build, gap mask, two-type max, issue scan, text and per-contig scoring are independent
+  per contig -> each rank owns a set of contigs (longest-processing-time packing).
+* The read-name join is NOT contig-local (a read aligned to different contigs in two files must
+  be dropped, GCI.py:296-297; a repeated name keeps only its last record, GCI.py:269), so every
+  rank decodes a slice of each file's records (K1) and the 32-byte compact records plus the
+  name bytes are replicated with an RCCL all-gather; every rank then runs the full join and
+  keeps the intervals of the contigs it owns (`contig_map`).
+* Genome-wide totals (sum of depth, bases) are one integer all-reduce: exact in any order.
+
+Everything here is device-agnostic torch (`nccl` == RCCL on the GPUs, `gloo` in the CPU tests).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def lpt_assign(lengths: Sequence[int], world: int) -> List[int]:
+    """Owner rank of each contig: longest first onto the least loaded rank (ties -> lowest rank)."""
+    load = [0] * world
+    owner = [0] * len(lengths)
+    for c in sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[c] = r
+        load[r] += int(lengths[c])
+    return owner
+
+
+def contig_map_for(owner: Sequence[int], rank: int) -> Tuple[np.ndarray, List[int]]:
+    """-> (int32 map global contig -> local track index or -1, list of owned global contigs in order)."""
+    mine = [c for c, o in enumerate(owner) if o == rank]
+    m = np.full(len(owner), -1, dtype=np.int32)
+    for k, c in enumerate(mine):
+        m[c] = k
+    return m, mine
+
+
+def record_slices(n_rec: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, near-equal [lo, hi) slices of a file's records, one per rank."""
+    step = -(-n_rec // world) if n_rec else 0
+    return [(min(n_rec, r * step), min(n_rec, (r + 1) * step)) for r in range(world)]
+
+
+@dataclass
+class Gathered:
+    recs: torch.Tensor          # uint8 [world * max_n, 32]; rows past a rank's count have flags == 0
+    names: torch.Tensor         # uint8 [world * name_cap]
+    name_index: torch.Tensor    # int64 [world * max_n]: byte offset of record (r * max_n + i)'s name in `names`
+    max_n: int
+
+
+class RecordExchange:
+    """All-gather of one file's compact records + packed names with fixed (padded) shapes, so the
+    collective sizes are identical on every rank and every step.
+
+    Rank r's record i travels as global index r * max_n + i; K1 is called with
+    rec_idx_base = r * max_n so `gci_rec.rec_idx` already is that global index."""
+
+    def __init__(self, n_local: int, name_bytes_local: int, device: torch.device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device
+        sizes = torch.tensor([n_local, name_bytes_local], dtype=torch.int64, device=device)
+        allsz = [torch.zeros_like(sizes) for _ in range(self.world)]
+        dist.all_gather(allsz, sizes, group=group)
+        self.counts = [int(s[0].item()) for s in allsz]
+        self.max_n = max(1, max(self.counts))
+        self.name_cap = max(16, max(int(s[1].item()) for s in allsz))
+        self.rec_idx_base = self.rank * self.max_n
+        self.send_recs = torch.zeros((self.max_n, 32), dtype=torch.uint8, device=device)
+        self.send_names = torch.zeros(self.name_cap, dtype=torch.uint8, device=device)
+        self.send_off = torch.zeros(self.max_n + 1, dtype=torch.int64, device=device)
+        self.g_recs = torch.zeros((self.world * self.max_n, 32), dtype=torch.uint8, device=device)
+        self.g_names = torch.zeros(self.world * self.name_cap, dtype=torch.uint8, device=device)
+        self.g_off = torch.zeros(self.world * (self.max_n + 1), dtype=torch.int64, device=device)
+        self._chunk_base = (torch.arange(self.world, device=device, dtype=torch.int64) * self.name_cap
+                            ).repeat_interleave(self.max_n + 1)
+
+    def gather(self) -> Gathered:
+        """Call after filling send_recs[:n], send_names and send_off[:n + 1]."""
+        dist.all_gather_into_tensor(self.g_recs, self.send_recs, group=self.group)
+        dist.all_gather_into_tensor(self.g_names, self.send_names, group=self.group)
+        dist.all_gather_into_tensor(self.g_off, self.send_off, group=self.group)
+        goff = self.g_off + self._chunk_base
+        idx = goff.view(self.world, self.max_n + 1)[:, :self.max_n].reshape(-1).contiguous()
+        return Gathered(self.g_recs, self.g_names, idx, self.max_n)
+
+
+def allreduce_totals(sum_depth: int, n_bases: int, device: torch.device, group=None) -> Tuple[int, int]:
+    """Genome-wide (sum of depth, bases): the numerator / denominator of the global mean depth
+    (GCI.py:862-868).  Integers, so the result is independent of the reduction order."""
+    t = torch.tensor([int(sum_depth), int(n_bases)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t[0].item()), int(t[1].item())
+
+
+def gather_interval_lists(local: List[Tuple[int, int, int]], group=None) -> List[Tuple[int, int, int]]:
+    """(global contig, start, end) issue intervals of every rank, on every rank, sorted by
+    (contig, start): what rank 0 needs to write the BED / .gci in header order.  <= 10^4 items."""
+    out: List[Optional[list]] = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, list(local), group=group)
+    return sorted(x for part in out for x in part)

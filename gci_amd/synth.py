@@ -95,6 +95,18 @@ class ReadSet:
         return self.take(np.lexsort((self.pos, self.ref_id)))
 
 
+def concat(a: "ReadSet", b: "ReadSet") -> "ReadSet":
+    """Records of `a` followed by records of `b` (same contig table); not re-sorted."""
+    off = np.concatenate([a.cigar_off, a.cigar_off[-1] + b.cigar_off[1:]])
+    w = max(a.names.dtype.itemsize, b.names.dtype.itemsize)
+    return replace(a, ref_id=np.concatenate([a.ref_id, b.ref_id]), pos=np.concatenate([a.pos, b.pos]),
+                   mapq=np.concatenate([a.mapq, b.mapq]), flag=np.concatenate([a.flag, b.flag]),
+                   l_seq=np.concatenate([a.l_seq, b.l_seq]), nm=np.concatenate([a.nm, b.nm]),
+                   nm_last=np.concatenate([a.nm_last, b.nm_last]),
+                   names=np.concatenate([a.names.astype("S%d" % w), b.names.astype("S%d" % w)]),
+                   cigar=np.concatenate([a.cigar, b.cigar]), cigar_off=off)
+
+
 def _within(counts: np.ndarray) -> np.ndarray:
     """[0..c0-1, 0..c1-1, ...] for a vector of counts."""
     counts = np.asarray(counts, dtype=np.int64)

@@ -1,0 +1,153 @@
+"""GPU end-to-end parity: the drop-in CLI against files the UNMODIFIED reference wrote
+(tests/golden/*), the reference's own MH63 example through the HIP kernels, hand-assembled
+records through K1, reference error behaviour, and size-independent properties at full size."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, GOLDEN, cli_args, expected, read_outputs
+from gci_amd import pipeline, synth
+from gci_amd._lib import GciError
+from gci_amd.device import JoinInput, REC_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_reproduces_reference_files(engine, case, tmp_path, capsys):
+    from gci_amd import cli
+    out = str(tmp_path / "out")
+    pipeline._ENGINE = engine
+    cli.main(cli_args(case, out))
+    got, want = read_outputs(out), expected(case)
+    assert sorted(got) == sorted(want)
+    for fn in want:
+        assert got[fn] == want[fn], fn
+    stdout = capsys.readouterr().out
+    assert stdout.rstrip().endswith("GCI finished!!!\nBye!!!")
+    # refuses to overwrite without -f, like the reference
+    with pytest.raises(SystemExit) as e:
+        cli.main(cli_args(case, out))
+    assert "exists" in str(e.value) and "--force" in str(e.value)
+    cli.main(cli_args(case, out) + ["-f"])
+    assert read_outputs(out) == got
+
+
+def test_mh63_example_through_gpu(engine, oracle):
+    """example/MH63.depth.gz -> MH63.0.depth.bed + MH63.gci, byte for byte, with the scan and the
+    text on the GPU (396 Mb, 12 contigs)."""
+    d = os.path.join(GOLDEN, "MH63")
+    text = gzip.open(os.path.join(d, "MH63.depth.gz"), "rb").read()
+    depths = oracle.parse_depth_text(text)
+    targets = list(depths)
+    tl = {t: int(depths[t].shape[0]) for t in targets}
+    offs = engine.set_layout([tl[t] for t in targets])
+    flat = np.zeros(engine.total, dtype=np.int32)
+    for o, t in zip(offs, targets):
+        flat[o:o + tl[t]] = depths[t]
+    tr = pipeline.DepthTracks(engine, tl, engine.to_device(flat))
+    merged = pipeline.collapse_depth_range(tr, -1, 0, 15, 0)
+    bed = "".join(f"{t}\t{s}\t{e}\n" for t, v in merged.items() for s, e in v)
+    assert bed == open(os.path.join(d, "MH63.0.depth.bed")).read()
+    from gci_amd import score
+    assert score.index_text(tl, [merged], ["HiFi"]) == open(os.path.join(d, "MH63.gci")).read()
+    t_dev, toff = engine.depth_text(tr.track)
+    host = t_dev.cpu().numpy()
+    rebuilt = b"".join((">%s\n" % t).encode() + host[int(toff[c]):int(toff[c + 1])].tobytes() for c, t in enumerate(targets))
+    assert rebuilt == text
+    assert tr.mean() == oracle.mean_depth(depths)
+
+
+def test_hand_assembled_records_through_k1(engine):
+    from test_bam_decode import HAND, stream_of
+    s, offs, h = stream_of([r for _, r, _ in HAND])
+    recs = engine.bam_filter(engine.to_device(s), engine.to_device(offs), engine.to_device(np.array([0, 1], np.int32)),
+                             30, 50, 0.1, 0.9).cpu().numpy().reshape(-1).view(REC_DTYPE)
+    for i, (desc, _, want) in enumerate(HAND):
+        if want is None:
+            continue
+        f = int(recs["flags"][i])
+        got = (f & 1, (f >> 1) & 1, int(recs["start"][i]), int(recs["end"][i]), int(recs["qlen"][i]))
+        assert got == want, desc
+
+
+def test_reference_errors_surface_as_the_same_exceptions(engine, tmp_path):
+    from test_bam_decode import op, rec_bytes
+    from gci_amd.formats import bam
+    good = rec_bytes(0, 10, b"ok", 60, 0, [op(100, "M")], 100, b"NMC\x00")
+    for bad, exc in ((rec_bytes(0, 10, b"nonm", 60, 0, [op(100, "M")], 100, b"ASi\x00\x00\x00\x00"), KeyError),
+                     (rec_bytes(0, 10, b"zd", 60, 0, [op(100, "H")], 0, b"NMC\x00"), ZeroDivisionError)):
+        p = str(tmp_path / ("%s.bam" % exc.__name__))
+        bam.write_bam(p, ["chr1"], [100000], [good, bad, good])
+        with pytest.raises(exc):
+            pipeline.filter([], [p], prefix="x", directory=str(tmp_path), engine=engine, write=False)
+    # qlen == 0 on the second file of a join -> ZeroDivisionError at GCI.py:292
+    a = rec_bytes(0, 10, b"q", 60, 0, [op(100, "M")], 100, b"NMC\x00")
+    b = rec_bytes(0, 10, b"q", 60, 0, [op(100, "M")], 0, b"NMC\x00")
+    pa, pb = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    bam.write_bam(pa, ["chr1"], [100000], [a])
+    bam.write_bam(pb, ["chr1"], [100000], [b])
+    with pytest.raises(ZeroDivisionError):
+        pipeline.filter([], [pa, pb], prefix="x", directory=str(tmp_path), engine=engine, write=False)
+
+
+def test_full_size_properties_chr19(engine, oracle):
+    """BASELINE configs[1] size (61.7 Mb, 40x): properties that do not need the oracle to finish the
+    whole thing -- sum of depth == sum of trimmed interval lengths (a checksum of checksums),
+    text round trip, linearity of the depth build, idempotence of the gap mask, max2 with self."""
+    L = 61_707_364
+    rs = synth.simulate_reads((("chr19", L),), 40, "hifi", seed=synth.seed_for(2, 0))
+    stream, offs = synth.to_bam_stream(rs)
+    engine.set_layout([L])
+    d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+    recs = engine.bam_filter(d_bam, d_off, engine.to_device(np.zeros(1, np.int32)), 30, 50, 0.1, 0.9)
+    ivl, cnt = engine.name_join([JoinInput(recs, d_bam, d_off, 36)], 0.9)
+    n = int(cnt.item())
+    track = engine.new_track()
+    engine.depth_build(ivl, cnt, 15, track)
+    tr = pipeline.DepthTracks(engine, {"chr19": L}, track)
+    h = ivl[:n].cpu().numpy().astype(np.int64)
+    a = np.clip(h[:, 1] + 15, 0, L)
+    b = np.clip(h[:, 2] - 15 + 1, 0, L)
+    assert int(tr.sums()[0]) == int(np.maximum(b - a, 0).sum())
+    # oracle on the same records (C, a few seconds at this size)
+    want = oracle.bam_filter_arrays(stream, offs, np.zeros(1, np.int32), 30, 50, 0.1, 0.9)
+    assert n == int(want["passed"].sum())
+    # linearity: depth(A u B) == depth(A) + depth(B)
+    half = n // 2
+    t1, t2 = engine.new_track(), engine.new_track()
+    engine.depth_build(ivl[:half].contiguous(), None, 15, t1)
+    engine.depth_build(ivl[half:n].contiguous(), None, 15, t2)
+    assert torch.equal(t1 + t2, track)
+    # text round trip at full size
+    text, toff = engine.depth_text(track)
+    back = oracle.parse_depth_text(b">chr19\n" + text.cpu().numpy().tobytes())["chr19"]
+    assert np.array_equal(back, tr["chr19"])
+    # issue scan == oracle scan of the same depth
+    assert pipeline.collapse_depth_range(tr, -1, 0, 15, 0)["chr19"] == oracle.collapse_contig(back, -1, 0, 15, 0)
+    # gap mask idempotent, max2(x, x) == x
+    gaps = {"chr19": [(1_000_000, 1_200_000), (L - 10, L + 50)]}
+    pipeline.merge_gaps_depths(tr, gaps)
+    once = tr.track.clone()
+    pipeline.merge_gaps_depths(tr, gaps)
+    assert torch.equal(once, tr.track)
+    assert torch.equal(engine.max2(tr.track, tr.track), tr.track)
+    assert int(tr.track[1_000_000:1_200_000].sum().item()) == 0
+
+
+def test_empty_and_ragged_inputs(engine, oracle, tmp_path):
+    from gci_amd.formats import bam
+    # a BAM with a header and no records; contigs shorter than 2 * flank; a 1-base contig
+    p = str(tmp_path / "empty.bam")
+    bam.write_bam(p, ["c1", "tiny", "one"], [5000, 20, 1], [])
+    depths, tl = pipeline.filter([], [p], prefix="e", directory=str(tmp_path), engine=engine, threads=1)
+    assert tl == {"c1": 5000, "tiny": 20, "one": 1}
+    host = depths.to_host()
+    assert all(int(v.sum()) == 0 for v in host.values())
+    got = pipeline.collapse_depth_range(depths, -1, 0, 15, 0)
+    assert got == oracle.collapse_depth_range(host, -1, 0, 15, 0) == {"c1": [(15, 4985)], "tiny": [], "one": []}
+    assert gzip.open(str(tmp_path / "e.depth.gz"), "rb").read() == oracle.depth_text(host)

@@ -93,16 +93,7 @@ def test_name_join_matches_oracle(engine, oracle, n_files):
     assert len(want) > 100
 
 
-def _concat(a, b):
-    from dataclasses import replace
-    off = np.concatenate([a.cigar_off, a.cigar_off[-1] + b.cigar_off[1:]])
-    w = max(a.names.dtype.itemsize, b.names.dtype.itemsize)
-    return replace(a, ref_id=np.concatenate([a.ref_id, b.ref_id]), pos=np.concatenate([a.pos, b.pos]),
-                   mapq=np.concatenate([a.mapq, b.mapq]), flag=np.concatenate([a.flag, b.flag]),
-                   l_seq=np.concatenate([a.l_seq, b.l_seq]), nm=np.concatenate([a.nm, b.nm]),
-                   nm_last=np.concatenate([a.nm_last, b.nm_last]),
-                   names=np.concatenate([a.names.astype("S%d" % w), b.names.astype("S%d" % w)]),
-                   cigar=np.concatenate([a.cigar, b.cigar]), cigar_off=off)
+_concat = synth.concat
 
 
 def test_depth_build_slice_semantics(engine, oracle):

@@ -1,0 +1,128 @@
+"""Host-side product code (no GPU): interval algebra and score text against the reference's
+known answers, the PAF path against the oracle, FASTA / depth-file formats, the run-closing
+rules, LPT sharding."""
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, expected, inputs, manifest
+from gci_amd import score
+from gci_amd.formats import depthfile, fasta
+
+
+@pytest.fixture(scope="module")
+def kats():
+    return json.load(open(os.path.join(GOLDEN, "kats.json")))
+
+
+def test_interval_algebra_kats(kats):
+    for c in kats["interval_algebra"]:
+        segs = [tuple(x) for x in c["segs"]]
+        assert score.complement_merged_depth({"t": segs}, {"t": c["L"]}, c["fl"], c["start"], c["end"])["t"] == c["complement"]
+        got = score.merge_merged_depth_bed({"t": segs}, {"t": c["L"]}, c["dp"], c["fl"], c["start"], c["end"])["t"]
+        assert [list(x) for x in got] == c["merged"]
+    for c in kats["compute_n50"]:
+        assert score.compute_n50(c["lengths"]) == c["out"]
+    for c in kats["score_repr"]:
+        assert repr(score.gci_score(c["obs_n50"], c["exp_n50"], c["obs_n"], c["exp_n"])) == c["out"]
+
+
+def test_index_text_reproduces_mh63_gci():
+    d = os.path.join(GOLDEN, "MH63")
+    bed = {}
+    for line in open(os.path.join(d, "MH63.0.depth.bed")):
+        t, s, e = line.split("\t")
+        bed.setdefault(t, []).append((int(s), int(e)))
+    want = open(os.path.join(d, "MH63.gci")).read()
+    tl = {}
+    for line in want.splitlines()[2:14]:
+        f = line.split("\t")
+        tl[f[0]] = int(f[1])
+        bed.setdefault(f[0], [])
+    bed = {t: bed[t] for t in tl}
+    assert score.index_text(tl, [bed], ["HiFi"]) == want
+
+
+def test_issue_closing_rules_match_reference_kats(kats):
+    """pipeline._issues_from_runs turns raw maximal runs (what K8 emits) into the reference's
+    intervals: checked here with runs computed by numpy from the KAT depth vectors."""
+    from gci_amd.pipeline import _issues_from_runs, _slice_bound
+    for c in kats["collapse_depth_range"]:
+        d = np.array(c["depth"], dtype=np.int64)
+        L, fl = d.shape[0], c["fl"]
+        a, b = _slice_bound(fl, L), _slice_bound(L - fl, L)
+        b = max(a, b)
+        g = (d[a:b] > c["lo"]) & (d[a:b] <= c["hi"])
+        e = np.diff(np.concatenate(([0], g.astype(np.int8), [0])))
+        runs = np.stack([np.flatnonzero(e == 1), np.flatnonzero(e == -1)], axis=1)
+        assert _issues_from_runs(runs, b - a, L, fl, c["sp"]) == [tuple(x) for x in c["out"]], c
+
+
+def test_paf_filter_matches_oracle(oracle, tmp_path):
+    from gci_amd.pipeline import paf_filter
+    case = "c5_two_type"
+    m = manifest(case)
+    pafs = [p for p in inputs(case, m["hifi"] + m["nano"]) if p.endswith(".paf")]
+    targets = ["mat_chr1", "pat_chr1", "mat_chr2"]
+    for sel in (targets, targets[:2]):
+        for args in ((30, 50, 0.9), (10, 60, 0.99)):
+            got = paf_filter(pafs, sel, *args)          # two files: exercises the un-reset block table
+            want = oracle.paf_filter(pafs, sel, *args)
+            assert got[1] == want[1]
+            assert [list(d.items()) for d in got[0]] == [list(d.items()) for d in want[0]]
+    # a hand-made file: ties between targets broken by name, touching blocks merge, longest block wins
+    p = tmp_path / "t.paf"
+    rows = [("q1", 1000, 0, 400, "+", "tB", 9000, 100, 500, 400, 400, 60), ("q1", 1000, 400, 800, "+", "tB", 9000, 500, 900, 400, 400, 60),
+            ("q1", 1000, 0, 800, "+", "tA", 9000, 2000, 2800, 800, 800, 60), ("q2", 500, 0, 100, "+", "tA", 9000, 10, 110, 95, 100, 5),
+            ("q3", 500, 0, 100, "+", "tZ", 9000, 10, 110, 100, 100, 60), ("q4", 500, 0, 200, "-", "tA", 9000, 50, 250, 199, 200, 49),
+            ("q4", 500, 300, 350, "-", "tA", 9000, 5000, 5050, 50, 50, 49)]
+    p.write_text("".join("\t".join(map(str, r)) + "\n" for r in rows))
+    got = paf_filter([str(p)], ["tA", "tB"], 30, 50, 0.9)
+    want = oracle.paf_filter([str(p)], ["tA", "tB"], 30, 50, 0.9)
+    assert got == want
+    assert got[0][0]["q1"] == ("tB", 100, 900, 1000) and "q2" not in got[0][0] and "q3" not in got[0][0]
+    assert got[0][0]["q4"] == ("tA", 50, 250, 500) and got[1] == {"q1"}
+
+
+def test_fasta_n_runs_match_regex(tmp_path):
+    p = tmp_path / "r.fa"
+    p.write_bytes(b">c1 desc here\nACGTNNNN\nNNacgt\nnNnN\n>c2\nNNNN\n>c3\tx\nACGT\r\nAC GT\n>c4\n\nN\n")
+    ids, runs = fasta.n_runs(str(p))
+    assert ids == ["c1", "c2", "c3", "c4"]
+    seqs = {"c1": "ACGTNNNNNNacgtnNnN", "c2": "NNNN", "c3": "ACGTACGT", "c4": "N"}
+    want = {k: [(m.start(), m.end()) for m in re.finditer(r"(?i)N+", v)] for k, v in seqs.items()}
+    assert runs == {k: v for k, v in want.items() if v}
+    assert fasta.record_ids(str(p)) == ids
+    # the golden case's FASTA: gaps.bed written by the reference
+    case = "c5_two_type"
+    _, r2 = fasta.n_runs(os.path.join(GOLDEN, case, "inputs", "ref.fa"))
+    text = "".join(f"{t}\t{a}\t{b}\n" for t, segs in r2.items() for a, b in segs)
+    assert text.encode() == expected(case)["GCI.gaps.bed"]
+
+
+def test_depth_file_round_trip(tmp_path, oracle):
+    d = {"a": np.array([0, 1, 22, 333, 4444, 0], dtype=np.int64), "b": np.zeros(3, dtype=np.int64)}
+    text = oracle.depth_text(d)
+    path = str(tmp_path / "x.depth.gz")
+    body = {"a": text[3:text.index(b">b")], "b": text[text.index(b">b") + 3:]}
+    depthfile.write_depth_gz(path, [(k, memoryview(v)) for k, v in body.items()], threads=2)
+    assert gzip.open(path, "rb").read() == text == oracle.depth_text_py(d)
+    back = depthfile.read_depth_gz(path)
+    assert list(back) == ["a", "b"] and all(np.array_equal(back[k], d[k]) for k in d)
+    assert depthfile.sha256_of_text(path) == __import__("hashlib").sha256(text).hexdigest()
+
+
+def test_lpt_sharding():
+    from gci_amd import shard, synth
+    lens = [l for _, l in synth.CHM13]
+    owner = shard.lpt_assign(lens, 8)
+    load = [sum(l for l, o in zip(lens, owner) if o == r) for r in range(8)]
+    assert sum(load) == sum(lens) and max(load) <= 1.05 * sum(lens) / 8 + max(lens) * 0.0 + 2e7
+    m, mine = shard.contig_map_for(owner, 3)
+    assert [m[c] for c in mine] == list(range(len(mine))) and (m >= 0).sum() == len(mine)
+    assert shard.record_slices(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)] and shard.record_slices(0, 2) == [(0, 0), (0, 0)]
+    assert shard.lpt_assign([5], 4) == [0]

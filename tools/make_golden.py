@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ by running the UNMODIFIED reference (/root/reference/GCI.py) in this
+container.  Only data is written: synthetic inputs made by gci_amd.synth and the
+files / return values the reference produced from them.  The reference source is never copied;
+this script cannot run on the GPU box (no /root/reference there) and nothing at test time needs it.
+
+    python tools/make_golden.py            # regenerates every case (about a minute)
+
+Two kinds of fixtures:
+  tests/golden/<case>/inputs/*, expected/*      end-to-end runs of GCI() on small synthetic inputs
+  tests/golden/kats.json                        direct calls of single reference functions
+"""
+from __future__ import annotations
+
+import contextlib
+import gzip
+import hashlib
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import load_reference  # noqa: E402
+from gci_amd import synth  # noqa: E402
+from gci_amd.formats import paf as paffmt  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def write_inputs(case_dir, contigs, files, gaps=None, regions=None):
+    """files: {name: ReadSet | list of PAF lines}"""
+    inp = os.path.join(case_dir, "inputs")
+    os.makedirs(inp, exist_ok=True)
+    synth.write_reference_fasta(os.path.join(inp, "ref.fa"), contigs, gaps)
+    for name, obj in files.items():
+        path = os.path.join(inp, name)
+        if name.endswith(".bam"):
+            synth.write_bam_file(path, obj, level=9, threads=4)
+        else:
+            paffmt.write(path, obj)
+    if regions:
+        with open(os.path.join(inp, "regions.bed"), "w") as f:
+            for t, s, e in regions:
+                f.write(f"{t}\t{s}\t{e}\n")
+    return inp
+
+
+def run_reference(case, args, hifi=None, nano=None, regions=False):
+    ref = load_reference.load()
+    case_dir = os.path.join(GOLDEN, case)
+    inp = os.path.join(case_dir, "inputs")
+    exp = os.path.join(case_dir, "expected")
+    shutil.rmtree(exp, ignore_errors=True)
+    os.makedirs(exp)
+    tmp = tempfile.mkdtemp(prefix="gci_golden_")
+    kw = dict(hifi=[os.path.join(inp, f) for f in hifi] if hifi else None,
+              nano=[os.path.join(inp, f) for f in nano] if nano else None,
+              directory=tmp, prefix="GCI", reference=os.path.join(inp, "ref.fa"),
+              regions=os.path.join(inp, "regions.bed") if regions else None, threads=1, force=True)
+    kw.update(args)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        ref.GCI(**kw)
+    manifest = {"args": {k: v for k, v in args.items()}, "hifi": hifi, "nano": nano, "regions": bool(regions),
+                "files": {}}
+    for fn in sorted(os.listdir(tmp)):
+        src = os.path.join(tmp, fn)
+        if not os.path.isfile(src):
+            continue
+        if fn.endswith(".depth.gz"):
+            text = gzip.open(src, "rb").read()
+            manifest["files"][fn] = {"sha256_decompressed": hashlib.sha256(text).hexdigest(), "bytes": len(text)}
+            with gzip.GzipFile(os.path.join(exp, fn), "wb", 9, mtime=0) as g:      # reproducible container
+                g.write(text)
+        else:
+            shutil.copy(src, os.path.join(exp, fn))
+            manifest["files"][fn] = {"sha256": hashlib.sha256(open(src, "rb").read()).hexdigest()}
+    with open(os.path.join(case_dir, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+    print(case, "->", ", ".join(manifest["files"]))
+
+
+def case_single_bam():
+    contigs = (("ctg1", 300_000),)
+    rs = synth.simulate_reads(contigs, 20, "hifi", seed=synth.seed_for(1, 0))
+    write_inputs(os.path.join(GOLDEN, "c1_single_bam"), contigs, {"hifi.mm2.bam": rs})
+    run_reference("c1_single_bam", {}, hifi=["hifi.mm2.bam"])
+
+
+def case_two_bam():
+    contigs = (("chrA", 220_000), ("chrB", 90_000), ("chrC", 9_000))
+    a = synth.simulate_reads(contigs, 22, "hifi", seed=synth.seed_for(3, 0))
+    b = synth.perturb(a, synth.seed_for(3, 1))
+    write_inputs(os.path.join(GOLDEN, "c3_two_bam"), contigs, {"hifi.mm2.bam": a, "hifi.wm2.bam": b})
+    run_reference("c3_two_bam", {}, hifi=["hifi.mm2.bam", "hifi.wm2.bam"])
+
+
+def case_three_bam_chrs():
+    contigs = (("chrA", 150_000), ("chrB", 120_000), ("chrC", 60_000))
+    a = synth.simulate_reads(contigs, 18, "hifi", seed=synth.seed_for(3, 10))
+    b = synth.perturb(a, synth.seed_for(3, 11))
+    c = synth.perturb(a, synth.seed_for(3, 12))
+    write_inputs(os.path.join(GOLDEN, "c3_three_bam_chrs"), contigs, {"a.bam": a, "b.bam": b, "c.bam": c})
+    run_reference("c3_three_bam_chrs", {"chrs": "chrA,chrC", "map_qual": 20, "mq_cutoff": 45, "ovlp_percent": 0.95,
+                                        "threshold": 1}, hifi=["a.bam", "b.bam", "c.bam"])
+
+
+def case_paf_bam():
+    contigs = (("chrA", 200_000), ("chrB", 80_000))
+    a = synth.simulate_reads(contigs, 20, "hifi", seed=synth.seed_for(4, 0))
+    b = synth.perturb(a, synth.seed_for(4, 1))
+    write_inputs(os.path.join(GOLDEN, "c4_paf_bam"), contigs,
+                 {"hifi.wm2.bam": a, "hifi.mm2.paf": synth.to_paf_lines(b, synth.seed_for(4, 2), split_frac=0.1)})
+    run_reference("c4_paf_bam", {}, hifi=["hifi.mm2.paf", "hifi.wm2.bam"])
+
+
+def case_two_type():
+    contigs = (("mat_chr1", 180_000), ("pat_chr1", 160_000), ("mat_chr2", 70_000))
+    gaps = {"mat_chr1": [(40_000, 40_500), (100_000, 100_001)], "pat_chr1": [(0, 120)], "mat_chr2": [(69_900, 70_000)]}
+    h = synth.simulate_reads(contigs, 25, "hifi", seed=synth.seed_for(5, 0))
+    h2 = synth.perturb(h, synth.seed_for(5, 1))
+    n = synth.simulate_reads(contigs, 30, "ont", seed=synth.seed_for(5, 2), long_cigar_frac=0.0)
+    n2 = synth.perturb(n, synth.seed_for(5, 3))
+    regions = [("mat_chr1", 1000, 60_000), ("mat_chr1", 39_000, 41_000), ("pat_chr1", 0, 160_000),
+               ("mat_chr2", 50_000, 70_000), ("pat_chr1", 100, 300)]
+    write_inputs(os.path.join(GOLDEN, "c5_two_type"), contigs,
+                 {"hifi.wm2.bam": h, "hifi.mm2.paf": synth.to_paf_lines(h2, synth.seed_for(5, 4), 0.05),
+                  "ont.wm2.bam": n, "ont.mm2.bam": n2,
+                  "ont.mm2.paf": synth.to_paf_lines(n2, synth.seed_for(5, 5), 0.05)},
+                 gaps=gaps, regions=regions)
+    run_reference("c5_two_type", {"threshold": 2, "dist_percent": 0.001, "flank_len": 10},
+                  hifi=["hifi.wm2.bam", "hifi.mm2.paf"], nano=["ont.mm2.paf", "ont.wm2.bam", "ont.mm2.bam"],
+                  regions=True)
+
+
+def case_nano_only_long_cigar():
+    contigs = (("tig", 400_000),)
+    n = synth.simulate_reads(contigs, 12, "ont", seed=synth.seed_for(4, 7), long_cigar_frac=0.05)
+    write_inputs(os.path.join(GOLDEN, "c4_nano_long_cigar"), contigs, {"ont.bam": n})
+    run_reference("c4_nano_long_cigar", {"flank_len": 0}, nano=["ont.bam"])
+
+
+# ----------------------------------------------------------------------------------------------
+# known-answer tests from single reference functions
+# ----------------------------------------------------------------------------------------------
+
+def make_kats():
+    ref = load_reference.load()
+    rng = np.random.default_rng(20250919)
+    kats = {}
+
+    # R10 collapse_depth_range
+    cases = []
+    fixed = [([0] * 10, -1, 0, 2, 0), ([0, 0, 0, 0, 5, 5, 5, 5, 0, 0], -1, 0, 2, 0),
+             ([0, 0, 0, 0, 0, 5, 5, 5, 0, 0], -1, 0, 2, 0), ([0, 0, 5, 5, 5, 5, 5, 0, 0, 0], -1, 0, 2, 0),
+             ([0, 3, 0, 0, 3, 0], -1, 0, 0, 100), ([0], -1, 0, 0, 0), ([], -1, 0, 0, 0), ([0, 0, 0], -1, 0, 1, 7),
+             ([1, 2, 3, 2, 1, 0, 1, 2, 3], 0, 2, 0, 0), ([0] * 5, -1, 0, 3, 0), ([2, 0, 0, 2] * 8, -1, 1.5, 1, 0)]
+    for d, lo, hi, fl, sp in fixed:
+        cases.append(dict(depth=d, lo=lo, hi=hi, fl=fl, sp=sp))
+    for _ in range(60):
+        L = int(rng.integers(1, 120))
+        d = (rng.random(L) < rng.uniform(0.2, 0.9)).astype(int) * rng.integers(1, 5, L)
+        cases.append(dict(depth=d.tolist(), lo=-1, hi=int(rng.integers(0, 3)), fl=int(rng.integers(0, 12)),
+                          sp=int(rng.integers(0, 50))))
+    for c in cases:
+        c["out"] = ref.collapse_depth_range({"t": np.array(c["depth"], dtype=int)}, c["lo"], c["hi"], c["fl"], c["sp"])["t"]
+    kats["collapse_depth_range"] = cases
+
+    # R11 / R12 interval algebra
+    alg = []
+    for _ in range(80):
+        L = int(rng.integers(40, 3000))
+        fl = int(rng.integers(0, 16))
+        n = int(rng.integers(0, 7))
+        pts = np.sort(rng.choice(np.arange(fl, max(fl + 2 * n + 2, L - fl)), size=2 * n, replace=False)) if n else []
+        segs = [(int(pts[2 * i]), int(pts[2 * i + 1])) for i in range(n)]
+        dp = float(rng.choice([0.0, 0.001, 0.005, 0.02, 0.1]))
+        explicit = bool(rng.random() < 0.3)
+        s, e = (int(rng.integers(0, L // 2)), int(rng.integers(L // 2, L))) if explicit else (None, None)
+        alg.append(dict(L=L, fl=fl, segs=segs, dp=dp, start=s, end=e,
+                        complement=ref.complement_merged_depth({"t": segs}, {"t": L}, fl, s, e)["t"],
+                        merged=[list(x) for x in ref.merge_merged_depth_bed({"t": segs}, {"t": L}, dp, fl, s, e)["t"]]))
+    alg.append(dict(L=1000, fl=15, segs=[(15, 40), (100, 120), (130, 140), (900, 985)], dp=0.02, start=None, end=None,
+                    complement=ref.complement_merged_depth({"t": [(15, 40), (100, 120), (130, 140), (900, 985)]},
+                                                           {"t": 1000}, 15)["t"],
+                    merged=[list(x) for x in ref.merge_merged_depth_bed(
+                        {"t": [(15, 40), (100, 120), (130, 140), (900, 985)]}, {"t": 1000}, 0.02, 15)["t"]]))
+    kats["interval_algebra"] = alg
+    n50 = []
+    for _ in range(40):
+        v = rng.integers(0, 1000, int(rng.integers(0, 12))).tolist()
+        n50.append(dict(lengths=v, out=int(ref.compute_n50(v))))
+    n50 += [dict(lengths=x, out=int(ref.compute_n50(x))) for x in ([5, 4, 3, 2, 1], [], [3, 3, 2], [0, 0], [-10])]
+    kats["compute_n50"] = n50
+
+    # R6 numpy slice semantics (incl. the negative-stop wrap)
+    sl = []
+    for s, e, fl, L in [(0, 10, 15, 50), (0, 13, 15, 50), (0, 14, 15, 50), (0, 16, 15, 50), (20, 48, 15, 50),
+                        (30, 80, 15, 50), (0, 50, 0, 50), (49, 50, 0, 50), (5, 200, 3, 50), (0, 29, 15, 50)]:
+        d = np.zeros(L, dtype=int)
+        d[s + fl:e - fl + 1] += 1
+        sl.append(dict(s=s, e=e, fl=fl, L=L, out=d.tolist()))
+    kats["slice_add"] = sl
+
+    # R3 merge_alns_properties + scoring pieces
+    mp = []
+    for _ in range(60):
+        n = int(rng.integers(1, 6))
+        alns = []
+        for _ in range(n):
+            qs = int(rng.integers(0, 900)); qe = qs + int(rng.integers(1, 400))
+            ts = int(rng.integers(0, 9000)); te = ts + int(rng.integers(1, 400))
+            alns.append((1500, qs, qe, ts, te, float(rng.uniform(0.9, 1.0))))
+        mp.append(dict(alns=[list(a) for a in alns], q=list(ref.merge_alns_properties(alns, 1, 2)),
+                       t=list(ref.merge_alns_properties(alns, 3, 4)), avg=ref.get_average_identity(alns)))
+    kats["merge_alns_properties"] = mp
+
+    # R5 join fold on hand-made dicts (incl. resurrection with three files and qlen of the current file)
+    joins = []
+    def J(files, hq, op=0.9):
+        import copy
+        f = copy.deepcopy(files)
+        # the join is inlined in filter(); restate its inputs as the per-file dicts and let the reference's
+        # own code run by feeding filter()'s local logic through a tiny driver
+        return None
+    kats["_note_join"] = "R5 is inlined in filter(); it is pinned end-to-end by the c3_* / c4_* / c5_* cases"
+
+    # R13 score formatting
+    sc = []
+    for on50, en50, on, en in [(266013, 45027022, 65, 1), (259735, 31921180, 850, 12), (100, 100, 1, 1), (0, 100, 3, 1),
+                               (50, 100, 0, 1), (31921180, 31921180, 12, 12), (1, 3, 2, 1)]:
+        from math import log2
+        sc.append(dict(obs_n50=on50, exp_n50=en50, obs_n=on, exp_n=en,
+                       out=repr(0 if on == 0 else round(100 * log2(on50 / en50 + 1) / log2(on / en + 1), 4))))
+    kats["score_repr"] = sc
+
+    with open(os.path.join(GOLDEN, "kats.json"), "w") as f:
+        json.dump(kats, f, indent=0, sort_keys=True, default=lambda o: o.tolist() if hasattr(o, "tolist") else list(o))
+    print("kats.json written")
+
+
+def copy_reference_example():
+    """The reference's own data triple (example/MH63.*) -- data files, not source."""
+    dst = os.path.join(GOLDEN, "MH63")
+    os.makedirs(dst, exist_ok=True)
+    for fn in ("MH63.depth.gz", "MH63.0.depth.bed", "MH63.gci"):
+        shutil.copy(os.path.join("/root/reference/example", fn), os.path.join(dst, fn))
+        os.chmod(os.path.join(dst, fn), 0o644)
+    print("MH63 triple copied")
+
+
+if __name__ == "__main__":
+    if not load_reference.available():
+        sys.exit("needs /root/reference (build container only)")
+    os.makedirs(GOLDEN, exist_ok=True)
+    only = set(sys.argv[1:])
+    todo = [("c1", case_single_bam), ("c3a", case_two_bam), ("c3b", case_three_bam_chrs), ("c4a", case_paf_bam),
+            ("c4b", case_nano_only_long_cigar), ("c5", case_two_type), ("kats", make_kats),
+            ("mh63", copy_reference_example)]
+    for name, fn in todo:
+        if not only or name in only:
+            fn()
