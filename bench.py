@@ -5,7 +5,8 @@ A "step" is one pass of the hot path over one batch of synthetic alignments whos
 bytes are already resident in HBM:
 
     K1 record filter -> [N>1: RCCL all-gather of compact records + names] -> K3 name join
-    -> K4/K5 depth build -> K8 issue scan -> K10 depth text (size + write) -> per-contig sums
+    -> K4/K5 depth build with, fused into the same two passes over the per-tile event buckets, the
+       per-contig sums, the issue-scan run boundaries and the decimal depth text (K8 / K10 / R15)
     -> [N>1: RCCL all-reduce of the int64 totals]
 
 Workload at N=1: BASELINE.json configs[1] -- CHM13 chr19 (61,707,364 bp), one 40x HiFi BAM.
@@ -90,6 +91,13 @@ class Workload:
         self.status = torch.zeros(2, dtype=torch.int64, device=dev)
         self.text = None
         self.rec_base = 0
+        from gci_amd._lib import BuildOpts
+        o = BuildOpts()
+        o.flank, o.want_text = 15, 1
+        o.d_contig_text_off, o.d_sums = self.text_off.data_ptr(), self.sums.data_ptr()
+        o.d_n_keys, o.d_keys, o.key_cap = self.nkeys.data_ptr(), self.keys.data_ptr(), int(self.keys.shape[0])
+        o.issue_flank, o.lo, o.hi = 15, -1.0, 0.0
+        self.opts = o
         if world > 1:
             self._setup_exchange()
 
@@ -131,17 +139,16 @@ class Workload:
             jf[0].d_name_base, jf[0].d_name_off = g.names.data_ptr(), g.name_index.data_ptr()
         chk(lib.gci_name_join(ctx, jf, 1, 0.9, self._p(self.contig_map), self._p(self.ivl), int(self.ivl.shape[0]),
                               self._p(self.count), self._p(self.status[1:2])), "gci_name_join")
-        chk(lib.gci_depth_build(ctx, self._p(self.ivl), self._p(self.count), int(self.ivl.shape[0]), 15,
-                                self._p(self.track)), "gci_depth_build")
-        chk(lib.gci_issue_scan(ctx, self._p(self.track), -1.0, 0.0, 15, self._p(self.keys), int(self.keys.shape[0]),
-                               self._p(self.nkeys)), "gci_issue_scan")
-        chk(lib.gci_depth_text_size(ctx, self._p(self.track), self._p(self.text_off)), "gci_depth_text_size")
+        # fused build: depth + per-contig sums + text byte offsets + issue-run boundaries from one pass over
+        # the per-tile event buckets (no HBM re-read of the track), then depth + decimal text in the second
+        o = self.opts
+        chk(lib.gci_depth_build_begin(ctx, self._p(self.ivl), self._p(self.count), int(self.ivl.shape[0]),
+                                      ctypes.byref(o)), "gci_depth_build_begin")
         if self.text is None:                              # first (warm-up) call sizes the text buffer
             total = int(self.text_off[1].item())
             self.text = self.torch.empty(total + (total >> 4) + 4096, dtype=self.torch.uint8, device=eng.device)
-        chk(lib.gci_depth_text_write(ctx, self._p(self.track), self._p(self.text), int(self.text.shape[0])),
-            "gci_depth_text_write")
-        chk(lib.gci_depth_sum(ctx, self._p(self.track), self._p(self.sums)), "gci_depth_sum")
+        chk(lib.gci_depth_build_finish(ctx, self._p(self.track), self._p(self.text), int(self.text.shape[0])),
+            "gci_depth_build_finish")
         if self.world > 1:
             import torch.distributed as dist
             self.totals[0] = self.sums[0]
@@ -235,9 +242,11 @@ def main():
     else:
         aligned_total = w.aligned_bases
 
-    scan_ms, scan_n = prof.get("k_depth_scan", (0.0, 0))
+    scan_ms, scan_n = prof.get("k_tile_build<2>", (0.0, 0))
     scan_avg_ms = scan_ms / max(1, scan_n)
-    algo_bytes = 8.0 * args.contig_len                     # K5: 4 B read + 4 B write per base
+    # k_tile_build<2> writes the int32 track (4 B/base) and the decimal text; it reads only the event buckets
+    text_bytes = int(w.text_off[1].item())
+    algo_bytes = 4.0 * args.contig_len + text_bytes       # DESIGN.md "algorithmic bytes"
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
 
     breakdown = None
@@ -265,7 +274,7 @@ def main():
                                "issue scan -> depth text" % (args.contig_len, world, args.coverage),
                    "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
                    "inflated_bam_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_depth_scan", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_tile_build<2> (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
         "kernel_us_per_launch": breakdown,
@@ -281,6 +290,10 @@ def main():
         tr = pipeline.DepthTracks(eng, dict(w.contigs), w.track)
         ok = np.array_equal(tr["chr19"], depths["chr19"])
         ok = ok and pipeline.collapse_depth_range(tr, -1, 0, 15, 0) == bed
+        nk = int(w.nkeys.item())                              # the fused issue keys of the last timed step
+        runs = eng._keys_to_runs(w.keys[:nk].cpu().numpy().view(np.uint64), 1)
+        ok = ok and pipeline._issues_from_runs(runs[0], args.contig_len - 30, args.contig_len, 15, 0) == bed["chr19"]
+        ok = ok and int(w.sums[0].item()) == int(depths["chr19"].sum())
         n_text = int(w.text_off[1].item())
         ok = ok and (b">chr19\n" + w.text[:n_text].cpu().numpy().tobytes()) == text
         ok = ok and tr.mean() == mean

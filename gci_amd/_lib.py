@@ -18,8 +18,9 @@ GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, G
 GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
 REC_PASS, REC_HQ = 1, 2
-PROF_COUNT = 13
-PROF_DEPTH_SCAN = 5
+PROF_COUNT = 14
+PROF_DEPTH_SCAN = 5          # k_tile_build<2>: the pass that writes the depth track (+ text)
+PROF_TILE_PASS1 = 13
 
 
 class GciError(RuntimeError):
@@ -35,6 +36,12 @@ class JoinFile(ctypes.Structure):
 
 class Window(ctypes.Structure):
     _fields_ = [("begin", c_int64), ("end", c_int64)]
+
+
+class BuildOpts(ctypes.Structure):
+    _fields_ = [("flank", c_int), ("want_text", c_int), ("d_contig_text_off", c_void_p), ("d_sums", c_void_p),
+                ("d_n_keys", c_void_p), ("d_keys", c_void_p), ("key_cap", c_uint32), ("issue_flank", c_int),
+                ("lo", c_double), ("hi", c_double)]
 
 
 # every symbol include/gci_hip.h declares: (name, restype, argtypes)
@@ -64,6 +71,8 @@ EXPORTS = [
     ("gci_name_join", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
                               c_void_p]),
     ("gci_depth_build", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_int, c_void_p]),
+    ("gci_depth_build_begin", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, POINTER(BuildOpts)]),
+    ("gci_depth_build_finish", c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     ("gci_gap_mask", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("gci_max2", c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     ("gci_issue_scan", c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_uint32, c_void_p]),

@@ -97,14 +97,17 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         print("Finding gaps done!!! Awesome! No gaps were found!\n\n")
 
     common = (map_qual, mq_cutoff, iden_percent, clip_percent, ovlp_percent, flank_len, directory, force)
+    hint = (-1, threshold, flank_len)          # the merge_depth() scan that follows every filter()
     if nano == None:  # noqa: E711
-        depths, targets_length = pipeline.filter(hifi_paf, hifi_bam, prefix, *common, "HiFi", chrs_list, threads)
+        depths, targets_length = pipeline.filter(hifi_paf, hifi_bam, prefix, *common, "HiFi", chrs_list, threads,
+                                                 issue_hint=hint)
         depths = pipeline.merge_gaps_depths(depths, Ns_bed)
         bed = pipeline.merge_depth(depths, prefix, threshold, flank_len, directory, force, "HiFi")
         pipeline.compute_index(targets_length, prefix, directory, force, [bed], ["HiFi"], flank_len, dist_percent,
                                regions_bed, [depths], threshold, chrs_list)
     elif hifi == None:  # noqa: E711
-        depths, targets_length = pipeline.filter(nano_paf, nano_bam, prefix, *common, "ONT", chrs_list, threads)
+        depths, targets_length = pipeline.filter(nano_paf, nano_bam, prefix, *common, "ONT", chrs_list, threads,
+                                                 issue_hint=hint)
         depths = pipeline.merge_gaps_depths(depths, Ns_bed)
         bed = pipeline.merge_depth(depths, prefix, threshold, flank_len, directory, force, "ONT")
         pipeline.compute_index(targets_length, prefix, directory, force, [bed], ["Nano"], flank_len, dist_percent,
@@ -119,10 +122,10 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
                          f'that in ont alignment files which is "{target}:{nano_refs_lengths[target]}"\n'
                          'Please check the reference used in mapping both hifi and ont reads')
         hifi_depths, targets_length = pipeline.filter(hifi_paf, hifi_bam, prefix + "_hifi", *common, "HiFi", chrs_list,
-                                                      threads)
+                                                      threads, issue_hint=hint)
         hifi_depths = pipeline.merge_gaps_depths(hifi_depths, Ns_bed)
         nano_depths, targets_length = pipeline.filter(nano_paf, nano_bam, prefix + "_nano", *common, "ONT", chrs_list,
-                                                      threads)
+                                                      threads, issue_hint=hint)
         nano_depths = pipeline.merge_gaps_depths(nano_depths, Ns_bed)
         two = pipeline.merge_two_type_depth(hifi_depths, nano_depths, prefix + "_two_type", directory, force, threads)
         two = pipeline.merge_gaps_depths(two, Ns_bed)

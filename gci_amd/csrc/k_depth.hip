@@ -1,0 +1,379 @@
+// k_depth.hip -- K4 / K5: per-base depth from the surviving intervals
+// (/root/reference/GCI.py:302-306: depths[target][start+fl : end-fl+1] += 1).
+//
+// Difference array + prefix sum, with the difference array kept OUT of HBM:
+//
+//   k_evt_count    per interval: Python-slice-normalised [a, b); counts one +1 event in tile(a), one -1
+//                  event in tile(b), and adds +1 / -1 to a coarse per-tile table (one int per 4096 bases).
+//   k_scan2_*      exclusive scans of both per-tile tables: bucket offsets and every tile's carry-in.
+//   k_evt_scatter  writes each event (12-bit position in its tile + sign) into its tile's bucket.
+//   k_tile_build   one workgroup per tile: zero a 16 KiB difference array in LDS, LDS-atomicAdd the tile's
+//                  events (about 2 * coverage * 4096 / read length of them: ~20 at 40x HiFi), wave/workgroup
+//                  prefix sum seeded with the carry-in, and
+//                    pass 1 (by-products, no HBM write of depth): per-tile sum, decimal-text byte count,
+//                            optionally the issue-scan run boundaries;
+//                    pass 2: the depth track (16-byte coalesced stores) and, optionally, its decimal text.
+//
+// HBM traffic of the depth build is therefore its OUTPUT only: 4 B/base (+ text bytes), instead of
+// memset 4 + scan read 4 + write 4 (+ 4 to count text + 4 to render it + 4 to scan issues + 4 to sum).
+// Recomputing a tile in pass 2 costs LDS atomics and shuffles, not bandwidth.  Tiles are independent
+// (the carry-in comes from the coarse table), so there is no look-back chain across the 8 XCDs, whose
+// L2s are not coherent with each other.
+//
+// The -1 of an interval that reaches the contig end is kept in the coarse table (last tile) so every
+// contig sums to zero and ONE unsegmented scan over all tiles serves all contigs; its event is dropped
+// (or lands in the tail padding, which keeps the padding at zero).
+#include "gci_ctx.hpp"
+
+// ---- per interval ---------------------------------------------------------------------------------
+
+struct IvlSpan { int64_t tile_a, tile_b; uint32_t pos_a, pos_b; bool valid, has_b; int64_t tile_bc; };
+
+__device__ __forceinline__ IvlSpan span_of(const gci_ivl v, int flank, const int64_t* __restrict__ len,
+                                           const int64_t* __restrict__ tile_first, int32_t n_contigs)
+{
+    IvlSpan s;
+    s.valid = false; s.has_b = false; s.tile_a = s.tile_b = s.tile_bc = 0; s.pos_a = s.pos_b = 0;
+    if (v.contig < 0 || v.contig >= n_contigs) return s;
+    const int64_t L = len[v.contig];
+    const int64_t a = gci_slice_bound((int64_t)v.start + flank, L);
+    const int64_t b = gci_slice_bound((int64_t)v.end - flank + 1, L);
+    if (a >= b) return s;
+    const int64_t t0 = tile_first[v.contig];
+    s.valid = true;
+    s.tile_a = t0 + a / TILE; s.pos_a = (uint32_t)(a % TILE);
+    s.has_b = b < (L + TILE - 1) / TILE * TILE;          // b == L lands in tail padding when there is any
+    s.tile_b = t0 + b / TILE; s.pos_b = (uint32_t)(b % TILE);
+    s.tile_bc = t0 + (b < L ? b : L - 1) / TILE;         // coarse -1: last tile of the contig when b == L
+    return s;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_evt_count(const gci_ivl* __restrict__ ivl, const uint32_t* __restrict__ d_n,
+                                                     uint32_t max_n, int flank, const int64_t* __restrict__ len,
+                                                     const int64_t* __restrict__ tile_first, int32_t n_contigs,
+                                                     uint32_t* __restrict__ evt_cnt, int32_t* __restrict__ tile_diff)
+{
+    const uint32_t n = d_n ? min(*d_n, max_n) : max_n;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const IvlSpan s = span_of(ivl[i], flank, len, tile_first, n_contigs);
+    if (!s.valid) return;
+    atomicAdd(evt_cnt + s.tile_a, 1u);
+    atomicAdd(tile_diff + s.tile_a, 1);
+    if (s.has_b) atomicAdd(evt_cnt + s.tile_b, 1u);
+    atomicAdd(tile_diff + s.tile_bc, -1);
+}
+
+// evt_cnt is decremented back to zero while handing out bucket slots: no memset next time
+__global__ __launch_bounds__(BLOCK) void k_evt_scatter(const gci_ivl* __restrict__ ivl, const uint32_t* __restrict__ d_n,
+                                                       uint32_t max_n, int flank, const int64_t* __restrict__ len,
+                                                       const int64_t* __restrict__ tile_first, int32_t n_contigs,
+                                                       uint32_t* __restrict__ evt_cnt, const uint32_t* __restrict__ evt_off,
+                                                       uint16_t* __restrict__ events)
+{
+    const uint32_t n = d_n ? min(*d_n, max_n) : max_n;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const IvlSpan s = span_of(ivl[i], flank, len, tile_first, n_contigs);
+    if (!s.valid) return;
+    events[evt_off[s.tile_a] + atomicSub(evt_cnt + s.tile_a, 1u) - 1u] = (uint16_t)(s.pos_a << 1);
+    if (s.has_b) events[evt_off[s.tile_b] + atomicSub(evt_cnt + s.tile_b, 1u) - 1u] = (uint16_t)((s.pos_b << 1) | 1u);
+}
+
+// zero the coarse table and the small outputs of a build in one launch
+__global__ __launch_bounds__(BLOCK) void k_build_prep(int32_t* __restrict__ tile_diff, int64_t n_tiles,
+                                                      uint32_t* __restrict__ n_keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_tiles) tile_diff[i] = 0;
+    if (i == 0 && n_keys) *n_keys = 0;
+}
+
+// both per-tile scans in one launch: blockIdx.y == 0 coarse difference -> carry, == 1 counts -> offsets
+__global__ __launch_bounds__(BLOCK) void k_scan2_local(const int32_t* __restrict__ diff, int32_t* __restrict__ carry,
+                                                       int32_t* __restrict__ blk_a, const uint32_t* __restrict__ cnt,
+                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ blk_b, int64_t n)
+{
+    if (blockIdx.y == 0) scan_local_body<int32_t, int32_t>(diff, carry, blk_a, n, blockIdx.x);
+    else scan_local_body<uint32_t, uint32_t>(cnt, off, blk_b, n, blockIdx.x);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan2_add(int32_t* __restrict__ carry, const int32_t* __restrict__ blk_a,
+                                                     uint32_t* __restrict__ off, const uint32_t* __restrict__ blk_b,
+                                                     int64_t n, int32_t n_blocks)
+{
+    if (blockIdx.y == 0) { if ((int32_t)blockIdx.x < n_blocks) scan_add_body<int32_t>(carry, blk_a, n, n_blocks, blockIdx.x); }
+    else scan_add_body<uint32_t>(off, blk_b, n, n_blocks, blockIdx.x);     // block n_blocks writes off[n] = total
+}
+
+// ---- per tile -------------------------------------------------------------------------------------
+
+struct IssueArgs {
+    unsigned long long* keys;      // nullptr: no fused issue scan
+    uint32_t* n_keys;
+    uint32_t cap;
+    int flank;
+    double lo, hi;
+};
+
+// PASS 1: by-products only.  PASS 2: depth (+ text).
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void k_tile_build(
+    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
+    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
+    // pass 1 outputs
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss,
+    // pass 2 outputs
+    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap)
+{
+    __shared__ __attribute__((aligned(16))) int32_t lds[TILE];          // difference array, then depth (pass 1)
+    __shared__ int32_t wtot[4][BLOCK / 64];
+    __shared__ uint32_t twtot[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t tile = blockIdx.x;
+    int4* l4 = reinterpret_cast<int4*>(lds);
+#pragma unroll
+    for (int j = 0; j < 4; j++) l4[j * BLOCK + t] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
+    for (uint32_t e = e0 + t; e < e1; e += BLOCK) {
+        const uint32_t ev = events[e];
+        atomicAdd(&lds[ev >> 1], (ev & 1u) ? -1 : 1);
+    }
+    __syncthreads();
+    int4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = l4[j * BLOCK + t];
+    int32_t tot[4], inc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j].y += v[j].x; v[j].z += v[j].y; v[j].w += v[j].z;
+        tot[j] = v[j].w;
+        inc[j] = tot[j];
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { int32_t n = __shfl_up(inc[j], d, 64); if (lane >= d) inc[j] += n; }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) wtot[j][wave] = inc[j];
+    }
+    __syncthreads();                       // also: every thread has read its slice of the LDS difference array
+    const int32_t carry_in = tile_carry[tile];
+    int32_t carry = carry_in;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int32_t pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { const int32_t x = wtot[j][w]; if (w < wave) pre += x; all += x; }
+        const int32_t ex = carry + pre + inc[j] - tot[j];
+        v[j].x += ex; v[j].y += ex; v[j].z += ex; v[j].w += ex;
+        carry += all;
+    }
+    // v[j] now holds depth of elements (j * 256 + t) * 4 .. + 3 of this tile
+    const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
+    const int64_t elem0 = (tile - tile_first[c]) * TILE;          // index of the tile's first element in its contig
+    const int64_t L = len[c];
+    const int64_t valid = L - elem0;                              // elements of this tile inside the contig
+
+    if (PASS == 1) {
+        long long s = 0;
+        uint32_t bytes = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t i = (int64_t)(j * BLOCK + t) * 4;
+            const int32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i + k < valid) { s += d[k]; bytes += ndigits((uint32_t)d[k]) + 1; }
+        }
+        s = wave_sum<long long>(s);
+        bytes = wave_sum<uint32_t>(bytes);
+        __shared__ long long ssum[BLOCK / 64];
+        if (lane == 0) { ssum[wave] = s; twtot[wave] = bytes; }
+        if (iss.keys) {
+            // depth of the whole tile to LDS so each thread can see its predecessor element
+#pragma unroll
+            for (int j = 0; j < 4; j++) l4[j * BLOCK + t] = v[j];
+        }
+        __syncthreads();
+        if (t == 0) {
+            tile_sum[tile] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+            tile_bytes[tile] = twtot[0] + twtot[1] + twtot[2] + twtot[3];
+        }
+        if (iss.keys) {
+            // window of this contig: depth_list[flank : L - flank] with Python slice normalisation (GCI.py:374)
+            const int64_t wa = gci_slice_bound(iss.flank, L);
+            int64_t wb = gci_slice_bound(L - iss.flank, L);
+            if (wb < wa) wb = wa;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t i = (int64_t)(j * BLOCK + t) * 4;
+                const int64_t e = elem0 + i;                       // contig coordinate of this thread's first element
+                if (e + 3 < wa || e >= wb) continue;
+                const int32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                const int32_t dprev = i > 0 ? lds[i - 1] : carry_in;
+                bool gp = (e - 1 >= wa) && (e - 1 < wb) && (iss.lo < (double)dprev) && ((double)dprev <= iss.hi);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int64_t p = e + k;
+                    const bool g = (p >= wa) && (p < wb) && (iss.lo < (double)d[k]) && ((double)d[k] <= iss.hi);
+                    if (g != gp && p >= wa && p <= wb) {           // run boundary at p (start if g, else end)
+                        if (g || p < wb) {
+                            const uint32_t slot = atomicAdd(iss.n_keys, 1u);
+                            if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, p - wa, !g);
+                        }
+                    }
+                    if (g && p == wb - 1) {                         // run reaches the end of the window
+                        const uint32_t slot = atomicAdd(iss.n_keys, 1u);
+                        if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, wb - wa, true);
+                    }
+                    gp = g;
+                }
+            }
+        }
+    } else {
+        int4* g4 = reinterpret_cast<int4*>(depth + (size_t)tile * TILE);
+#pragma unroll
+        for (int j = 0; j < 4; j++) g4[j * BLOCK + t] = v[j];
+        if (text) {
+            uint8_t* stage = reinterpret_cast<uint8_t*>(lds);        // 11 KiB of the 16 KiB, free after the sync above
+            uint64_t dst = tile_text_off[tile];
+            for (int j = 0; j < 4; j++) {
+                const uint32_t u[4] = {(uint32_t)v[j].x, (uint32_t)v[j].y, (uint32_t)v[j].z, (uint32_t)v[j].w};
+                dst += text_round(u, (int64_t)(j * BLOCK + t) * 4, valid, stage, twtot, text, dst, text_cap, t, lane, wave);
+            }
+        }
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------------
+
+static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_depth, uint8_t* d_text, uint64_t text_cap)
+{
+    const dim3 grid((uint32_t)ctx->n_tiles), block(BLOCK);
+    const uint16_t* ev = (const uint16_t*)ctx->events.p;
+    const uint32_t* eo = (const uint32_t*)ctx->evt_off.p;
+    const int32_t* tc = (const int32_t*)ctx->tile_carry.p;
+    const int64_t* tf = (const int64_t*)ctx->d_tile_first.p;
+    const int64_t* ln = (const int64_t*)ctx->d_len.p;
+    if (pass == 1) {
+        ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
+        hipLaunchKernelGGL(k_tile_build<1>, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs,
+                           (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, (int32_t*)nullptr,
+                           (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
+    } else {
+        ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
+        IssueArgs none;
+        memset(&none, 0, sizeof none);
+        hipLaunchKernelGGL(k_tile_build<2>, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs,
+                           (long long*)nullptr, (uint32_t*)nullptr, none, d_depth, (const uint64_t*)ctx->tile_u64.p, d_text,
+                           text_cap);
+    }
+    LAUNCHCHK("k_tile_build");
+    return GCI_OK;
+}
+
+extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n,
+                                     const gci_build_opts* o)
+{
+    if (!ctx || !o || (max_n && !d_ivl)) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (o->want_text && !o->d_contig_text_off) return GCI_E_INVALID;
+    if (o->d_n_keys && o->key_cap && !o->d_keys) return GCI_E_INVALID;
+    ctx->build_pending = false;
+    const int64_t nt = ctx->n_tiles;
+    if (nt == 0) {
+        if (o->d_contig_text_off) HIPCHK(hipMemsetAsync(o->d_contig_text_off, 0, (size_t)(ctx->n_contigs + 1) * 8, ctx->stream));
+        if (o->d_sums) HIPCHK(hipMemsetAsync(o->d_sums, 0, (size_t)ctx->n_contigs * 8, ctx->stream));
+        if (o->d_n_keys) HIPCHK(hipMemsetAsync(o->d_n_keys, 0, 4, ctx->stream));
+        ctx->build_pending = true; ctx->build_text = false;
+        return GCI_OK;
+    }
+    GCI_TRY(gci_ensure(ctx, ctx->events, (size_t)max_n * 2 * sizeof(uint16_t) + 16));
+    const int64_t* ln = (const int64_t*)ctx->d_len.p;
+    const int64_t* tf = (const int64_t*)ctx->d_tile_first.p;
+    int32_t* diff = (int32_t*)ctx->tile_diff.p;
+    uint32_t* cnt = (uint32_t*)ctx->evt_cnt.p;
+    uint32_t* off = (uint32_t*)ctx->evt_off.p;
+    const int32_t nb = (int32_t)((nt + TILE - 1) / TILE);
+    {
+        ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
+        hipLaunchKernelGGL(k_build_prep, dim3((uint32_t)((nt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, diff, nt,
+                           o->d_n_keys);
+        LAUNCHCHK("k_build_prep");
+        if (max_n) {
+            hipLaunchKernelGGL(k_evt_count, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
+                               o->flank, ln, tf, ctx->n_contigs, cnt, diff);
+            LAUNCHCHK("k_evt_count");
+        }
+    }
+    {
+        ProfScope _ps(ctx, GCI_PROF_SCAN_TILES);
+        hipLaunchKernelGGL(k_scan2_local, dim3(nb, 2), dim3(BLOCK), 0, ctx->stream, diff, (int32_t*)ctx->tile_carry.p,
+                           (int32_t*)ctx->blk_a.p, cnt, off, (uint32_t*)ctx->blk_b.p, nt);
+        LAUNCHCHK("k_scan2_local");
+        hipLaunchKernelGGL(k_scan2_add, dim3(nb + 1, 2), dim3(BLOCK), 0, ctx->stream, (int32_t*)ctx->tile_carry.p,
+                           (const int32_t*)ctx->blk_a.p, off, (const uint32_t*)ctx->blk_b.p, nt, nb);
+        LAUNCHCHK("k_scan2_add");
+    }
+    if (max_n) {
+        ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
+        hipLaunchKernelGGL(k_evt_scatter, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
+                           o->flank, ln, tf, ctx->n_contigs, cnt, (const uint32_t*)off, (uint16_t*)ctx->events.p);
+        LAUNCHCHK("k_evt_scatter");
+    }
+    const bool by_products = o->want_text || o->d_sums || o->d_n_keys;
+    if (by_products) {
+        IssueArgs iss;
+        memset(&iss, 0, sizeof iss);
+        if (o->d_n_keys) {
+            iss.keys = (unsigned long long*)o->d_keys; iss.n_keys = o->d_n_keys; iss.cap = o->key_cap;
+            iss.flank = o->issue_flank; iss.lo = o->lo; iss.hi = o->hi;
+            if (!iss.keys) { static unsigned long long dummy; iss.keys = &dummy; iss.cap = 0; }   // count only
+        }
+        GCI_TRY(launch_tile_build(ctx, 1, iss, nullptr, nullptr, 0));
+        if (o->d_sums) {
+            ProfScope _ps(ctx, GCI_PROF_DEPTH_SUM);
+            hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs), dim3(BLOCK), 0, ctx->stream,
+                               (const long long*)ctx->tile_sum.p, tf, (long long*)o->d_sums);
+            LAUNCHCHK("k_reduce_tiles");
+        }
+        if (o->want_text) {
+            ProfScope _ps(ctx, GCI_PROF_TEXT_COUNT);
+            GCI_TRY((device_exclusive_scan<uint32_t, unsigned long long>(ctx, (const uint32_t*)ctx->tile_u32.p,
+                                                                         (unsigned long long*)ctx->tile_u64.p,
+                                                                         (unsigned long long*)ctx->blk_u64.p, nt, true)));
+            hipLaunchKernelGGL(k_contig_text_off, dim3((ctx->n_contigs + 1 + 63) / 64), dim3(64), 0, ctx->stream,
+                               (const uint64_t*)ctx->tile_u64.p, tf, ctx->n_contigs, nt, o->d_contig_text_off);
+            LAUNCHCHK("k_contig_text_off");
+        }
+    }
+    ctx->build_pending = true;
+    ctx->build_text = o->want_text != 0;
+    return GCI_OK;
+}
+
+extern "C" int gci_depth_build_finish(gci_ctx* ctx, int32_t* d_depth, uint8_t* d_text, uint64_t text_cap)
+{
+    if (!ctx || !d_depth) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (!ctx->build_pending) return GCI_E_INVALID;          // gci_depth_build_begin() first
+    if (d_text && !ctx->build_text) return GCI_E_INVALID;   // begin() was not asked for text offsets
+    if (ctx->n_tiles == 0) return GCI_OK;
+    IssueArgs none;
+    memset(&none, 0, sizeof none);
+    return launch_tile_build(ctx, 2, none, d_depth, d_text, text_cap);
+}
+
+extern "C" int gci_depth_build(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, int flank,
+                               int32_t* d_depth)
+{
+    if (!d_depth) return GCI_E_INVALID;
+    gci_build_opts o;
+    memset(&o, 0, sizeof o);
+    o.flank = flank;
+    GCI_TRY(gci_depth_build_begin(ctx, d_ivl, d_n, max_n, &o));
+    return gci_depth_build_finish(ctx, d_depth, nullptr, 0);
+}

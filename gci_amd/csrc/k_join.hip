@@ -1,0 +1,241 @@
+// k_join.hip -- K3: cross-file join by read name (/root/reference/GCI.py:272-301) and the dict
+// "last record wins" semantics (GCI.py:166, 269); names blob for the multi-GPU exchange.
+#include "gci_ctx.hpp"
+//
+// Open-addressing table keyed by the 64-bit name hash, one slot per DISTINCT name.  A slot holds
+// the id (file << 32 | index) of the record that claimed it; keys are compared through the
+// immutable record arrays, and a hash match is confirmed on the full name bytes, so a 64-bit
+// collision can never merge two reads.  Per (slot, file) an atomicMax keeps the record that the
+// reference's dict would keep: the last one in (contig order, file order).  The fold over files
+// is then independent per name: one thread per slot.
+
+struct JoinFiles {
+    gci_join_file f[GCI_MAX_JOIN_FILES];
+    int n;
+};
+
+#define SLOT_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ const uint8_t* name_ptr(const gci_join_file& f, const gci_rec& r)
+{
+    return f.d_name_base + f.d_name_off[r.rec_idx] + f.name_delta;
+}
+
+__device__ __forceinline__ bool same_name(const JoinFiles& F, int fa, const gci_rec& a, unsigned long long owner)
+{
+    const int fb = (int)(owner >> 32);
+    const gci_rec& b = F.f[fb].d_recs[(uint32_t)owner];
+    if (a.name_hash != b.name_hash || a.name_len != b.name_len) return false;
+    const uint8_t* pa = name_ptr(F.f[fa], a);
+    const uint8_t* pb = name_ptr(F.f[fb], b);
+    for (uint32_t i = 0; i < a.name_len; i++) if (pa[i] != pb[i]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_join_insert(JoinFiles F, int file, unsigned long long* __restrict__ table,
+                                                       uint64_t mask, unsigned long long* __restrict__ last,
+                                                       uint32_t* __restrict__ hq)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= F.f[file].n_recs) return;
+    const gci_rec r = F.f[file].d_recs[i];
+    if (!(r.flags & GCI_REC_PASS)) return;
+    const unsigned long long me = ((unsigned long long)file << 32) | i;
+    uint64_t slot = r.name_hash & mask;
+    for (;;) {
+        unsigned long long cur = table[slot];
+        if (cur == SLOT_EMPTY) {
+            cur = atomicCAS(table + slot, SLOT_EMPTY, me);
+            if (cur == SLOT_EMPTY) break;               // claimed
+        }
+        if (same_name(F, file, r, cur)) break;
+        slot = (slot + 1) & mask;
+    }
+    // order of dict insertion in the reference: contig by contig (header order), file order inside
+    const unsigned long long ord = (((unsigned long long)(uint32_t)r.contig << 32) | i) + 1ull;
+    atomicMax(last + slot * F.n + file, ord);
+    if (r.flags & GCI_REC_HQ) atomicOr(hq + slot, 1u);
+}
+
+// Fold of one name over the files (GCI.py:279-299); returns true when an interval survives.
+__device__ __forceinline__ bool fold_slot(const JoinFiles& F, uint64_t slot, const unsigned long long* __restrict__ last,
+                                          bool high, double ovlp_percent, const int32_t* __restrict__ contig_map,
+                                          unsigned long long* __restrict__ status, gci_ivl& o)
+{
+    bool comm = true;
+    for (int f = 0; f < F.n; f++) comm = comm && last[slot * F.n + f] != 0;
+    // file1 = entries of files[0] whose name is in high_qual | comm   (GCI.py:279-280)
+    bool have = false;
+    int32_t contig = -1, s = 0, e = 0;
+    {
+        const unsigned long long v = last[slot * F.n];
+        if (v && (F.n == 1 || high || comm)) {
+            const gci_rec& r = F.f[0].d_recs[(uint32_t)(v - 1)];
+            have = true; contig = r.contig; s = r.start; e = r.end;
+        }
+    }
+    for (int f = 1; f < F.n; f++) {                                          // GCI.py:281-299
+        const unsigned long long v = last[slot * F.n + f];
+        if (!v) continue;
+        const gci_rec& r = F.f[f].d_recs[(uint32_t)(v - 1)];
+        if (have) {
+            if (r.contig == contig) {
+                const int32_t ms = max(r.start, s), me = min(r.end, e);
+                const int64_t ovlp = (int64_t)me - (int64_t)ms;
+                if (r.qlen == 0) {                                           // ZeroDivisionError at GCI.py:292
+                    atomicMin(status, ((unsigned long long)r.rec_idx << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                    return false;
+                }
+                if ((double)ovlp / (double)r.qlen < ovlp_percent) have = false;
+                else { s = ms; e = me; }
+            } else have = false;
+        } else if (high) {
+            have = true; contig = r.contig; s = r.start; e = r.end;
+        }
+    }
+    if (!have) return false;
+    if (contig_map) { contig = contig_map[contig]; if (contig < 0) return false; }
+    o.contig = contig; o.start = s; o.end = e; o.pad = 0;
+    return true;
+}
+
+// One thread per slot, FOLD_PER_THREAD consecutive slots each; survivors are appended with ONE
+// returning atomic per workgroup (a same-address atomic costs ~12 ns on this chip, so per-wave
+// appends would serialise for ~100 us at 10^5 intervals).
+#define FOLD_PER_THREAD 4
+__global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned long long* __restrict__ table,
+                                                     uint64_t n_slots, const unsigned long long* __restrict__ last,
+                                                     const uint32_t* __restrict__ hq, double ovlp_percent,
+                                                     const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out,
+                                                     uint32_t cap, uint32_t* __restrict__ n_out,
+                                                     unsigned long long* __restrict__ status)
+{
+    __shared__ uint32_t wtot[BLOCK / 64];
+    __shared__ uint32_t s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t slot0 = ((uint64_t)blockIdx.x * BLOCK + t) * FOLD_PER_THREAD;
+    gci_ivl keep[FOLD_PER_THREAD];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < FOLD_PER_THREAD; k++) {
+        const uint64_t slot = slot0 + k;
+        if (slot < n_slots && table[slot] != SLOT_EMPTY) {
+            gci_ivl o;
+            if (fold_slot(F, slot, last, hq[slot] != 0, ovlp_percent, contig_map, status, o)) keep[mine++] = o;
+        }
+    }
+    const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t pre = inc - mine, all = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
+    if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
+    __syncthreads();
+    const uint32_t base = s_base + pre;
+    for (uint32_t k = 0; k < mine; k++) if (base + k < cap) out[base + k] = keep[k];
+}
+
+// table <- EMPTY, last <- 0, hq <- 0, *n_out <- 0, *status <- ~0 in one launch
+__global__ __launch_bounds__(BLOCK) void k_join_clear(unsigned long long* __restrict__ table,
+                                                      unsigned long long* __restrict__ last, uint32_t* __restrict__ hq,
+                                                      uint64_t n_slots, int n_files, uint32_t* __restrict__ n_out,
+                                                      unsigned long long* __restrict__ status)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    const uint64_t i0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    for (uint64_t i = i0; i < n_slots; i += stride) { table[i] = SLOT_EMPTY; hq[i] = 0; }
+    for (uint64_t i = i0; i < n_slots * n_files; i += stride) last[i] = 0;
+    if (i0 == 0) { *n_out = 0; *status = SLOT_EMPTY; }
+}
+
+extern "C" int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
+                             const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                             uint64_t* d_status)
+{
+    if (!ctx || !h_files || n_files < 1 || n_files > GCI_MAX_JOIN_FILES || !d_n_out || !d_status || (cap && !d_out))
+        return GCI_E_INVALID;
+    JoinFiles F;
+    memset(&F, 0, sizeof F);
+    F.n = n_files;
+    uint64_t total = 0;
+    for (int f = 0; f < n_files; f++) { F.f[f] = h_files[f]; total += h_files[f].n_recs; }
+    uint64_t slots = 1024;
+    while (slots < 2 * total) slots <<= 1;
+    GCI_TRY(gci_ensure(ctx, ctx->join_table, slots * 8));
+    GCI_TRY(gci_ensure(ctx, ctx->join_last, slots * 8 * n_files));
+    GCI_TRY(gci_ensure(ctx, ctx->join_hq, slots * 4));
+    {
+        ProfScope _ps(ctx, GCI_PROF_MEMSET);
+        const uint64_t want = (slots + BLOCK * 4 - 1) / (BLOCK * 4);
+        hipLaunchKernelGGL(k_join_clear, dim3((uint32_t)(want > 4096 ? 4096 : want)), dim3(BLOCK), 0, ctx->stream,
+                           (unsigned long long*)ctx->join_table.p, (unsigned long long*)ctx->join_last.p,
+                           (uint32_t*)ctx->join_hq.p, slots, n_files, d_n_out, (unsigned long long*)d_status);
+        LAUNCHCHK("k_join_clear");
+    }
+    for (int f = 0; f < n_files; f++) {
+        if (!F.f[f].n_recs) continue;
+        ProfScope _ps(ctx, GCI_PROF_JOIN_INSERT);
+        hipLaunchKernelGGL(k_join_insert, dim3((F.f[f].n_recs + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, F, f,
+                           (unsigned long long*)ctx->join_table.p, slots - 1, (unsigned long long*)ctx->join_last.p,
+                           (uint32_t*)ctx->join_hq.p);
+        LAUNCHCHK("k_join_insert");
+    }
+    {
+        ProfScope _ps(ctx, GCI_PROF_JOIN_FOLD);
+        const uint64_t per_block = (uint64_t)BLOCK * FOLD_PER_THREAD;
+        hipLaunchKernelGGL(k_join_fold, dim3((uint32_t)((slots + per_block - 1) / per_block)), dim3(BLOCK), 0, ctx->stream,
+                           F, (const unsigned long long*)ctx->join_table.p, slots,
+                           (const unsigned long long*)ctx->join_last.p, (const uint32_t*)ctx->join_hq.p, ovlp_percent,
+                           d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status);
+        LAUNCHCHK("k_join_fold");
+    }
+    return GCI_OK;
+}
+
+// ---- names blob for the multi-GPU exchange ------------------------------------------------------
+
+__global__ __launch_bounds__(BLOCK) void k_name_len(const gci_rec* __restrict__ recs, uint32_t n, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = recs[i].name_len;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pack_names(gci_join_file f, const unsigned long long* __restrict__ off,
+                                                      uint8_t* __restrict__ out, uint64_t cap)
+{
+    // 16 lanes per record copy its name bytes
+    const uint32_t i = (blockIdx.x * BLOCK + threadIdx.x) / 16, gl = threadIdx.x % 16;
+    if (i >= f.n_recs) return;
+    const gci_rec r = f.d_recs[i];
+    const uint64_t o = off[i];
+    if (o + r.name_len > cap) return;
+    const uint8_t* src = f.d_name_base + f.d_name_off[r.rec_idx] + f.name_delta;
+    for (uint32_t b = gl; b < r.name_len; b += 16) out[o + b] = src[b];
+}
+
+extern "C" int gci_pack_names(gci_ctx* ctx, const gci_join_file* h_file, uint8_t* d_out_names, uint64_t cap,
+                              uint64_t* d_out_off)
+{
+    if (!ctx || !h_file || !d_out_off || (cap && !d_out_names)) return GCI_E_INVALID;
+    const uint32_t n = h_file->n_recs;
+    int r;
+    GCI_TRY(gci_ensure(ctx, ctx->tile_u32, (size_t)(n + 1) * 4));
+    GCI_TRY(gci_ensure(ctx, ctx->blk_u64, (size_t)(n / TILE + 2) * 8));
+    if (n) {
+        hipLaunchKernelGGL(k_name_len, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, h_file->d_recs, n,
+                           (uint32_t*)ctx->tile_u32.p);
+        LAUNCHCHK("k_name_len");
+    }
+    r = device_exclusive_scan<uint32_t, unsigned long long>(ctx, (const uint32_t*)ctx->tile_u32.p,
+                                                            (unsigned long long*)d_out_off,
+                                                            (unsigned long long*)ctx->blk_u64.p, n, true);
+    if (r) return r;
+    if (n) {
+        hipLaunchKernelGGL(k_pack_names, dim3((uint32_t)(((uint64_t)n * 16 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                           ctx->stream, *h_file, (const unsigned long long*)d_out_off, d_out_names, cap);
+        LAUNCHCHK("k_pack_names");
+    }
+    return GCI_OK;
+}
+

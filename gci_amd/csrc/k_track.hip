@@ -1,0 +1,305 @@
+// k_track.hip -- kernels over an existing depth track: K6 gap mask, K7 two-type max, per-contig sums,
+// K8 issue scan, K10 decimal text.  These serve the seams that run on a track AFTER it was built
+// (masked, merged or uploaded tracks); a fresh build gets the same results fused into
+// k_tile_build (k_depth.hip) without re-reading the track.
+#include "gci_ctx.hpp"
+
+// ============================================================================================
+// K6: gap mask (GCI.py:324-328), K7: two-type max (GCI.py:350)
+// ============================================================================================
+
+__global__ __launch_bounds__(BLOCK) void k_gap_mask(int32_t* __restrict__ depth, const gci_ivl* __restrict__ gaps,
+                                                    const int64_t* __restrict__ len, const int64_t* __restrict__ off,
+                                                    int32_t n_contigs)
+{
+    const gci_ivl g = gaps[blockIdx.y];
+    if (g.contig < 0 || g.contig >= n_contigs) return;
+    const int64_t L = len[g.contig];
+    const int64_t a = gci_slice_bound(g.start, L), b = gci_slice_bound(g.end, L);
+    int32_t* d = depth + off[g.contig];
+    for (int64_t p = a + (int64_t)blockIdx.x * BLOCK + threadIdx.x; p < b; p += (int64_t)gridDim.x * BLOCK) d[p] = 0;
+}
+
+extern "C" int gci_gap_mask(gci_ctx* ctx, int32_t* d_depth, const gci_ivl* d_gaps, uint32_t n_gaps)
+{
+    if (!ctx || !d_depth || (n_gaps && !d_gaps)) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    ProfScope _ps(ctx, GCI_PROF_GAP_MASK);
+    for (uint32_t done = 0; done < n_gaps; done += 65535) {
+        const uint32_t n = n_gaps - done < 65535 ? n_gaps - done : 65535;
+        hipLaunchKernelGGL(k_gap_mask, dim3(32, n), dim3(BLOCK), 0, ctx->stream, d_depth, d_gaps + done,
+                           (const int64_t*)ctx->d_len.p, (const int64_t*)ctx->d_off.p, ctx->n_contigs);
+        LAUNCHCHK("k_gap_mask");
+    }
+    return GCI_OK;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_max2(const int4* __restrict__ a, const int4* __restrict__ b,
+                                                int4* __restrict__ o, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * BLOCK) {
+        const int4 x = a[i], y = b[i];
+        int4 r;
+        r.x = max(x.x, y.x); r.y = max(x.y, y.y); r.z = max(x.z, y.z); r.w = max(x.w, y.w);
+        o[i] = r;
+    }
+}
+
+extern "C" int gci_max2(gci_ctx* ctx, const int32_t* a, const int32_t* b, int32_t* o)
+{
+    if (!ctx || !a || !b || !o) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    const int64_t n4 = ctx->total / 4;
+    if (n4 == 0) return GCI_OK;
+    const int64_t want = (n4 + BLOCK * 4 - 1) / (BLOCK * 4);
+    const uint32_t grid = (uint32_t)(want < 1 ? 1 : want > 16384 ? 16384 : want);
+    ProfScope _ps(ctx, GCI_PROF_MAX2);
+    hipLaunchKernelGGL(k_max2, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const int4*)a, (const int4*)b, (int4*)o, n4);
+    LAUNCHCHK("k_max2");
+    return GCI_OK;
+}
+
+// ============================================================================================
+// R15: per-contig sums -- per-tile partials, then one workgroup per contig (no same-address atomics:
+// one returning atomic per tile on a single word costs ~12 ns each and serialises)
+// ============================================================================================
+
+__global__ __launch_bounds__(BLOCK) void k_tile_sum(const int32_t* __restrict__ depth, long long* __restrict__ tile_sum)
+{
+    __shared__ long long part[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int4* base = reinterpret_cast<const int4*>(depth + (size_t)blockIdx.x * TILE);
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int4 v = base[j * BLOCK + t]; s += (long long)v.x + v.y + v.z + v.w; }
+    s = wave_sum<long long>(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (t == 0) tile_sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+extern "C" int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums)
+{
+    if (!ctx || !d_depth || !d_sums) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (ctx->n_tiles == 0) { HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)ctx->n_contigs * 8, ctx->stream)); return GCI_OK; }
+    ProfScope _ps(ctx, GCI_PROF_DEPTH_SUM);
+    hipLaunchKernelGGL(k_tile_sum, dim3((uint32_t)ctx->n_tiles), dim3(BLOCK), 0, ctx->stream, d_depth,
+                       (long long*)ctx->tile_sum.p);
+    LAUNCHCHK("k_tile_sum");
+    hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs), dim3(BLOCK), 0, ctx->stream,
+                       (const long long*)ctx->tile_sum.p, (const int64_t*)ctx->d_tile_first.p, (long long*)d_sums);
+    LAUNCHCHK("k_reduce_tiles");
+    return GCI_OK;
+}
+
+// ============================================================================================
+// K8: issue scan (collapse_depth_range, GCI.py:369-390) as run-boundary detection
+// ============================================================================================
+//
+// g[p] = (lo < depth[p] <= hi) and p inside the window.  A boundary sits at p when g[p] != g[p-1]:
+// a run START if g[p], else the (exclusive) END of the run before it; a run that reaches the window
+// end is closed at the window end by the thread holding its last element.  Only the predecessor is
+// needed, so each thread reads one extra element.  Low-depth runs are rare (CHM13: 11, MH63: 2328):
+// boundaries are appended with one atomic each and the kernel is a pure 4 B/base read stream.
+
+__global__ __launch_bounds__(BLOCK) void k_issue_scan(const int32_t* __restrict__ depth,
+                                                      const gci_window* __restrict__ win,
+                                                      const int64_t* __restrict__ win_tile_first, int32_t n_win,
+                                                      double lo, double hi, unsigned long long* __restrict__ keys,
+                                                      uint32_t cap, uint32_t* __restrict__ n_keys)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    const int32_t w = contig_of_tile(win_tile_first, n_win, blockIdx.x);
+    const gci_window W = win[w];
+    const int64_t p0 = (W.begin / TILE + ((int64_t)blockIdx.x - win_tile_first[w])) * TILE;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int64_t p = p0 + (int64_t)(j * BLOCK + t) * 4;
+        const int4 v = *reinterpret_cast<const int4*>(depth + p);
+        const int32_t d[4] = {v.x, v.y, v.z, v.w};
+        bool g[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double x = (double)d[k];
+            g[k] = (p + k >= W.begin) && (p + k < W.end) && (lo < x) && (x <= hi);
+        }
+        int gp = __shfl_up((int)g[3], 1, 64);
+        if (lane == 0) {
+            gp = 0;
+            if (p - 1 >= W.begin && p - 1 < W.end) { const double x = (double)depth[p - 1]; gp = (lo < x) && (x <= hi); }
+        }
+        if (!(g[0] | g[1] | g[2] | g[3] | (bool)gp)) continue;
+        bool prev = (bool)gp;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t q = p + k;
+            if (g[k] != prev && q >= W.begin && (g[k] || q < W.end)) {
+                const uint32_t s = atomicAdd(n_keys, 1u);
+                if (s < cap) keys[s] = issue_key((uint32_t)w, q - W.begin, !g[k]);
+            }
+            if (g[k] && q == W.end - 1) {
+                const uint32_t s = atomicAdd(n_keys, 1u);
+                if (s < cap) keys[s] = issue_key((uint32_t)w, W.end - W.begin, true);
+            }
+            prev = g[k];
+        }
+    }
+}
+
+static int issue_scan_launch(gci_ctx* ctx, const int32_t* d_depth, uint32_t n_win, int64_t n_tiles, double lo, double hi,
+                             uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys)
+{
+    HIPCHK(hipMemsetAsync(d_n_keys, 0, 4, ctx->stream));
+    if (n_tiles == 0) return GCI_OK;
+    ProfScope _ps(ctx, GCI_PROF_ISSUE_SCAN);
+    hipLaunchKernelGGL(k_issue_scan, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, d_depth,
+                       (const gci_window*)ctx->win.p, (const int64_t*)ctx->win_tile_first.p, (int32_t)n_win, lo, hi,
+                       (unsigned long long*)d_keys, cap, d_n_keys);
+    LAUNCHCHK("k_issue_scan");
+    return GCI_OK;
+}
+
+static int set_windows(gci_ctx* ctx, const gci_window* h_win, uint32_t n_win)
+{
+    std::vector<gci_window> ws;
+    std::vector<int64_t> first;
+    ws.reserve(n_win + 1);
+    first.reserve(n_win + 2);
+    int64_t tiles = 0;
+    for (uint32_t i = 0; i < n_win; i++) {
+        gci_window w = h_win[i];
+        if (w.begin < 0) w.begin = 0;
+        if (w.end > ctx->total) w.end = ctx->total;
+        if (w.end < w.begin) w.end = w.begin;
+        first.push_back(tiles);
+        if (w.end > w.begin) tiles += (w.end + TILE - 1) / TILE - w.begin / TILE;
+        ws.push_back(w);
+    }
+    first.push_back(tiles);
+    GCI_TRY(gci_ensure(ctx, ctx->win, (size_t)(n_win + 1) * sizeof(gci_window)));
+    GCI_TRY(gci_ensure(ctx, ctx->win_tile_first, (size_t)(n_win + 2) * 8));
+    if (n_win) GCI_TRY(gci_upload_small(ctx, ctx->win.p, ws.data(), n_win * sizeof(gci_window)));
+    GCI_TRY(gci_upload_small(ctx, ctx->win_tile_first.p, first.data(), first.size() * 8));
+    ctx->win_n = n_win;
+    ctx->win_tiles = tiles;
+    return GCI_OK;
+}
+
+extern "C" int gci_issue_scan_windows(gci_ctx* ctx, const int32_t* d_depth, const gci_window* h_windows,
+                                      uint32_t n_windows, double lo, double hi, uint64_t* d_keys, uint32_t cap,
+                                      uint32_t* d_n_keys)
+{
+    if (!ctx || !d_depth || !d_n_keys || (cap && !d_keys) || (n_windows && !h_windows)) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (n_windows >= (1u << 31)) return GCI_E_INVALID;
+    GCI_TRY(set_windows(ctx, h_windows, n_windows));
+    ctx->win_flank = INT32_MIN;
+    return issue_scan_launch(ctx, d_depth, n_windows, ctx->win_tiles, lo, hi, d_keys, cap, d_n_keys);
+}
+
+extern "C" int gci_issue_scan(gci_ctx* ctx, const int32_t* d_depth, double lo, double hi, int flank, uint64_t* d_keys,
+                              uint32_t cap, uint32_t* d_n_keys)
+{
+    if (!ctx || !d_depth || !d_n_keys || (cap && !d_keys)) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (ctx->win_flank != flank) {
+        // depth_list[flank_len : chr_len - flank_len] with Python slice normalisation (GCI.py:374)
+        std::vector<gci_window> ws(ctx->n_contigs);
+        for (int32_t c = 0; c < ctx->n_contigs; c++) {
+            const int64_t L = ctx->len[c];
+            int64_t a = gci_slice_bound(flank, L), b = gci_slice_bound(L - flank, L);
+            if (b < a) b = a;
+            ws[c].begin = ctx->off[c] + a;
+            ws[c].end = ctx->off[c] + b;
+        }
+        GCI_TRY(set_windows(ctx, ws.data(), (uint32_t)ctx->n_contigs));
+        ctx->win_flank = flank;
+    }
+    return issue_scan_launch(ctx, d_depth, ctx->win_n, ctx->win_tiles, lo, hi, d_keys, cap, d_n_keys);
+}
+
+// ============================================================================================
+// K10: depth -> decimal text (write_depth body, GCI.py:115-117) for an existing track
+// ============================================================================================
+
+// bytes of text per tile: sum over the contig's valid elements of (digits + 1)
+__global__ __launch_bounds__(BLOCK) void k_text_count(const int32_t* __restrict__ depth,
+                                                      const int64_t* __restrict__ tile_first,
+                                                      const int64_t* __restrict__ len, int32_t n_contigs,
+                                                      uint32_t* __restrict__ tile_bytes)
+{
+    __shared__ uint32_t part[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int32_t c = contig_of_tile(tile_first, n_contigs, blockIdx.x);
+    const int64_t valid = len[c] - ((int64_t)blockIdx.x - tile_first[c]) * TILE;
+    const int4* base = reinterpret_cast<const int4*>(depth + (size_t)blockIdx.x * TILE);
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int64_t i = (int64_t)(j * BLOCK + t) * 4;
+        const int4 v = base[j * BLOCK + t];
+        if (i + 0 < valid) s += ndigits((uint32_t)v.x) + 1;
+        if (i + 1 < valid) s += ndigits((uint32_t)v.y) + 1;
+        if (i + 2 < valid) s += ndigits((uint32_t)v.z) + 1;
+        if (i + 3 < valid) s += ndigits((uint32_t)v.w) + 1;
+    }
+    s = wave_sum<uint32_t>(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (t == 0) tile_bytes[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_text_write(const int32_t* __restrict__ depth,
+                                                      const int64_t* __restrict__ tile_first,
+                                                      const int64_t* __restrict__ len, int32_t n_contigs,
+                                                      const uint64_t* __restrict__ tile_off, uint8_t* __restrict__ out,
+                                                      uint64_t cap)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[TEXT_STAGE];
+    __shared__ uint32_t wtot[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int32_t c = contig_of_tile(tile_first, n_contigs, blockIdx.x);
+    const int64_t valid = len[c] - ((int64_t)blockIdx.x - tile_first[c]) * TILE;
+    const int4* base = reinterpret_cast<const int4*>(depth + (size_t)blockIdx.x * TILE);
+    uint64_t dst = tile_off[blockIdx.x];
+    for (int j = 0; j < 4; j++) {
+        const int4 q = base[j * BLOCK + t];
+        const uint32_t v[4] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w};
+        dst += text_round(v, (int64_t)(j * BLOCK + t) * 4, valid, stage, wtot, out, dst, cap, t, lane, wave);
+    }
+}
+
+extern "C" int gci_depth_text_size(gci_ctx* ctx, const int32_t* d_depth, uint64_t* d_contig_off)
+{
+    if (!ctx || !d_depth || !d_contig_off) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    const int64_t nt = ctx->n_tiles;
+    if (nt == 0) { HIPCHK(hipMemsetAsync(d_contig_off, 0, (size_t)(ctx->n_contigs + 1) * 8, ctx->stream)); return GCI_OK; }
+    ProfScope _ps(ctx, GCI_PROF_TEXT_COUNT);
+    hipLaunchKernelGGL(k_text_count, dim3((uint32_t)nt), dim3(BLOCK), 0, ctx->stream, d_depth,
+                       (const int64_t*)ctx->d_tile_first.p, (const int64_t*)ctx->d_len.p, ctx->n_contigs,
+                       (uint32_t*)ctx->tile_u32.p);
+    LAUNCHCHK("k_text_count");
+    GCI_TRY((device_exclusive_scan<uint32_t, unsigned long long>(ctx, (const uint32_t*)ctx->tile_u32.p,
+                                                                 (unsigned long long*)ctx->tile_u64.p,
+                                                                 (unsigned long long*)ctx->blk_u64.p, nt, true)));
+    hipLaunchKernelGGL(k_contig_text_off, dim3((ctx->n_contigs + 1 + 63) / 64), dim3(64), 0, ctx->stream,
+                       (const uint64_t*)ctx->tile_u64.p, (const int64_t*)ctx->d_tile_first.p, ctx->n_contigs, nt,
+                       d_contig_off);
+    LAUNCHCHK("k_contig_text_off");
+    return GCI_OK;
+}
+
+extern "C" int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_t* d_out, uint64_t cap)
+{
+    if (!ctx || !d_depth || !d_out) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (ctx->n_tiles == 0) return GCI_OK;
+    ProfScope _ps(ctx, GCI_PROF_TEXT_WRITE);
+    hipLaunchKernelGGL(k_text_write, dim3((uint32_t)ctx->n_tiles), dim3(BLOCK), 0, ctx->stream, d_depth,
+                       (const int64_t*)ctx->d_tile_first.p, (const int64_t*)ctx->d_len.p, ctx->n_contigs,
+                       (const uint64_t*)ctx->tile_u64.p, d_out, cap);
+    LAUNCHCHK("k_text_write");
+    return GCI_OK;
+}

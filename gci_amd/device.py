@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GciError, JoinFile, Window
+from ._lib import BuildOpts, GciError, JoinFile, Window
 
 REC_DTYPE = np.dtype([("name_hash", "<u8"), ("contig", "<i4"), ("start", "<i4"), ("end", "<i4"), ("qlen", "<i4"),
                       ("rec_idx", "<u4"), ("mapq", "u1"), ("flags", "u1"), ("name_len", "<u2")])
@@ -217,6 +217,56 @@ class Engine:
                                       self._p(track))
         self._chk(st, "gci_depth_build")
         return track
+
+    def depth_build_fused(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
+                          want_text: bool = True, want_sums: bool = False,
+                          issue: Optional[Tuple[float, float, int]] = None, max_n: Optional[int] = None):
+        """Depth build that also returns what the reference derives from the fresh depths, computed in
+        the same pass (no re-read of the track): decimal text, per-contig sums and -- only valid when
+        no gap mask follows -- the raw issue runs for (lo, hi, flank).
+
+        -> dict(text=uint8 tensor | None, text_off=int64 ndarray | None, sums=ndarray | None,
+                runs=list of per-contig arrays | None)"""
+        n = int(ivl.shape[0]) if max_n is None else int(max_n)
+        nc = len(self.lengths)
+        o = BuildOpts()
+        o.flank = int(flank)
+        o.want_text = 1 if want_text else 0
+        text_off = torch.zeros(nc + 1, dtype=torch.int64, device=self.device) if want_text else None
+        sums = torch.zeros(max(nc, 1), dtype=torch.int64, device=self.device) if want_sums else None
+        o.d_contig_text_off = text_off.data_ptr() if want_text else None
+        o.d_sums = sums.data_ptr() if want_sums else None
+        cap = 1 << 16
+        keys = None
+        while True:
+            if issue is not None:
+                keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+                o.d_n_keys, o.d_keys, o.key_cap = self._count.data_ptr(), keys.data_ptr(), cap
+                o.lo, o.hi, o.issue_flank = float(issue[0]), float(issue[1]), int(issue[2])
+            self._chk(self.lib.gci_depth_build_begin(self.ctx, self._p(ivl) if n else None, self._p(count), n,
+                                                     ctypes.byref(o)), "gci_depth_build_begin")
+            if issue is None:
+                break
+            nk = int(self._count.item())
+            if nk <= cap:
+                break
+            cap = nk
+        out = dict(text=None, text_off=None, sums=None, runs=None)
+        text = None
+        if want_text:
+            h = text_off.cpu().numpy()
+            total = int(h[nc])
+            text = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+            out["text_off"] = h
+        self._chk(self.lib.gci_depth_build_finish(self.ctx, self._p(track), self._p(text), int(text.shape[0]) if want_text else 0),
+                  "gci_depth_build_finish")
+        if want_text:
+            out["text"] = text[:int(out["text_off"][nc])]
+        if want_sums:
+            out["sums"] = sums.cpu().numpy()[:nc]
+        if issue is not None:
+            out["runs"] = self._keys_to_runs(keys[:nk].cpu().numpy().view(np.uint64), nc)
+        return out
 
     def gap_mask(self, track: torch.Tensor, gaps: torch.Tensor) -> torch.Tensor:
         n = int(gaps.shape[0])

@@ -55,6 +55,13 @@ class DepthTracks:
         self.targets = list(targets_length.keys())
         self.lengths = [int(targets_length[t]) for t in self.targets]
         self.track = track
+        # by-products of the fused build, valid until the track is modified (gap mask)
+        self._fresh_runs = None        # ((lo, hi, flank), per-contig raw runs)
+        self._fresh_sums = None
+
+    def invalidate(self) -> None:
+        self._fresh_runs = None
+        self._fresh_sums = None
 
     def _bind(self) -> None:
         if self.engine.lengths != self.lengths:
@@ -80,6 +87,8 @@ class DepthTracks:
         return {t: self[t] for t in self.targets}
 
     def sums(self) -> np.ndarray:
+        if self._fresh_sums is not None:
+            return self._fresh_sums
         self._bind()
         return self.engine.depth_sum(self.track)
 
@@ -113,6 +122,7 @@ def merge_gaps_depths(depths: DepthTracks = None, Ns_bed=None) -> DepthTracks:
             depths._bind()
             gaps = depths.engine.to_device(np.asarray(rows, dtype=np.int32).reshape(-1, 4))
             depths.engine.gap_mask(depths.track, gaps)
+            depths.invalidate()
     return depths
 
 
@@ -215,9 +225,13 @@ def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
 
 def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, iden_percent=0.9,  # noqa: A001
            clip_percent=0.1, ovlp_percent=0.9, flank_len=15, directory=".", force=False, log_reads_type="",
-           chrs_list=[], threads=1, engine: Optional[Engine] = None, write=True):
+           chrs_list=[], threads=1, engine: Optional[Engine] = None, write=True, issue_hint=None):
     """Filter the PAF and BAM file(s), build the per-base depth in HBM and write
-    `{prefix}.depth.gz`.  Returns (depths, targets_length) like the reference."""
+    `{prefix}.depth.gz`.  Returns (depths, targets_length) like the reference.
+
+    `issue_hint` = (leftmost, rightmost, flank_len) of the collapse_depth_range() call that will follow:
+    its run boundaries are then detected in the same pass that builds the depth (used as long as no gap
+    mask modifies the track first)."""
     engine = engine or default_engine()
     if write and os.path.exists(f"{directory}/{prefix}.depth.gz") and force == False:  # noqa: E712
         sys.exit(f'ERROR!!! The file "{directory}/{prefix}.depth.gz" exists\nPlease use "-f" or "--force" to rewrite')
@@ -253,13 +267,17 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     except GciError as e:
         _reraise_like_reference(e)
     track = engine.new_track()
-    engine.depth_build(ivl, count, flank_len, track)
+    fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=bool(write), want_sums=True,
+                                     issue=issue_hint)
     depths = DepthTracks(engine, targets_length, track)
+    depths._fresh_sums = fused["sums"]
+    if issue_hint is not None:
+        depths._fresh_runs = (tuple(float(x) for x in issue_hint[:2]) + (int(issue_hint[2]),), fused["runs"])
 
     print(f"Filtering {log_reads_type} alignment files done!!!")
     if write:
         print(f'Writing depths into "{directory}/{prefix}.depth.gz" ...')
-        write_depth(directory, prefix, depths, threads)
+        _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
         print("Writing depths done!!!\n\n")
     return depths, targets_length
 
@@ -278,6 +296,10 @@ def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads
     Text is rendered on the GPU; the host only frames it as gzip members."""
     depths._bind()
     text, offs = depths.engine.depth_text(depths.track)
+    _write_depth_text(directory, prefix, depths, text, offs, threads)
+
+
+def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, threads) -> None:
     host = text.cpu().numpy()
     mv = memoryview(host)
     pieces = ((t, mv[int(offs[c]):int(offs[c + 1])]) for c, t in enumerate(depths.targets))
@@ -328,7 +350,11 @@ def _issues_from_runs(runs: np.ndarray, n_slice: int, chr_len: int, flank_len: i
 def collapse_depth_range(depths: DepthTracks = None, leftmost=-1, rightmost=0, flank_len=15, start_pos=0
                          ) -> Dict[str, List[Tuple[int, int]]]:
     depths._bind()
-    runs = depths.engine.issue_scan(depths.track, leftmost, rightmost, flank_len)
+    key = (float(leftmost), float(rightmost), int(flank_len))
+    if depths._fresh_runs is not None and depths._fresh_runs[0] == key:
+        runs = depths._fresh_runs[1]
+    else:
+        runs = depths.engine.issue_scan(depths.track, leftmost, rightmost, flank_len)
     out = {}
     for c, t in enumerate(depths.targets):
         L = depths.lengths[c]

@@ -124,7 +124,7 @@ int gci_memset(gci_ctx* ctx, void* d_dst, int byte, size_t bytes);              
 enum {
     GCI_PROF_BAM_FILTER = 0, GCI_PROF_JOIN_INSERT, GCI_PROF_JOIN_FOLD, GCI_PROF_DEPTH_DIFF, GCI_PROF_SCAN_TILES,
     GCI_PROF_DEPTH_SCAN, GCI_PROF_GAP_MASK, GCI_PROF_MAX2, GCI_PROF_ISSUE_SCAN, GCI_PROF_TEXT_COUNT,
-    GCI_PROF_TEXT_WRITE, GCI_PROF_DEPTH_SUM, GCI_PROF_MEMSET, GCI_PROF_COUNT
+    GCI_PROF_TEXT_WRITE, GCI_PROF_DEPTH_SUM, GCI_PROF_MEMSET, GCI_PROF_TILE_PASS1, GCI_PROF_COUNT
 };
 int gci_profile_enable(gci_ctx* ctx, int mask);
 int gci_profile_read(gci_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, int reset);
@@ -169,6 +169,29 @@ int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, doubl
  * (n read from *d_n if d_n != NULL, clamped to max_n).  Overwrites the whole track. */
 int gci_depth_build(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, int flank,
                     int32_t* d_depth);
+
+/* Fused form of the depth build (same result as gci_depth_build) that also delivers, from the
+ * same pass and without re-reading the track from HBM, the things the reference computes from the
+ * freshly built depths: the decimal text of write_depth (GCI.py:115-117), the per-contig sums behind
+ * np.mean (GCI.py:862-868) and -- valid only when no gap mask will follow -- the run boundaries of
+ * collapse_depth_range (GCI.py:369-390; same key format as gci_issue_scan).
+ *   begin : buckets the intervals per tile, computes the requested by-products.  After it (and a
+ *           sync) d_contig_text_off[n_contigs] tells the caller how large the text buffer must be.
+ *   finish: writes the track and, if d_text != NULL, the text (requires want_text at begin). */
+typedef struct gci_build_opts {
+    int flank;                    /* --flank-len of the depth build */
+    int want_text;                /* compute text offsets in begin so that finish can render text */
+    uint64_t* d_contig_text_off;  /* n_contigs + 1 entries; required if want_text */
+    int64_t* d_sums;              /* n_contigs entries or NULL */
+    uint32_t* d_n_keys;           /* NULL: no fused issue scan */
+    uint64_t* d_keys;
+    uint32_t key_cap;
+    int issue_flank;
+    double lo, hi;
+} gci_build_opts;
+int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n,
+                          const gci_build_opts* h_opts);
+int gci_depth_build_finish(gci_ctx* ctx, int32_t* d_depth, uint8_t* d_text, uint64_t text_cap);
 
 /* ---- R8 / R9 -------------------------------------------------------------------------------- */
 int gci_gap_mask(gci_ctx* ctx, int32_t* d_depth, const gci_ivl* d_gaps, uint32_t n_gaps);

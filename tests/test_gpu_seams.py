@@ -199,3 +199,41 @@ def test_gap_mask_max2_text(engine, oracle):
     assert host == want_text
     assert [int(x) for x in offs] == list(np.cumsum([0] + [len(oracle.depth_text_contig(want2[k])) for k in h]))
     assert two.mean() == oracle.mean_depth(want2)
+
+
+def test_fused_build_equals_seams_and_oracle(engine, oracle):
+    """gci_depth_build_begin/finish: depth, text, sums and issue runs from the fused passes equal the
+    separate seams (and therefore the oracle) -- including contig ends on / off tile boundaries."""
+    rng = np.random.default_rng(17)
+    lengths = {"x": 50_000, "y": 4096, "z": 8193, "w": 31, "v": 300_001}
+    targets = list(lengths)
+    engine.set_layout([lengths[t] for t in targets])
+    ivls = []
+    for c, t in enumerate(targets):
+        L = lengths[t]
+        for _ in range(300 if L > 1000 else 5):
+            s = int(rng.integers(0, L))
+            ivls.append((c, s, int(min(L + 30, s + rng.integers(1, max(2, L // 4))))))
+    ivls += [(1, 0, 4096), (2, 8000, 8193), (3, 0, 10), (0, 49_000, 50_000)]
+    d = engine.to_device(np.array([(c, s, e, 0) for c, s, e in ivls], dtype=np.int32))
+    for fl, thr in ((15, 0), (0, 2), (7, 1)):
+        want = oracle.depth_build_py([(targets[c], s, e) for c, s, e in ivls], lengths, fl)
+        track = engine.new_track()
+        out = engine.depth_build_fused(d, None, fl, track, want_text=True, want_sums=True, issue=(-1, thr, fl))
+        tr = pipeline.DepthTracks(engine, lengths, track)
+        for t in targets:
+            assert np.array_equal(tr[t], want[t]), (t, fl)
+        assert np.array_equal(out["sums"], np.array([want[t].sum() for t in targets]))
+        assert out["text"].cpu().numpy().tobytes() == b"".join(oracle.depth_text_contig(want[t]) for t in targets)
+        tr._fresh_runs = ((-1.0, float(thr), fl), out["runs"])
+        fused_bed = pipeline.collapse_depth_range(tr, -1, thr, fl, 0)
+        tr.invalidate()
+        assert fused_bed == pipeline.collapse_depth_range(tr, -1, thr, fl, 0) == oracle.collapse_depth_range(want, -1, thr, fl, 0)
+        # a count held on the device limits how many intervals are used
+        cnt = torch.tensor([len(ivls) // 2], dtype=torch.int32, device=engine.device)
+        t2 = engine.new_track()
+        engine.depth_build(d, cnt, fl, t2)
+        half = oracle.depth_build_py([(targets[c], s, e) for c, s, e in ivls[:len(ivls) // 2]], lengths, fl)
+        tr2 = pipeline.DepthTracks(engine, lengths, t2)
+        for t in targets:
+            assert np.array_equal(tr2[t], half[t])
