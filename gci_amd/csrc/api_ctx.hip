@@ -51,6 +51,16 @@ extern "C" int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx*
         if (e != hipSuccess) { delete ctx; return GCI_E_HIP; }
         ctx->own_stream = true;
     }
+    {
+        uint32_t lut[TEXT_LUT];
+        gci_text_lut_host(lut);
+        if (hipMalloc(&ctx->text_lut.p, sizeof lut) != hipSuccess ||
+            hipMemcpy(ctx->text_lut.p, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
+            gci_ctx_destroy(ctx);
+            return GCI_E_HIP;
+        }
+        ctx->text_lut.cap = sizeof lut;
+    }
     *out = ctx;
     return GCI_OK;
 }
@@ -63,7 +73,7 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
     DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_diff, &ctx->tile_carry, &ctx->evt_cnt,
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->win,
-                      &ctx->win_tile_first};
+                      &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto* v : {&ctx->prof_live, &ctx->prof_free}) for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

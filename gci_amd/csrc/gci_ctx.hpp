@@ -16,6 +16,7 @@
 #include "gci_common.h"
 
 #define TILE GCI_TILE
+#define TEXT_LUT 1000                    // depths below this come out of a 4-byte-per-entry table
 #define BLOCK 256
 static_assert(TILE == BLOCK * 16, "a tile is 16 elements per thread");
 
@@ -47,6 +48,8 @@ struct gci_ctx {
     bool build_pending = false, build_text = false;
     // join scratch
     DevBuf join_table, join_last, join_hq;
+    DevBuf text_lut;                        // uint32[TEXT_LUT]: decimal characters of 0..999
+    DevBuf long_items;                      // K1: queue of long-CIGAR records + its counter
     // issue-scan windows
     DevBuf win, win_tile_first;
     int win_flank = INT32_MIN;              // flank the cached per-contig windows were built for
@@ -119,27 +122,76 @@ __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __bui
 __device__ __forceinline__ int32_t ld_i32(const uint8_t* p) { int32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint16_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
-// inclusive scan across the 64 lanes of a wave
+// ---- wave-level scans and sums -------------------------------------------------------------------
+// 32-bit values go through DPP (one v_add_*_dpp per step: row_shr 1/2/4/8 inside each 16-lane row, then
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3); 64-bit values through ds_bpermute.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int32_t dpp_add(int32_t v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+
+__device__ __forceinline__ int32_t wave_inclusive_i32(int32_t v)
+{
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);
+    v = dpp_add<0x143, 0xC>(v);
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_inclusive(T v, int lane)
 {
+    if constexpr (sizeof(T) == 4) {
+        return (T)wave_inclusive_i32((int32_t)v);
+    } else {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { T n = __shfl_up(v, d, 64); if (lane >= d) v += n; }
-    return v;
+        for (int d = 1; d < 64; d <<= 1) { T n = __shfl_up(v, d, 64); if (lane >= d) v += n; }
+        return v;
+    }
 }
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v)
 {
+    if constexpr (sizeof(T) == 4) {
+        return (T)__builtin_amdgcn_readlane(wave_inclusive_i32((int32_t)v), 63);
+    } else {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
 }
 
 __device__ __forceinline__ uint32_t ndigits(uint32_t v)
 {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) +
            (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+
+// depths are small almost everywhere: five compares, the long tail behind a rarely taken branch
+__device__ __forceinline__ uint32_t ndigits_fast(uint32_t v)
+{
+    uint32_t n = 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u);
+    if (__builtin_expect(v >= 100000u, 0)) n = ndigits(v);
+    return n;
+}
+
+// `lo < d <= hi` for an integer d as integer bounds: d in [ilo, ihi]  (empty range: ilo > ihi)
+struct IntRange { int32_t lo, hi; };
+static inline IntRange gci_int_range(double lo, double hi)
+{
+    IntRange r;
+    if (!(lo == lo) || !(hi == hi)) { r.lo = 1; r.hi = 0; return r; }           // NaN: every comparison is false
+    double fl = __builtin_floor(lo) + 1.0, fh = __builtin_floor(hi);
+    if (fl < -2147483648.0) fl = -2147483648.0;
+    if (fh > 2147483647.0) fh = 2147483647.0;
+    if (fl > fh) { r.lo = 1; r.hi = 0; return r; }
+    r.lo = (int32_t)fl; r.hi = (int32_t)fh;
+    return r;
 }
 
 // issue-scan boundary key: (window << 33) | (rel << 1) | is_end
@@ -235,73 +287,148 @@ static inline int device_exclusive_scan(gci_ctx* ctx, const TIn* in, TOut* out, 
 // decimal text of depth values through LDS staging (K10)
 // ---------------------------------------------------------------------------------------------
 
-#define TEXT_SUB 1024                    // elements per text staging round
-#define TEXT_STAGE (TEXT_SUB * 11)       // worst case: 10 digits + '\n'
+#define TEXT_STAGE 16384                 // LDS bytes of staging: 16 for the alignment shift + text
 
-// staging -> global: byte head up to a 4-byte boundary, dword body, byte tail
-__device__ __forceinline__ void copy_out(uint8_t* __restrict__ g, const uint8_t* stage, uint32_t total, int t)
+// lut[x] = the characters of "x\n" packed little endian (x < 1000: at most 3 digits + newline).
+// Built once per context in global memory (gci_text_lut_host); every workgroup copies it to LDS.
+static inline void gci_text_lut_host(uint32_t* lut)
 {
-    const uint32_t head = min((uint32_t)((4 - ((uintptr_t)g & 3)) & 3), total);
-    const uint32_t nw = (total - head) >> 2;
-    if ((uint32_t)t < head) g[t] = stage[t];
-    uint32_t* gw = reinterpret_cast<uint32_t*>(g + head);
-    for (uint32_t wi = t; wi < nw; wi += BLOCK) {
-        const uint8_t* s = stage + head + 4 * wi;
-        gw[wi] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    for (uint32_t x = 0; x < TEXT_LUT; x++) {
+        const uint32_t d2 = x / 100u, d1 = (x / 10u) % 10u, d0 = x % 10u;
+        if (x >= 100u) lut[x] = ('0' + d2) | (('0' + d1) << 8) | (('0' + d0) << 16) | ((uint32_t)'\n' << 24);
+        else if (x >= 10u) lut[x] = ('0' + d1) | (('0' + d0) << 8) | ((uint32_t)'\n' << 16);
+        else lut[x] = ('0' + d0) | ((uint32_t)'\n' << 8);
     }
-    const uint32_t done = head + 4 * nw;
-    if ((uint32_t)t < total - done) g[done + t] = stage[done + t];
 }
 
-// Render the decimal lines of up to TEXT_SUB elements (4 per thread) through LDS staging.
-// Returns the bytes this round produced.  Ends with a __syncthreads().
-__device__ __forceinline__ uint32_t text_round(const uint32_t (&v)[4], int64_t i0, int64_t valid, uint8_t* stage,
-                                               uint32_t* wtot, uint8_t* __restrict__ out, uint64_t dst, uint64_t cap,
-                                               int t, int lane, int wave)
+__device__ __forceinline__ void text_lut_load(uint32_t* lut, const uint32_t* __restrict__ g_lut, int t)
 {
-    uint32_t nd[4], mine = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { nd[k] = i0 + k < valid ? ndigits(v[k]) + 1 : 0; mine += nd[k]; }
-    const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t o = inc - mine, total = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; w++) { if (w < wave) o += wtot[w]; total += wtot[w]; }
+    for (uint32_t x = t; x < TEXT_LUT; x += BLOCK) lut[x] = g_lut[x];
+}
+
+// write the decimal lines of 4 consecutive elements into the staging buffer at byte offset o
+__device__ __forceinline__ void text_put4(const uint32_t (&v)[4], const uint32_t (&nd)[4], uint32_t o, uint8_t* stage,
+                                          const uint32_t* lut)
+{
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (nd[k]) {
+        if (!nd[k]) continue;
+        if (v[k] < TEXT_LUT) {
+            const uint32_t w = lut[v[k]];
+            stage[o] = (uint8_t)w;
+            stage[o + 1] = (uint8_t)(w >> 8);
+            if (nd[k] > 2) stage[o + 2] = (uint8_t)(w >> 16);
+            if (nd[k] > 3) stage[o + 3] = (uint8_t)(w >> 24);
+        } else {
             uint32_t x = v[k];
             const uint32_t e = o + nd[k] - 1;
             stage[e] = '\n';
             for (uint32_t d = 1; d < nd[k]; d++) { stage[e - d] = (uint8_t)('0' + x % 10u); x /= 10u; }
-            o += nd[k];
+        }
+        o += nd[k];
+    }
+}
+
+// staging -> global.  The staging buffer mirrors the 16-byte alignment of the destination (the text starts
+// at stage[shift], shift = dst & 15), so whole chunks move as ds_read_b128 + global_store_dwordx4; the first
+// and last partial chunk are written byte-wise and only where this tile owns the bytes.
+__device__ __forceinline__ void text_copy_out(uint8_t* __restrict__ g, const uint8_t* stage, uint32_t shift,
+                                              uint32_t total, int t)
+{
+    uint8_t* ga = g - shift;
+    const uint32_t end = shift + total;
+    const uint32_t nchunks = (end + 15u) >> 4;
+    for (uint32_t c = t; c < nchunks; c += BLOCK) {
+        const uint32_t lo = c << 4, hi = lo + 16u;
+        if (lo >= shift && hi <= end) {
+            *reinterpret_cast<int4*>(ga + lo) = *reinterpret_cast<const int4*>(stage + lo);
+        } else {
+            const uint32_t a = lo > shift ? lo : shift, b = hi < end ? hi : end;
+            for (uint32_t i = a; i < b; i++) ga[i] = stage[i];
         }
     }
+}
+
+// Decimal text of one tile held in registers (thread t, group j: elements (j * 256 + t) * 4 .. + 3) to
+// out[dst ...].  One staging round
+// when the tile's text fits the LDS buffer (it does unless depths reach 5+ digits), else one per group.
+// Needs: stage[TEXT_STAGE] (16-byte aligned), wtot[4][BLOCK / 64], lut[TEXT_LUT] built and synced.
+template <bool FULL>
+__device__ __forceinline__ void text_tile(const int4 (&v)[4], int64_t valid, uint8_t* stage,
+                                          uint32_t (*wtot)[BLOCK / 64], const uint32_t* lut, uint8_t* __restrict__ out,
+                                          uint64_t dst, uint64_t cap, int t, int lane, int wave)
+{
+    uint32_t u[4][4], nd[4][4], mine[4], inc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u[j][0] = (uint32_t)v[j].x; u[j][1] = (uint32_t)v[j].y; u[j][2] = (uint32_t)v[j].z; u[j][3] = (uint32_t)v[j].w;
+        const int64_t i = (int64_t)(j * BLOCK + t) * 4;
+        mine[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            nd[j][k] = (FULL || i + k < valid) ? ndigits_fast(u[j][k]) + 1u : 0u;
+            mine[j] += nd[j][k];
+        }
+        inc[j] = (uint32_t)wave_inclusive_i32((int32_t)mine[j]);
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) wtot[j][wave] = inc[j];
+    }
     __syncthreads();
-    if (dst + total <= cap) copy_out(out + dst, stage, total, t);
-    __syncthreads();
-    return total;
+    uint32_t off[4], gtot[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { const uint32_t x = wtot[j][w]; if (w < wave) pre += x; all += x; }
+        off[j] = pre + inc[j] - mine[j];
+        gtot[j] = all;
+    }
+    const uint32_t tile_bytes = gtot[0] + gtot[1] + gtot[2] + gtot[3];
+    if (dst + tile_bytes > cap) return;                       // caller's buffer too small: write nothing
+    if (tile_bytes + 16u <= TEXT_STAGE) {
+        const uint32_t shift = (uint32_t)((uintptr_t)(out + dst) & 15u);
+        uint32_t base = shift;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { text_put4(u[j], nd[j], base + off[j], stage, lut); base += gtot[j]; }
+        __syncthreads();
+        text_copy_out(out + dst, stage, shift, tile_bytes, t);
+    } else {
+        for (int j = 0; j < 4; j++) {
+            const uint32_t shift = (uint32_t)((uintptr_t)(out + dst) & 15u);
+            text_put4(u[j], nd[j], shift + off[j], stage, lut);
+            __syncthreads();
+            text_copy_out(out + dst, stage, shift, gtot[j], t);
+            dst += gtot[j];
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // small kernels used by more than one translation unit
 // ---------------------------------------------------------------------------------------------
 
-// per-contig reduction of the per-tile sums (one workgroup per contig)
+// per-contig reduction of the per-tile sums: REDUCE_SPLIT workgroups per contig, each adds its share with one
+// 64-bit atomic (sums must be zeroed first)
+#define REDUCE_SPLIT 32
 __attribute__((unused)) static __global__ __launch_bounds__(BLOCK) void k_reduce_tiles(const long long* __restrict__ tile_sum,
                                                         const int64_t* __restrict__ tile_first,
-                                                        long long* __restrict__ sums)
+                                                        unsigned long long* __restrict__ sums)
 {
     __shared__ long long part[BLOCK / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t a = tile_first[blockIdx.x], b = tile_first[blockIdx.x + 1];
     long long s = 0;
-    for (int64_t i = a + t; i < b; i += BLOCK) s += tile_sum[i];
+    for (int64_t i = a + (int64_t)blockIdx.y * BLOCK + t; i < b; i += (int64_t)REDUCE_SPLIT * BLOCK) s += tile_sum[i];
     s = wave_sum<long long>(s);
     if (lane == 0) part[wave] = s;
     __syncthreads();
-    if (t == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (t == 0) {
+        const long long v = part[0] + part[1] + part[2] + part[3];
+        if (v) atomicAdd(sums + blockIdx.x, (unsigned long long)v);
+    }
 }
 
 __attribute__((unused)) static __global__ void k_contig_text_off(const uint64_t* __restrict__ tile_off, const int64_t* __restrict__ tile_first,

@@ -82,11 +82,13 @@ __global__ __launch_bounds__(BLOCK) void k_evt_scatter(const gci_ivl* __restrict
 
 // zero the coarse table and the small outputs of a build in one launch
 __global__ __launch_bounds__(BLOCK) void k_build_prep(int32_t* __restrict__ tile_diff, int64_t n_tiles,
-                                                      uint32_t* __restrict__ n_keys)
+                                                      uint32_t* __restrict__ n_keys, long long* __restrict__ sums,
+                                                      int32_t n_contigs)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n_tiles) tile_diff[i] = 0;
     if (i == 0 && n_keys) *n_keys = 0;
+    if (sums) for (int64_t c = i; c < n_contigs; c += (int64_t)gridDim.x * BLOCK) sums[c] = 0;
 }
 
 // both per-tile scans in one launch: blockIdx.y == 0 coarse difference -> carry, == 1 counts -> offsets
@@ -108,76 +110,26 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_add(int32_t* __restrict__ carry
 
 // ---- per tile -------------------------------------------------------------------------------------
 
+
 struct IssueArgs {
     unsigned long long* keys;      // nullptr: no fused issue scan
     uint32_t* n_keys;
     uint32_t cap;
     int flank;
-    double lo, hi;
+    int32_t lo, hi;                // depth in [lo, hi]  (gci_int_range of the caller's lo < d <= hi)
 };
 
-// PASS 1: by-products only.  PASS 2: depth (+ text).
-template <int PASS>
-__global__ __launch_bounds__(BLOCK) void k_tile_build(
-    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
-    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
-    // pass 1 outputs
-    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss,
-    // pass 2 outputs
-    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap)
+// Body of one tile.  PASS 1: by-products only (sum, text bytes, issue boundaries).  PASS 2: depth (+ text).
+// FULL: every element of the tile lies inside its contig (all tiles but the last of each contig).
+template <int PASS, bool FULL>
+__device__ __forceinline__ void tile_body(
+    int32_t* lds, const int4 (&v)[4], int32_t carry_in, int64_t tile, int32_t c, int64_t elem0, int64_t L,
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, const IssueArgs& iss,
+    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text,
+    uint64_t text_cap, uint32_t (*twtot)[BLOCK / 64], const uint32_t* lut, int t, int lane, int wave)
 {
-    __shared__ __attribute__((aligned(16))) int32_t lds[TILE];          // difference array, then depth (pass 1)
-    __shared__ int32_t wtot[4][BLOCK / 64];
-    __shared__ uint32_t twtot[BLOCK / 64];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t tile = blockIdx.x;
-    int4* l4 = reinterpret_cast<int4*>(lds);
-#pragma unroll
-    for (int j = 0; j < 4; j++) l4[j * BLOCK + t] = make_int4(0, 0, 0, 0);
-    __syncthreads();
-    const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
-    for (uint32_t e = e0 + t; e < e1; e += BLOCK) {
-        const uint32_t ev = events[e];
-        atomicAdd(&lds[ev >> 1], (ev & 1u) ? -1 : 1);
-    }
-    __syncthreads();
-    int4 v[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = l4[j * BLOCK + t];
-    int32_t tot[4], inc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        v[j].y += v[j].x; v[j].z += v[j].y; v[j].w += v[j].z;
-        tot[j] = v[j].w;
-        inc[j] = tot[j];
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) { int32_t n = __shfl_up(inc[j], d, 64); if (lane >= d) inc[j] += n; }
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) wtot[j][wave] = inc[j];
-    }
-    __syncthreads();                       // also: every thread has read its slice of the LDS difference array
-    const int32_t carry_in = tile_carry[tile];
-    int32_t carry = carry_in;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int32_t pre = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) { const int32_t x = wtot[j][w]; if (w < wave) pre += x; all += x; }
-        const int32_t ex = carry + pre + inc[j] - tot[j];
-        v[j].x += ex; v[j].y += ex; v[j].z += ex; v[j].w += ex;
-        carry += all;
-    }
-    // v[j] now holds depth of elements (j * 256 + t) * 4 .. + 3 of this tile
-    const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
-    const int64_t elem0 = (tile - tile_first[c]) * TILE;          // index of the tile's first element in its contig
-    const int64_t L = len[c];
     const int64_t valid = L - elem0;                              // elements of this tile inside the contig
-
+    int4* l4 = reinterpret_cast<int4*>(lds);
     if (PASS == 1) {
         long long s = 0;
         uint32_t bytes = 0;
@@ -186,12 +138,16 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
             const int64_t i = (int64_t)(j * BLOCK + t) * 4;
             const int32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (i + k < valid) { s += d[k]; bytes += ndigits((uint32_t)d[k]) + 1; }
+            for (int k = 0; k < 4; k++) {
+                const bool in = FULL || i + k < valid;
+                s += in ? d[k] : 0;
+                bytes += in ? ndigits_fast((uint32_t)d[k]) + 1u : 0u;
+            }
         }
         s = wave_sum<long long>(s);
         bytes = wave_sum<uint32_t>(bytes);
         __shared__ long long ssum[BLOCK / 64];
-        if (lane == 0) { ssum[wave] = s; twtot[wave] = bytes; }
+        if (lane == 0) { ssum[wave] = s; twtot[0][wave] = bytes; }
         if (iss.keys) {
             // depth of the whole tile to LDS so each thread can see its predecessor element
 #pragma unroll
@@ -200,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
         __syncthreads();
         if (t == 0) {
             tile_sum[tile] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
-            tile_bytes[tile] = twtot[0] + twtot[1] + twtot[2] + twtot[3];
+            tile_bytes[tile] = twtot[0][0] + twtot[0][1] + twtot[0][2] + twtot[0][3];
         }
         if (iss.keys) {
             // window of this contig: depth_list[flank : L - flank] with Python slice normalisation (GCI.py:374)
@@ -211,25 +167,29 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
             for (int j = 0; j < 4; j++) {
                 const int64_t i = (int64_t)(j * BLOCK + t) * 4;
                 const int64_t e = elem0 + i;                       // contig coordinate of this thread's first element
-                if (e + 3 < wa || e >= wb) continue;
                 const int32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
                 const int32_t dprev = i > 0 ? lds[i - 1] : carry_in;
-                bool gp = (e - 1 >= wa) && (e - 1 < wb) && (iss.lo < (double)dprev) && ((double)dprev <= iss.hi);
+                bool gp = (e - 1 >= wa) && (e - 1 < wb) && (dprev >= iss.lo) && (dprev <= iss.hi);
+                bool g[4];
+                bool any = gp;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    g[k] = (e + k >= wa) && (e + k < wb) && (d[k] >= iss.lo) && (d[k] <= iss.hi);
+                    any |= g[k];
+                }
+                if (!any) continue;                                 // nearly always: low-depth runs are rare
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int64_t p = e + k;
-                    const bool g = (p >= wa) && (p < wb) && (iss.lo < (double)d[k]) && ((double)d[k] <= iss.hi);
-                    if (g != gp && p >= wa && p <= wb) {           // run boundary at p (start if g, else end)
-                        if (g || p < wb) {
-                            const uint32_t slot = atomicAdd(iss.n_keys, 1u);
-                            if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, p - wa, !g);
-                        }
+                    if (g[k] != gp && p >= wa && (g[k] || p < wb)) {   // run boundary at p: start if g, else end
+                        const uint32_t slot = atomicAdd(iss.n_keys, 1u);
+                        if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, p - wa, !g[k]);
                     }
-                    if (g && p == wb - 1) {                         // run reaches the end of the window
+                    if (g[k] && p == wb - 1) {                      // run reaches the end of the window
                         const uint32_t slot = atomicAdd(iss.n_keys, 1u);
                         if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, wb - wa, true);
                     }
-                    gp = g;
+                    gp = g[k];
                 }
             }
         }
@@ -237,15 +197,75 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
         int4* g4 = reinterpret_cast<int4*>(depth + (size_t)tile * TILE);
 #pragma unroll
         for (int j = 0; j < 4; j++) g4[j * BLOCK + t] = v[j];
-        if (text) {
-            uint8_t* stage = reinterpret_cast<uint8_t*>(lds);        // 11 KiB of the 16 KiB, free after the sync above
-            uint64_t dst = tile_text_off[tile];
-            for (int j = 0; j < 4; j++) {
-                const uint32_t u[4] = {(uint32_t)v[j].x, (uint32_t)v[j].y, (uint32_t)v[j].z, (uint32_t)v[j].w};
-                dst += text_round(u, (int64_t)(j * BLOCK + t) * 4, valid, stage, twtot, text, dst, text_cap, t, lane, wave);
-            }
-        }
+        if (text)
+            text_tile<FULL>(v, valid, reinterpret_cast<uint8_t*>(lds), twtot, lut, text, tile_text_off[tile], text_cap, t,
+                            lane, wave);
     }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void k_tile_build(
+    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
+    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
+    // pass 1 outputs
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss,
+    // pass 2 outputs
+    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
+    const uint32_t* __restrict__ g_lut)
+{
+    __shared__ __attribute__((aligned(16))) int32_t lds[TILE];    // difference array; later depth (pass 1) / text staging
+    __shared__ int32_t wtot[4][BLOCK / 64];
+    __shared__ uint32_t twtot[4][BLOCK / 64];
+    __shared__ uint32_t lut[PASS == 2 ? TEXT_LUT : 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t tile = blockIdx.x;
+    int4* l4 = reinterpret_cast<int4*>(lds);
+#pragma unroll
+    for (int j = 0; j < 4; j++) l4[j * BLOCK + t] = make_int4(0, 0, 0, 0);
+    if (PASS == 2 && text) text_lut_load(lut, g_lut, t);
+    __syncthreads();
+    const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
+    for (uint32_t e = e0 + t; e < e1; e += BLOCK) {
+        const uint32_t ev = events[e];
+        atomicAdd(&lds[ev >> 1], (ev & 1u) ? -1 : 1);
+    }
+    const int32_t carry_in = tile_carry[tile];
+    const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
+    const int64_t elem0 = (tile - tile_first[c]) * TILE;          // index of the tile's first element in its contig
+    const int64_t L = len[c];
+    __syncthreads();
+    int4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = l4[j * BLOCK + t];
+    int32_t tot[4], inc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j].y += v[j].x; v[j].z += v[j].y; v[j].w += v[j].z;
+        tot[j] = v[j].w;
+        inc[j] = wave_inclusive_i32(tot[j]);
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) wtot[j][wave] = inc[j];
+    }
+    __syncthreads();                       // also: every thread has read its slice of the LDS difference array
+    int32_t carry = carry_in;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int32_t pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { const int32_t x = wtot[j][w]; if (w < wave) pre += x; all += x; }
+        const int32_t ex = carry + pre + inc[j] - tot[j];
+        v[j].x += ex; v[j].y += ex; v[j].z += ex; v[j].w += ex;
+        carry += all;
+    }
+    // v[j] now holds the depth of elements (j * 256 + t) * 4 .. + 3 of this tile
+    if (L - elem0 >= TILE)
+        tile_body<PASS, true>(lds, v, carry_in, tile, c, elem0, L, tile_sum, tile_bytes, iss, depth, tile_text_off, text,
+                              text_cap, twtot, lut, t, lane, wave);
+    else
+        tile_body<PASS, false>(lds, v, carry_in, tile, c, elem0, L, tile_sum, tile_bytes, iss, depth, tile_text_off, text,
+                               text_cap, twtot, lut, t, lane, wave);
 }
 
 // ---- host -----------------------------------------------------------------------------------------
@@ -262,14 +282,14 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
         ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
         hipLaunchKernelGGL(k_tile_build<1>, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs,
                            (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, (int32_t*)nullptr,
-                           (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0);
+                           (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0, (const uint32_t*)ctx->text_lut.p);
     } else {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
         IssueArgs none;
         memset(&none, 0, sizeof none);
         hipLaunchKernelGGL(k_tile_build<2>, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs,
                            (long long*)nullptr, (uint32_t*)nullptr, none, d_depth, (const uint64_t*)ctx->tile_u64.p, d_text,
-                           text_cap);
+                           text_cap, (const uint32_t*)ctx->text_lut.p);
     }
     LAUNCHCHK("k_tile_build");
     return GCI_OK;
@@ -301,7 +321,7 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
         hipLaunchKernelGGL(k_build_prep, dim3((uint32_t)((nt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, diff, nt,
-                           o->d_n_keys);
+                           o->d_n_keys, (long long*)o->d_sums, ctx->n_contigs);
         LAUNCHCHK("k_build_prep");
         if (max_n) {
             hipLaunchKernelGGL(k_evt_count, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
@@ -330,14 +350,15 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
         memset(&iss, 0, sizeof iss);
         if (o->d_n_keys) {
             iss.keys = (unsigned long long*)o->d_keys; iss.n_keys = o->d_n_keys; iss.cap = o->key_cap;
-            iss.flank = o->issue_flank; iss.lo = o->lo; iss.hi = o->hi;
+            const IntRange rg = gci_int_range(o->lo, o->hi);
+            iss.flank = o->issue_flank; iss.lo = rg.lo; iss.hi = rg.hi;
             if (!iss.keys) { static unsigned long long dummy; iss.keys = &dummy; iss.cap = 0; }   // count only
         }
         GCI_TRY(launch_tile_build(ctx, 1, iss, nullptr, nullptr, 0));
         if (o->d_sums) {
             ProfScope _ps(ctx, GCI_PROF_DEPTH_SUM);
-            hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs), dim3(BLOCK), 0, ctx->stream,
-                               (const long long*)ctx->tile_sum.p, tf, (long long*)o->d_sums);
+            hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs, REDUCE_SPLIT), dim3(BLOCK), 0, ctx->stream,
+                               (const long long*)ctx->tile_sum.p, tf, (unsigned long long*)o->d_sums);
             LAUNCHCHK("k_reduce_tiles");
         }
         if (o->want_text) {

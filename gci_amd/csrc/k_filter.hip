@@ -1,32 +1,296 @@
 // k_filter.hip -- K1: BAM record filter (read_sam, /root/reference/GCI.py:146-169).
-#include "gci_ctx.hpp"
-
-template <int G>
-__device__ __forceinline__ int64_t group_sum_i64(int64_t v)
-{
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
-    return v;
-}
-template <int G>
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) { uint32_t o = __shfl_xor(v, m, G); v = o < v ? o : v; }
-    return v;
-}
-
 //
-// G lanes cooperate on one record (G = 16: four records per wave): the CIGAR words and the
-// name bytes are read group-strided (contiguous 4*G bytes per step), op totals are reduced with
-// xor-shuffles, the aux walk (NM, CG) is done redundantly by every lane of the group (same
-// addresses: one transaction), the two IEEE f64 divisions decide, lane 0 writes the 32-byte
-// compact record.  SEQ and QUAL are skipped by pointer arithmetic and never touched.
+// The decode is bound by vector-memory address processing, not by bytes: a wave that parses 16 scattered
+// records with 4-byte loads issues ~47 load instructions that each touch 16 different cache lines.  So the
+// record is STAGED: four lanes per record pull its first 256 bytes (core, name, first CIGAR words) and the
+// first 128 bytes of its aux block into LDS with 16-byte loads (6 load instructions per wave), and all
+// parsing -- core fields, NUL search, name hash, the aux walk for NM / CG, most of the CIGAR -- runs out
+// of LDS (gfx950 serves unaligned ds_read_b32 / b64; checked by tools/hwtests/lds_unaligned.hip).
+//
+//   fast path (k_bam_filter), 16 records per wave:
+//     flag / MAPQ tests (GCI.py:152-156) -> query_name (first NUL) + 64-bit name hash -> first NM tag
+//     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162): one fire-and-forget
+//     ds_add_u64 per op into a per-record LDS row indexed by op code -> the two IEEE f64 divisions of
+//     GCI.py:165 -> 32-byte compact record.
+//   slow path (k_bam_filter_slow), one 256-thread workgroup per queued record, everything from global
+//     memory: CIGARs of more than LONG_OPS operations (ultra-long ONT reads and htslib's CG:B,I restore),
+//     records whose NM tag does not show up in the staged part of the aux block, names longer than the
+//     staged head.  Same decisions, same status codes.
+// SEQ and QUAL are skipped by pointer arithmetic and never touched.
+#include "gci_ctx.hpp"
+#include <stdlib.h>
+
+#define G 4                      // lanes per record on the fast path
+#define NSLOT 10                 // op codes 0..8 (M I D N S H P = X) + one slot for everything else
+#define LONG_OPS 4096u
+#define HEAD 256                 // staged bytes from the record start
+#define AUXB 128                 // staged bytes from the aux start
+#define HEADP (HEAD + 16)        // staged from the 16-byte boundary below the record start
+#define AUXP (AUXB + 16)
+#define ROW (HEADP + AUXP)
 
 __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec, int code)
 {
     atomicMin(status, ((unsigned long long)rec << 8) | (unsigned long long)(uint8_t)(-code));
 }
+
+__device__ __forceinline__ bool has_zero_byte(uint32_t x) { return ((x - 0x01010101u) & ~x & 0x80808080u) != 0; }
+
+// The decision of GCI.py:163-168 from the op totals; fills r and returns a gci_status (GCI_OK also when filtered).
+__device__ __forceinline__ int decide(gci_rec& r, const int64_t (&tot)[NSLOT], bool have_nm, bool nm_bad_type, int64_t NM,
+                                      int32_t pos, int32_t contig, int32_t l_seq, uint32_t n_cigar_field, int mapq,
+                                      int mq_cutoff, double clip_percent, double iden_percent)
+{
+    const int64_t M = tot[0] + tot[7] + tot[8], I = tot[1], D = tot[2], N = tot[3], S = tot[4];
+    if (!have_nm) return GCI_E_NO_NM;                                              // get_tag('NM'): KeyError
+    if (nm_bad_type) return GCI_E_BAD_NM_TYPE;
+    const int64_t mm = NM - (I + D);                                               // GCI.py:164
+    const int64_t den1 = M + I + S, den2 = M + I + D;
+    if (den1 == 0) return GCI_E_ZERO_DIV;
+    // Python's `and` short-circuits: the identity division only runs when the clip test passed
+    if (!((double)S / (double)den1 <= clip_percent)) return GCI_OK;                // GCI.py:165
+    if (den2 == 0) return GCI_E_ZERO_DIV;
+    if (!((double)(M - mm) / (double)den2 >= iden_percent)) return GCI_OK;
+    if (n_cigar_field == 0) return GCI_E_NO_END;
+    const int64_t rlen = M + D + N;
+    r.contig = contig;
+    r.start = pos;
+    r.end = (int32_t)((int64_t)pos + (rlen > 0 ? rlen : 1));                        // bam_endpos
+    r.qlen = l_seq;                                                                // query_length
+    r.flags = GCI_REC_PASS | (mapq >= mq_cutoff ? GCI_REC_HQ : 0);                 // GCI.py:166-168
+    return GCI_OK;
+}
+
+// integer value of an NM tag whose type byte is at t (value follows); false if the type is not an integer
+template <typename P>
+__device__ __forceinline__ bool nm_value(P t, int64_t& NM)
+{
+    uint32_t w = 0;
+    switch (t[0]) {
+    case 'c': NM = (int8_t)t[1]; return true;
+    case 'C': NM = t[1]; return true;
+    case 's': w = (uint32_t)t[1] | ((uint32_t)t[2] << 8); NM = (int16_t)w; return true;
+    case 'S': w = (uint32_t)t[1] | ((uint32_t)t[2] << 8); NM = w; return true;
+    case 'i': w = (uint32_t)t[1] | ((uint32_t)t[2] << 8) | ((uint32_t)t[3] << 16) | ((uint32_t)t[4] << 24); NM = (int32_t)w; return true;
+    case 'I': w = (uint32_t)t[1] | ((uint32_t)t[2] << 8) | ((uint32_t)t[3] << 16) | ((uint32_t)t[4] << 24); NM = w; return true;
+    default: return false;
+    }
+}
+
+// 16 bytes global -> LDS from a 16-byte aligned stream offset; bytes past the end of the stream read as zero
+__device__ __forceinline__ void stage16(uint8_t* dst, const uint8_t* __restrict__ bam, uint64_t at, uint64_t n_bytes)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (at + 16 <= n_bytes) v = *reinterpret_cast<const uint4*>(bam + at);
+    else if (at < n_bytes) {
+        uint8_t tmp[16];
+        for (int b = 0; b < 16; b++) tmp[b] = at + b < n_bytes ? bam[at + b] : 0;
+        __builtin_memcpy(&v, tmp, 16);
+    }
+    *reinterpret_cast<uint4*>(dst) = v;
+}
+
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+__global__ __launch_bounds__(BLOCK) void k_bam_filter(
+    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+    const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
+    double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status,
+    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ n_slow
+#ifdef GCI_K1_TRACE
+    , unsigned long long* __restrict__ trace
+#endif
+    )
+{
+#ifdef GCI_K1_TRACE
+#define TR(i) do { if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define TR(i) do {} while (0)
+#endif
+    TR(0);
+    __shared__ __attribute__((aligned(16))) uint8_t stage[BLOCK / G][ROW];           // 24 KiB
+    __shared__ unsigned long long tot_lds[BLOCK / G][NSLOT];                          // 5 KiB: op totals per record
+    const int t = threadIdx.x;
+    const int gl = t & (G - 1), grp = t / G;
+    const uint32_t rec = (uint32_t)((uint64_t)blockIdx.x * (BLOCK / G) + grp);
+    uint8_t* row = stage[grp];
+
+    // ---- stage the head ---------------------------------------------------------------------------------------
+    bool live = rec < n_rec;
+    uint64_t off = 0;
+    if (live) {
+        off = rec_off[rec];
+        live = off + 36 <= n_bytes;
+        if (live) {
+            const uint64_t a0 = off & ~15ull;                       // aligned loads; the record starts at row[off & 15]
+#pragma unroll
+            for (int i = 0; i < (HEADP / 16 + G - 1) / G; i++) {
+                const int c = gl + G * i;
+                if (c < HEADP / 16) stage16(row + 16 * c, bam, a0 + 16ull * c, n_bytes);
+            }
+        } else if (gl == 0) {
+            gci_rec r; r.name_hash = 0; r.contig = -1; r.start = r.end = r.qlen = 0; r.rec_idx = rec + rec_idx_base;
+            r.mapq = 0; r.flags = 0; r.name_len = 0;
+            report(status, rec, GCI_E_MALFORMED); out[rec] = r;
+        }
+    }
+    if (gl < NSLOT / 2) { tot_lds[grp][2 * gl] = 0ull; tot_lds[grp][2 * gl + 1] = 0ull; }
+    if (gl == G - 1 && NSLOT / 2 > G - 1) { for (int s = 2 * (G - 1) + 2; s < NSLOT; s++) tot_lds[grp][s] = 0ull; }
+    TR(1);
+    __syncthreads();
+    TR(2);
+
+    // ---- core fields (GCI.py:152-156) ---------------------------------------------------------------------------
+    gci_rec r;
+    r.name_hash = 0; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + rec_idx_base; r.mapq = 0;
+    r.flags = 0; r.name_len = 0;
+    int32_t block_size = 0, ref_id = -1, pos = 0, l_seq = 0;
+    uint32_t l_read_name = 0, n_cigar = 0, flag = 0;
+    int mapq = 0;
+    uint64_t aux_off = 0, rec_end = 0;
+    bool want = false;                       // record passes the flag / MAPQ tests and needs the rest
+    const uint8_t* hd = row + (off & 15ull);          // record byte k is hd[k]
+    if (live) {
+        block_size = (int32_t)lds_u32(hd);
+        ref_id = (int32_t)lds_u32(hd + 4);
+        pos = (int32_t)lds_u32(hd + 8);
+        const uint32_t w12 = lds_u32(hd + 12), w16 = lds_u32(hd + 16);
+        l_read_name = w12 & 0xFF;
+        mapq = (w12 >> 8) & 0xFF;
+        n_cigar = w16 & 0xFFFF;
+        flag = w16 >> 16;
+        l_seq = (int32_t)lds_u32(hd + 20);
+        rec_end = off + 4 + (uint64_t)(uint32_t)block_size;
+        aux_off = off + 36 + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+        r.mapq = (uint8_t)mapq;
+        if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) {
+            if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
+            live = false;
+        } else {
+            // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
+            const bool sel = ref_id >= 0 && ref_id < n_ref && ref_sel[ref_id] >= 0;
+            want = sel && !(flag & (0x4u | 0x100u | 0x800u)) && mapq >= map_qual;
+            if (!want && gl == 0) out[rec] = r;
+        }
+    }
+    // ---- stage the head of the aux block --------------------------------------------------------------------------
+    if (live && want) {
+        const uint64_t a0 = aux_off & ~15ull;
+#pragma unroll
+        for (int i = 0; i < (AUXP / 16 + G - 1) / G; i++) {
+            const int c = gl + G * i;
+            if (c < AUXP / 16) stage16(row + HEADP + 16 * c, bam, a0 + 16ull * c, n_bytes);
+        }
+    }
+    TR(3);
+    __syncthreads();
+    TR(4);
+    if (!(live && want)) return;
+
+    // ---- anything the staged window cannot answer goes to the slow path -------------------------------------------
+    const uint32_t cig_at = 36 + l_read_name;                       // byte offset of the CIGAR in the record
+    bool slow = l_read_name > HEAD - 36 || n_cigar > LONG_OPS;
+    // htslib's long-CIGAR placeholder: op0 == <l_seq>S and a CG:B,I tag somewhere in the aux block
+    if (!slow && n_cigar > 0 && pos >= 0) {
+        const uint32_t op0 = cig_at + 4 <= HEAD ? lds_u32(hd + cig_at) : ld_u32(bam + off + cig_at);
+        if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)l_seq) slow = true;      // (rare: let the slow path look for CG)
+    }
+    // ---- aux walk in the staged window: first NM (bam_aux_get semantics) ------------------------------------------
+    const uint32_t aux_len = (uint32_t)min((uint64_t)AUXB, rec_end - aux_off);
+    const uint8_t* ax = row + HEADP + (aux_off & 15ull);
+    bool have_nm = false, nm_bad = false, walked_all = false;
+    int64_t NM = 0;
+    if (!slow) {
+        uint32_t q = 0;
+        for (;;) {
+            if (q + 3 > aux_len) { walked_all = aux_off + q + 3 > rec_end; break; }          // no further complete tag header
+            const uint32_t tag = (uint32_t)ax[q] | ((uint32_t)ax[q + 1] << 8);
+            const uint8_t ty = ax[q + 2];
+            uint32_t sz;
+            switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            default: sz = 0xFFFFFFFFu;                                                  // Z, H, B, malformed: not decided here
+            }
+            if (tag == (uint32_t)('N' | ('M' << 8))) {
+                if (sz == 0xFFFFFFFFu || q + 3 + sz > aux_len) break;                    // odd type / value not staged: slow path
+                have_nm = nm_value(ax + q + 2, NM);
+                nm_bad = !have_nm; have_nm = true;
+                break;
+            }
+            if (sz == 0xFFFFFFFFu || q + 3 + sz > aux_len) break;                        // variable-size tag or window end
+            q += 3 + sz;
+        }
+        if (!have_nm && !walked_all) slow = true;          // NM (if any) lies beyond what was staged or behind a string tag
+    }
+    if (slow) {
+        if (gl == 0) { slow_list[atomicAdd(n_slow, 1u)] = rec; }
+        return;
+    }
+
+    TR(5);
+    // ---- query_name: bytes up to the first NUL, 64-bit hash of its 8-byte words -----------------------------------
+    const uint8_t* name = hd + 36;
+    uint32_t nul = l_read_name;
+    for (uint32_t i = gl * 4; i < l_read_name; i += 4 * G) {
+        if (has_zero_byte(lds_u32(name + i))) {
+            for (uint32_t b = i; b < i + 4 && b < l_read_name; b++) if (name[b] == 0) { nul = min(nul, b); break; }
+            break;
+        }
+    }
+    nul = min(nul, (uint32_t)__shfl_xor((int)nul, 1, G));
+    nul = min(nul, (uint32_t)__shfl_xor((int)nul, 2, G));
+    const uint32_t name_len = nul;
+    uint64_t acc = 0;
+    for (uint32_t k = gl; k * 8 < name_len; k += G) {
+        const uint32_t b0 = k * 8;
+        uint64_t w;
+        __builtin_memcpy(&w, name + b0, 8);                                        // stays inside the staged row
+        const uint32_t keep = name_len - b0;                                       // bytes of this word inside the name
+        if (keep < 8) w &= (1ull << (8 * keep)) - 1ull;
+        acc += gci_hash_word(w, k);
+    }
+    acc += (uint64_t)__shfl_xor((long long)acc, 1, G);
+    acc += (uint64_t)__shfl_xor((long long)acc, 2, G);
+    r.name_hash = gci_hash_finish(acc, name_len);
+    r.name_len = (uint16_t)name_len;
+
+    TR(6);
+    // ---- get_cigar_stats()[0] (GCI.py:157-162): base totals per op code ---------------------------------------------
+    unsigned long long* tot = tot_lds[grp];
+    const uint32_t staged_ops = cig_at + 4 <= HEAD ? min(n_cigar, (HEAD - cig_at) / 4u) : 0u;
+    for (uint32_t k = gl; k < staged_ops; k += G) {
+        const uint32_t v = lds_u32(hd + cig_at + 4 * k);
+        const uint32_t op = v & 0xF;
+        atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4));
+    }
+    {   // the rest straight from global memory, 4 ops (16 bytes) per lane and step
+        const uint8_t* gc = bam + off + cig_at;
+        for (uint32_t k = staged_ops + 4 * gl; k < n_cigar; k += 4 * G) {
+            uint32_t v[4] = {0, 0, 0, 0};
+            const uint32_t m = min(4u, n_cigar - k);
+            if (m == 4) __builtin_memcpy(v, gc + 4ull * k, 16);
+            else for (uint32_t j = 0; j < m; j++) v[j] = ld_u32(gc + 4ull * (k + j));
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (j < m) { const uint32_t op = v[j] & 0xF; atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v[j] >> 4)); }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (gl != 0) return;        // the rest is scalar per record; the LDS operations of a wave complete in order
+    int64_t tt[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) tt[s] = (int64_t)tot[s];
+    const int st = decide(r, tt, have_nm, nm_bad, NM, pos, ref_sel[ref_id], l_seq, n_cigar, mapq, mq_cutoff, clip_percent,
+                          iden_percent);
+    if (st != GCI_OK) report(status, rec, st);
+    out[rec] = r;
+    TR(7);
+}
+
+// ---- slow path: one workgroup per queued record, everything read from global memory -----------------------------
 
 // size of an aux value of type t at p; -1 if malformed / past end
 __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_t* end, uint8_t t)
@@ -37,157 +301,127 @@ __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_
     case 'i': case 'I': case 'f': return 4;
     case 'Z': case 'H': {
         const uint8_t* q = p;
+        while (q + 4 <= end && !has_zero_byte(ld_u32(q))) q += 4;
         while (q < end && *q) q++;
         return q < end ? (q - p) + 1 : -1;
     }
     case 'B': {
         if (p + 5 > end) return -1;
-        uint8_t sub = p[0];
-        int64_t n = ld_u32(p + 1);
-        int64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2
-                   : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : -1;
+        const uint8_t sub = p[0];
+        const int64_t n = ld_u32(p + 1);
+        const int64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2
+                         : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : -1;
         return es < 0 ? -1 : 5 + n * es;
     }
     default: return -1;
     }
 }
 
-template <int G>
-__global__ __launch_bounds__(BLOCK) void k_bam_filter(
-    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
-    const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
+struct SlowHead {                 // what thread 0 parses for the whole workgroup
+    const uint8_t* ops;
+    uint32_t n_ops, n_cigar, name_len;
+    int64_t nm;
+    int32_t pos, contig, l_seq, mapq;
+    int have_nm, nm_bad;
+    uint64_t name_hash;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
+    const uint8_t* __restrict__ bam, const uint64_t* __restrict__ rec_off, const int32_t* __restrict__ ref_sel,
+    const uint32_t* __restrict__ slow_list, const uint32_t* __restrict__ n_slow, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status)
 {
-    const int gl = threadIdx.x % G;
-    const uint32_t rec = (uint32_t)(((uint64_t)blockIdx.x * BLOCK + threadIdx.x) / G);
-    if (rec >= n_rec) return;
-
-    gci_rec r;
-    r.name_hash = 0; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + rec_idx_base; r.mapq = 0; r.flags = 0;
-    r.name_len = 0;
-    const uint64_t off = rec_off[rec];
-    bool ok = off + 36 <= n_bytes;
-    int32_t block_size = 0;
-    if (ok) { block_size = ld_i32(bam + off); ok = block_size >= 32 && off + 4 + (uint64_t)block_size <= n_bytes; }
-    if (!ok) {
-        if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
-        return;
-    }
-    const uint8_t* p = bam + off;
-    const int32_t ref_id = ld_i32(p + 4);
-    const int32_t pos = ld_i32(p + 8);
-    const uint32_t l_read_name = p[12];
-    const int mapq = p[13];
-    const uint32_t n_cigar = ld_u16(p + 16);
-    const uint32_t flag = ld_u16(p + 18);
-    const int32_t l_seq = ld_i32(p + 20);
-    const uint8_t* name = p + 36;
-    const uint8_t* rec_end = p + 4 + block_size;
-    const uint8_t* cig = name + l_read_name;
-    const uint8_t* aux = cig + 4 * (uint64_t)n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
-    if (l_seq < 0 || aux > rec_end) {
-        if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
-        return;
-    }
-    r.mapq = (uint8_t)mapq;
-
-    // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260);
-    // then GCI.py:152-156: mapped, not secondary, not supplementary, MAPQ >= -mq.
-    const bool sel = ref_id >= 0 && ref_id < n_ref && ref_sel[ref_id] >= 0;
-    if (!sel || (flag & (0x4u | 0x100u | 0x800u)) || mapq < map_qual) {
-        if (gl == 0) out[rec] = r;
-        return;
-    }
-
-    // ---- query_name: bytes up to the first NUL; hash of its 8-byte words ----------------------
-    uint32_t nul = l_read_name;
-    for (uint32_t i = gl; i < l_read_name; i += G) if (name[i] == 0) { nul = i; break; }
-    const uint32_t name_len = group_min_u32<G>(nul);
-    uint64_t acc = 0;
-    for (uint32_t k = gl; k * 8 < name_len; k += G) {
-        uint64_t w = 0;
-        const uint32_t b0 = k * 8;
+    __shared__ SlowHead h;
+    __shared__ long long part[BLOCK / 64][NSLOT];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t n = *n_slow;
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const uint32_t rec = slow_list[it];
+        __syncthreads();
+        if (t == 0) {
+            // the fast path has already validated the record's bounds and passed its flag / MAPQ tests
+            const uint8_t* p = bam + rec_off[rec];
+            const int32_t block_size = ld_i32(p);
+            const int32_t ref_id = ld_i32(p + 4);
+            h.pos = ld_i32(p + 8);
+            const uint32_t l_read_name = p[12];
+            h.mapq = p[13];
+            h.n_cigar = ld_u16(p + 16);
+            h.l_seq = ld_i32(p + 20);
+            h.contig = ref_sel[ref_id];
+            const uint8_t* name = p + 36;
+            const uint8_t* rec_end = p + 4 + block_size;
+            const uint8_t* cig = name + l_read_name;
+            const uint8_t* aux = cig + 4 * (uint64_t)h.n_cigar + (((uint64_t)(uint32_t)h.l_seq + 1) >> 1) + (uint64_t)(uint32_t)h.l_seq;
+            uint32_t nl = 0;
+            while (nl < l_read_name && name[nl]) nl++;
+            h.name_len = nl;
+            uint64_t acc = 0;
+            for (uint32_t k = 0; k * 8 < nl; k++) {
+                uint64_t w = 0;
+                for (int b = 0; b < 8; b++) if (k * 8 + b < nl) w |= (uint64_t)name[k * 8 + b] << (8 * b);
+                acc += gci_hash_word(w, k);
+            }
+            h.name_hash = gci_hash_finish(acc, nl);
+            // first NM, first CG (bam_aux_get semantics)
+            const uint8_t* nm_p = nullptr;
+            const uint8_t* cg_p = nullptr;
+            for (const uint8_t* q = aux; q + 3 <= rec_end;) {
+                const int64_t sz = aux_value_size(q + 3, rec_end, q[2]);
+                if (sz < 0 || q + 3 + sz > rec_end) break;
+                if (q[0] == 'N' && q[1] == 'M' && !nm_p) nm_p = q + 2;
+                if (q[0] == 'C' && q[1] == 'G' && !cg_p) cg_p = q + 2;
+                q += 3 + sz;
+            }
+            h.have_nm = nm_p != nullptr;
+            h.nm = 0;
+            h.nm_bad = nm_p ? !nm_value(nm_p, h.nm) : 0;
+            // htslib moves a >65535-op CIGAR back from CG:B,I when op0 == <l_seq>S
+            h.ops = cig;
+            h.n_ops = h.n_cigar;
+            if (h.n_cigar > 0 && h.pos >= 0) {
+                const uint32_t op0 = ld_u32(cig);
+                if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)h.l_seq && cg_p && cg_p[0] == 'B' &&
+                    (cg_p[1] == 'I' || cg_p[1] == 'i')) {
+                    const uint32_t cg_len = ld_u32(cg_p + 2);
+                    if (cg_len >= h.n_cigar && cg_len < (1u << 29)) { h.ops = cg_p + 6; h.n_ops = cg_len; }
+                }
+            }
+        }
+        __syncthreads();
+        long long s[NSLOT];
 #pragma unroll
-        for (int b = 0; b < 8; b++) if (b0 + b < name_len) w |= (uint64_t)name[b0 + b] << (8 * b);
-        acc += gci_hash_word(w, k);
-    }
-    acc = (uint64_t)group_sum_i64<G>((int64_t)acc);
-    r.name_hash = gci_hash_finish(acc, name_len);
-    r.name_len = (uint16_t)name_len;
-
-    // ---- aux walk: first NM, first CG (bam_aux_get semantics) ----------------------------------
-    const uint8_t* nm_p = nullptr;
-    const uint8_t* cg_p = nullptr;
-    {
-        const uint8_t* q = aux;
-        while (q + 3 <= rec_end) {
-            const uint8_t t0 = q[0], t1 = q[1], ty = q[2];
-            const int64_t sz = aux_value_size(q + 3, rec_end, ty);
-            if (sz < 0 || q + 3 + sz > rec_end) break;
-            if (t0 == 'N' && t1 == 'M' && !nm_p) nm_p = q + 2;
-            if (t0 == 'C' && t1 == 'G' && !cg_p) cg_p = q + 2;
-            q += 3 + sz;
+        for (int k = 0; k < NSLOT; k++) s[k] = 0;
+        const uint8_t* ops = h.ops;
+        for (uint32_t k = t; k < h.n_ops; k += BLOCK) {
+            const uint32_t v = ld_u32(ops + 4 * (uint64_t)k);
+            const uint32_t op = v & 0xFu;
+            const long long len = v >> 4;
+#pragma unroll
+            for (int q = 0; q < NSLOT - 1; q++) s[q] += op == (uint32_t)q ? len : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NSLOT - 1; k++) s[k] = wave_sum<long long>(s[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NSLOT - 1; k++) part[wave][k] = s[k];
+        }
+        __syncthreads();
+        if (t == 0) {
+            int64_t tot[NSLOT];
+#pragma unroll
+            for (int k = 0; k < NSLOT; k++) tot[k] = 0;
+            for (int w = 0; w < BLOCK / 64; w++)
+                for (int k = 0; k < NSLOT - 1; k++) tot[k] += part[w][k];
+            gci_rec r;
+            r.name_hash = h.name_hash; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + rec_idx_base;
+            r.mapq = (uint8_t)h.mapq; r.flags = 0; r.name_len = (uint16_t)h.name_len;
+            const int st = decide(r, tot, h.have_nm != 0, h.nm_bad != 0, h.nm, h.pos, h.contig, h.l_seq, h.n_cigar, h.mapq,
+                                  mq_cutoff, clip_percent, iden_percent);
+            if (st != GCI_OK) report(status, rec, st);
+            out[rec] = r;
         }
     }
-
-    // ---- htslib moves a >65535-op CIGAR back from CG:B,I when op0 == <l_seq>S --------------------
-    const uint8_t* ops = cig;
-    uint64_t n_ops = n_cigar;
-    if (n_cigar > 0 && pos >= 0) {
-        const uint32_t op0 = ld_u32(cig);
-        if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)l_seq && cg_p && cg_p[0] == 'B' &&
-            (cg_p[1] == 'I' || cg_p[1] == 'i')) {
-            const uint32_t cg_len = ld_u32(cg_p + 2);
-            if (cg_len >= n_cigar && cg_len < (1u << 29)) { ops = cg_p + 6; n_ops = cg_len; }
-        }
-    }
-
-    // ---- get_cigar_stats()[0] (GCI.py:157-162): base totals per op ------------------------------
-    int64_t sM = 0, sI = 0, sD = 0, sN = 0, sS = 0, sE = 0, sX = 0;
-    for (uint64_t k = gl; k < n_ops; k += G) {
-        const uint32_t v = ld_u32(ops + 4 * k);
-        const int64_t len = v >> 4;
-        const uint32_t op = v & 0xF;
-        sM += op == 0 ? len : 0;
-        sI += op == 1 ? len : 0;
-        sD += op == 2 ? len : 0;
-        sN += op == 3 ? len : 0;
-        sS += op == 4 ? len : 0;
-        sE += op == 7 ? len : 0;
-        sX += op == 8 ? len : 0;
-    }
-    sM = group_sum_i64<G>(sM); sI = group_sum_i64<G>(sI); sD = group_sum_i64<G>(sD); sN = group_sum_i64<G>(sN);
-    sS = group_sum_i64<G>(sS); sE = group_sum_i64<G>(sE); sX = group_sum_i64<G>(sX);
-
-    if (gl != 0) return;        // the rest is scalar per record
-
-    // ---- get_tag('NM') (GCI.py:163) ---------------------------------------------------------------
-    if (!nm_p) { report(status, rec, GCI_E_NO_NM); out[rec] = r; return; }
-    int64_t NM;
-    switch (nm_p[0]) {
-    case 'c': NM = (int8_t)nm_p[1]; break;
-    case 'C': NM = nm_p[1]; break;
-    case 's': NM = (int16_t)ld_u16(nm_p + 1); break;
-    case 'S': NM = ld_u16(nm_p + 1); break;
-    case 'i': NM = ld_i32(nm_p + 1); break;
-    case 'I': NM = ld_u32(nm_p + 1); break;
-    default: report(status, rec, GCI_E_BAD_NM_TYPE); out[rec] = r; return;
-    }
-    const int64_t mm = NM - (sI + sD);                                             // GCI.py:164
-    const int64_t den1 = sM + sE + sX + sI + sS, den2 = sM + sE + sX + sI + sD;
-    if (den1 == 0) { report(status, rec, GCI_E_ZERO_DIV); out[rec] = r; return; }
-    // Python's `and` short-circuits: the identity division only runs when the clip test passed
-    if (!((double)sS / (double)den1 <= clip_percent)) { out[rec] = r; return; }   // GCI.py:165
-    if (den2 == 0) { report(status, rec, GCI_E_ZERO_DIV); out[rec] = r; return; }
-    if (!((double)(sM + sE + sX - mm) / (double)den2 >= iden_percent)) { out[rec] = r; return; }
-    if (n_cigar == 0) { report(status, rec, GCI_E_NO_END); out[rec] = r; return; }
-    const int64_t rlen = sM + sD + sN + sE + sX;
-    r.contig = ref_sel[ref_id];
-    r.start = pos;
-    r.end = (int32_t)((int64_t)pos + (rlen > 0 ? rlen : 1));                        // bam_endpos
-    r.qlen = l_seq;                                                                // query_length
-    r.flags = GCI_REC_PASS | (mapq >= mq_cutoff ? GCI_REC_HQ : 0);                 // GCI.py:166-168
-    out[rec] = r;
 }
 
 extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
@@ -196,17 +430,26 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                               uint64_t* d_status)
 {
     if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
+    GCI_TRY(gci_ensure(ctx, ctx->long_items, (size_t)(n_rec + 4) * 4));
+    uint32_t* n_slow = (uint32_t*)ctx->long_items.p;           // [0] = counter, [1..] = queued record indices
+    uint32_t* slow_list = n_slow + 1;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(n_slow, 0, 4, ctx->stream));
     if (n_rec == 0) return GCI_OK;
-    constexpr int G = 16;
-    const uint64_t threads = (uint64_t)n_rec * G;
-    const uint32_t grid = (uint32_t)((threads + BLOCK - 1) / BLOCK);
-    { ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
-    hipLaunchKernelGGL(k_bam_filter<G>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_bam, n_bytes, d_rec_off, n_rec,
-                       d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base, d_out,
-                       (unsigned long long*)d_status);
-    }
+    ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
+    const uint32_t per_block = BLOCK / G;
+    hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(BLOCK), 0, ctx->stream, d_bam, n_bytes,
+                       d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base,
+                       d_out, (unsigned long long*)d_status, slow_list, n_slow
+#ifdef GCI_K1_TRACE
+                       , (unsigned long long*)strtoull(getenv("GCI_K1_TRACE_PTR") ? getenv("GCI_K1_TRACE_PTR") : "0", nullptr, 0)
+#endif
+                       );
     LAUNCHCHK("k_bam_filter");
+    hipLaunchKernelGGL(k_bam_filter_slow, dim3(n_rec < 2048u ? n_rec : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam,
+                       d_rec_off, d_ref_sel, (const uint32_t*)slow_list, (const uint32_t*)n_slow, mq_cutoff, clip_percent,
+                       iden_percent, rec_idx_base, d_out, (unsigned long long*)d_status);
+    LAUNCHCHK("k_bam_filter_slow");
     return GCI_OK;
 }
 
@@ -227,4 +470,3 @@ extern "C" uint64_t gci_name_hash(const uint8_t* name, uint32_t len)
     }
     return gci_hash_finish(acc, len);
 }
-

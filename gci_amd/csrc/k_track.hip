@@ -84,11 +84,12 @@ extern "C" int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_su
     if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
     if (ctx->n_tiles == 0) { HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)ctx->n_contigs * 8, ctx->stream)); return GCI_OK; }
     ProfScope _ps(ctx, GCI_PROF_DEPTH_SUM);
+    HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)ctx->n_contigs * 8, ctx->stream));
     hipLaunchKernelGGL(k_tile_sum, dim3((uint32_t)ctx->n_tiles), dim3(BLOCK), 0, ctx->stream, d_depth,
                        (long long*)ctx->tile_sum.p);
     LAUNCHCHK("k_tile_sum");
-    hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs), dim3(BLOCK), 0, ctx->stream,
-                       (const long long*)ctx->tile_sum.p, (const int64_t*)ctx->d_tile_first.p, (long long*)d_sums);
+    hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs, REDUCE_SPLIT), dim3(BLOCK), 0, ctx->stream,
+                       (const long long*)ctx->tile_sum.p, (const int64_t*)ctx->d_tile_first.p, (unsigned long long*)d_sums);
     LAUNCHCHK("k_reduce_tiles");
     return GCI_OK;
 }
@@ -106,7 +107,7 @@ extern "C" int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_su
 __global__ __launch_bounds__(BLOCK) void k_issue_scan(const int32_t* __restrict__ depth,
                                                       const gci_window* __restrict__ win,
                                                       const int64_t* __restrict__ win_tile_first, int32_t n_win,
-                                                      double lo, double hi, unsigned long long* __restrict__ keys,
+                                                      int32_t lo, int32_t hi, unsigned long long* __restrict__ keys,
                                                       uint32_t cap, uint32_t* __restrict__ n_keys)
 {
     const int t = threadIdx.x, lane = t & 63;
@@ -120,14 +121,11 @@ __global__ __launch_bounds__(BLOCK) void k_issue_scan(const int32_t* __restrict_
         const int32_t d[4] = {v.x, v.y, v.z, v.w};
         bool g[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double x = (double)d[k];
-            g[k] = (p + k >= W.begin) && (p + k < W.end) && (lo < x) && (x <= hi);
-        }
+        for (int k = 0; k < 4; k++) g[k] = (p + k >= W.begin) && (p + k < W.end) && (d[k] >= lo) && (d[k] <= hi);
         int gp = __shfl_up((int)g[3], 1, 64);
         if (lane == 0) {
             gp = 0;
-            if (p - 1 >= W.begin && p - 1 < W.end) { const double x = (double)depth[p - 1]; gp = (lo < x) && (x <= hi); }
+            if (p - 1 >= W.begin && p - 1 < W.end) { const int32_t x = depth[p - 1]; gp = (x >= lo) && (x <= hi); }
         }
         if (!(g[0] | g[1] | g[2] | g[3] | (bool)gp)) continue;
         bool prev = (bool)gp;
@@ -153,8 +151,9 @@ static int issue_scan_launch(gci_ctx* ctx, const int32_t* d_depth, uint32_t n_wi
     HIPCHK(hipMemsetAsync(d_n_keys, 0, 4, ctx->stream));
     if (n_tiles == 0) return GCI_OK;
     ProfScope _ps(ctx, GCI_PROF_ISSUE_SCAN);
+    const IntRange rg = gci_int_range(lo, hi);
     hipLaunchKernelGGL(k_issue_scan, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, d_depth,
-                       (const gci_window*)ctx->win.p, (const int64_t*)ctx->win_tile_first.p, (int32_t)n_win, lo, hi,
+                       (const gci_window*)ctx->win.p, (const int64_t*)ctx->win_tile_first.p, (int32_t)n_win, rg.lo, rg.hi,
                        (unsigned long long*)d_keys, cap, d_n_keys);
     LAUNCHCHK("k_issue_scan");
     return GCI_OK;
@@ -254,20 +253,22 @@ __global__ __launch_bounds__(BLOCK) void k_text_write(const int32_t* __restrict_
                                                       const int64_t* __restrict__ tile_first,
                                                       const int64_t* __restrict__ len, int32_t n_contigs,
                                                       const uint64_t* __restrict__ tile_off, uint8_t* __restrict__ out,
-                                                      uint64_t cap)
+                                                      uint64_t cap, const uint32_t* __restrict__ g_lut)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[TEXT_STAGE];
-    __shared__ uint32_t wtot[BLOCK / 64];
+    __shared__ uint32_t wtot[4][BLOCK / 64];
+    __shared__ uint32_t lut[TEXT_LUT];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    text_lut_load(lut, g_lut, t);
     const int32_t c = contig_of_tile(tile_first, n_contigs, blockIdx.x);
     const int64_t valid = len[c] - ((int64_t)blockIdx.x - tile_first[c]) * TILE;
     const int4* base = reinterpret_cast<const int4*>(depth + (size_t)blockIdx.x * TILE);
-    uint64_t dst = tile_off[blockIdx.x];
-    for (int j = 0; j < 4; j++) {
-        const int4 q = base[j * BLOCK + t];
-        const uint32_t v[4] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w};
-        dst += text_round(v, (int64_t)(j * BLOCK + t) * 4, valid, stage, wtot, out, dst, cap, t, lane, wave);
-    }
+    int4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = base[j * BLOCK + t];
+    __syncthreads();
+    if (valid >= TILE) text_tile<true>(v, valid, stage, wtot, lut, out, tile_off[blockIdx.x], cap, t, lane, wave);
+    else text_tile<false>(v, valid, stage, wtot, lut, out, tile_off[blockIdx.x], cap, t, lane, wave);
 }
 
 extern "C" int gci_depth_text_size(gci_ctx* ctx, const int32_t* d_depth, uint64_t* d_contig_off)
@@ -299,7 +300,7 @@ extern "C" int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_
     ProfScope _ps(ctx, GCI_PROF_TEXT_WRITE);
     hipLaunchKernelGGL(k_text_write, dim3((uint32_t)ctx->n_tiles), dim3(BLOCK), 0, ctx->stream, d_depth,
                        (const int64_t*)ctx->d_tile_first.p, (const int64_t*)ctx->d_len.p, ctx->n_contigs,
-                       (const uint64_t*)ctx->tile_u64.p, d_out, cap);
+                       (const uint64_t*)ctx->tile_u64.p, d_out, cap, (const uint32_t*)ctx->text_lut.p);
     LAUNCHCHK("k_text_write");
     return GCI_OK;
 }

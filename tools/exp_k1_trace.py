@@ -1,0 +1,32 @@
+"""Phase timestamps (shader clock) inside k_bam_filter, built with -DGCI_K1_TRACE into a separate .so."""
+import sys, subprocess, os, ctypes, numpy as np, torch
+sys.path.insert(0, '.')
+from gci_amd import build, synth, _lib
+so = "/tmp/libgci_trace.so"
+subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGCI_K1_TRACE", "-o", so] + build.SOURCES, check=True)
+_lib.LIB_PATH = so
+from gci_amd.device import Engine
+e = Engine(0)
+L = 61_707_364
+rs = synth.simulate_reads((("chr19", L),), 40, "hifi", seed=synth.seed_for(2, 0))
+stream, offs = synth.to_bam_stream(rs)
+e.set_layout([L])
+d_bam, d_off = e.to_device(stream), e.to_device(offs)
+sel = e.to_device(np.zeros(1, np.int32))
+out = torch.empty((len(rs), 32), dtype=torch.uint8, device=e.device)
+nb = (len(rs) + 63) // 64
+trace = torch.zeros(nb * 8, dtype=torch.int64, device=e.device)
+os.environ["GCI_K1_TRACE_PTR"] = str(trace.data_ptr())
+for _ in range(3):
+    e.bam_filter(d_bam, d_off, sel, 30, 50, 0.1, 0.9, out=out, check=False)
+torch.cuda.synchronize()
+tr = trace.cpu().numpy().reshape(nb, 8)
+t0 = tr[:, 0].min()
+rel = (tr - tr[:, :1])
+ok = tr[:, 7] > 0
+print("blocks", nb, "kernel span (cycles)", int(tr[:, 7].max() - t0))
+for i in range(1, 8):
+    v = rel[ok][:, i]
+    print("phase %d: median %8.0f  p90 %8.0f  max %8.0f cycles since block start" % (i, np.median(v), np.percentile(v, 90), v.max()))
+starts = np.sort(tr[:, 0] - t0)
+print("block start times: p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(starts, [10, 50, 90, 100]).astype(int)))
