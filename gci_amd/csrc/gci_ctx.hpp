@@ -306,10 +306,32 @@ __device__ __forceinline__ void text_lut_load(uint32_t* lut, const uint32_t* __r
     for (uint32_t x = t; x < TEXT_LUT; x += BLOCK) lut[x] = g_lut[x];
 }
 
-// write the decimal lines of 4 consecutive elements into the staging buffer at byte offset o
+__device__ __forceinline__ void lds_put_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }   // any alignment
+
+// write the decimal lines of 4 consecutive elements into the staging buffer at byte offset o.
+// Common case -- all four below 1000 with the same width W (digits + newline): the 4 * W bytes are assembled
+// from the table words in registers and leave as W unaligned dword stores (gfx950 LDS takes any alignment).
 __device__ __forceinline__ void text_put4(const uint32_t (&v)[4], const uint32_t (&nd)[4], uint32_t o, uint8_t* stage,
                                           const uint32_t* lut)
 {
+    const uint32_t W = nd[0];
+    const bool uniform = W >= 2u && nd[1] == W && nd[2] == W && nd[3] == W &&
+                         v[0] < TEXT_LUT && v[1] < TEXT_LUT && v[2] < TEXT_LUT && v[3] < TEXT_LUT;
+    if (uniform) {
+        const uint32_t w0 = lut[v[0]], w1 = lut[v[1]], w2 = lut[v[2]], w3 = lut[v[3]];
+        if (W == 3u) {
+            lds_put_u32(stage + o, w0 | (w1 << 24));
+            lds_put_u32(stage + o + 4, (w1 >> 8) | (w2 << 16));
+            lds_put_u32(stage + o + 8, (w2 >> 16) | (w3 << 8));
+        } else if (W == 2u) {
+            lds_put_u32(stage + o, w0 | (w1 << 16));
+            lds_put_u32(stage + o + 4, w2 | (w3 << 16));
+        } else {
+            lds_put_u32(stage + o, w0); lds_put_u32(stage + o + 4, w1);
+            lds_put_u32(stage + o + 8, w2); lds_put_u32(stage + o + 12, w3);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (!nd[k]) continue;

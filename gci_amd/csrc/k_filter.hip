@@ -28,6 +28,7 @@
 #define HEADP (HEAD + 16)        // staged from the 16-byte boundary below the record start
 #define AUXP (AUXB + 16)
 #define ROW (HEADP + AUXP)
+#define KB 128                    // threads per workgroup of the fast path (32 records)
 
 __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec, int code)
 {
@@ -90,9 +91,28 @@ __device__ __forceinline__ void stage16(uint8_t* dst, const uint8_t* __restrict_
     *reinterpret_cast<uint4*>(dst) = v;
 }
 
+// the 16 bytes at aligned offset `at`, zero past the end of the stream (the last, partial chunk)
+__device__ __forceinline__ uint4 load16_tail(const uint8_t* __restrict__ bam, uint64_t at, uint64_t n_bytes)
+{
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) if (at + i < n_bytes) w[i >> 2] |= (uint32_t)bam[at + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-__global__ __launch_bounds__(BLOCK) void k_bam_filter(
+// lanes of one wave exchange data through LDS: the LDS unit executes a wave's operations in order, so only the
+// compiler has to be kept from moving accesses across this point
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define REF_LDS 2048             // refID -> selected-contig table kept in LDS up to this many references
+
+__global__ __launch_bounds__(KB) void k_bam_filter(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status,
@@ -103,78 +123,84 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter(
     )
 {
 #ifdef GCI_K1_TRACE
-#define TR(i) do { if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#define TR(i) do { if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
 #else
 #define TR(i) do {} while (0)
 #endif
     TR(0);
-    __shared__ __attribute__((aligned(16))) uint8_t stage[BLOCK / G][ROW];           // 24 KiB
-    __shared__ unsigned long long tot_lds[BLOCK / G][NSLOT];                          // 5 KiB: op totals per record
+    __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
+    __shared__ unsigned long long tot_lds[KB / G][NSLOT];                   // op totals per record
+    __shared__ int32_t sel_lds[REF_LDS];
+    __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
     const int t = threadIdx.x;
     const int gl = t & (G - 1), grp = t / G;
-    const uint32_t rec = (uint32_t)((uint64_t)blockIdx.x * (BLOCK / G) + grp);
+    const uint32_t rec = (uint32_t)((uint64_t)blockIdx.x * (KB / G) + grp);
     uint8_t* row = stage[grp];
 
-    // ---- stage the head ---------------------------------------------------------------------------------------
+    // ---- independent loads first: the record offset, then (one round trip later) its head ------------------------
     bool live = rec < n_rec;
-    uint64_t off = 0;
-    if (live) {
-        off = rec_off[rec];
-        live = off + 36 <= n_bytes;
-        if (live) {
-            const uint64_t a0 = off & ~15ull;                       // aligned loads; the record starts at row[off & 15]
-#pragma unroll
-            for (int i = 0; i < (HEADP / 16 + G - 1) / G; i++) {
-                const int c = gl + G * i;
-                if (c < HEADP / 16) stage16(row + 16 * c, bam, a0 + 16ull * c, n_bytes);
-            }
-        } else if (gl == 0) {
+    const uint64_t off = live ? rec_off[rec] : 0;
+    const bool sel_in_lds = n_ref <= REF_LDS;
+    if (sel_in_lds) for (int i = t; i < n_ref; i += KB) sel_lds[i] = ref_sel[i];
+    for (int i = t; i < 256; i += KB) {
+        const char c = (char)i;
+        aux_sz[i] = (c == 'A' || c == 'c' || c == 'C') ? 1 : (c == 's' || c == 'S') ? 2 : (c == 'i' || c == 'I' || c == 'f') ? 4 : 0;
+    }
+    if (gl < NSLOT / 2) { tot_lds[grp][2 * gl] = 0ull; tot_lds[grp][2 * gl + 1] = 0ull; }
+    if (gl == G - 1) { for (int s = 2 * G; s < NSLOT; s++) tot_lds[grp][s] = 0ull; }
+    if (live && off + 36 > n_bytes) {
+        if (gl == 0) {
             gci_rec r; r.name_hash = 0; r.contig = -1; r.start = r.end = r.qlen = 0; r.rec_idx = rec + rec_idx_base;
             r.mapq = 0; r.flags = 0; r.name_len = 0;
             report(status, rec, GCI_E_MALFORMED); out[rec] = r;
         }
+        live = false;
     }
-    if (gl < NSLOT / 2) { tot_lds[grp][2 * gl] = 0ull; tot_lds[grp][2 * gl + 1] = 0ull; }
-    if (gl == G - 1 && NSLOT / 2 > G - 1) { for (int s = 2 * (G - 1) + 2; s < NSLOT; s++) tot_lds[grp][s] = 0ull; }
+    if (live) {
+        const uint64_t a0 = off & ~15ull;                       // aligned loads; the record starts at row[off & 15]
+#pragma unroll
+        for (int i = 0; i < (HEADP / 16 + G - 1) / G; i++) {
+            const int c = gl + G * i;
+            if (c < HEADP / 16) stage16(row + 16 * c, bam, a0 + 16ull * c, n_bytes);
+        }
+    }
     TR(1);
-    __syncthreads();
+    __syncthreads();                                            // the two small tables; (also covers the staged heads)
     TR(2);
+    if (!live) return;
 
     // ---- core fields (GCI.py:152-156) ---------------------------------------------------------------------------
     gci_rec r;
     r.name_hash = 0; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + rec_idx_base; r.mapq = 0;
     r.flags = 0; r.name_len = 0;
-    int32_t block_size = 0, ref_id = -1, pos = 0, l_seq = 0;
-    uint32_t l_read_name = 0, n_cigar = 0, flag = 0;
-    int mapq = 0;
-    uint64_t aux_off = 0, rec_end = 0;
-    bool want = false;                       // record passes the flag / MAPQ tests and needs the rest
     const uint8_t* hd = row + (off & 15ull);          // record byte k is hd[k]
-    if (live) {
-        block_size = (int32_t)lds_u32(hd);
-        ref_id = (int32_t)lds_u32(hd + 4);
-        pos = (int32_t)lds_u32(hd + 8);
-        const uint32_t w12 = lds_u32(hd + 12), w16 = lds_u32(hd + 16);
-        l_read_name = w12 & 0xFF;
-        mapq = (w12 >> 8) & 0xFF;
-        n_cigar = w16 & 0xFFFF;
-        flag = w16 >> 16;
-        l_seq = (int32_t)lds_u32(hd + 20);
-        rec_end = off + 4 + (uint64_t)(uint32_t)block_size;
-        aux_off = off + 36 + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
-        r.mapq = (uint8_t)mapq;
-        if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) {
-            if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
-            live = false;
-        } else {
-            // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
-            const bool sel = ref_id >= 0 && ref_id < n_ref && ref_sel[ref_id] >= 0;
-            want = sel && !(flag & (0x4u | 0x100u | 0x800u)) && mapq >= map_qual;
-            if (!want && gl == 0) out[rec] = r;
-        }
+    const int32_t block_size = (int32_t)lds_u32(hd);
+    const int32_t ref_id = (int32_t)lds_u32(hd + 4);
+    const int32_t pos = (int32_t)lds_u32(hd + 8);
+    const uint32_t w12 = lds_u32(hd + 12), w16 = lds_u32(hd + 16);
+    const uint32_t l_read_name = w12 & 0xFF;
+    const int mapq = (w12 >> 8) & 0xFF;
+    const uint32_t n_cigar = w16 & 0xFFFF;
+    const uint32_t flag = w16 >> 16;
+    const int32_t l_seq = (int32_t)lds_u32(hd + 20);
+    const uint64_t rec_end = off + 4 + (uint64_t)(uint32_t)block_size;
+    const uint64_t aux_off = off + 36 + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+    r.mapq = (uint8_t)mapq;
+    if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) {
+        if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
+        return;
     }
-    // ---- stage the head of the aux block --------------------------------------------------------------------------
-    if (live && want) {
+    // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
+    int32_t contig = -1;
+    if (ref_id >= 0 && ref_id < n_ref) contig = sel_in_lds ? sel_lds[ref_id] : ref_sel[ref_id];
+    if (contig < 0 || (flag & (0x4u | 0x100u | 0x800u)) || mapq < map_qual) {
+        if (gl == 0) out[rec] = r;
+        return;
+    }
+    TR(8);
+    // ---- second (and last) dependent round trip: the aux head and the CIGAR words behind the staged head ---------
+    const uint32_t cig_at = 36 + l_read_name;                       // byte offset of the CIGAR in the record
+    {
         const uint64_t a0 = aux_off & ~15ull;
 #pragma unroll
         for (int i = 0; i < (AUXP / 16 + G - 1) / G; i++) {
@@ -182,17 +208,68 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter(
             if (c < AUXP / 16) stage16(row + HEADP + 16 * c, bam, a0 + 16ull * c, n_bytes);
         }
     }
+    TR(9);
+    const bool odd = l_read_name > HEAD - 36 || n_cigar > LONG_OPS;
+    const uint32_t staged_ops = odd ? 0u : min(n_cigar, (HEAD - cig_at) / 4u);
+    unsigned long long* tot = tot_lds[grp];
+    if (!odd) {
+        // CIGAR words behind the staged head, straight from global memory.  Unaligned vector loads from global
+        // memory are served, but ~100x slower than aligned ones on gfx950 (tools/exp_k1_trace.py), and a CIGAR
+        // starts at 36 + l_read_name: so each lane walks a CONTIGUOUS quarter of the tail with 16-byte ALIGNED
+        // loads and re-aligns in registers (v_alignbyte), carrying the previous chunk over.
+        const uint32_t n_tail = n_cigar - staged_ops;
+        const uint32_t per = (n_tail + G - 1) / G;
+        const uint32_t k0 = staged_ops + gl * per, k1 = min(n_cigar, k0 + per);
+        if (k0 < k1) {
+            const uint64_t p0 = off + cig_at + 4ull * k0;                   // byte offset of this lane's first op
+            const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
+            uint64_t a = p0 & ~15ull;
+            const uint64_t lim = n_bytes & ~15ull;                           // aligned chunks fully inside the stream
+            auto ld = [&](uint64_t at) { return at < lim ? *reinterpret_cast<const uint4*>(bam + at) : load16_tail(bam, at, n_bytes); };
+            auto take = [&](const uint4& lo, const uint4& hi, uint32_t m) {
+                const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
+                    const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
+                    const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
+                    if ((uint32_t)j < m) { const uint32_t op = v & 0xF; atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4)); }
+                }
+            };
+            // the first three chunks are requested together (a lane's share of a HiFi tail is ~6 ops: one round
+            // trip); longer tails continue with one new chunk per four ops
+            const uint32_t nch = (sh + 4u * (k1 - k0) + 15u) >> 4;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4 c0 = ld(a), c1 = nch > 1 ? ld(a + 16) : z, c2 = nch > 2 ? ld(a + 32) : z;
+            uint32_t k = k0;
+            take(c0, c1, min(4u, k1 - k)); k += 4;
+            if (k < k1) { take(c1, c2, min(4u, k1 - k)); k += 4; }
+            uint4 lo = c2;
+            a += 32;
+            for (; k < k1; k += 4) {
+                a += 16;
+                const uint4 hi = ld(a);
+                take(lo, hi, min(4u, k1 - k));
+                lo = hi;
+            }
+        }
+        TR(10);
+        // staged part of the CIGAR (GCI.py:157-162: get_cigar_stats()[0], base totals per op code)
+        for (uint32_t k = gl; k < staged_ops; k += G) {
+            const uint32_t v = lds_u32(hd + cig_at + 4 * k);
+            const uint32_t op = v & 0xF;
+            atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4));
+        }
+    }
     TR(3);
-    __syncthreads();
+    wave_lds_fence();                                               // aux head visible to the 4 lanes of the record
     TR(4);
-    if (!(live && want)) return;
 
     // ---- anything the staged window cannot answer goes to the slow path -------------------------------------------
-    const uint32_t cig_at = 36 + l_read_name;                       // byte offset of the CIGAR in the record
-    bool slow = l_read_name > HEAD - 36 || n_cigar > LONG_OPS;
+    bool slow = odd;
     // htslib's long-CIGAR placeholder: op0 == <l_seq>S and a CG:B,I tag somewhere in the aux block
     if (!slow && n_cigar > 0 && pos >= 0) {
-        const uint32_t op0 = cig_at + 4 <= HEAD ? lds_u32(hd + cig_at) : ld_u32(bam + off + cig_at);
+        const uint32_t op0 = lds_u32(hd + cig_at);
         if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)l_seq) slow = true;      // (rare: let the slow path look for CG)
     }
     // ---- aux walk in the staged window: first NM (bam_aux_get semantics) ------------------------------------------
@@ -204,25 +281,36 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter(
         uint32_t q = 0;
         for (;;) {
             if (q + 3 > aux_len) { walked_all = aux_off + q + 3 > rec_end; break; }          // no further complete tag header
-            const uint32_t tag = (uint32_t)ax[q] | ((uint32_t)ax[q + 1] << 8);
-            const uint8_t ty = ax[q + 2];
-            uint32_t sz;
-            switch (ty) {
-            case 'A': case 'c': case 'C': sz = 1; break;
-            case 's': case 'S': sz = 2; break;
-            case 'i': case 'I': case 'f': sz = 4; break;
-            default: sz = 0xFFFFFFFFu;                                                  // Z, H, B, malformed: not decided here
-            }
+            const uint32_t w = lds_u32(ax + q);                                          // tag[2] | type | first value byte
+            const uint32_t tag = w & 0xFFFF;
+            const uint8_t ty = (uint8_t)(w >> 16);
+            uint32_t sz = aux_sz[ty];
             if (tag == (uint32_t)('N' | ('M' << 8))) {
-                if (sz == 0xFFFFFFFFu || q + 3 + sz > aux_len) break;                    // odd type / value not staged: slow path
+                if (sz == 0 || q + 3 + sz > aux_len) break;                              // odd type / value not staged: slow path
                 have_nm = nm_value(ax + q + 2, NM);
                 nm_bad = !have_nm; have_nm = true;
                 break;
             }
-            if (sz == 0xFFFFFFFFu || q + 3 + sz > aux_len) break;                        // variable-size tag or window end
+            if (sz == 0) {
+                // variable-size values, decided here only if they end inside the staged window
+                if (ty == 'Z' || ty == 'H') {
+                    uint32_t e = q + 3;
+                    while (e < aux_len && ax[e]) e++;
+                    if (e >= aux_len) break;
+                    sz = e - (q + 3) + 1;
+                } else if (ty == 'B' && q + 8 <= aux_len) {
+                    const uint8_t sub = ax[q + 3];
+                    const uint32_t es = aux_sz[sub] == 1 && sub != 'A' ? 1u : (sub == 's' || sub == 'S') ? 2u
+                                      : (sub == 'i' || sub == 'I' || sub == 'f') ? 4u : 0u;
+                    const uint32_t cnt = lds_u32(ax + q + 4);
+                    if (es == 0 || cnt > AUXB) break;
+                    sz = 5 + cnt * es;
+                } else break;
+            }
+            if (q + 3 + sz > aux_len) break;                                             // window end
             q += 3 + sz;
         }
-        if (!have_nm && !walked_all) slow = true;          // NM (if any) lies beyond what was staged or behind a string tag
+        if (!have_nm && !walked_all) slow = true;          // NM (if any) lies beyond what was staged
     }
     if (slow) {
         if (gl == 0) { slow_list[atomicAdd(n_slow, 1u)] = rec; }
@@ -257,33 +345,12 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter(
     r.name_len = (uint16_t)name_len;
 
     TR(6);
-    // ---- get_cigar_stats()[0] (GCI.py:157-162): base totals per op code ---------------------------------------------
-    unsigned long long* tot = tot_lds[grp];
-    const uint32_t staged_ops = cig_at + 4 <= HEAD ? min(n_cigar, (HEAD - cig_at) / 4u) : 0u;
-    for (uint32_t k = gl; k < staged_ops; k += G) {
-        const uint32_t v = lds_u32(hd + cig_at + 4 * k);
-        const uint32_t op = v & 0xF;
-        atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4));
-    }
-    {   // the rest straight from global memory, 4 ops (16 bytes) per lane and step
-        const uint8_t* gc = bam + off + cig_at;
-        for (uint32_t k = staged_ops + 4 * gl; k < n_cigar; k += 4 * G) {
-            uint32_t v[4] = {0, 0, 0, 0};
-            const uint32_t m = min(4u, n_cigar - k);
-            if (m == 4) __builtin_memcpy(v, gc + 4ull * k, 16);
-            else for (uint32_t j = 0; j < m; j++) v[j] = ld_u32(gc + 4ull * (k + j));
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                if (j < m) { const uint32_t op = v[j] & 0xF; atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v[j] >> 4)); }
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
     if (gl != 0) return;        // the rest is scalar per record; the LDS operations of a wave complete in order
     int64_t tt[NSLOT];
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) tt[s] = (int64_t)tot[s];
-    const int st = decide(r, tt, have_nm, nm_bad, NM, pos, ref_sel[ref_id], l_seq, n_cigar, mapq, mq_cutoff, clip_percent,
+    const int st = decide(r, tt, have_nm, nm_bad, NM, pos, contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent,
                           iden_percent);
     if (st != GCI_OK) report(status, rec, st);
     out[rec] = r;
@@ -437,8 +504,8 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
     HIPCHK(hipMemsetAsync(n_slow, 0, 4, ctx->stream));
     if (n_rec == 0) return GCI_OK;
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
-    const uint32_t per_block = BLOCK / G;
-    hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(BLOCK), 0, ctx->stream, d_bam, n_bytes,
+    const uint32_t per_block = KB / G;
+    hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(KB), 0, ctx->stream, d_bam, n_bytes,
                        d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base,
                        d_out, (unsigned long long*)d_status, slow_list, n_slow
 #ifdef GCI_K1_TRACE
