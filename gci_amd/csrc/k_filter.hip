@@ -12,8 +12,8 @@
 //     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162): one fire-and-forget
 //     ds_add_u64 per op into a per-record LDS row indexed by op code -> the two IEEE f64 divisions of
 //     GCI.py:165 -> 32-byte compact record.
-//   slow path (k_bam_filter_slow), one 256-thread workgroup per queued record, everything from global
-//     memory: CIGARs of more than LONG_OPS operations (ultra-long ONT reads and htslib's CG:B,I restore),
+//   slow path (k_bam_filter_slow), one wave per queued record, everything from global memory with
+//     naturally aligned loads only: CIGARs of more than LONG_OPS operations (ultra-long ONT reads and htslib's CG:B,I restore),
 //     records whose NM tag does not show up in the staged part of the aux block, names longer than the
 //     staged head.  Same decisions, same status codes.
 // SEQ and QUAL are skipped by pointer arithmetic and never touched.
@@ -22,7 +22,7 @@
 
 #define G 4                      // lanes per record on the fast path
 #define NSLOT 10                 // op codes 0..8 (M I D N S H P = X) + one slot for everything else
-#define LONG_OPS 4096u
+#define LONG_OPS 512u
 #define HEAD 256                 // staged bytes from the record start
 #define AUXB 128                 // staged bytes from the aux start
 #define HEADP (HEAD + 16)        // staged from the 16-byte boundary below the record start
@@ -357,7 +357,12 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     TR(7);
 }
 
-// ---- slow path: one workgroup per queued record, everything read from global memory -----------------------------
+// ---- slow path: one WAVE per queued record, everything read from global memory --------------------------------
+// Only naturally aligned global loads: bytes for the scalar fields and the aux walk, 16-byte aligned chunks
+// (re-aligned in registers) for the CIGAR.
+
+__device__ __forceinline__ uint32_t rd16b(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t rd32b(const uint8_t* p) { return rd16b(p) | (rd16b(p + 2) << 16); }
 
 // size of an aux value of type t at p; -1 if malformed / past end
 __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_t* end, uint8_t t)
@@ -368,14 +373,13 @@ __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_
     case 'i': case 'I': case 'f': return 4;
     case 'Z': case 'H': {
         const uint8_t* q = p;
-        while (q + 4 <= end && !has_zero_byte(ld_u32(q))) q += 4;
         while (q < end && *q) q++;
         return q < end ? (q - p) + 1 : -1;
     }
     case 'B': {
         if (p + 5 > end) return -1;
         const uint8_t sub = p[0];
-        const int64_t n = ld_u32(p + 1);
+        const int64_t n = rd32b(p + 1);
         const int64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2
                          : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : -1;
         return es < 0 ? -1 : 5 + n * es;
@@ -384,107 +388,116 @@ __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_
     }
 }
 
-struct SlowHead {                 // what thread 0 parses for the whole workgroup
-    const uint8_t* ops;
-    uint32_t n_ops, n_cigar, name_len;
-    int64_t nm;
-    int32_t pos, contig, l_seq, mapq;
-    int have_nm, nm_bad;
-    uint64_t name_hash;
-};
-
 __global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
-    const uint8_t* __restrict__ bam, const uint64_t* __restrict__ rec_off, const int32_t* __restrict__ ref_sel,
-    const uint32_t* __restrict__ slow_list, const uint32_t* __restrict__ n_slow, int mq_cutoff, double clip_percent,
-    double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status)
+    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
+    const int32_t* __restrict__ ref_sel, const uint32_t* __restrict__ slow_list, const uint32_t* __restrict__ n_slow,
+    int mq_cutoff, double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out,
+    unsigned long long* __restrict__ status)
 {
-    __shared__ SlowHead h;
-    __shared__ long long part[BLOCK / 64][NSLOT];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lane = threadIdx.x & 63;
     const uint32_t n = *n_slow;
-    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+    const uint32_t waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t it = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); it < n; it += waves) {
         const uint32_t rec = slow_list[it];
-        __syncthreads();
-        if (t == 0) {
-            // the fast path has already validated the record's bounds and passed its flag / MAPQ tests
-            const uint8_t* p = bam + rec_off[rec];
-            const int32_t block_size = ld_i32(p);
-            const int32_t ref_id = ld_i32(p + 4);
-            h.pos = ld_i32(p + 8);
-            const uint32_t l_read_name = p[12];
-            h.mapq = p[13];
-            h.n_cigar = ld_u16(p + 16);
-            h.l_seq = ld_i32(p + 20);
-            h.contig = ref_sel[ref_id];
-            const uint8_t* name = p + 36;
-            const uint8_t* rec_end = p + 4 + block_size;
-            const uint8_t* cig = name + l_read_name;
-            const uint8_t* aux = cig + 4 * (uint64_t)h.n_cigar + (((uint64_t)(uint32_t)h.l_seq + 1) >> 1) + (uint64_t)(uint32_t)h.l_seq;
-            uint32_t nl = 0;
-            while (nl < l_read_name && name[nl]) nl++;
-            h.name_len = nl;
-            uint64_t acc = 0;
-            for (uint32_t k = 0; k * 8 < nl; k++) {
-                uint64_t w = 0;
-                for (int b = 0; b < 8; b++) if (k * 8 + b < nl) w |= (uint64_t)name[k * 8 + b] << (8 * b);
-                acc += gci_hash_word(w, k);
+        // the fast path has already validated the record's bounds and passed its flag / MAPQ tests;
+        // every lane parses the scalar part redundantly (same addresses: one transaction per load)
+        const uint64_t off = rec_off[rec];
+        const uint8_t* p = bam + off;
+        const int32_t block_size = (int32_t)rd32b(p);
+        const int32_t ref_id = (int32_t)rd32b(p + 4);
+        const int32_t pos = (int32_t)rd32b(p + 8);
+        const uint32_t l_read_name = p[12];
+        const int mapq = p[13];
+        const uint32_t n_cigar = rd16b(p + 16);
+        const int32_t l_seq = (int32_t)rd32b(p + 20);
+        const int32_t contig = ref_sel[ref_id];
+        const uint8_t* name = p + 36;
+        const uint8_t* rec_end = p + 4 + block_size;
+        const uint8_t* cig = name + l_read_name;
+        const uint8_t* aux = cig + 4 * (uint64_t)n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+        // query_name and its hash, lanes striding over bytes / words
+        uint32_t nul = l_read_name;
+        for (uint32_t i = lane; i < l_read_name; i += 64) if (name[i] == 0) { nul = i; break; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nul = min(nul, (uint32_t)__shfl_xor((int)nul, m, 64));
+        const uint32_t name_len = nul;
+        uint64_t acc = 0;
+        for (uint32_t k = lane; k * 8 < name_len; k += 64) {
+            uint64_t w = 0;
+            for (int b = 0; b < 8; b++) if (k * 8 + b < name_len) w |= (uint64_t)name[k * 8 + b] << (8 * b);
+            acc += gci_hash_word(w, k);
+        }
+        acc = (uint64_t)wave_sum<long long>((long long)acc);
+        // first NM, first CG (bam_aux_get semantics)
+        const uint8_t* nm_p = nullptr;
+        const uint8_t* cg_p = nullptr;
+        for (const uint8_t* q = aux; q + 3 <= rec_end;) {
+            const int64_t sz = aux_value_size(q + 3, rec_end, q[2]);
+            if (sz < 0 || q + 3 + sz > rec_end) break;
+            if (q[0] == 'N' && q[1] == 'M' && !nm_p) nm_p = q + 2;
+            if (q[0] == 'C' && q[1] == 'G' && !cg_p) cg_p = q + 2;
+            q += 3 + sz;
+        }
+        int64_t NM = 0;
+        const bool nm_bad = nm_p ? !nm_value(nm_p, NM) : false;
+        // htslib moves a >65535-op CIGAR back from CG:B,I when op0 == <l_seq>S
+        const uint8_t* ops = cig;
+        uint32_t n_ops = n_cigar;
+        if (n_cigar > 0 && pos >= 0) {
+            const uint32_t op0 = rd32b(cig);
+            if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)l_seq && cg_p && cg_p[0] == 'B' && (cg_p[1] == 'I' || cg_p[1] == 'i')) {
+                const uint32_t cg_len = rd32b(cg_p + 2);
+                if (cg_len >= n_cigar && cg_len < (1u << 29)) { ops = cg_p + 6; n_ops = cg_len; }
             }
-            h.name_hash = gci_hash_finish(acc, nl);
-            // first NM, first CG (bam_aux_get semantics)
-            const uint8_t* nm_p = nullptr;
-            const uint8_t* cg_p = nullptr;
-            for (const uint8_t* q = aux; q + 3 <= rec_end;) {
-                const int64_t sz = aux_value_size(q + 3, rec_end, q[2]);
-                if (sz < 0 || q + 3 + sz > rec_end) break;
-                if (q[0] == 'N' && q[1] == 'M' && !nm_p) nm_p = q + 2;
-                if (q[0] == 'C' && q[1] == 'G' && !cg_p) cg_p = q + 2;
-                q += 3 + sz;
-            }
-            h.have_nm = nm_p != nullptr;
-            h.nm = 0;
-            h.nm_bad = nm_p ? !nm_value(nm_p, h.nm) : 0;
-            // htslib moves a >65535-op CIGAR back from CG:B,I when op0 == <l_seq>S
-            h.ops = cig;
-            h.n_ops = h.n_cigar;
-            if (h.n_cigar > 0 && h.pos >= 0) {
-                const uint32_t op0 = ld_u32(cig);
-                if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)h.l_seq && cg_p && cg_p[0] == 'B' &&
-                    (cg_p[1] == 'I' || cg_p[1] == 'i')) {
-                    const uint32_t cg_len = ld_u32(cg_p + 2);
-                    if (cg_len >= h.n_cigar && cg_len < (1u << 29)) { h.ops = cg_p + 6; h.n_ops = cg_len; }
+        }
+        // CIGAR totals: lane handles 16-byte pieces lane, lane + 64, ... of the op array
+        long long sum[NSLOT];
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) sum[k] = 0;
+        {
+            const uint64_t p0 = (uint64_t)(ops - bam);
+            const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
+            const uint64_t a0 = p0 & ~15ull, lim = n_bytes & ~15ull;
+            // four independent chunk pairs per lane and step keep enough loads in flight for long CIGARs
+            for (uint32_t c0 = lane; 4ull * c0 < n_ops; c0 += 256) {
+                uint4 lo[4], hi[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t c = c0 + 64u * u;
+                    const uint64_t a = a0 + 16ull * c;
+                    const bool in = 4ull * c < n_ops;
+                    lo[u] = !in ? make_uint4(0, 0, 0, 0) : a < lim ? *reinterpret_cast<const uint4*>(bam + a) : load16_tail(bam, a, n_bytes);
+                    hi[u] = !in ? make_uint4(0, 0, 0, 0) : a + 16 < lim ? *reinterpret_cast<const uint4*>(bam + a + 16) : load16_tail(bam, a + 16, n_bytes);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t c = c0 + 64u * u;
+                    if (4ull * c >= n_ops) continue;
+                    const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+                    const uint32_t m = min(4u, n_ops - 4u * c);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
+                        const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
+                        const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
+                        const uint32_t op = v & 0xFu;
+                        const long long len = (uint32_t)j < m ? (long long)(v >> 4) : 0;
+#pragma unroll
+                        for (int q = 0; q < NSLOT - 1; q++) sum[q] += op == (uint32_t)q ? len : 0;
+                    }
                 }
             }
         }
-        __syncthreads();
-        long long s[NSLOT];
+        int64_t tot[NSLOT];
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) s[k] = 0;
-        const uint8_t* ops = h.ops;
-        for (uint32_t k = t; k < h.n_ops; k += BLOCK) {
-            const uint32_t v = ld_u32(ops + 4 * (uint64_t)k);
-            const uint32_t op = v & 0xFu;
-            const long long len = v >> 4;
-#pragma unroll
-            for (int q = 0; q < NSLOT - 1; q++) s[q] += op == (uint32_t)q ? len : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < NSLOT - 1; k++) s[k] = wave_sum<long long>(s[k]);
+        for (int k = 0; k < NSLOT - 1; k++) tot[k] = wave_sum<long long>(sum[k]);
+        tot[NSLOT - 1] = 0;
         if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < NSLOT - 1; k++) part[wave][k] = s[k];
-        }
-        __syncthreads();
-        if (t == 0) {
-            int64_t tot[NSLOT];
-#pragma unroll
-            for (int k = 0; k < NSLOT; k++) tot[k] = 0;
-            for (int w = 0; w < BLOCK / 64; w++)
-                for (int k = 0; k < NSLOT - 1; k++) tot[k] += part[w][k];
             gci_rec r;
-            r.name_hash = h.name_hash; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + rec_idx_base;
-            r.mapq = (uint8_t)h.mapq; r.flags = 0; r.name_len = (uint16_t)h.name_len;
-            const int st = decide(r, tot, h.have_nm != 0, h.nm_bad != 0, h.nm, h.pos, h.contig, h.l_seq, h.n_cigar, h.mapq,
-                                  mq_cutoff, clip_percent, iden_percent);
+            r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
+            r.rec_idx = rec + rec_idx_base; r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = (uint16_t)name_len;
+            const int st = decide(r, tot, nm_p != nullptr, nm_bad, NM, pos, contig, l_seq, n_cigar, mapq, mq_cutoff,
+                                  clip_percent, iden_percent);
             if (st != GCI_OK) report(status, rec, st);
             out[rec] = r;
         }
@@ -513,8 +526,8 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
 #endif
                        );
     LAUNCHCHK("k_bam_filter");
-    hipLaunchKernelGGL(k_bam_filter_slow, dim3(n_rec < 2048u ? n_rec : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam,
-                       d_rec_off, d_ref_sel, (const uint32_t*)slow_list, (const uint32_t*)n_slow, mq_cutoff, clip_percent,
+    hipLaunchKernelGGL(k_bam_filter_slow, dim3(n_rec < 8192u ? (n_rec + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam,
+                       n_bytes, d_rec_off, d_ref_sel, (const uint32_t*)slow_list, (const uint32_t*)n_slow, mq_cutoff, clip_percent,
                        iden_percent, rec_idx_base, d_out, (unsigned long long*)d_status);
     LAUNCHCHK("k_bam_filter_slow");
     return GCI_OK;
