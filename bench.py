@@ -44,14 +44,15 @@ def parse_args():
     ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="per-rank contig length (default chr19)")
     ap.add_argument("--coverage", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel HIP-event table to stderr")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-GPU record / name exchange and the all-reduce even with one rank (self-test)")
     return ap.parse_args()
 
 
 class Workload:
     """Per-rank resident inputs + preallocated outputs for one step."""
 
-    def __init__(self, eng, rank, world, contig_len, coverage):
+    def __init__(self, eng, rank, world, contig_len, coverage, exchange=False):
         import torch
         from gci_amd import synth
         self.torch = torch
@@ -77,7 +78,8 @@ class Workload:
         eng.set_layout([contig_len])                       # local track: the contig this rank owns
         cmap = np.full(world, -1, dtype=np.int32)
         cmap[rank] = 0
-        self.contig_map = eng.to_device(cmap) if world > 1 else None
+        self.exchange = exchange or world > 1
+        self.contig_map = eng.to_device(cmap) if self.exchange else None
         dev = eng.device
         self.recs = torch.empty((self.n_rec, 32), dtype=torch.uint8, device=dev)
         self.track = eng.new_track()
@@ -98,7 +100,7 @@ class Workload:
         o.d_n_keys, o.d_keys, o.key_cap = self.nkeys.data_ptr(), self.keys.data_ptr(), int(self.keys.shape[0])
         o.issue_flank, o.lo, o.hi = 15, -1.0, 0.0
         self.opts = o
-        if world > 1:
+        if self.exchange:
             self._setup_exchange()
 
     # ---- multi-GPU: every rank needs every record's (hash, interval, name) for the join ----------
@@ -120,7 +122,7 @@ class Workload:
                                self._p(self.ref_sel), self.world, 30, 50, 0.1, 0.9, self.rec_base, self._p(self.recs),
                                self._p(self.status[0:1])), "gci_bam_filter")
         jf = (JoinFile * 1)()
-        if self.world == 1:
+        if not self.exchange:
             jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
             jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
         else:
@@ -149,7 +151,7 @@ class Workload:
             self.text = self.torch.empty(total + (total >> 4) + 4096, dtype=self.torch.uint8, device=eng.device)
         chk(lib.gci_depth_build_finish(ctx, self._p(self.track), self._p(self.text), int(self.text.shape[0])),
             "gci_depth_build_finish")
-        if self.world > 1:
+        if self.exchange:
             import torch.distributed as dist
             self.totals[0] = self.sums[0]
             self.totals[1] = self.contigs[self.rank][1]
@@ -195,9 +197,15 @@ def main():
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL logs to stdout: keep it off the channel on which rank 0 prints its ONE JSON line
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "WARN"):
+            os.environ.pop("NCCL_DEBUG")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from gci_amd.build import build_hip, needs_build
     if needs_build():
@@ -208,7 +216,7 @@ def main():
     from gci_amd import _lib
     from gci_amd.device import Engine
     eng = Engine(local_rank)
-    w = Workload(eng, rank, world, args.contig_len, args.coverage)
+    w = Workload(eng, rank, world, args.contig_len, args.coverage, exchange=args.force_exchange)
 
     def fence():
         torch.cuda.synchronize()
@@ -305,8 +313,9 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
