@@ -45,14 +45,16 @@ def parse_args():
     ap.add_argument("--coverage", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="run the multi-GPU record / name exchange and the all-reduce even with one rank (self-test)")
+                    help="run the multi-GPU name check / exchange and the all-reduce even with one rank (self-test)")
+    ap.add_argument("--force-replicated", action="store_true",
+                    help="with the exchange: always take the replicated-join fallback (all-gather of records + names)")
     return ap.parse_args()
 
 
 class Workload:
     """Per-rank resident inputs + preallocated outputs for one step."""
 
-    def __init__(self, eng, rank, world, contig_len, coverage, exchange=False):
+    def __init__(self, eng, rank, world, contig_len, coverage, exchange=False, replicated=False):
         import torch
         from gci_amd import synth
         self.torch = torch
@@ -79,6 +81,7 @@ class Workload:
         cmap = np.full(world, -1, dtype=np.int32)
         cmap[rank] = 0
         self.exchange = exchange or world > 1
+        self.force_replicated = replicated
         self.contig_map = eng.to_device(cmap) if self.exchange else None
         dev = eng.device
         self.recs = torch.empty((self.n_rec, 32), dtype=torch.uint8, device=dev)
@@ -89,10 +92,11 @@ class Workload:
         self.nkeys = torch.zeros(1, dtype=torch.int32, device=dev)
         self.text_off = torch.zeros(2, dtype=torch.int64, device=dev)
         self.sums = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.totals = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.totals = torch.zeros(3, dtype=torch.int64, device=dev)
         self.status = torch.zeros(2, dtype=torch.int64, device=dev)
         self.text = None
         self.rec_base = 0
+        self.replicated_steps = 0
         from gci_amd._lib import BuildOpts
         o = BuildOpts()
         o.flank, o.want_text = 15, 1
@@ -110,6 +114,8 @@ class Workload:
         self.rec_base = self.ex.rec_idx_base
         self.recs = self.ex.send_recs                       # K1 writes straight into the send buffer
         self.ivl = self.torch.empty((self.world * self.ex.max_n, 4), dtype=self.torch.int32, device=self.eng.device)
+        self.check_names = shard.NameCheck(self.n_rec, self.eng.device, self.eng.hash_bucket, self.eng.hash_conflicts)
+        self.replicated_steps = 0
 
     def _p(self, t):
         return ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -125,8 +131,17 @@ class Workload:
         if not self.exchange:
             jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
             jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
+        elif not self.force_replicated:
+            # Exact cross-rank name test (hash all-to-all, 8 bytes per record), enqueued without a host sync: the
+            # step goes on SPECULATIVELY with the local join; check() reads the accumulated verdict after the
+            # timed region and main() redoes everything with the replicated join if any step saw a conflict.
+            # rec_idx is global (rec_base + i), so the offset table is indexed through a shifted base pointer.
+            self.check_names.enqueue(self.recs[:self.n_rec])          # adds to check_names.n_conf (device, local)
+            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
+            jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr() - 8 * self.rec_base
         else:
-            # names of the local records as a dense blob, then exchange records + names
+            # a name occurs on two ranks: replicate records + names and join everything everywhere
+            self.replicated_steps += 1
             ex = self.ex
             loc = (JoinFile * 1)()
             loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
@@ -153,8 +168,10 @@ class Workload:
             "gci_depth_build_finish")
         if self.exchange:
             import torch.distributed as dist
+            # ONE integer all-reduce per step: [sum of depth, bases, cross-rank name conflicts seen so far]
             self.totals[0] = self.sums[0]
             self.totals[1] = self.contigs[self.rank][1]
+            self.totals[2] = self.check_names.n_conf[0]
             dist.all_reduce(self.totals, op=dist.ReduceOp.SUM)      # global mean depth = totals[0] / totals[1]
 
     def check(self):
@@ -167,6 +184,9 @@ class Workload:
                 raise GciError(st, "%s failed on record %d" % (what, rec.value))
         if int(self.nkeys.item()) > self.keys.shape[0] or int(self.count.item()) > self.ivl.shape[0]:
             raise GciError(-8, "bench output buffers too small")
+        if self.exchange and not self.force_replicated and int(self.totals[2].item()) > 0:
+            return False          # a query name is shared between ranks: the speculative local joins were not exact
+        return True
 
 
 def cpu_baseline(w: Workload):
@@ -197,7 +217,7 @@ def main():
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_exchange:
+    if world > 1 or args.force_exchange or args.force_replicated:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL logs to stdout: keep it off the channel on which rank 0 prints its ONE JSON line
         if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "WARN"):
@@ -216,7 +236,7 @@ def main():
     from gci_amd import _lib
     from gci_amd.device import Engine
     eng = Engine(local_rank)
-    w = Workload(eng, rank, world, args.contig_len, args.coverage, exchange=args.force_exchange)
+    w = Workload(eng, rank, world, args.contig_len, args.coverage, exchange=args.force_exchange or args.force_replicated, replicated=args.force_replicated)
 
     def fence():
         torch.cuda.synchronize()
@@ -227,7 +247,13 @@ def main():
     for _ in range(max(1, args.warmup)):
         w.step()
     fence()
-    w.check()
+    if not w.check():             # shared names between ranks: every further step takes the replicated join
+        w.force_replicated = True
+        w.check_names.reset()
+        for _ in range(max(1, args.warmup)):
+            w.step()
+        fence()
+        w.check()
 
     eng.profile_enable(1 << _lib.PROF_DEPTH_SCAN)          # HIP events around the dominant kernel only
     eng.profile_read(reset=True)
@@ -239,7 +265,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read(reset=True)
     eng.profile_enable(0)
-    w.check()
+    if not w.check():
+        sys.exit("bench: a query name became shared between ranks during the timed region")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -281,7 +308,10 @@ def main():
         "config": {"workload": "CHM13 chr19 (%d bp) x %d contig(s), one %gx HiFi BAM, filter -> join -> depth -> "
                                "issue scan -> depth text" % (args.contig_len, world, args.coverage),
                    "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
-                   "inflated_bam_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world},
+                   "inflated_bam_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
+                   "join": ("local" if not w.exchange else
+                            "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
+                            "replicated (all-gather of records + names)")},
         "roofline": {"bound": "hbm", "kernel": "k_tile_build<2> (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},

@@ -239,3 +239,105 @@ extern "C" int gci_pack_names(gci_ctx* ctx, const gci_join_file* h_file, uint8_t
     return GCI_OK;
 }
 
+
+// ---- cross-rank name check for the contig-sharded run ---------------------------------------------------------------
+//
+// A rank that holds the records of its own contigs can run the join locally iff no query name also occurs on
+// another rank.  Equal names have equal hashes, so it is enough (and exact) to look for 64-bit hashes that
+// arrive from two different ranks: every rank sends each passing record's hash to rank (hash >> 33) % n_parts
+// (ONE all-to-all of fixed-size buckets, 8 bytes per record, constant per rank), and the receiver counts hashes
+// seen from more than one source.  Zero conflicts on every rank => local joins are exact; otherwise the caller
+// falls back to the replicated join over gathered records + names.
+// Bucket layout (uint64 words): [0] = number of hashes the sender had for this bucket (may exceed the capacity:
+// overflow), [1 .. part_cap] = hashes.
+
+__global__ __launch_bounds__(BLOCK) void k_hash_bucket(const gci_rec* __restrict__ recs, uint32_t n, uint32_t n_parts,
+                                                       uint32_t part_cap, unsigned long long* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const size_t stride = (size_t)part_cap + 1;
+    unsigned long long h = 0;
+    bool live = false;
+    if (i < n) { const gci_rec r = recs[i]; h = r.name_hash; live = (r.flags & GCI_REC_PASS) != 0; }
+    const uint32_t d = (uint32_t)((h >> 33) % n_parts);
+    // one returning atomic per (wave, destination): lanes bound for the same bucket are served together
+    // (a same-address atomic costs ~12 ns on this chip; per-lane atomics would serialise for milliseconds)
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t dsel = (uint32_t)__shfl((int)d, first, 64);
+        const unsigned long long grp = __ballot(live && d == dsel) & todo;
+        unsigned long long base = 0;
+        if (lane == first) base = atomicAdd(out + dsel * stride, (unsigned long long)__popcll(grp));
+        base = (unsigned long long)__shfl((long long)base, first, 64);
+        if (live && d == dsel) {
+            const unsigned long long slot = base + (unsigned long long)__popcll(grp & ((1ull << lane) - 1ull));
+            if (slot < part_cap) out[d * stride + 1 + slot] = h;
+        }
+        todo &= ~grp;
+    }
+}
+
+__global__ void k_hash_bucket_clear(unsigned long long* out, uint32_t n_parts, uint32_t part_cap)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_parts) out[(size_t)d * ((size_t)part_cap + 1)] = 0ull;
+}
+
+// table <- EMPTY and the conflict kernel in one launch would need a grid barrier; the clear is its own tiny launch
+__global__ __launch_bounds__(BLOCK) void k_hash_conflicts(const unsigned long long* __restrict__ buckets, uint32_t n_parts,
+                                                          uint32_t part_cap, unsigned long long* __restrict__ table,
+                                                          uint64_t mask, uint32_t* __restrict__ n_conflicts)
+{
+    const uint32_t src = blockIdx.y;
+    const unsigned long long* b = buckets + (size_t)src * ((size_t)part_cap + 1);
+    const unsigned long long cnt = b[0];
+    if (cnt > part_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(n_conflicts, 1u); }   // overflow: force the fallback
+    const uint32_t m = (uint32_t)(cnt < part_cap ? cnt : part_cap);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < m; i += gridDim.x * BLOCK) {
+        const unsigned long long h = b[1 + i];
+        const unsigned long long word = (h << 8) | src;               // 56 hash bits + source rank (n_parts <= 255)
+        uint64_t slot = (h ^ (h >> 29)) & mask;
+        for (;;) {
+            unsigned long long cur = table[slot];
+            if (cur == SLOT_EMPTY) {
+                cur = atomicCAS(table + slot, SLOT_EMPTY, word);
+                if (cur == SLOT_EMPTY) break;
+            }
+            if ((cur >> 8) == (word >> 8)) { if ((cur & 0xFF) != src) atomicAdd(n_conflicts, 1u); break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
+extern "C" int gci_hash_bucket(gci_ctx* ctx, const gci_rec* d_recs, uint32_t n, uint32_t n_parts, uint32_t part_cap,
+                               uint64_t* d_out)
+{
+    if (!ctx || !d_out || n_parts == 0 || n_parts > 255 || (n && !d_recs)) return GCI_E_INVALID;
+    hipLaunchKernelGGL(k_hash_bucket_clear, dim3(1), dim3(256), 0, ctx->stream, (unsigned long long*)d_out, n_parts, part_cap);
+    LAUNCHCHK("k_hash_bucket_clear");
+    if (n) {
+        hipLaunchKernelGGL(k_hash_bucket, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_recs, n, n_parts,
+                           part_cap, (unsigned long long*)d_out);
+        LAUNCHCHK("k_hash_bucket");
+    }
+    return GCI_OK;
+}
+
+// *d_n_conflicts is ADDED to (the caller zeroes it when it wants a fresh count)
+extern "C" int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint32_t n_parts, uint32_t part_cap,
+                                  uint32_t* d_n_conflicts)
+{
+    if (!ctx || !d_buckets || !d_n_conflicts || n_parts == 0 || n_parts > 255) return GCI_E_INVALID;
+    uint64_t slots = 1024;
+    while (slots < 2ull * n_parts * part_cap) slots <<= 1;
+    GCI_TRY(gci_ensure(ctx, ctx->join_table, slots * 8));
+    HIPCHK(hipMemsetAsync(ctx->join_table.p, 0xFF, slots * 8, ctx->stream));
+    const uint32_t gx = (part_cap + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_hash_conflicts, dim3(gx ? (gx > 1024 ? 1024 : gx) : 1, n_parts), dim3(BLOCK), 0, ctx->stream,
+                       (const unsigned long long*)d_buckets, n_parts, part_cap, (unsigned long long*)ctx->join_table.p,
+                       slots - 1, d_n_conflicts);
+    LAUNCHCHK("k_hash_conflicts");
+    return GCI_OK;
+}

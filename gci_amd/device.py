@@ -62,13 +62,14 @@ class JoinInput:
 class Engine:
     """A gci_ctx bound to torch's current stream on `device`."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, stream: Optional["torch.cuda.Stream"] = None):
+        """`stream`: the torch stream this context enqueues on (default: the device's current stream)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise GciError(_lib.GCI_E_HIP, "no MI355X visible: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.current_stream(self.device)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         h = ctypes.c_void_p()
         st = self.lib.gci_ctx_create(device, ctypes.c_void_p(self.stream.cuda_stream), 0, ctypes.byref(h))
         if st != 0:
@@ -198,6 +199,16 @@ class Engine:
             if n <= out.shape[0]:
                 return out, count
             out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+
+    def hash_bucket(self, recs: torch.Tensor, n_parts: int, part_cap: int, out: torch.Tensor) -> None:
+        """out: int64 [n_parts * (part_cap + 1)]; word 0 of each bucket = its count."""
+        self._chk(self.lib.gci_hash_bucket(self.ctx, self._p(recs), int(recs.shape[0]), int(n_parts), int(part_cap),
+                                           self._p(out)), "gci_hash_bucket")
+
+    def hash_conflicts(self, buckets: torch.Tensor, n_parts: int, part_cap: int, n_conflicts: torch.Tensor) -> None:
+        """Adds to n_conflicts (int32 [1])."""
+        self._chk(self.lib.gci_hash_conflicts(self.ctx, self._p(buckets), int(n_parts), int(part_cap),
+                                              self._p(n_conflicts)), "gci_hash_conflicts")
 
     def pack_names(self, f: JoinInput) -> Tuple[torch.Tensor, torch.Tensor]:
         n = int(f.recs.shape[0])

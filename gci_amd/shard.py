@@ -94,6 +94,50 @@ class RecordExchange:
         return Gathered(self.g_recs, self.g_names, idx, self.max_n)
 
 
+class NameCheck:
+    """Exact, constant-per-rank test "does any query name occur on more than one rank?" for contig-sharded runs
+    (gci_hash_bucket / gci_hash_conflicts in include/gci_hip.h): every rank sends the 64-bit hash of each passing
+    record to rank (hash >> 33) % world with ONE all-to-all of fixed-size buckets (word 0 = count); the receiver
+    counts hashes that arrive from two different ranks into a local device counter.  The caller sums that counter
+    over ranks with whatever integer all-reduce it already does (the genome-wide totals) -- zero => every rank's
+    local join equals the global join (equal names have equal hashes).  Non-zero (a shared name, a 56-bit hash
+    collision or a bucket overflow) => run the replicated join over gathered records + names instead.
+
+    `bucket_fn(recs, n_parts, cap, out)` and `conflict_fn(buckets, n_parts, cap, n_conflicts)` are the two device
+    operations (Engine.hash_bucket / Engine.hash_conflicts on the GPU)."""
+
+    def __init__(self, n_local: int, device: torch.device, bucket_fn, conflict_fn, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.bucket_fn, self.conflict_fn = bucket_fn, conflict_fn
+        n = torch.tensor([n_local], dtype=torch.int64, device=device)
+        alln = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(alln, n, group=group)
+        max_n = max(int(x.item()) for x in alln)
+        self.cap = -(-max_n * 13 // (10 * self.world)) + 1024       # 1.3 x the mean bucket + slack
+        self.send = torch.zeros(self.world * (self.cap + 1), dtype=torch.int64, device=device)
+        self.recv = torch.zeros_like(self.send)
+        self.n_conf = torch.zeros(1, dtype=torch.int32, device=device)   # local, cumulative until reset()
+
+    def reset(self) -> None:
+        self.n_conf.zero_()
+
+    def enqueue(self, recs: torch.Tensor) -> torch.Tensor:
+        """Asynchronous: adds this step's LOCAL conflict count to self.n_conf (device) and returns it.  A caller
+        may go on speculatively with the local join and read the (all-reduced) verdict later."""
+        self.bucket_fn(recs, self.world, self.cap, self.send)
+        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self.conflict_fn(self.recv, self.world, self.cap, self.n_conf)
+        return self.n_conf
+
+    def conflicts(self, recs: torch.Tensor) -> int:
+        """Synchronous, global verdict for one record set."""
+        self.reset()
+        t = self.enqueue(recs).clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+
 def allreduce_totals(sum_depth: int, n_bases: int, device: torch.device, group=None) -> Tuple[int, int]:
     """Genome-wide (sum of depth, bases): the numerator / denominator of the global mean depth
     (GCI.py:862-868).  Integers, so the result is independent of the reduction order."""

@@ -164,6 +164,17 @@ int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, doubl
                   const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
                   uint64_t* d_status);
 
+/* Cross-rank name check for contig-sharded runs (exact).  gci_hash_bucket sorts the 64-bit name hashes of the
+ * passing records into n_parts buckets by (hash >> 33) % n_parts; a bucket is part_cap + 1 uint64 words:
+ * [0] = number of hashes the sender had for it (> part_cap: overflow), [1..] = the hashes.  After ONE all-to-all of
+ * the buckets, gci_hash_conflicts ADDS to *d_n_conflicts the number of hashes that arrived from more than one
+ * source bucket (+1 per overflowing bucket).  Zero on every rank => no query name is shared between ranks, so
+ * each rank's local join equals the global one. */
+int gci_hash_bucket(gci_ctx* ctx, const gci_rec* d_recs, uint32_t n, uint32_t n_parts, uint32_t part_cap,
+                    uint64_t* d_out);
+int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint32_t n_parts, uint32_t part_cap,
+                       uint32_t* d_n_conflicts);
+
 /* ---- R6: depth build ------------------------------------------------------------------------
  * depth[c][start+flank : end-flank+1] += 1 with Python/NumPy slice semantics, for n intervals
  * (n read from *d_n if d_n != NULL, clamped to max_n).  Overwrites the whole track. */

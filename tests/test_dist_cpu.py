@@ -79,6 +79,42 @@ def _worker(rank, world, port, q):
         allissues = shard.gather_interval_lists(issues)
         ref_issues = [(targets.index(t), s0, e0) for t, v in O.collapse_depth_range(full, -1, 0, 15, 0).items() for s0, e0 in v]
         assert allissues == sorted(ref_issues)
+        # ---- NameCheck glue (all-to-all of padded hash buckets) with numpy stand-ins for the two kernels ----------
+        def bucket_np(recs_t, n_parts, cap, out):
+            rr = recs_t.numpy().reshape(-1).view(REC_DTYPE)
+            o = out.view(n_parts, cap + 1)
+            o[:, 0] = 0
+            for h in rr["name_hash"][(rr["flags"] & 1) == 1].tolist():
+                d = (h >> 33) % n_parts
+                k = int(o[d, 0]); o[d, 0] += 1
+                if k < cap:
+                    o[d, 1 + k] = int(np.uint64(h).astype(np.int64))
+
+        def conflicts_np(buckets, n_parts, cap, out_n):
+            bb = buckets.view(n_parts, cap + 1)
+            seen, n = {}, 0
+            for src in range(n_parts):
+                cnt = int(bb[src, 0])
+                if cnt > cap:
+                    n += 1
+                for h in bb[src, 1:1 + min(cap, cnt)].tolist():
+                    if h in seen and seen[h] != src:
+                        n += 1
+                    seen.setdefault(h, src)
+            out_n[0] += n
+
+        local = torch.from_numpy(recs.view(np.uint8).reshape(n, 32).copy())
+        chk = shard.NameCheck(n, torch.device("cpu"), bucket_np, conflicts_np)
+        got_conf = chk.conflicts(local)
+        # truth: names held (as passing records) by both ranks' slices
+        mine = {nm for nm, f in zip(names, recs["flags"]) if f & 1}
+        allsets = [None, None]
+        dist.all_gather_object(allsets, mine)
+        assert (got_conf > 0) == (len(allsets[0] & allsets[1]) > 0), (got_conf, len(allsets[0] & allsets[1]))
+        # and with disjoint name sets the verdict is "no conflict"
+        uniq = recs.copy()
+        uniq["name_hash"] = name_hash_np([b"rank%d/%d" % (rank, i) for i in range(n)])
+        assert chk.conflicts(torch.from_numpy(uniq.view(np.uint8).reshape(n, 32).copy())) == 0
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback

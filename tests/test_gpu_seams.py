@@ -237,3 +237,39 @@ def test_fused_build_equals_seams_and_oracle(engine, oracle):
         tr2 = pipeline.DepthTracks(engine, lengths, t2)
         for t in targets:
             assert np.array_equal(tr2[t], half[t])
+
+
+def test_cross_rank_name_check_kernels(engine):
+    """gci_hash_bucket + gci_hash_conflicts with two simulated ranks on one GPU: unique names -> 0 conflicts;
+    a name present on both ranks is found; a repeated name inside ONE rank is not a conflict; overflow counts."""
+    rng = np.random.default_rng(23)
+
+    def recs_for(names, passed=None):
+        r = np.zeros(len(names), dtype=REC_DTYPE)
+        r["name_hash"] = name_hash_np(names)
+        r["flags"] = 1 if passed is None else passed
+        return engine.to_device(r.view(np.uint8).reshape(len(names), 32))
+
+    a = [b"readA/%d" % i for i in range(5000)]
+    b = [b"readB/%d" % i for i in range(4000)]
+
+    def conflicts(na, nb, cap=6000, pa=None, pb=None):
+        world = 2
+        outs = []
+        for names, p in ((na, pa), (nb, pb)):
+            o = torch.zeros(world * (cap + 1), dtype=torch.int64, device=engine.device)
+            engine.hash_bucket(recs_for(names, p), world, cap, o)
+            outs.append(o.view(world, cap + 1))
+        n = torch.zeros(1, dtype=torch.int32, device=engine.device)
+        for me in range(world):                       # what rank `me` receives: bucket `me` of every source
+            recv = torch.stack([outs[src][me] for src in range(world)]).reshape(-1).contiguous()
+            engine.hash_conflicts(recv, world, cap, n)
+        return int(n.item())
+
+    assert conflicts(a, b) == 0
+    assert conflicts(a, b + [a[17]]) == 1
+    assert conflicts(a + [a[3], a[3]], b) == 0                       # duplicates inside one rank: the local join's business
+    assert conflicts(a, b + [a[5], a[900], a[4999]]) == 3
+    flags = np.ones(len(b) + 1, dtype=np.uint8); flags[-1] = 0
+    assert conflicts(a, b + [a[17]], pb=flags) == 0                   # filtered records do not take part
+    assert conflicts(a, b, cap=100) > 0                              # bucket overflow forces the fallback
