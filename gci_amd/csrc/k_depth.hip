@@ -220,19 +220,23 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t tile = blockIdx.x;
     int4* l4 = reinterpret_cast<int4*>(lds);
-#pragma unroll
-    for (int j = 0; j < 4; j++) l4[j * BLOCK + t] = make_int4(0, 0, 0, 0);
-    if (PASS == 2 && text) text_lut_load(lut, g_lut, t);
-    __syncthreads();
+    // every global load this tile depends on is issued before the LDS work so that their latencies overlap:
+    // bucket bounds, the first event of this thread (buckets hold ~20 events: one per thread at most), carry-in
     const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
-    for (uint32_t e = e0 + t; e < e1; e += BLOCK) {
-        const uint32_t ev = events[e];
-        atomicAdd(&lds[ev >> 1], (ev & 1u) ? -1 : 1);
-    }
     const int32_t carry_in = tile_carry[tile];
     const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
     const int64_t elem0 = (tile - tile_first[c]) * TILE;          // index of the tile's first element in its contig
     const int64_t L = len[c];
+#pragma unroll
+    for (int j = 0; j < 4; j++) l4[j * BLOCK + t] = make_int4(0, 0, 0, 0);
+    if (PASS == 2 && text) text_lut_load(lut, g_lut, t);
+    const uint32_t ev0 = e0 + t < e1 ? (uint32_t)events[e0 + t] : 0xFFFFFFFFu;
+    __syncthreads();
+    if (ev0 != 0xFFFFFFFFu) atomicAdd(&lds[ev0 >> 1], (ev0 & 1u) ? -1 : 1);
+    for (uint32_t e = e0 + BLOCK + t; e < e1; e += BLOCK) {
+        const uint32_t ev = events[e];
+        atomicAdd(&lds[ev >> 1], (ev & 1u) ? -1 : 1);
+    }
     __syncthreads();
     int4 v[4];
 #pragma unroll
