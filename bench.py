@@ -284,6 +284,16 @@ def main():
     algo_bytes = 4.0 * args.contig_len + text_bytes       # DESIGN.md "algorithmic bytes"
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
 
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected from inside
+    # this process: rocprofv3 wraps the command; see tools/prof_pmc.sh and profiles/)
+    traffic = None
+    try:
+        tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+        if tj and args.contig_len == CHR19_LEN and args.coverage == 40.0:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     breakdown = None
     if True:
         eng.profile_enable((1 << _lib.PROF_COUNT) - 1)
@@ -313,7 +323,7 @@ def main():
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
         "roofline": {"bound": "hbm", "kernel": "k_tile_build<2> (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
         "kernel_us_per_launch": breakdown,
     }
