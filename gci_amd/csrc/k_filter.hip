@@ -209,7 +209,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         }
     }
     TR(9);
-    const bool odd = l_read_name > HEAD - 36 || n_cigar > LONG_OPS;
+    const bool odd = cig_at + 4 > HEAD || n_cigar > LONG_OPS;     // first CIGAR word must lie inside the staged head
     const uint32_t staged_ops = odd ? 0u : min(n_cigar, (HEAD - cig_at) / 4u);
     unsigned long long* tot = tot_lds[grp];
     if (!odd) {

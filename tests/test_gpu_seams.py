@@ -8,6 +8,7 @@ import torch
 from gci_amd import synth
 from gci_amd.device import JoinInput, REC_DTYPE, name_hash_np
 from gci_amd import pipeline
+from gci_amd._lib import GciError as GciErr
 
 pytestmark = pytest.mark.gpu
 
@@ -273,3 +274,81 @@ def test_cross_rank_name_check_kernels(engine):
     flags = np.ones(len(b) + 1, dtype=np.uint8); flags[-1] = 0
     assert conflicts(a, b + [a[17]], pb=flags) == 0                   # filtered records do not take part
     assert conflicts(a, b, cap=100) > 0                              # bucket overflow forces the fallback
+
+
+def test_bam_filter_randomised_records(engine, oracle):
+    """Differential test of K1 (staged fast path + slow path) against the oracle on records built field by
+    field: names of 1..254 bytes, 0..6000 CIGAR ops with every op code, NM at any place among Z / H / B / scalar
+    tags (inside and beyond the staged window), SEQ '*', placed-unmapped, long-CIGAR placeholders with and without
+    a CG tag, contigs in and out of the selection."""
+    from gci_amd.formats import bam
+    rng = np.random.default_rng(31)
+    refs = [("c%d" % i, 3_000_000) for i in range(5)]
+    recs = []
+    for i in range(3000):
+        n_ops = int(rng.choice([0, 1, 2, 3, 40, 70, 130, 600, 6000], p=[.02, .1, .1, .1, .2, .2, .15, .1, .03]))
+        ops = []
+        for _ in range(n_ops):
+            o = int(rng.choice([0, 7, 8, 1, 2, 3, 4, 5, 6], p=[.3, .3, .1, .1, .1, .02, .04, .02, .02]))
+            ops.append((o, int(rng.integers(20, 300)) if o in (0, 7) else int(rng.integers(1, 4))))
+        qlen = sum(l for o, l in ops if (bam.QUERY_CONSUMING >> o) & 1)
+        l_seq = 0 if rng.random() < 0.05 else qlen
+        name = bytes(rng.integers(33, 127, int(rng.choice([1, 5, 30, 40, 100, 219, 220, 221, 254]))).astype(np.uint8)).decode()
+        tags = []
+        for _ in range(int(rng.integers(0, 7))):
+            k = rng.integers(0, 6)
+            tg = "X%s" % chr(int(rng.integers(97, 123)))
+            if k == 0: tags.append((tg, "i", int(rng.integers(-5, 5))))
+            elif k == 1: tags.append((tg, "Z", "s" * int(rng.integers(0, 200))))
+            elif k == 2: tags.append((tg, "B:C", list(range(int(rng.integers(0, 60))))))
+            elif k == 3: tags.append((tg, "A", "P"))
+            elif k == 4: tags.append((tg, "f", 0.5))
+            else: tags.append((tg, "B:I", [7] * int(rng.integers(0, 12))))
+        nm_total = sum(l for o, l in ops if o in (1, 2, 8))
+        if rng.random() < 0.97:
+            nmv = max(0, nm_total + int(rng.integers(-2, 40)))
+            typ = "C" if nmv < 256 and rng.random() < 0.7 else ("S" if nmv < 65536 and rng.random() < 0.5 else "i")
+            tags.insert(int(rng.integers(0, len(tags) + 1)), ("NM", typ, nmv))
+        flag = int(rng.choice([0, 16, 0x100, 0x800, 0x4, 0x1, 0x400]))
+        mapq = int(rng.choice([0, 10, 29, 30, 49, 50, 60]))
+        ref = int(rng.integers(-1, 5))
+        aux = bam.encode_aux(tags)
+        if n_ops >= 2 and rng.random() < 0.05:            # placeholder-looking CIGAR, with or without a CG tag
+            real = ops
+            rl = sum(l for o, l in real if (bam.REF_CONSUMING >> o) & 1)
+            ops = [(4, l_seq), (3, max(rl, 1))]
+            if rng.random() < 0.7:
+                aux += bam.encode_aux([("CG", "B:I", [(l << 4) | o for o, l in real])])
+        recs.append(bam.encode_record(ref, int(rng.integers(0, 2_000_000)), name, mapq, flag, ops, l_seq, aux))
+    hdr = bam.encode_header([r for r, _ in refs], [l for _, l in refs])
+    stream = np.frombuffer(hdr + b"".join(recs), dtype=np.uint8).copy()
+    offs = bam.record_offsets(stream, bam.parse_header(stream).first_record)
+    d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+    n_checked = 0
+    for ref_sel, (cp, ip) in ((np.array([0, 1, 2, 3, 4], np.int32), (0.1, 0.9)), (np.array([-1, 0, -1, 1, -1], np.int32), (0.5, 0.5))):
+        # the reference raises on the first bad record; remove offenders one by one until the oracle is clean, checking
+        # that the GPU reports the same status for the same record each time
+        keep = np.ones(len(offs), dtype=bool)
+        for _ in range(400):
+            o_sub = offs[keep]
+            try:
+                want = oracle.bam_filter_arrays(stream, o_sub, ref_sel, 30, 50, cp, ip)
+                break
+            except oracle.OracleRecordError as e:
+                with pytest.raises(GciErr) as g:
+                    engine.bam_filter(d_bam, engine.to_device(o_sub), engine.to_device(ref_sel), 30, 50, cp, ip)
+                assert g.value.status == e.status, (e.status, g.value.status)
+                # the GPU reports the FIRST failing record in file order, like the oracle's loop
+                assert g.value.rec == e.rec
+                keep[np.flatnonzero(keep)[e.rec]] = False
+                n_checked += 1
+        got = _recs_np(engine.bam_filter(d_bam, engine.to_device(o_sub), engine.to_device(ref_sel), 30, 50, cp, ip))
+        p = want["passed"].astype(bool)
+        assert np.array_equal((got["flags"] & 1).astype(bool), p)
+        assert np.array_equal((got["flags"] & 2) != 0, want["hq"].astype(bool))
+        for f in ("contig", "start", "end", "qlen", "name_len"):
+            assert np.array_equal(got[f][p], want[f][p]), f
+        names = [bytes(stream[int(a):int(a) + int(n)]) for a, n in zip(want["name_off"][p], want["name_len"][p])]
+        assert np.array_equal(got["name_hash"][p], name_hash_np(names))
+        assert p.sum() > 100
+    assert n_checked > 5
