@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libgci_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("api_ctx.hip", "k_filter.hip", "k_join.hip", "k_depth.hip", "k_track.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("api_ctx.hip", "k_filter.hip", "k_join.hip", "k_depth.hip", "k_track.hip", "host_io.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "gci_common.h"), os.path.join(CSRC, "gci_ctx.hpp"),
                   os.path.join(_HERE, "..", "include", "gci_hip.h")]
 
@@ -29,7 +29,7 @@ def needs_build() -> bool:
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fno-fast-math", "-ffp-contract=off", "-Wall", "-o", LIB] + SOURCES
+               "-fno-fast-math", "-ffp-contract=off", "-Wall", "-o", LIB] + SOURCES + ["-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

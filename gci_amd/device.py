@@ -107,6 +107,8 @@ class Engine:
 
     def to_device(self, a: np.ndarray) -> torch.Tensor:
         a = np.ascontiguousarray(a)
+        if not a.flags.writeable:
+            a = a.copy()
         if a.dtype == np.uint64:
             a = a.view(np.int64)
         elif a.dtype == np.uint32:

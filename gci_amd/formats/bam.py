@@ -184,29 +184,23 @@ def read_bam(path: str, threads: int = 1):
 
 
 def read_header(path: str) -> BamHeader:
-    """Header only: inflate members until the reference table is complete."""
+    """Header only: inflate BGZF members one at a time until the reference table is complete."""
     import zlib
+    data = bytearray()
     with open(path, "rb") as f:
-        raw = f.read(1 << 20)
-        data = b""
         while True:
+            head = f.read(18)
+            if len(head) < 18:
+                raise BAMError("truncated BAM header in %s" % path)
+            if head[0] != 0x1F or head[1] != 0x8B or head[12:16] != b"BC\x02\x00":
+                raise BAMError("%s is not a BGZF file" % path)
+            bsize = head[16] | (head[17] << 8)
+            rest = f.read(bsize + 1 - 18)
+            data += zlib.decompress(rest[:-8], -15)
             try:
-                blocks = bgzf.scan_blocks(raw)
-            except bgzf.BGZFError:
-                more = f.read(1 << 22)
-                if not more:
-                    raise
-                raw += more
+                return parse_header(bytes(data))
+            except (struct.error, IndexError, UnicodeDecodeError):
                 continue
-            data = b"".join(
-                zlib.decompress(raw[p + 12 + (raw[p + 10] | raw[p + 11] << 8): p + s - 8], -15) for p, s, _ in blocks)
-            try:
-                return parse_header(data)
-            except (struct.error, IndexError):
-                more = f.read(1 << 22)
-                if not more:
-                    raise BAMError("truncated BAM header in %s" % path)
-                raw += more
 
 
 # ----------------------------------------------------------------------------------------------

@@ -103,8 +103,16 @@ def decompress(raw: bytes, threads: int = 1, check_crc: bool = False) -> np.ndar
         out[offs[i]:offs[i + 1]] = np.frombuffer(data, dtype=np.uint8)
 
     if threads > 1 and len(blocks) > 1:
+        # one task per contiguous run of blocks: zlib releases the GIL, the per-task overhead does not
+        n_tasks = min(len(blocks), threads * 4)
+        step = -(-len(blocks) // n_tasks)
+
+        def span(k: int) -> None:
+            for i in range(k * step, min(len(blocks), (k + 1) * step)):
+                work(i)
+
         with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(work, range(len(blocks))))
+            list(ex.map(span, range(n_tasks)))
     else:
         for i in range(len(blocks)):
             work(i)

@@ -1,0 +1,70 @@
+"""Native host-side container I/O (gci_amd/csrc/host_io.cpp through the C ABI): parallel BGZF inflate,
+the BAM record-offset chase and parallel gzip framing.  The pure-Python twins in gci_amd/formats/ stay as the
+readable reference of the formats (and are what the golden generator and the pysam stand-in use); these are
+what the product path calls (tests/test_host_logic.py checks the two agree)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import GciError
+
+
+def _chk(st: int, what: str) -> None:
+    if st != 0:
+        raise GciError(st, "%s: %s" % (what, _lib.load().gci_strerror(st).decode()))
+
+
+def default_threads() -> int:
+    return max(1, min(64, os.cpu_count() or 1))
+
+
+def bgzf_inflate(raw, threads: int = 0, out: np.ndarray = None, check_crc: bool = False) -> np.ndarray:
+    """Inflate a whole BGZF byte string (bytes / uint8 array) into one uint8 array."""
+    lib = _lib.load()
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    nb, total = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _chk(lib.gci_bgzf_scan(buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], ctypes.byref(nb), ctypes.byref(total)),
+         "gci_bgzf_scan")
+    if out is None or out.shape[0] < total.value:
+        out = np.empty(total.value, dtype=np.uint8)
+    _chk(lib.gci_bgzf_inflate(buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], out.ctypes.data_as(ctypes.c_void_p),
+                              out.shape[0], int(threads or default_threads()), int(check_crc)), "gci_bgzf_inflate")
+    return out[:total.value]
+
+
+def read_bgzf_file(path: str, threads: int = 0) -> np.ndarray:
+    return bgzf_inflate(np.fromfile(path, dtype=np.uint8), threads=threads)
+
+
+def bam_record_offsets(stream: np.ndarray) -> Tuple[np.ndarray, int]:
+    """-> (uint64 offsets of every record's block_size word, byte offset of the first record)."""
+    lib = _lib.load()
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    n, first = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    p = stream.ctypes.data_as(ctypes.c_void_p)
+    _chk(lib.gci_bam_record_offsets(p, stream.shape[0], None, 0, ctypes.byref(n), ctypes.byref(first)),
+         "gci_bam_record_offsets")
+    offs = np.empty(n.value, dtype=np.uint64)
+    _chk(lib.gci_bam_record_offsets(p, stream.shape[0], offs.ctypes.data_as(ctypes.c_void_p), offs.shape[0],
+                                    ctypes.byref(n), ctypes.byref(first)), "gci_bam_record_offsets")
+    return offs, int(first.value)
+
+
+def gzip_members(text, threads: int = 0, chunk: int = 8 << 20, level: int = 1) -> bytes:
+    """Multi-member gzip of `text` (bytes-like / uint8 array), members compressed in parallel."""
+    lib = _lib.load()
+    buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text)
+    if buf.shape[0] == 0:
+        return b""
+    cap = int(lib.gci_gzip_bound(buf.shape[0], chunk))
+    out = np.empty(cap, dtype=np.uint8)
+    n = ctypes.c_uint64(0)
+    _chk(lib.gci_gzip_members(buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], chunk, level,
+                              int(threads or default_threads()), out.ctypes.data_as(ctypes.c_void_p), cap,
+                              ctypes.byref(n)), "gci_gzip_members")
+    return out[:n.value].tobytes()

@@ -218,8 +218,12 @@ def _paf_join_input(engine: Engine, d: Dict[str, Tuple[str, int, int, int]], hig
 
 
 def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
-    """Inflate (host threads), find record boundaries (the one serial step), upload."""
-    stream, hdr, offs = bamfmt.read_bam(path, threads=threads)
+    """Inflate (native host threads), find record boundaries (the one serial step), upload."""
+    from . import hostio
+    stream = hostio.read_bgzf_file(path, threads=max(int(threads), hostio.default_threads()))
+    hdr = bamfmt.parse_header(stream)
+    offs, first = hostio.bam_record_offsets(stream)
+    assert first == hdr.first_record
     return engine.to_device(stream), engine.to_device(offs), hdr
 
 
@@ -300,13 +304,18 @@ def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads
 
 
 def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, threads) -> None:
+    """Frame the GPU-rendered text as a multi-member gzip: '>contig' member, then the contig's lines compressed in
+    parallel by the native host helper (any gzip whose payload equals the text is a valid .depth.gz)."""
+    from . import hostio
     host = text.cpu().numpy()
-    mv = memoryview(host)
-    pieces = ((t, mv[int(offs[c]):int(offs[c + 1])]) for c, t in enumerate(depths.targets))
     path = f"{directory}/{prefix}.depth.gz"
     if os.path.exists(path):
         os.remove(path)
-    depthfile.write_depth_gz(path, pieces, level=1, threads=max(1, threads))
+    nthreads = max(int(threads), hostio.default_threads())
+    with open(path, "wb") as f:
+        for c, t in enumerate(depths.targets):
+            f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
+            f.write(hostio.gzip_members(host[int(offs[c]):int(offs[c + 1])], threads=nthreads))
 
 
 def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTracks = None, prefix="GCI_two_type",

@@ -230,6 +230,23 @@ int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_t* d_out, u
 /* ---- R15 ------------------------------------------------------------------------------------ */
 int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums /* n_contigs */);
 
+/* ---- host-side container helpers (no GPU work) ---------------------------------
+ * The reference reaches BGZF / BAM through pysam/htslib (GCI.py:150-151) and writes gzip through Python's gzip
+ * module (GCI.py:111).  All pointers are HOST pointers.
+ *   gci_bgzf_scan            member count and total inflated size (sum of ISIZE) of a BGZF byte string
+ *   gci_bgzf_inflate         inflate every member into h_out, members in parallel on `threads` host threads
+ *   gci_bam_record_offsets   end of the BAM header and the byte offset of every record (the one serial step of
+ *                            the decode); h_offs may be NULL to count only
+ *   gci_gzip_members         gzip-frame text as independent members of `chunk` input bytes, compressed in
+ *                            parallel (any multi-member gzip whose payload equals the text is a valid .depth.gz) */
+int gci_bgzf_scan(const uint8_t* h_raw, uint64_t n_raw, uint64_t* n_blocks, uint64_t* inflated_bytes);
+int gci_bgzf_inflate(const uint8_t* h_raw, uint64_t n_raw, uint8_t* h_out, uint64_t cap, int threads, int check_crc);
+int gci_bam_record_offsets(const uint8_t* h_stream, uint64_t n, uint64_t* h_offs, uint64_t cap, uint64_t* n_rec,
+                           uint64_t* first_record);
+uint64_t gci_gzip_bound(uint64_t n, uint64_t chunk);
+int gci_gzip_members(const uint8_t* h_text, uint64_t n, uint64_t chunk, int level, int threads, uint8_t* h_out,
+                     uint64_t cap, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,3 +352,48 @@ def test_bam_filter_randomised_records(engine, oracle):
         assert np.array_equal(got["name_hash"][p], name_hash_np(names))
         assert p.sum() > 100
     assert n_checked > 5
+
+
+@pytest.mark.parametrize("n_files,seed", [(2, 1), (3, 2), (4, 3), (5, 4)])
+def test_name_join_randomised_dicts(engine, oracle, n_files, seed):
+    """The fold of GCI.py:279-299 on random per-file dicts drawn from a small name pool (many names in several
+    files, on the same / different contigs, high-quality or not): exercises deletion, interval intersection, the
+    ovlp / qlen-of-the-current-file test and resurrection by a later file with >= 3 files."""
+    rng = np.random.default_rng(100 + seed)
+    pool = [("read%05d" % i) for i in range(4000)]
+    targets = ["t0", "t1", "t2"]
+    files, hq = [], set()
+    for f in range(n_files):
+        d = {}
+        for q in rng.choice(pool, size=int(rng.integers(1500, 3500)), replace=False):
+            s = int(rng.integers(0, 50_000))
+            ln = int(rng.integers(50, 20_000))
+            qlen = int(max(1, ln + rng.integers(-40, 400)))
+            d[str(q)] = (targets[int(rng.integers(0, 3)) if rng.random() < 0.15 else 0], s, s + ln, qlen)
+        files.append(d)
+    # make most shared names agree roughly with file 0 so that survivors exist
+    for f in range(1, n_files):
+        for q in list(files[f])[::2]:
+            if q in files[0]:
+                t, s, e, ql = files[0][q]
+                j = int(rng.integers(-30, 30))
+                files[f][q] = (t, max(0, s + j), e + j, max(1, e - s + int(rng.integers(-5, 60))))
+    hq = set(str(q) for q in rng.choice(pool, size=1200, replace=False))
+    # the reference's high-quality set only holds names that occur in some file
+    hq &= set().union(*[set(d) for d in files])
+    want = oracle.name_join(files, hq, 0.9)
+    want = sorted((targets.index(v[0]), v[1], v[2]) for v in want.values())
+
+    inputs = []
+    tindex = {t: i for i, t in enumerate(targets)}
+    for d in files:
+        inputs.append(pipeline._paf_join_input(engine, d, hq, tindex))
+    ivl, cnt = engine.name_join(inputs, 0.9)
+    got = sorted(map(tuple, ivl[:int(cnt.item()), :3].cpu().numpy().tolist()))
+    assert got == want
+    assert len(want) > 300
+    # a contig map that keeps only t0 (multi-GPU ownership filter) and renumbers it
+    cmap = engine.to_device(np.array([0, -1, -1], dtype=np.int32))
+    ivl2, cnt2 = engine.name_join(inputs, 0.9, contig_map=cmap)
+    got2 = sorted(map(tuple, ivl2[:int(cnt2.item()), :3].cpu().numpy().tolist()))
+    assert got2 == [w for w in want if w[0] == 0]

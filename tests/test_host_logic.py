@@ -126,3 +126,32 @@ def test_lpt_sharding():
     assert [m[c] for c in mine] == list(range(len(mine))) and (m >= 0).sum() == len(mine)
     assert shard.record_slices(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)] and shard.record_slices(0, 2) == [(0, 0), (0, 0)]
     assert shard.lpt_assign([5], 4) == [0]
+
+
+def test_native_host_io_matches_python_twins(tmp_path):
+    """gci_bgzf_inflate / gci_bam_record_offsets / gci_gzip_members (host_io.cpp) against the pure-Python formats."""
+    import gzip as _gz
+    from gci_amd import hostio, synth
+    from gci_amd.formats import bam, bgzf
+    rs = synth.simulate_reads((("a", 400_000), ("b", 90_000)), 10, "hifi", seed=5)
+    stream, offs = synth.to_bam_stream(rs)
+    p = str(tmp_path / "x.bam")
+    bam.write_bam_stream(p, stream, level=1, threads=4)
+    raw = open(p, "rb").read()
+    a = bgzf.decompress(raw, threads=2, check_crc=True)
+    b = hostio.bgzf_inflate(raw, threads=4, check_crc=True)
+    assert np.array_equal(a, b) and np.array_equal(b, stream)
+    assert np.array_equal(hostio.read_bgzf_file(p, threads=3), stream)
+    o2, first = hostio.bam_record_offsets(b)
+    assert first == bam.parse_header(stream).first_record and np.array_equal(o2, offs)
+    bad = bytearray(raw); bad[200] ^= 0xFF                                  # a flipped byte inside the first member
+    with pytest.raises(Exception):
+        hostio.bgzf_inflate(bytes(bad), threads=2, check_crc=True)
+    with pytest.raises(Exception):
+        hostio.bgzf_inflate(raw[:-41], threads=2)                         # truncated member
+    with pytest.raises(Exception):
+        hostio.bam_record_offsets(stream[:-7])
+    text = b"".join(b"%d\n" % (i % 977) for i in range(300_000))
+    z = hostio.gzip_members(text, threads=4, chunk=100_000)
+    assert _gz.decompress(z) == text and z.count(b"\x1f\x8b\x08") >= len(text) // 100_000
+    assert hostio.gzip_members(b"") == b""
