@@ -135,10 +135,9 @@ class Workload:
             # Exact cross-rank name test (hash all-to-all, 8 bytes per record), enqueued without a host sync: the
             # step goes on SPECULATIVELY with the local join; check() reads the accumulated verdict after the
             # timed region and main() redoes everything with the replicated join if any step saw a conflict.
-            # rec_idx is global (rec_base + i), so the offset table is indexed through a shifted base pointer.
             self.check_names.enqueue(self.recs[:self.n_rec])          # adds to check_names.n_conf (device, local)
             jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
-            jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr() - 8 * self.rec_base
+            jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
         else:
             # a name occurs on two ranks: replicate records + names and join everything everywhere
             self.replicated_steps += 1
@@ -146,8 +145,7 @@ class Workload:
             loc = (JoinFile * 1)()
             loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
             loc[0].d_name_base = self.d_bam.data_ptr()
-            # rec_idx is global (rec_base + i): index the local offset table through a shifted base pointer
-            loc[0].d_name_off = self.d_off.data_ptr() - 8 * self.rec_base
+            loc[0].d_name_off = self.d_off.data_ptr()
             chk(lib.gci_pack_names(ctx, loc, self._p(ex.send_names), ex.name_cap, self._p(ex.send_off)),
                 "gci_pack_names")
             g = ex.gather()

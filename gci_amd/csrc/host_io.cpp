@@ -81,6 +81,23 @@ extern "C" int gci_bgzf_scan(const uint8_t* h_raw, uint64_t n_raw, uint64_t* n_b
     return GCI_OK;
 }
 
+// Member table of a BGZF byte string: h_pos[i] = byte offset of member i, h_isize[i] = its inflated size
+// (h_pos[n_blocks] = n_raw when cap allows).  Lets a host stream a large file chunk by chunk.
+extern "C" int gci_bgzf_blocks(const uint8_t* h_raw, uint64_t n_raw, uint64_t* h_pos, uint64_t* h_isize, uint64_t cap,
+                               uint64_t* n_blocks)
+{
+    if ((!h_raw && n_raw) || !h_pos || !h_isize) return GCI_E_INVALID;
+    std::vector<Block> blocks;
+    uint64_t total = 0;
+    const int st = scan(h_raw, n_raw, blocks, total);
+    if (st) return st;
+    if (n_blocks) *n_blocks = blocks.size();
+    if (blocks.size() > cap) return GCI_E_CAPACITY;
+    for (size_t i = 0; i < blocks.size(); i++) { h_pos[i] = blocks[i].pos; h_isize[i] = blocks[i].isize; }
+    if (blocks.size() < cap) h_pos[blocks.size()] = n_raw;
+    return GCI_OK;
+}
+
 // Inflate every member into h_out (capacity cap >= the size gci_bgzf_scan reported), members in parallel.
 extern "C" int gci_bgzf_inflate(const uint8_t* h_raw, uint64_t n_raw, uint8_t* h_out, uint64_t cap, int threads,
                                 int check_crc)
@@ -149,6 +166,28 @@ extern "C" int gci_bam_record_offsets(const uint8_t* h_stream, uint64_t n, uint6
         p += 4 + (uint64_t)bs;
     }
     if (n_rec) *n_rec = k;
+    return GCI_OK;
+}
+
+// Record offsets inside one CHUNK of an inflated stream (a whole number of records is not guaranteed): starts at
+// byte `start`, stops before the first record that is not completely inside [0, n).  *consumed = offset of that
+// record (== n when the chunk ends on a record boundary): the caller carries h_buf[consumed:] into the next chunk.
+extern "C" int gci_bam_chunk_offsets(const uint8_t* h_buf, uint64_t n, uint64_t start, uint64_t* h_offs, uint64_t cap,
+                                     uint64_t* n_rec, uint64_t* consumed)
+{
+    if ((!h_buf && n) || !n_rec || !consumed || start > n) return GCI_E_INVALID;
+    uint64_t p = start, k = 0;
+    while (p + 4 <= n) {
+        int32_t bs;
+        memcpy(&bs, h_buf + p, 4);
+        if (bs < 32) return GCI_E_MALFORMED;
+        if (p + 4 + (uint64_t)bs > n) break;
+        if (h_offs) { if (k >= cap) return GCI_E_CAPACITY; h_offs[k] = p; }
+        k++;
+        p += 4 + (uint64_t)bs;
+    }
+    *n_rec = k;
+    *consumed = p;
     return GCI_OK;
 }
 

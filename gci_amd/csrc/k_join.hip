@@ -16,18 +16,21 @@ struct JoinFiles {
 
 #define SLOT_EMPTY 0xFFFFFFFFFFFFFFFFull
 
-__device__ __forceinline__ const uint8_t* name_ptr(const gci_join_file& f, const gci_rec& r)
+// name bytes of the record at POSITION idx of file f's record array
+__device__ __forceinline__ const uint8_t* name_ptr(const gci_join_file& f, uint32_t idx)
 {
-    return f.d_name_base + f.d_name_off[r.rec_idx] + f.name_delta;
+    return f.d_name_base + f.d_name_off[idx] + f.name_delta;
 }
 
-__device__ __forceinline__ bool same_name(const JoinFiles& F, int fa, const gci_rec& a, unsigned long long owner)
+__device__ __forceinline__ bool same_name(const JoinFiles& F, int fa, uint32_t ia, const gci_rec& a,
+                                          unsigned long long owner)
 {
     const int fb = (int)(owner >> 32);
-    const gci_rec& b = F.f[fb].d_recs[(uint32_t)owner];
+    const uint32_t ib = (uint32_t)owner;
+    const gci_rec& b = F.f[fb].d_recs[ib];
     if (a.name_hash != b.name_hash || a.name_len != b.name_len) return false;
-    const uint8_t* pa = name_ptr(F.f[fa], a);
-    const uint8_t* pb = name_ptr(F.f[fb], b);
+    const uint8_t* pa = name_ptr(F.f[fa], ia);
+    const uint8_t* pb = name_ptr(F.f[fb], ib);
     for (uint32_t i = 0; i < a.name_len; i++) if (pa[i] != pb[i]) return false;
     return true;
 }
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_insert(JoinFiles F, int file, un
             cur = atomicCAS(table + slot, SLOT_EMPTY, me);
             if (cur == SLOT_EMPTY) break;               // claimed
         }
-        if (same_name(F, file, r, cur)) break;
+        if (same_name(F, file, i, r, cur)) break;
         slot = (slot + 1) & mask;
     }
     // order of dict insertion in the reference: contig by contig (header order), file order inside
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_names(gci_join_file f, const uns
     const gci_rec r = f.d_recs[i];
     const uint64_t o = off[i];
     if (o + r.name_len > cap) return;
-    const uint8_t* src = f.d_name_base + f.d_name_off[r.rec_idx] + f.name_delta;
+    const uint8_t* src = f.d_name_base + f.d_name_off[i] + f.name_delta;
     for (uint32_t b = gl; b < r.name_len; b += 16) out[o + b] = src[b];
 }
 

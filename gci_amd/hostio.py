@@ -68,3 +68,30 @@ def gzip_members(text, threads: int = 0, chunk: int = 8 << 20, level: int = 1) -
                               int(threads or default_threads()), out.ctypes.data_as(ctypes.c_void_p), cap,
                               ctypes.byref(n)), "gci_gzip_members")
     return out[:n.value].tobytes()
+
+
+def bgzf_blocks(raw: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Member table of a BGZF byte array: (uint64 byte offsets with one trailing entry = len(raw), uint64 ISIZEs)."""
+    lib = _lib.load()
+    nb = ctypes.c_uint64(0)
+    p = raw.ctypes.data_as(ctypes.c_void_p)
+    _chk(lib.gci_bgzf_scan(p, raw.shape[0], ctypes.byref(nb), None), "gci_bgzf_scan")
+    pos = np.empty(nb.value + 1, dtype=np.uint64)
+    isz = np.empty(nb.value + 1, dtype=np.uint64)
+    _chk(lib.gci_bgzf_blocks(p, raw.shape[0], pos.ctypes.data_as(ctypes.c_void_p), isz.ctypes.data_as(ctypes.c_void_p),
+                             nb.value + 1, ctypes.byref(nb)), "gci_bgzf_blocks")
+    return pos, isz[:nb.value]
+
+
+def bam_chunk_offsets(buf: np.ndarray, start: int = 0) -> Tuple[np.ndarray, int]:
+    """Record offsets of one chunk of an inflated stream -> (uint64 offsets, bytes consumed); buf[consumed:] is the
+    partial record to carry into the next chunk."""
+    lib = _lib.load()
+    n, used = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    p = buf.ctypes.data_as(ctypes.c_void_p)
+    _chk(lib.gci_bam_chunk_offsets(p, buf.shape[0], int(start), None, 0, ctypes.byref(n), ctypes.byref(used)),
+         "gci_bam_chunk_offsets")
+    offs = np.empty(n.value, dtype=np.uint64)
+    _chk(lib.gci_bam_chunk_offsets(p, buf.shape[0], int(start), offs.ctypes.data_as(ctypes.c_void_p), offs.shape[0],
+                                   ctypes.byref(n), ctypes.byref(used)), "gci_bam_chunk_offsets")
+    return offs, int(used.value)

@@ -227,6 +227,103 @@ def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
     return engine.to_device(stream), engine.to_device(offs), hdr
 
 
+# A BAM whose inflated stream exceeds this many bytes is streamed through the GPU chunk by chunk (K1 per chunk,
+# compact records + packed names kept, SEQ/QUAL bytes dropped): real 40x whole-genome BAMs inflate to hundreds of GB.
+BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
+
+
+def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
+                   threads: int = 1, chunk_bytes: Optional[int] = None) -> JoinInput:
+    """K1 over one BAM file -> the file's join input (compact records + where their names are).
+
+    Small files: one upload, names stay addressable inside the inflated stream.  Large files: groups of BGZF
+    members are inflated into a host buffer (the next group on a background thread while the GPU works on the
+    current one), the partial record at the end of a group is carried over, K1 runs per chunk and only the 32-byte
+    records and the packed names (gci_pack_names) are kept on the device."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import hostio
+    chunk_bytes = int(chunk_bytes or BAM_CHUNK_BYTES)
+    nthreads = max(int(threads), hostio.default_threads())
+    raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+    pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+    map_qual, mq_cutoff, clip_percent, iden_percent = filt
+
+    def ref_sel_for(hdr):
+        for t in targets:
+            if t not in hdr.references:
+                raise ValueError(f"invalid contig `{t}`")          # what pysam's fetch() raises
+        tindex = {t: i for i, t in enumerate(targets)}
+        return engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
+
+    if int(isz.sum()) <= chunk_bytes:
+        stream = hostio.bgzf_inflate(np.asarray(raw), threads=nthreads)
+        hdr = bamfmt.parse_header(stream)
+        offs, _ = hostio.bam_record_offsets(stream)
+        d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+        recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent)
+        return JoinInput(recs, d_bam, d_off, 36)
+
+    # ---- streamed ------------------------------------------------------------------------------------------
+    groups, a, acc = [], 0, 0
+    for i, sz in enumerate(isz.tolist()):
+        if acc and acc + sz > chunk_bytes:
+            groups.append((a, i))
+            a, acc = i, 0
+        acc += sz
+    groups.append((a, len(isz)))
+
+    def inflate(g):
+        lo, hi = g
+        return hostio.bgzf_inflate(np.asarray(raw[int(pos[lo]):int(pos[hi])]), threads=nthreads)
+
+    rec_parts, name_parts, off_parts = [], [], []
+    carry = np.zeros(0, dtype=np.uint8)
+    n_done, name_base, hdr, ref_sel = 0, 0, None, None
+    with ThreadPoolExecutor(1) as ex:
+        nxt = ex.submit(inflate, groups[0])
+        for k in range(len(groups)):
+            data = nxt.result()
+            if k + 1 < len(groups):
+                nxt = ex.submit(inflate, groups[k + 1])
+            buf = np.concatenate([carry, data]) if carry.shape[0] else data
+            start = 0
+            if hdr is None:
+                try:
+                    hdr = bamfmt.parse_header(buf)
+                except Exception:                              # header longer than one chunk: keep accumulating
+                    carry = buf
+                    continue
+                start, ref_sel = hdr.first_record, ref_sel_for(hdr)
+            offs, used = hostio.bam_chunk_offsets(buf, start)
+            carry = buf[used:].copy()
+            if offs.shape[0] == 0:
+                continue
+            d_buf, d_off = engine.to_device(buf[:used]), engine.to_device(offs)
+            try:
+                recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent,
+                                         rec_idx_base=n_done)
+            except GciError as e:
+                if e.rec >= 0:
+                    e.rec += n_done
+                raise
+            names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
+            rec_parts.append(recs.clone())
+            name_parts.append(names.clone())
+            off_parts.append(noff[:-1] + name_base)
+            name_base += int(names.shape[0])
+            n_done += int(offs.shape[0])
+            del d_buf, d_off
+    if carry.shape[0]:
+        raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % carry.shape[0])
+    if hdr is None:
+        raise bamfmt.BAMError("no BAM header in %s" % path)
+    dev = engine.device
+    recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
+    names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
+    noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
+    return JoinInput(recs, names if names.shape[0] else torch.zeros(1, dtype=torch.uint8, device=dev), noff, 0)
+
+
 def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, iden_percent=0.9,  # noqa: A001
            clip_percent=0.1, ovlp_percent=0.9, flank_len=15, directory=".", force=False, log_reads_type="",
            chrs_list=[], threads=1, engine: Optional[Engine] = None, write=True, issue_hint=None):
@@ -253,19 +350,11 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     if len(paf_files) != 0:
         paf_dicts, high_qual = paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
         inputs += [_paf_join_input(engine, d, high_qual, tindex) for d in paf_dicts]
-    keep_alive = []
     for path in bam_files:
-        d_bam, d_off, hdr = load_bam_to_device(engine, path, threads)
-        for t in targets:
-            if t not in hdr.references:
-                raise ValueError(f"invalid contig `{t}`")          # what pysam's fetch() raises
-        ref_sel = engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
         try:
-            recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
+            inputs.append(bam_join_input(engine, path, targets, (map_qual, mq_cutoff, clip_percent, iden_percent), threads))
         except GciError as e:
             _reraise_like_reference(e)
-        inputs.append(JoinInput(recs, d_bam, d_off, 36))
-        keep_alive.append((d_bam, d_off))
     try:
         ivl, count = engine.name_join(inputs, ovlp_percent)
     except GciError as e:

@@ -65,7 +65,7 @@ typedef struct gci_rec {
     int32_t start;             /* reference_start */
     int32_t end;               /* reference_end */
     int32_t qlen;              /* query_length */
-    uint32_t rec_idx;          /* index of the record in its file (order = file order) */
+    uint32_t rec_idx;          /* rec_idx_base + index of the record in the K1 call (informational) */
     uint8_t mapq;
     uint8_t flags;             /* GCI_REC_PASS | GCI_REC_HQ */
     uint16_t name_len;         /* bytes, without NUL */
@@ -81,9 +81,10 @@ typedef struct gci_ivl {
     int32_t pad;
 } gci_ivl;
 
-/* One input of the join: compact records + where the query-name bytes of record i live:
- * d_name_base + d_name_off[recs[i].rec_idx] + name_delta  (BAM: base = the inflated stream,
- * off = record offsets, delta = 36;  PAF: base = a names blob, off = blob offsets, delta = 0). */
+/* One input of the join: compact records + where the query-name bytes of the record at POSITION i of d_recs
+ * live:  d_name_base + d_name_off[i] + name_delta  (BAM: base = the inflated stream, off = record offsets,
+ * delta = 36;  packed names / PAF: base = a names blob, off = blob offsets, delta = 0).  Records must be in file
+ * order: among records of one file with the same name the LAST position wins (dict semantics, GCI.py:166, 269). */
 typedef struct gci_join_file {
     const gci_rec* d_recs;
     uint32_t n_recs;
@@ -238,8 +239,14 @@ int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums /* n_con
  *   gci_bam_record_offsets   end of the BAM header and the byte offset of every record (the one serial step of
  *                            the decode); h_offs may be NULL to count only
  *   gci_gzip_members         gzip-frame text as independent members of `chunk` input bytes, compressed in
- *                            parallel (any multi-member gzip whose payload equals the text is a valid .depth.gz) */
+ *                            parallel (any multi-member gzip whose payload equals the text is a valid .depth.gz)
+ *   gci_bgzf_blocks / gci_bam_chunk_offsets   the same for a host that streams a large file chunk by chunk: the
+ *                            member table, and the record offsets of one chunk with the partial tail reported */
 int gci_bgzf_scan(const uint8_t* h_raw, uint64_t n_raw, uint64_t* n_blocks, uint64_t* inflated_bytes);
+int gci_bgzf_blocks(const uint8_t* h_raw, uint64_t n_raw, uint64_t* h_pos, uint64_t* h_isize, uint64_t cap,
+                    uint64_t* n_blocks);
+int gci_bam_chunk_offsets(const uint8_t* h_buf, uint64_t n, uint64_t start, uint64_t* h_offs, uint64_t cap,
+                          uint64_t* n_rec, uint64_t* consumed);
 int gci_bgzf_inflate(const uint8_t* h_raw, uint64_t n_raw, uint8_t* h_out, uint64_t cap, int threads, int check_crc);
 int gci_bam_record_offsets(const uint8_t* h_stream, uint64_t n, uint64_t* h_offs, uint64_t cap, uint64_t* n_rec,
                            uint64_t* first_record);

@@ -151,3 +151,44 @@ def test_empty_and_ragged_inputs(engine, oracle, tmp_path):
     got = pipeline.collapse_depth_range(depths, -1, 0, 15, 0)
     assert got == oracle.collapse_depth_range(host, -1, 0, 15, 0) == {"c1": [(15, 4985)], "tiny": [], "one": []}
     assert gzip.open(str(tmp_path / "e.depth.gz"), "rb").read() == oracle.depth_text(host)
+
+
+def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkeypatch):
+    """A BAM larger than the chunk budget is streamed: groups of BGZF members, partial records carried over, K1 per
+    chunk, packed names.  Same join input content, same depth, for chunk sizes that cut records at every phase."""
+    from gci_amd.formats import bam
+    contigs = (("a", 600_000), ("b", 250_000))
+    rs = synth.simulate_reads(contigs, 12, "hifi", seed=91)
+    dup = rs.take(np.arange(0, len(rs), 11))                        # repeated names far apart in the file
+    dup.pos[:] = np.minimum(dup.pos + 70_000, 200_000)
+    rs = synth.concat(rs, dup).sorted()
+    stream, offs = synth.to_bam_stream(rs)
+    p = str(tmp_path / "s.bam")
+    bam.write_bam_stream(p, stream, level=1, threads=4)
+    targets = ["a", "b"]
+    tl = dict(contigs)
+    filt = (30, 50, 0.1, 0.9)
+    want_d, hq = oracle.bam_file_dict(stream, offs, targets, targets, *filt)
+    want = oracle.depth_build(oracle.name_join([want_d], hq, 0.9), tl, 15)
+    engine.set_layout([tl[t] for t in targets])
+    for chunk in (None, 9_000_001, 1_234_567, 300_000):
+        ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk)
+        assert ji.recs.shape[0] == len(rs)
+        assert (ji.name_delta == 0) == (chunk is not None)
+        ivl, cnt = engine.name_join([ji], 0.9)
+        track = engine.new_track()
+        engine.depth_build(ivl, cnt, 15, track)
+        tr = pipeline.DepthTracks(engine, tl, track)
+        for t in targets:
+            assert np.array_equal(tr[t], want[t]), (chunk, t)
+    # and through filter() with the environment knob, including a second (perturbed) file and the join
+    rs2 = synth.perturb(rs, 92)
+    p2 = str(tmp_path / "s2.bam")
+    synth.write_bam_file(p2, rs2, threads=4)
+    s2, o2 = synth.to_bam_stream(rs2)
+    d2, h2 = oracle.bam_file_dict(s2, o2, targets, targets, *filt)
+    want2 = oracle.depth_build(oracle.name_join([want_d, d2], hq | h2, 0.9), tl, 15)
+    monkeypatch.setattr(pipeline, "BAM_CHUNK_BYTES", 2_000_000)
+    depths, _ = pipeline.filter([], [p, p2], prefix="st", directory=str(tmp_path), engine=engine, threads=4)
+    for t in targets:
+        assert np.array_equal(depths[t], want2[t]), t
