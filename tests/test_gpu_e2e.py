@@ -192,3 +192,60 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     depths, _ = pipeline.filter([], [p, p2], prefix="st", directory=str(tmp_path), engine=engine, threads=4)
     for t in targets:
         assert np.array_equal(depths[t], want2[t]), t
+
+
+def test_genome_scale_layout_chm13(engine, oracle):
+    """BASELINE configs[2] geometry: CHM13 (25 contigs, 3.117 Gb => 761 k tiles, > 2^31 elements in one track).
+    Intervals are generated directly (5x); checks that no 32-bit index is hiding anywhere: per-contig sums equal the
+    sum of trimmed interval lengths, the fused by-products equal the stand-alone kernels, three whole contigs
+    (first, last = chrM, one in the middle past the 2^31st element) equal the oracle bit for bit, text sizes add up."""
+    contigs = synth.CHM13
+    lens = np.array([l for _, l in contigs], dtype=np.int64)
+    assert lens.sum() > 2**31
+    rng = np.random.default_rng(2025)
+    n = 900_000
+    c = np.searchsorted(np.cumsum(lens), rng.integers(0, lens.sum(), n), side="right").astype(np.int32)
+    c[:200] = 24                                                     # some reads on chrM (16,569 bp)
+    L = lens[c]
+    span = np.minimum(np.clip(rng.normal(18_000, 2_500, n), 5_000, 30_000).astype(np.int64), np.maximum(L - 1, 1))
+    s = (rng.random(n) * (L - span)).astype(np.int64)
+    e = s + span
+    e[::1000] = L[::1000]                                            # reads reaching the contig end exactly
+    ivl = np.stack([c, s.astype(np.int32), e.astype(np.int32), np.zeros(n, np.int32)], axis=1).astype(np.int32)
+    offs = engine.set_layout(lens.tolist())
+    assert engine.total > 2**31 and offs[12] * 1 > 0
+    d_ivl = engine.to_device(ivl)
+    track = engine.new_track()
+    fl = 15
+    out = engine.depth_build_fused(d_ivl, None, fl, track, want_text=True, want_sums=True, issue=(-1, 0, fl))
+    a = np.clip(s + fl, 0, L)
+    b = np.clip(e - fl + 1, 0, L)
+    want_sums = np.zeros(len(lens), dtype=np.int64)
+    np.add.at(want_sums, c, np.maximum(b - a, 0))
+    assert np.array_equal(out["sums"], want_sums)
+    assert np.array_equal(engine.depth_sum(track), want_sums)
+    tl = {nme: int(l) for nme, l in contigs}
+    tr = pipeline.DepthTracks(engine, tl, track)
+    names = [nme for nme, _ in contigs]
+    for ci in (0, 13, 24):                                           # chr1, chr14 (starts beyond 2^31 elements), chrM
+        assert ci != 13 or offs[ci] > 2**31
+        sel = c == ci
+        want = oracle.depth_build({i: (names[ci], int(s[i]), int(e[i])) for i in np.flatnonzero(sel)}, {names[ci]: tl[names[ci]]}, fl)[names[ci]]
+        got = tr[names[ci]]
+        assert np.array_equal(got, want), names[ci]
+        t0, t1 = int(out["text_off"][ci]), int(out["text_off"][ci + 1])
+        assert out["text"][t0:t1].cpu().numpy().tobytes() == oracle.depth_text_contig(want)
+        tr._fresh_runs = ((-1.0, 0.0, fl), out["runs"])
+        fused = pipeline.collapse_depth_range(tr, -1, 0, fl, 0)[names[ci]]
+        assert fused == oracle.collapse_contig(want, -1, 0, fl, 0)
+    tr.invalidate()
+    standalone = pipeline.collapse_depth_range(tr, -1, 0, fl, 0)
+    tr._fresh_runs = ((-1.0, 0.0, fl), out["runs"])
+    assert standalone == pipeline.collapse_depth_range(tr, -1, 0, fl, 0)
+    # stand-alone text kernels agree with the fused text
+    text2, off2 = engine.depth_text(track)
+    assert np.array_equal(off2, out["text_off"]) and torch.equal(text2, out["text"])
+    # total text bytes = sum over bases of (digits + 1): recompute from the per-depth histogram of one big contig
+    h = np.bincount(tr["chr2"])
+    digits = np.array([len(str(v)) + 1 for v in range(h.shape[0])])
+    assert int((h * digits).sum()) == int(out["text_off"][2] - out["text_off"][1])
