@@ -30,6 +30,16 @@
 #define ROW (HEADP + AUXP)
 #define KB 128                    // threads per workgroup of the fast path (32 records)
 
+struct LongItem {                // a parsed record whose CIGAR totals are still to be summed (k_cigar_long)
+    uint64_t ops_off;            // byte offset of its CIGAR words in the stream
+    uint32_t n_ops;
+    uint32_t rec;
+    int64_t nm;                  // INT64_MAX: no NM tag, INT64_MIN: NM of a non-integer type
+    int32_t pos, contig, l_seq, n_cigar_field;
+    uint32_t mapq;
+    uint32_t pad;
+};
+
 __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec, int code)
 {
     atomicMin(status, ((unsigned long long)rec << 8) | (unsigned long long)(uint8_t)(-code));
@@ -116,7 +126,8 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status,
-    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ n_slow
+    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ n_slow, LongItem* __restrict__ long_items,
+    uint32_t* __restrict__ n_long
 #ifdef GCI_K1_TRACE
     , unsigned long long* __restrict__ trace
 #endif
@@ -209,7 +220,9 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         }
     }
     TR(9);
-    const bool odd = cig_at + 4 > HEAD || n_cigar > LONG_OPS;     // first CIGAR word must lie inside the staged head
+    const bool odd_name = cig_at + 4 > HEAD;                    // first CIGAR word must lie inside the staged head
+    const bool long_cigar = n_cigar > LONG_OPS;                // its totals are computed by k_cigar_long
+    const bool odd = odd_name || long_cigar;
     const uint32_t staged_ops = odd ? 0u : min(n_cigar, (HEAD - cig_at) / 4u);
     unsigned long long* tot = tot_lds[grp];
     if (!odd) {
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     TR(4);
 
     // ---- anything the staged window cannot answer goes to the slow path -------------------------------------------
-    bool slow = odd;
+    bool slow = odd_name;
     // htslib's long-CIGAR placeholder: op0 == <l_seq>S and a CG:B,I tag somewhere in the aux block
     if (!slow && n_cigar > 0 && pos >= 0) {
         const uint32_t op0 = lds_u32(hd + cig_at);
@@ -345,6 +358,18 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     r.name_len = (uint16_t)name_len;
 
     TR(6);
+    if (long_cigar) {           // parse is complete: hand only the CIGAR totals + decision to k_cigar_long
+        if (gl == 0) {
+            LongItem it;
+            it.ops_off = off + cig_at; it.n_ops = n_cigar; it.rec = rec;
+            it.nm = have_nm ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;               // sentinels: bad type / absent
+            it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
+            it.mapq = (uint32_t)mapq; it.pad = 0;
+            long_items[atomicAdd(n_long, 1u)] = it;
+            out[rec] = r;                                                           // name hash / length are final
+        }
+        return;
+    }
     wave_lds_fence();
     if (gl != 0) return;        // the rest is scalar per record; the LDS operations of a wave complete in order
     int64_t tt[NSLOT];
@@ -355,6 +380,72 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     if (st != GCI_OK) report(status, rec, st);
     out[rec] = r;
     TR(7);
+}
+
+// ---- long CIGARs: one WAVE per queued record sums the op array (16-byte aligned loads, four chunk pairs in flight)
+// and takes the decision; everything else about the record was parsed by the fast path ------------------------------
+
+__device__ __forceinline__ void cigar_totals_wave(const uint8_t* __restrict__ bam, uint64_t n_bytes, uint64_t p0,
+                                                  uint32_t n_ops, int lane, int64_t (&tot)[NSLOT])
+{
+    long long sum[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) sum[k] = 0;
+    const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
+    const uint64_t a0 = p0 & ~15ull, lim = n_bytes & ~15ull;
+    for (uint32_t c0 = lane; 4ull * c0 < n_ops; c0 += 256) {
+        uint4 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = c0 + 64u * u;
+            const uint64_t a = a0 + 16ull * c;
+            const bool in = 4ull * c < n_ops;
+            lo[u] = !in ? make_uint4(0, 0, 0, 0) : a < lim ? *reinterpret_cast<const uint4*>(bam + a) : load16_tail(bam, a, n_bytes);
+            hi[u] = !in ? make_uint4(0, 0, 0, 0) : a + 16 < lim ? *reinterpret_cast<const uint4*>(bam + a + 16) : load16_tail(bam, a + 16, n_bytes);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = c0 + 64u * u;
+            if (4ull * c >= n_ops) continue;
+            const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            const uint32_t m = min(4u, n_ops - 4u * c);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
+                const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
+                const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
+                const uint32_t op = v & 0xFu;
+                const long long len = (uint32_t)j < m ? (long long)(v >> 4) : 0;
+#pragma unroll
+                for (int q = 0; q < NSLOT - 1; q++) sum[q] += op == (uint32_t)q ? len : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; k++) tot[k] = wave_sum<long long>(sum[k]);
+    tot[NSLOT - 1] = 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cigar_long(const uint8_t* __restrict__ bam, uint64_t n_bytes,
+                                                      const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long,
+                                                      int mq_cutoff, double clip_percent, double iden_percent,
+                                                      gci_rec* __restrict__ out, unsigned long long* __restrict__ status)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = *n_long;
+    const uint32_t waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t it = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); it < n; it += waves) {
+        const LongItem x = items[it];
+        int64_t tot[NSLOT];
+        cigar_totals_wave(bam, n_bytes, x.ops_off, x.n_ops, lane, tot);
+        if (lane == 0) {
+            gci_rec r = out[x.rec];
+            const int st = decide(r, tot, x.nm != INT64_MAX, x.nm == INT64_MIN, x.nm, x.pos, x.contig, x.l_seq,
+                                  (uint32_t)x.n_cigar_field, (int)x.mapq, mq_cutoff, clip_percent, iden_percent);
+            if (st != GCI_OK) report(status, x.rec, st);
+            out[x.rec] = r;
+        }
+    }
 }
 
 // ---- slow path: one WAVE per queued record, everything read from global memory --------------------------------
@@ -450,48 +541,8 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
                 if (cg_len >= n_cigar && cg_len < (1u << 29)) { ops = cg_p + 6; n_ops = cg_len; }
             }
         }
-        // CIGAR totals: lane handles 16-byte pieces lane, lane + 64, ... of the op array
-        long long sum[NSLOT];
-#pragma unroll
-        for (int k = 0; k < NSLOT; k++) sum[k] = 0;
-        {
-            const uint64_t p0 = (uint64_t)(ops - bam);
-            const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
-            const uint64_t a0 = p0 & ~15ull, lim = n_bytes & ~15ull;
-            // four independent chunk pairs per lane and step keep enough loads in flight for long CIGARs
-            for (uint32_t c0 = lane; 4ull * c0 < n_ops; c0 += 256) {
-                uint4 lo[4], hi[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t c = c0 + 64u * u;
-                    const uint64_t a = a0 + 16ull * c;
-                    const bool in = 4ull * c < n_ops;
-                    lo[u] = !in ? make_uint4(0, 0, 0, 0) : a < lim ? *reinterpret_cast<const uint4*>(bam + a) : load16_tail(bam, a, n_bytes);
-                    hi[u] = !in ? make_uint4(0, 0, 0, 0) : a + 16 < lim ? *reinterpret_cast<const uint4*>(bam + a + 16) : load16_tail(bam, a + 16, n_bytes);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t c = c0 + 64u * u;
-                    if (4ull * c >= n_ops) continue;
-                    const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
-                    const uint32_t m = min(4u, n_ops - 4u * c);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
-                        const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
-                        const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
-                        const uint32_t op = v & 0xFu;
-                        const long long len = (uint32_t)j < m ? (long long)(v >> 4) : 0;
-#pragma unroll
-                        for (int q = 0; q < NSLOT - 1; q++) sum[q] += op == (uint32_t)q ? len : 0;
-                    }
-                }
-            }
-        }
         int64_t tot[NSLOT];
-#pragma unroll
-        for (int k = 0; k < NSLOT - 1; k++) tot[k] = wave_sum<long long>(sum[k]);
-        tot[NSLOT - 1] = 0;
+        cigar_totals_wave(bam, n_bytes, (uint64_t)(ops - bam), n_ops, lane, tot);
         if (lane == 0) {
             gci_rec r;
             r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
@@ -510,17 +561,21 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                               uint64_t* d_status)
 {
     if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
-    GCI_TRY(gci_ensure(ctx, ctx->long_items, (size_t)(n_rec + 4) * 4));
-    uint32_t* n_slow = (uint32_t*)ctx->long_items.p;           // [0] = counter, [1..] = queued record indices
-    uint32_t* slow_list = n_slow + 1;
+    // scratch: [n_slow u32][n_long u32][slow_list u32 x n_rec (+pad)][long items x n_rec]
+    const size_t list_bytes = ((size_t)n_rec * 4 + 15) & ~(size_t)15;
+    GCI_TRY(gci_ensure(ctx, ctx->long_items, 16 + list_bytes + (size_t)n_rec * sizeof(LongItem)));
+    uint32_t* n_slow = (uint32_t*)ctx->long_items.p;
+    uint32_t* n_long = n_slow + 1;
+    uint32_t* slow_list = n_slow + 4;
+    LongItem* long_items = (LongItem*)((uint8_t*)ctx->long_items.p + 16 + list_bytes);
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(n_slow, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(n_slow, 0, 8, ctx->stream));
     if (n_rec == 0) return GCI_OK;
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
     const uint32_t per_block = KB / G;
     hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(KB), 0, ctx->stream, d_bam, n_bytes,
                        d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base,
-                       d_out, (unsigned long long*)d_status, slow_list, n_slow
+                       d_out, (unsigned long long*)d_status, slow_list, n_slow, long_items, n_long
 #ifdef GCI_K1_TRACE
                        , (unsigned long long*)strtoull(getenv("GCI_K1_TRACE_PTR") ? getenv("GCI_K1_TRACE_PTR") : "0", nullptr, 0)
 #endif
@@ -530,6 +585,10 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                        n_bytes, d_rec_off, d_ref_sel, (const uint32_t*)slow_list, (const uint32_t*)n_slow, mq_cutoff, clip_percent,
                        iden_percent, rec_idx_base, d_out, (unsigned long long*)d_status);
     LAUNCHCHK("k_bam_filter_slow");
+    hipLaunchKernelGGL(k_cigar_long, dim3(n_rec < 8192u ? (n_rec + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam, n_bytes,
+                       (const LongItem*)long_items, (const uint32_t*)n_long, mq_cutoff, clip_percent, iden_percent, d_out,
+                       (unsigned long long*)d_status);
+    LAUNCHCHK("k_cigar_long");
     return GCI_OK;
 }
 
