@@ -123,6 +123,19 @@ def case_paf_bam():
     run_reference("c4_paf_bam", {}, hifi=["hifi.mm2.paf", "hifi.wm2.bam"])
 
 
+def case_two_paf():
+    """Two PAF files + one BAM in one read type: pins the reference's quirk that `synteny` is created once, before
+    the per-file loop (GCI.py:214-215), so the second PAF re-emits every query and block of the first."""
+    contigs = (("chrA", 160_000), ("chrB", 70_000))
+    a = synth.simulate_reads(contigs, 18, "hifi", seed=synth.seed_for(4, 20))
+    b = synth.perturb(a, synth.seed_for(4, 21))
+    c = synth.perturb(a, synth.seed_for(4, 22))
+    write_inputs(os.path.join(GOLDEN, "c4_two_paf"), contigs,
+                 {"hifi.wm2.bam": a, "hifi.mm2.paf": synth.to_paf_lines(b, synth.seed_for(4, 23), split_frac=0.15),
+                  "hifi.other.paf": synth.to_paf_lines(c.take(np.arange(0, len(c), 2)), synth.seed_for(4, 24), split_frac=0.15)})
+    run_reference("c4_two_paf", {"mq_cutoff": 40}, hifi=["hifi.mm2.paf", "hifi.other.paf", "hifi.wm2.bam"])
+
+
 def case_two_type():
     contigs = (("mat_chr1", 180_000), ("pat_chr1", 160_000), ("mat_chr2", 70_000))
     gaps = {"mat_chr1": [(40_000, 40_500), (100_000, 100_001)], "pat_chr1": [(0, 120)], "mat_chr2": [(69_900, 70_000)]}
@@ -264,7 +277,7 @@ if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
     todo = [("c1", case_single_bam), ("c3a", case_two_bam), ("c3b", case_three_bam_chrs), ("c4a", case_paf_bam),
-            ("c4b", case_nano_only_long_cigar), ("c5", case_two_type), ("kats", make_kats),
+            ("c4b", case_nano_only_long_cigar), ("c4c", case_two_paf), ("c5", case_two_type), ("kats", make_kats),
             ("mh63", copy_reference_example)]
     for name, fn in todo:
         if not only or name in only:
