@@ -70,7 +70,7 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
     if (!ctx) return GCI_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_diff, &ctx->tile_carry, &ctx->evt_cnt,
+    DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_cd, &ctx->tile_carry,
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->win,
                       &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items};
@@ -203,9 +203,8 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     if ((r = gci_upload_small(ctx, ctx->d_off.p, ctx->off.data(), n * 8))) return r;
     if ((r = gci_upload_small(ctx, ctx->d_tile_first.p, ctx->tile_first.data(), (n + 1) * 8))) return r;
     const size_t nb = (size_t)(tiles / TILE + 2);
-    GCI_TRY(gci_ensure(ctx, ctx->tile_diff, (size_t)(tiles + 1) * 4));
+    GCI_TRY(gci_ensure(ctx, ctx->tile_cd, (size_t)(tiles + 1) * 8));
     GCI_TRY(gci_ensure(ctx, ctx->tile_carry, (size_t)(tiles + 1) * 4));
-    GCI_TRY(gci_ensure(ctx, ctx->evt_cnt, (size_t)(tiles + 1) * 4));
     GCI_TRY(gci_ensure(ctx, ctx->evt_off, (size_t)(tiles + 2) * 4));
     GCI_TRY(gci_ensure(ctx, ctx->blk_a, nb * 4));
     GCI_TRY(gci_ensure(ctx, ctx->blk_b, nb * 4));
@@ -213,8 +212,10 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     GCI_TRY(gci_ensure(ctx, ctx->tile_u32, (size_t)(tiles + 1) * 4));
     GCI_TRY(gci_ensure(ctx, ctx->tile_u64, (size_t)(tiles + 2) * 8));
     GCI_TRY(gci_ensure(ctx, ctx->blk_u64, nb * 8));
-    // the event counters are self-cleaning (k_evt_scatter returns them to zero): zero them once here
-    HIPCHK(hipMemsetAsync(ctx->evt_cnt.p, 0, (size_t)(tiles + 1) * 4, ctx->stream));
+    // the per-tile (count, difference) table is self-cleaning (k_scan2_local zeroes the differences, k_evt_scatter
+    // returns the counts to zero): zero it once here
+    HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(tiles + 1) * 8, ctx->stream));
+    ctx->cd_dirty = false;
     ctx->build_pending = false;
     return GCI_OK;
 }

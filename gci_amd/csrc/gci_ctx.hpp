@@ -37,8 +37,11 @@ struct gci_ctx {
     int64_t total = 0, n_tiles = 0;
     DevBuf d_len, d_off, d_tile_first;      // int64 each
     // depth-build scratch (per tile unless noted)
-    DevBuf tile_diff, tile_carry;           // int32: coarse difference table, its exclusive scan
-    DevBuf evt_cnt, evt_off;                // uint32: events per tile, bucket offsets (n_tiles + 1)
+    DevBuf tile_cd;                         // uint64 per tile: low word = events in the tile, high word = coarse
+                                            // difference (int32); both return to zero by the end of a build
+    DevBuf tile_carry;                      // int32: exclusive scan of the coarse difference = depth entering a tile
+    DevBuf evt_off;                         // uint32: bucket offsets (n_tiles + 1)
+    bool cd_dirty = false;                  // a build stopped between count and scatter: tile_cd must be re-zeroed
     DevBuf events;                          // uint16 per event: local position << 1 | is_minus
     DevBuf blk_a, blk_b;                    // block totals of the two scans
     DevBuf tile_sum;                        // int64: sum of depth per tile
@@ -206,7 +209,7 @@ __device__ __forceinline__ unsigned long long issue_key(uint32_t window, int64_t
 
 template <typename TIn, typename TOut>
 __device__ __forceinline__ void scan_local_body(const TIn* __restrict__ in, TOut* __restrict__ out,
-                                                TOut* __restrict__ blk_tot, int64_t n, uint32_t blk)
+                                                TOut* __restrict__ blk_tot, int64_t n, uint32_t blk, int64_t stride = 1)
 {
     __shared__ TOut wtot[BLOCK / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void scan_local_body(const TIn* __restrict__ in, TOut
     TOut v[16];
     TOut run = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { v[i] = base + i < n ? (TOut)in[base + i] : (TOut)0; run += v[i]; }
+    for (int i = 0; i < 16; i++) { v[i] = base + i < n ? (TOut)in[(base + i) * stride] : (TOut)0; run += v[i]; }
     const TOut inc = wave_inclusive<TOut>(run, lane);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();

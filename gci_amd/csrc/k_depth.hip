@@ -48,27 +48,32 @@ __device__ __forceinline__ IvlSpan span_of(const gci_ivl v, int flank, const int
     return s;
 }
 
+// One 64-bit atomic per interval end: the low word of tile_cd counts the events of a tile, the high word carries
+// the coarse difference (+1 in the tile of the start, -1 in the tile of the stop).
 __global__ __launch_bounds__(BLOCK) void k_evt_count(const gci_ivl* __restrict__ ivl, const uint32_t* __restrict__ d_n,
                                                      uint32_t max_n, int flank, const int64_t* __restrict__ len,
                                                      const int64_t* __restrict__ tile_first, int32_t n_contigs,
-                                                     uint32_t* __restrict__ evt_cnt, int32_t* __restrict__ tile_diff)
+                                                     unsigned long long* __restrict__ tile_cd)
 {
     const uint32_t n = d_n ? min(*d_n, max_n) : max_n;
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const IvlSpan s = span_of(ivl[i], flank, len, tile_first, n_contigs);
     if (!s.valid) return;
-    atomicAdd(evt_cnt + s.tile_a, 1u);
-    atomicAdd(tile_diff + s.tile_a, 1);
-    if (s.has_b) atomicAdd(evt_cnt + s.tile_b, 1u);
-    atomicAdd(tile_diff + s.tile_bc, -1);
+    const unsigned long long minus1 = 0xFFFFFFFFull << 32;         // -1 in the high word (the low word never carries)
+    atomicAdd(tile_cd + s.tile_a, 1ull | (1ull << 32));
+    if (s.has_b && s.tile_b == s.tile_bc) atomicAdd(tile_cd + s.tile_b, 1ull | minus1);
+    else {
+        if (s.has_b) atomicAdd(tile_cd + s.tile_b, 1ull);
+        atomicAdd(tile_cd + s.tile_bc, minus1);
+    }
 }
 
-// evt_cnt is decremented back to zero while handing out bucket slots: no memset next time
+// the counts are decremented back to zero while handing out bucket slots: no memset next time
 __global__ __launch_bounds__(BLOCK) void k_evt_scatter(const gci_ivl* __restrict__ ivl, const uint32_t* __restrict__ d_n,
                                                        uint32_t max_n, int flank, const int64_t* __restrict__ len,
                                                        const int64_t* __restrict__ tile_first, int32_t n_contigs,
-                                                       uint32_t* __restrict__ evt_cnt, const uint32_t* __restrict__ evt_off,
+                                                       uint32_t* __restrict__ tile_cd_words, const uint32_t* __restrict__ evt_off,
                                                        uint16_t* __restrict__ events)
 {
     const uint32_t n = d_n ? min(*d_n, max_n) : max_n;
@@ -76,28 +81,27 @@ __global__ __launch_bounds__(BLOCK) void k_evt_scatter(const gci_ivl* __restrict
     if (i >= n) return;
     const IvlSpan s = span_of(ivl[i], flank, len, tile_first, n_contigs);
     if (!s.valid) return;
-    events[evt_off[s.tile_a] + atomicSub(evt_cnt + s.tile_a, 1u) - 1u] = (uint16_t)(s.pos_a << 1);
-    if (s.has_b) events[evt_off[s.tile_b] + atomicSub(evt_cnt + s.tile_b, 1u) - 1u] = (uint16_t)((s.pos_b << 1) | 1u);
+    events[evt_off[s.tile_a] + atomicSub(tile_cd_words + 2 * s.tile_a, 1u) - 1u] = (uint16_t)(s.pos_a << 1);
+    if (s.has_b) events[evt_off[s.tile_b] + atomicSub(tile_cd_words + 2 * s.tile_b, 1u) - 1u] = (uint16_t)((s.pos_b << 1) | 1u);
 }
 
-// zero the coarse table and the small outputs of a build in one launch
-__global__ __launch_bounds__(BLOCK) void k_build_prep(int32_t* __restrict__ tile_diff, int64_t n_tiles,
-                                                      uint32_t* __restrict__ n_keys, long long* __restrict__ sums,
-                                                      int32_t n_contigs)
+// Both per-tile scans in one launch: blockIdx.y == 0 coarse difference (high words) -> carry, == 1 counts (low
+// words) -> offsets.  The y == 0 blocks also zero the high words they consumed and the small outputs of the build.
+__global__ __launch_bounds__(BLOCK) void k_scan2_local(uint32_t* __restrict__ cd_words, int32_t* __restrict__ carry,
+                                                       int32_t* __restrict__ blk_a, uint32_t* __restrict__ off,
+                                                       uint32_t* __restrict__ blk_b, int64_t n, uint32_t* __restrict__ n_keys,
+                                                       long long* __restrict__ sums, int32_t n_contigs)
 {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n_tiles) tile_diff[i] = 0;
-    if (i == 0 && n_keys) *n_keys = 0;
-    if (sums) for (int64_t c = i; c < n_contigs; c += (int64_t)gridDim.x * BLOCK) sums[c] = 0;
-}
-
-// both per-tile scans in one launch: blockIdx.y == 0 coarse difference -> carry, == 1 counts -> offsets
-__global__ __launch_bounds__(BLOCK) void k_scan2_local(const int32_t* __restrict__ diff, int32_t* __restrict__ carry,
-                                                       int32_t* __restrict__ blk_a, const uint32_t* __restrict__ cnt,
-                                                       uint32_t* __restrict__ off, uint32_t* __restrict__ blk_b, int64_t n)
-{
-    if (blockIdx.y == 0) scan_local_body<int32_t, int32_t>(diff, carry, blk_a, n, blockIdx.x);
-    else scan_local_body<uint32_t, uint32_t>(cnt, off, blk_b, n, blockIdx.x);
+    if (blockIdx.y == 0) {
+        scan_local_body<int32_t, int32_t>((const int32_t*)cd_words + 1, carry, blk_a, n, blockIdx.x, 2);
+        const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) if (base + i < n) cd_words[2 * (base + i) + 1] = 0u;      // own elements only
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0 && n_keys) *n_keys = 0;
+            if (sums) for (int32_t c = threadIdx.x; c < n_contigs; c += BLOCK) sums[c] = 0;
+        }
+    } else scan_local_body<uint32_t, uint32_t>(cd_words, off, blk_b, n, blockIdx.x, 2);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_scan2_add(int32_t* __restrict__ carry, const int32_t* __restrict__ blk_a,
@@ -318,25 +322,22 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     GCI_TRY(gci_ensure(ctx, ctx->events, (size_t)max_n * 2 * sizeof(uint16_t) + 16));
     const int64_t* ln = (const int64_t*)ctx->d_len.p;
     const int64_t* tf = (const int64_t*)ctx->d_tile_first.p;
-    int32_t* diff = (int32_t*)ctx->tile_diff.p;
-    uint32_t* cnt = (uint32_t*)ctx->evt_cnt.p;
+    unsigned long long* cd = (unsigned long long*)ctx->tile_cd.p;
     uint32_t* off = (uint32_t*)ctx->evt_off.p;
     const int32_t nb = (int32_t)((nt + TILE - 1) / TILE);
-    {
+    if (ctx->cd_dirty) HIPCHK(hipMemsetAsync(cd, 0, (size_t)(nt + 1) * 8, ctx->stream));
+    ctx->cd_dirty = true;
+    if (max_n) {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
-        hipLaunchKernelGGL(k_build_prep, dim3((uint32_t)((nt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, diff, nt,
-                           o->d_n_keys, (long long*)o->d_sums, ctx->n_contigs);
-        LAUNCHCHK("k_build_prep");
-        if (max_n) {
-            hipLaunchKernelGGL(k_evt_count, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
-                               o->flank, ln, tf, ctx->n_contigs, cnt, diff);
-            LAUNCHCHK("k_evt_count");
-        }
+        hipLaunchKernelGGL(k_evt_count, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
+                           o->flank, ln, tf, ctx->n_contigs, cd);
+        LAUNCHCHK("k_evt_count");
     }
     {
         ProfScope _ps(ctx, GCI_PROF_SCAN_TILES);
-        hipLaunchKernelGGL(k_scan2_local, dim3(nb, 2), dim3(BLOCK), 0, ctx->stream, diff, (int32_t*)ctx->tile_carry.p,
-                           (int32_t*)ctx->blk_a.p, cnt, off, (uint32_t*)ctx->blk_b.p, nt);
+        hipLaunchKernelGGL(k_scan2_local, dim3(nb, 2), dim3(BLOCK), 0, ctx->stream, (uint32_t*)cd, (int32_t*)ctx->tile_carry.p,
+                           (int32_t*)ctx->blk_a.p, off, (uint32_t*)ctx->blk_b.p, nt, o->d_n_keys, (long long*)o->d_sums,
+                           ctx->n_contigs);
         LAUNCHCHK("k_scan2_local");
         hipLaunchKernelGGL(k_scan2_add, dim3(nb + 1, 2), dim3(BLOCK), 0, ctx->stream, (int32_t*)ctx->tile_carry.p,
                            (const int32_t*)ctx->blk_a.p, off, (const uint32_t*)ctx->blk_b.p, nt, nb);
@@ -345,9 +346,10 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     if (max_n) {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
         hipLaunchKernelGGL(k_evt_scatter, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
-                           o->flank, ln, tf, ctx->n_contigs, cnt, (const uint32_t*)off, (uint16_t*)ctx->events.p);
+                           o->flank, ln, tf, ctx->n_contigs, (uint32_t*)cd, (const uint32_t*)off, (uint16_t*)ctx->events.p);
         LAUNCHCHK("k_evt_scatter");
     }
+    ctx->cd_dirty = false;
     const bool by_products = o->want_text || o->d_sums || o->d_n_keys;
     if (by_products) {
         IssueArgs iss;
