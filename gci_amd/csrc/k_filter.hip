@@ -13,7 +13,7 @@
 //     ds_add_u64 per op into a per-record LDS row indexed by op code -> the two IEEE f64 divisions of
 //     GCI.py:165 -> 32-byte compact record.
 //   slow path (k_bam_filter_slow), one wave per queued record, everything from global memory with
-//     naturally aligned loads only: CIGARs of more than LONG_OPS operations (ultra-long ONT reads and htslib's CG:B,I restore),
+//     naturally aligned loads only: htslib's CG:B,I restore (CIGARs of more than 65535 operations),
 //     records whose NM tag does not show up in the staged part of the aux block, names longer than the
 //     staged head.  Same decisions, same status codes.
 // SEQ and QUAL are skipped by pointer arithmetic and never touched.
@@ -30,14 +30,34 @@
 #define ROW (HEADP + AUXP)
 #define KB 128                    // threads per workgroup of the fast path (32 records)
 
-struct LongItem {                // a parsed record whose CIGAR totals are still to be summed (k_cigar_long)
+#define PIECES 8                  // 16-byte pieces per lane of one CIGAR chunk
+#define CHUNK_DW (64 * PIECES * 4)   // aligned dwords (= CIGAR ops) per chunk: 2048 ops, 8 KiB
+
+// A parsed record whose CIGAR totals are still to be summed.  Its op array is cut at multiples of CHUNK_DW aligned
+// dwords into chunks; k_cigar_chunks gives every chunk to one wave and stores the chunk's class sums, k_cigar_finish
+// adds an item's chunk sums and takes the decision.  No atomics, no fences on that path.
+struct LongItem {
     uint64_t ops_off;            // byte offset of its CIGAR words in the stream
     uint32_t n_ops;
     uint32_t rec;
     int64_t nm;                  // INT64_MAX: no NM tag, INT64_MIN: NM of a non-integer type
     int32_t pos, contig, l_seq, n_cigar_field;
     uint32_t mapq;
+    uint32_t n_chunks;           // 0: refused (queue full), nothing to finish
+    uint32_t chunk_base;         // its chunks are queue entries chunk_base .. chunk_base + n_chunks - 1
     uint32_t pad;
+};
+
+struct ChunkSums { unsigned long long v[5]; };       // bases per class: M/=/X, I, D, N, S
+
+struct LongQueue {
+    uint32_t* n_slow;
+    unsigned long long* n_long;  // (long items << 32) | chunks: one atomic hands out both
+    uint32_t* slow_list;
+    LongItem* items;
+    unsigned long long* chunks;  // (item << 32) | chunk index; ~0 = hole left by a refused item
+    ChunkSums* sums;             // per queue entry
+    uint32_t cap_items, cap_chunks;
 };
 
 __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec, int code)
@@ -48,11 +68,12 @@ __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec,
 __device__ __forceinline__ bool has_zero_byte(uint32_t x) { return ((x - 0x01010101u) & ~x & 0x80808080u) != 0; }
 
 // The decision of GCI.py:163-168 from the op totals; fills r and returns a gci_status (GCI_OK also when filtered).
-__device__ __forceinline__ int decide(gci_rec& r, const int64_t (&tot)[NSLOT], bool have_nm, bool nm_bad_type, int64_t NM,
-                                      int32_t pos, int32_t contig, int32_t l_seq, uint32_t n_cigar_field, int mapq,
-                                      int mq_cutoff, double clip_percent, double iden_percent)
+// M = bases under M, = and X together.
+__device__ __forceinline__ int decide(gci_rec& r, int64_t M, int64_t I, int64_t D, int64_t N, int64_t S, bool have_nm,
+                                      bool nm_bad_type, int64_t NM, int32_t pos, int32_t contig, int32_t l_seq,
+                                      uint32_t n_cigar_field, int mapq, int mq_cutoff, double clip_percent,
+                                      double iden_percent)
 {
-    const int64_t M = tot[0] + tot[7] + tot[8], I = tot[1], D = tot[2], N = tot[3], S = tot[4];
     if (!have_nm) return GCI_E_NO_NM;                                              // get_tag('NM'): KeyError
     if (nm_bad_type) return GCI_E_BAD_NM_TYPE;
     const int64_t mm = NM - (I + D);                                               // GCI.py:164
@@ -88,25 +109,24 @@ __device__ __forceinline__ bool nm_value(P t, int64_t& NM)
     }
 }
 
+// the 16 bytes at aligned offset `at`, zero past the end of the stream (the last, partial chunk)
+__device__ __forceinline__ uint4 load16_tail(const uint8_t* __restrict__ bam, uint64_t at, uint64_t n_bytes)
+{
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (at + i < n_bytes) w[i >> 2] |= (uint32_t)bam[at + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // 16 bytes global -> LDS from a 16-byte aligned stream offset; bytes past the end of the stream read as zero
 __device__ __forceinline__ void stage16(uint8_t* dst, const uint8_t* __restrict__ bam, uint64_t at, uint64_t n_bytes)
 {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (at + 16 <= n_bytes) v = *reinterpret_cast<const uint4*>(bam + at);
     else if (at < n_bytes) {
-        uint8_t tmp[16];
-        for (int b = 0; b < 16; b++) tmp[b] = at + b < n_bytes ? bam[at + b] : 0;
-        __builtin_memcpy(&v, tmp, 16);
+        v = load16_tail(bam, at, n_bytes);
     }
     *reinterpret_cast<uint4*>(dst) = v;
-}
-
-// the 16 bytes at aligned offset `at`, zero past the end of the stream (the last, partial chunk)
-__device__ __forceinline__ uint4 load16_tail(const uint8_t* __restrict__ bam, uint64_t at, uint64_t n_bytes)
-{
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 16; i++) if (at + i < n_bytes) w[i >> 2] |= (uint32_t)bam[at + i] << (8 * (i & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 __device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -120,14 +140,51 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define REF_LDS 2048             // refID -> selected-contig table kept in LDS up to this many references
+// Queue a parsed record for chunked CIGAR summing.  Called by W consecutive lanes (li = index among them) that hold
+// the same item -- W == G: any subset of a wave's record groups, their requests combined into one atomic; W == 64: a
+// whole wave with one record.  False when the queues are full (only possible with overlapping record offsets).
+template <int W>
+__device__ __forceinline__ bool enqueue_long(const LongQueue& q, LongItem it, int li)
+{
+    const uint32_t d0 = (uint32_t)(it.ops_off & 15ull) >> 2;       // first op's dword inside its 16-byte piece
+    const uint32_t nch = (uint32_t)(((uint64_t)d0 + it.n_ops + CHUNK_DW - 1) / CHUNK_DW);
+    uint32_t slot, base;
+    if (W == 64) {
+        unsigned long long old = 0;
+        if (li == 0) old = atomicAdd(q.n_long, (1ull << 32) | nch);
+        slot = (uint32_t)__shfl((int)(old >> 32), 0, 64);
+        base = (uint32_t)__shfl((int)(uint32_t)old, 0, 64);
+    } else {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long leaders = __ballot(li == 0);      // the first lane of every group that is here
+        uint32_t items_below = 0, chunks_below = 0, chunks_all = 0;
+        for (unsigned long long m = leaders; m; m &= m - 1ull) {
+            const int l = __builtin_ctzll(m);
+            const uint32_t v = (uint32_t)__shfl((int)nch, l, 64);
+            if (l < (lane & ~(W - 1))) { items_below++; chunks_below += v; }
+            chunks_all += v;
+        }
+        const int first = __builtin_ctzll(leaders);
+        unsigned long long old = 0;
+        if (lane == first) old = atomicAdd(q.n_long, ((unsigned long long)__builtin_popcountll(leaders) << 32) | chunks_all);
+        slot = (uint32_t)__shfl((int)(old >> 32), first, 64) + items_below;
+        base = (uint32_t)__shfl((int)(uint32_t)old, first, 64) + chunks_below;
+    }
+    const bool ok = slot < q.cap_items && (uint64_t)base + nch <= q.cap_chunks;
+    if (li == 0 && slot < q.cap_items) {
+        it.n_chunks = ok ? nch : 0u; it.chunk_base = base; it.pad = 0;
+        q.items[slot] = it;
+    }
+    for (uint32_t c = li; c < nch; c += W)
+        if ((uint64_t)base + c < q.cap_chunks) q.chunks[base + c] = ok ? ((unsigned long long)slot << 32) | c : ~0ull;
+    return ok;
+}
 
 __global__ __launch_bounds__(KB) void k_bam_filter(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status,
-    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ n_slow, LongItem* __restrict__ long_items,
-    uint32_t* __restrict__ n_long
+    const LongQueue lq
 #ifdef GCI_K1_TRACE
     , unsigned long long* __restrict__ trace
 #endif
@@ -141,7 +198,6 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     TR(0);
     __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
     __shared__ unsigned long long tot_lds[KB / G][NSLOT];                   // op totals per record
-    __shared__ int32_t sel_lds[REF_LDS];
     __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
     const int t = threadIdx.x;
     const int gl = t & (G - 1), grp = t / G;
@@ -151,8 +207,6 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     // ---- independent loads first: the record offset, then (one round trip later) its head ------------------------
     bool live = rec < n_rec;
     const uint64_t off = live ? rec_off[rec] : 0;
-    const bool sel_in_lds = n_ref <= REF_LDS;
-    if (sel_in_lds) for (int i = t; i < n_ref; i += KB) sel_lds[i] = ref_sel[i];
     for (int i = t; i < 256; i += KB) {
         const char c = (char)i;
         aux_sz[i] = (c == 'A' || c == 'c' || c == 'C') ? 1 : (c == 's' || c == 'S') ? 2 : (c == 'i' || c == 'I' || c == 'f') ? 4 : 0;
@@ -201,15 +255,14 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
         return;
     }
-    // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
-    int32_t contig = -1;
-    if (ref_id >= 0 && ref_id < n_ref) contig = sel_in_lds ? sel_lds[ref_id] : ref_sel[ref_id];
-    if (contig < 0 || (flag & (0x4u | 0x100u | 0x800u)) || mapq < map_qual) {
+    if (ref_id < 0 || ref_id >= n_ref || (flag & (0x4u | 0x100u | 0x800u)) || mapq < map_qual) {
         if (gl == 0) out[rec] = r;
         return;
     }
     TR(8);
-    // ---- second (and last) dependent round trip: the aux head and the CIGAR words behind the staged head ---------
+    // ---- second (and last) dependent round trip: the refID -> selected-contig entry, the aux head and the CIGAR
+    // words behind the staged head.  (The table is not kept in LDS: 16 KB per workgroup buys 5 waves per SIMD.)
+    const int32_t contig = ref_sel[ref_id];
     const uint32_t cig_at = 36 + l_read_name;                       // byte offset of the CIGAR in the record
     {
         const uint64_t a0 = aux_off & ~15ull;
@@ -220,8 +273,13 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         }
     }
     TR(9);
+    // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
+    if (contig < 0) {
+        if (gl == 0) out[rec] = r;
+        return;
+    }
     const bool odd_name = cig_at + 4 > HEAD;                    // first CIGAR word must lie inside the staged head
-    const bool long_cigar = n_cigar > LONG_OPS;                // its totals are computed by k_cigar_long
+    const bool long_cigar = n_cigar > LONG_OPS;                // its totals are computed by k_cigar_chunks
     const bool odd = odd_name || long_cigar;
     const uint32_t staged_ops = odd ? 0u : min(n_cigar, (HEAD - cig_at) / 4u);
     unsigned long long* tot = tot_lds[grp];
@@ -235,34 +293,31 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         const uint32_t k0 = staged_ops + gl * per, k1 = min(n_cigar, k0 + per);
         if (k0 < k1) {
             const uint64_t p0 = off + cig_at + 4ull * k0;                   // byte offset of this lane's first op
-            const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
-            uint64_t a = p0 & ~15ull;
+            const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u, cnt = k1 - k0;
+            const uint64_t a = p0 & ~15ull;
             const uint64_t lim = n_bytes & ~15ull;                           // aligned chunks fully inside the stream
             auto ld = [&](uint64_t at) { return at < lim ? *reinterpret_cast<const uint4*>(bam + at) : load16_tail(bam, at, n_bytes); };
-            auto take = [&](const uint4& lo, const uint4& hi, uint32_t m) {
-                const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            // chunk c holds aligned dwords 4c .. 4c + 3; this lane's op k starts in dword d + k.  Every dword of a
+            // chunk is decoded (static register indexing) and the ops outside [0, cnt) are predicated off.
+            auto take = [&](const uint4& lo, uint32_t next_x, uint32_t c) {
+                const uint32_t w[5] = {lo.x, lo.y, lo.z, lo.w, next_x};
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
-                    const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
-                    const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
-                    if ((uint32_t)j < m) { const uint32_t op = v & 0xF; atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4)); }
+                    const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], b);
+                    if (4u * c + j - d < cnt) { const uint32_t op = v & 0xF; atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4)); }
                 }
             };
             // the first three chunks are requested together (a lane's share of a HiFi tail is ~6 ops: one round
-            // trip); longer tails continue with one new chunk per four ops
-            const uint32_t nch = (sh + 4u * (k1 - k0) + 15u) >> 4;
+            // trip); longer tails continue with one new chunk at a time
+            const uint32_t nch = (sh + 4u * cnt + 15u) >> 4;
             const uint4 z = make_uint4(0, 0, 0, 0);
             const uint4 c0 = ld(a), c1 = nch > 1 ? ld(a + 16) : z, c2 = nch > 2 ? ld(a + 32) : z;
-            uint32_t k = k0;
-            take(c0, c1, min(4u, k1 - k)); k += 4;
-            if (k < k1) { take(c1, c2, min(4u, k1 - k)); k += 4; }
+            take(c0, c1.x, 0);
+            if (nch > 1) take(c1, c2.x, 1);
             uint4 lo = c2;
-            a += 32;
-            for (; k < k1; k += 4) {
-                a += 16;
-                const uint4 hi = ld(a);
-                take(lo, hi, min(4u, k1 - k));
+            for (uint32_t c = 2; c < nch; c++) {
+                const uint4 hi = c + 1 < nch ? ld(a + 16ull * (c + 1)) : z;
+                take(lo, hi.x, c);
                 lo = hi;
             }
         }
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         if (!have_nm && !walked_all) slow = true;          // NM (if any) lies beyond what was staged
     }
     if (slow) {
-        if (gl == 0) { slow_list[atomicAdd(n_slow, 1u)] = rec; }
+        if (gl == 0) { lq.slow_list[atomicAdd(lq.n_slow, 1u)] = rec; }
         return;
     }
 
@@ -358,16 +413,14 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     r.name_len = (uint16_t)name_len;
 
     TR(6);
-    if (long_cigar) {           // parse is complete: hand only the CIGAR totals + decision to k_cigar_long
-        if (gl == 0) {
-            LongItem it;
-            it.ops_off = off + cig_at; it.n_ops = n_cigar; it.rec = rec;
-            it.nm = have_nm ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;               // sentinels: bad type / absent
-            it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
-            it.mapq = (uint32_t)mapq; it.pad = 0;
-            long_items[atomicAdd(n_long, 1u)] = it;
-            out[rec] = r;                                                           // name hash / length are final
-        }
+    if (long_cigar) {           // parse is complete: hand only the CIGAR totals + decision to k_cigar_chunks
+        LongItem it;
+        it.ops_off = off + cig_at; it.n_ops = n_cigar; it.rec = rec;
+        it.nm = have_nm ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;                   // sentinels: bad type / absent
+        it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
+        it.mapq = (uint32_t)mapq;
+        if (gl == 0) out[rec] = r;                                                  // name hash / length are final
+        if (!enqueue_long<G>(lq, it, gl) && gl == 0) report(status, rec, GCI_E_CAPACITY);
         return;
     }
     wave_lds_fence();
@@ -375,8 +428,8 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     int64_t tt[NSLOT];
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) tt[s] = (int64_t)tot[s];
-    const int st = decide(r, tt, have_nm, nm_bad, NM, pos, contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent,
-                          iden_percent);
+    const int st = decide(r, tt[0] + tt[7] + tt[8], tt[1], tt[2], tt[3], tt[4], have_nm, nm_bad, NM, pos, contig, l_seq,
+                          n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
     if (st != GCI_OK) report(status, rec, st);
     out[rec] = r;
     TR(7);
@@ -426,25 +479,101 @@ __device__ __forceinline__ void cigar_totals_wave(const uint8_t* __restrict__ ba
     tot[NSLOT - 1] = 0;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_cigar_long(const uint8_t* __restrict__ bam, uint64_t n_bytes,
-                                                      const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long,
-                                                      int mq_cutoff, double clip_percent, double iden_percent,
-                                                      gci_rec* __restrict__ out, unsigned long long* __restrict__ status)
+// ---- long CIGARs, chunk by chunk: one wave per chunk of CHUNK_DW aligned dwords.  A lane owns PIECES 16-byte
+// pieces (all requested up front), takes the dword after each piece from its neighbour, re-aligns with
+// v_alignbyte and adds the op lengths to five class sums; the wave stores the chunk's sums.
+
+__device__ __forceinline__ unsigned long long wave_sum_u40(unsigned long long v)        // v < 2^40 in every lane
+{
+    const uint32_t lo = wave_sum<uint32_t>((uint32_t)v & 0xFFFFu);
+    const uint32_t hi = wave_sum<uint32_t>((uint32_t)(v >> 16));
+    return (unsigned long long)lo + ((unsigned long long)hi << 16);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cigar_chunks(const uint8_t* __restrict__ bam, uint64_t n_bytes, const LongQueue lq)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t n = *n_long;
+    const uint32_t n = (uint32_t)min((unsigned long long)(uint32_t)*lq.n_long, (unsigned long long)lq.cap_chunks);
     const uint32_t waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t it = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); it < n; it += waves) {
-        const LongItem x = items[it];
-        int64_t tot[NSLOT];
-        cigar_totals_wave(bam, n_bytes, x.ops_off, x.n_ops, lane, tot);
-        if (lane == 0) {
-            gci_rec r = out[x.rec];
-            const int st = decide(r, tot, x.nm != INT64_MAX, x.nm == INT64_MIN, x.nm, x.pos, x.contig, x.l_seq,
-                                  (uint32_t)x.n_cigar_field, (int)x.mapq, mq_cutoff, clip_percent, iden_percent);
-            if (st != GCI_OK) report(status, x.rec, st);
-            out[x.rec] = r;
+    for (uint32_t wi = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); wi < n; wi += waves) {
+        const unsigned long long e = lq.chunks[wi];
+        if (e == ~0ull) continue;
+        const LongItem* it = lq.items + (uint32_t)(e >> 32);
+        const uint32_t ci = (uint32_t)e;
+        const uint64_t p0 = it->ops_off;
+        const uint32_t n_ops = it->n_ops;
+        const uint32_t d0 = (uint32_t)(p0 & 15ull) >> 2, b = (uint32_t)p0 & 3u;
+        // op k of the record starts in aligned dword d0 + k (counted from the 16-byte boundary below p0);
+        // this chunk owns the ops that start in its dwords [r0, r1)
+        const uint64_t g0 = (uint64_t)ci * CHUNK_DW;
+        const uint64_t abase = (p0 & ~15ull) + g0 * 4ull;
+        const uint32_t r0 = ci == 0 ? d0 : 0u;
+        const uint32_t r1 = (uint32_t)min((uint64_t)CHUNK_DW, (uint64_t)d0 + n_ops - g0);
+        uint4 pc[PIECES];
+#pragma unroll
+        for (int u = 0; u < PIECES; u++) {
+            const uint32_t c = lane + 64u * u;
+            const uint64_t at = abase + 16ull * c;
+            const bool need = 4u * c < r1 + 1u && 4u * c + 4u > r0;           // + 1: the dword that completes the last op
+            pc[u] = !need ? make_uint4(0, 0, 0, 0) : at + 16 <= n_bytes ? *reinterpret_cast<const uint4*>(bam + at)
+                                                                          : load16_tail(bam, at, n_bytes);
         }
+        uint32_t ext = 0;                                                       // first dword of the next chunk
+        if (r1 == CHUNK_DW && b != 0) {
+            const uint64_t at = abase + 4ull * CHUNK_DW;
+            ext = at + 4 <= n_bytes ? *reinterpret_cast<const uint32_t*>(bam + at) : load16_tail(bam, at, n_bytes).x;
+        }
+        unsigned long long wide[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+        uint32_t s[5] = {0u, 0u, 0u, 0u, 0u};                                   // at most 16 lengths < 2^28 each
+#pragma unroll
+        for (int u = 0; u < PIECES; u++) {
+            uint32_t w4 = (uint32_t)__shfl((int)pc[u].x, (lane + 1) & 63, 64);
+            const uint32_t first_next = u + 1 < PIECES ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pc[(u + 1) % PIECES].x) : ext;
+            if (lane == 63) w4 = first_next;
+            const uint32_t w[5] = {pc[u].x, pc[u].y, pc[u].z, pc[u].w, w4};
+            const uint32_t li0 = 4u * (lane + 64u * u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], b);
+                const uint32_t len = (li0 + j - r0) < (r1 - r0) ? v >> 4 : 0u;     // unsigned: r0 <= li < r1
+                const uint32_t op = v & 0xFu;
+                s[0] += len & (0u - ((0x181u >> op) & 1u));                        // M, =, X
+                s[1] += op == 1u ? len : 0u;
+                s[2] += op == 2u ? len : 0u;
+                s[3] += op == 3u ? len : 0u;
+                s[4] += op == 4u ? len : 0u;
+            }
+            if ((u & 3) == 3) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) { wide[k] += s[k]; s[k] = 0u; }
+            }
+        }
+        ChunkSums out;
+#pragma unroll
+        for (int k = 0; k < 5; k++) out.v[k] = wave_sum_u40(wide[k]);
+        if (lane == 0) lq.sums[wi] = out;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cigar_finish(const LongQueue lq, int mq_cutoff, double clip_percent,
+                                                        double iden_percent, gci_rec* __restrict__ out,
+                                                        unsigned long long* __restrict__ status)
+{
+    const uint32_t n = (uint32_t)min(*lq.n_long >> 32, (unsigned long long)lq.cap_items);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const LongItem x = lq.items[i];
+        if (x.n_chunks == 0) continue;
+        int64_t t[5] = {0, 0, 0, 0, 0};
+        for (uint32_t c = 0; c < x.n_chunks; c++) {
+            const ChunkSums cs = lq.sums[x.chunk_base + c];
+#pragma unroll
+            for (int k = 0; k < 5; k++) t[k] += (int64_t)cs.v[k];
+        }
+        gci_rec r = out[x.rec];
+        const int st = decide(r, t[0], t[1], t[2], t[3], t[4], x.nm != INT64_MAX, x.nm == INT64_MIN, x.nm, x.pos, x.contig,
+                              x.l_seq, (uint32_t)x.n_cigar_field, (int)x.mapq, mq_cutoff, clip_percent, iden_percent);
+        if (st != GCI_OK) report(status, x.rec, st);
+        out[x.rec] = r;
     }
 }
 
@@ -481,15 +610,14 @@ __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_
 
 __global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
-    const int32_t* __restrict__ ref_sel, const uint32_t* __restrict__ slow_list, const uint32_t* __restrict__ n_slow,
-    int mq_cutoff, double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out,
-    unsigned long long* __restrict__ status)
+    const int32_t* __restrict__ ref_sel, const LongQueue lq, int mq_cutoff, double clip_percent, double iden_percent,
+    uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t n = *n_slow;
+    const uint32_t n = *lq.n_slow;
     const uint32_t waves = gridDim.x * (BLOCK / 64);
     for (uint32_t it = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); it < n; it += waves) {
-        const uint32_t rec = slow_list[it];
+        const uint32_t rec = lq.slow_list[it];
         // the fast path has already validated the record's bounds and passed its flag / MAPQ tests;
         // every lane parses the scalar part redundantly (same addresses: one transaction per load)
         const uint64_t off = rec_off[rec];
@@ -541,14 +669,24 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
                 if (cg_len >= n_cigar && cg_len < (1u << 29)) { ops = cg_p + 6; n_ops = cg_len; }
             }
         }
+        gci_rec r;
+        r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
+        r.rec_idx = rec + rec_idx_base; r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = (uint16_t)name_len;
+        if (n_ops > LONG_OPS) {                 // summed chunk by chunk like the fast path's long CIGARs
+            LongItem li;
+            li.ops_off = (uint64_t)(ops - bam); li.n_ops = n_ops; li.rec = rec;
+            li.nm = nm_p ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
+            li.pos = pos; li.contig = contig; li.l_seq = l_seq; li.n_cigar_field = (int32_t)n_cigar;
+            li.mapq = (uint32_t)mapq;
+            if (lane == 0) out[rec] = r;
+            if (!enqueue_long<64>(lq, li, lane) && lane == 0) report(status, rec, GCI_E_CAPACITY);
+            continue;
+        }
         int64_t tot[NSLOT];
         cigar_totals_wave(bam, n_bytes, (uint64_t)(ops - bam), n_ops, lane, tot);
         if (lane == 0) {
-            gci_rec r;
-            r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
-            r.rec_idx = rec + rec_idx_base; r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = (uint16_t)name_len;
-            const int st = decide(r, tot, nm_p != nullptr, nm_bad, NM, pos, contig, l_seq, n_cigar, mapq, mq_cutoff,
-                                  clip_percent, iden_percent);
+            const int st = decide(r, tot[0] + tot[7] + tot[8], tot[1], tot[2], tot[3], tot[4], nm_p != nullptr, nm_bad, NM, pos,
+                                  contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
             if (st != GCI_OK) report(status, rec, st);
             out[rec] = r;
         }
@@ -561,34 +699,48 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                               uint64_t* d_status)
 {
     if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
-    // scratch: [n_slow u32][n_long u32][slow_list u32 x n_rec (+pad)][long items x n_rec]
+    // scratch: [n_slow u32, pad, n_long u64][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
+    // A long item has more than LONG_OPS ops = 4 * LONG_OPS bytes of stream of its own and a chunk covers
+    // 4 * CHUNK_DW bytes: that bounds both queues
     const size_t list_bytes = ((size_t)n_rec * 4 + 15) & ~(size_t)15;
-    GCI_TRY(gci_ensure(ctx, ctx->long_items, 16 + list_bytes + (size_t)n_rec * sizeof(LongItem)));
-    uint32_t* n_slow = (uint32_t*)ctx->long_items.p;
-    uint32_t* n_long = n_slow + 1;
-    uint32_t* slow_list = n_slow + 4;
-    LongItem* long_items = (LongItem*)((uint8_t*)ctx->long_items.p + 16 + list_bytes);
+    const uint64_t by_bytes = n_bytes / (4ull * LONG_OPS) + 1;
+    const uint32_t cap_items = (uint32_t)(by_bytes < n_rec ? by_bytes : n_rec);
+    const uint64_t cap_chunks64 = n_bytes / (4ull * CHUNK_DW) + 2ull * cap_items + 1;
+    if (cap_chunks64 > 0xFFFFFFFFull) return GCI_E_INVALID;
+    const uint32_t cap_chunks = (uint32_t)cap_chunks64;
+    GCI_TRY(gci_ensure(ctx, ctx->long_items, 16 + list_bytes + (size_t)cap_items * sizeof(LongItem) +
+                                             (size_t)cap_chunks * (8 + sizeof(ChunkSums))));
+    LongQueue lq;
+    lq.n_slow = (uint32_t*)ctx->long_items.p;
+    lq.n_long = (unsigned long long*)(lq.n_slow + 2);
+    lq.slow_list = lq.n_slow + 4;
+    lq.items = (LongItem*)((uint8_t*)ctx->long_items.p + 16 + list_bytes);
+    lq.chunks = (unsigned long long*)((uint8_t*)lq.items + (size_t)cap_items * sizeof(LongItem));
+    lq.sums = (ChunkSums*)(lq.chunks + cap_chunks);
+    lq.cap_items = cap_items; lq.cap_chunks = cap_chunks;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(n_slow, 0, 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(lq.n_slow, 0, 16, ctx->stream));
     if (n_rec == 0) return GCI_OK;
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
     const uint32_t per_block = KB / G;
     hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(KB), 0, ctx->stream, d_bam, n_bytes,
                        d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base,
-                       d_out, (unsigned long long*)d_status, slow_list, n_slow, long_items, n_long
+                       d_out, (unsigned long long*)d_status, lq
 #ifdef GCI_K1_TRACE
                        , (unsigned long long*)strtoull(getenv("GCI_K1_TRACE_PTR") ? getenv("GCI_K1_TRACE_PTR") : "0", nullptr, 0)
 #endif
                        );
     LAUNCHCHK("k_bam_filter");
     hipLaunchKernelGGL(k_bam_filter_slow, dim3(n_rec < 8192u ? (n_rec + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam,
-                       n_bytes, d_rec_off, d_ref_sel, (const uint32_t*)slow_list, (const uint32_t*)n_slow, mq_cutoff, clip_percent,
-                       iden_percent, rec_idx_base, d_out, (unsigned long long*)d_status);
-    LAUNCHCHK("k_bam_filter_slow");
-    hipLaunchKernelGGL(k_cigar_long, dim3(n_rec < 8192u ? (n_rec + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam, n_bytes,
-                       (const LongItem*)long_items, (const uint32_t*)n_long, mq_cutoff, clip_percent, iden_percent, d_out,
+                       n_bytes, d_rec_off, d_ref_sel, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, d_out,
                        (unsigned long long*)d_status);
-    LAUNCHCHK("k_cigar_long");
+    LAUNCHCHK("k_bam_filter_slow");
+    hipLaunchKernelGGL(k_cigar_chunks, dim3(cap_chunks < 8192u ? (cap_chunks + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream,
+                       d_bam, n_bytes, lq);
+    LAUNCHCHK("k_cigar_chunks");
+    hipLaunchKernelGGL(k_cigar_finish, dim3(cap_items < 65536u ? (cap_items + BLOCK - 1) / BLOCK : 256u), dim3(BLOCK), 0,
+                       ctx->stream, lq, mq_cutoff, clip_percent, iden_percent, d_out, (unsigned long long*)d_status);
+    LAUNCHCHK("k_cigar_finish");
     return GCI_OK;
 }
 
