@@ -275,9 +275,9 @@ def main():
     else:
         aligned_total = w.aligned_bases
 
-    scan_ms, scan_n = prof.get("k_tile_build<2>", (0.0, 0))
+    scan_ms, scan_n = prof.get("k_tile_build", (0.0, 0))
     scan_avg_ms = scan_ms / max(1, scan_n)
-    # k_tile_build<2> writes the int32 track (4 B/base) and the decimal text; it reads only the event buckets
+    # k_tile_build writes the int32 track (4 B/base) and the decimal text; it reads only the event buckets
     text_bytes = int(w.text_off[1].item())
     algo_bytes = 4.0 * args.contig_len + text_bytes       # DESIGN.md "algorithmic bytes"
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
@@ -320,7 +320,7 @@ def main():
                    "join": ("local" if not w.exchange else
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
-        "roofline": {"bound": "hbm", "kernel": "k_tile_build<2> (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_tile_build (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
         "kernel_us_per_launch": breakdown,

@@ -19,7 +19,7 @@ GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
 REC_PASS, REC_HQ = 1, 2
 PROF_COUNT = 14
-PROF_DEPTH_SCAN = 5          # k_tile_build<2>: the pass that writes the depth track (+ text)
+PROF_DEPTH_SCAN = 5          # k_tile_build: the pass that writes the depth track (+ text)
 PROF_TILE_PASS1 = 13
 
 

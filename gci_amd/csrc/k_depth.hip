@@ -207,13 +207,12 @@ __device__ __forceinline__ void tile_body(
     }
 }
 
+// One tile by one workgroup: difference array in LDS, scan, tile_body.
 template <int PASS>
-__global__ __launch_bounds__(BLOCK) void k_tile_build(
-    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
-    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
-    // pass 1 outputs
-    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss,
-    // pass 2 outputs
+__device__ __forceinline__ void tile_dense(
+    int64_t tile, const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off,
+    const int32_t* __restrict__ tile_carry, const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len,
+    int32_t n_contigs, long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, const IssueArgs& iss,
     int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
     const uint32_t* __restrict__ g_lut)
 {
@@ -222,7 +221,6 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     __shared__ uint32_t twtot[4][BLOCK / 64];
     __shared__ uint32_t lut[PASS == 2 ? TEXT_LUT : 1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t tile = blockIdx.x;
     int4* l4 = reinterpret_cast<int4*>(lds);
     // every global load this tile depends on is issued before the LDS work so that their latencies overlap:
     // bucket bounds, the first event of this thread (buckets hold ~20 events: one per thread at most), carry-in
@@ -276,6 +274,118 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
                                text_cap, twtot, lut, t, lane, wave);
 }
 
+// PASS 2 (depth + text): one workgroup per tile.
+__global__ __launch_bounds__(BLOCK) void k_tile_build(
+    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
+    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
+    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
+    const uint32_t* __restrict__ g_lut)
+{
+    IssueArgs none;
+    none.keys = nullptr; none.n_keys = nullptr; none.cap = 0; none.flank = 0; none.lo = 0; none.hi = 0;
+    tile_dense<2>(blockIdx.x, events, evt_off, tile_carry, tile_first, len, n_contigs, nullptr, nullptr, none, depth,
+                  tile_text_off, text, text_cap, g_lut);
+}
+
+// PASS 1 (by-products: depth sum, text bytes, issue-run boundaries of every tile).  The depth inside a tile is
+// piecewise constant with one piece per event, and a tile of long-read data holds ~20 events: so a tile with at most
+// SPARSE_MAX events is done by ONE WAVE straight from its event list -- rank the events by position, scan the
+// signs, and every lane owns one constant-depth segment: sum += depth * length, bytes += (digits + 1) * length, run
+// boundaries only where a segment meets its neighbour or the window edge.  Tiles with more events (short reads,
+// pile-ups) fall back to the dense path, one after the other, by the whole workgroup.
+#define SPARSE_MAX 63
+
+__device__ __forceinline__ void tile_sparse1(
+    int64_t tile, uint32_t e0, uint32_t n_ev, const uint16_t* __restrict__ events, int32_t carry_in, int32_t c,
+    int64_t elem0, int64_t L, long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, const IssueArgs& iss,
+    int lane)
+{
+    const int32_t valid = (int32_t)min((int64_t)TILE, L - elem0);
+    // lane 0: a null event at position 0 (the segment that continues the previous tile); lanes 1 .. n_ev: the events
+    const bool has = lane >= 1 && (uint32_t)lane <= n_ev;
+    const uint32_t ev = has ? (uint32_t)events[e0 + lane - 1] : 0u;
+    const uint32_t key = lane == 0 ? 0u : has ? ((ev >> 1) << 7) | (uint32_t)lane : 0xFFFFFFFFu;   // position, then lane: distinct
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j <= n_ev; j++) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) < key ? 1u : 0u;
+    // forward permute: the lane with rank r hands its event to lane r (idle lanes keep rank > n_ev among themselves)
+    const int32_t delta = has ? ((ev & 1u) ? -1 : 1) : 0;
+    const uint32_t packed = ((has ? ev >> 1 : lane == 0 ? 0u : (uint32_t)TILE) << 2) | (uint32_t)(delta + 1);
+    const uint32_t dst = lane <= (int)n_ev ? rank : (uint32_t)lane;
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)packed);
+    const int32_t my_delta = (int32_t)(got & 3u) - 1;
+    const int32_t p = min((int32_t)(got >> 2), valid);                       // segment start, clipped to the contig
+    const int32_t d = carry_in + wave_inclusive_i32(my_delta);              // depth of the segment
+    int32_t p_next = __shfl_down(p, 1, 64);
+    if (lane == 63) p_next = valid;
+    p_next = min(p_next, valid);                                             // (idle lanes sit at TILE >= valid)
+    const int32_t seg = p_next - p;                                         // >= 0: positions are sorted
+    long long s = (long long)seg * d;
+    uint32_t bytes = (uint32_t)seg * (ndigits_fast((uint32_t)d) + 1u);
+    s = wave_sum<long long>(s);
+    bytes = wave_sum<uint32_t>(bytes);
+    if (lane == 0) { tile_sum[tile] = s; tile_bytes[tile] = bytes; }
+    if (!iss.keys) return;
+    // ---- issue-run boundaries (same rules as the dense path: tile_body) -----------------------------------------
+    const int64_t wa = gci_slice_bound(iss.flank, L);
+    int64_t wb = gci_slice_bound(L - iss.flank, L);
+    if (wb < wa) wb = wa;
+    const bool low = d >= iss.lo && d <= iss.hi;
+    const bool nonempty = seg > 0;
+    const unsigned long long m_ne = __ballot(nonempty), m_low = __ballot(nonempty && low);
+    if (m_ne == 0ull) return;
+    const unsigned long long below = lane ? m_ne & ((1ull << lane) - 1ull) : 0ull;
+    const unsigned long long above = lane < 63 ? m_ne >> (lane + 1) : 0ull;
+    // the element before this segment: previous non-empty segment, or the last element of the previous tile
+    const bool first = below == 0ull;
+    const bool prev_in_window = elem0 - 1 >= wa && elem0 - 1 < wb;
+    const bool low_prev = first ? (prev_in_window && carry_in >= iss.lo && carry_in <= iss.hi)
+                                : ((m_low >> (63 - __builtin_clzll(below))) & 1ull) != 0ull;
+    const bool has_next = above != 0ull;
+    const bool low_next = has_next && ((m_low >> (lane + 1 + __builtin_ctzll(above))) & 1ull) != 0ull;
+    if (!nonempty) return;
+    const int64_t A = elem0 + p, B = elem0 + p_next;
+    const int64_t a = max(A, wa), b = min(B, wb);
+    auto put = [&](int64_t rel, bool is_end) {
+        const uint32_t slot = atomicAdd(iss.n_keys, 1u);
+        if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, rel, is_end);
+    };
+    if (low && a < b) {
+        if (A <= wa || !low_prev) put(a - wa, false);                        // a run starts at a
+        if (b == wb) put(wb - wa, true);                                     // ... and reaches the end of the window
+        else if (has_next && !low_next) put(b - wa, true);                   // ... or ends where the next segment begins
+    } else if (first && low_prev && A < wb) {
+        put(A - wa, true);                                                   // the previous tile's run ends at this tile's first element
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_tile_pass1(
+    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
+    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs, int64_t n_tiles,
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss, const uint32_t* __restrict__ g_lut)
+{
+    __shared__ int dense[BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+    bool is_dense = false;
+    if (tile < n_tiles) {
+        const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
+        is_dense = e1 - e0 > SPARSE_MAX;
+        if (!is_dense) {
+            const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
+            tile_sparse1(tile, e0, e1 - e0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum,
+                         tile_bytes, iss, lane);
+        }
+    }
+    if (lane == 0) dense[wave] = is_dense ? 1 : 0;
+    __syncthreads();
+    for (int w = 0; w < BLOCK / 64; w++) {
+        if (!dense[w]) continue;                                             // uniform over the workgroup
+        tile_dense<1>((int64_t)blockIdx.x * (BLOCK / 64) + w, events, evt_off, tile_carry, tile_first, len, n_contigs,
+                      tile_sum, tile_bytes, iss, nullptr, nullptr, nullptr, 0, g_lut);
+        __syncthreads();
+    }
+}
+
 // ---- host -----------------------------------------------------------------------------------------
 
 static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_depth, uint8_t* d_text, uint64_t text_cap)
@@ -288,16 +398,14 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
     const int64_t* ln = (const int64_t*)ctx->d_len.p;
     if (pass == 1) {
         ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
-        hipLaunchKernelGGL(k_tile_build<1>, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs,
-                           (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, (int32_t*)nullptr,
-                           (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0, (const uint32_t*)ctx->text_lut.p);
+        const int64_t per = BLOCK / 64;
+        hipLaunchKernelGGL(k_tile_pass1, dim3((uint32_t)((ctx->n_tiles + per - 1) / per)), block, 0, ctx->stream, ev, eo, tc,
+                           tf, ln, ctx->n_contigs, ctx->n_tiles, (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss,
+                           (const uint32_t*)ctx->text_lut.p);
     } else {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
-        IssueArgs none;
-        memset(&none, 0, sizeof none);
-        hipLaunchKernelGGL(k_tile_build<2>, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs,
-                           (long long*)nullptr, (uint32_t*)nullptr, none, d_depth, (const uint64_t*)ctx->tile_u64.p, d_text,
-                           text_cap, (const uint32_t*)ctx->text_lut.p);
+        hipLaunchKernelGGL(k_tile_build, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, d_depth,
+                           (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, (const uint32_t*)ctx->text_lut.p);
     }
     LAUNCHCHK("k_tile_build");
     return GCI_OK;

@@ -117,15 +117,15 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned
     __shared__ uint32_t s_base;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint64_t slot0 = ((uint64_t)blockIdx.x * BLOCK + t) * FOLD_PER_THREAD;
-    gci_ivl keep[FOLD_PER_THREAD];
+    gci_ivl keep[FOLD_PER_THREAD];                  // indexed with compile-time constants only: stays in registers
+    bool ok[FOLD_PER_THREAD];
     uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < FOLD_PER_THREAD; k++) {
         const uint64_t slot = slot0 + k;
-        if (slot < n_slots && table[slot] != SLOT_EMPTY) {
-            gci_ivl o;
-            if (fold_slot(F, slot, last, hq[slot] != 0, ovlp_percent, contig_map, status, o)) keep[mine++] = o;
-        }
+        ok[k] = slot < n_slots && table[slot] != SLOT_EMPTY &&
+                fold_slot(F, slot, last, hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
+        mine += ok[k] ? 1u : 0u;
     }
     const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
     if (lane == 63) wtot[wave] = inc;
@@ -135,8 +135,11 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned
     for (int w = 0; w < BLOCK / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
     if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
     __syncthreads();
-    const uint32_t base = s_base + pre;
-    for (uint32_t k = 0; k < mine; k++) if (base + k < cap) out[base + k] = keep[k];
+    uint32_t w = s_base + pre;
+#pragma unroll
+    for (int k = 0; k < FOLD_PER_THREAD; k++) {
+        if (ok[k]) { if (w < cap) out[w] = keep[k]; w++; }
+    }
 }
 
 // table <- EMPTY, last <- 0, hq <- 0, *n_out <- 0, *status <- ~0 in one launch

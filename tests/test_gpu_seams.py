@@ -240,6 +240,49 @@ def test_fused_build_equals_seams_and_oracle(engine, oracle):
             assert np.array_equal(tr2[t], half[t])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed):
+    """Pass 1 derives sums / text sizes / issue-run boundaries from the event list of a tile when the tile holds few
+    events and from the dense difference array otherwise: low coverage with many short runs, runs crossing tile and
+    window edges, pile-ups (> 63 events in a tile) next to empty tiles, contigs ending on and off tile boundaries."""
+    rng = np.random.default_rng(100 + seed)
+    lengths = {"a": 70_000, "b": 8192, "c": 4097, "d": 12_288, "e": 40, "f": 33_333}
+    targets = list(lengths)
+    engine.set_layout([lengths[t] for t in targets])
+    ivls = []
+    for c, t in enumerate(targets):
+        L = lengths[t]
+        for _ in range(max(2, L // 900)):                       # ~1-2x of short reads: depth 0/1/2/3 everywhere
+            s = int(rng.integers(0, L))
+            ivls.append((c, s, int(min(L + 5, s + rng.integers(1, 2500)))))
+        for _ in range(L // 20_000):                            # pile-ups: > 63 events inside one tile
+            s0 = int(rng.integers(0, max(1, L - 3000)))
+            for _ in range(60):
+                s = s0 + int(rng.integers(0, 2000))
+                ivls.append((c, s, s + int(rng.integers(1, 800))))
+    ivls += [(1, 0, 4096), (1, 4096, 8192), (3, 4095, 4097), (3, 8191, 8193), (0, 0, 1), (0, 69_999, 70_000), (4, 0, 40)]
+    d = engine.to_device(np.array([(c, s, e, 0) for c, s, e in ivls], dtype=np.int32))
+    for fl, lo, hi in ((0, -1, 0), (15, -1, 1), (3, 0, 2), (5000, -1, 0), (1, 1, 3)):
+        want = oracle.depth_build_py([(targets[c], s, e) for c, s, e in ivls], lengths, fl)
+        track = engine.new_track()
+        out = engine.depth_build_fused(d, None, fl, track, want_text=True, want_sums=True, issue=(lo, hi, fl))
+        tr = pipeline.DepthTracks(engine, lengths, track)
+        for t in targets:
+            assert np.array_equal(tr[t], want[t]), (t, fl)
+        assert np.array_equal(out["sums"], np.array([want[t].sum() for t in targets]))
+        assert out["text"].cpu().numpy().tobytes() == b"".join(oracle.depth_text_contig(want[t]) for t in targets)
+        raw = engine.issue_scan(track, lo, hi, fl)               # stand-alone scan of the finished track
+        for c in range(len(targets)):
+            assert np.array_equal(np.asarray(out["runs"][c]), np.asarray(raw[c])), (targets[c], fl, lo, hi)
+        tr._fresh_runs = ((float(lo), float(hi), fl), out["runs"])
+        fused_bed = pipeline.collapse_depth_range(tr, lo, hi, fl, 0)
+        tr.invalidate()
+        scanned = pipeline.collapse_depth_range(tr, lo, hi, fl, 0)
+        assert fused_bed == scanned == oracle.collapse_depth_range(want, lo, hi, fl, 0), (fl, lo, hi)
+        if fl < 5000:
+            assert sum(len(v) for v in scanned.values()) > 20
+
+
 def test_cross_rank_name_check_kernels(engine):
     """gci_hash_bucket + gci_hash_conflicts with two simulated ranks on one GPU: unique names -> 0 conflicts;
     a name present on both ranks is found; a repeated name inside ONE rank is not a conflict; overflow counts."""

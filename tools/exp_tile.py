@@ -1,4 +1,4 @@
-"""Experiment: split of k_tile_build<2> between the depth write and the text render."""
+"""Experiment: split of k_tile_build between the depth write and the text render."""
 import sys, ctypes, numpy as np, torch
 sys.path.insert(0, '.')
 from gci_amd import synth, _lib
