@@ -1,6 +1,8 @@
 // api_ctx.hip -- context, memory helpers, per-kernel event timing and the genome layout of
 // libgci_hip.so (include/gci_hip.h).
 #include "gci_ctx.hpp"
+#include <stdlib.h>
+#include <vector>
 
 int gci_fail(gci_ctx* c, hipError_t e, const char* what)
 {
@@ -43,6 +45,8 @@ extern "C" int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx*
     gci_ctx* ctx = new (std::nothrow) gci_ctx();
     if (!ctx) return GCI_E_NOMEM;
     ctx->device = device;
+    { const char* fd = getenv("GCI_FORCE_DENSE"); if (fd && fd[0] == '1') ctx->sparse_max = -1; }   // testing / A-B timing
+    { const char* st = getenv("GCI_SPLIT_TEXT"); if (st && st[0] == '1') ctx->split_text = true; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete ctx; return GCI_E_HIP; }
     if (!own_stream) { ctx->stream = (hipStream_t)stream; }    // NULL = the device's default stream
@@ -70,7 +74,7 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
     if (!ctx) return GCI_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_cd, &ctx->tile_carry,
+    DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_cd, &ctx->tile_carry, &ctx->dense_flag, &ctx->d_tile_valid,
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->win,
                       &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items};
@@ -206,6 +210,14 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     GCI_TRY(gci_ensure(ctx, ctx->tile_cd, (size_t)(tiles + 1) * 8));
     GCI_TRY(gci_ensure(ctx, ctx->tile_carry, (size_t)(tiles + 1) * 4));
     GCI_TRY(gci_ensure(ctx, ctx->evt_off, (size_t)(tiles + 2) * 4));
+    GCI_TRY(gci_ensure(ctx, ctx->dense_flag, (size_t)tiles + 16));
+    GCI_TRY(gci_ensure(ctx, ctx->d_tile_valid, (size_t)(tiles + 1) * 4));
+    {
+        std::vector<int32_t> tv((size_t)tiles + 1, TILE);
+        for (int32_t c = 0; c < n; c++)
+            if (h_len[c] > 0) tv[(size_t)ctx->tile_first[c + 1] - 1] = (int32_t)(h_len[c] - ((h_len[c] - 1) / TILE) * TILE);
+        GCI_TRY(gci_upload_small(ctx, ctx->d_tile_valid.p, tv.data(), tv.size() * 4));
+    }
     GCI_TRY(gci_ensure(ctx, ctx->blk_a, nb * 4));
     GCI_TRY(gci_ensure(ctx, ctx->blk_b, nb * 4));
     GCI_TRY(gci_ensure(ctx, ctx->tile_sum, (size_t)(tiles + 1) * 8));

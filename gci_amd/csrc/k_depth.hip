@@ -24,6 +24,7 @@
 // contig sums to zero and ONE unsegmented scan over all tiles serves all contigs; its event is dropped
 // (or lands in the tail padding, which keeps the padding at zero).
 #include "gci_ctx.hpp"
+#include <stdlib.h>
 
 // ---- per interval ---------------------------------------------------------------------------------
 
@@ -274,26 +275,41 @@ __device__ __forceinline__ void tile_dense(
                                text_cap, twtot, lut, t, lane, wave);
 }
 
-// PASS 2 (depth + text): one workgroup per tile.
-__global__ __launch_bounds__(BLOCK) void k_tile_build(
-    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
-    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
-    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
-    const uint32_t* __restrict__ g_lut)
-{
-    IssueArgs none;
-    none.keys = nullptr; none.n_keys = nullptr; none.cap = 0; none.flank = 0; none.lo = 0; none.hi = 0;
-    tile_dense<2>(blockIdx.x, events, evt_off, tile_carry, tile_first, len, n_contigs, nullptr, nullptr, none, depth,
-                  tile_text_off, text, text_cap, g_lut);
-}
-
 // PASS 1 (by-products: depth sum, text bytes, issue-run boundaries of every tile).  The depth inside a tile is
 // piecewise constant with one piece per event, and a tile of long-read data holds ~20 events: so a tile with at most
 // SPARSE_MAX events is done by ONE WAVE straight from its event list -- rank the events by position, scan the
 // signs, and every lane owns one constant-depth segment: sum += depth * length, bytes += (digits + 1) * length, run
 // boundaries only where a segment meets its neighbour or the window edge.  Tiles with more events (short reads,
-// pile-ups) fall back to the dense path, one after the other, by the whole workgroup.
-#define SPARSE_MAX 63
+// pile-ups) are left to the dense path (k_tile_dense: one workgroup per tile).
+#define SPARSE_MAX 62     // + the null event of lane 0 + one lane for the padding behind a contig end
+
+// The constant-depth segments of a tile with at most SPARSE_MAX events, one per lane and sorted by position:
+// lane r owns elements [p, p_next) of the tile (clipped to `valid`, possibly empty) at depth d.
+struct Seg { int32_t p, p_next, d, len; };
+
+__device__ __forceinline__ Seg sparse_segments(uint32_t e0, uint32_t n_ev, const uint16_t* __restrict__ events,
+                                               int32_t carry_in, int32_t valid, int lane)
+{
+    // lane 0: a null event at position 0 (the segment that continues the previous tile); lanes 1 .. n_ev: the events
+    const bool has = lane >= 1 && (uint32_t)lane <= n_ev;
+    const uint32_t ev = has ? (uint32_t)events[e0 + lane - 1] : 0u;
+    const uint32_t key = lane == 0 ? 0u : has ? ((ev >> 1) << 7) | (uint32_t)lane : 0xFFFFFFFFu;   // position, then lane: distinct
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j <= n_ev; j++) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) < key ? 1u : 0u;
+    // forward permute: the lane with rank r hands its event to lane r (idle lanes keep their own place behind them)
+    const int32_t delta = has ? ((ev & 1u) ? -1 : 1) : 0;
+    const uint32_t packed = ((has ? ev >> 1 : lane == 0 ? 0u : (uint32_t)TILE) << 2) | (uint32_t)(delta + 1);
+    const uint32_t dst = lane <= (int)n_ev ? rank : (uint32_t)lane;
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)packed);
+    Seg sg;
+    sg.p = min((int32_t)(got >> 2), valid);                                  // segment start, clipped to the contig
+    sg.d = carry_in + wave_inclusive_i32((int32_t)(got & 3u) - 1);          // depth of the segment
+    int32_t p_next = __shfl_down(sg.p, 1, 64);
+    if (lane == 63) p_next = valid;
+    sg.p_next = min(p_next, valid);                                          // (idle lanes sit at TILE >= valid)
+    sg.len = sg.p_next - sg.p;                                               // >= 0: positions are sorted
+    return sg;
+}
 
 __device__ __forceinline__ void tile_sparse1(
     int64_t tile, uint32_t e0, uint32_t n_ev, const uint16_t* __restrict__ events, int32_t carry_in, int32_t c,
@@ -301,24 +317,8 @@ __device__ __forceinline__ void tile_sparse1(
     int lane)
 {
     const int32_t valid = (int32_t)min((int64_t)TILE, L - elem0);
-    // lane 0: a null event at position 0 (the segment that continues the previous tile); lanes 1 .. n_ev: the events
-    const bool has = lane >= 1 && (uint32_t)lane <= n_ev;
-    const uint32_t ev = has ? (uint32_t)events[e0 + lane - 1] : 0u;
-    const uint32_t key = lane == 0 ? 0u : has ? ((ev >> 1) << 7) | (uint32_t)lane : 0xFFFFFFFFu;   // position, then lane: distinct
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j <= n_ev; j++) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j) < key ? 1u : 0u;
-    // forward permute: the lane with rank r hands its event to lane r (idle lanes keep rank > n_ev among themselves)
-    const int32_t delta = has ? ((ev & 1u) ? -1 : 1) : 0;
-    const uint32_t packed = ((has ? ev >> 1 : lane == 0 ? 0u : (uint32_t)TILE) << 2) | (uint32_t)(delta + 1);
-    const uint32_t dst = lane <= (int)n_ev ? rank : (uint32_t)lane;
-    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)packed);
-    const int32_t my_delta = (int32_t)(got & 3u) - 1;
-    const int32_t p = min((int32_t)(got >> 2), valid);                       // segment start, clipped to the contig
-    const int32_t d = carry_in + wave_inclusive_i32(my_delta);              // depth of the segment
-    int32_t p_next = __shfl_down(p, 1, 64);
-    if (lane == 63) p_next = valid;
-    p_next = min(p_next, valid);                                             // (idle lanes sit at TILE >= valid)
-    const int32_t seg = p_next - p;                                         // >= 0: positions are sorted
+    const Seg sg = sparse_segments(e0, n_ev, events, carry_in, valid, lane);
+    const int32_t p = sg.p, p_next = sg.p_next, d = sg.d, seg = sg.len;
     long long s = (long long)seg * d;
     uint32_t bytes = (uint32_t)seg * (ndigits_fast((uint32_t)d) + 1u);
     s = wave_sum<long long>(s);
@@ -361,53 +361,357 @@ __device__ __forceinline__ void tile_sparse1(
 __global__ __launch_bounds__(BLOCK) void k_tile_pass1(
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs, int64_t n_tiles,
-    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss, const uint32_t* __restrict__ g_lut)
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss, int32_t sparse_max)
 {
-    __shared__ int dense[BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
-    bool is_dense = false;
-    if (tile < n_tiles) {
-        const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
-        is_dense = e1 - e0 > SPARSE_MAX;
-        if (!is_dense) {
-            const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
-            tile_sparse1(tile, e0, e1 - e0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum,
-                         tile_bytes, iss, lane);
+    const int lane = threadIdx.x & 63;
+    // the wave index is uniform: say so, and everything per tile (bounds, carry, offsets, loop counts) lives in SGPRs
+    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (tile >= n_tiles) return;
+    const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
+    if ((int64_t)(e1 - e0) > sparse_max) return;                             // k_tile_dense<1> takes it
+    const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
+    tile_sparse1(tile, e0, e1 - e0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum, tile_bytes, iss,
+                 lane);
+}
+
+// ---- PASS 2 (depth + text) ------------------------------------------------------------------------
+// Same idea as pass 1: a tile with few events is a handful of constant-depth segments, so one wave writes it segment
+// by segment -- 16-byte splat stores for the depth, and for the text the decimal pattern of the segment ("37\n")
+// repeated through a 64-bit register, 16 bytes per lane and store, phase taken from the distance to the segment
+// start.  The 16-byte groups that hold a boundary between two segments are composed in registers, all boundaries of
+// the tile at once (lane r owns the boundary at the start of segment r), so that nothing but whole aligned groups
+// reaches memory, except at the two ends of the tile's text.  No LDS, no workgroup barrier.  A tile with more than
+// SPARSE_MAX events, or with a depth of four or more digits when text is wanted, is done densely by a whole
+// workgroup (k_tile_dense).
+
+#ifdef GCI_TILE_TRACE           // tools/exp_tile_trace.py: shader-clock stamps per tile
+#define TT(i) do { if ((threadIdx.x & 63) == 0) g_tt[(i)] = clock64(); } while (0)
+#define TT_PARAM , unsigned long long* g_tt
+#define TT_ARG , g_tt
+#else
+#define TT(i) do {} while (0)
+#define TT_PARAM
+#define TT_ARG
+#endif
+
+__device__ __forceinline__ uint32_t mod_w(uint32_t x, uint32_t w)        // x mod w for x < 2^16, w in {2, 3, 4}
+{
+    const uint32_t m3 = x - 3u * ((x * 43691u) >> 17);
+    return w == 3u ? m3 : x & (w - 1u);
+}
+
+// the 16 bytes of a w-byte pattern (held repeated in X, 8 valid bytes) whose first byte has phase ph < w
+__device__ __forceinline__ uint4 pattern16(unsigned long long X, uint32_t w, uint32_t ph)
+{
+    // 4 = 1 (mod 3) and 0 (mod 2 or 4): the phase moves by one per dword only for w == 3
+    const bool three = w == 3u;
+    uint32_t p1 = three ? ph + 1u : ph;  p1 = three && p1 >= 3u ? p1 - 3u : p1;
+    uint32_t p2 = three ? p1 + 1u : ph;  p2 = three && p2 >= 3u ? p2 - 3u : p2;
+    uint4 c;
+    c.x = (uint32_t)(X >> (8u * ph)); c.y = (uint32_t)(X >> (8u * p1)); c.z = (uint32_t)(X >> (8u * p2)); c.w = c.x;
+    return c;
+}
+
+// dword k of: bytes [0, cut) from a, bytes [cut, 16) from b
+__device__ __forceinline__ uint32_t cut_dword(uint32_t a, uint32_t b, int32_t cut, int k)
+{
+    const int32_t n = cut - 4 * k;                                       // bytes of this dword taken from a
+    if (n <= 0) return b;
+    if (n >= 4) return a;
+    const uint32_t m = (1u << (8 * n)) - 1u;
+    return (a & m) | (b & ~m);
+}
+
+// returns false when the tile needs the dense path (nothing has been written then)
+//
+// What bounds this kernel besides the HBM write rate is VALU issue (a wave64 instruction holds its SIMD16 for four
+// cycles and a CU works through ~60 tiles): everything that is uniform over a segment is kept in scalar registers
+// (v_readlane of the owning lane), so a group of 16 text bytes costs a handful of vector instructions.
+__device__ __forceinline__ bool tile_sparse2(
+    int64_t tile, uint32_t e0, uint32_t n_ev, const uint16_t* __restrict__ events, int32_t carry_in, int32_t valid,
+    int32_t* __restrict__ depth, uint64_t T0, uint8_t* __restrict__ text, uint64_t text_cap, int lane, uint32_t wi,
+    uint32_t nw TT_PARAM)
+{
+    // wi / nw: this wave is one of nw that share the tile: every one derives the segments, wave 0 writes the groups
+    // that hold boundaries, and the whole groups of segment r go to wave r mod nw
+    TT(1);
+    Seg sg = sparse_segments(e0, n_ev, events, carry_in, valid, lane);
+    TT(2);
+    // padding behind the contig end: the first idle lane owns [valid, TILE) at depth 0 and has no text
+    const bool pad_lane = (uint32_t)lane == n_ev + 1u && valid < TILE;
+    if (pad_lane) { sg.p = valid; sg.p_next = TILE; sg.len = TILE - valid; sg.d = 0; }
+    const uint32_t n_seg = n_ev + 2u;                                    // lanes 0 .. n_ev + 1 can own something
+    const uint32_t d = (uint32_t)sg.d;
+    const int32_t len_t = pad_lane ? 0 : sg.len;
+    if (text && __ballot(len_t > 0 && d >= 1000u) != 0ull) return false;
+    const unsigned long long lanes_below = lane ? (1ull << lane) - 1ull : 0ull;
+
+    // ---- depth ---------------------------------------------------------------------------------------------------
+    if (depth) {
+        int32_t* dt = depth + (size_t)tile * TILE;
+        int4* dt4 = reinterpret_cast<int4*>(dt);
+        const bool ne = sg.len > 0;
+        const unsigned long long m_ne = __ballot(ne);
+        const unsigned long long below = m_ne & lanes_below;
+        const bool has_prev = below != 0ull;
+        const int q = has_prev ? 63 - __builtin_clzll(below) : 0;           // previous non-empty segment
+        const int32_t p_q = __shfl(sg.p, q, 64), d_q = __shfl(sg.d, q, 64);
+        const int32_t al = sg.p & 3, gs = sg.p - al;                        // the group of four that holds the boundary
+        const bool hb = ne && al != 0;
+        const bool prev_covers = has_prev && p_q <= gs;                     // ... from its first element
+        const bool simple = hb && prev_covers && sg.p_next >= gs + 4;
+        if (simple && wi == 0) dt4[gs >> 2] = make_int4(d_q, al > 1 ? d_q : sg.d, al > 2 ? d_q : sg.d, sg.d);
+        // several boundaries inside one group: every segment writes its own elements, and the previous segment's when
+        // that one began before the group (its own boundary logic then never sees this group).  One boundary at a
+        // time, four lanes.
+        for (unsigned long long m = wi == 0 ? __ballot(hb && !simple) : 0ull; m; m &= m - 1ull) {
+            const int r = __builtin_ctzll(m);
+            const int32_t pr = __builtin_amdgcn_readlane(sg.p, r), pn = __builtin_amdgcn_readlane(sg.p_next, r);
+            const int32_t e = (pr & ~3) + lane;
+            const bool own = lane < 4 && e >= pr && e < pn;
+            const bool prv = lane < 4 && __builtin_amdgcn_readlane((int)prev_covers, r) && e < pr;
+            if (own || prv) dt[e] = own ? __builtin_amdgcn_readlane(sg.d, r) : __builtin_amdgcn_readlane(d_q, r);
+        }
+        // whole groups of every segment: one store instruction per segment and 1024 bytes
+        const int32_t g0v = (sg.p + 3) >> 2, g1v = sg.p_next >> 2;
+        for (uint32_t r = wi; r < n_seg; r += nw) {
+            const int32_t g0 = __builtin_amdgcn_readlane(g0v, (int)r), g1 = __builtin_amdgcn_readlane(g1v, (int)r);
+            if (g0 >= g1) continue;
+            const int32_t dr = __builtin_amdgcn_readlane(sg.d, (int)r);
+            const int4 v4 = make_int4(dr, dr, dr, dr);
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int32_t g = g0 + lane; g < g1; g += 64) dt4[g] = v4;
         }
     }
-    if (lane == 0) dense[wave] = is_dense ? 1 : 0;
-    __syncthreads();
-    for (int w = 0; w < BLOCK / 64; w++) {
-        if (!dense[w]) continue;                                             // uniform over the workgroup
-        tile_dense<1>((int64_t)blockIdx.x * (BLOCK / 64) + w, events, evt_off, tile_carry, tile_first, len, n_contigs,
-                      tile_sum, tile_bytes, iss, nullptr, nullptr, nullptr, 0, g_lut);
-        __syncthreads();
+    TT(3);
+    if (!text) return true;
+
+    // ---- text ----------------------------------------------------------------------------------------------------
+    // "row": the 16-byte aligned byte string TB that holds the tile's text; the text starts at row byte A0
+    const uint32_t A0 = (uint32_t)(((uint64_t)(uintptr_t)text + T0) & 15ull);
+    const uint64_t row0 = T0 - A0;                                          // offset of TB in the caller's buffer
+    uint8_t* TB = text + T0 - A0;
+    const uint64_t room = text_cap > row0 ? text_cap - row0 : 0ull;
+    const uint32_t capu = room > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)room;   // row bytes [0, capu) may be written
+    // decimal pattern of this lane's segment: "d\n", w = digits + 1 bytes, repeated to 8 bytes
+    const uint32_t q10 = d / 10u, r0 = d - 10u * q10, q100 = q10 / 10u, r1 = q10 - 10u * q100;
+    const uint32_t w = d >= 100u ? 4u : d >= 10u ? 3u : 2u;
+    const uint32_t pd = d >= 100u ? (('0' + q100) | (('0' + r1) << 8) | (('0' + r0) << 16) | ((uint32_t)'\n' << 24))
+                      : d >= 10u ? (('0' + r1) | (('0' + r0) << 8) | ((uint32_t)'\n' << 16))
+                                 : (('0' + r0) | ((uint32_t)'\n' << 8));
+    const unsigned long long X = w == 4u ? (unsigned long long)pd | ((unsigned long long)pd << 32)
+                               : w == 3u ? (unsigned long long)pd * 0x0001000001000001ull
+                                         : (unsigned long long)pd * 0x0001000100010001ull;
+    const uint32_t Xlo = (uint32_t)X, Xhi = (uint32_t)(X >> 32);
+    const uint32_t bytes = (uint32_t)len_t * w;
+    const uint32_t u2 = A0 + (uint32_t)wave_inclusive_i32((int32_t)bytes), u1 = u2 - bytes;   // the segment is row bytes [u1, u2)
+    const bool net = len_t > 0;
+    const unsigned long long m_net = __ballot(net);
+    if (m_net == 0ull) return true;
+    const unsigned long long below = m_net & lanes_below;
+    const bool has_prev = below != 0ull;
+    const int q = has_prev ? 63 - __builtin_clzll(below) : 0;
+    const uint32_t u1_q = (uint32_t)__shfl((int)u1, q, 64), w_q = (uint32_t)__shfl((int)w, q, 64);
+    const unsigned long long X_q = ((unsigned long long)(uint32_t)__shfl((int)Xhi, q, 64) << 32) | (uint32_t)__shfl((int)Xlo, q, 64);
+    const uint32_t al = u1 & 15u, cs = u1 - al;                              // the 16-byte group that holds the boundary
+    const bool hb = net && al != 0u;
+    const bool prev_covers = has_prev && u1_q <= cs;
+    const bool to_group_end = u2 >= cs + 16u;
+    const bool simple = hb && prev_covers && to_group_end && cs + 16u <= capu;
+    if (simple && wi == 0) {
+        const uint4 a = pattern16(X_q, w_q, mod_w(cs - u1_q, w_q));
+        const uint4 b = pattern16(X, w, mod_w(cs + 48u - u1, w));           // (cs - u1) mod w: 48 = 0 (mod 2, 3, 4)
+        uint4 c;
+        c.x = cut_dword(a.x, b.x, (int32_t)al, 0); c.y = cut_dword(a.y, b.y, (int32_t)al, 1);
+        c.z = cut_dword(a.z, b.z, (int32_t)al, 2); c.w = cut_dword(a.w, b.w, (int32_t)al, 3);
+        *reinterpret_cast<uint4*>(TB + cs) = c;
     }
+    // The two ends of the tile's text, one byte-store instruction for both: lanes 0-15 the head (first segment, when
+    // the text starts inside a group: the bytes before belong to the previous tile), lanes 16-31 the tail (last
+    // segment, when the text ends inside a group; when that segment begins inside the group its boundary logic owns it).
+    const int first = __builtin_ctzll(m_net), last = 63 - __builtin_clzll(m_net);
+    const bool head_own = hb && !has_prev && to_group_end;
+    if (wi == 0) {
+        const uint32_t fu1 = (uint32_t)__builtin_amdgcn_readlane((int)u1, first), fw = (uint32_t)__builtin_amdgcn_readlane((int)w, first);
+        const unsigned long long fX = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Xhi, first) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)Xlo, first);
+        const bool f_head = __builtin_amdgcn_readlane((int)head_own, first) != 0;
+        const uint32_t lu1 = (uint32_t)__builtin_amdgcn_readlane((int)u1, last), lu2 = (uint32_t)__builtin_amdgcn_readlane((int)u2, last);
+        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)w, last);
+        const unsigned long long lX = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Xhi, last) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)Xlo, last);
+        const uint32_t lce = lu2 & ~15u;
+        const bool l_tail = (lu2 & 15u) != 0u && lu1 <= lce;
+        const bool is_head = lane < 16;
+        const uint32_t y = is_head ? fu1 + (uint32_t)lane : lce + (uint32_t)(lane - 16);
+        const bool on = lane < 32 && (is_head ? (f_head && y < ((fu1 + 15u) & ~15u)) : (l_tail && y < lu2));
+        if (on && y < capu) TB[y] = is_head ? (uint8_t)(fX >> (8u * mod_w(y - fu1, fw))) : (uint8_t)(lX >> (8u * mod_w(y - lu1, lw)));
+    }
+    // anything else (several boundaries inside one group, a write limit inside the group): byte by byte, every segment
+    // its own bytes of the group, and the previous segment's when that one began before the group.  One boundary at
+    // a time, sixteen lanes.
+    for (unsigned long long m = wi == 0 ? __ballot(hb && !simple && !head_own) : 0ull; m; m &= m - 1ull) {
+        const int r = __builtin_ctzll(m);
+        const uint32_t ru1 = (uint32_t)__builtin_amdgcn_readlane((int)u1, r), ru2 = (uint32_t)__builtin_amdgcn_readlane((int)u2, r);
+        const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)w, r);
+        const unsigned long long rX = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Xhi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)Xlo, r);
+        const uint32_t qu1 = (uint32_t)__builtin_amdgcn_readlane((int)u1_q, r), qw = (uint32_t)__builtin_amdgcn_readlane((int)w_q, r);
+        const unsigned long long qX = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(X_q >> 32), r) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)X_q, r);
+        const bool q_covers = __builtin_amdgcn_readlane((int)prev_covers, r) != 0;
+        const uint32_t y = (ru1 & ~15u) + (uint32_t)lane;
+        const bool own = lane < 16 && y >= ru1 && y < ru2, prv = lane < 16 && q_covers && y < ru1;
+        if ((own || prv) && y < capu) TB[y] = own ? (uint8_t)(rX >> (8u * mod_w(y - ru1, rw))) : (uint8_t)(qX >> (8u * mod_w(y - qu1, qw)));
+    }
+    TT(4);
+    // whole groups of every segment.  The pattern of a segment is wave-uniform, and so is its phase at a group start
+    // when w divides 16 (w = 2, 4): the group is four copies of one scalar dword.  For w = 3 the phase moves by one
+    // per group (16 = 1 mod 3) and the group is a rotation of three scalar dwords.
+    {
+        const uint32_t c0v = (u1 + 15u) >> 4, c1v = min(u2, capu) >> 4;
+        const uint32_t lane3 = (uint32_t)lane - 3u * (((uint32_t)lane * 43691u) >> 17);        // lane mod 3
+        for (uint32_t r = wi; r < n_seg; r += nw) {
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c0v, (int)r), c1 = (uint32_t)__builtin_amdgcn_readlane((int)c1v, (int)r);
+            if (c0 >= c1 || !__builtin_amdgcn_readlane((int)net, (int)r)) continue;
+            const uint32_t wr = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)r);
+            const uint32_t x0 = 16u * c0 - (uint32_t)__builtin_amdgcn_readlane((int)u1, (int)r);   // < 16
+            const unsigned long long Xr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Xhi, (int)r) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)Xlo, (int)r);
+            if (wr != 3u) {
+                const uint32_t D = (uint32_t)(Xr >> (8u * (x0 & (wr - 1u))));
+                const uint4 v = make_uint4(D, D, D, D);
+#pragma clang loop vectorize(disable) unroll(disable)
+                for (uint32_t c = c0 + lane; c < c1; c += 64) *reinterpret_cast<uint4*>(TB + 16u * c) = v;
+            } else {
+                const uint32_t D0 = (uint32_t)Xr, D1 = (uint32_t)(Xr >> 8), D2 = (uint32_t)(Xr >> 16);
+                uint32_t ph = x0 - 3u * ((x0 * 43691u) >> 17) + lane3;                          // scalar part + lane part
+                ph = ph >= 3u ? ph - 3u : ph;
+#pragma clang loop vectorize(disable) unroll(disable)
+                for (uint32_t c = c0 + lane; c < c1; c += 64) {
+                    uint4 v;
+                    v.x = ph == 0u ? D0 : ph == 1u ? D1 : D2;
+                    v.y = ph == 0u ? D1 : ph == 1u ? D2 : D0;
+                    v.z = ph == 0u ? D2 : ph == 1u ? D0 : D1;
+                    v.w = v.x;
+                    *reinterpret_cast<uint4*>(TB + 16u * c) = v;
+                    ph = ph == 2u ? 0u : ph + 1u;                                               // 64 groups on: 64 = 1 (mod 3)
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// Sparse tiles, SHARE waves each; the others are flagged for k_tile_dense.
+#ifndef SHARE
+#define SHARE 4
+#endif
+// Every load a tile needs is issued before its first store: on gfx9 stores count in vmcnt, so a load issued behind
+// them (s_waitcnt vmcnt(0)) would wait for every store of the wave to be acknowledged by a write-saturated memory.
+__global__ __launch_bounds__(BLOCK) void k_tile_build(
+    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
+    const int32_t* __restrict__ tile_valid, int64_t n_tiles, int32_t* __restrict__ depth,
+    const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
+    uint8_t* __restrict__ dense_flag, int32_t sparse_max
+#ifdef GCI_TILE_TRACE
+    , unsigned long long* __restrict__ trace
+#endif
+    )
+{
+    const int lane = threadIdx.x & 63;
+    // the wave index is uniform: say so, and everything per tile (bounds, carry, offsets, loop counts) lives in SGPRs
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64 / SHARE) + wv / SHARE;
+    if (tile >= n_tiles) return;
+#ifdef GCI_TILE_TRACE
+    unsigned long long* g_tt = trace + tile * 8;
+    TT(0);
+#endif
+    const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
+    const int32_t carry_in = tile_carry[tile], valid = tile_valid[tile];
+    const uint64_t T0 = text ? tile_text_off[tile] : 0ull;
+    bool done = false;
+    if ((int64_t)(e1 - e0) <= sparse_max)
+        done = tile_sparse2(tile, e0, e1 - e0, events, carry_in, valid, depth, T0, text, text_cap, lane, wv % SHARE, SHARE TT_ARG);
+    if (lane == 0 && wv % SHARE == 0) dense_flag[tile] = done ? 0 : 1;      // k_tile_dense<2> takes the rest
+    TT(7);
+}
+
+// The dense tiles: those with more than sparse_max events and (pass 2) those the sparse kernel flagged.  One
+// workgroup looks at DENSE_SPAN consecutive tiles, so that the launch stays small when (as usual) none is dense.
+#define DENSE_SPAN 4
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void k_tile_dense(
+    const uint8_t* __restrict__ dense_flag, int32_t sparse_max, int64_t n_tiles,
+    const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
+    const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss,
+    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
+    const uint32_t* __restrict__ g_lut)
+{
+    // (written out rather than looped: a loop around tile_dense doubles its register count)
+#define DENSE_ONE(k)                                                                                                         \
+    {                                                                                                                        \
+        const int64_t tile = (int64_t)blockIdx.x * DENSE_SPAN + (k);                                                         \
+        if (tile >= n_tiles) return;                                                                                         \
+        if ((int64_t)(evt_off[tile + 1] - evt_off[tile]) > sparse_max || (PASS == 2 && dense_flag[tile])) {                  \
+            tile_dense<PASS>(tile, events, evt_off, tile_carry, tile_first, len, n_contigs, tile_sum, tile_bytes, iss, depth, \
+                             tile_text_off, text, text_cap, g_lut);                                                          \
+            __syncthreads();                                                                                                 \
+        }                                                                                                                    \
+    }
+    DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3)
+#undef DENSE_ONE
 }
 
 // ---- host -----------------------------------------------------------------------------------------
 
+#ifdef GCI_TILE_TRACE
+#define TILE_TRACE_ARG , (unsigned long long*)strtoull(getenv("GCI_TILE_TRACE_PTR") ? getenv("GCI_TILE_TRACE_PTR") : "0", nullptr, 0)
+#else
+#define TILE_TRACE_ARG
+#endif
+
 static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_depth, uint8_t* d_text, uint64_t text_cap)
 {
-    const dim3 grid((uint32_t)ctx->n_tiles), block(BLOCK);
+    const dim3 block(BLOCK);
     const uint16_t* ev = (const uint16_t*)ctx->events.p;
     const uint32_t* eo = (const uint32_t*)ctx->evt_off.p;
     const int32_t* tc = (const int32_t*)ctx->tile_carry.p;
     const int64_t* tf = (const int64_t*)ctx->d_tile_first.p;
     const int64_t* ln = (const int64_t*)ctx->d_len.p;
+    const int32_t* tv = (const int32_t*)ctx->d_tile_valid.p;
+    const int64_t per = BLOCK / 64;
+    const dim3 grid((uint32_t)((ctx->n_tiles + per - 1) / per));
+    const int64_t per2 = BLOCK / 64 / SHARE;
+    const dim3 grid2((uint32_t)((ctx->n_tiles + per2 - 1) / per2));
+    const dim3 dense_grid((uint32_t)((ctx->n_tiles + DENSE_SPAN - 1) / DENSE_SPAN));
+    uint8_t* flag = (uint8_t*)ctx->dense_flag.p;          // written by k_tile_build for every tile, read by k_tile_dense<2>
+    IssueArgs none;
+    memset(&none, 0, sizeof none);
     if (pass == 1) {
         ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
-        const int64_t per = BLOCK / 64;
-        hipLaunchKernelGGL(k_tile_pass1, dim3((uint32_t)((ctx->n_tiles + per - 1) / per)), block, 0, ctx->stream, ev, eo, tc,
-                           tf, ln, ctx->n_contigs, ctx->n_tiles, (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss,
+        hipLaunchKernelGGL(k_tile_pass1, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, ctx->n_tiles,
+                           (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, ctx->sparse_max);
+        LAUNCHCHK("k_tile_pass1");
+        hipLaunchKernelGGL(k_tile_dense<1>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
+                           ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss,
+                           (int32_t*)nullptr, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0,
                            (const uint32_t*)ctx->text_lut.p);
     } else {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
-        hipLaunchKernelGGL(k_tile_build, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, d_depth,
+        if (ctx->split_text && d_text) {       // two write streams, one after the other
+            hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
+                               (const uint64_t*)ctx->tile_u64.p, (uint8_t*)nullptr, (uint64_t)0, flag, ctx->sparse_max TILE_TRACE_ARG);
+            hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles,
+                               (int32_t*)nullptr, (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max TILE_TRACE_ARG);
+        } else
+        hipLaunchKernelGGL(k_tile_build, grid2, block, (size_t)(getenv("GCI_TILE_LDS") ? atoi(getenv("GCI_TILE_LDS")) : 0), ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
+                           (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max TILE_TRACE_ARG);
+        LAUNCHCHK("k_tile_build");
+        hipLaunchKernelGGL(k_tile_dense<2>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
+                           ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)nullptr, (uint32_t*)nullptr, none, d_depth,
                            (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, (const uint32_t*)ctx->text_lut.p);
     }
-    LAUNCHCHK("k_tile_build");
+    LAUNCHCHK("k_tile_dense");
     return GCI_OK;
 }
 

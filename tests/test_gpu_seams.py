@@ -261,6 +261,8 @@ def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed):
                 s = s0 + int(rng.integers(0, 2000))
                 ivls.append((c, s, s + int(rng.integers(1, 800))))
     ivls += [(1, 0, 4096), (1, 4096, 8192), (3, 4095, 4097), (3, 8191, 8193), (0, 0, 1), (0, 69_999, 70_000), (4, 0, 40)]
+    if seed == 3:       # depth >= 1000 over tiles that hold no event of their own: four-digit text from the dense path
+        ivls += [(5, 3000, 30_000)] * 1100 + [(5, 10_000, 10_010)] * 9000
     d = engine.to_device(np.array([(c, s, e, 0) for c, s, e in ivls], dtype=np.int32))
     for fl, lo, hi in ((0, -1, 0), (15, -1, 1), (3, 0, 2), (5000, -1, 0), (1, 1, 3)):
         want = oracle.depth_build_py([(targets[c], s, e) for c, s, e in ivls], lengths, fl)
