@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgci_hip.so")
+LIB_PATH = os.environ.get("GCI_LIB_PATH") or os.path.join(_HERE, "csrc", "libgci_hip.so")   # GCI_LIB_PATH: an experimental build
 
 GCI_OK, GCI_E_INVALID, GCI_E_HIP, GCI_E_NO_NM, GCI_E_ZERO_DIV = 0, -1, -2, -3, -4
 GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, GCI_E_NO_LAYOUT = -5, -6, -7, -8, -9, -10

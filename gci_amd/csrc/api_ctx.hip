@@ -46,7 +46,6 @@ extern "C" int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx*
     if (!ctx) return GCI_E_NOMEM;
     ctx->device = device;
     { const char* fd = getenv("GCI_FORCE_DENSE"); if (fd && fd[0] == '1') ctx->sparse_max = -1; }   // testing / A-B timing
-    { const char* st = getenv("GCI_SPLIT_TEXT"); if (st && st[0] == '1') ctx->split_text = true; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete ctx; return GCI_E_HIP; }
     if (!own_stream) { ctx->stream = (hipStream_t)stream; }    // NULL = the device's default stream
@@ -224,7 +223,7 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     GCI_TRY(gci_ensure(ctx, ctx->tile_u32, (size_t)(tiles + 1) * 4));
     GCI_TRY(gci_ensure(ctx, ctx->tile_u64, (size_t)(tiles + 2) * 8));
     GCI_TRY(gci_ensure(ctx, ctx->blk_u64, nb * 8));
-    // the per-tile (count, difference) table is self-cleaning (k_scan2_local zeroes the differences, k_evt_scatter
+    // the per-tile (count, difference) table is self-cleaning (k_tile_build zeroes the differences, k_evt_scatter
     // returns the counts to zero): zero it once here
     HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(tiles + 1) * 8, ctx->stream));
     ctx->cd_dirty = false;

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(BLOCK) void k_evt_scatter(const gci_ivl* __restrict
 }
 
 // Both per-tile scans in one launch: blockIdx.y == 0 coarse difference (high words) -> carry, == 1 counts (low
-// words) -> offsets.  The y == 0 blocks also zero the high words they consumed and the small outputs of the build.
+// words) -> offsets.  The y == 0 blocks also zero the small outputs of the build (the high words are zeroed by
+// k_tile_build, tile by tile).
 __global__ __launch_bounds__(BLOCK) void k_scan2_local(uint32_t* __restrict__ cd_words, int32_t* __restrict__ carry,
                                                        int32_t* __restrict__ blk_a, uint32_t* __restrict__ off,
                                                        uint32_t* __restrict__ blk_b, int64_t n, uint32_t* __restrict__ n_keys,
@@ -95,9 +96,6 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_local(uint32_t* __restrict__ cd
 {
     if (blockIdx.y == 0) {
         scan_local_body<int32_t, int32_t>((const int32_t*)cd_words + 1, carry, blk_a, n, blockIdx.x, 2);
-        const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * 16;
-#pragma unroll
-        for (int i = 0; i < 16; i++) if (base + i < n) cd_words[2 * (base + i) + 1] = 0u;      // own elements only
         if (blockIdx.x == 0) {
             if (threadIdx.x == 0 && n_keys) *n_keys = 0;
             if (sums) for (int32_t c = threadIdx.x; c < n_contigs; c += BLOCK) sums[c] = 0;
@@ -111,6 +109,168 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_add(int32_t* __restrict__ carry
 {
     if (blockIdx.y == 0) { if ((int32_t)blockIdx.x < n_blocks) scan_add_body<int32_t>(carry, blk_a, n, n_blocks, blockIdx.x); }
     else scan_add_body<uint32_t>(off, blk_b, n, n_blocks, blockIdx.x);     // block n_blocks writes off[n] = total
+}
+
+// ---- the same table work in ONE launch ------------------------------------------------------------------
+// A kernel on this stream costs ~4.5 us however little it does, and a build of one chromosome (15 000 tiles, four
+// workgroups' worth of table) spent a quarter of its time in two-launch scans.  Up to FEW_BLOCKS workgroups every
+// workgroup simply re-reduces the entries in front of its own instead of waiting for a second launch.
+#define FEW_BLOCKS 8
+
+// sum of in[0 .. n_before) (entry i at in[i * stride]) by the whole workgroup
+template <typename TIn, typename TOut>
+__device__ __forceinline__ TOut block_sum_before(const TIn* __restrict__ in, int64_t n_before, int64_t stride)
+{
+    __shared__ TOut part[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    TOut s = 0;
+    for (int64_t i = t; i < n_before; i += 8 * BLOCK) {            // eight independent loads in flight per thread
+        TIn v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i + k * BLOCK < n_before ? in[(i + k * BLOCK) * stride] : (TIn)0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += (TOut)v[k];
+    }
+    s = wave_sum<TOut>(s);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    TOut all = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) all += part[w];
+    __syncthreads();
+    return all;
+}
+
+// exclusive scan of this workgroup's TILE entries on top of `before`; returns before + the workgroup's total
+template <typename TIn, typename TOut>
+__device__ __forceinline__ TOut scan_block_from(const TIn* __restrict__ in, TOut* __restrict__ out, int64_t n, uint32_t blk,
+                                                int64_t stride, TOut before)
+{
+    __shared__ TOut wtot[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t base = (int64_t)blk * TILE + (int64_t)t * 16;
+    TOut v[16], run = 0;
+    if (stride == 1 && sizeof(TIn) == 4 && base + 16 <= n) {       // the table starts 16-byte aligned, base is a multiple of 16
+        const uint4* in4 = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 q = in4[k];
+            v[4 * k] = (TOut)(TIn)q.x; v[4 * k + 1] = (TOut)(TIn)q.y; v[4 * k + 2] = (TOut)(TIn)q.z; v[4 * k + 3] = (TOut)(TIn)q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = base + i < n ? (TOut)in[(base + i) * stride] : (TOut)0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) run += v[i];
+    const TOut inc = wave_inclusive<TOut>(run, lane);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    TOut pre = before + inc - run, all = before;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) { const TOut x = wtot[w]; if (w < wave) pre += x; all += x; }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { if (base + i < n) out[base + i] = pre; pre += v[i]; }
+    return all;
+}
+
+// Both scans of the (count, difference) table by the same workgroups: 16-byte loads bring two tiles' pairs at a time.
+// (The difference words are zeroed by k_tile_build: other workgroups still read them here.)
+__global__ __launch_bounds__(BLOCK) void k_scan2_few(const uint32_t* __restrict__ cd_words, int32_t* __restrict__ carry,
+                                                     uint32_t* __restrict__ off, int64_t n, uint32_t* __restrict__ n_keys,
+                                                     long long* __restrict__ sums, int32_t n_contigs)
+{
+    __shared__ uint32_t part_c[BLOCK / 64];
+    __shared__ int32_t part_d[BLOCK / 64];
+    __shared__ uint32_t wtot_c[BLOCK / 64];
+    __shared__ int32_t wtot_d[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint2* cd = reinterpret_cast<const uint2*>(cd_words);            // .x = count, .y = difference
+    // everything in front of this workgroup, eight independent loads in flight per thread
+    const int64_t n_before = (int64_t)blockIdx.x * TILE;
+    uint32_t bc = 0; int32_t bd = 0;
+    for (int64_t i = t; i < n_before; i += 8 * BLOCK) {
+        uint2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i + k * BLOCK < n_before ? cd[i + k * BLOCK] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { bc += v[k].x; bd += (int32_t)v[k].y; }
+    }
+    bc = wave_sum<uint32_t>(bc); bd = wave_sum<int32_t>(bd);
+    if (lane == 0) { part_c[wave] = bc; part_d[wave] = bd; }
+    // this workgroup's own TILE entries: 16 per thread
+    const int64_t base = n_before + (int64_t)t * 16;
+    uint32_t c[16], run_c = 0; int32_t d[16], run_d = 0;
+    const uint4* cd4 = reinterpret_cast<const uint4*>(cd_words);           // two tiles per load; tile_cd has n + 1 entries
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int64_t i = base + 2 * k;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i + 1 < n) v = cd4[i >> 1];
+        else if (i < n) { const uint2 u = cd[i]; v.x = u.x; v.y = u.y; }
+        c[2 * k] = v.x; d[2 * k] = (int32_t)v.y; c[2 * k + 1] = v.z; d[2 * k + 1] = (int32_t)v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { run_c += c[i]; run_d += d[i]; }
+    const uint32_t inc_c = (uint32_t)wave_inclusive_i32((int32_t)run_c);
+    const int32_t inc_d = wave_inclusive_i32(run_d);
+    if (lane == 63) { wtot_c[wave] = inc_c; wtot_d[wave] = inc_d; }
+    __syncthreads();
+    uint32_t pre_c = inc_c - run_c, all_c = 0; int32_t pre_d = inc_d - run_d;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+        pre_c += part_c[w]; pre_d += part_d[w]; all_c += part_c[w] + wtot_c[w];
+        if (w < wave) { pre_c += wtot_c[w]; pre_d += wtot_d[w]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (base + i < n) { off[base + i] = pre_c; carry[base + i] = pre_d; }
+        pre_c += c[i]; pre_d += d[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && t == 0) off[n] = all_c;
+    if (blockIdx.x == 0) {
+        if (t == 0 && n_keys) *n_keys = 0;
+        if (sums) for (int32_t k = t; k < n_contigs; k += BLOCK) sums[k] = 0;
+    }
+}
+
+// after pass 1, one launch: workgroups [0, nb): text offset of every tile (+ total) and of every contig;
+// workgroups [nb, nb + n_contigs * REDUCE_SPLIT): depth sum of every contig (sums zeroed by k_scan2_*)
+__global__ __launch_bounds__(BLOCK) void k_after_pass1_few(const uint32_t* __restrict__ tile_bytes, unsigned long long* __restrict__ tile_off,
+                                                           int64_t n, uint32_t nb, const int64_t* __restrict__ tile_first,
+                                                           int32_t n_contigs, uint64_t* __restrict__ contig_off,
+                                                           const long long* __restrict__ tile_sum, unsigned long long* __restrict__ sums)
+{
+    const int t = threadIdx.x;
+    if (blockIdx.x < nb) {
+        if (!contig_off) return;
+        const uint32_t blk = blockIdx.x;
+        const unsigned long long before = block_sum_before<uint32_t, unsigned long long>(tile_bytes, (int64_t)blk * TILE, 1);
+        const unsigned long long all = scan_block_from<uint32_t, unsigned long long>(tile_bytes, tile_off, n, blk, 1, before);
+        if (blk == nb - 1 && t == 0) { tile_off[n] = all; contig_off[n_contigs] = all; }
+        __syncthreads();                                   // this workgroup's offsets are visible to it
+        const int64_t lo = (int64_t)blk * TILE, hi = min(n, lo + TILE);
+        for (int32_t c = t; c < n_contigs; c += BLOCK) {
+            const int64_t ft = tile_first[c];
+            if (ft >= lo && ft < hi) contig_off[c] = tile_off[ft];
+            else if (ft >= n && blk == nb - 1) contig_off[c] = all;          // contigs of length zero at the end
+        }
+    } else {
+        if (!sums) return;
+        __shared__ long long part[BLOCK / 64];
+        const uint32_t w = blockIdx.x - nb, c = w / REDUCE_SPLIT, y = w % REDUCE_SPLIT;
+        const int lane = t & 63, wave = t >> 6;
+        const int64_t a = tile_first[c], b = tile_first[c + 1];
+        long long s = 0;
+        for (int64_t i = a + (int64_t)y * BLOCK + t; i < b; i += (int64_t)REDUCE_SPLIT * BLOCK) s += tile_sum[i];
+        s = wave_sum<long long>(s);
+        if (lane == 0) part[wave] = s;
+        __syncthreads();
+        if (t == 0) {
+            const long long v = part[0] + part[1] + part[2] + part[3];
+            if (v) atomicAdd(sums + c, (unsigned long long)v);
+        }
+    }
 }
 
 // ---- per tile -------------------------------------------------------------------------------------
@@ -610,7 +770,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int32_t* __restrict__ tile_valid, int64_t n_tiles, int32_t* __restrict__ depth,
     const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
-    uint8_t* __restrict__ dense_flag, int32_t sparse_max
+    uint8_t* __restrict__ dense_flag, int32_t sparse_max, uint32_t* __restrict__ cd_words
 #ifdef GCI_TILE_TRACE
     , unsigned long long* __restrict__ trace
 #endif
@@ -619,7 +779,9 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const int lane = threadIdx.x & 63;
     // the wave index is uniform: say so, and everything per tile (bounds, carry, offsets, loop counts) lives in SGPRs
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64 / SHARE) + wv / SHARE;
+    const int64_t gw = (int64_t)blockIdx.x * (BLOCK / 64) + wv;               // SHARE consecutive waves share a tile
+    const int64_t tile = gw / SHARE;
+    const uint32_t wi = (uint32_t)(gw % SHARE);
     if (tile >= n_tiles) return;
 #ifdef GCI_TILE_TRACE
     unsigned long long* g_tt = trace + tile * 8;
@@ -630,8 +792,11 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const uint64_t T0 = text ? tile_text_off[tile] : 0ull;
     bool done = false;
     if ((int64_t)(e1 - e0) <= sparse_max)
-        done = tile_sparse2(tile, e0, e1 - e0, events, carry_in, valid, depth, T0, text, text_cap, lane, wv % SHARE, SHARE TT_ARG);
-    if (lane == 0 && wv % SHARE == 0) dense_flag[tile] = done ? 0 : 1;      // k_tile_dense<2> takes the rest
+        done = tile_sparse2(tile, e0, e1 - e0, events, carry_in, valid, depth, T0, text, text_cap, lane, wi, SHARE TT_ARG);
+    if (lane == 0 && wi == 0) {
+        dense_flag[tile] = done ? 0 : 1;                                     // k_tile_dense<2> takes the rest
+        cd_words[2 * tile + 1] = 0u;                                         // the coarse difference has been consumed: table clean again
+    }
     TT(7);
 }
 
@@ -681,8 +846,7 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
     const int32_t* tv = (const int32_t*)ctx->d_tile_valid.p;
     const int64_t per = BLOCK / 64;
     const dim3 grid((uint32_t)((ctx->n_tiles + per - 1) / per));
-    const int64_t per2 = BLOCK / 64 / SHARE;
-    const dim3 grid2((uint32_t)((ctx->n_tiles + per2 - 1) / per2));
+    const dim3 grid2((uint32_t)((ctx->n_tiles * SHARE + per - 1) / per));
     const dim3 dense_grid((uint32_t)((ctx->n_tiles + DENSE_SPAN - 1) / DENSE_SPAN));
     uint8_t* flag = (uint8_t*)ctx->dense_flag.p;          // written by k_tile_build for every tile, read by k_tile_dense<2>
     IssueArgs none;
@@ -698,14 +862,8 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
                            (const uint32_t*)ctx->text_lut.p);
     } else {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
-        if (ctx->split_text && d_text) {       // two write streams, one after the other
-            hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
-                               (const uint64_t*)ctx->tile_u64.p, (uint8_t*)nullptr, (uint64_t)0, flag, ctx->sparse_max TILE_TRACE_ARG);
-            hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles,
-                               (int32_t*)nullptr, (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max TILE_TRACE_ARG);
-        } else
-        hipLaunchKernelGGL(k_tile_build, grid2, block, (size_t)(getenv("GCI_TILE_LDS") ? atoi(getenv("GCI_TILE_LDS")) : 0), ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
-                           (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max TILE_TRACE_ARG);
+        hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
+                           (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max, (uint32_t*)ctx->tile_cd.p TILE_TRACE_ARG);
         LAUNCHCHK("k_tile_build");
         hipLaunchKernelGGL(k_tile_dense<2>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
                            ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)nullptr, (uint32_t*)nullptr, none, d_depth,
@@ -747,13 +905,19 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     }
     {
         ProfScope _ps(ctx, GCI_PROF_SCAN_TILES);
-        hipLaunchKernelGGL(k_scan2_local, dim3(nb, 2), dim3(BLOCK), 0, ctx->stream, (uint32_t*)cd, (int32_t*)ctx->tile_carry.p,
-                           (int32_t*)ctx->blk_a.p, off, (uint32_t*)ctx->blk_b.p, nt, o->d_n_keys, (long long*)o->d_sums,
-                           ctx->n_contigs);
-        LAUNCHCHK("k_scan2_local");
-        hipLaunchKernelGGL(k_scan2_add, dim3(nb + 1, 2), dim3(BLOCK), 0, ctx->stream, (int32_t*)ctx->tile_carry.p,
-                           (const int32_t*)ctx->blk_a.p, off, (const uint32_t*)ctx->blk_b.p, nt, nb);
-        LAUNCHCHK("k_scan2_add");
+        if (nb <= FEW_BLOCKS) {
+            hipLaunchKernelGGL(k_scan2_few, dim3(nb), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)cd, (int32_t*)ctx->tile_carry.p,
+                               off, nt, o->d_n_keys, (long long*)o->d_sums, ctx->n_contigs);
+            LAUNCHCHK("k_scan2_few");
+        } else {
+            hipLaunchKernelGGL(k_scan2_local, dim3(nb, 2), dim3(BLOCK), 0, ctx->stream, (uint32_t*)cd, (int32_t*)ctx->tile_carry.p,
+                               (int32_t*)ctx->blk_a.p, off, (uint32_t*)ctx->blk_b.p, nt, o->d_n_keys, (long long*)o->d_sums,
+                               ctx->n_contigs);
+            LAUNCHCHK("k_scan2_local");
+            hipLaunchKernelGGL(k_scan2_add, dim3(nb + 1, 2), dim3(BLOCK), 0, ctx->stream, (int32_t*)ctx->tile_carry.p,
+                               (const int32_t*)ctx->blk_a.p, off, (const uint32_t*)ctx->blk_b.p, nt, nb);
+            LAUNCHCHK("k_scan2_add");
+        }
     }
     if (max_n) {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
@@ -761,7 +925,6 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
                            o->flank, ln, tf, ctx->n_contigs, (uint32_t*)cd, (const uint32_t*)off, (uint16_t*)ctx->events.p);
         LAUNCHCHK("k_evt_scatter");
     }
-    ctx->cd_dirty = false;
     const bool by_products = o->want_text || o->d_sums || o->d_n_keys;
     if (by_products) {
         IssueArgs iss;
@@ -773,20 +936,30 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
             if (!iss.keys) { static unsigned long long dummy; iss.keys = &dummy; iss.cap = 0; }   // count only
         }
         GCI_TRY(launch_tile_build(ctx, 1, iss, nullptr, nullptr, 0));
-        if (o->d_sums) {
-            ProfScope _ps(ctx, GCI_PROF_DEPTH_SUM);
-            hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs, REDUCE_SPLIT), dim3(BLOCK), 0, ctx->stream,
-                               (const long long*)ctx->tile_sum.p, tf, (unsigned long long*)o->d_sums);
-            LAUNCHCHK("k_reduce_tiles");
-        }
-        if (o->want_text) {
+        if (nb <= FEW_BLOCKS && (o->want_text || o->d_sums)) {
             ProfScope _ps(ctx, GCI_PROF_TEXT_COUNT);
-            GCI_TRY((device_exclusive_scan<uint32_t, unsigned long long>(ctx, (const uint32_t*)ctx->tile_u32.p,
-                                                                         (unsigned long long*)ctx->tile_u64.p,
-                                                                         (unsigned long long*)ctx->blk_u64.p, nt, true)));
-            hipLaunchKernelGGL(k_contig_text_off, dim3((ctx->n_contigs + 1 + 63) / 64), dim3(64), 0, ctx->stream,
-                               (const uint64_t*)ctx->tile_u64.p, tf, ctx->n_contigs, nt, o->d_contig_text_off);
-            LAUNCHCHK("k_contig_text_off");
+            const uint32_t reduce_blocks = o->d_sums ? (uint32_t)ctx->n_contigs * REDUCE_SPLIT : 0u;
+            hipLaunchKernelGGL(k_after_pass1_few, dim3((uint32_t)nb + reduce_blocks), dim3(BLOCK), 0, ctx->stream,
+                               (const uint32_t*)ctx->tile_u32.p, (unsigned long long*)ctx->tile_u64.p, nt, (uint32_t)nb, tf,
+                               ctx->n_contigs, o->want_text ? o->d_contig_text_off : (uint64_t*)nullptr,
+                               (const long long*)ctx->tile_sum.p, (unsigned long long*)o->d_sums);
+            LAUNCHCHK("k_after_pass1_few");
+        } else {
+            if (o->d_sums) {
+                ProfScope _ps(ctx, GCI_PROF_DEPTH_SUM);
+                hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs, REDUCE_SPLIT), dim3(BLOCK), 0, ctx->stream,
+                                   (const long long*)ctx->tile_sum.p, tf, (unsigned long long*)o->d_sums);
+                LAUNCHCHK("k_reduce_tiles");
+            }
+            if (o->want_text) {
+                ProfScope _ps(ctx, GCI_PROF_TEXT_COUNT);
+                GCI_TRY((device_exclusive_scan<uint32_t, unsigned long long>(ctx, (const uint32_t*)ctx->tile_u32.p,
+                                                                             (unsigned long long*)ctx->tile_u64.p,
+                                                                             (unsigned long long*)ctx->blk_u64.p, nt, true)));
+                hipLaunchKernelGGL(k_contig_text_off, dim3((ctx->n_contigs + 1 + 63) / 64), dim3(64), 0, ctx->stream,
+                                   (const uint64_t*)ctx->tile_u64.p, tf, ctx->n_contigs, nt, o->d_contig_text_off);
+                LAUNCHCHK("k_contig_text_off");
+            }
         }
     }
     ctx->build_pending = true;
@@ -803,7 +976,9 @@ extern "C" int gci_depth_build_finish(gci_ctx* ctx, int32_t* d_depth, uint8_t* d
     if (ctx->n_tiles == 0) return GCI_OK;
     IssueArgs none;
     memset(&none, 0, sizeof none);
-    return launch_tile_build(ctx, 2, none, d_depth, d_text, text_cap);
+    GCI_TRY(launch_tile_build(ctx, 2, none, d_depth, d_text, text_cap));
+    ctx->cd_dirty = false;                                  // k_evt_scatter returned the counts, k_tile_build the differences
+    return GCI_OK;
 }
 
 extern "C" int gci_depth_build(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, int flank,
