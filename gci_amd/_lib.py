@@ -18,9 +18,10 @@ GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, G
 GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
 REC_PASS, REC_HQ = 1, 2
-PROF_COUNT = 14
+PROF_COUNT = 15
 PROF_DEPTH_SCAN = 5          # k_tile_build: the pass that writes the depth track (+ text)
 PROF_TILE_PASS1 = 13
+PROF_TILE_DENSE = 14         # k_tile_dense<1>, <2>: the tiles the event-list kernels left over
 
 
 class GciError(RuntimeError):

@@ -852,19 +852,26 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
     IssueArgs none;
     memset(&none, 0, sizeof none);
     if (pass == 1) {
-        ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
-        hipLaunchKernelGGL(k_tile_pass1, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, ctx->n_tiles,
-                           (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, ctx->sparse_max);
-        LAUNCHCHK("k_tile_pass1");
+        {
+            ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
+            hipLaunchKernelGGL(k_tile_pass1, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, ctx->n_tiles,
+                               (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, ctx->sparse_max);
+            LAUNCHCHK("k_tile_pass1");
+        }
+        ProfScope _ps(ctx, GCI_PROF_TILE_DENSE);
         hipLaunchKernelGGL(k_tile_dense<1>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
                            ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss,
                            (int32_t*)nullptr, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0,
                            (const uint32_t*)ctx->text_lut.p);
     } else {
-        ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
-        hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
-                           (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max, (uint32_t*)ctx->tile_cd.p TILE_TRACE_ARG);
-        LAUNCHCHK("k_tile_build");
+        {
+            ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
+            hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
+                               (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max,
+                               (uint32_t*)ctx->tile_cd.p TILE_TRACE_ARG);
+            LAUNCHCHK("k_tile_build");
+        }
+        ProfScope _ps(ctx, GCI_PROF_TILE_DENSE);
         hipLaunchKernelGGL(k_tile_dense<2>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
                            ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)nullptr, (uint32_t*)nullptr, none, d_depth,
                            (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, (const uint32_t*)ctx->text_lut.p);
