@@ -246,7 +246,7 @@ def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed):
     events and from the dense difference array otherwise: low coverage with many short runs, runs crossing tile and
     window edges, pile-ups (> 63 events in a tile) next to empty tiles, contigs ending on and off tile boundaries."""
     rng = np.random.default_rng(100 + seed)
-    lengths = {"a": 70_000, "b": 8192, "c": 4097, "d": 12_288, "e": 40, "f": 33_333}
+    lengths = {"a": 70_000, "b": 8192, "c": 4097, "d": 12_288, "e": 40, "f": 33_333, "g": 1, "h": 3, "i": 16, "j": 17, "k": 5}
     targets = list(lengths)
     engine.set_layout([lengths[t] for t in targets])
     ivls = []
@@ -261,6 +261,9 @@ def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed):
                 s = s0 + int(rng.integers(0, 2000))
                 ivls.append((c, s, s + int(rng.integers(1, 800))))
     ivls += [(1, 0, 4096), (1, 4096, 8192), (3, 4095, 4097), (3, 8191, 8193), (0, 0, 1), (0, 69_999, 70_000), (4, 0, 40)]
+    ivls += [(6, 0, 1), (7, 1, 3), (8, 0, 16), (8, 3, 9), (9, 0, 17), (9, 16, 17), (10, 2, 4)]     # tiny contigs: every edge case at once
+    if seed == 2:       # three-digit depths (4-byte text pattern) over tiles with few events, next to 1- and 2-digit ones
+        ivls += [(0, 5000, 60_000)] * 99 + [(0, 20_000, 40_000)] * 2 + [(5, 100, 33_000)] * 300 + [(5, 4090, 4100)] * 5
     if seed == 3:       # depth >= 1000 over tiles that hold no event of their own: four-digit text from the dense path
         ivls += [(5, 3000, 30_000)] * 1100 + [(5, 10_000, 10_010)] * 9000
     d = engine.to_device(np.array([(c, s, e, 0) for c, s, e in ivls], dtype=np.int32))
@@ -282,7 +285,37 @@ def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed):
         scanned = pipeline.collapse_depth_range(tr, lo, hi, fl, 0)
         assert fused_bed == scanned == oracle.collapse_depth_range(want, lo, hi, fl, 0), (fl, lo, hi)
         if fl < 5000:
-            assert sum(len(v) for v in scanned.values()) > 20
+            assert sum(len(v) for v in scanned.values()) > 5
+
+
+def test_dense_path_equals_event_list_path(engine, monkeypatch):
+    """GCI_FORCE_DENSE=1 (read when a context is created) sends every tile through the dense difference-array kernels;
+    the event-list kernels must produce the same track, text, sums and issue runs byte for byte."""
+    from gci_amd.device import Engine
+    rng = np.random.default_rng(77)
+    lengths = [150_000, 4096, 9_000, 77]
+    ivls = []
+    for c, L in enumerate(lengths):
+        for _ in range(max(3, L // 400)):
+            s0 = int(rng.integers(0, L))
+            ivls.append((c, s0, int(min(L + 3, s0 + rng.integers(1, 6000))), 0))
+    ivls += [(0, 1000, 140_000, 0)] * 120                      # three-digit depths
+    arr = np.array(ivls, dtype=np.int32)
+    monkeypatch.setenv("GCI_FORCE_DENSE", "1")
+    dense = Engine(0)
+    monkeypatch.delenv("GCI_FORCE_DENSE")
+    outs = []
+    for eng in (engine, dense):
+        eng.set_layout(lengths)
+        track = eng.new_track()
+        out = eng.depth_build_fused(eng.to_device(arr), None, 7, track, want_text=True, want_sums=True, issue=(-1, 2, 7))
+        outs.append((track.cpu().numpy(), out["text"].cpu().numpy().tobytes(), out["text_off"], out["sums"],
+                     [np.asarray(r) for r in out["runs"]]))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+    assert len(a[1]) > 400_000
 
 
 def test_cross_rank_name_check_kernels(engine):
