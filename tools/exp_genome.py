@@ -26,7 +26,7 @@ p = lambda t: ctypes.c_void_p(t.data_ptr())
 e._chk(e.lib.gci_depth_build_begin(e.ctx, p(d_ivl), None, n, ctypes.byref(o)), "b")
 tb = int(toff[nc].item())
 text = torch.empty(tb + 64, dtype=torch.uint8, device=e.device)
-e.profile_enable((1 << 14) - 1); e.profile_read()
+e.profile_enable((1 << _lib.PROF_COUNT) - 1); e.profile_read()
 for _ in range(5):
     e._chk(e.lib.gci_depth_build_begin(e.ctx, p(d_ivl), None, n, ctypes.byref(o)), "b")
     e._chk(e.lib.gci_depth_build_finish(e.ctx, p(track), p(text), tb + 64), "f")

@@ -22,7 +22,7 @@ def run(label, want_text, want_sums):
     o.d_sums = sums.data_ptr() if want_sums else None
     e._chk(e.lib.gci_depth_build_begin(e.ctx, p(ivl), p(cnt), int(ivl.shape[0]), ctypes.byref(o)), "b")
     text = torch.empty(int(toff[1].item()) + 64, dtype=torch.uint8, device=e.device) if want_text else None
-    e.profile_enable((1 << 14) - 1); e.profile_read()
+    e.profile_enable((1 << _lib.PROF_COUNT) - 1); e.profile_read()
     for _ in range(10):
         e._chk(e.lib.gci_depth_build_begin(e.ctx, p(ivl), p(cnt), int(ivl.shape[0]), ctypes.byref(o)), "b")
         e._chk(e.lib.gci_depth_build_finish(e.ctx, p(track), p(text) if want_text else None, int(text.shape[0]) if want_text else 0), "f")
