@@ -105,7 +105,9 @@ typedef struct gci_ctx gci_ctx;
 int gci_abi_version(void);
 /* own_stream == 0: enqueue on `stream`, a hipStream_t of the caller (e.g. torch's current stream;
  * NULL is the device's default stream).  own_stream != 0: `stream` is ignored and the ctx creates
- * (and later destroys) a non-blocking stream of its own. */
+ * (and later destroys) a non-blocking stream of its own.
+ * Environment, read here: GCI_FORCE_DENSE=1 makes the depth build take its dense (difference array in LDS) path for
+ * every tile instead of only for tiles with many events -- same results, for testing and A/B timing. */
 int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx** out);
 int gci_ctx_destroy(gci_ctx* ctx);
 int gci_sync(gci_ctx* ctx);
