@@ -9,9 +9,9 @@
 //
 //   fast path (k_bam_filter), 16 records per wave:
 //     flag / MAPQ tests (GCI.py:152-156) -> query_name (first NUL) + 64-bit name hash -> first NM tag
-//     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162): one fire-and-forget
-//     ds_add_u64 per op into a per-record LDS row indexed by op code -> the two IEEE f64 divisions of
-//     GCI.py:165 -> 32-byte compact record.
+//     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162) in five per-lane register
+//     sums, added over the four lanes of the record -> the two IEEE f64 divisions of GCI.py:165 -> 32-byte
+//     compact record.
 //   slow path (k_bam_filter_slow), one wave per queued record, everything from global memory with
 //     naturally aligned loads only: htslib's CG:B,I restore (CIGARs of more than 65535 operations),
 //     records whose NM tag does not show up in the staged part of the aux block, names longer than the
@@ -197,7 +197,6 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
 #endif
     TR(0);
     __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
-    __shared__ unsigned long long tot_lds[KB / G][NSLOT];                   // op totals per record
     __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
     const int t = threadIdx.x;
     const int gl = t & (G - 1), grp = t / G;
@@ -211,8 +210,6 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         const char c = (char)i;
         aux_sz[i] = (c == 'A' || c == 'c' || c == 'C') ? 1 : (c == 's' || c == 'S') ? 2 : (c == 'i' || c == 'I' || c == 'f') ? 4 : 0;
     }
-    if (gl < NSLOT / 2) { tot_lds[grp][2 * gl] = 0ull; tot_lds[grp][2 * gl + 1] = 0ull; }
-    if (gl == G - 1) { for (int s = 2 * G; s < NSLOT; s++) tot_lds[grp][s] = 0ull; }
     if (live && off + 36 > n_bytes) {
         if (gl == 0) {
             gci_rec r; r.name_hash = 0; r.contig = -1; r.start = r.end = r.qlen = 0; r.rec_idx = rec + rec_idx_base;
@@ -282,7 +279,18 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     const bool long_cigar = n_cigar > LONG_OPS;                // its totals are computed by k_cigar_chunks
     const bool odd = odd_name || long_cigar;
     const uint32_t staged_ops = odd ? 0u : min(n_cigar, (HEAD - cig_at) / 4u);
-    unsigned long long* tot = tot_lds[grp];
+    // CIGAR base totals of this lane's share of the ops, in registers: M/=/X, I, D, N, S (get_cigar_stats()[0],
+    // GCI.py:157-162; the other op codes do not enter the decision)
+    unsigned long long sM = 0, sI = 0, sD = 0, sN = 0, sS = 0;
+    auto add_op = [&](uint32_t v) {
+        const uint32_t op = v & 0xFu;
+        const unsigned long long len = v >> 4;
+        sM += ((0x181u >> op) & 1u) ? len : 0ull;
+        sI += op == 1u ? len : 0ull;
+        sD += op == 2u ? len : 0ull;
+        sN += op == 3u ? len : 0ull;
+        sS += op == 4u ? len : 0ull;
+    };
     if (!odd) {
         // CIGAR words behind the staged head, straight from global memory.  Unaligned vector loads from global
         // memory are served, but ~100x slower than aligned ones on gfx950 (tools/exp_k1_trace.py), and a CIGAR
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], b);
-                    if (4u * c + j - d < cnt) { const uint32_t op = v & 0xF; atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4)); }
+                    if (4u * c + j - d < cnt) add_op(v);
                 }
             };
             // the first three chunks are requested together (a lane's share of a HiFi tail is ~6 ops: one round
@@ -324,9 +332,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         TR(10);
         // staged part of the CIGAR (GCI.py:157-162: get_cigar_stats()[0], base totals per op code)
         for (uint32_t k = gl; k < staged_ops; k += G) {
-            const uint32_t v = lds_u32(hd + cig_at + 4 * k);
-            const uint32_t op = v & 0xF;
-            atomicAdd(&tot[op < NSLOT - 1 ? op : NSLOT - 1], (unsigned long long)(v >> 4));
+            add_op(lds_u32(hd + cig_at + 4 * k));
         }
     }
     TR(3);
@@ -423,12 +429,12 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         if (!enqueue_long<G>(lq, it, gl) && gl == 0) report(status, rec, GCI_E_CAPACITY);
         return;
     }
-    wave_lds_fence();
-    if (gl != 0) return;        // the rest is scalar per record; the LDS operations of a wave complete in order
-    int64_t tt[NSLOT];
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++) tt[s] = (int64_t)tot[s];
-    const int st = decide(r, tt[0] + tt[7] + tt[8], tt[1], tt[2], tt[3], tt[4], have_nm, nm_bad, NM, pos, contig, l_seq,
+    // the four lanes' shares -> every lane of the group holds the record's totals
+#define GRP_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, G); x += (unsigned long long)__shfl_xor((long long)x, 2, G); } while (0)
+    GRP_SUM(sM); GRP_SUM(sI); GRP_SUM(sD); GRP_SUM(sN); GRP_SUM(sS);
+#undef GRP_SUM
+    if (gl != 0) return;        // the rest is scalar per record
+    const int st = decide(r, (int64_t)sM, (int64_t)sI, (int64_t)sD, (int64_t)sN, (int64_t)sS, have_nm, nm_bad, NM, pos, contig, l_seq,
                           n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
     if (st != GCI_OK) report(status, rec, st);
     out[rec] = r;
