@@ -57,7 +57,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_insert(JoinFiles F, int file, un
     // order of dict insertion in the reference: contig by contig (header order), file order inside
     const unsigned long long ord = (((unsigned long long)(uint32_t)r.contig << 32) | i) + 1ull;
     atomicMax(last + slot * F.n + file, ord);
-    if (r.flags & GCI_REC_HQ) atomicOr(hq + slot, 1u);
+    if (F.n > 1 && (r.flags & GCI_REC_HQ)) atomicOr(hq + slot, 1u);    // (a single file keeps every passing name: GCI.py:270)
 }
 
 // Fold of one name over the files (GCI.py:279-299); returns true when an interval survives.
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned
     for (int k = 0; k < FOLD_PER_THREAD; k++) {
         const uint64_t slot = slot0 + k;
         ok[k] = slot < n_slots && table[slot] != SLOT_EMPTY &&
-                fold_slot(F, slot, last, hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
+                fold_slot(F, slot, last, F.n > 1 && hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
         mine += ok[k] ? 1u : 0u;
     }
     const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
