@@ -649,10 +649,10 @@ __device__ __forceinline__ bool tile_sparse2(
     // ---- text ----------------------------------------------------------------------------------------------------
     // "row": the 16-byte aligned byte string TB that holds the tile's text; the text starts at row byte A0
     const uint32_t A0 = (uint32_t)(((uint64_t)(uintptr_t)text + T0) & 15ull);
-    const uint64_t row0 = T0 - A0;                                          // offset of TB in the caller's buffer
-    uint8_t* TB = text + T0 - A0;
-    const uint64_t room = text_cap > row0 ? text_cap - row0 : 0ull;
-    const uint32_t capu = room > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)room;   // row bytes [0, capu) may be written
+    const int64_t row0 = (int64_t)T0 - (int64_t)A0;                         // offset of TB in the caller's buffer (>= -15:
+    uint8_t* TB = text + row0;                                              //  a buffer need not start 16-byte aligned)
+    const int64_t room = (int64_t)text_cap - row0;
+    const uint32_t capu = room <= 0 ? 0u : room > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)room;   // row bytes [0, capu) may be written
     // decimal pattern of this lane's segment: "d\n", w = digits + 1 bytes, repeated to 8 bytes
     const uint32_t q10 = d / 10u, r0 = d - 10u * q10, q100 = q10 / 10u, r1 = q10 - 10u * q100;
     const uint32_t w = d >= 100u ? 4u : d >= 10u ? 3u : 2u;

@@ -311,6 +311,23 @@ def test_dense_path_equals_event_list_path(engine, monkeypatch):
         out = eng.depth_build_fused(eng.to_device(arr), None, 7, track, want_text=True, want_sums=True, issue=(-1, 2, 7))
         outs.append((track.cpu().numpy(), out["text"].cpu().numpy().tobytes(), out["text_off"], out["sums"],
                      [np.asarray(r) for r in out["runs"]]))
+    # a text buffer that does not start 16-byte aligned (C callers): same bytes
+    import ctypes
+    from gci_amd._lib import BuildOpts
+    for eng in (engine, dense):
+        toff = torch.zeros(len(lengths) + 1, dtype=torch.int64, device=eng.device)
+        o = BuildOpts(); o.flank = 7; o.want_text = 1; o.d_contig_text_off = toff.data_ptr()
+        d_iv = eng.to_device(arr)
+        eng._chk(eng.lib.gci_depth_build_begin(eng.ctx, ctypes.c_void_p(d_iv.data_ptr()), None, len(ivls), ctypes.byref(o)), "begin")
+        total = int(toff[-1].item())
+        for shift in (3, 8, 13):
+            buf = torch.full((total + 64,), 0x55, dtype=torch.uint8, device=eng.device)
+            trk = eng.new_track()
+            eng._chk(eng.lib.gci_depth_build_begin(eng.ctx, ctypes.c_void_p(d_iv.data_ptr()), None, len(ivls), ctypes.byref(o)), "begin")
+            eng._chk(eng.lib.gci_depth_build_finish(eng.ctx, ctypes.c_void_p(trk.data_ptr()), ctypes.c_void_p(buf.data_ptr() + shift), total), "finish")
+            got = buf.cpu().numpy()
+            assert got[shift:shift + total].tobytes() == outs[0][1], shift
+            assert (got[:shift] == 0x55).all() and (got[shift + total:] == 0x55).all(), shift      # nothing outside [0, total)
     a, b = outs
     assert np.array_equal(a[0], b[0]) and a[1] == b[1]
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
