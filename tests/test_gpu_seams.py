@@ -335,6 +335,30 @@ def test_dense_path_equals_event_list_path(engine, monkeypatch):
     assert len(a[1]) > 400_000
 
 
+def test_build_begin_twice_then_finish(engine):
+    """A build that is begun again before it was finished (the wrapper does that when the issue-key buffer was too
+    small) must not see the first attempt's per-tile counters: the table is re-zeroed."""
+    import ctypes
+    from gci_amd._lib import BuildOpts
+    rng = np.random.default_rng(5)
+    lengths = [90_000, 5000]
+    engine.set_layout(lengths)
+    ivls = [(int(c), int(s0), int(s0 + l), 0) for c, s0, l in zip(rng.integers(0, 2, 700), rng.integers(0, 4000, 700), rng.integers(1, 9000, 700))]
+    d_iv = engine.to_device(np.array(ivls, dtype=np.int32))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    want = engine.new_track()
+    engine.depth_build(d_iv, None, 3, want)
+    o = BuildOpts(); o.flank = 3
+    got = engine.new_track()
+    for _ in range(3):
+        engine._chk(engine.lib.gci_depth_build_begin(engine.ctx, p(d_iv), None, len(ivls), ctypes.byref(o)), "begin")
+    engine._chk(engine.lib.gci_depth_build_finish(engine.ctx, p(got), None, 0), "finish")
+    assert torch.equal(got, want) and int(want.sum().item()) > 0
+    again = engine.new_track()
+    engine.depth_build(d_iv, None, 3, again)                 # and the table is clean for the next build
+    assert torch.equal(again, want)
+
+
 def test_cross_rank_name_check_kernels(engine):
     """gci_hash_bucket + gci_hash_conflicts with two simulated ranks on one GPU: unique names -> 0 conflicts;
     a name present on both ranks is found; a repeated name inside ONE rank is not a conflict; overflow counts."""
