@@ -304,3 +304,33 @@ extern "C" int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_
     LAUNCHCHK("k_text_write");
     return GCI_OK;
 }
+
+// ---- N3: window sums for the -p numeric front-end (sliding_window_average_depth, GCI.py:660-705) ----------------
+// The reference walks a contig base by base, restarting its window at every zero-depth base.  Which bases emit a
+// value follows from the zero runs alone (gci_issue_scan_windows with depth == 0) and the window size; what is left
+// for the device is the sum of each window: one wave per [begin, end) range of the track, coalesced 4-byte loads.
+__global__ __launch_bounds__(BLOCK) void k_range_sums(const int32_t* __restrict__ depth, const int64_t* __restrict__ ranges,
+                                                      uint64_t n, long long* __restrict__ sums)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t b = ranges[2 * r], e = ranges[2 * r + 1];
+    long long s = 0;
+    for (int64_t i = b + lane; i < e; i += 64) s += depth[i];
+    s = wave_sum<long long>(s);
+    if (lane == 0) sums[r] = s;
+}
+
+extern "C" int gci_range_sums(gci_ctx* ctx, const int32_t* d_depth, const int64_t* d_ranges, uint64_t n_ranges, int64_t* d_sums)
+{
+    if (!ctx || !d_depth || (n_ranges && (!d_ranges || !d_sums))) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (!n_ranges) return GCI_OK;
+    const uint64_t blocks = (n_ranges + BLOCK / 64 - 1) / (BLOCK / 64);
+    if (blocks > 0x7FFFFFFFull) return GCI_E_INVALID;
+    hipLaunchKernelGGL(k_range_sums, dim3((uint32_t)blocks), dim3(BLOCK), 0, ctx->stream, d_depth, d_ranges, n_ranges,
+                       (long long*)d_sums);
+    LAUNCHCHK("k_range_sums");
+    return GCI_OK;
+}

@@ -298,6 +298,17 @@ class Engine:
         self._chk(self.lib.gci_depth_sum(self.ctx, self._p(track), self._p(sums)), "gci_depth_sum")
         return sums.cpu().numpy()[:len(self.lengths)]
 
+    def range_sums(self, track: torch.Tensor, ranges: np.ndarray) -> np.ndarray:
+        """Sum of the depths in each [begin, end) of track element indices (int64 [n, 2]) -> int64 [n]."""
+        ranges = np.ascontiguousarray(ranges, dtype=np.int64).reshape(-1, 2)
+        n = int(ranges.shape[0])
+        if n == 0:
+            return np.zeros(0, dtype=np.int64)
+        d_r = self.to_device(ranges)
+        sums = torch.empty(n, dtype=torch.int64, device=self.device)
+        self._chk(self.lib.gci_range_sums(self.ctx, self._p(track), self._p(d_r), n, self._p(sums)), "gci_range_sums")
+        return sums.cpu().numpy()
+
     # ---- R10 ---------------------------------------------------------------------------------
     @staticmethod
     def _keys_to_runs(keys: np.ndarray, n_windows: int) -> List[np.ndarray]:

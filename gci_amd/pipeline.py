@@ -499,6 +499,77 @@ def merge_depth(depths: DepthTracks = None, prefix="GCI", threshold=0, flank_len
 
 
 # ==============================================================================================
+# N3: the `-p` numeric front-end
+# ==============================================================================================
+
+def sliding_window_average_depth(depths: DepthTracks, target: str, window_size=50000, max_depth=None, start=0, end=None):
+    """sliding_window_average_depth(depths[target][start:end], window_size, max_depth, start, target) of the
+    reference (GCI.py:660-705) for a track in HBM: -> (positions in Mb: list of float, values: float64 array).
+
+    The reference walks the bases one by one and restarts its window at every zero-depth base.  Which bases emit a
+    value follows from the zero runs and the window size alone, so the device finds the zero runs
+    (gci_issue_scan_windows) and sums the windows (gci_range_sums); the few thousand windows are assembled here."""
+    depths._bind()
+    c = depths.targets.index(target)
+    L = depths.lengths[c]
+    a = _slice_bound(start, L)
+    b = max(a, _slice_bound(L if end is None else end, L))
+    n = b - a
+    if n < window_size:
+        print(f'Warning!!! The length ({n}) of plotting region ({target}:{start}-{start + n}) is less than the window size '
+              f'({window_size}), and therefore the window size will be 1 bp', file=sys.stderr)
+        window_size = 1
+    if n == 0:
+        return [], np.array([], dtype=np.float64)
+    o = depths.engine.offsets[c] + a
+    zero = depths.engine.issue_scan_windows(depths.track, [(o, o + n)], -1, 0)[0].reshape(-1, 2)     # runs of depth 0
+    # the non-zero runs in between
+    edges = np.concatenate([[0], zero.reshape(-1), [n]]).astype(np.int64)
+    p, q = edges[0::2], edges[1::2]
+    keep = q > p
+    p, q = p[keep], q[keep]
+    full = (q - p) // window_size                           # whole windows per run, then one partial flush
+    rem = (q - p) - full * window_size
+    # window k of run r: [p + k w, p + (k + 1) w); emitted at its last base
+    run_of = np.repeat(np.arange(p.shape[0]), full)
+    k = np.arange(int(full.sum()), dtype=np.int64) - np.repeat(np.cumsum(full) - full, full)
+    wb = p[run_of] + k * window_size
+    we = wb + window_size
+    has_rem = rem > 0
+    rb, re_ = (q - rem)[has_rem], q[has_rem]
+    begins = np.concatenate([wb, rb])
+    ends = np.concatenate([we, re_])
+    sums = depths.engine.range_sums(depths.track, np.stack([begins + o, ends + o], axis=1))
+    means = sums.astype(np.float64) / (ends - begins).astype(np.float64)    # int / int, both < 2^53: as Python's true division
+    means = np.where(means > max_depth, np.float64(max_depth), means)
+    zlen = zero[:, 1] - zero[:, 0]
+    zidx = np.repeat(zero[:, 0] - (np.cumsum(zlen) - zlen), zlen) + np.arange(int(zlen.sum()), dtype=np.int64)
+    idx = np.concatenate([ends - 1, zidx])
+    val = np.concatenate([means, np.zeros(zidx.shape[0], dtype=np.float64)])
+    order = np.argsort(idx, kind="stable")
+    idx, val = idx[order], val[order]
+    return ((idx + start) / 1e6).tolist(), val
+
+
+def pre_plot_base(depths_list: Sequence[DepthTracks], max_depths: Sequence[float], window_size=50000, start=0,
+                  region: Optional[Tuple[str, int, int]] = None):
+    """pre_plot_base of the reference (GCI.py:708-739).  region = (target, start, end) is the reference's
+    `{target: depths[start:end]}` input of the regions loop (GCI.py:887-892); None = every contig, whole."""
+    averaged = [{} for _ in depths_list]
+    maxima = [[] for _ in depths_list]
+    targets = [region[0]] if region else depths_list[0].targets
+    for target in targets:
+        for i, tr in enumerate(depths_list):
+            pos, val = sliding_window_average_depth(tr, target, window_size, max_depths[i], region[1] if region else start,
+                                                    region[2] if region else None)
+            averaged[i][target] = (pos, val)
+            maxima[i].append(max(val))
+    y_max = max(maxima[0]) + 10
+    y_min = 0 if len(depths_list) == 1 else max(maxima[1]) + 10
+    return averaged, y_min / (y_max + y_min), y_min, y_max
+
+
+# ==============================================================================================
 # score files
 # ==============================================================================================
 

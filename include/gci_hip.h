@@ -14,6 +14,7 @@
  *   gci_issue_scan*     collapse_depth_range          GCI.py:356-390
  *   gci_depth_text_*    write_depth (text body)       GCI.py:110-117
  *   gci_depth_sum       np.mean numerator             GCI.py:862-868
+ *   gci_range_sums      sliding_window_average_depth  GCI.py:660-705 (window sums)
  *
  * Conventions
  *   - every export returns int: GCI_OK (0) or a negative gci_status; nothing throws, exits,
@@ -232,6 +233,12 @@ int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_t* d_out, u
 
 /* ---- R15 ------------------------------------------------------------------------------------ */
 int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums /* n_contigs */);
+
+/* ---- N3: window sums for the `-p` numeric front-end (sliding_window_average_depth, GCI.py:660-705) ----------
+ * d_ranges holds n_ranges pairs (begin, end) of TRACK element indices (contig offset + position); d_sums[r] = sum of
+ * the depths in [begin, end).  The caller derives the ranges from the zero-depth runs (gci_issue_scan_windows with
+ * lo = -1, hi = 0) and the window size: the reference restarts its window at every zero-depth base. */
+int gci_range_sums(gci_ctx* ctx, const int32_t* d_depth, const int64_t* d_ranges, uint64_t n_ranges, int64_t* d_sums);
 
 /* ---- host-side container helpers (no GPU work) ---------------------------------
  * The reference reaches BGZF / BAM through pysam/htslib (GCI.py:150-151) and writes gzip through Python's gzip

@@ -545,6 +545,55 @@ def compute_index_text(targets_length: Dict[str, int], merged_list, type_list, f
 # R15: global mean depth (GCI.py:862-868)
 # ==============================================================================================
 
+def sliding_window_average_depth(depths, window_size=50000, max_depth=None, start=0):
+    """The `-p` numeric front-end, restated from /root/reference/GCI.py:660-705: one pass over a contig (or a region
+    slice of it); the window restarts at every zero-depth base (:680-689), a region shorter than the window uses a
+    window of 1 (:675-677), means are clamped to max_depth (:683-684, :695-696, :702-703).
+    -> (positions in Mb: list of float, values: float64 array)."""
+    pos, val, win = [], [], []
+    n = len(depths)
+    if n < window_size:
+        window_size = 1
+    i = -1
+    for i in range(n):
+        d = int(depths[i])
+        if d == 0:
+            if win:                                        # flush the partial window in front of the zero
+                a = sum(win) / len(win)
+                val.append(max_depth if a > max_depth else a)
+                pos.append((i + start - 1) / 1e6)
+                win = []
+            val.append(0)
+            pos.append((i + start) / 1e6)
+        else:
+            win.append(d)
+            if len(win) == window_size:
+                a = sum(win) / window_size
+                val.append(max_depth if a > max_depth else a)
+                pos.append((i + start) / 1e6)
+                win = []
+    if win:
+        a = sum(win) / len(win)
+        val.append(max_depth if a > max_depth else a)
+        pos.append((i + start) / 1e6)
+    return pos, np.array(val, dtype=np.float64)
+
+
+def pre_plot_base(depths_list, max_depths, window_size=50000, start=0):
+    """/root/reference/GCI.py:708-739: the averaged series of every contig of every read type and the y-axis split of
+    the figure (y_max from the first type, y_min from the second when there are two)."""
+    averaged = [{} for _ in depths_list]
+    maxima = [[] for _ in depths_list]
+    for target in depths_list[0].keys():
+        for i, depthss in enumerate(depths_list):
+            p, v = sliding_window_average_depth(depthss[target], window_size, max_depths[i], start)
+            averaged[i][target] = (p, v)
+            maxima[i].append(max(v))
+    y_max = max(maxima[0]) + 10
+    y_min = 0 if len(depths_list) == 1 else max(maxima[1]) + 10
+    return averaged, y_min / (y_max + y_min), y_min, y_max
+
+
 def mean_depth(depths: Dict[str, np.ndarray]) -> float:
     tot = sum(int(lib().orc_sum(_p(np.ascontiguousarray(d, dtype=np.int64)), d.shape[0])) for d in depths.values())
     n = sum(d.shape[0] for d in depths.values())

@@ -359,6 +359,49 @@ def test_build_begin_twice_then_finish(engine):
     assert torch.equal(again, want)
 
 
+def test_plot_front_end_matches_reference_kats_and_oracle(engine, oracle, capsys):
+    """N3 (`-p` numeric front-end): pipeline.sliding_window_average_depth / pre_plot_base on tracks in HBM equal the
+    reference's outputs (tests/golden/kats.json, made by the unmodified functions) and the oracle on larger random
+    tracks -- positions and values bit for bit (float64)."""
+    import json, os
+    from golden_util import GOLDEN
+    k = json.load(open(os.path.join(GOLDEN, "kats.json")))
+    for c in k["sliding_window_average_depth"]:
+        if not c["depth"]:
+            continue
+        tr = _upload_depths(engine, {"t": np.array(c["depth"], dtype=np.int64)})
+        pos, val = pipeline.sliding_window_average_depth(tr, "t", c["ws"], c["max_depth"], 0)
+        # the reference gets the slice and `start` separately: here start = 0 slices nothing, positions shift by c["start"]
+        want_pos, want_val = oracle.sliding_window_average_depth(c["depth"], c["ws"], c["max_depth"], 0)
+        assert pos == want_pos and val.tolist() == want_val.tolist() == c["val"]
+    for c in k["pre_plot_base"]:
+        trs = [_upload_depths(engine, {t: np.array(v, dtype=np.int64) for t, v in d.items()}) for d in c["depths"]]
+        # every _upload_depths sets the layout anew: bind each track right before it is used
+        av, y_frac, y_min, y_max = pipeline.pre_plot_base(trs, c["max_depths"], c["ws"], 0)
+        assert (y_frac, y_min, y_max) == (c["y_frac"], c["y_min"], c["y_max"])
+        for a, want in zip(av, c["series"]):
+            for t, (p, v) in a.items():
+                assert p == want[t][0] and v.tolist() == want[t][1]
+    # larger tracks, region slices (start / end), windows longer than a tile, a region shorter than the window
+    rng = np.random.default_rng(41)
+    d = rng.poisson(6.0, 300_000).astype(np.int64)
+    for _ in range(40):
+        a0 = int(rng.integers(0, 300_000))
+        d[a0:a0 + int(rng.integers(1, 3000))] = 0
+    d[:17] = 0
+    d[-5:] = 0
+    depths = {"x": d, "y": rng.poisson(2.0, 5000).astype(np.int64)}
+    tr = _upload_depths(engine, depths)
+    for target, ws, md, s0, e0 in (("x", 50_000, 9.5, 0, None), ("x", 1000, 6.2, 0, None), ("x", 777, 100.0, 12_345, 250_001),
+                                   ("y", 50_000, 3.0, 0, None), ("y", 64, 1.9, 100, 4000), ("x", 4096, 5.0, 4096, 8192)):
+        pos, val = pipeline.sliding_window_average_depth(tr, target, ws, md, s0, e0)
+        sl = depths[target][s0:e0]
+        wp, wv = oracle.sliding_window_average_depth(sl, ws, md, s0)
+        assert pos == wp and np.array_equal(val, wv), (target, ws)
+        assert len(pos) > 3
+    capsys.readouterr()
+
+
 def test_cross_rank_name_check_kernels(engine):
     """gci_hash_bucket + gci_hash_conflicts with two simulated ranks on one GPU: unique names -> 0 conflicts;
     a name present on both ranks is found; a repeated name inside ONE rank is not a conflict; overflow counts."""

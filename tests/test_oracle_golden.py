@@ -87,3 +87,14 @@ def test_oracle_kats(oracle):
         assert list(oracle._merge_blocks(alns, 3, 4)) == c["t"]
     for c in k["score_repr"]:
         assert repr(oracle._score(c["obs_n50"], c["exp_n50"], c["obs_n"], c["exp_n"])) == c["out"]
+    # N3: the -p numeric front-end
+    for c in k["sliding_window_average_depth"]:
+        pos, val = oracle.sliding_window_average_depth(c["depth"], c["ws"], c["max_depth"], c["start"])
+        assert pos == c["pos"] and val.tolist() == c["val"]
+    for c in k["pre_plot_base"]:
+        dl = [{t: np.array(v) for t, v in d.items()} for d in c["depths"]]
+        av, y_frac, y_min, y_max = oracle.pre_plot_base(dl, c["max_depths"], c["ws"], 0)
+        assert (y_frac, y_min, y_max) == (c["y_frac"], c["y_min"], c["y_max"])
+        for a, want in zip(av, c["series"]):
+            for t, (p, v) in a.items():
+                assert p == want[t][0] and v.tolist() == want[t][1]

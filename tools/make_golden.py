@@ -256,6 +256,41 @@ def make_kats():
                        out=repr(0 if on == 0 else round(100 * log2(on50 / en50 + 1) / log2(on / en + 1), 4))))
     kats["score_repr"] = sc
 
+    # N3 the -p numeric front-end: sliding_window_average_depth / pre_plot_base (own generator: the cases above keep
+    # their random inputs)
+    rng3 = np.random.default_rng(20250928)
+    sw = []
+    fixed = [([3, 3, 0, 0, 2, 2, 2, 2, 2, 0, 1], 2, 10.0, 0), ([0] * 6, 2, 5.0, 3), ([4] * 10, 3, 3.5, 0), ([4] * 9, 3, 100.0, 1000),
+             ([], 5, 1.0, 0), ([7], 1, 2.0, 0), ([1, 2, 3], 5, 10.0, 40), ([5, 0, 5, 0, 5], 1, 4.0, 0), ([2, 4, 6, 8, 0], 4, 4.9, 9)]
+    for d, ws, md, st in fixed:
+        sw.append(dict(depth=d, ws=ws, max_depth=md, start=st))
+    for _ in range(40):
+        L = int(rng3.integers(1, 400))
+        d = rng3.poisson(rng3.uniform(0.3, 6.0), L)
+        for _z in range(int(rng3.integers(0, 4))):
+            a = int(rng3.integers(0, L))
+            d[a:a + int(rng3.integers(1, 30))] = 0
+        sw.append(dict(depth=d.tolist(), ws=int(rng3.integers(1, 60)), max_depth=float(rng3.uniform(0.5, 8.0)),
+                       start=int(rng3.integers(0, 10_000_000))))
+    for c in sw:
+        with contextlib.redirect_stderr(io.StringIO()):
+            pos, val = ref.sliding_window_average_depth(list(c["depth"]), c["ws"], c["max_depth"], c["start"], "t")
+        c["pos"], c["val"] = [float(x) for x in pos], [float(x) for x in val]
+    kats["sliding_window_average_depth"] = sw
+    pp = []
+    for n_types in (1, 2):
+        for _ in range(6):
+            targets = {"a": int(rng3.integers(30, 300)), "b": int(rng3.integers(30, 300))}
+            dl = [{t: rng3.poisson(3.0 + 2 * i, L) for t, L in targets.items()} for i in range(n_types)]
+            md = [float(rng3.uniform(3, 12)) for _ in range(n_types)]
+            ws = int(rng3.integers(2, 25))
+            with contextlib.redirect_stderr(io.StringIO()):
+                av, y_frac, y_min, y_max = ref.pre_plot_base(dl, md, ws, 0)
+            pp.append(dict(depths=[{t: v.tolist() for t, v in d.items()} for d in dl], max_depths=md, ws=ws,
+                           y_frac=float(y_frac), y_min=float(y_min), y_max=float(y_max),
+                           series=[{t: ([float(x) for x in p], [float(x) for x in v]) for t, (p, v) in a.items()} for a in av]))
+    kats["pre_plot_base"] = pp
+
     with open(os.path.join(GOLDEN, "kats.json"), "w") as f:
         json.dump(kats, f, indent=0, sort_keys=True, default=lambda o: o.tolist() if hasattr(o, "tolist") else list(o))
     print("kats.json written")
