@@ -1,8 +1,8 @@
 """Drop-in command line: the flags, defaults, validation order, messages and output files of
 /root/reference/GCI.py:897-1113, driving the HIP path in gci_amd/pipeline.py.
 
-Not carried over: `-p/--plot` (matplotlib figures are outside the hot path);
-the flag is accepted and reports that plotting is not part of this build.
+`-p/--plot`: the numbers of the figures come from the GPU (gci_amd/plot.py), the drawing
+is matplotlib on the host as in the reference.
 """
 from __future__ import annotations
 
@@ -11,6 +11,7 @@ import os
 import sys
 
 from . import pipeline
+from .plot import plot_depth
 from .formats import bam as bamfmt
 from .formats import fasta
 
@@ -48,8 +49,14 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         sys.exit(f'ERROR!!! The prefix "{prefix}" is not allowed')
 
     if plot == True:  # noqa: E712
-        print("Warning!!! `-p/--plot` is not part of this build (plotting is outside the GPU hot path); "
-              "use the reference's utility/plot_depth.py on the .depth.gz written here", file=sys.stderr)
+        if os.path.exists(f"{directory}/images"):
+            if not os.access(f"{directory}/images", os.R_OK):
+                sys.exit(f'ERROR!!! The path "{directory}/images" is unable to read')
+            if not os.access(f"{directory}/images", os.W_OK):
+                sys.exit(f'ERROR!!! The path "{directory}/images" is unable to write')
+        else:
+            os.makedirs(f"{directory}/images")
+        image_type = image_type.lower()
 
     ref_refs = fasta.record_ids(reference)
     if len(chrs_list) > 0:
@@ -105,6 +112,9 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         bed = pipeline.merge_depth(depths, prefix, threshold, flank_len, directory, force, "HiFi")
         pipeline.compute_index(targets_length, prefix, directory, force, [bed], ["HiFi"], flank_len, dist_percent,
                                regions_bed, [depths], threshold, chrs_list)
+        if plot == True:  # noqa: E712
+            plot_depth([depths], depth_min, depth_max, window_size, image_type, directory, prefix, force, targets_length,
+                       dist_percent, regions_bed, threshold)
     elif hifi == None:  # noqa: E711
         depths, targets_length = pipeline.filter(nano_paf, nano_bam, prefix, *common, "ONT", chrs_list, threads,
                                                  issue_hint=hint)
@@ -112,6 +122,9 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         bed = pipeline.merge_depth(depths, prefix, threshold, flank_len, directory, force, "ONT")
         pipeline.compute_index(targets_length, prefix, directory, force, [bed], ["Nano"], flank_len, dist_percent,
                                regions_bed, [depths], threshold, chrs_list)
+        if plot == True:  # noqa: E712
+            plot_depth([depths], depth_min, depth_max, window_size, image_type, directory, prefix, force, targets_length,
+                       dist_percent, regions_bed, threshold)
     else:
         if set(hifi_refs_lengths.keys()) != set(nano_refs_lengths.keys()):
             sys.exit('ERROR!!! The targets in hifi and nano alignment files are inconsistent\n'
@@ -135,6 +148,9 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         pipeline.compute_index(targets_length, prefix, directory, force, [hb, nb, tb], ["HiFi", "Nano", "HiFi + Nano"],
                                flank_len, dist_percent, regions_bed, [hifi_depths, nano_depths, two], threshold,
                                chrs_list)
+        if plot == True:  # noqa: E712
+            plot_depth([hifi_depths, nano_depths], depth_min, depth_max, window_size, image_type, directory, prefix, force,
+                       targets_length, dist_percent, regions_bed, threshold)
     print("GCI finished!!!\nBye!!!")
 
 

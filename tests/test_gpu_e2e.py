@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, GOLDEN, cli_args, expected, read_outputs
+from golden_util import CASES, GOLDEN, cli_args, expected, images, read_outputs
 from gci_amd import pipeline, synth
 from gci_amd._lib import GciError
 from gci_amd.device import JoinInput, REC_DTYPE
@@ -27,6 +27,11 @@ def test_cli_reproduces_reference_files(engine, case, tmp_path, capsys):
     assert sorted(got) == sorted(want)
     for fn in want:
         assert got[fn] == want[fn], fn
+    # -p: the figures, pixel for pixel (the numbers come from the GPU, the drawing is matplotlib as in the reference)
+    got_img, want_img = images(out), images(os.path.join(GOLDEN, case, "expected"))
+    assert sorted(got_img) == sorted(want_img)
+    for fn in want_img:
+        assert got_img[fn].shape == want_img[fn].shape and np.array_equal(got_img[fn], want_img[fn]), fn
     stdout = capsys.readouterr().out
     assert stdout.rstrip().endswith("GCI finished!!!\nBye!!!")
     # refuses to overwrite without -f, like the reference

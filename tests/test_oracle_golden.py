@@ -40,6 +40,8 @@ def test_oracle_reproduces_reference_outputs(oracle, case):
             regions.setdefault(t, []).append((int(s), int(e)))
     a = dict(m["args"])
     chrs = a.pop("chrs", None)
+    for k in ("plot", "window_size", "depth_min", "depth_max"):      # -p: the figures are checked in tests/test_plot.py
+        a.pop(k, None)
     got = oracle.run_path(hifi=_kind(case, m["hifi"]), nano=_kind(case, m["nano"]), references=hdr.references,
                           lengths=hdr.lengths, ns_bed=ns_bed or None, chrs_list=chrs.split(",") if chrs else (),
                           regions_bed=regions, **a)

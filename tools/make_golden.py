@@ -83,6 +83,11 @@ def run_reference(case, args, hifi=None, nano=None, regions=False):
         else:
             shutil.copy(src, os.path.join(exp, fn))
             manifest["files"][fn] = {"sha256": hashlib.sha256(open(src, "rb").read()).hexdigest()}
+    if os.path.isdir(os.path.join(tmp, "images")):              # -p: the figures
+        os.makedirs(os.path.join(exp, "images"))
+        for fn in sorted(os.listdir(os.path.join(tmp, "images"))):
+            shutil.copy(os.path.join(tmp, "images", fn), os.path.join(exp, "images", fn))
+            manifest["files"]["images/" + fn] = {"sha256": hashlib.sha256(open(os.path.join(tmp, "images", fn), "rb").read()).hexdigest()}
     with open(os.path.join(case_dir, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     shutil.rmtree(tmp)
@@ -296,6 +301,53 @@ def make_kats():
     print("kats.json written")
 
 
+def case_cli_plot():
+    """The whole command line with -p: two read types, two contigs, two regions, 500-base windows."""
+    contigs = (("ctgP", 60_000), ("ctgQ", 24_000))
+    gaps = {"ctgP": [(30_000, 30_300)]}
+    h = synth.simulate_reads(contigs, 28, "hifi", seed=synth.seed_for(6, 0))
+    n = synth.simulate_reads(contigs, 22, "ont", seed=synth.seed_for(6, 1), long_cigar_frac=0.0)
+    regions = [("ctgP", 8000, 12_000), ("ctgQ", 0, 24_000)]
+    write_inputs(os.path.join(GOLDEN, "c6_plot"), contigs, {"hifi.mm2.bam": h, "ont.mm2.bam": n}, gaps=gaps, regions=regions)
+    os.makedirs(os.path.join(tempfile.gettempdir(), "gci_plot_tmp"), exist_ok=True)
+    run_reference("c6_plot", {"plot": True, "window_size": 500, "depth_min": 0.2, "depth_max": 3.0},
+                  hifi=["hifi.mm2.bam"], nano=["ont.mm2.bam"], regions=True)
+
+
+def case_plot():
+    """N3 end to end: the figures the reference's plot_base draws for a small one-type and a small two-type input
+    (tests/golden/plot/*.png) together with the depth arrays they were drawn from (inputs.npz)."""
+    ref = load_reference.load()
+    out = os.path.join(GOLDEN, "plot")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(os.path.join(out, "images"))
+    rng = np.random.default_rng(20250929)
+    L = 60_000
+    h = rng.poisson(30, L)
+    n = rng.poisson(22, L)
+    for d in (h, n):
+        d[:15] = 0
+        d[-15:] = 0
+    h[9_000:9_700] = 0; h[20_000:20_400] = rng.integers(1, 3, 400); h[41_000:41_050] = 0
+    n[9_200:9_500] = 0; n[50_000:52_000] = rng.integers(0, 2, 2000)
+    np.savez_compressed(os.path.join(out, "inputs.npz"), hifi=h.astype(np.int32), nano=n.astype(np.int32))
+    meta = {}
+    for name, dl in (("one", [{"ctgP": h}]), ("two", [{"ctgP": h}, {"ctgP": n}])):
+        means = [float(np.mean(d["ctgP"])) for d in dl]
+        maxd = [m * 4.0 for m in means]
+        with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+            av, y_frac, y_min, y_max = ref.pre_plot_base(dl, maxd, 500, 0)
+            ref.plot_base(dl, "ctgP", av, means, y_frac, 0, 0.1, 0.005, y_min, y_max, "png", out, name, L, False, 0)
+            ref.pre_plot_base([{"ctgP": d["ctgP"][8000:12000]} for d in dl], maxd, 500, 8000)
+            av2, y_frac2, y_min2, y_max2 = ref.pre_plot_base([{"ctgP": d["ctgP"][8000:12000]} for d in dl], maxd, 500, 8000)
+            ref.plot_base([{"ctgP": d["ctgP"][8000:12000]} for d in dl], "ctgP", av2, means, y_frac2, 8000, 0.1, 0.005, y_min2,
+                          y_max2, "png", out, name, 12000, True, 0)
+        meta[name] = dict(means=means, y=[float(y_frac), float(y_min), float(y_max)], y_region=[float(y_frac2), float(y_min2), float(y_max2)])
+    with open(os.path.join(out, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("plot ->", sorted(os.listdir(os.path.join(out, "images"))))
+
+
 def copy_reference_example():
     """The reference's own data triple (example/MH63.*) -- data files, not source."""
     dst = os.path.join(GOLDEN, "MH63")
@@ -312,7 +364,7 @@ if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
     todo = [("c1", case_single_bam), ("c3a", case_two_bam), ("c3b", case_three_bam_chrs), ("c4a", case_paf_bam),
-            ("c4b", case_nano_only_long_cigar), ("c4c", case_two_paf), ("c5", case_two_type), ("kats", make_kats),
+            ("c4b", case_nano_only_long_cigar), ("c4c", case_two_paf), ("plot", case_plot), ("c6", case_cli_plot), ("c5", case_two_type), ("kats", make_kats),
             ("mh63", copy_reference_example)]
     for name, fn in todo:
         if not only or name in only:
