@@ -334,3 +334,64 @@ extern "C" int gci_range_sums(gci_ctx* ctx, const int32_t* d_depth, const int64_
     LAUNCHCHK("k_range_sums");
     return GCI_OK;
 }
+
+// ---- N4 (first half): N runs of the assembly (get_Ns_ref, GCI.py:27-35) ---------------------------------------------
+// The FASTA bytes go to the device as they are in the file.  Sequence coordinates do not count line ends, carriage
+// returns and blanks (Bio.SeqIO's reader), and runs do not cross records.  One pass over the bytes: every workgroup
+// counts the bytes of its 4096-byte tile that do count (the host's prefix sum over tiles turns a byte offset into a
+// sequence coordinate) and emits the byte offsets where a run of N / n begins or ends; "the base before this one" is
+// found by stepping back over dropped bytes (a line end or two), never beyond the start of the record's body.
+__device__ __forceinline__ bool fasta_dropped(uint8_t c) { return c == '\n' || c == '\r' || c == ' '; }
+__device__ __forceinline__ bool fasta_is_n(uint8_t c) { return c == 'N' || c == 'n'; }
+
+__global__ __launch_bounds__(BLOCK) void k_fasta_n_scan(const uint8_t* __restrict__ text, uint64_t n_bytes,
+                                                        const int64_t* __restrict__ body, uint32_t n_records,
+                                                        uint32_t* __restrict__ tile_kept, unsigned long long* __restrict__ keys,
+                                                        uint32_t cap, uint32_t* __restrict__ n_keys)
+{
+    __shared__ uint32_t part[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    // the last record whose body begins at or before this tile's end (bodies are sorted and disjoint)
+    uint32_t lo = 0, hi = n_records;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)body[2 * mid] < tile0 + TILE) lo = mid + 1; else hi = mid; }
+    int64_t r = (int64_t)lo - 1;                                   // candidate record for the bytes of this tile
+    uint32_t kept = 0;
+    for (uint32_t k = 0; k < TILE / BLOCK; k++) {
+        const uint64_t i = tile0 + (uint64_t)k * BLOCK + t;
+        if (i >= n_bytes) break;
+        // the record whose body holds byte i: step back from the candidate (a tile rarely meets more than one)
+        int64_t rr = r;
+        while (rr >= 0 && (uint64_t)body[2 * rr] > i) rr--;
+        if (rr < 0 || i >= (uint64_t)body[2 * rr + 1]) continue;   // title line or in front of the first record
+        const uint8_t c = text[i];
+        if (fasta_dropped(c)) continue;
+        kept++;
+        const uint64_t b0 = (uint64_t)body[2 * rr];
+        bool prev_n = false;
+        for (uint64_t j = i; j > b0;) { const uint8_t p = text[--j]; if (!fasta_dropped(p)) { prev_n = fasta_is_n(p); break; } }
+        const bool cur_n = fasta_is_n(c);
+        if (cur_n != prev_n) {
+            const uint32_t slot = atomicAdd(n_keys, 1u);
+            if (slot < cap) keys[slot] = ((unsigned long long)i << 1) | (cur_n ? 0ull : 1ull);    // low bit: the run ended before i
+        }
+    }
+    kept = wave_sum<uint32_t>(kept);
+    if (lane == 0) part[wave] = kept;
+    __syncthreads();
+    if (t == 0) tile_kept[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+extern "C" int gci_fasta_n_scan(gci_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const int64_t* d_body, uint32_t n_records,
+                                uint32_t* d_tile_kept, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys)
+{
+    if (!ctx || !d_n_keys || (n_bytes && (!d_text || !d_tile_kept)) || (n_records && !d_body) || (cap && !d_keys)) return GCI_E_INVALID;
+    HIPCHK(hipMemsetAsync(d_n_keys, 0, 4, ctx->stream));
+    if (!n_bytes) return GCI_OK;
+    const uint64_t tiles = (n_bytes + TILE - 1) / TILE;
+    if (tiles > 0x7FFFFFFFull) return GCI_E_INVALID;
+    hipLaunchKernelGGL(k_fasta_n_scan, dim3((uint32_t)tiles), dim3(BLOCK), 0, ctx->stream, d_text, n_bytes, d_body, n_records,
+                       d_tile_kept, (unsigned long long*)d_keys, cap, d_n_keys);
+    LAUNCHCHK("k_fasta_n_scan");
+    return GCI_OK;
+}

@@ -298,6 +298,25 @@ class Engine:
         self._chk(self.lib.gci_depth_sum(self.ctx, self._p(track), self._p(sums)), "gci_depth_sum")
         return sums.cpu().numpy()[:len(self.lengths)]
 
+    def fasta_n_scan(self, text: np.ndarray, bodies: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """gci_fasta_n_scan over the bytes of a FASTA file: bodies = int64 [n_records, 2] byte ranges of the record
+        bodies -> (uint32 kept-byte count per 4096-byte tile, sorted uint64 keys (offset << 1 | is_end))."""
+        n = int(text.shape[0])
+        d_text = self.to_device(text)
+        d_body = self.to_device(np.ascontiguousarray(bodies, dtype=np.int64).reshape(-1, 2))
+        tiles = (n + 4095) // 4096
+        kept = torch.zeros(max(tiles, 1), dtype=torch.int32, device=self.device)
+        cap = 1 << 16
+        while True:
+            keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            self._chk(self.lib.gci_fasta_n_scan(self.ctx, self._p(d_text), n, self._p(d_body), int(bodies.shape[0]), self._p(kept),
+                                                self._p(keys), cap, self._p(self._count)), "gci_fasta_n_scan")
+            nk = int(self._count.item())
+            if nk <= cap:
+                break
+            cap = nk
+        return kept.cpu().numpy().view(np.uint32)[:tiles], np.sort(keys[:nk].cpu().numpy().view(np.uint64))
+
     def range_sums(self, track: torch.Tensor, ranges: np.ndarray) -> np.ndarray:
         """Sum of the depths in each [begin, end) of track element indices (int64 [n, 2]) -> int64 [n]."""
         ranges = np.ascontiguousarray(ranges, dtype=np.int64).reshape(-1, 2)

@@ -74,6 +74,63 @@ def n_runs(path: str) -> Tuple[List[str], Dict[str, List[Tuple[int, int]]]]:
     return ids, runs
 
 
+def record_spans(buf: np.ndarray) -> List[Tuple[str, int, int]]:
+    """[(id, body begin, body end)] byte offsets of every record, in file order: the body runs from behind the title
+    line to the next title line (or the end of the file)."""
+    n = int(buf.shape[0])
+    gt = np.flatnonzero(buf == ord(">"))
+    starts = [int(p) for p in gt if p == 0 or buf[p - 1] == 10]
+    out = []
+    for k, hs in enumerate(starts):
+        stop = starts[k + 1] if k + 1 < len(starts) else n
+        nl = np.flatnonzero(buf[hs:stop] == 10)
+        he = hs + int(nl[0]) if nl.shape[0] else stop
+        parts = bytes(buf[hs + 1:he]).decode(errors="replace").rstrip().split(None, 1)
+        out.append((parts[0] if parts else "", min(he + 1, stop), stop))
+    return out
+
+
+def n_runs_device(engine, path: str) -> Tuple[List[str], Dict[str, List[Tuple[int, int]]]]:
+    """n_runs() with the scan on the GPU (gci_fasta_n_scan): the file's bytes are uploaded as they are; the device
+    returns the byte offsets where runs of N / n begin and end and how many bytes of every 4096-byte tile count as
+    sequence; the handful of offsets is turned into sequence coordinates here."""
+    buf = load(path)
+    spans = record_spans(buf)
+    ids = [rid for rid, _, _ in spans]
+    if not spans:
+        return ids, {}
+    bodies = np.array([(b, e) for _, b, e in spans], dtype=np.int64)
+    kept, keys = engine.fasta_n_scan(buf, bodies)
+    before_tile = np.concatenate(([0], np.cumsum(kept, dtype=np.int64)))
+
+    def coord(off: int, r: int) -> int:
+        """sequence bytes of the file in front of byte `off` (which lies in, or at the end of, the body of record r)"""
+        t0 = (off // 4096) * 4096
+        c = int(before_tile[off // 4096])
+        lo = t0
+        # the part of the tile in front of `off`: only bytes inside record bodies count
+        q = r
+        while q >= 0 and bodies[q, 1] > lo:
+            a, b = max(int(bodies[q, 0]), lo), min(int(bodies[q, 1]), off)
+            if b > a:
+                c += int(np.count_nonzero(~_DROP[buf[a:b]]))
+            q -= 1
+        return c
+
+    runs: Dict[str, List[Tuple[int, int]]] = {}
+    rec_of = np.searchsorted(bodies[:, 0], (keys >> np.uint64(1)).astype(np.int64), side="right") - 1
+    for r, (rid, b, e) in enumerate(spans):
+        mine = keys[rec_of == r]
+        if mine.shape[0] == 0:
+            continue
+        base = coord(b, r)
+        pos = [coord(int(k >> np.uint64(1)), r) - base for k in mine]
+        if len(pos) & 1:                                   # the run reaches the end of the record
+            pos.append(coord(e, r) - base)
+        runs.setdefault(rid, []).extend((pos[i], pos[i + 1]) for i in range(0, len(pos), 2))
+    return ids, runs
+
+
 def write(path: str, records: List[Tuple[str, bytes]], width: int = 60) -> None:
     with open(path, "wb") as f:
         for rid, seq in records:

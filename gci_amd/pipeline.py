@@ -102,7 +102,7 @@ class DepthTracks:
 # ==============================================================================================
 
 def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
-    _, ns_bed = fasta.n_runs(reference)
+    _, ns_bed = fasta.n_runs_device(default_engine(), reference)          # N4: the scan itself runs on the GPU
     if len(ns_bed) > 0:
         path = f"{directory}/{prefix}.gaps.bed"
         if os.path.exists(path) and force == False:  # noqa: E712

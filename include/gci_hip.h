@@ -15,6 +15,7 @@
  *   gci_depth_text_*    write_depth (text body)       GCI.py:110-117
  *   gci_depth_sum       np.mean numerator             GCI.py:862-868
  *   gci_range_sums      sliding_window_average_depth  GCI.py:660-705 (window sums)
+ *   gci_fasta_n_scan    get_Ns_ref                    GCI.py:27-35
  *
  * Conventions
  *   - every export returns int: GCI_OK (0) or a negative gci_status; nothing throws, exits,
@@ -239,6 +240,16 @@ int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums /* n_con
  * the depths in [begin, end).  The caller derives the ranges from the zero-depth runs (gci_issue_scan_windows with
  * lo = -1, hi = 0) and the window size: the reference restarts its window at every zero-depth base. */
 int gci_range_sums(gci_ctx* ctx, const int32_t* d_depth, const int64_t* d_ranges, uint64_t n_ranges, int64_t* d_sums);
+
+/* ---- N4 (first half): N runs of the assembly, get_Ns_ref (GCI.py:27-35) ------------------------------------------
+ * d_text: the FASTA file's bytes.  d_body: n_records pairs (begin, end) of byte offsets, the body of every record
+ * (behind its title line, up to the next '>' line), sorted.  Output: d_tile_kept[k] = bytes of the 4096-byte tile k
+ * that count as sequence (not a line end, '\r' or blank, not in a title line), and keys = (byte offset << 1) | e for
+ * every base where a run of N / n begins (e = 0) or that follows the last base of a run (e = 1); *d_n_keys may exceed
+ * cap (nothing is written beyond it: call again with more room).  A run that reaches the end of a record has no end
+ * key.  The host turns byte offsets into sequence coordinates with the prefix sum of d_tile_kept. */
+int gci_fasta_n_scan(gci_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const int64_t* d_body, uint32_t n_records,
+                     uint32_t* d_tile_kept, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys);
 
 /* ---- host-side container helpers (no GPU work) ---------------------------------
  * The reference reaches BGZF / BAM through pysam/htslib (GCI.py:150-151) and writes gzip through Python's gzip

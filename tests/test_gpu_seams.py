@@ -402,6 +402,53 @@ def test_plot_front_end_matches_reference_kats_and_oracle(engine, oracle, capsys
     capsys.readouterr()
 
 
+def test_fasta_n_runs_on_gpu(engine, oracle, tmp_path):
+    """N4 (first half): get_Ns_ref's scan on the GPU equals the host parser and the oracle's regex on awkward files:
+    CRLF, blank lines, lower-case n, runs at record starts / ends and across line ends and tile boundaries, records
+    that end and begin with N, '>' inside a title, empty records, no final newline, a repeated id."""
+    from gci_amd.formats import fasta
+    rng = np.random.default_rng(3)
+
+    def seq(n, p_n=0.02):
+        s = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), n)
+        for _ in range(max(1, int(n * p_n / 50))):
+            a = int(rng.integers(0, n))
+            s[a:a + int(rng.integers(1, 200))] = rng.choice(np.frombuffer(b"Nn", dtype=np.uint8))
+        return s.tobytes()
+
+    recs = [("chrA desc > with gt", b"NNN" + seq(20_000) + b"nn"), ("chrB", b"N" + seq(9_000) + b"N"), ("empty", b""),
+            ("chrC", seq(4096 * 3, 0.2)), ("onlyN", b"N" * 5000), ("chrA", seq(300)), ("tail", seq(777))]
+    cases = {}
+    for name, width, eol in (("lf60", 60, b"\n"), ("crlf70", 70, b"\r\n"), ("w4096", 4096, b"\n"), ("w1", 1, b"\n")):
+        out = bytearray()
+        for rid, sq in recs:
+            out += b">" + rid.encode() + eol
+            for i in range(0, len(sq), width):
+                out += sq[i:i + width] + eol
+                if rng.random() < 0.01:
+                    out += eol                                  # a blank line inside the record
+        cases[name] = bytes(out)
+    cases["no_final_newline"] = cases["lf60"].rstrip(b"\n")
+    cases["blanks"] = cases["lf60"].replace(b"AC", b"A C", 50)
+    cases["one_line"] = b">x\nNNACGTNNNN"
+    cases["no_records"] = b"just text\n"
+    cases["empty_file"] = b""
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".fa"))
+        open(p, "wb").write(data)
+        ids_h, runs_h = fasta.n_runs(p)
+        ids_d, runs_d = fasta.n_runs_device(engine, p)
+        assert ids_d == ids_h and runs_d == runs_h and list(runs_d) == list(runs_h), name
+        if name in ("lf60", "crlf70"):                         # and the reference's regex on the assembled strings
+            want = {}
+            for rid, sq in recs:
+                r = oracle.n_runs_of(sq.decode())
+                if r:
+                    want.setdefault(rid.split()[0], []).extend(r)
+            assert runs_d == want, name
+    assert sum(len(v) for v in fasta.n_runs_device(engine, str(tmp_path / "lf60.fa"))[1].values()) > 20
+
+
 def test_cross_rank_name_check_kernels(engine):
     """gci_hash_bucket + gci_hash_conflicts with two simulated ranks on one GPU: unique names -> 0 conflicts;
     a name present on both ranks is found; a repeated name inside ONE rank is not a conflict; overflow counts."""
