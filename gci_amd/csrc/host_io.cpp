@@ -232,3 +232,208 @@ extern "C" int gci_gzip_members(const uint8_t* h_text, uint64_t n, uint64_t chun
     *n_out = total;
     return GCI_OK;
 }
+
+// ---- N4 (second half, host): the PAF filter (filter(), GCI.py:211-254) in native code -----------------------------------
+// Same arithmetic in the same order as the reference: identity = nmatch / alnlen (IEEE double), blocks accumulate per
+// (query, target) in file order and ACROSS files (the reference creates its table once, outside the per-file loop), per
+// query the target with the largest (mean identity * covered / qlen, target name) wins, its interval is the longest
+// merged target block (leftmost on ties).  Output per file: one compact record + name per query seen so far, in first-
+// appearance order -- what gci_name_join takes.
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+
+namespace {
+
+struct PafAln { int64_t qlen, qs, qe, ts, te; double identity; };
+struct PafTarget { int32_t t; std::vector<PafAln> alns; };
+struct PafQuery { std::string name; std::vector<PafTarget> targets; bool hq = false; };
+struct PafEmit { uint32_t query; int32_t target; int64_t s, e, qlen; };
+
+// union of closed-touching blocks: covered length and the longest merged block (leftmost on ties)
+void merge_span(std::vector<std::pair<int64_t, int64_t>>& p, int64_t& covered, int64_t& bs, int64_t& be)
+{
+    std::sort(p.begin(), p.end());
+    covered = 0;
+    int64_t best = -1;
+    bs = be = 0;
+    int64_t lo = p[0].first, hi = p[0].second;
+    for (size_t i = 1; i <= p.size(); i++) {
+        if (i < p.size() && hi >= p[i].first) { hi = std::max(hi, p[i].second); continue; }
+        covered += hi - lo;
+        if (hi - lo > best) { best = hi - lo; bs = lo; be = hi; }
+        if (i < p.size()) { lo = p[i].first; hi = p[i].second; }
+    }
+}
+
+bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c; }
+
+// Python's int() on a column: optional blanks, optional sign, digits
+bool parse_int(const uint8_t* a, const uint8_t* b, int64_t& v)
+{
+    while (a < b && is_space(*a)) a++;
+    while (b > a && is_space(b[-1])) b--;
+    bool neg = false;
+    if (a < b && (*a == '+' || *a == '-')) { neg = *a == '-'; a++; }
+    if (a >= b) return false;
+    uint64_t x = 0;
+    for (; a < b; a++) {
+        if (*a < '0' || *a > '9') return false;
+        if (x > (0x7fffffffffffffffULL - (*a - '0')) / 10) return false;
+        x = x * 10 + (*a - '0');
+    }
+    v = neg ? -(int64_t)x : (int64_t)x;
+    return true;
+}
+
+}  // namespace
+
+struct gci_paf {
+    std::vector<PafQuery> queries;
+    std::vector<std::vector<PafEmit>> per_file;
+};
+
+extern "C" int gci_paf_filter(const uint8_t* const* h_files, const uint64_t* n_bytes, int n_files, const char* const* targets,
+                              int n_targets, int map_qual, int mq_cutoff, double iden_percent, gci_paf** out, uint64_t* err_line)
+{
+    if (!out || n_files < 0 || (n_files && (!h_files || !n_bytes)) || (n_targets && !targets)) return GCI_E_INVALID;
+    gci_paf* R = new (std::nothrow) gci_paf();
+    if (!R) return GCI_E_NOMEM;
+    std::unordered_map<std::string, int32_t> tmap;
+    for (int t = 0; t < n_targets; t++) tmap.emplace(targets[t], t);
+    std::unordered_map<std::string, uint32_t> qmap;
+    int status = GCI_OK;
+    for (int f = 0; f < n_files && status == GCI_OK; f++) {
+        const uint8_t* p = h_files[f];
+        const uint8_t* end = p + n_bytes[f];
+        uint64_t line_no = 0;
+        while (p < end) {
+            // one line (universal newlines), stripped like str.strip()
+            const uint8_t* le = p;
+            while (le < end && *le != '\n' && *le != '\r') le++;
+            const uint8_t* next = le;
+            if (next < end) next += (*next == '\r' && next + 1 < end && next[1] == '\n') ? 2 : 1;
+            const uint8_t *a = p, *b = le;
+            p = next;
+            line_no++;
+            while (a < b && is_space(*a)) a++;
+            while (b > a && is_space(b[-1])) b--;
+            const uint8_t* col[13];
+            int nc = 0;
+            col[0] = a;
+            for (const uint8_t* q = a; q < b && nc < 12; q++) if (*q == '\t') col[++nc] = q + 1;
+            // col[k] .. col[k + 1] - 1 is column k for k < nc; the last found column runs to the next tab or b
+            auto col_end = [&](int k) { const uint8_t* q = col[k]; while (q < b && *q != '\t') q++; return q; };
+            if (nc < 5) { status = GCI_E_MALFORMED; if (err_line) *err_line = line_no; break; }       // col[5]: IndexError
+            const auto ti = tmap.find(std::string((const char*)col[5], (size_t)(col_end(5) - col[5])));
+            if (ti == tmap.end()) continue;
+            int64_t v[12] = {0};
+            bool ok = nc >= 11;
+            for (int k : {1, 2, 3, 7, 8, 9, 10, 11}) ok = ok && parse_int(col[k], col_end(k), v[k]);
+            if (!ok) { status = GCI_E_MALFORMED; if (err_line) *err_line = line_no; break; }
+            if (v[10] == 0) { status = GCI_E_ZERO_DIV; if (err_line) *err_line = line_no; break; }      // nmatch / alnlen
+            const double identity = (double)v[9] / (double)v[10];
+            if (v[11] >= map_qual && identity >= iden_percent) {
+                std::string qname((const char*)col[0], (size_t)(col_end(0) - col[0]));
+                auto qi = qmap.find(qname);
+                uint32_t qidx;
+                if (qi == qmap.end()) {
+                    qidx = (uint32_t)R->queries.size();
+                    qmap.emplace(qname, qidx);
+                    R->queries.emplace_back();
+                    R->queries.back().name = std::move(qname);
+                } else qidx = qi->second;
+                PafQuery& Q = R->queries[qidx];
+                PafTarget* T = nullptr;
+                for (auto& x : Q.targets) if (x.t == ti->second) { T = &x; break; }
+                if (!T) { Q.targets.push_back(PafTarget{ti->second, {}}); T = &Q.targets.back(); }
+                T->alns.push_back(PafAln{v[1], v[2], v[3], v[7], v[8], identity});
+                if (v[11] >= mq_cutoff) Q.hq = true;
+            }
+        }
+        if (status != GCI_OK) break;
+        // every query seen so far, in first-appearance order
+        std::vector<PafEmit> emit;
+        emit.reserve(R->queries.size());
+        std::vector<std::pair<int64_t, int64_t>> pairs;
+        for (uint32_t qi = 0; qi < R->queries.size(); qi++) {
+            const PafQuery& Q = R->queries[qi];
+            bool have = false;
+            double best_rank = 0;
+            const char* best_name = nullptr;
+            PafEmit best{qi, -1, 0, 0, 0};
+            for (const PafTarget& T : Q.targets) {
+                pairs.clear();
+                for (const PafAln& x : T.alns) pairs.emplace_back(x.qs, x.qe);
+                int64_t covered, s, e;
+                merge_span(pairs, covered, s, e);
+                const int64_t qlen = T.alns[0].qlen;
+                if (qlen == 0) { status = GCI_E_ZERO_DIV; break; }
+                double total = 0.0;
+                for (const PafAln& x : T.alns) total = total + x.identity;          // file order, as sum() does
+                const double rank = total / (double)T.alns.size() * ((double)covered / (double)qlen);
+                const char* name = targets[T.t];
+                if (!have || rank > best_rank || (rank == best_rank && strcmp(name, best_name) > 0)) {
+                    pairs.clear();
+                    for (const PafAln& x : T.alns) pairs.emplace_back(x.ts, x.te);
+                    merge_span(pairs, covered, s, e);
+                    have = true; best_rank = rank; best_name = name;
+                    best = PafEmit{qi, T.t, s, e, qlen};
+                }
+            }
+            if (status != GCI_OK) break;
+            emit.push_back(best);
+        }
+        R->per_file.push_back(std::move(emit));
+    }
+    if (status != GCI_OK) { delete R; return status; }
+    *out = R;
+    return GCI_OK;
+}
+
+extern "C" uint64_t gci_paf_count(const gci_paf* r, int file)
+{
+    return r && file >= 0 && (size_t)file < r->per_file.size() ? r->per_file[file].size() : 0;
+}
+
+extern "C" uint64_t gci_paf_name_bytes(const gci_paf* r, int file)
+{
+    if (!r || file < 0 || (size_t)file >= r->per_file.size()) return 0;
+    uint64_t n = 0;
+    for (const PafEmit& e : r->per_file[file]) n += r->queries[e.query].name.size();
+    return n;
+}
+
+// h_recs: gci_paf_count() records; h_names: gci_paf_name_bytes() bytes; h_name_off: count + 1 offsets into h_names
+extern "C" int gci_paf_export(const gci_paf* r, int file, gci_rec* h_recs, uint8_t* h_names, uint64_t* h_name_off)
+{
+    if (!r || file < 0 || (size_t)file >= r->per_file.size() || !h_name_off) return GCI_E_INVALID;
+    const auto& em = r->per_file[file];
+    if (em.size() && (!h_recs || !h_names)) {
+        bool any_bytes = false;
+        for (const PafEmit& e : em) any_bytes = any_bytes || !r->queries[e.query].name.empty();
+        if (!h_recs || (any_bytes && !h_names)) return GCI_E_INVALID;
+    }
+    uint64_t off = 0;
+    for (size_t i = 0; i < em.size(); i++) {
+        const PafEmit& e = em[i];
+        const PafQuery& Q = r->queries[e.query];
+        for (int64_t x : {e.s, e.e, e.qlen}) if (x > 0x7fffffffLL || x < -0x80000000LL) return GCI_E_INVALID;
+        if (Q.name.size() > 0xFFFF) return GCI_E_INVALID;
+        gci_rec rec;
+        memset(&rec, 0, sizeof rec);
+        rec.name_hash = gci_name_hash((const uint8_t*)Q.name.data(), (uint32_t)Q.name.size());
+        rec.contig = e.target; rec.start = (int32_t)e.s; rec.end = (int32_t)e.e; rec.qlen = (int32_t)e.qlen;
+        rec.rec_idx = (uint32_t)i; rec.mapq = 0;
+        rec.flags = (uint8_t)(GCI_REC_PASS | (Q.hq ? GCI_REC_HQ : 0));
+        rec.name_len = (uint16_t)Q.name.size();
+        h_recs[i] = rec;
+        h_name_off[i] = off;
+        if (!Q.name.empty()) memcpy(h_names + off, Q.name.data(), Q.name.size());
+        off += Q.name.size();
+    }
+    h_name_off[em.size()] = off;
+    return GCI_OK;
+}
+
+extern "C" int gci_paf_free(gci_paf* r) { delete r; return GCI_OK; }

@@ -95,3 +95,34 @@ def bam_chunk_offsets(buf: np.ndarray, start: int = 0) -> Tuple[np.ndarray, int]
     _chk(lib.gci_bam_chunk_offsets(p, buf.shape[0], int(start), offs.ctypes.data_as(ctypes.c_void_p), offs.shape[0],
                                    ctypes.byref(n), ctypes.byref(used)), "gci_bam_chunk_offsets")
     return offs, int(used.value)
+
+
+def paf_filter(paths, targets, map_qual: int, mq_cutoff: int, iden_percent: float):
+    """The PAF filter of filter() (GCI.py:211-254) in native code (gci_paf_filter): per PAF file, in command-line
+    order, -> (records uint8 [n, 32] = gci_rec, names uint8 blob, int64 [n + 1] name offsets): one entry per query seen
+    so far, in first-appearance order; the HQ flag carries the reference's high_qual set."""
+    lib = _lib.load()
+    bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
+    n = len(bufs)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data if b.shape[0] else None for b in bufs])
+    sizes = (ctypes.c_uint64 * max(n, 1))(*[int(b.shape[0]) for b in bufs])
+    tnames = [t.encode() for t in targets]
+    tarr = (ctypes.c_char_p * max(len(tnames), 1))(*tnames)
+    handle, line = ctypes.c_void_p(None), ctypes.c_uint64(0)
+    st = lib.gci_paf_filter(ptrs, sizes, n, tarr, len(tnames), int(map_qual), int(mq_cutoff), float(iden_percent),
+                            ctypes.byref(handle), ctypes.byref(line))
+    if st != 0:
+        raise GciError(st, "gci_paf_filter: %s (line %d)" % (lib.gci_strerror(st).decode(), line.value))
+    try:
+        out = []
+        for f in range(n):
+            cnt, nb = int(lib.gci_paf_count(handle, f)), int(lib.gci_paf_name_bytes(handle, f))
+            recs = np.zeros((cnt, 32), dtype=np.uint8)
+            names = np.zeros(max(nb, 1), dtype=np.uint8)
+            off = np.zeros(cnt + 1, dtype=np.uint64)
+            _chk(lib.gci_paf_export(handle, f, recs.ctypes.data_as(ctypes.c_void_p), names.ctypes.data_as(ctypes.c_void_p),
+                                    off.ctypes.data_as(ctypes.c_void_p)), "gci_paf_export")
+            out.append((recs, names, off.astype(np.int64)))
+        return out
+    finally:
+        lib.gci_paf_free(handle)

@@ -151,7 +151,26 @@ def _merge_span(pairs: List[Tuple[int, int]]) -> Tuple[int, int, int]:
 
 def paf_filter(paf_files: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int, iden_percent: float
                ) -> Tuple[List[Dict[str, Tuple[str, int, int, int]]], Set[str]]:
-    """GCI.py:211-254.  Block lists accumulate ACROSS files (the reference creates `synteny` once,
+    """GCI.py:211-254 as dicts, from the native filter (hostio.paf_filter / gci_paf_filter): what the reference's
+    paf_lines and high_qual hold.  The product path (filter()) uploads the native records directly."""
+    from . import hostio
+    per_file, high_qual = [], set()
+    for recs, names, off in hostio.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent):
+        r = recs.reshape(-1).view(REC_DTYPE)
+        d = {}
+        for i in range(r.shape[0]):
+            q = bytes(names[int(off[i]):int(off[i + 1])]).decode()
+            d[q] = (targets[int(r["contig"][i])], int(r["start"][i]), int(r["end"][i]), int(r["qlen"][i]))
+            if int(r["flags"][i]) & REC_HQ:
+                high_qual.add(q)
+        per_file.append(d)
+    return per_file, high_qual
+
+
+def paf_filter_py(paf_files: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int, iden_percent: float
+                  ) -> Tuple[List[Dict[str, Tuple[str, int, int, int]]], Set[str]]:
+    """The same filter in plain Python (the readable statement of the rules; tests hold the native one against it).
+    GCI.py:211-254.  Block lists accumulate ACROSS files (the reference creates `synteny` once,
     before the per-file loop), so file i re-emits every query seen in files < i."""
     tset = set(targets)
     high_qual: Set[str] = set()
@@ -348,8 +367,13 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     inputs: List[JoinInput] = []
     high_qual: Set[str] = set()
     if len(paf_files) != 0:
-        paf_dicts, high_qual = paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
-        inputs += [_paf_join_input(engine, d, high_qual, tindex) for d in paf_dicts]
+        from . import hostio
+        try:
+            native = hostio.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
+        except GciError as e:
+            _reraise_like_reference(e)
+        for recs, names, off in native:                       # compact records + names, as K1 makes them from a BAM
+            inputs.append(JoinInput(engine.to_device(recs), engine.to_device(names), engine.to_device(off), 0))
     for path in bam_files:
         try:
             inputs.append(bam_join_input(engine, path, targets, (map_qual, mq_cutoff, clip_percent, iden_percent), threads))

@@ -274,6 +274,20 @@ uint64_t gci_gzip_bound(uint64_t n, uint64_t chunk);
 int gci_gzip_members(const uint8_t* h_text, uint64_t n, uint64_t chunk, int level, int threads, uint8_t* h_out,
                      uint64_t cap, uint64_t* n_out);
 
+/* ---- N4 (second half, host): the PAF filter of filter(), GCI.py:211-254 --------------------------------------------
+ * h_files[i] / n_bytes[i]: the bytes of PAF file i, in command-line order.  targets: the selected contigs (index =
+ * gci_rec.contig).  On success *out holds, per file, one compact record + name for every query seen so far in first-
+ * appearance order (the reference's block table is created once, outside its per-file loop); GCI_REC_HQ marks the
+ * names of the reference's high_qual set as it stands after the last file.  GCI_E_MALFORMED / GCI_E_ZERO_DIV: a line
+ * the reference would raise IndexError / ValueError / ZeroDivisionError on; *err_line = its 1-based number. */
+typedef struct gci_paf gci_paf;
+int gci_paf_filter(const uint8_t* const* h_files, const uint64_t* n_bytes, int n_files, const char* const* targets,
+                   int n_targets, int map_qual, int mq_cutoff, double iden_percent, gci_paf** out, uint64_t* err_line);
+uint64_t gci_paf_count(const gci_paf* r, int file);
+uint64_t gci_paf_name_bytes(const gci_paf* r, int file);
+int gci_paf_export(const gci_paf* r, int file, gci_rec* h_recs, uint8_t* h_names, uint64_t* h_name_off /* count + 1 */);
+int gci_paf_free(gci_paf* r);
+
 #ifdef __cplusplus
 }
 #endif

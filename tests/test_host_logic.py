@@ -88,6 +88,51 @@ def test_paf_filter_matches_oracle(oracle, tmp_path):
     assert got[0][0]["q4"] == ("tA", 50, 250, 500) and got[1] == {"q1"}
 
 
+def test_native_paf_filter_randomised(oracle, tmp_path):
+    """gci_paf_filter (native) against the plain-Python statement and the oracle: many queries over few targets so
+    that rank ties and touching / nested blocks happen, three files (the block table is never reset), CRLF line ends,
+    extra columns, names the targets list does not hold; and the lines the reference would raise on."""
+    from gci_amd.pipeline import paf_filter, paf_filter_py
+    from gci_amd._lib import GciError
+    rng = np.random.default_rng(11)
+    targets = ["t%d" % i for i in range(6)]
+    paths = []
+    for f in range(3):
+        rows = []
+        for _ in range(1500):
+            q = "read_%d" % int(rng.integers(0, 400))
+            qlen = int(rng.choice([1000, 2000, 5000]))
+            qs = int(rng.integers(0, qlen // 100)) * 50
+            qe = min(qlen, qs + int(rng.integers(1, 20)) * 50)
+            t = str(rng.choice(targets + ["other"]))
+            ts = int(rng.integers(0, 100)) * 100
+            te = ts + (qe - qs)
+            aln = qe - qs
+            nm = int(aln * rng.choice([0.85, 0.9, 0.95, 1.0]))
+            rows.append("\t".join(map(str, (q, qlen, qs, qe, "+-"[int(rng.integers(0, 2))], t, 100000, ts, te, nm, aln,
+                                            int(rng.choice([0, 29, 30, 49, 50, 60])), "tp:A:P", "cm:i:5"))))
+        p = tmp_path / ("f%d.paf" % f)
+        p.write_bytes(("\r\n" if f == 1 else "\n").join(rows).encode() + (b"" if f == 2 else b"\n"))
+        paths.append(str(p))
+    for sel in (targets, targets[1:4]):
+        for args in ((30, 50, 0.9), (0, 60, 0.0), (50, 30, 0.95)):
+            got, py, want = paf_filter(paths, sel, *args), paf_filter_py(paths, sel, *args), oracle.paf_filter(paths, sel, *args)
+            assert got[1] == py[1] == want[1]
+            for a, b, c in zip(got[0], py[0], want[0]):
+                assert list(a.items()) == list(b.items()) == list(c.items())
+            assert len(got[0][2]) >= len(got[0][0]) > 20
+    bad = tmp_path / "bad.paf"
+    for text in ("q\t100\t0\t50\t+\n", "q\t100\t0\t50\t+\tt0\t1000\t0\t50\t50\t0\t60\n",
+                 "q\t100\t0\tx\t+\tt0\t1000\t0\t50\t50\t50\t60\n", "q\t100\t0\t50\t+\tt0\t1000\t0\t50\t50\t50\n"):
+        bad.write_text(text)
+        with pytest.raises(GciError):
+            paf_filter([str(bad)], ["t0"], 30, 50, 0.9)
+        with pytest.raises((IndexError, ValueError, ZeroDivisionError)):
+            paf_filter_py([str(bad)], ["t0"], 30, 50, 0.9)
+    bad.write_text("q\t100\t0\tx\t+\tother\t1000\t0\t50\t50\t50\t60\n")      # not a selected target: never parsed
+    assert paf_filter([str(bad)], ["t0"], 30, 50, 0.9) == paf_filter_py([str(bad)], ["t0"], 30, 50, 0.9) == ([{}], set())
+
+
 def test_fasta_n_runs_match_regex(tmp_path):
     p = tmp_path / "r.fa"
     p.write_bytes(b">c1 desc here\nACGTNNNN\nNNacgt\nnNnN\n>c2\nNNNN\n>c3\tx\nACGT\r\nAC GT\n>c4\n\nN\n")
