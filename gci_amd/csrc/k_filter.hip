@@ -51,6 +51,7 @@ struct LongItem {
 struct ChunkSums { unsigned long long v[5]; };       // bases per class: M/=/X, I, D, N, S
 
 struct LongQueue {
+    uint32_t* next_counters;     // the counters of the NEXT call (the other half of a ping-pong pair): zeroed by this one
     uint32_t* n_slow;
     unsigned long long* n_long;  // (long items << 32) | chunks: one atomic hands out both
     uint32_t* slow_list;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
 #define TR(i) do {} while (0)
 #endif
     TR(0);
+    if (blockIdx.x == 0 && threadIdx.x < 4) lq.next_counters[threadIdx.x] = 0u;    // nobody reads that set during this call
     __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
     __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
     const int t = threadIdx.x;
@@ -705,7 +707,7 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                               uint64_t* d_status)
 {
     if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
-    // scratch: [n_slow u32, pad, n_long u64][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
+    // scratch: [2 x (n_slow u32, pad, n_long u64)][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
     // A long item has more than LONG_OPS ops = 4 * LONG_OPS bytes of stream of its own and a chunk covers
     // 4 * CHUNK_DW bytes: that bounds both queues
     const size_t list_bytes = ((size_t)n_rec * 4 + 15) & ~(size_t)15;
@@ -714,19 +716,25 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
     const uint64_t cap_chunks64 = n_bytes / (4ull * CHUNK_DW) + 2ull * cap_items + 1;
     if (cap_chunks64 > 0xFFFFFFFFull) return GCI_E_INVALID;
     const uint32_t cap_chunks = (uint32_t)cap_chunks64;
-    GCI_TRY(gci_ensure(ctx, ctx->long_items, 16 + list_bytes + (size_t)cap_items * sizeof(LongItem) +
+    const size_t cap_before = ctx->long_items.cap;
+    GCI_TRY(gci_ensure(ctx, ctx->long_items, 32 + list_bytes + (size_t)cap_items * sizeof(LongItem) +
                                              (size_t)cap_chunks * (8 + sizeof(ChunkSums))));
     LongQueue lq;
-    lq.n_slow = (uint32_t*)ctx->long_items.p;
+    // two sets of counters [n_slow u32, pad, n_long u64], used alternately: the fast kernel of one call zeroes the set of
+    // the next, so no memset is launched per call (a fill costs a whole dependent launch, ~4.6 us)
+    if (ctx->long_items.cap != cap_before) { HIPCHK(hipMemsetAsync(ctx->long_items.p, 0, 32, ctx->stream)); ctx->k1_parity = 0; }
+    const uint32_t par = ctx->k1_parity;
+    lq.n_slow = (uint32_t*)ctx->long_items.p + 4 * par;
+    lq.next_counters = (uint32_t*)ctx->long_items.p + 4 * (par ^ 1u);
     lq.n_long = (unsigned long long*)(lq.n_slow + 2);
-    lq.slow_list = lq.n_slow + 4;
-    lq.items = (LongItem*)((uint8_t*)ctx->long_items.p + 16 + list_bytes);
+    lq.slow_list = (uint32_t*)ctx->long_items.p + 8;
+    lq.items = (LongItem*)((uint8_t*)ctx->long_items.p + 32 + list_bytes);
     lq.chunks = (unsigned long long*)((uint8_t*)lq.items + (size_t)cap_items * sizeof(LongItem));
     lq.sums = (ChunkSums*)(lq.chunks + cap_chunks);
     lq.cap_items = cap_items; lq.cap_chunks = cap_chunks;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(lq.n_slow, 0, 16, ctx->stream));
     if (n_rec == 0) return GCI_OK;
+    ctx->k1_parity ^= 1u;                   // the fast kernel below zeroes the other set for the next call
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
     const uint32_t per_block = KB / G;
     hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(KB), 0, ctx->stream, d_bam, n_bytes,
