@@ -44,6 +44,7 @@ struct gci_ctx {
     DevBuf d_tile_valid;                    // int32 per tile: elements of the tile inside its contig (TILE but for the last)
     DevBuf dense_flag;                      // uint8 per tile: pass 2 left it to the dense kernel
     int32_t sparse_max = 62;                // tiles with more events take the dense path (GCI_FORCE_DENSE=1: all of them)
+    bool join_dirty = false;                // the join tables are not in their clean state (a join was cut short)
     uint32_t k1_parity = 0;                 // which of the two K1 counter sets the next gci_bam_filter uses
     bool cd_dirty = false;                  // a build began and was not finished: tile_cd must be re-zeroed
     DevBuf events;                          // uint16 per event: local position << 1 | is_minus
@@ -55,6 +56,7 @@ struct gci_ctx {
     bool build_pending = false, build_text = false;
     // join scratch
     DevBuf join_table, join_last, join_hq;
+    DevBuf conflict_table;                  // gci_hash_conflicts' own open-addressing table
     DevBuf text_lut;                        // uint32[TEXT_LUT]: decimal characters of 0..999
     DevBuf long_items;                      // K1: queue of long-CIGAR records + its counter
     // issue-scan windows

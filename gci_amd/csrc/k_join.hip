@@ -37,9 +37,11 @@ __device__ __forceinline__ bool same_name(const JoinFiles& F, int fa, uint32_t i
 
 __global__ __launch_bounds__(BLOCK) void k_join_insert(JoinFiles F, int file, unsigned long long* __restrict__ table,
                                                        uint64_t mask, unsigned long long* __restrict__ last,
-                                                       uint32_t* __restrict__ hq)
+                                                       uint32_t* __restrict__ hq, uint32_t* __restrict__ reset_n_out,
+                                                       unsigned long long* __restrict__ reset_status)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0 && reset_n_out) { *reset_n_out = 0; *reset_status = SLOT_EMPTY; }    // first launch of a join: the fold appends later
     if (i >= F.f[file].n_recs) return;
     const gci_rec r = F.f[file].d_recs[i];
     if (!(r.flags & GCI_REC_PASS)) return;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_insert(JoinFiles F, int file, un
 }
 
 // Fold of one name over the files (GCI.py:279-299); returns true when an interval survives.
-__device__ __forceinline__ bool fold_slot(const JoinFiles& F, uint64_t slot, const unsigned long long* __restrict__ last,
+__device__ __forceinline__ bool fold_slot(const JoinFiles& F, uint64_t slot, const unsigned long long* last,
                                           bool high, double ovlp_percent, const int32_t* __restrict__ contig_map,
                                           unsigned long long* __restrict__ status, gci_ivl& o)
 {
@@ -106,9 +108,9 @@ __device__ __forceinline__ bool fold_slot(const JoinFiles& F, uint64_t slot, con
 // returning atomic per workgroup (a same-address atomic costs ~12 ns on this chip, so per-wave
 // appends would serialise for ~100 us at 10^5 intervals).
 #define FOLD_PER_THREAD 4
-__global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned long long* __restrict__ table,
-                                                     uint64_t n_slots, const unsigned long long* __restrict__ last,
-                                                     const uint32_t* __restrict__ hq, double ovlp_percent,
+__global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long long* __restrict__ table,
+                                                     uint64_t n_slots, unsigned long long* last,
+                                                     uint32_t* __restrict__ hq, double ovlp_percent,
                                                      const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out,
                                                      uint32_t cap, uint32_t* __restrict__ n_out,
                                                      unsigned long long* __restrict__ status)
@@ -123,9 +125,14 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned
 #pragma unroll
     for (int k = 0; k < FOLD_PER_THREAD; k++) {
         const uint64_t slot = slot0 + k;
-        ok[k] = slot < n_slots && table[slot] != SLOT_EMPTY &&
-                fold_slot(F, slot, last, F.n > 1 && hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
+        const bool used = slot < n_slots && table[slot] != SLOT_EMPTY;
+        ok[k] = used && fold_slot(F, slot, last, F.n > 1 && hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
         mine += ok[k] ? 1u : 0u;
+        if (used) {                                 // leave the tables as they were found: no clearing launch next time
+            table[slot] = SLOT_EMPTY;
+            if (F.n > 1) hq[slot] = 0u;
+            for (int f = 0; f < F.n; f++) last[slot * F.n + f] = 0ull;
+        }
     }
     const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
     if (lane == 63) wtot[wave] = inc;
@@ -142,19 +149,6 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, const unsigned
     }
 }
 
-// table <- EMPTY, last <- 0, hq <- 0, *n_out <- 0, *status <- ~0 in one launch
-__global__ __launch_bounds__(BLOCK) void k_join_clear(unsigned long long* __restrict__ table,
-                                                      unsigned long long* __restrict__ last, uint32_t* __restrict__ hq,
-                                                      uint64_t n_slots, int n_files, uint32_t* __restrict__ n_out,
-                                                      unsigned long long* __restrict__ status)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    const uint64_t i0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    for (uint64_t i = i0; i < n_slots; i += stride) { table[i] = SLOT_EMPTY; hq[i] = 0; }
-    for (uint64_t i = i0; i < n_slots * n_files; i += stride) last[i] = 0;
-    if (i0 == 0) { *n_out = 0; *status = SLOT_EMPTY; }
-}
-
 extern "C" int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
                              const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
                              uint64_t* d_status)
@@ -168,34 +162,42 @@ extern "C" int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_f
     for (int f = 0; f < n_files; f++) { F.f[f] = h_files[f]; total += h_files[f].n_recs; }
     uint64_t slots = 1024;
     while (slots < 2 * total) slots <<= 1;
+    // The three tables are kept clean between calls (k_join_fold empties every slot it reads), whatever the slot count
+    // and the number of files of the next call: a memset only when a buffer is new or a
+    // join was cut short.
+    const size_t cap_t = ctx->join_table.cap, cap_l = ctx->join_last.cap, cap_h = ctx->join_hq.cap;
     GCI_TRY(gci_ensure(ctx, ctx->join_table, slots * 8));
     GCI_TRY(gci_ensure(ctx, ctx->join_last, slots * 8 * n_files));
     GCI_TRY(gci_ensure(ctx, ctx->join_hq, slots * 4));
-    {
-        ProfScope _ps(ctx, GCI_PROF_MEMSET);
-        const uint64_t want = (slots + BLOCK * 4 - 1) / (BLOCK * 4);
-        hipLaunchKernelGGL(k_join_clear, dim3((uint32_t)(want > 4096 ? 4096 : want)), dim3(BLOCK), 0, ctx->stream,
-                           (unsigned long long*)ctx->join_table.p, (unsigned long long*)ctx->join_last.p,
-                           (uint32_t*)ctx->join_hq.p, slots, n_files, d_n_out, (unsigned long long*)d_status);
-        LAUNCHCHK("k_join_clear");
-    }
+    if (ctx->join_table.cap != cap_t || ctx->join_dirty) HIPCHK(hipMemsetAsync(ctx->join_table.p, 0xFF, ctx->join_table.cap, ctx->stream));
+    if (ctx->join_last.cap != cap_l || ctx->join_dirty) HIPCHK(hipMemsetAsync(ctx->join_last.p, 0, ctx->join_last.cap, ctx->stream));
+    if (ctx->join_hq.cap != cap_h || ctx->join_dirty) HIPCHK(hipMemsetAsync(ctx->join_hq.p, 0, ctx->join_hq.cap, ctx->stream));
+    ctx->join_dirty = true;
+    bool reset_done = false;
     for (int f = 0; f < n_files; f++) {
         if (!F.f[f].n_recs) continue;
         ProfScope _ps(ctx, GCI_PROF_JOIN_INSERT);
         hipLaunchKernelGGL(k_join_insert, dim3((F.f[f].n_recs + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, F, f,
                            (unsigned long long*)ctx->join_table.p, slots - 1, (unsigned long long*)ctx->join_last.p,
-                           (uint32_t*)ctx->join_hq.p);
+                           (uint32_t*)ctx->join_hq.p, reset_done ? (uint32_t*)nullptr : d_n_out,
+                           reset_done ? (unsigned long long*)nullptr : (unsigned long long*)d_status);
         LAUNCHCHK("k_join_insert");
+        reset_done = true;
+    }
+    if (!reset_done) {
+        HIPCHK(hipMemsetAsync(d_n_out, 0, 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
     }
     {
         ProfScope _ps(ctx, GCI_PROF_JOIN_FOLD);
         const uint64_t per_block = (uint64_t)BLOCK * FOLD_PER_THREAD;
         hipLaunchKernelGGL(k_join_fold, dim3((uint32_t)((slots + per_block - 1) / per_block)), dim3(BLOCK), 0, ctx->stream,
-                           F, (const unsigned long long*)ctx->join_table.p, slots,
-                           (const unsigned long long*)ctx->join_last.p, (const uint32_t*)ctx->join_hq.p, ovlp_percent,
+                           F, (unsigned long long*)ctx->join_table.p, slots,
+                           (unsigned long long*)ctx->join_last.p, (uint32_t*)ctx->join_hq.p, ovlp_percent,
                            d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status);
         LAUNCHCHK("k_join_fold");
     }
+    ctx->join_dirty = false;
     return GCI_OK;
 }
 
@@ -338,11 +340,11 @@ extern "C" int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint3
     if (!ctx || !d_buckets || !d_n_conflicts || n_parts == 0 || n_parts > 255) return GCI_E_INVALID;
     uint64_t slots = 1024;
     while (slots < 2ull * n_parts * part_cap) slots <<= 1;
-    GCI_TRY(gci_ensure(ctx, ctx->join_table, slots * 8));
-    HIPCHK(hipMemsetAsync(ctx->join_table.p, 0xFF, slots * 8, ctx->stream));
+    GCI_TRY(gci_ensure(ctx, ctx->conflict_table, slots * 8));  // its own table: the join's tables stay in their clean state
+    HIPCHK(hipMemsetAsync(ctx->conflict_table.p, 0xFF, slots * 8, ctx->stream));
     const uint32_t gx = (part_cap + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(k_hash_conflicts, dim3(gx ? (gx > 1024 ? 1024 : gx) : 1, n_parts), dim3(BLOCK), 0, ctx->stream,
-                       (const unsigned long long*)d_buckets, n_parts, part_cap, (unsigned long long*)ctx->join_table.p,
+                       (const unsigned long long*)d_buckets, n_parts, part_cap, (unsigned long long*)ctx->conflict_table.p,
                        slots - 1, d_n_conflicts);
     LAUNCHCHK("k_hash_conflicts");
     return GCI_OK;
