@@ -518,20 +518,45 @@ __device__ __forceinline__ void tile_sparse1(
     }
 }
 
+template <int PASS>
+__device__ __forceinline__ void tile_dense(
+    int64_t tile, const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off,
+    const int32_t* __restrict__ tile_carry, const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len,
+    int32_t n_contigs, long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, const IssueArgs& iss,
+    int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
+    const uint32_t* __restrict__ g_lut);
+
+// One workgroup, four tiles: every wave does its own tile from the event list; a tile with too many events is then
+// done densely by the whole workgroup (no second launch: a dependent launch costs ~4.6 us even when it finds nothing).
 __global__ __launch_bounds__(BLOCK) void k_tile_pass1(
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs, int64_t n_tiles,
-    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss, int32_t sparse_max)
+    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss, int32_t sparse_max,
+    const uint32_t* __restrict__ g_lut)
 {
     const int lane = threadIdx.x & 63;
     // the wave index is uniform: say so, and everything per tile (bounds, carry, offsets, loop counts) lives in SGPRs
     const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (tile >= n_tiles) return;
-    const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
-    if ((int64_t)(e1 - e0) > sparse_max) return;                             // k_tile_dense<1> takes it
-    const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
-    tile_sparse1(tile, e0, e1 - e0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum, tile_bytes, iss,
-                 lane);
+    if (tile < n_tiles) {
+        const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
+        if ((int64_t)(e1 - e0) <= sparse_max) {
+            const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
+            tile_sparse1(tile, e0, e1 - e0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum, tile_bytes,
+                         iss, lane);
+        }
+    }
+    // (written out rather than looped: a loop around tile_dense doubles its register count)
+#define DENSE_ONE(k)                                                                                                        \
+    {                                                                                                                       \
+        const int64_t td = (int64_t)blockIdx.x * (BLOCK / 64) + (k);                                                        \
+        if (td < n_tiles && (int64_t)(evt_off[td + 1] - evt_off[td]) > sparse_max) {                                        \
+            __syncthreads();                                                                                                \
+            tile_dense<1>(td, events, evt_off, tile_carry, tile_first, len, n_contigs, tile_sum, tile_bytes, iss, nullptr,  \
+                          nullptr, nullptr, 0, g_lut);                                                                      \
+        }                                                                                                                   \
+    }
+    DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3)
+#undef DENSE_ONE
 }
 
 // ---- PASS 2 (depth + text) ------------------------------------------------------------------------
@@ -852,17 +877,12 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
     IssueArgs none;
     memset(&none, 0, sizeof none);
     if (pass == 1) {
-        {
-            ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
-            hipLaunchKernelGGL(k_tile_pass1, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, ctx->n_tiles,
-                               (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, ctx->sparse_max);
-            LAUNCHCHK("k_tile_pass1");
-        }
-        ProfScope _ps(ctx, GCI_PROF_TILE_DENSE);
-        hipLaunchKernelGGL(k_tile_dense<1>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
-                           ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss,
-                           (int32_t*)nullptr, (const uint64_t*)nullptr, (uint8_t*)nullptr, (uint64_t)0,
+        ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
+        hipLaunchKernelGGL(k_tile_pass1, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, ctx->n_tiles,
+                           (long long*)ctx->tile_sum.p, (uint32_t*)ctx->tile_u32.p, iss, ctx->sparse_max,
                            (const uint32_t*)ctx->text_lut.p);
+        LAUNCHCHK("k_tile_pass1");
+        return GCI_OK;
     } else {
         {
             ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
