@@ -99,7 +99,7 @@ class Workload:
         self.replicated_steps = 0
         from gci_amd._lib import BuildOpts
         o = BuildOpts()
-        o.flank, o.want_text = 15, 1
+        o.flank, o.want_text, o.counted = 15, 1, 1          # counted: the join has done the build's counting pass
         o.d_contig_text_off, o.d_sums = self.text_off.data_ptr(), self.sums.data_ptr()
         o.d_n_keys, o.d_keys, o.key_cap = self.nkeys.data_ptr(), self.keys.data_ptr(), int(self.keys.shape[0])
         o.issue_flank, o.lo, o.hi = 15, -1.0, 0.0
@@ -152,8 +152,9 @@ class Workload:
             self._g = g                                     # keep the index tensor alive until the join ran
             jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = g.recs.data_ptr(), self.world * g.max_n, 0
             jf[0].d_name_base, jf[0].d_name_off = g.names.data_ptr(), g.name_index.data_ptr()
-        chk(lib.gci_name_join(ctx, jf, 1, 0.9, self._p(self.contig_map), self._p(self.ivl), int(self.ivl.shape[0]),
-                              self._p(self.count), self._p(self.status[1:2])), "gci_name_join")
+        # the join also does the counting pass of the depth build over the intervals it emits (gci_name_join_count)
+        chk(lib.gci_name_join_count(ctx, jf, 1, 0.9, self._p(self.contig_map), self._p(self.ivl), int(self.ivl.shape[0]),
+                                    self._p(self.count), self._p(self.status[1:2]), int(self.opts.flank)), "gci_name_join_count")
         # fused build: depth + per-contig sums + text byte offsets + issue-run boundaries from one pass over
         # the per-tile event buckets (no HBM re-read of the track), then depth + decimal text in the second
         o = self.opts

@@ -42,7 +42,7 @@ class Window(ctypes.Structure):
 class BuildOpts(ctypes.Structure):
     _fields_ = [("flank", c_int), ("want_text", c_int), ("d_contig_text_off", c_void_p), ("d_sums", c_void_p),
                 ("d_n_keys", c_void_p), ("d_keys", c_void_p), ("key_cap", c_uint32), ("issue_flank", c_int),
-                ("lo", c_double), ("hi", c_double)]
+                ("lo", c_double), ("hi", c_double), ("counted", c_int)]
 
 
 # every symbol include/gci_hip.h declares: (name, restype, argtypes)
@@ -71,6 +71,8 @@ EXPORTS = [
     ("gci_pack_names", c_int, [c_void_p, POINTER(JoinFile), c_void_p, c_uint64, c_void_p]),
     ("gci_name_join", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
                               c_void_p]),
+    ("gci_name_join_count", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
+                              c_void_p, c_int]),
     ("gci_hash_bucket", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p]),
     ("gci_hash_conflicts", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
     ("gci_depth_build", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_int, c_void_p]),

@@ -226,7 +226,7 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     // the per-tile (count, difference) table is self-cleaning (k_tile_build zeroes the differences, k_evt_scatter
     // returns the counts to zero): zero it once here
     HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(tiles + 1) * 8, ctx->stream));
-    ctx->cd_dirty = false;
+    ctx->cd_state = 0;
     ctx->build_pending = false;
     return GCI_OK;
 }

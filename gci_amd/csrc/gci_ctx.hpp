@@ -46,7 +46,8 @@ struct gci_ctx {
     int32_t sparse_max = 62;                // tiles with more events take the dense path (GCI_FORCE_DENSE=1: all of them)
     bool join_dirty = false;                // the join tables are not in their clean state (a join was cut short)
     uint32_t k1_parity = 0;                 // which of the two K1 counter sets the next gci_bam_filter uses
-    bool cd_dirty = false;                  // a build began and was not finished: tile_cd must be re-zeroed
+    int cd_state = 0;                       // tile_cd: 0 clean, 1 counted by gci_name_join_count, 2 in use / left over
+    int counted_flank = 0;                  // the flank gci_name_join_count counted with
     DevBuf events;                          // uint16 per event: local position << 1 | is_minus
     DevBuf blk_a, blk_b;                    // block totals of the two scans
     DevBuf tile_sum;                        // int64: sum of depth per tile
@@ -130,6 +131,41 @@ __device__ __forceinline__ int32_t contig_of_tile(const int64_t* __restrict__ ti
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ int32_t ld_i32(const uint8_t* p) { int32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint16_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+// ---- interval -> tile events (shared by k_evt_count / k_evt_scatter and the counting join) -------------------------
+struct IvlSpan { int64_t tile_a, tile_b; uint32_t pos_a, pos_b; bool valid, has_b; int64_t tile_bc; };
+
+__device__ __forceinline__ IvlSpan span_of(const gci_ivl v, int flank, const int64_t* __restrict__ len,
+                                           const int64_t* __restrict__ tile_first, int32_t n_contigs)
+{
+    IvlSpan s;
+    s.valid = false; s.has_b = false; s.tile_a = s.tile_b = s.tile_bc = 0; s.pos_a = s.pos_b = 0;
+    if (v.contig < 0 || v.contig >= n_contigs) return s;
+    const int64_t L = len[v.contig];
+    const int64_t a = gci_slice_bound((int64_t)v.start + flank, L);
+    const int64_t b = gci_slice_bound((int64_t)v.end - flank + 1, L);
+    if (a >= b) return s;
+    const int64_t t0 = tile_first[v.contig];
+    s.valid = true;
+    s.tile_a = t0 + a / TILE; s.pos_a = (uint32_t)(a % TILE);
+    s.has_b = b < (L + TILE - 1) / TILE * TILE;          // b == L lands in tail padding when there is any
+    s.tile_b = t0 + b / TILE; s.pos_b = (uint32_t)(b % TILE);
+    s.tile_bc = t0 + (b < L ? b : L - 1) / TILE;         // coarse -1: last tile of the contig when b == L
+    return s;
+}
+
+// One 64-bit atomic per interval end: the low word of tile_cd counts the events of a tile, the high word carries
+// the coarse difference (+1 in the tile of the start, -1 in the tile of the stop).
+__device__ __forceinline__ void count_span(const IvlSpan& s, unsigned long long* __restrict__ tile_cd)
+{
+    const unsigned long long minus1 = 0xFFFFFFFFull << 32;         // -1 in the high word (the low word never carries)
+    atomicAdd(tile_cd + s.tile_a, 1ull | (1ull << 32));
+    if (s.has_b && s.tile_b == s.tile_bc) atomicAdd(tile_cd + s.tile_b, 1ull | minus1);
+    else {
+        if (s.has_b) atomicAdd(tile_cd + s.tile_b, 1ull);
+        atomicAdd(tile_cd + s.tile_bc, minus1);
+    }
+}
 
 // ---- wave-level scans and sums -------------------------------------------------------------------
 // 32-bit values go through DPP (one v_add_*_dpp per step: row_shr 1/2/4/8 inside each 16-lane row, then

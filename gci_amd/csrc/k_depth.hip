@@ -28,27 +28,6 @@
 
 // ---- per interval ---------------------------------------------------------------------------------
 
-struct IvlSpan { int64_t tile_a, tile_b; uint32_t pos_a, pos_b; bool valid, has_b; int64_t tile_bc; };
-
-__device__ __forceinline__ IvlSpan span_of(const gci_ivl v, int flank, const int64_t* __restrict__ len,
-                                           const int64_t* __restrict__ tile_first, int32_t n_contigs)
-{
-    IvlSpan s;
-    s.valid = false; s.has_b = false; s.tile_a = s.tile_b = s.tile_bc = 0; s.pos_a = s.pos_b = 0;
-    if (v.contig < 0 || v.contig >= n_contigs) return s;
-    const int64_t L = len[v.contig];
-    const int64_t a = gci_slice_bound((int64_t)v.start + flank, L);
-    const int64_t b = gci_slice_bound((int64_t)v.end - flank + 1, L);
-    if (a >= b) return s;
-    const int64_t t0 = tile_first[v.contig];
-    s.valid = true;
-    s.tile_a = t0 + a / TILE; s.pos_a = (uint32_t)(a % TILE);
-    s.has_b = b < (L + TILE - 1) / TILE * TILE;          // b == L lands in tail padding when there is any
-    s.tile_b = t0 + b / TILE; s.pos_b = (uint32_t)(b % TILE);
-    s.tile_bc = t0 + (b < L ? b : L - 1) / TILE;         // coarse -1: last tile of the contig when b == L
-    return s;
-}
-
 // One 64-bit atomic per interval end: the low word of tile_cd counts the events of a tile, the high word carries
 // the coarse difference (+1 in the tile of the start, -1 in the tile of the stop).
 __global__ __launch_bounds__(BLOCK) void k_evt_count(const gci_ivl* __restrict__ ivl, const uint32_t* __restrict__ d_n,
@@ -61,13 +40,7 @@ __global__ __launch_bounds__(BLOCK) void k_evt_count(const gci_ivl* __restrict__
     if (i >= n) return;
     const IvlSpan s = span_of(ivl[i], flank, len, tile_first, n_contigs);
     if (!s.valid) return;
-    const unsigned long long minus1 = 0xFFFFFFFFull << 32;         // -1 in the high word (the low word never carries)
-    atomicAdd(tile_cd + s.tile_a, 1ull | (1ull << 32));
-    if (s.has_b && s.tile_b == s.tile_bc) atomicAdd(tile_cd + s.tile_b, 1ull | minus1);
-    else {
-        if (s.has_b) atomicAdd(tile_cd + s.tile_b, 1ull);
-        atomicAdd(tile_cd + s.tile_bc, minus1);
-    }
+    count_span(s, tile_cd);
 }
 
 // the counts are decremented back to zero while handing out bucket slots: no memset next time
@@ -922,9 +895,12 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     unsigned long long* cd = (unsigned long long*)ctx->tile_cd.p;
     uint32_t* off = (uint32_t*)ctx->evt_off.p;
     const int32_t nb = (int32_t)((nt + TILE - 1) / TILE);
-    if (ctx->cd_dirty) HIPCHK(hipMemsetAsync(cd, 0, (size_t)(nt + 1) * 8, ctx->stream));
-    ctx->cd_dirty = true;
-    if (max_n) {
+    // tile_cd: clean (0), counted by gci_name_join_count for exactly this build (1), or in use / left over (2)
+    const bool counted = o->counted != 0;
+    if (counted && (ctx->cd_state != 1 || ctx->counted_flank != o->flank)) return GCI_E_INVALID;
+    if (!counted && ctx->cd_state != 0) HIPCHK(hipMemsetAsync(cd, 0, (size_t)(nt + 1) * 8, ctx->stream));
+    ctx->cd_state = 2;
+    if (max_n && !counted) {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
         hipLaunchKernelGGL(k_evt_count, dim3((max_n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_ivl, d_n, max_n,
                            o->flank, ln, tf, ctx->n_contigs, cd);
@@ -1004,7 +980,7 @@ extern "C" int gci_depth_build_finish(gci_ctx* ctx, int32_t* d_depth, uint8_t* d
     IssueArgs none;
     memset(&none, 0, sizeof none);
     GCI_TRY(launch_tile_build(ctx, 2, none, d_depth, d_text, text_cap));
-    ctx->cd_dirty = false;                                  // k_evt_scatter returned the counts, k_tile_build the differences
+    ctx->cd_state = 0;                                      // k_evt_scatter returned the counts, k_tile_build the differences
     return GCI_OK;
 }
 

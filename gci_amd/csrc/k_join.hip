@@ -108,16 +108,21 @@ __device__ __forceinline__ bool fold_slot(const JoinFiles& F, uint64_t slot, con
 // returning atomic per workgroup (a same-address atomic costs ~12 ns on this chip, so per-wave
 // appends would serialise for ~100 us at 10^5 intervals).
 #define FOLD_PER_THREAD 4
+#define COUNT_LDS 256
+struct CountArgs { unsigned long long* tile_cd; const int64_t* len; const int64_t* tile_first; int32_t n_contigs; int flank; };
 __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long long* __restrict__ table,
                                                      uint64_t n_slots, unsigned long long* last,
                                                      uint32_t* __restrict__ hq, double ovlp_percent,
                                                      const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out,
                                                      uint32_t cap, uint32_t* __restrict__ n_out,
-                                                     unsigned long long* __restrict__ status)
+                                                     unsigned long long* __restrict__ status, const CountArgs cnt)
 {
     __shared__ uint32_t wtot[BLOCK / 64];
     __shared__ uint32_t s_base;
+    __shared__ int64_t s_len[COUNT_LDS], s_tf[COUNT_LDS];        // contig tables for the counting pass, loaded up front
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool tables_in_lds = cnt.tile_cd && cnt.n_contigs <= COUNT_LDS;
+    if (tables_in_lds) for (int c = t; c < cnt.n_contigs; c += BLOCK) { s_len[c] = cnt.len[c]; s_tf[c] = cnt.tile_first[c]; }
     const uint64_t slot0 = ((uint64_t)blockIdx.x * BLOCK + t) * FOLD_PER_THREAD;
     gci_ivl keep[FOLD_PER_THREAD];                  // indexed with compile-time constants only: stays in registers
     bool ok[FOLD_PER_THREAD];
@@ -145,13 +150,21 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long 
     uint32_t w = s_base + pre;
 #pragma unroll
     for (int k = 0; k < FOLD_PER_THREAD; k++) {
-        if (ok[k]) { if (w < cap) out[w] = keep[k]; w++; }
+        if (ok[k]) {
+            if (w < cap) out[w] = keep[k];
+            w++;
+            if (cnt.tile_cd) {                      // gci_name_join_count: the first pass of the depth build, here
+                const IvlSpan sp = tables_in_lds ? span_of(keep[k], cnt.flank, s_len, s_tf, cnt.n_contigs)
+                                                 : span_of(keep[k], cnt.flank, cnt.len, cnt.tile_first, cnt.n_contigs);
+                if (sp.valid) count_span(sp, cnt.tile_cd);
+            }
+        }
     }
 }
 
-extern "C" int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
-                             const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
-                             uint64_t* d_status)
+static int name_join_impl(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
+                          const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                          uint64_t* d_status, const CountArgs& cnt)
 {
     if (!ctx || !h_files || n_files < 1 || n_files > GCI_MAX_JOIN_FILES || !d_n_out || !d_status || (cap && !d_out))
         return GCI_E_INVALID;
@@ -194,11 +207,40 @@ extern "C" int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_f
         hipLaunchKernelGGL(k_join_fold, dim3((uint32_t)((slots + per_block - 1) / per_block)), dim3(BLOCK), 0, ctx->stream,
                            F, (unsigned long long*)ctx->join_table.p, slots,
                            (unsigned long long*)ctx->join_last.p, (uint32_t*)ctx->join_hq.p, ovlp_percent,
-                           d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status);
+                           d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt);
         LAUNCHCHK("k_join_fold");
     }
     ctx->join_dirty = false;
     return GCI_OK;
+}
+
+extern "C" int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
+                             const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                             uint64_t* d_status)
+{
+    CountArgs none;
+    memset(&none, 0, sizeof none);
+    return name_join_impl(ctx, h_files, n_files, ovlp_percent, d_contig_map, d_out, cap, d_n_out, d_status, none);
+}
+
+// The join, and in the same kernel that emits an interval the first pass of the depth build over it (the per-tile event
+// counts and coarse differences that gci_depth_build_begin would otherwise get from a launch of its own).
+extern "C" int gci_name_join_count(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
+                                   const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                                   uint64_t* d_status, int flank)
+{
+    if (!ctx) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    if (ctx->n_tiles && ctx->cd_state != 0)
+        HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(ctx->n_tiles + 1) * 8, ctx->stream));
+    ctx->cd_state = 2;
+    CountArgs cnt;
+    cnt.tile_cd = ctx->n_tiles ? (unsigned long long*)ctx->tile_cd.p : nullptr;
+    cnt.len = (const int64_t*)ctx->d_len.p; cnt.tile_first = (const int64_t*)ctx->d_tile_first.p;
+    cnt.n_contigs = ctx->n_contigs; cnt.flank = flank;
+    const int st = name_join_impl(ctx, h_files, n_files, ovlp_percent, d_contig_map, d_out, cap, d_n_out, d_status, cnt);
+    if (st == GCI_OK) { ctx->cd_state = 1; ctx->counted_flank = flank; }
+    return st;
 }
 
 // ---- names blob for the multi-GPU exchange ------------------------------------------------------

@@ -180,10 +180,13 @@ class Engine:
         return arr
 
     def name_join(self, files: Sequence[JoinInput], ovlp_percent: float, contig_map: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None, check: bool = True
-                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+                  out: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None, check: bool = True,
+                  count_flank: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (intervals int32 [cap, 4], device count).  With check=True the count is read back,
-        capacity is grown if needed and the record-level status is raised."""
+        capacity is grown if needed and the record-level status is raised.
+
+        count_flank = the flank of the depth build that follows: gci_name_join_count then does that build's counting
+        pass inside the join (pass counted=True to depth_build_fused / depth_build)."""
         total = sum(int(f.recs.shape[0]) for f in files)
         if out is None:
             out = torch.empty((max(total, 1), 4), dtype=torch.int32, device=self.device)
@@ -191,8 +194,13 @@ class Engine:
             count = torch.zeros(1, dtype=torch.int32, device=self.device)
         arr = self._join_files(files)
         while True:
-            st = self.lib.gci_name_join(self.ctx, arr, len(files), float(ovlp_percent), self._p(contig_map),
-                                        self._p(out), int(out.shape[0]), self._p(count), self._p(self._status))
+            if count_flank is None:
+                st = self.lib.gci_name_join(self.ctx, arr, len(files), float(ovlp_percent), self._p(contig_map),
+                                            self._p(out), int(out.shape[0]), self._p(count), self._p(self._status))
+            else:
+                st = self.lib.gci_name_join_count(self.ctx, arr, len(files), float(ovlp_percent), self._p(contig_map),
+                                                  self._p(out), int(out.shape[0]), self._p(count), self._p(self._status),
+                                                  int(count_flank))
             self._chk(st, "gci_name_join")
             if not check:
                 return out, count
@@ -233,7 +241,8 @@ class Engine:
 
     def depth_build_fused(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
                           want_text: bool = True, want_sums: bool = False,
-                          issue: Optional[Tuple[float, float, int]] = None, max_n: Optional[int] = None):
+                          issue: Optional[Tuple[float, float, int]] = None, max_n: Optional[int] = None,
+                          counted: bool = False):
         """Depth build that also returns what the reference derives from the fresh depths, computed in
         the same pass (no re-read of the track): decimal text, per-contig sums and -- only valid when
         no gap mask follows -- the raw issue runs for (lo, hi, flank).
@@ -244,6 +253,7 @@ class Engine:
         nc = len(self.lengths)
         o = BuildOpts()
         o.flank = int(flank)
+        o.counted = 1 if counted else 0
         o.want_text = 1 if want_text else 0
         text_off = torch.zeros(nc + 1, dtype=torch.int64, device=self.device) if want_text else None
         sums = torch.zeros(max(nc, 1), dtype=torch.int64, device=self.device) if want_sums else None
@@ -264,6 +274,7 @@ class Engine:
             if nk <= cap:
                 break
             cap = nk
+            o.counted = 0                                  # the join's counts are used up: the second begin counts again
         out = dict(text=None, text_off=None, sums=None, runs=None)
         text = None
         if want_text:

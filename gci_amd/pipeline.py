@@ -380,12 +380,12 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
         except GciError as e:
             _reraise_like_reference(e)
     try:
-        ivl, count = engine.name_join(inputs, ovlp_percent)
+        ivl, count = engine.name_join(inputs, ovlp_percent, count_flank=flank_len)     # + the build's counting pass
     except GciError as e:
         _reraise_like_reference(e)
     track = engine.new_track()
     fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=bool(write), want_sums=True,
-                                     issue=issue_hint)
+                                     issue=issue_hint, counted=True)
     depths = DepthTracks(engine, targets_length, track)
     depths._fresh_sums = fused["sums"]
     if issue_hint is not None:

@@ -168,6 +168,13 @@ int gci_pack_names(gci_ctx* ctx, const gci_join_file* h_file, uint8_t* d_out_nam
 int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
                   const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
                   uint64_t* d_status);
+/* The same join, fused with the first pass of the depth build: the kernel that emits an interval also counts it into
+ * the per-tile tables of the layout (flank = the build's --flank-len), so a gci_depth_build_begin over exactly this
+ * output with opts.counted = 1 skips that pass (one dependent launch and one read of the intervals less).  Needs
+ * gci_layout_set; if *d_n_out exceeds cap, call it again with more room before building. */
+int gci_name_join_count(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
+                        const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                        uint64_t* d_status, int flank);
 
 /* Cross-rank name check for contig-sharded runs (exact).  gci_hash_bucket sorts the 64-bit name hashes of the
  * passing records into n_parts buckets by (hash >> 33) % n_parts; a bucket is part_cap + 1 uint64 words:
@@ -204,6 +211,8 @@ typedef struct gci_build_opts {
     uint32_t key_cap;
     int issue_flank;
     double lo, hi;
+    int counted;                  /* 1: the intervals are exactly what the last gci_name_join_count emitted (same flank):
+                                     the per-tile counting pass has been done there */
 } gci_build_opts;
 int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n,
                           const gci_build_opts* h_opts);

@@ -449,6 +449,45 @@ def test_fasta_n_runs_on_gpu(engine, oracle, tmp_path):
     assert sum(len(v) for v in fasta.n_runs_device(engine, str(tmp_path / "lf60.fa"))[1].values()) > 20
 
 
+def test_counting_join_equals_join_then_count(engine, oracle):
+    """gci_name_join_count + gci_depth_build_begin(counted = 1) produce the same track, text, sums and issue runs as
+    gci_name_join + a plain build; a counted build over other intervals or another flank is refused; a plain build after
+    an unused counting join starts from a clean table."""
+    from gci_amd._lib import GciError
+    contigs = (("cA", 200_000), ("cB", 50_000))
+    a = synth.simulate_reads(contigs, 25, "hifi", seed=101)
+    b = synth.perturb(a, 102)
+    lengths = [l for _, l in contigs]
+    engine.set_layout(lengths)
+    files = []
+    for rs in (a, b):
+        stream, offs = synth.to_bam_stream(rs)
+        d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+        recs = engine.bam_filter(d_bam, d_off, engine.to_device(np.arange(2, dtype=np.int32)), 30, 50, 0.1, 0.9)
+        files.append(JoinInput(recs, d_bam, d_off, 36))
+    results = []
+    for fused in (False, True):
+        ivl, cnt = engine.name_join(files, 0.9, count_flank=15 if fused else None)
+        track = engine.new_track()
+        out = engine.depth_build_fused(ivl, cnt, 15, track, want_text=True, want_sums=True, issue=(-1, 0, 15), counted=fused)
+        results.append((track.cpu().numpy(), out["text"].cpu().numpy().tobytes(), out["sums"].tolist(),
+                        [np.asarray(r).tolist() for r in out["runs"]], int(cnt.item())))
+    assert results[0][4] == results[1][4] > 100
+    assert np.array_equal(results[0][0], results[1][0]) and results[0][1:4] == results[1][1:4]
+    # counted build with another flank: refused
+    ivl, cnt = engine.name_join(files, 0.9, count_flank=15)
+    with pytest.raises(GciError):
+        engine.depth_build_fused(ivl, cnt, 3, engine.new_track(), want_text=False, counted=True)
+    # ... and the table is clean again for a plain build
+    t2 = engine.new_track()
+    engine.depth_build(ivl, cnt, 15, t2)
+    assert np.array_equal(t2.cpu().numpy(), results[0][0])
+    # counted build without a counting join before it: refused
+    ivl, cnt = engine.name_join(files, 0.9)
+    with pytest.raises(GciError):
+        engine.depth_build_fused(ivl, cnt, 15, engine.new_track(), want_text=False, counted=True)
+
+
 def test_cross_rank_name_check_kernels(engine):
     """gci_hash_bucket + gci_hash_conflicts with two simulated ranks on one GPU: unique names -> 0 conflicts;
     a name present on both ranks is found; a repeated name inside ONE rank is not a conflict; overflow counts."""
