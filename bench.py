@@ -91,7 +91,10 @@ class Workload:
         self.keys = torch.empty(1 << 16, dtype=torch.int64, device=dev)
         self.nkeys = torch.zeros(1, dtype=torch.int32, device=dev)
         self.text_off = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.sums = torch.zeros(1, dtype=torch.int64, device=dev)
+        # [sum of depth (written by the build: d_sums), bases of this rank, cross-rank name conflicts (low word: the int32
+        # counter of the name check)] -- one copy into `totals` and ONE all-reduce per step at N > 1
+        self.totals_src = torch.zeros(3, dtype=torch.int64, device=dev)
+        self.sums = self.totals_src[0:1]
         self.totals = torch.zeros(3, dtype=torch.int64, device=dev)
         self.status = torch.zeros(2, dtype=torch.int64, device=dev)
         self.text = None
@@ -115,6 +118,8 @@ class Workload:
         self.recs = self.ex.send_recs                       # K1 writes straight into the send buffer
         self.ivl = self.torch.empty((self.world * self.ex.max_n, 4), dtype=self.torch.int32, device=self.eng.device)
         self.check_names = shard.NameCheck(self.n_rec, self.eng.device, self.eng.hash_bucket, self.eng.hash_conflicts)
+        self.check_names.n_conf = self.totals_src[2:3].view(self.torch.int32)[0:1]      # counted straight into the totals
+        self.totals_src[1] = self.contigs[self.rank][1]
         self.replicated_steps = 0
 
     def _p(self, t):
@@ -168,9 +173,7 @@ class Workload:
         if self.exchange:
             import torch.distributed as dist
             # ONE integer all-reduce per step: [sum of depth, bases, cross-rank name conflicts seen so far]
-            self.totals[0] = self.sums[0]
-            self.totals[1] = self.contigs[self.rank][1]
-            self.totals[2] = self.check_names.n_conf[0]
+            self.totals.copy_(self.totals_src)
             dist.all_reduce(self.totals, op=dist.ReduceOp.SUM)      # global mean depth = totals[0] / totals[1]
 
     def check(self):
