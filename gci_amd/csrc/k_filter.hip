@@ -52,6 +52,8 @@ struct ChunkSums { unsigned long long v[5]; };       // bases per class: M/=/X, 
 
 struct LongQueue {
     uint32_t* next_counters;     // the counters of the NEXT call (the other half of a ping-pong pair): zeroed by this one
+    unsigned long long* status_in;    // what k_bam_filter and k_bam_filter_slow report into (k_cigar_chunks publishes it)
+    unsigned long long* next_status;  // ... of the next call: set to "no error" by this one
     uint32_t* n_slow;
     unsigned long long* n_long;  // (long items << 32) | chunks: one atomic hands out both
     uint32_t* slow_list;
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
 #endif
     TR(0);
     if (blockIdx.x == 0 && threadIdx.x < 4) lq.next_counters[threadIdx.x] = 0u;    // nobody reads that set during this call
+    if (blockIdx.x == 0 && threadIdx.x == 4) *lq.next_status = ~0ull;
     __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
     __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
     const int t = threadIdx.x;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         if (gl == 0) {
             gci_rec r; r.name_hash = 0; r.contig = -1; r.start = r.end = r.qlen = 0; r.rec_idx = rec + rec_idx_base;
             r.mapq = 0; r.flags = 0; r.name_len = 0;
-            report(status, rec, GCI_E_MALFORMED); out[rec] = r;
+            report(lq.status_in, rec, GCI_E_MALFORMED); out[rec] = r;
         }
         live = false;
     }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     const uint64_t aux_off = off + 36 + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
     r.mapq = (uint8_t)mapq;
     if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) {
-        if (gl == 0) { report(status, rec, GCI_E_MALFORMED); out[rec] = r; }
+        if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); out[rec] = r; }
         return;
     }
     if (ref_id < 0 || ref_id >= n_ref || (flag & (0x4u | 0x100u | 0x800u)) || mapq < map_qual) {
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
         it.mapq = (uint32_t)mapq;
         if (gl == 0) out[rec] = r;                                                  // name hash / length are final
-        if (!enqueue_long<G>(lq, it, gl) && gl == 0) report(status, rec, GCI_E_CAPACITY);
+        if (!enqueue_long<G>(lq, it, gl) && gl == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
         return;
     }
     // the four lanes' shares -> every lane of the group holds the record's totals
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     if (gl != 0) return;        // the rest is scalar per record
     const int st = decide(r, (int64_t)sM, (int64_t)sI, (int64_t)sD, (int64_t)sN, (int64_t)sS, have_nm, nm_bad, NM, pos, contig, l_seq,
                           n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
-    if (st != GCI_OK) report(status, rec, st);
+    if (st != GCI_OK) report(lq.status_in, rec, st);
     out[rec] = r;
     TR(7);
 }
@@ -498,8 +501,12 @@ __device__ __forceinline__ unsigned long long wave_sum_u40(unsigned long long v)
     return (unsigned long long)lo + ((unsigned long long)hi << 16);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_cigar_chunks(const uint8_t* __restrict__ bam, uint64_t n_bytes, const LongQueue lq)
+__global__ __launch_bounds__(BLOCK) void k_cigar_chunks(const uint8_t* __restrict__ bam, uint64_t n_bytes, const LongQueue lq,
+                                                        unsigned long long* __restrict__ status)
 {
+    // Publish what the two kernels before this one reported (they are complete, this kernel reports nothing and the
+    // one after it reports into `status` directly): the caller's word is written without a memset launch in front.
+    if (blockIdx.x == 0 && threadIdx.x == 0) *status = *lq.status_in;
     const int lane = threadIdx.x & 63;
     const uint32_t n = (uint32_t)min((unsigned long long)(uint32_t)*lq.n_long, (unsigned long long)lq.cap_chunks);
     const uint32_t waves = gridDim.x * (BLOCK / 64);
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
             li.pos = pos; li.contig = contig; li.l_seq = l_seq; li.n_cigar_field = (int32_t)n_cigar;
             li.mapq = (uint32_t)mapq;
             if (lane == 0) out[rec] = r;
-            if (!enqueue_long<64>(lq, li, lane) && lane == 0) report(status, rec, GCI_E_CAPACITY);
+            if (!enqueue_long<64>(lq, li, lane) && lane == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
             continue;
         }
         int64_t tot[NSLOT];
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
         if (lane == 0) {
             const int st = decide(r, tot[0] + tot[7] + tot[8], tot[1], tot[2], tot[3], tot[4], nm_p != nullptr, nm_bad, NM, pos,
                                   contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
-            if (st != GCI_OK) report(status, rec, st);
+            if (st != GCI_OK) report(lq.status_in, rec, st);
             out[rec] = r;
         }
     }
@@ -707,7 +714,7 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                               uint64_t* d_status)
 {
     if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
-    // scratch: [2 x (n_slow u32, pad, n_long u64)][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
+    // scratch: [2 x (n_slow u32, pad, n_long u64)][2 x status u64][pad][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
     // A long item has more than LONG_OPS ops = 4 * LONG_OPS bytes of stream of its own and a chunk covers
     // 4 * CHUNK_DW bytes: that bounds both queues
     const size_t list_bytes = ((size_t)n_rec * 4 + 15) & ~(size_t)15;
@@ -717,23 +724,28 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
     if (cap_chunks64 > 0xFFFFFFFFull) return GCI_E_INVALID;
     const uint32_t cap_chunks = (uint32_t)cap_chunks64;
     const size_t cap_before = ctx->long_items.cap;
-    GCI_TRY(gci_ensure(ctx, ctx->long_items, 32 + list_bytes + (size_t)cap_items * sizeof(LongItem) +
+    GCI_TRY(gci_ensure(ctx, ctx->long_items, 64 + list_bytes + (size_t)cap_items * sizeof(LongItem) +
                                              (size_t)cap_chunks * (8 + sizeof(ChunkSums))));
     LongQueue lq;
     // two sets of counters [n_slow u32, pad, n_long u64], used alternately: the fast kernel of one call zeroes the set of
     // the next, so no memset is launched per call (a fill costs a whole dependent launch, ~4.6 us)
-    if (ctx->long_items.cap != cap_before) { HIPCHK(hipMemsetAsync(ctx->long_items.p, 0, 32, ctx->stream)); ctx->k1_parity = 0; }
+    if (ctx->long_items.cap != cap_before) {
+        HIPCHK(hipMemsetAsync(ctx->long_items.p, 0, 32, ctx->stream));
+        HIPCHK(hipMemsetAsync((uint8_t*)ctx->long_items.p + 32, 0xFF, 16, ctx->stream));       // the two status words: no error
+        ctx->k1_parity = 0;
+    }
     const uint32_t par = ctx->k1_parity;
     lq.n_slow = (uint32_t*)ctx->long_items.p + 4 * par;
     lq.next_counters = (uint32_t*)ctx->long_items.p + 4 * (par ^ 1u);
+    lq.status_in = (unsigned long long*)((uint8_t*)ctx->long_items.p + 32) + par;
+    lq.next_status = (unsigned long long*)((uint8_t*)ctx->long_items.p + 32) + (par ^ 1u);
     lq.n_long = (unsigned long long*)(lq.n_slow + 2);
-    lq.slow_list = (uint32_t*)ctx->long_items.p + 8;
-    lq.items = (LongItem*)((uint8_t*)ctx->long_items.p + 32 + list_bytes);
+    lq.slow_list = (uint32_t*)ctx->long_items.p + 16;
+    lq.items = (LongItem*)((uint8_t*)ctx->long_items.p + 64 + list_bytes);
     lq.chunks = (unsigned long long*)((uint8_t*)lq.items + (size_t)cap_items * sizeof(LongItem));
     lq.sums = (ChunkSums*)(lq.chunks + cap_chunks);
     lq.cap_items = cap_items; lq.cap_chunks = cap_chunks;
-    HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
-    if (n_rec == 0) return GCI_OK;
+    if (n_rec == 0) { HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream)); return GCI_OK; }
     ctx->k1_parity ^= 1u;                   // the fast kernel below zeroes the other set for the next call
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
     const uint32_t per_block = KB / G;
@@ -750,7 +762,7 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                        (unsigned long long*)d_status);
     LAUNCHCHK("k_bam_filter_slow");
     hipLaunchKernelGGL(k_cigar_chunks, dim3(cap_chunks < 8192u ? (cap_chunks + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream,
-                       d_bam, n_bytes, lq);
+                       d_bam, n_bytes, lq, (unsigned long long*)d_status);
     LAUNCHCHK("k_cigar_chunks");
     hipLaunchKernelGGL(k_cigar_finish, dim3(cap_items < 65536u ? (cap_items + BLOCK - 1) / BLOCK : 256u), dim3(BLOCK), 0,
                        ctx->stream, lq, mq_cutoff, clip_percent, iden_percent, d_out, (unsigned long long*)d_status);
