@@ -12,7 +12,7 @@
 //     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162) in five per-lane register
 //     sums, added over the four lanes of the record -> the two IEEE f64 divisions of GCI.py:165 -> 32-byte
 //     compact record.
-//   slow path (k_bam_filter_slow), one wave per queued record, everything from global memory with
+//   slow path (slow_record, at the end of the same kernel), one wave per record, everything from global memory with
 //     naturally aligned loads only: htslib's CG:B,I restore (CIGARs of more than 65535 operations),
 //     records whose NM tag does not show up in the staged part of the aux block, names longer than the
 //     staged head.  Same decisions, same status codes.
@@ -183,6 +183,162 @@ __device__ __forceinline__ bool enqueue_long(const LongQueue& q, LongItem it, in
     return ok;
 }
 
+// ---- long CIGARs: one WAVE per queued record sums the op array (16-byte aligned loads, four chunk pairs in flight)
+// and takes the decision; everything else about the record was parsed by the fast path ------------------------------
+
+__device__ __forceinline__ void cigar_totals_wave(const uint8_t* __restrict__ bam, uint64_t n_bytes, uint64_t p0,
+                                                  uint32_t n_ops, int lane, int64_t (&tot)[NSLOT])
+{
+    long long sum[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) sum[k] = 0;
+    const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
+    const uint64_t a0 = p0 & ~15ull, lim = n_bytes & ~15ull;
+    for (uint32_t c0 = lane; 4ull * c0 < n_ops; c0 += 256) {
+        uint4 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = c0 + 64u * u;
+            const uint64_t a = a0 + 16ull * c;
+            const bool in = 4ull * c < n_ops;
+            lo[u] = !in ? make_uint4(0, 0, 0, 0) : a < lim ? *reinterpret_cast<const uint4*>(bam + a) : load16_tail(bam, a, n_bytes);
+            hi[u] = !in ? make_uint4(0, 0, 0, 0) : a + 16 < lim ? *reinterpret_cast<const uint4*>(bam + a + 16) : load16_tail(bam, a + 16, n_bytes);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = c0 + 64u * u;
+            if (4ull * c >= n_ops) continue;
+            const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            const uint32_t m = min(4u, n_ops - 4u * c);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
+                const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
+                const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
+                const uint32_t op = v & 0xFu;
+                const long long len = (uint32_t)j < m ? (long long)(v >> 4) : 0;
+#pragma unroll
+                for (int q = 0; q < NSLOT - 1; q++) sum[q] += op == (uint32_t)q ? len : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; k++) tot[k] = wave_sum<long long>(sum[k]);
+    tot[NSLOT - 1] = 0;
+}
+
+// ---- slow path: one WAVE per queued record, everything read from global memory --------------------------------
+// Only naturally aligned global loads: bytes for the scalar fields and the aux walk, 16-byte aligned chunks
+// (re-aligned in registers) for the CIGAR.
+
+__device__ __forceinline__ uint32_t rd16b(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t rd32b(const uint8_t* p) { return rd16b(p) | (rd16b(p + 2) << 16); }
+
+// size of an aux value of type t at p; -1 if malformed / past end
+__device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_t* end, uint8_t t)
+{
+    switch (t) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'Z': case 'H': {
+        const uint8_t* q = p;
+        while (q < end && *q) q++;
+        return q < end ? (q - p) + 1 : -1;
+    }
+    case 'B': {
+        if (p + 5 > end) return -1;
+        const uint8_t sub = p[0];
+        const int64_t n = rd32b(p + 1);
+        const int64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2
+                         : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : -1;
+        return es < 0 ? -1 : 5 + n * es;
+    }
+    default: return -1;
+    }
+}
+
+// One record, one wave (all 64 lanes): called by k_bam_filter for the records its staged window could not answer.
+__device__ __forceinline__ void slow_record(
+    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
+    const int32_t* __restrict__ ref_sel, uint32_t rec, int lane, const LongQueue& lq, int mq_cutoff, double clip_percent,
+    double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out)
+{
+    // the fast path has already validated the record's bounds and passed its flag / MAPQ tests;
+    // every lane parses the scalar part redundantly (same addresses: one transaction per load)
+    const uint64_t off = rec_off[rec];
+    const uint8_t* p = bam + off;
+    const int32_t block_size = (int32_t)rd32b(p);
+    const int32_t ref_id = (int32_t)rd32b(p + 4);
+    const int32_t pos = (int32_t)rd32b(p + 8);
+    const uint32_t l_read_name = p[12];
+    const int mapq = p[13];
+    const uint32_t n_cigar = rd16b(p + 16);
+    const int32_t l_seq = (int32_t)rd32b(p + 20);
+    const int32_t contig = ref_sel[ref_id];
+    const uint8_t* name = p + 36;
+    const uint8_t* rec_end = p + 4 + block_size;
+    const uint8_t* cig = name + l_read_name;
+    const uint8_t* aux = cig + 4 * (uint64_t)n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+    // query_name and its hash, lanes striding over bytes / words
+    uint32_t nul = l_read_name;
+    for (uint32_t i = lane; i < l_read_name; i += 64) if (name[i] == 0) { nul = i; break; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nul = min(nul, (uint32_t)__shfl_xor((int)nul, m, 64));
+    const uint32_t name_len = nul;
+    uint64_t acc = 0;
+    for (uint32_t k = lane; k * 8 < name_len; k += 64) {
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) if (k * 8 + b < name_len) w |= (uint64_t)name[k * 8 + b] << (8 * b);
+        acc += gci_hash_word(w, k);
+    }
+    acc = (uint64_t)wave_sum<long long>((long long)acc);
+    // first NM, first CG (bam_aux_get semantics)
+    const uint8_t* nm_p = nullptr;
+    const uint8_t* cg_p = nullptr;
+    for (const uint8_t* q = aux; q + 3 <= rec_end;) {
+        const int64_t sz = aux_value_size(q + 3, rec_end, q[2]);
+        if (sz < 0 || q + 3 + sz > rec_end) break;
+        if (q[0] == 'N' && q[1] == 'M' && !nm_p) nm_p = q + 2;
+        if (q[0] == 'C' && q[1] == 'G' && !cg_p) cg_p = q + 2;
+        q += 3 + sz;
+    }
+    int64_t NM = 0;
+    const bool nm_bad = nm_p ? !nm_value(nm_p, NM) : false;
+    // htslib moves a >65535-op CIGAR back from CG:B,I when op0 == <l_seq>S
+    const uint8_t* ops = cig;
+    uint32_t n_ops = n_cigar;
+    if (n_cigar > 0 && pos >= 0) {
+        const uint32_t op0 = rd32b(cig);
+        if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)l_seq && cg_p && cg_p[0] == 'B' && (cg_p[1] == 'I' || cg_p[1] == 'i')) {
+            const uint32_t cg_len = rd32b(cg_p + 2);
+            if (cg_len >= n_cigar && cg_len < (1u << 29)) { ops = cg_p + 6; n_ops = cg_len; }
+        }
+    }
+    gci_rec r;
+    r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
+    r.rec_idx = rec + rec_idx_base; r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = (uint16_t)name_len;
+    if (n_ops > LONG_OPS) {                 // summed chunk by chunk like the fast path's long CIGARs
+        LongItem li;
+        li.ops_off = (uint64_t)(ops - bam); li.n_ops = n_ops; li.rec = rec;
+        li.nm = nm_p ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
+        li.pos = pos; li.contig = contig; li.l_seq = l_seq; li.n_cigar_field = (int32_t)n_cigar;
+        li.mapq = (uint32_t)mapq;
+        if (lane == 0) out[rec] = r;
+        if (!enqueue_long<64>(lq, li, lane) && lane == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
+        return;
+    }
+    int64_t tot[NSLOT];
+    cigar_totals_wave(bam, n_bytes, (uint64_t)(ops - bam), n_ops, lane, tot);
+    if (lane == 0) {
+        const int st = decide(r, tot[0] + tot[7] + tot[8], tot[1], tot[2], tot[3], tot[4], nm_p != nullptr, nm_bad, NM, pos,
+                              contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
+        if (st != GCI_OK) report(lq.status_in, rec, st);
+        out[rec] = r;
+    }
+
+}
+
 __global__ __launch_bounds__(KB) void k_bam_filter(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
@@ -234,7 +390,10 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     TR(1);
     __syncthreads();                                            // the two small tables; (also covers the staged heads)
     TR(2);
-    if (!live) return;
+    // The fast path of one record (its four lanes); true when the staged window cannot answer and the record has to be
+    // parsed from global memory.  Written as a lambda so that no lane LEAVES the kernel here: the slow records of a wave
+    // are handled below by all 64 of its lanes.
+    auto fast_path = [&]() -> bool {
 
     // ---- core fields (GCI.py:152-156) ---------------------------------------------------------------------------
     gci_rec r;
@@ -255,11 +414,11 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     r.mapq = (uint8_t)mapq;
     if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) {
         if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); out[rec] = r; }
-        return;
+        return false;
     }
     if (ref_id < 0 || ref_id >= n_ref || (flag & (0x4u | 0x100u | 0x800u)) || mapq < map_qual) {
         if (gl == 0) out[rec] = r;
-        return;
+        return false;
     }
     TR(8);
     // ---- second (and last) dependent round trip: the refID -> selected-contig entry, the aux head and the CIGAR
@@ -278,7 +437,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
     if (contig < 0) {
         if (gl == 0) out[rec] = r;
-        return;
+        return false;
     }
     const bool odd_name = cig_at + 4 > HEAD;                    // first CIGAR word must lie inside the staged head
     const bool long_cigar = n_cigar > LONG_OPS;                // its totals are computed by k_cigar_chunks
@@ -391,10 +550,7 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         }
         if (!have_nm && !walked_all) slow = true;          // NM (if any) lies beyond what was staged
     }
-    if (slow) {
-        if (gl == 0) { lq.slow_list[atomicAdd(lq.n_slow, 1u)] = rec; }
-        return;
-    }
+    if (slow) return true;
 
     TR(5);
     // ---- query_name: bytes up to the first NUL, 64-bit hash of its 8-byte words -----------------------------------
@@ -432,62 +588,27 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
         it.mapq = (uint32_t)mapq;
         if (gl == 0) out[rec] = r;                                                  // name hash / length are final
         if (!enqueue_long<G>(lq, it, gl) && gl == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
-        return;
+        return false;
     }
     // the four lanes' shares -> every lane of the group holds the record's totals
 #define GRP_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, G); x += (unsigned long long)__shfl_xor((long long)x, 2, G); } while (0)
     GRP_SUM(sM); GRP_SUM(sI); GRP_SUM(sD); GRP_SUM(sN); GRP_SUM(sS);
 #undef GRP_SUM
-    if (gl != 0) return;        // the rest is scalar per record
+    if (gl != 0) return false;  // the rest is scalar per record
     const int st = decide(r, (int64_t)sM, (int64_t)sI, (int64_t)sD, (int64_t)sN, (int64_t)sS, have_nm, nm_bad, NM, pos, contig, l_seq,
                           n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
     if (st != GCI_OK) report(lq.status_in, rec, st);
     out[rec] = r;
     TR(7);
-}
-
-// ---- long CIGARs: one WAVE per queued record sums the op array (16-byte aligned loads, four chunk pairs in flight)
-// and takes the decision; everything else about the record was parsed by the fast path ------------------------------
-
-__device__ __forceinline__ void cigar_totals_wave(const uint8_t* __restrict__ bam, uint64_t n_bytes, uint64_t p0,
-                                                  uint32_t n_ops, int lane, int64_t (&tot)[NSLOT])
-{
-    long long sum[NSLOT];
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) sum[k] = 0;
-    const uint32_t sh = (uint32_t)(p0 & 15ull), d = sh >> 2, b = sh & 3u;
-    const uint64_t a0 = p0 & ~15ull, lim = n_bytes & ~15ull;
-    for (uint32_t c0 = lane; 4ull * c0 < n_ops; c0 += 256) {
-        uint4 lo[4], hi[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t c = c0 + 64u * u;
-            const uint64_t a = a0 + 16ull * c;
-            const bool in = 4ull * c < n_ops;
-            lo[u] = !in ? make_uint4(0, 0, 0, 0) : a < lim ? *reinterpret_cast<const uint4*>(bam + a) : load16_tail(bam, a, n_bytes);
-            hi[u] = !in ? make_uint4(0, 0, 0, 0) : a + 16 < lim ? *reinterpret_cast<const uint4*>(bam + a + 16) : load16_tail(bam, a + 16, n_bytes);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t c = c0 + 64u * u;
-            if (4ull * c >= n_ops) continue;
-            const uint32_t w[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
-            const uint32_t m = min(4u, n_ops - 4u * c);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t x0 = d == 0 ? w[j] : d == 1 ? w[j + 1] : d == 2 ? w[j + 2] : w[j + 3];
-                const uint32_t x1 = d == 0 ? w[j + 1] : d == 1 ? w[j + 2] : d == 2 ? w[j + 3] : w[j + 4];
-                const uint32_t v = __builtin_amdgcn_alignbyte(x1, x0, b);
-                const uint32_t op = v & 0xFu;
-                const long long len = (uint32_t)j < m ? (long long)(v >> 4) : 0;
-#pragma unroll
-                for (int q = 0; q < NSLOT - 1; q++) sum[q] += op == (uint32_t)q ? len : 0;
-            }
-        }
+    return false;
+    };
+    const bool is_slow = live && fast_path();
+    // ---- slow records of this wave, one after the other, by the whole wave (rare: NM beyond the staged window, htslib's
+    // CG:B,I long-CIGAR restore, names >= 217 bytes); no second kernel launch for them
+    for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
+        const uint32_t rs = (uint32_t)__shfl((int)rec, __builtin_ctzll(m), 64);
+        slow_record(bam, n_bytes, rec_off, ref_sel, rs, t & 63, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, out);
     }
-#pragma unroll
-    for (int k = 0; k < NSLOT - 1; k++) tot[k] = wave_sum<long long>(sum[k]);
-    tot[NSLOT - 1] = 0;
 }
 
 // ---- long CIGARs, chunk by chunk: one wave per chunk of CHUNK_DW aligned dwords.  A lane owns PIECES 16-byte
@@ -592,122 +713,6 @@ __global__ __launch_bounds__(BLOCK) void k_cigar_finish(const LongQueue lq, int 
     }
 }
 
-// ---- slow path: one WAVE per queued record, everything read from global memory --------------------------------
-// Only naturally aligned global loads: bytes for the scalar fields and the aux walk, 16-byte aligned chunks
-// (re-aligned in registers) for the CIGAR.
-
-__device__ __forceinline__ uint32_t rd16b(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-__device__ __forceinline__ uint32_t rd32b(const uint8_t* p) { return rd16b(p) | (rd16b(p + 2) << 16); }
-
-// size of an aux value of type t at p; -1 if malformed / past end
-__device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_t* end, uint8_t t)
-{
-    switch (t) {
-    case 'A': case 'c': case 'C': return 1;
-    case 's': case 'S': return 2;
-    case 'i': case 'I': case 'f': return 4;
-    case 'Z': case 'H': {
-        const uint8_t* q = p;
-        while (q < end && *q) q++;
-        return q < end ? (q - p) + 1 : -1;
-    }
-    case 'B': {
-        if (p + 5 > end) return -1;
-        const uint8_t sub = p[0];
-        const int64_t n = rd32b(p + 1);
-        const int64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2
-                         : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : -1;
-        return es < 0 ? -1 : 5 + n * es;
-    }
-    default: return -1;
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_bam_filter_slow(
-    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
-    const int32_t* __restrict__ ref_sel, const LongQueue lq, int mq_cutoff, double clip_percent, double iden_percent,
-    uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t n = *lq.n_slow;
-    const uint32_t waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t it = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); it < n; it += waves) {
-        const uint32_t rec = lq.slow_list[it];
-        // the fast path has already validated the record's bounds and passed its flag / MAPQ tests;
-        // every lane parses the scalar part redundantly (same addresses: one transaction per load)
-        const uint64_t off = rec_off[rec];
-        const uint8_t* p = bam + off;
-        const int32_t block_size = (int32_t)rd32b(p);
-        const int32_t ref_id = (int32_t)rd32b(p + 4);
-        const int32_t pos = (int32_t)rd32b(p + 8);
-        const uint32_t l_read_name = p[12];
-        const int mapq = p[13];
-        const uint32_t n_cigar = rd16b(p + 16);
-        const int32_t l_seq = (int32_t)rd32b(p + 20);
-        const int32_t contig = ref_sel[ref_id];
-        const uint8_t* name = p + 36;
-        const uint8_t* rec_end = p + 4 + block_size;
-        const uint8_t* cig = name + l_read_name;
-        const uint8_t* aux = cig + 4 * (uint64_t)n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
-        // query_name and its hash, lanes striding over bytes / words
-        uint32_t nul = l_read_name;
-        for (uint32_t i = lane; i < l_read_name; i += 64) if (name[i] == 0) { nul = i; break; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) nul = min(nul, (uint32_t)__shfl_xor((int)nul, m, 64));
-        const uint32_t name_len = nul;
-        uint64_t acc = 0;
-        for (uint32_t k = lane; k * 8 < name_len; k += 64) {
-            uint64_t w = 0;
-            for (int b = 0; b < 8; b++) if (k * 8 + b < name_len) w |= (uint64_t)name[k * 8 + b] << (8 * b);
-            acc += gci_hash_word(w, k);
-        }
-        acc = (uint64_t)wave_sum<long long>((long long)acc);
-        // first NM, first CG (bam_aux_get semantics)
-        const uint8_t* nm_p = nullptr;
-        const uint8_t* cg_p = nullptr;
-        for (const uint8_t* q = aux; q + 3 <= rec_end;) {
-            const int64_t sz = aux_value_size(q + 3, rec_end, q[2]);
-            if (sz < 0 || q + 3 + sz > rec_end) break;
-            if (q[0] == 'N' && q[1] == 'M' && !nm_p) nm_p = q + 2;
-            if (q[0] == 'C' && q[1] == 'G' && !cg_p) cg_p = q + 2;
-            q += 3 + sz;
-        }
-        int64_t NM = 0;
-        const bool nm_bad = nm_p ? !nm_value(nm_p, NM) : false;
-        // htslib moves a >65535-op CIGAR back from CG:B,I when op0 == <l_seq>S
-        const uint8_t* ops = cig;
-        uint32_t n_ops = n_cigar;
-        if (n_cigar > 0 && pos >= 0) {
-            const uint32_t op0 = rd32b(cig);
-            if ((op0 & 0xF) == 4 && (op0 >> 4) == (uint32_t)l_seq && cg_p && cg_p[0] == 'B' && (cg_p[1] == 'I' || cg_p[1] == 'i')) {
-                const uint32_t cg_len = rd32b(cg_p + 2);
-                if (cg_len >= n_cigar && cg_len < (1u << 29)) { ops = cg_p + 6; n_ops = cg_len; }
-            }
-        }
-        gci_rec r;
-        r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
-        r.rec_idx = rec + rec_idx_base; r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = (uint16_t)name_len;
-        if (n_ops > LONG_OPS) {                 // summed chunk by chunk like the fast path's long CIGARs
-            LongItem li;
-            li.ops_off = (uint64_t)(ops - bam); li.n_ops = n_ops; li.rec = rec;
-            li.nm = nm_p ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
-            li.pos = pos; li.contig = contig; li.l_seq = l_seq; li.n_cigar_field = (int32_t)n_cigar;
-            li.mapq = (uint32_t)mapq;
-            if (lane == 0) out[rec] = r;
-            if (!enqueue_long<64>(lq, li, lane) && lane == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
-            continue;
-        }
-        int64_t tot[NSLOT];
-        cigar_totals_wave(bam, n_bytes, (uint64_t)(ops - bam), n_ops, lane, tot);
-        if (lane == 0) {
-            const int st = decide(r, tot[0] + tot[7] + tot[8], tot[1], tot[2], tot[3], tot[4], nm_p != nullptr, nm_bad, NM, pos,
-                                  contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
-            if (st != GCI_OK) report(lq.status_in, rec, st);
-            out[rec] = r;
-        }
-    }
-}
-
 extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
                               uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
                               double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
@@ -757,10 +762,6 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
 #endif
                        );
     LAUNCHCHK("k_bam_filter");
-    hipLaunchKernelGGL(k_bam_filter_slow, dim3(n_rec < 8192u ? (n_rec + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream, d_bam,
-                       n_bytes, d_rec_off, d_ref_sel, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, d_out,
-                       (unsigned long long*)d_status);
-    LAUNCHCHK("k_bam_filter_slow");
     hipLaunchKernelGGL(k_cigar_chunks, dim3(cap_chunks < 8192u ? (cap_chunks + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream,
                        d_bam, n_bytes, lq, (unsigned long long*)d_status);
     LAUNCHCHK("k_cigar_chunks");
