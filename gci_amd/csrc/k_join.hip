@@ -47,6 +47,20 @@ __global__ __launch_bounds__(BLOCK) void k_join_insert(JoinFiles F, int file, un
     if (!(r.flags & GCI_REC_PASS)) return;
     const unsigned long long me = ((unsigned long long)file << 32) | i;
     uint64_t slot = r.name_hash & mask;
+    if (F.n == 1) {
+        // One file: only the dict's "last record of a name wins" (GCI.py:166, 269).  The slot word itself is the
+        // order key (contig, index) + 1 of the record that holds the name: one CAS for a new name, no second table.
+        const unsigned long long ord1 = (((unsigned long long)(uint32_t)r.contig << 32) | i) + 1ull;
+        for (;;) {
+            unsigned long long cur = table[slot];
+            if (cur == SLOT_EMPTY) {
+                cur = atomicCAS(table + slot, SLOT_EMPTY, ord1);
+                if (cur == SLOT_EMPTY) return;
+            }
+            if (same_name(F, 0, i, r, (unsigned long long)(uint32_t)(cur - 1ull))) { atomicMax(table + slot, ord1); return; }
+            slot = (slot + 1) & mask;
+        }
+    }
     for (;;) {
         unsigned long long cur = table[slot];
         if (cur == SLOT_EMPTY) {
@@ -130,14 +144,27 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long 
 #pragma unroll
     for (int k = 0; k < FOLD_PER_THREAD; k++) {
         const uint64_t slot = slot0 + k;
-        const bool used = slot < n_slots && table[slot] != SLOT_EMPTY;
-        ok[k] = used && fold_slot(F, slot, last, F.n > 1 && hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
-        mine += ok[k] ? 1u : 0u;
-        if (used) {                                 // leave the tables as they were found: no clearing launch next time
-            table[slot] = SLOT_EMPTY;
-            if (F.n > 1) hq[slot] = 0u;
-            for (int f = 0; f < F.n; f++) last[slot * F.n + f] = 0ull;
+        const unsigned long long owner = slot < n_slots ? table[slot] : SLOT_EMPTY;
+        const bool used = owner != SLOT_EMPTY;
+        if (F.n == 1) {                             // the slot word is the order key of the name's last record
+            ok[k] = false;
+            if (used) {
+                const gci_rec& r = F.f[0].d_recs[(uint32_t)(owner - 1ull)];
+                int32_t contig = r.contig;
+                if (contig_map) contig = contig_map[contig];
+                ok[k] = contig >= 0;
+                keep[k].contig = contig; keep[k].start = r.start; keep[k].end = r.end; keep[k].pad = 0;
+                table[slot] = SLOT_EMPTY;
+            }
+        } else {
+            ok[k] = used && fold_slot(F, slot, last, hq[slot] != 0, ovlp_percent, contig_map, status, keep[k]);
+            if (used) {                             // leave the tables as they were found: no clearing launch next time
+                table[slot] = SLOT_EMPTY;
+                hq[slot] = 0u;
+                for (int f = 0; f < F.n; f++) last[slot * F.n + f] = 0ull;
+            }
         }
+        mine += ok[k] ? 1u : 0u;
     }
     const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
     if (lane == 63) wtot[wave] = inc;
