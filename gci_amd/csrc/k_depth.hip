@@ -97,6 +97,17 @@ __device__ __forceinline__ TOut block_sum_before(const TIn* __restrict__ in, int
     __shared__ TOut part[BLOCK / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     TOut s = 0;
+    if (stride == 1 && sizeof(TIn) == 4) {                       // n_before is a multiple of TILE: whole 16-byte loads
+        const uint4* in4 = reinterpret_cast<const uint4*>(in);
+        const int64_t n4 = n_before >> 2;
+        for (int64_t i = t; i < n4; i += 8 * BLOCK) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = i + k * BLOCK < n4 ? in4[i + k * BLOCK] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += (TOut)(TIn)v[k].x + (TOut)(TIn)v[k].y + (TOut)(TIn)v[k].z + (TOut)(TIn)v[k].w;
+        }
+    } else
     for (int64_t i = t; i < n_before; i += 8 * BLOCK) {            // eight independent loads in flight per thread
         TIn v[8];
 #pragma unroll
@@ -162,12 +173,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_few(const uint32_t* __restrict_
     // everything in front of this workgroup, eight independent loads in flight per thread
     const int64_t n_before = (int64_t)blockIdx.x * TILE;
     uint32_t bc = 0; int32_t bd = 0;
-    for (int64_t i = t; i < n_before; i += 8 * BLOCK) {
-        uint2 v[8];
+    {
+        const uint4* cdq = reinterpret_cast<const uint4*>(cd_words);        // two tiles per 16-byte load; n_before is even
+        const int64_t n_pairs = n_before >> 1;
+        for (int64_t i = t; i < n_pairs; i += 8 * BLOCK) {
+            uint4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = i + k * BLOCK < n_before ? cd[i + k * BLOCK] : make_uint2(0u, 0u);
+            for (int k = 0; k < 8; k++) v[k] = i + k * BLOCK < n_pairs ? cdq[i + k * BLOCK] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int k = 0; k < 8; k++) { bc += v[k].x; bd += (int32_t)v[k].y; }
+            for (int k = 0; k < 8; k++) { bc += v[k].x + v[k].z; bd += (int32_t)v[k].y + (int32_t)v[k].w; }
+        }
     }
     bc = wave_sum<uint32_t>(bc); bd = wave_sum<int32_t>(bd);
     if (lane == 0) { part_c[wave] = bc; part_d[wave] = bd; }
