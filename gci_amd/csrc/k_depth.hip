@@ -815,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
 
 // The dense tiles: those with more than sparse_max events and (pass 2) those the sparse kernel flagged.  One
 // workgroup looks at DENSE_SPAN consecutive tiles, so that the launch stays small when (as usual) none is dense.
-#define DENSE_SPAN 4
+#define DENSE_SPAN 8
 template <int PASS>
 __global__ __launch_bounds__(BLOCK) void k_tile_dense(
     const uint8_t* __restrict__ dense_flag, int32_t sparse_max, int64_t n_tiles,
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_dense(
             __syncthreads();                                                                                                 \
         }                                                                                                                    \
     }
-    DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3)
+    DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3) DENSE_ONE(4) DENSE_ONE(5) DENSE_ONE(6) DENSE_ONE(7)
 #undef DENSE_ONE
 }
 
