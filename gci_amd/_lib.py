@@ -66,6 +66,8 @@ EXPORTS = [
     ("gci_layout_offsets", c_int, [c_void_p, c_void_p]),
     ("gci_bam_filter", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_int32, c_int, c_int,
                                c_double, c_double, c_uint32, c_void_p, c_void_p]),
+    ("gci_bam_filter_heads", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_int32, c_int, c_int,
+                                     c_double, c_double, c_uint32, c_void_p, c_void_p]),
     ("gci_decode_status", c_int, [c_uint64, POINTER(c_uint32)]),
     ("gci_name_hash", c_uint64, [c_void_p, c_uint32]),
     ("gci_pack_names", c_int, [c_void_p, POINTER(JoinFile), c_void_p, c_uint64, c_void_p]),
@@ -98,6 +100,13 @@ EXPORTS = [
     ("gci_bam_chunk_offsets", c_int, [c_void_p, c_uint64, c_uint64, c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
     ("gci_bgzf_inflate", c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_int, c_int]),
     ("gci_bam_record_offsets", c_int, [c_void_p, c_uint64, c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
+    ("gci_bam_heads", c_int, [c_void_p, c_uint64, c_int, c_uint64, c_int, POINTER(c_void_p)]),
+    ("gci_bam_heads_bytes", c_uint64, [c_void_p]),
+    ("gci_bam_heads_count", c_uint64, [c_void_p]),
+    ("gci_bam_heads_first", c_uint64, [c_void_p]),
+    ("gci_bam_heads_stream", c_void_p, [c_void_p]),
+    ("gci_bam_heads_offsets", c_void_p, [c_void_p]),
+    ("gci_bam_heads_free", c_int, [c_void_p]),
     ("gci_gzip_bound", c_uint64, [c_uint64, c_uint64]),
     ("gci_gzip_members", c_int, [c_void_p, c_uint64, c_uint64, c_int, c_int, c_void_p, c_uint64, POINTER(c_uint64)]),
 ]

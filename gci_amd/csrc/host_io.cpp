@@ -437,3 +437,309 @@ extern "C" int gci_paf_export(const gci_paf* r, int file, gci_rec* h_recs, uint8
 }
 
 extern "C" int gci_paf_free(gci_paf* r) { delete r; return GCI_OK; }
+
+// ---- N1: BGZF file -> heads stream --------------------------------------------------------------------------------
+// The record filter reads a record's fixed part, name, CIGAR and aux block; SEQ and QUAL (98 % of a HiFi record) are
+// skipped by pointer arithmetic (GCI.py:146-169 never looks at them).  gci_bam_heads inflates the file group by group
+// into three rotating buffers (worker threads, member-parallel), walks the block_size chain of the group inflated
+// before (the one serial step, on the calling thread, overlapped with the inflate of the next group) and copies
+// everything but SEQ / QUAL of each record into one compact "heads stream" (workers again):
+//     [BAM header, verbatim][record 0 without SEQ/QUAL][record 1 without SEQ/QUAL] ...
+// block_size of an emitted record is its new length - 4, l_seq keeps its value.  A record whose fields contradict its
+// block_size (l_seq < 0, or name + CIGAR + SEQ + QUAL longer than the record) is emitted as its 36 fixed bytes with
+// l_seq = -1: the filter kernel reports it as GCI_E_MALFORMED with its index, as it would on the full stream.
+// The inflated stream is never held as a whole: host memory is 3 groups + the heads (about 400 B per HiFi record).
+#include <sys/mman.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <new>
+
+namespace {
+
+struct HeadTask { const uint8_t* src; uint64_t dst; uint32_t head, aux_src, aux; int32_t bad; };
+
+// compact form of one complete record at p (block_size already validated >= 32): lengths only
+inline void head_shape(const uint8_t* p, HeadTask& t)
+{
+    int32_t bs, l_seq;
+    memcpy(&bs, p, 4);
+    memcpy(&l_seq, p + 20, 4);
+    const uint32_t l_name = p[12];
+    const uint32_t n_cig = p[16] | (p[17] << 8);
+    const uint64_t head = 36ull + l_name + 4ull * n_cig;
+    const uint64_t seq = l_seq < 0 ? 0 : (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+    const uint64_t total = 4ull + (uint64_t)(uint32_t)bs;
+    t.src = p;
+    if (l_seq < 0 || head + seq > total) { t.bad = 1; t.head = 36; t.aux_src = 0; t.aux = 0; return; }
+    t.bad = 0;
+    t.head = (uint32_t)head;
+    t.aux_src = (uint32_t)(head + seq);
+    t.aux = (uint32_t)(total - head - seq);
+}
+
+inline void head_copy(uint8_t* out, const HeadTask& t)
+{
+    uint8_t* d = out + t.dst;
+    memcpy(d, t.src, t.head);
+    if (t.aux) memcpy(d + t.head, t.src + t.aux_src, t.aux);
+    const int32_t bs = (int32_t)(t.head + t.aux - 4);
+    memcpy(d, &bs, 4);
+    if (t.bad) { const int32_t m1 = -1; memcpy(d + 20, &m1, 4); }
+}
+
+// length of a complete BAM header at p, or 0 when [p, p+n) does not hold all of it yet, or -1 when it is not one
+int64_t bam_header_len(const uint8_t* p, uint64_t n)
+{
+    if (n < 4) return 0;
+    if (memcmp(p, "BAM\1", 4) != 0) return -1;
+    if (n < 12) return 0;
+    int32_t l_text, n_ref;
+    memcpy(&l_text, p + 4, 4);
+    if (l_text < 0) return -1;
+    uint64_t q = 8 + (uint64_t)l_text;
+    if (q + 4 > n) return 0;
+    memcpy(&n_ref, p + q, 4);
+    if (n_ref < 0) return -1;
+    q += 4;
+    for (int32_t i = 0; i < n_ref; i++) {
+        int32_t l_name;
+        if (q + 4 > n) return 0;
+        memcpy(&l_name, p + q, 4);
+        if (l_name < 0) return -1;
+        q += 4 + (uint64_t)l_name + 4;
+        if (q > n) return 0;
+    }
+    return (int64_t)q;
+}
+
+// all-thread rendezvous.  Blocking, not spinning: under a CPU quota (containers) 64 spinning threads burn the quota of
+// the whole process and get it throttled.
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t count = 0, gen = 0;
+    const uint32_t n;
+    explicit Barrier(uint32_t n_) : n(n_) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const uint32_t g = gen;
+        if (++count == n) {
+            count = 0;
+            gen++;
+            lk.unlock();
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+
+bool inflate_member(const uint8_t* raw, const Block& b, uint8_t* out, int check_crc)
+{
+    if (b.isize == 0) return true;
+    const uint8_t* h = raw + b.pos;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(h + 12 + xlen);
+    zs.avail_in = (uInt)(b.size - 12 - xlen - 8);
+    zs.next_out = out;
+    zs.avail_out = (uInt)b.isize;
+    const int r = inflate(&zs, Z_FINISH);
+    bool ok = r == Z_STREAM_END && zs.total_out == b.isize;
+    inflateEnd(&zs);
+    if (ok && check_crc) {
+        uint32_t crc;
+        memcpy(&crc, h + b.size - 8, 4);
+        ok = (uint32_t)crc32(0L, out, (uInt)b.isize) == crc;
+    }
+    return ok;
+}
+
+struct Group { size_t lo, hi; uint64_t bytes; };
+
+}  // namespace
+
+struct gci_heads {
+    uint8_t* stream = nullptr;        // mmap'ed, reserved = inflated size of the file (an upper bound), touched = n_bytes
+    uint64_t reserved = 0, n_bytes = 0, first_record = 0;
+    std::vector<uint64_t> offs;
+    ~gci_heads() { if (stream) munmap(stream, reserved); }
+};
+
+extern "C" int gci_bam_heads(const uint8_t* h_raw, uint64_t n_raw, int threads, uint64_t group_bytes, int check_crc,
+                             gci_heads** out)
+{
+    if ((!h_raw && n_raw) || !out) return GCI_E_INVALID;
+    *out = nullptr;
+    std::vector<Block> blocks;
+    uint64_t total = 0;
+    const int st = scan(h_raw, n_raw, blocks, total);
+    if (st) return st;
+    if (group_bytes == 0) group_bytes = 16ull << 20;
+    // groups of whole members, at most group_bytes each (a member inflates to <= 64 KiB; at least one per group)
+    std::vector<Group> groups;
+    uint64_t cap = 0;
+    for (size_t i = 0; i < blocks.size();) {
+        size_t j = i;
+        uint64_t acc = 0;
+        while (j < blocks.size() && (j == i || acc + blocks[j].isize <= group_bytes)) acc += blocks[j++].isize;
+        groups.push_back({i, j, acc});
+        cap = acc > cap ? acc : cap;
+        i = j;
+    }
+    gci_heads* H = new (std::nothrow) gci_heads;
+    if (!H) return GCI_E_NOMEM;
+    H->reserved = total + 64;
+    void* m = mmap(nullptr, H->reserved, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) { delete H; return GCI_E_NOMEM; }
+    H->stream = (uint8_t*)m;
+    std::unique_ptr<uint8_t[]> bufs[3];                        // not zero-filled: first touched by the inflating threads
+    for (auto& b : bufs) {
+        b.reset(new (std::nothrow) uint8_t[cap + 64]);
+        if (!b) { delete H; return GCI_E_NOMEM; }
+    }
+
+    const int n_groups = (int)groups.size();
+    if (threads < 2) threads = 2;                               // the chaser + at least one worker
+    const int n_workers = threads - 1;
+    Barrier bar((uint32_t)n_workers + 1);
+    std::atomic<int> err{GCI_OK};
+    std::vector<HeadTask> tasks[2];                            // tasks[g & 1] = records of group g that lie inside its buffer
+    const int n_steps = n_groups + 2;
+    std::unique_ptr<std::atomic<uint64_t>[]> next_member(new std::atomic<uint64_t>[n_steps]);
+    std::unique_ptr<std::atomic<uint64_t>[]> next_task(new std::atomic<uint64_t>[n_steps]);
+    for (int s = 0; s < n_steps; s++) { next_member[s].store(0); next_task[s].store(0); }
+
+    // step s: the workers inflate group s (into buffer s % 3) and copy the heads of group s - 2 (out of buffer
+    // (s - 2) % 3) while the caller chases group s - 1 (buffer (s - 1) % 3); one rendezvous per step
+    auto worker = [&]() {
+        for (int s = 0; s < n_steps; s++) {
+            if (s < n_groups && err.load(std::memory_order_relaxed) == GCI_OK) {
+                const Group& g = groups[s];
+                uint8_t* buf = bufs[s % 3].get();
+                for (;;) {
+                    const uint64_t a = next_member[s].fetch_add(4);
+                    if (a >= g.hi - g.lo) break;
+                    for (uint64_t k = a; k < a + 4 && k < g.hi - g.lo; k++) {
+                        const Block& b = blocks[g.lo + k];
+                        if (!inflate_member(h_raw, b, buf + (b.out - blocks[g.lo].out), check_crc)) err = GCI_E_MALFORMED;
+                    }
+                }
+            }
+            if (s >= 2) {
+                const std::vector<HeadTask>& T = tasks[s & 1];
+                for (;;) {
+                    const uint64_t a = next_task[s].fetch_add(64);
+                    if (a >= T.size()) break;
+                    for (uint64_t k = a; k < a + 64 && k < T.size(); k++) head_copy(H->stream, T[k]);
+                }
+            }
+            bar.wait();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_workers; t++) pool.emplace_back(worker);
+
+    // ---- the chaser
+    std::vector<uint8_t> carry;                                 // a header or record that straddles groups, assembled here
+    bool in_header = true;
+    uint64_t w = 0;                                             // bytes of heads stream assigned so far
+    int chase_err = GCI_OK;
+    auto emit_direct = [&](const uint8_t* p) {                   // a record assembled in `carry`: copied here and now
+        HeadTask t;
+        head_shape(p, t);
+        t.dst = w;
+        head_copy(H->stream, t);
+        H->offs.push_back(w);
+        w += t.head + t.aux;
+    };
+    auto chase = [&](const uint8_t* D, uint64_t n, std::vector<HeadTask>& T) {
+        uint64_t p = 0;
+        if (in_header) {
+            const uint8_t* src = D;
+            uint64_t len = n;
+            if (!carry.empty()) { carry.insert(carry.end(), D, D + n); src = carry.data(); len = carry.size(); }
+            const int64_t hl = bam_header_len(src, len);
+            if (hl < 0) { chase_err = GCI_E_MALFORMED; return; }
+            if (hl == 0) { if (carry.empty()) carry.assign(D, D + n); return; }
+            memcpy(H->stream, src, (size_t)hl);
+            w = H->first_record = (uint64_t)hl;
+            in_header = false;
+            if (!carry.empty()) {                               // header longer than a group (rare): go on inside `carry`
+                std::vector<uint8_t> rest(carry.begin() + hl, carry.end());
+                carry.clear();
+                uint64_t q = 0;
+                while (q + 4 <= rest.size()) {
+                    int32_t bs;
+                    memcpy(&bs, rest.data() + q, 4);
+                    if (bs < 32) { chase_err = GCI_E_MALFORMED; return; }
+                    if (q + 4 + (uint64_t)bs > rest.size()) break;
+                    emit_direct(rest.data() + q);
+                    q += 4 + (uint64_t)bs;
+                }
+                carry.assign(rest.begin() + q, rest.end());
+                return;
+            }
+            p = (uint64_t)hl;
+        } else if (!carry.empty()) {
+            // complete the straddling record from the front of this group
+            while (p < n) {
+                if (carry.size() < 4) { carry.push_back(D[p++]); continue; }
+                int32_t bs;
+                memcpy(&bs, carry.data(), 4);
+                if (bs < 32) { chase_err = GCI_E_MALFORMED; return; }
+                const uint64_t need = 4ull + (uint64_t)bs - carry.size();
+                const uint64_t take = need < n - p ? need : n - p;
+                carry.insert(carry.end(), D + p, D + p + take);
+                p += take;
+                if (take == need) { emit_direct(carry.data()); carry.clear(); break; }
+            }
+            if (!carry.empty()) return;                          // the group ended inside the record
+        }
+        while (p + 4 <= n) {
+            int32_t bs;
+            memcpy(&bs, D + p, 4);
+            if (bs < 32) { chase_err = GCI_E_MALFORMED; return; }
+            if (p + 4 + (uint64_t)bs > n) break;
+            HeadTask t;
+            head_shape(D + p, t);
+            t.dst = w;
+            T.push_back(t);
+            H->offs.push_back(w);
+            w += t.head + t.aux;
+            p += 4 + (uint64_t)bs;
+        }
+        carry.assign(D + p, D + n);
+    };
+
+    for (int s = 0; s < n_steps; s++) {
+        if (s >= 1 && s <= n_groups) {
+            std::vector<HeadTask>& T = tasks[(s - 1) & 1];
+            T.clear();
+            if (!chase_err && err.load() == GCI_OK) chase(bufs[(s - 1) % 3].get(), groups[s - 1].bytes, T);
+            if (chase_err) { err = chase_err; T.clear(); }
+        } else if (s > n_groups) {
+            tasks[(s - 1) & 1].clear();
+        }
+        bar.wait();
+    }
+    for (auto& th : pool) th.join();
+    int rc = err.load();
+    if (rc == GCI_OK && (in_header || !carry.empty())) rc = GCI_E_MALFORMED;       // no header / truncated last record
+    if (rc != GCI_OK) { delete H; return rc; }
+    H->n_bytes = w;
+    *out = H;
+    return GCI_OK;
+}
+
+extern "C" uint64_t gci_bam_heads_bytes(const gci_heads* h) { return h ? h->n_bytes : 0; }
+extern "C" uint64_t gci_bam_heads_count(const gci_heads* h) { return h ? h->offs.size() : 0; }
+extern "C" uint64_t gci_bam_heads_first(const gci_heads* h) { return h ? h->first_record : 0; }
+extern "C" const uint8_t* gci_bam_heads_stream(const gci_heads* h) { return h ? h->stream : nullptr; }
+extern "C" const uint64_t* gci_bam_heads_offsets(const gci_heads* h) { return h ? h->offs.data() : nullptr; }
+extern "C" int gci_bam_heads_free(gci_heads* h) { delete h; return GCI_OK; }

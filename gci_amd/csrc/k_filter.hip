@@ -61,6 +61,7 @@ struct LongQueue {
     unsigned long long* chunks;  // (item << 32) | chunk index; ~0 = hole left by a refused item
     ChunkSums* sums;             // per queue entry
     uint32_t cap_items, cap_chunks;
+    uint32_t has_seq;            // 0: heads stream (records without SEQ / QUAL, gci_bam_heads)
 };
 
 __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec, int code)
@@ -279,7 +280,7 @@ __device__ __forceinline__ void slow_record(
     const uint8_t* name = p + 36;
     const uint8_t* rec_end = p + 4 + block_size;
     const uint8_t* cig = name + l_read_name;
-    const uint8_t* aux = cig + 4 * (uint64_t)n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+    const uint8_t* aux = cig + 4 * (uint64_t)n_cigar + (lq.has_seq ? (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq : 0ull);
     // query_name and its hash, lanes striding over bytes / words
     uint32_t nul = l_read_name;
     for (uint32_t i = lane; i < l_read_name; i += 64) if (name[i] == 0) { nul = i; break; }
@@ -410,7 +411,9 @@ __global__ __launch_bounds__(KB) void k_bam_filter(
     const uint32_t flag = w16 >> 16;
     const int32_t l_seq = (int32_t)lds_u32(hd + 20);
     const uint64_t rec_end = off + 4 + (uint64_t)(uint32_t)block_size;
-    const uint64_t aux_off = off + 36 + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+    // a heads stream (gci_bam_heads) holds the records without their SEQ / QUAL bytes; l_seq keeps its value
+    const uint64_t aux_off = off + 36 + l_read_name + 4ull * n_cigar +
+                             (lq.has_seq ? (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq : 0ull);
     r.mapq = (uint8_t)mapq;
     if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) {
         if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); out[rec] = r; }
@@ -713,10 +716,10 @@ __global__ __launch_bounds__(BLOCK) void k_cigar_finish(const LongQueue lq, int 
     }
 }
 
-extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
-                              uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
-                              double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
-                              uint64_t* d_status)
+static int bam_filter_impl(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
+                           uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                           double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                           uint64_t* d_status, bool has_seq)
 {
     if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
     // scratch: [2 x (n_slow u32, pad, n_long u64)][2 x status u64][pad][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
@@ -750,6 +753,7 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
     lq.chunks = (unsigned long long*)((uint8_t*)lq.items + (size_t)cap_items * sizeof(LongItem));
     lq.sums = (ChunkSums*)(lq.chunks + cap_chunks);
     lq.cap_items = cap_items; lq.cap_chunks = cap_chunks;
+    lq.has_seq = has_seq ? 1u : 0u;
     if (n_rec == 0) { HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream)); return GCI_OK; }
     ctx->k1_parity ^= 1u;                   // the fast kernel below zeroes the other set for the next call
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
@@ -769,6 +773,25 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
                        ctx->stream, lq, mq_cutoff, clip_percent, iden_percent, d_out, (unsigned long long*)d_status);
     LAUNCHCHK("k_cigar_finish");
     return GCI_OK;
+}
+
+extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
+                              uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                              double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                              uint64_t* d_status)
+{
+    return bam_filter_impl(ctx, d_bam, n_bytes, d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent,
+                           iden_percent, rec_idx_base, d_out, d_status, true);
+}
+
+// The same filter over a heads stream (gci_bam_heads: every record without its SEQ and QUAL bytes).
+extern "C" int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes, const uint64_t* d_rec_off,
+                                    uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                                    double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                                    uint64_t* d_status)
+{
+    return bam_filter_impl(ctx, d_heads, n_bytes, d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent,
+                           iden_percent, rec_idx_base, d_out, d_status, false);
 }
 
 extern "C" int gci_decode_status(uint64_t w, uint32_t* rec_idx)

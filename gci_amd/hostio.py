@@ -20,7 +20,28 @@ def _chk(st: int, what: str) -> None:
 
 
 def default_threads() -> int:
-    return max(1, min(64, os.cpu_count() or 1))
+    """Host threads for the native helpers: the CPUs this process may really use -- the affinity mask and, inside a
+    container, the cgroup CPU quota (twice the quota: the helpers block on memory) -- at most 64."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, 2 * -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(64, n))
+
+
+def pick_threads(requested: int = 1) -> int:
+    """`-t` is a hint (results never depend on it): the default of 1 means "all this process may use", a larger value
+    is honoured up to that."""
+    d = default_threads()
+    return d if int(requested) <= 1 else min(int(requested), d)
 
 
 def bgzf_inflate(raw, threads: int = 0, out: np.ndarray = None, check_crc: bool = False) -> np.ndarray:
@@ -95,6 +116,45 @@ def bam_chunk_offsets(buf: np.ndarray, start: int = 0) -> Tuple[np.ndarray, int]
     _chk(lib.gci_bam_chunk_offsets(p, buf.shape[0], int(start), offs.ctypes.data_as(ctypes.c_void_p), offs.shape[0],
                                    ctypes.byref(n), ctypes.byref(used)), "gci_bam_chunk_offsets")
     return offs, int(used.value)
+
+
+class BamHeads:
+    """A BAM file as its heads stream (gci_bam_heads): the BAM header followed by every record without SEQ / QUAL, and
+    the offset of every record.  `stream` and `offsets` are views into native memory, valid until close()."""
+
+    def __init__(self, handle, stream: np.ndarray, offsets: np.ndarray, first_record: int):
+        self._h, self.stream, self.offsets, self.first_record = handle, stream, offsets, first_record
+
+    def close(self) -> None:
+        if self._h is not None:
+            self.stream = self.offsets = None
+            _lib.load().gci_bam_heads_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def bam_heads(raw: np.ndarray, threads: int = 0, group_bytes: int = 0, check_crc: bool = False) -> BamHeads:
+    """BGZF bytes of a BAM file -> BamHeads, inflate / record walk / compaction pipelined in native threads."""
+    lib = _lib.load()
+    raw = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    h = ctypes.c_void_p(None)
+    _chk(lib.gci_bam_heads(raw.ctypes.data_as(ctypes.c_void_p), raw.shape[0], int(threads or default_threads()),
+                           int(group_bytes), int(check_crc), ctypes.byref(h)), "gci_bam_heads")
+    nb, nr = int(lib.gci_bam_heads_bytes(h)), int(lib.gci_bam_heads_count(h))
+    stream = np.ctypeslib.as_array(ctypes.cast(lib.gci_bam_heads_stream(h), ctypes.POINTER(ctypes.c_uint8)), shape=(nb,))
+    if nr:
+        offs = np.ctypeslib.as_array(ctypes.cast(lib.gci_bam_heads_offsets(h), ctypes.POINTER(ctypes.c_uint64)), shape=(nr,))
+    else:
+        offs = np.zeros(0, dtype=np.uint64)
+    return BamHeads(h, stream, offs, int(lib.gci_bam_heads_first(h)))
 
 
 def paf_filter(paths, targets, map_qual: int, mq_cutoff: int, iden_percent: float):

@@ -239,7 +239,7 @@ def _paf_join_input(engine: Engine, d: Dict[str, Tuple[str, int, int, int]], hig
 def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
     """Inflate (native host threads), find record boundaries (the one serial step), upload."""
     from . import hostio
-    stream = hostio.read_bgzf_file(path, threads=max(int(threads), hostio.default_threads()))
+    stream = hostio.read_bgzf_file(path, threads=hostio.pick_threads(threads))
     hdr = bamfmt.parse_header(stream)
     offs, first = hostio.bam_record_offsets(stream)
     assert first == hdr.first_record
@@ -252,19 +252,24 @@ BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
 
 
 def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
-                   threads: int = 1, chunk_bytes: Optional[int] = None) -> JoinInput:
+                   threads: int = 1, chunk_bytes: Optional[int] = None, ingest: Optional[str] = None) -> JoinInput:
     """K1 over one BAM file -> the file's join input (compact records + where their names are).
 
-    Small files: one upload, names stay addressable inside the inflated stream.  Large files: groups of BGZF
-    members are inflated into a host buffer (the next group on a background thread while the GPU works on the
-    current one), the partial record at the end of a group is carried over, K1 runs per chunk and only the 32-byte
-    records and the packed names (gci_pack_names) are kept on the device."""
+    ingest = "heads" (default; GCI_BAM_INGEST overrides): the native host pipeline (gci_bam_heads) inflates the file
+    group by group and keeps every record without its SEQ / QUAL bytes; only that heads stream (about 400 B of a
+    27 KB HiFi record) is uploaded and filtered (gci_bam_filter_heads); names stay addressable inside it.
+    ingest = "full" (or an explicit chunk_bytes): the whole inflated stream goes to the device.  Small files: one
+    upload.  Large files: groups of BGZF members are inflated into a host buffer (the next group on a background
+    thread while the GPU works on the current one), the partial record at the end of a group is carried over, K1
+    runs per chunk and only the 32-byte records and the packed names (gci_pack_names) are kept on the device."""
     from concurrent.futures import ThreadPoolExecutor
     from . import hostio
+    ingest = ingest or ("full" if chunk_bytes else os.environ.get("GCI_BAM_INGEST", "heads"))
+    if ingest not in ("heads", "full"):
+        raise ValueError("ingest must be 'heads' or 'full'")
     chunk_bytes = int(chunk_bytes or BAM_CHUNK_BYTES)
-    nthreads = max(int(threads), hostio.default_threads())
+    nthreads = hostio.pick_threads(threads)
     raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
-    pos, isz = hostio.bgzf_blocks(np.asarray(raw))
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
 
     def ref_sel_for(hdr):
@@ -274,6 +279,14 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         tindex = {t: i for i, t in enumerate(targets)}
         return engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
 
+    if ingest == "heads":
+        with hostio.bam_heads(np.asarray(raw), threads=nthreads) as heads:
+            hdr = bamfmt.parse_header(heads.stream)
+            d_bam, d_off = engine.to_device(heads.stream), engine.to_device(heads.offsets)
+        recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
+        return JoinInput(recs, d_bam, d_off, 36)
+
+    pos, isz = hostio.bgzf_blocks(np.asarray(raw))
     if int(isz.sum()) <= chunk_bytes:
         stream = hostio.bgzf_inflate(np.asarray(raw), threads=nthreads)
         hdr = bamfmt.parse_header(stream)
@@ -424,7 +437,7 @@ def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, thread
     path = f"{directory}/{prefix}.depth.gz"
     if os.path.exists(path):
         os.remove(path)
-    nthreads = max(int(threads), hostio.default_threads())
+    nthreads = hostio.pick_threads(threads)
     with open(path, "wb") as f:
         for c, t in enumerate(depths.targets):
             f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))

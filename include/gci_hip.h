@@ -151,6 +151,13 @@ int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const u
                    uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
                    double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
                    uint64_t* d_status);
+/* The same filter over a HEADS STREAM (gci_bam_heads below): the BAM header followed by every record without its
+ * SEQ and QUAL bytes (block_size shortened accordingly, l_seq unchanged) -- the bytes read_sam never looks at
+ * (GCI.py:146-169), 98 % of a HiFi record.  Same outputs, same status word. */
+int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes, const uint64_t* d_rec_off,
+                         uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                         double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                         uint64_t* d_status);
 int gci_decode_status(uint64_t status_word, uint32_t* rec_idx);   /* -> gci_status */
 /* The name hash K1 uses, for hosts that build gci_rec themselves (PAF path). */
 uint64_t gci_name_hash(const uint8_t* h_name, uint32_t len);
@@ -270,7 +277,26 @@ int gci_fasta_n_scan(gci_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, cons
  *   gci_gzip_members         gzip-frame text as independent members of `chunk` input bytes, compressed in
  *                            parallel (any multi-member gzip whose payload equals the text is a valid .depth.gz)
  *   gci_bgzf_blocks / gci_bam_chunk_offsets   the same for a host that streams a large file chunk by chunk: the
- *                            member table, and the record offsets of one chunk with the partial tail reported */
+ *                            member table, and the record offsets of one chunk with the partial tail reported
+ *   gci_bam_heads            BGZF file bytes -> heads stream + record offsets in one pipelined pass (replaces
+ *                            pysam's AlignmentFile + fetch, GCI.py:150-151, for a host that feeds
+ *                            gci_bam_filter_heads): groups of `group_bytes` (0 = 16 MiB) of inflated members rotate
+ *                            through three buffers -- worker threads inflate group g while the caller's thread walks
+ *                            the block_size chain of group g-1 and the workers copy the heads of group g-2 -- so the
+ *                            inflated stream (27 KB per HiFi record) never exists as a whole and only ~400 B per
+ *                            record cross PCIe.  A record whose l_seq / name / CIGAR lengths contradict its
+ *                            block_size is emitted as its 36 fixed bytes with l_seq = -1 (the filter reports
+ *                            GCI_E_MALFORMED with its index, as on the full stream); block_size < 32, a bad
+ *                            member or a truncated last record return GCI_E_MALFORMED here.
+ *                            gci_bam_heads_stream / _offsets stay valid until gci_bam_heads_free. */
+typedef struct gci_heads gci_heads;
+int gci_bam_heads(const uint8_t* h_raw, uint64_t n_raw, int threads, uint64_t group_bytes, int check_crc, gci_heads** out);
+uint64_t gci_bam_heads_bytes(const gci_heads* h);          /* length of the heads stream */
+uint64_t gci_bam_heads_count(const gci_heads* h);          /* records */
+uint64_t gci_bam_heads_first(const gci_heads* h);          /* length of the BAM header = offset of record 0 */
+const uint8_t* gci_bam_heads_stream(const gci_heads* h);
+const uint64_t* gci_bam_heads_offsets(const gci_heads* h); /* offset of every record's block_size word */
+int gci_bam_heads_free(gci_heads* h);
 int gci_bgzf_scan(const uint8_t* h_raw, uint64_t n_raw, uint64_t* n_blocks, uint64_t* inflated_bytes);
 int gci_bgzf_blocks(const uint8_t* h_raw, uint64_t n_raw, uint64_t* h_pos, uint64_t* h_isize, uint64_t cap,
                     uint64_t* n_blocks);

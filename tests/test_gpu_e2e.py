@@ -176,8 +176,9 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     want_d, hq = oracle.bam_file_dict(stream, offs, targets, targets, *filt)
     want = oracle.depth_build(oracle.name_join([want_d], hq, 0.9), tl, 15)
     engine.set_layout([tl[t] for t in targets])
-    for chunk in (None, 9_000_001, 1_234_567, 300_000):
-        ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk)
+    # heads stream (the default), the whole inflated stream in one upload, and streamed in chunks
+    for chunk, ingest in ((None, None), (None, "full"), (9_000_001, None), (1_234_567, None), (300_000, None)):
+        ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk, ingest=ingest)
         assert ji.recs.shape[0] == len(rs)
         assert (ji.name_delta == 0) == (chunk is not None)
         ivl, cnt = engine.name_join([ji], 0.9)
@@ -194,6 +195,7 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     d2, h2 = oracle.bam_file_dict(s2, o2, targets, targets, *filt)
     want2 = oracle.depth_build(oracle.name_join([want_d, d2], hq | h2, 0.9), tl, 15)
     monkeypatch.setattr(pipeline, "BAM_CHUNK_BYTES", 2_000_000)
+    monkeypatch.setenv("GCI_BAM_INGEST", "full")
     depths, _ = pipeline.filter([], [p, p2], prefix="st", directory=str(tmp_path), engine=engine, threads=4)
     for t in targets:
         assert np.array_equal(depths[t], want2[t]), t

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from bam_util import heads_expected
 from gci_amd import synth
 from gci_amd.device import JoinInput, REC_DTYPE, name_hash_np
 from gci_amd import pipeline
@@ -25,7 +26,14 @@ def _filter_case(engine, oracle, rs, targets=None, mq=30, cut=50, cp=0.1, ip=0.9
     ref_sel = np.array([tindex.get(r, -1) for r in refs], dtype=np.int32)
     want = oracle.bam_filter_arrays(stream, offs, ref_sel, mq, cut, cp, ip)
     d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
-    got = _recs_np(engine.bam_filter(d_bam, d_off, engine.to_device(ref_sel), mq, cut, cp, ip))
+    full = engine.bam_filter(d_bam, d_off, engine.to_device(ref_sel), mq, cut, cp, ip).clone()
+    got = _recs_np(full)
+    # the same records without their SEQ / QUAL bytes (what the command line uploads): the same 32 bytes per record
+    from gci_amd.formats import bam
+    h_bytes, h_offs = heads_expected(stream, offs, bam.parse_header(stream).first_record)
+    via_heads = engine.bam_filter(engine.to_device(np.frombuffer(h_bytes, dtype=np.uint8)), engine.to_device(h_offs),
+                                  engine.to_device(ref_sel), mq, cut, cp, ip, heads=True)
+    assert torch.equal(via_heads, full)
     p = want["passed"].astype(bool)
     assert np.array_equal((got["flags"] & 1).astype(bool), p)
     assert np.array_equal(((got["flags"] & 2) != 0), want["hq"].astype(bool))
@@ -573,6 +581,8 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
     stream = np.frombuffer(hdr + b"".join(recs), dtype=np.uint8).copy()
     offs = bam.record_offsets(stream, bam.parse_header(stream).first_record)
     d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+    h_bytes, h_offs = heads_expected(stream, offs, bam.parse_header(stream).first_record)
+    d_heads = engine.to_device(np.frombuffer(h_bytes, dtype=np.uint8))
     n_checked = 0
     for ref_sel, (cp, ip) in ((np.array([0, 1, 2, 3, 4], np.int32), (0.1, 0.9)), (np.array([-1, 0, -1, 1, -1], np.int32), (0.5, 0.5))):
         # the reference raises on the first bad record; remove offenders one by one until the oracle is clean, checking
@@ -589,9 +599,17 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
                 assert g.value.status == e.status, (e.status, g.value.status)
                 # the GPU reports the FIRST failing record in file order, like the oracle's loop
                 assert g.value.rec == e.rec
+                with pytest.raises(GciErr) as gh:                       # the same through the heads stream
+                    engine.bam_filter(d_heads, engine.to_device(h_offs[keep]), engine.to_device(ref_sel), 30, 50, cp, ip,
+                                      heads=True)
+                assert (gh.value.status, gh.value.rec) == (e.status, e.rec)
                 keep[np.flatnonzero(keep)[e.rec]] = False
                 n_checked += 1
-        got = _recs_np(engine.bam_filter(d_bam, engine.to_device(o_sub), engine.to_device(ref_sel), 30, 50, cp, ip))
+        full = engine.bam_filter(d_bam, engine.to_device(o_sub), engine.to_device(ref_sel), 30, 50, cp, ip).clone()
+        got = _recs_np(full)
+        via_heads = engine.bam_filter(d_heads, engine.to_device(h_offs[keep]), engine.to_device(ref_sel), 30, 50, cp, ip,
+                                      heads=True)
+        assert torch.equal(via_heads, full)                              # records without SEQ / QUAL: same 32 bytes out
         p = want["passed"].astype(bool)
         assert np.array_equal((got["flags"] & 1).astype(bool), p)
         assert np.array_equal((got["flags"] & 2) != 0, want["hq"].astype(bool))

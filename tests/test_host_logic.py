@@ -9,6 +9,7 @@ import re
 import numpy as np
 import pytest
 
+from bam_util import heads_expected
 from golden_util import GOLDEN, expected, inputs, manifest
 from gci_amd import score
 from gci_amd.formats import depthfile, fasta
@@ -200,3 +201,53 @@ def test_native_host_io_matches_python_twins(tmp_path):
     z = hostio.gzip_members(text, threads=4, chunk=100_000)
     assert _gz.decompress(z) == text and z.count(b"\x1f\x8b\x08") >= len(text) // 100_000
     assert hostio.gzip_members(b"") == b""
+
+
+@pytest.mark.parametrize("kind,seed", [("hifi", 5), ("ont", 6)])
+def test_bam_heads_stream(tmp_path, kind, seed):
+    """gci_bam_heads (host_io.cpp): BGZF bytes -> header + records without SEQ / QUAL, for group sizes that cut the
+    header and the records at every phase; contradictory records are marked, truncated / corrupt input is refused."""
+    from gci_amd import hostio, synth
+    from gci_amd._lib import GciError
+    from gci_amd.formats import bam
+    many = tuple(("contig_with_a_long_name_%04d" % i, 30_000 + i) for i in range(3000))   # header > 64 KiB
+    rs = synth.simulate_reads((("a", 300_000), ("b", 90_000)) if kind == "hifi" else (("a", 200_000),), 8, kind, seed=seed)
+    stream, offs = synth.to_bam_stream(rs)
+    stream = stream.copy()
+    first = bam.parse_header(stream).first_record
+    # two records that contradict their block_size: negative l_seq, and SEQ + QUAL longer than the record
+    stream[int(offs[3]) + 20:int(offs[3]) + 24] = np.frombuffer(np.int32(-7).tobytes(), dtype=np.uint8)
+    stream[int(offs[9]) + 20:int(offs[9]) + 24] = np.frombuffer(np.int32(1 << 28).tobytes(), dtype=np.uint8)
+    if kind == "hifi":                                                   # and a long header in front
+        hdr = np.frombuffer(bam.encode_header(["a", "b"] + [n for n, _ in many], [300_000, 90_000] + [l for _, l in many]),
+                            dtype=np.uint8)
+        assert hdr.shape[0] > 2 * 65_536
+        offs = offs - np.uint64(first) + np.uint64(hdr.shape[0])
+        stream = np.concatenate([hdr, stream[first:]])
+        first = int(hdr.shape[0])
+    p = str(tmp_path / "h.bam")
+    bam.write_bam_stream(p, stream, level=1, threads=4)
+    raw = np.fromfile(p, dtype=np.uint8)
+    want, want_offs = heads_expected(stream, offs, first)
+    for group in (0, 1 << 20, 70_000, 65_536, 1):
+        with hostio.bam_heads(raw, threads=4, group_bytes=group, check_crc=True) as h:
+            assert h.first_record == first
+            assert np.array_equal(h.offsets, want_offs), group
+            assert h.stream.tobytes() == want, group
+    assert len(want) - first < (stream.shape[0] - first) // (20 if kind == "hifi" else 2)
+    with pytest.raises(GciError):
+        hostio.bam_heads(raw[:-41], threads=3)                             # truncated last member
+    cut = str(tmp_path / "cut.bam")
+    bam.write_bam_stream(cut, stream[:-9], level=1, threads=2)             # truncated last record
+    with pytest.raises(GciError):
+        hostio.bam_heads(np.fromfile(cut, dtype=np.uint8), threads=3)
+    bad = raw.copy(); bad[len(bad) // 2] ^= 0xFF
+    with pytest.raises(GciError):
+        hostio.bam_heads(bad, threads=3, check_crc=True)
+    short = stream.copy()
+    short[int(offs[5]):int(offs[5]) + 4] = np.frombuffer(np.int32(31).tobytes(), dtype=np.uint8)   # block_size < 32
+    bam.write_bam_stream(cut, short, level=1, threads=2)
+    with pytest.raises(GciError):
+        hostio.bam_heads(np.fromfile(cut, dtype=np.uint8), threads=3)
+    with pytest.raises(GciError):
+        hostio.bam_heads(np.zeros(0, dtype=np.uint8))                      # no header at all
