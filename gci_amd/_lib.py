@@ -107,6 +107,7 @@ EXPORTS = [
     ("gci_bam_heads_stream", c_void_p, [c_void_p]),
     ("gci_bam_heads_offsets", c_void_p, [c_void_p]),
     ("gci_bam_heads_free", c_int, [c_void_p]),
+    ("gci_fasta_titles", c_int, [c_void_p, c_uint64, c_int, c_void_p, c_uint64, POINTER(c_uint64)]),
     ("gci_gzip_bound", c_uint64, [c_uint64, c_uint64]),
     ("gci_gzip_members", c_int, [c_void_p, c_uint64, c_uint64, c_int, c_int, c_void_p, c_uint64, POINTER(c_uint64)]),
 ]

@@ -58,7 +58,7 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
             os.makedirs(f"{directory}/images")
         image_type = image_type.lower()
 
-    ref_refs = fasta.record_ids(reference)
+    ref_refs = fasta.record_ids_indexed(reference)
     if len(chrs_list) > 0:
         for i in chrs_list:
             if i not in ref_refs:

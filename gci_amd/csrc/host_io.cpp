@@ -743,3 +743,30 @@ extern "C" uint64_t gci_bam_heads_first(const gci_heads* h) { return h ? h->firs
 extern "C" const uint8_t* gci_bam_heads_stream(const gci_heads* h) { return h ? h->stream : nullptr; }
 extern "C" const uint64_t* gci_bam_heads_offsets(const gci_heads* h) { return h ? h->offs.data() : nullptr; }
 extern "C" int gci_bam_heads_free(gci_heads* h) { delete h; return GCI_OK; }
+
+// ---- FASTA record index (host): byte offsets of every '>' that begins a line, in file order ---------------------------
+// (SeqIO.parse at GCI.py:30 / :940 yields one record per such line.)  memchr over `threads` slices of the text.
+extern "C" int gci_fasta_titles(const uint8_t* h_text, uint64_t n, int threads, uint64_t* h_pos, uint64_t cap, uint64_t* n_pos)
+{
+    if ((!h_text && n) || !n_pos || (!h_pos && cap)) return GCI_E_INVALID;
+    if (threads < 1) threads = 1;
+    const uint64_t slices = n < (1u << 20) ? 1 : (uint64_t)threads * 4;
+    std::vector<std::vector<uint64_t>> found(slices);
+    parallel_for(slices, threads, [&](uint64_t i) {
+        const uint64_t a = n * i / slices, b = n * (i + 1) / slices;
+        const uint8_t* p = h_text + a;
+        while (p < h_text + b) {
+            p = (const uint8_t*)memchr(p, '>', (size_t)(h_text + b - p));
+            if (!p) break;
+            if (p == h_text || p[-1] == '\n') found[i].push_back((uint64_t)(p - h_text));
+            p++;
+        }
+    });
+    uint64_t k = 0;
+    for (auto& f : found) k += f.size();
+    *n_pos = k;
+    if (k > cap) return h_pos ? GCI_E_CAPACITY : GCI_OK;
+    k = 0;
+    for (auto& f : found) for (uint64_t v : f) h_pos[k++] = v;
+    return GCI_OK;
+}

@@ -90,12 +90,51 @@ def record_spans(buf: np.ndarray) -> List[Tuple[str, int, int]]:
     return out
 
 
+_INDEXED = None           # (key, bytes of the file, record spans) of the file read last: the command line asks for the
+                          # record ids first (GCI.py:939-941) and for the N runs afterwards (GCI.py:29-35)
+
+
+def indexed(path: str):
+    """-> (file bytes, [(id, body begin, body end)]), title lines found by the native helper (gci_fasta_titles); the
+    result for the last file is kept until n_runs_device() has used it."""
+    global _INDEXED
+    import os
+    from .. import hostio
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_size, st.st_mtime_ns)
+    if _INDEXED is not None and _INDEXED[0] == key:
+        return _INDEXED[1], _INDEXED[2]
+    buf = load(path)
+    n = int(buf.shape[0])
+    starts = [int(p) for p in hostio.fasta_titles(buf)]
+    spans = []
+    for k, hs in enumerate(starts):
+        stop = starts[k + 1] if k + 1 < len(starts) else n
+        he, step = -1, 4096
+        while he < 0:                                       # the end of the title line, looked for in growing windows
+            nl = np.flatnonzero(buf[hs:min(hs + step, stop)] == 10)
+            if nl.shape[0]:
+                he = hs + int(nl[0])
+            elif hs + step >= stop:
+                he = stop
+            step *= 16
+        parts = bytes(buf[hs + 1:he]).decode(errors="replace").rstrip().split(None, 1)
+        spans.append((parts[0] if parts else "", min(he + 1, stop), stop))
+    _INDEXED = (key, buf, spans)
+    return buf, spans
+
+
+def record_ids_indexed(path: str) -> List[str]:
+    return [rid for rid, _, _ in indexed(path)[1]]
+
+
 def n_runs_device(engine, path: str) -> Tuple[List[str], Dict[str, List[Tuple[int, int]]]]:
     """n_runs() with the scan on the GPU (gci_fasta_n_scan): the file's bytes are uploaded as they are; the device
     returns the byte offsets where runs of N / n begin and end and how many bytes of every 4096-byte tile count as
     sequence; the handful of offsets is turned into sequence coordinates here."""
-    buf = load(path)
-    spans = record_spans(buf)
+    global _INDEXED
+    buf, spans = indexed(path)
+    _INDEXED = None
     ids = [rid for rid, _, _ in spans]
     if not spans:
         return ids, {}

@@ -118,6 +118,21 @@ def bam_chunk_offsets(buf: np.ndarray, start: int = 0) -> Tuple[np.ndarray, int]
     return offs, int(used.value)
 
 
+def fasta_titles(buf: np.ndarray, threads: int = 0) -> np.ndarray:
+    """Byte offsets (uint64) of every '>' that begins a line of a FASTA byte array, in file order."""
+    lib = _lib.load()
+    n = ctypes.c_uint64(0)
+    p = buf.ctypes.data_as(ctypes.c_void_p)
+    th = int(threads or default_threads())
+    pos = np.empty(1 << 16, dtype=np.uint64)
+    st = lib.gci_fasta_titles(p, buf.shape[0], th, pos.ctypes.data_as(ctypes.c_void_p), pos.shape[0], ctypes.byref(n))
+    if st == _lib.GCI_E_CAPACITY:                                # more records than guessed: n holds the count
+        pos = np.empty(n.value, dtype=np.uint64)
+        st = lib.gci_fasta_titles(p, buf.shape[0], th, pos.ctypes.data_as(ctypes.c_void_p), pos.shape[0], ctypes.byref(n))
+    _chk(st, "gci_fasta_titles")
+    return pos[:n.value].copy()
+
+
 class BamHeads:
     """A BAM file as its heads stream (gci_bam_heads): the BAM header followed by every record without SEQ / QUAL, and
     the offset of every record.  `stream` and `offsets` are views into native memory, valid until close()."""

@@ -289,6 +289,9 @@ int gci_fasta_n_scan(gci_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, cons
  *                            GCI_E_MALFORMED with its index, as on the full stream); block_size < 32, a bad
  *                            member or a truncated last record return GCI_E_MALFORMED here.
  *                            gci_bam_heads_stream / _offsets stay valid until gci_bam_heads_free. */
+/*   gci_fasta_titles         byte offsets of every '>' that begins a line (one per record SeqIO.parse yields,
+ *                            GCI.py:30 / :940), in file order; h_pos may be NULL with cap 0 to count only */
+int gci_fasta_titles(const uint8_t* h_text, uint64_t n, int threads, uint64_t* h_pos, uint64_t cap, uint64_t* n_pos);
 typedef struct gci_heads gci_heads;
 int gci_bam_heads(const uint8_t* h_raw, uint64_t n_raw, int threads, uint64_t group_bytes, int check_crc, gci_heads** out);
 uint64_t gci_bam_heads_bytes(const gci_heads* h);          /* length of the heads stream */

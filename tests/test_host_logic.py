@@ -143,6 +143,15 @@ def test_fasta_n_runs_match_regex(tmp_path):
     want = {k: [(m.start(), m.end()) for m in re.finditer(r"(?i)N+", v)] for k, v in seqs.items()}
     assert runs == {k: v for k, v in want.items() if v}
     assert fasta.record_ids(str(p)) == ids
+    # the native title index (gci_fasta_titles) sees the same records as the numpy twin
+    for body in (p.read_bytes(), b"", b"ACGT\n", b">only_a_title", b">a\n>b x\nAC>GT\n>\nNN", b"\n>late\nN\n",
+                 b">big\n" + b"ACGTN>" * 400_000 + b"\n>tail y z\nNN\n"):
+        q = tmp_path / "t.fa"
+        q.write_bytes(body)
+        buf, spans = fasta.indexed(str(q))
+        assert spans == fasta.record_spans(buf)
+        assert fasta.record_ids_indexed(str(q)) == fasta.record_ids(str(q))
+        fasta._INDEXED = None
     # the golden case's FASTA: gaps.bed written by the reference
     case = "c5_two_type"
     _, r2 = fasta.n_runs(os.path.join(GOLDEN, case, "inputs", "ref.fa"))

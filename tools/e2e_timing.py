@@ -5,7 +5,7 @@ Writes a JSON summary to stdout."""
 import json, os, sys, time, tempfile, shutil, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gci_amd import synth, pipeline, cli
+from gci_amd import synth, pipeline, cli, hostio
 from gci_amd.formats import bam as bamfmt, bgzf
 
 def run(config, contigs, cov):
@@ -22,10 +22,17 @@ def run(config, contigs, cov):
     out["bam_file_bytes"] = os.path.getsize(bam_path); out["gen_s"] = time.perf_counter() - t
     eng = pipeline.default_engine()
     # stage timings
-    t = time.perf_counter(); s2 = bgzf.read_file(bam_path, threads=threads); out["inflate_s"] = time.perf_counter() - t
-    t = time.perf_counter(); hdr = bamfmt.parse_header(s2); o2 = bamfmt.record_offsets(s2, hdr.first_record); out["offsets_s"] = time.perf_counter() - t
+    nt = hostio.pick_threads(threads); out["host_threads_used"] = nt
+    t = time.perf_counter(); s2 = hostio.read_bgzf_file(bam_path, threads=nt); out["inflate_s"] = time.perf_counter() - t
+    t = time.perf_counter(); o2, _ = hostio.bam_record_offsets(s2); out["offsets_s"] = time.perf_counter() - t
     torch.cuda.synchronize(); t = time.perf_counter(); d_bam = eng.to_device(s2); d_off = eng.to_device(o2); torch.cuda.synchronize(); out["h2d_s"] = time.perf_counter() - t
-    del d_bam, d_off, s2
+    t = time.perf_counter(); del d_bam, d_off, s2; out["release_s"] = time.perf_counter() - t
+    # the heads-stream ingestion the command line uses instead of the three stages above
+    raw = np.fromfile(bam_path, dtype=np.uint8)
+    t = time.perf_counter(); hd = hostio.bam_heads(raw, threads=nt); out["heads_s"] = time.perf_counter() - t
+    out["heads_bytes"] = int(hd.stream.shape[0])
+    torch.cuda.synchronize(); t = time.perf_counter(); d_h = eng.to_device(hd.stream); d_o = eng.to_device(hd.offsets); torch.cuda.synchronize(); out["heads_h2d_s"] = time.perf_counter() - t
+    hd.close(); del d_h, d_o, raw
     # full CLI (twice: the second run has warm page cache and a built context)
     for k in ("cli_first_s", "cli_s"):
         od = os.path.join(tmp, k)
