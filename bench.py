@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="per-rank contig length (default chr19)")
     ap.add_argument("--coverage", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--heads", action="store_true",
+                    help="feed the filter the heads stream (records without SEQ / QUAL, what the command line uploads: "
+                         "gci_bam_heads + gci_bam_filter_heads) instead of the whole inflated stream")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU name check / exchange and the all-reduce even with one rank (self-test)")
     ap.add_argument("--force-replicated", action="store_true",
@@ -54,7 +57,7 @@ def parse_args():
 class Workload:
     """Per-rank resident inputs + preallocated outputs for one step."""
 
-    def __init__(self, eng, rank, world, contig_len, coverage, exchange=False, replicated=False):
+    def __init__(self, eng, rank, world, contig_len, coverage, exchange=False, replicated=False, heads=False):
         import torch
         from gci_amd import synth
         self.torch = torch
@@ -73,8 +76,21 @@ class Workload:
         stream, offs = synth.to_bam_stream(rs)
         self.stream_bytes = int(stream.shape[0])
         self.host_stream, self.host_offs = (stream, offs) if rank == 0 and world == 1 else (None, None)
-        self.d_bam = eng.to_device(stream)
-        self.d_off = eng.to_device(offs)
+        self.heads = heads
+        if heads:                                          # through a BGZF file and the native host pipeline, as the CLI does
+            import tempfile
+            from gci_amd import hostio
+            from gci_amd.formats import bam as bamfmt
+            with tempfile.TemporaryDirectory(prefix="gci_bench_") as tmp:
+                path = os.path.join(tmp, "r%d.bam" % rank)
+                bamfmt.write_bam_stream(path, stream, level=1, threads=hostio.default_threads())
+                with hostio.bam_heads(np.fromfile(path, dtype=np.uint8)) as hd:
+                    assert hd.offsets.shape[0] == self.n_rec
+                    self.d_bam, self.d_off = eng.to_device(hd.stream), eng.to_device(hd.offsets)
+            self.stream_bytes = int(self.d_bam.shape[0])
+        else:
+            self.d_bam = eng.to_device(stream)
+            self.d_off = eng.to_device(offs)
         del stream
         self.ref_sel = eng.to_device(np.arange(world, dtype=np.int32))
         eng.set_layout([contig_len])                       # local track: the contig this rank owns
@@ -129,9 +145,9 @@ class Workload:
         eng, lib, ctx = self.eng, self.eng.lib, self.eng.ctx
         from gci_amd._lib import JoinFile
         chk = eng._chk
-        chk(lib.gci_bam_filter(ctx, self._p(self.d_bam), self.stream_bytes, self._p(self.d_off), self.n_rec,
-                               self._p(self.ref_sel), self.world, 30, 50, 0.1, 0.9, self.rec_base, self._p(self.recs),
-                               self._p(self.status[0:1])), "gci_bam_filter")
+        k1 = lib.gci_bam_filter_heads if self.heads else lib.gci_bam_filter
+        chk(k1(ctx, self._p(self.d_bam), self.stream_bytes, self._p(self.d_off), self.n_rec, self._p(self.ref_sel),
+               self.world, 30, 50, 0.1, 0.9, self.rec_base, self._p(self.recs), self._p(self.status[0:1])), "gci_bam_filter")
         jf = (JoinFile * 1)()
         if not self.exchange:
             jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
@@ -238,7 +254,8 @@ def main():
     from gci_amd import _lib
     from gci_amd.device import Engine
     eng = Engine(local_rank)
-    w = Workload(eng, rank, world, args.contig_len, args.coverage, exchange=args.force_exchange or args.force_replicated, replicated=args.force_replicated)
+    w = Workload(eng, rank, world, args.contig_len, args.coverage, exchange=args.force_exchange or args.force_replicated,
+                 replicated=args.force_replicated, heads=args.heads)
 
     def fence():
         torch.cuda.synchronize()
@@ -320,7 +337,8 @@ def main():
         "config": {"workload": "CHM13 chr19 (%d bp) x %d contig(s), one %gx HiFi BAM, filter -> join -> depth -> "
                                "issue scan -> depth text" % (args.contig_len, world, args.coverage),
                    "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
-                   "inflated_bam_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
+                   "bam_input": "heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream",
+                   ("heads_bytes_per_gpu" if w.heads else "inflated_bam_bytes_per_gpu"): w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "join": ("local" if not w.exchange else
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
