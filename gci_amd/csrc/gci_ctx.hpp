@@ -57,7 +57,9 @@ struct gci_ctx {
     bool build_pending = false, build_text = false;
     // join scratch
     DevBuf join_table, join_last, join_hq;
-    DevBuf conflict_table;                  // gci_hash_conflicts' own open-addressing table
+    DevBuf conflict_table;                  // gci_hash_conflicts' own open-addressing tables (two, used alternately)
+    uint64_t conflict_slots = 0;            // slots per table
+    uint32_t conflict_parity = 0;           // which one the next call inserts into (the other one is clean by then)
     DevBuf text_lut;                        // uint32[TEXT_LUT]: decimal characters of 0..999
     DevBuf long_items;                      // K1: queue of long-CIGAR records + its counter
     // issue-scan windows

@@ -328,31 +328,34 @@ extern "C" int gci_pack_names(gci_ctx* ctx, const gci_join_file* h_file, uint8_t
 // Bucket layout (uint64 words): [0] = number of hashes the sender had for this bucket (may exceed the capacity:
 // overflow), [1 .. part_cap] = hashes.
 
-__global__ __launch_bounds__(BLOCK) void k_hash_bucket(const gci_rec* __restrict__ recs, uint32_t n, uint32_t n_parts,
-                                                       uint32_t part_cap, unsigned long long* __restrict__ out)
+// One global atomic per (workgroup, destination): a same-address returning atomic costs ~12 ns on this chip, so the
+// 2137 waves of a chr19 record set appending wave by wave took 29 us; 1024 records per workgroup rank themselves in
+// LDS first.  next_out (may be NULL): the bucket array of the NEXT call, whose count words this call zeroes.
+#define BUCKET_BLOCK 1024
+__global__ __launch_bounds__(BUCKET_BLOCK) void k_hash_bucket(const gci_rec* __restrict__ recs, uint32_t n, uint32_t n_parts,
+                                                              uint32_t part_cap, unsigned long long* __restrict__ out,
+                                                              unsigned long long* __restrict__ next_out)
 {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_cnt[256];
+    __shared__ unsigned long long s_base[256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t i = blockIdx.x * BUCKET_BLOCK + t;
     const size_t stride = (size_t)part_cap + 1;
+    if (t < n_parts) s_cnt[t] = 0;
+    if (next_out && blockIdx.x == 0 && t < n_parts) next_out[(size_t)t * stride] = 0ull;
+    __syncthreads();
     unsigned long long h = 0;
     bool live = false;
     if (i < n) { const gci_rec r = recs[i]; h = r.name_hash; live = (r.flags & GCI_REC_PASS) != 0; }
     const uint32_t d = (uint32_t)((h >> 33) % n_parts);
-    // one returning atomic per (wave, destination): lanes bound for the same bucket are served together
-    // (a same-address atomic costs ~12 ns on this chip; per-lane atomics would serialise for milliseconds)
-    unsigned long long todo = __ballot(live);
-    while (todo) {
-        const int first = __ffsll((long long)todo) - 1;
-        const uint32_t dsel = (uint32_t)__shfl((int)d, first, 64);
-        const unsigned long long grp = __ballot(live && d == dsel) & todo;
-        unsigned long long base = 0;
-        if (lane == first) base = atomicAdd(out + dsel * stride, (unsigned long long)__popcll(grp));
-        base = (unsigned long long)__shfl((long long)base, first, 64);
-        if (live && d == dsel) {
-            const unsigned long long slot = base + (unsigned long long)__popcll(grp & ((1ull << lane) - 1ull));
-            if (slot < part_cap) out[d * stride + 1 + slot] = h;
-        }
-        todo &= ~grp;
+    uint32_t mine = 0;
+    if (live) mine = atomicAdd(&s_cnt[d], 1u);                    // rank among this workgroup's records for bucket d
+    __syncthreads();
+    if (t < n_parts) s_base[t] = s_cnt[t] ? atomicAdd(out + (size_t)t * stride, (unsigned long long)s_cnt[t]) : 0ull;
+    __syncthreads();
+    if (live) {
+        const unsigned long long slot = s_base[d] + mine;
+        if (slot < part_cap) out[(size_t)d * stride + 1 + slot] = h;
     }
 }
 
@@ -362,12 +365,17 @@ __global__ void k_hash_bucket_clear(unsigned long long* out, uint32_t n_parts, u
     if (d < n_parts) out[(size_t)d * ((size_t)part_cap + 1)] = 0ull;
 }
 
-// table <- EMPTY and the conflict kernel in one launch would need a grid barrier; the clear is its own tiny launch
+// Two tables used alternately: a call inserts into one and wipes the other for the next call (a strip per thread,
+// streaming stores), so no fill is launched per call.
 __global__ __launch_bounds__(BLOCK) void k_hash_conflicts(const unsigned long long* __restrict__ buckets, uint32_t n_parts,
                                                           uint32_t part_cap, unsigned long long* __restrict__ table,
-                                                          uint64_t mask, uint32_t* __restrict__ n_conflicts)
+                                                          uint64_t mask, uint32_t* __restrict__ n_conflicts,
+                                                          unsigned long long* __restrict__ next_table)
 {
     const uint32_t src = blockIdx.y;
+    const size_t n_threads = (size_t)gridDim.x * gridDim.y * BLOCK;
+    for (size_t k = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x; k <= mask; k += n_threads)
+        __builtin_nontemporal_store(SLOT_EMPTY, next_table + k);
     const unsigned long long* b = buckets + (size_t)src * ((size_t)part_cap + 1);
     const unsigned long long cnt = b[0];
     if (cnt > part_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(n_conflicts, 1u); }   // overflow: force the fallback
@@ -389,14 +397,16 @@ __global__ __launch_bounds__(BLOCK) void k_hash_conflicts(const unsigned long lo
 }
 
 extern "C" int gci_hash_bucket(gci_ctx* ctx, const gci_rec* d_recs, uint32_t n, uint32_t n_parts, uint32_t part_cap,
-                               uint64_t* d_out)
+                               uint64_t* d_out, uint64_t* d_next_out)
 {
     if (!ctx || !d_out || n_parts == 0 || n_parts > 255 || (n && !d_recs)) return GCI_E_INVALID;
-    hipLaunchKernelGGL(k_hash_bucket_clear, dim3(1), dim3(256), 0, ctx->stream, (unsigned long long*)d_out, n_parts, part_cap);
-    LAUNCHCHK("k_hash_bucket_clear");
-    if (n) {
-        hipLaunchKernelGGL(k_hash_bucket, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_recs, n, n_parts,
-                           part_cap, (unsigned long long*)d_out);
+    if (!d_next_out) {                                     // no ping-pong partner: clear the count words here
+        hipLaunchKernelGGL(k_hash_bucket_clear, dim3(1), dim3(256), 0, ctx->stream, (unsigned long long*)d_out, n_parts, part_cap);
+        LAUNCHCHK("k_hash_bucket_clear");
+    }
+    if (n || d_next_out) {
+        hipLaunchKernelGGL(k_hash_bucket, dim3(n ? (n + BUCKET_BLOCK - 1) / BUCKET_BLOCK : 1), dim3(BUCKET_BLOCK), 0, ctx->stream,
+                           d_recs, n, n_parts, part_cap, (unsigned long long*)d_out, (unsigned long long*)d_next_out);
         LAUNCHCHK("k_hash_bucket");
     }
     return GCI_OK;
@@ -409,12 +419,20 @@ extern "C" int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint3
     if (!ctx || !d_buckets || !d_n_conflicts || n_parts == 0 || n_parts > 255) return GCI_E_INVALID;
     uint64_t slots = 1024;
     while (slots < 2ull * n_parts * part_cap) slots <<= 1;
-    GCI_TRY(gci_ensure(ctx, ctx->conflict_table, slots * 8));  // its own table: the join's tables stay in their clean state
-    HIPCHK(hipMemsetAsync(ctx->conflict_table.p, 0xFF, slots * 8, ctx->stream));
+    // its own tables (the join's stay in their clean state), two of them: [0, slots) and [slots, 2 slots)
+    const size_t cap_before = ctx->conflict_table.cap;
+    GCI_TRY(gci_ensure(ctx, ctx->conflict_table, 2 * slots * 8));
+    if (ctx->conflict_table.cap != cap_before || ctx->conflict_slots != slots) {
+        HIPCHK(hipMemsetAsync(ctx->conflict_table.p, 0xFF, 2 * slots * 8, ctx->stream));
+        ctx->conflict_slots = slots;
+        ctx->conflict_parity = 0;
+    }
+    unsigned long long* t0 = (unsigned long long*)ctx->conflict_table.p + (size_t)ctx->conflict_parity * slots;
+    unsigned long long* t1 = (unsigned long long*)ctx->conflict_table.p + (size_t)(ctx->conflict_parity ^ 1u) * slots;
+    ctx->conflict_parity ^= 1u;
     const uint32_t gx = (part_cap + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(k_hash_conflicts, dim3(gx ? (gx > 1024 ? 1024 : gx) : 1, n_parts), dim3(BLOCK), 0, ctx->stream,
-                       (const unsigned long long*)d_buckets, n_parts, part_cap, (unsigned long long*)ctx->conflict_table.p,
-                       slots - 1, d_n_conflicts);
+                       (const unsigned long long*)d_buckets, n_parts, part_cap, t0, slots - 1, d_n_conflicts, t1);
     LAUNCHCHK("k_hash_conflicts");
     return GCI_OK;
 }

@@ -211,10 +211,12 @@ class Engine:
                 return out, count
             out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
 
-    def hash_bucket(self, recs: torch.Tensor, n_parts: int, part_cap: int, out: torch.Tensor) -> None:
-        """out: int64 [n_parts * (part_cap + 1)]; word 0 of each bucket = its count."""
+    def hash_bucket(self, recs: torch.Tensor, n_parts: int, part_cap: int, out: torch.Tensor,
+                    next_out: Optional[torch.Tensor] = None) -> None:
+        """out: int64 [n_parts * (part_cap + 1)]; word 0 of each bucket = its count.  next_out: the array the caller
+        alternates with `out` (its count words are zeroed for the next call; `out`'s must be zero on entry)."""
         self._chk(self.lib.gci_hash_bucket(self.ctx, self._p(recs), int(recs.shape[0]), int(n_parts), int(part_cap),
-                                           self._p(out)), "gci_hash_bucket")
+                                           self._p(out), self._p(next_out)), "gci_hash_bucket")
 
     def hash_conflicts(self, buckets: torch.Tensor, n_parts: int, part_cap: int, n_conflicts: torch.Tensor) -> None:
         """Adds to n_conflicts (int32 [1])."""

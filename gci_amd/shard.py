@@ -106,7 +106,9 @@ class NameCheck:
     `bucket_fn(recs, n_parts, cap, out)` and `conflict_fn(buckets, n_parts, cap, n_conflicts)` are the two device
     operations (Engine.hash_bucket / Engine.hash_conflicts on the GPU)."""
 
-    def __init__(self, n_local: int, device: torch.device, bucket_fn, conflict_fn, group=None):
+    def __init__(self, n_local: int, device: torch.device, bucket_fn, conflict_fn, group=None, alternate: bool = False):
+        """alternate: two send arrays used in turn, bucket_fn(recs, n_parts, cap, out, next_out) zeroes the count
+        words of the one the next call fills (Engine.hash_bucket: no clearing launch per step)."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_fn, self.conflict_fn = bucket_fn, conflict_fn
@@ -116,6 +118,7 @@ class NameCheck:
         max_n = max(int(x.item()) for x in alln)
         self.cap = -(-max_n * 13 // (10 * self.world)) + 1024       # 1.3 x the mean bucket + slack
         self.send = torch.zeros(self.world * (self.cap + 1), dtype=torch.int64, device=device)
+        self.send_alt = torch.zeros_like(self.send) if alternate else None
         self.recv = torch.zeros_like(self.send)
         self.n_conf = torch.zeros(1, dtype=torch.int32, device=device)   # local, cumulative until reset()
 
@@ -125,8 +128,13 @@ class NameCheck:
     def enqueue(self, recs: torch.Tensor) -> torch.Tensor:
         """Asynchronous: adds this step's LOCAL conflict count to self.n_conf (device) and returns it.  A caller
         may go on speculatively with the local join and read the (all-reduced) verdict later."""
-        self.bucket_fn(recs, self.world, self.cap, self.send)
+        if self.send_alt is not None:
+            self.bucket_fn(recs, self.world, self.cap, self.send, self.send_alt)
+        else:
+            self.bucket_fn(recs, self.world, self.cap, self.send)
         dist.all_to_all_single(self.recv, self.send, group=self.group)
+        if self.send_alt is not None:
+            self.send, self.send_alt = self.send_alt, self.send
         self.conflict_fn(self.recv, self.world, self.cap, self.n_conf)
         return self.n_conf
 

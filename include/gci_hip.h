@@ -188,9 +188,12 @@ int gci_name_join_count(gci_ctx* ctx, const gci_join_file* h_files, int n_files,
  * [0] = number of hashes the sender had for it (> part_cap: overflow), [1..] = the hashes.  After ONE all-to-all of
  * the buckets, gci_hash_conflicts ADDS to *d_n_conflicts the number of hashes that arrived from more than one
  * source bucket (+1 per overflowing bucket).  Zero on every rank => no query name is shared between ranks, so
- * each rank's local join equals the global one. */
+ * each rank's local join equals the global one.
+ * d_next_out (may be NULL): a second bucket array the caller alternates with d_out.  When given, the call zeroes ITS
+ * count words for the next call and relies on d_out's count words being zero already (zero-filled at allocation, then
+ * kept so by this rule) -- no clearing launch per call.  NULL: d_out's count words are cleared by the call itself. */
 int gci_hash_bucket(gci_ctx* ctx, const gci_rec* d_recs, uint32_t n, uint32_t n_parts, uint32_t part_cap,
-                    uint64_t* d_out);
+                    uint64_t* d_out, uint64_t* d_next_out);
 int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint32_t n_parts, uint32_t part_cap,
                        uint32_t* d_n_conflicts);
 

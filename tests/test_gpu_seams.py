@@ -510,12 +510,25 @@ def test_cross_rank_name_check_kernels(engine):
     a = [b"readA/%d" % i for i in range(5000)]
     b = [b"readB/%d" % i for i in range(4000)]
 
-    def conflicts(na, nb, cap=6000, pa=None, pb=None):
+    pairs = {}                                        # alternate=True: per (rank, cap) two arrays used in turn
+
+    def conflicts(na, nb, cap=6000, pa=None, pb=None, alternate=False):
         world = 2
         outs = []
-        for names, p in ((na, pa), (nb, pb)):
-            o = torch.zeros(world * (cap + 1), dtype=torch.int64, device=engine.device)
-            engine.hash_bucket(recs_for(names, p), world, cap, o)
+        for k, (names, p) in enumerate(((na, pa), (nb, pb))):
+            if alternate:
+                # the ping-pong contract of gci_hash_bucket: zero-filled once, afterwards each call clears the count
+                # words of the array the next call fills (and garbage beyond the counts must not matter)
+                if (k, cap) not in pairs:
+                    pairs[(k, cap)] = [torch.zeros(world * (cap + 1), dtype=torch.int64, device=engine.device) for _ in range(2)]
+                    for t in pairs[(k, cap)]:
+                        t.view(world, cap + 1)[:, 1:] = 0x5A5A5A5A
+                o, nxt = pairs[(k, cap)]
+                engine.hash_bucket(recs_for(names, p), world, cap, o, nxt)
+                pairs[(k, cap)] = [nxt, o]
+            else:
+                o = torch.full((world * (cap + 1),), 0x77, dtype=torch.int64, device=engine.device)
+                engine.hash_bucket(recs_for(names, p), world, cap, o)
             outs.append(o.view(world, cap + 1))
         n = torch.zeros(1, dtype=torch.int32, device=engine.device)
         for me in range(world):                       # what rank `me` receives: bucket `me` of every source
@@ -530,6 +543,13 @@ def test_cross_rank_name_check_kernels(engine):
     flags = np.ones(len(b) + 1, dtype=np.uint8); flags[-1] = 0
     assert conflicts(a, b + [a[17]], pb=flags) == 0                   # filtered records do not take part
     assert conflicts(a, b, cap=100) > 0                              # bucket overflow forces the fallback
+    # call after call (the conflict tables alternate and wipe each other; the bucket arrays alternate too)
+    for rnd in range(5):
+        extra = [a[int(i)] for i in rng.choice(len(a), size=rnd, replace=False)]
+        assert conflicts(a, b + extra, alternate=True) == rnd
+        assert conflicts(a[:100 + rnd], b[:50], cap=3000, alternate=True) == 0        # another table size in between
+    big = [b"x%d" % i for i in range(70_000)]                           # several workgroups per bucket kernel
+    assert conflicts(big, [b"y%d" % i for i in range(65_000)] + big[:7], cap=80_000, alternate=True) == 7
 
 
 @pytest.mark.parametrize("seed", [31, 32])
