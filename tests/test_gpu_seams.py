@@ -570,7 +570,7 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
             ops.append((o, int(rng.integers(20, 300)) if o in (0, 7) else int(rng.integers(1, 4))))
         qlen = sum(l for o, l in ops if (bam.QUERY_CONSUMING >> o) & 1)
         l_seq = 0 if rng.random() < 0.05 else qlen
-        name = bytes(rng.integers(33, 127, int(rng.choice([1, 5, 30, 40, 100, 219, 220, 221, 254]))).astype(np.uint8)).decode()
+        name = bytes(rng.integers(33, 127, int(rng.choice([1, 5, 30, 40, 100, 183, 184, 185, 186, 219, 220, 221, 254]))).astype(np.uint8)).decode()
         tags = []
         for _ in range(int(rng.integers(0, 7))):
             k = rng.integers(0, 6)
