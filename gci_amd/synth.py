@@ -344,8 +344,11 @@ def _nm_bytes(nm: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return flat, ln
 
 
-def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] = None):
+def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] = None, heads: bool = False):
     """-> (inflated BAM stream uint8[n], record offsets uint64[R]).
+
+    heads=True: the heads stream of the same file (gci_bam_heads: every record without its SEQ / QUAL bytes,
+    l_seq unchanged) -- what a genome-scale experiment can hold in memory.
 
     Records whose CIGAR exceeds 65535 ops are written the spec's way (placeholder CIGAR plus
     a CG:B,I tag at the end of the aux block).  SEQ and QUAL are constant 0xFF fill: the
@@ -364,7 +367,8 @@ def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] 
     dummy = np.frombuffer(_DUMMY_TAGS, dtype=np.uint8)
     cg_len = np.where(is_long, 8 + 4 * n_ops, 0)
     aux_len = nm_len + dummy.shape[0] + cg_len
-    body = 32 + name_len + 4 * n_cig_field + (l_seq + 1) // 2 + l_seq + aux_len
+    seq_bytes = np.zeros_like(l_seq) if heads else (l_seq + 1) // 2 + l_seq
+    body = 32 + name_len + 4 * n_cig_field + seq_bytes + aux_len
     size = 4 + body
     offs = np.zeros(R + 1, dtype=np.int64)
     np.cumsum(size, out=offs[1:])
@@ -415,7 +419,7 @@ def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] 
             ph = np.array([(int(l_seq[g]) << 4) | OP_S, (int(span[g]) << 4) | OP_N], dtype="<u4").view(np.uint8)
             out[p_cig[r]:p_cig[r] + 8] = ph
         # aux
-        p_aux = p_cig + 4 * n_cig_field[sl] + (l_seq[sl] + 1) // 2 + l_seq[sl]
+        p_aux = p_cig + 4 * n_cig_field[sl] + seq_bytes[sl]
         last = rs.nm_last[sl]
         p_nm = np.where(last, p_aux + dummy.shape[0], p_aux)
         p_dm = np.where(last, p_aux, p_aux + nm_len[sl])
