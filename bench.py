@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="per-rank contig length (default chr19)")
     ap.add_argument("--coverage", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="steps in flight (1 GPU only): N > 1 runs consecutive steps on N streams, each with its own library "
+                         "context and buffers -- the latency-bound filter / join of one step then overlaps the HBM-bound tile "
+                         "build of another.  Default 1: every kernel runs alone and the roofline figure is that of the kernel")
     ap.add_argument("--heads", action="store_true",
                     help="feed the filter the heads stream (records without SEQ / QUAL, what the command line uploads: "
                          "gci_bam_heads + gci_bam_filter_heads) instead of the whole inflated stream")
@@ -268,6 +272,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # --inflight N: N - 1 more contexts on streams of their own; step k runs on context k % N
+    lanes = [(eng, w, None)]
+    if args.inflight > 1:
+        if world > 1 or w.exchange:
+            sys.exit("bench.py --inflight is for the single-GPU local path")
+        for _ in range(args.inflight - 1):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                e2 = Engine(local_rank, stream=st)
+                w2 = Workload(e2, rank, world, args.contig_len, args.coverage, heads=args.heads)
+                for _ in range(max(1, args.warmup)):
+                    w2.step()
+            lanes.append((e2, w2, st))
+
+    def run_steps(n):
+        for k in range(n):
+            e_k, w_k, st = lanes[k % len(lanes)]
+            if st is None:
+                w_k.step()
+            else:
+                with torch.cuda.stream(st):
+                    w_k.step()
+
     for _ in range(max(1, args.warmup)):
         w.step()
     fence()
@@ -279,18 +306,22 @@ def main():
         fence()
         w.check()
 
-    eng.profile_enable(1 << _lib.PROF_DEPTH_SCAN)          # HIP events around the dominant kernel only
-    eng.profile_read(reset=True)
+    for e_k, _, _ in lanes:
+        e_k.profile_enable(1 << _lib.PROF_DEPTH_SCAN)      # HIP events around the dominant kernel only
+        e_k.profile_read(reset=True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w.step()
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    prof = eng.profile_read(reset=True)
-    eng.profile_enable(0)
-    if not w.check():
-        sys.exit("bench: a query name became shared between ranks during the timed region")
+    prof = {}
+    for e_k, _, _ in lanes:
+        for name, (ms, n) in e_k.profile_read(reset=True).items():
+            prof[name] = (prof.get(name, (0.0, 0))[0] + ms, prof.get(name, (0.0, 0))[1] + n)
+        e_k.profile_enable(0)
+    for _, w_k, _ in lanes:
+        if not w_k.check():
+            sys.exit("bench: a query name became shared between ranks during the timed region")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -344,6 +375,7 @@ def main():
                    "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
                    "bam_input": "heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream",
                    ("heads_bytes_per_gpu" if w.heads else "inflated_bam_bytes_per_gpu"): w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
+                   "steps_in_flight": len(lanes),
                    "join": ("local" if not w.exchange else
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
