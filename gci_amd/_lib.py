@@ -75,6 +75,9 @@ EXPORTS = [
                               c_void_p]),
     ("gci_name_join_count", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
                               c_void_p, c_int]),
+    ("gci_depth_deflate_size", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("gci_depth_deflate_write", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_uint64]),
     ("gci_hash_bucket", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p]),
     ("gci_hash_conflicts", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
     ("gci_depth_build", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_int, c_void_p]),

@@ -1,0 +1,305 @@
+// k_deflate.hip -- N2: the depth text as gzip members, written by the GPU straight from the track
+// (write_depth, GCI.py:99-143: every base as f'{depth}\n' through gzip).
+//
+// The text of a depth track is runs of one short line repeated ("37\n37\n37\n..."): in DEFLATE terms w literals (the
+// line) followed by matches of distance w.  So the encoder never materialises the text: a lane walks one tile
+// (4096 bases) of the int32 track, collects its constant-depth runs, and emits per run the line's literals and
+// ceil((n-1)w / 258) length/distance pairs with the FIXED Huffman code (RFC 1951, 3.2.6) -- about 13 bits per 258 bytes
+// of text.  A tile is one deflate block closed by an empty stored block (byte alignment, as Z_SYNC_FLUSH does), so tile
+// streams concatenate bytewise; 64 tiles -- one wave -- form one gzip member:
+//     1f 8b 08 00 00000000 00 ff | tile 0 | ... | tile 63 | 03 00 | CRC-32 | ISIZE
+// CRC-32 of text that is never written: CRCs are polynomials mod P over GF(2), crc(A||B) = crc(A) * x^(8|B|) + crc(B), so
+// a run of n copies of a line is n - 1 such steps done by squaring (pairs (crc, x^(8 len)) multiply like 2x2 triangular
+// matrices), a tile is the product of its runs and the member the ordered product of its 64 tiles (wave tree).
+// Any multi-member gzip whose payload equals the reference's text is a valid .depth.gz; Python's gzip module checks
+// every member's CRC and length when the consumers (utility/GCI_score.py:25-37) read it.
+//
+// Two passes over the track (4 B/base each): sizes + CRCs, then the bytes at their scanned offsets.
+#include "gci_ctx.hpp"
+
+namespace {
+
+constexpr uint32_t CRC_POLY = 0xEDB88320u;      // reflected: bit 31 holds x^0, bit 0 holds x^31
+constexpr uint32_t GF_ONE = 0x80000000u;        // the polynomial 1
+constexpr int RUNS = 16;                        // runs a lane collects before the wave encodes them together
+constexpr int MEMBER_TILES = 64;
+
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)          // a * b mod P
+{
+    uint32_t p = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;                               // + b * x^i
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);                            // b *= x
+    }
+    return p;
+}
+
+// (crc, x^(8 len)) of a byte string; strings concatenate as  (a.c, a.x) . (b.c, b.x) = (a.c * b.x + b.c, a.x * b.x)
+struct CrcPair { uint32_t c, x; };
+__device__ __forceinline__ CrcPair crc_cat(CrcPair a, CrcPair b) { return {gf_mul(a.c, b.x) ^ b.c, gf_mul(a.x, b.x)}; }
+
+// one line of the text: decimal digits of v (v >= 0) and '\n', as bytes packed little-endian into 96 bits
+struct Line { uint32_t lo, mid, hi; uint32_t w; };
+__device__ __forceinline__ uint32_t line_byte(const Line& l, uint32_t k)
+{
+    const uint32_t word = k < 4 ? l.lo : k < 8 ? l.mid : l.hi;
+    return (word >> (8u * (k & 3u))) & 0xFFu;
+}
+__device__ __forceinline__ Line make_line(uint32_t v)
+{
+    uint32_t nd = 1;
+    for (uint32_t t = v; t >= 10u; t /= 10u) nd++;
+    Line l{0u, 0u, 0u, nd + 1u};
+    uint32_t t = v;
+    for (uint32_t k = nd; k-- > 0;) {                                           // digit k (0 = most significant)
+        const uint32_t dg = 0x30u + t % 10u;
+        t /= 10u;
+        const uint32_t sh = 8u * (k & 3u);
+        if (k < 4) l.lo |= dg << sh; else if (k < 8) l.mid |= dg << sh; else l.hi |= dg << sh;
+    }
+    const uint32_t sh = 8u * (nd & 3u);
+    if (nd < 4) l.lo |= 0x0Au << sh; else if (nd < 8) l.mid |= 0x0Au << sh; else l.hi |= 0x0Au << sh;
+    return l;
+}
+
+__device__ __forceinline__ CrcPair crc_line(const Line& l)
+{
+    uint32_t c = 0xFFFFFFFFu, x = GF_ONE;
+    for (uint32_t k = 0; k < l.w; k++) {
+        c ^= line_byte(l, k);
+        for (int b = 0; b < 8; b++) {
+            c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+            x = (x >> 1) ^ ((x & 1u) ? CRC_POLY : 0u);                          // x^(8 w) alongside
+        }
+    }
+    // c is the register of the string started at all-ones; the finalised CRC of a string S is reg(S) ^ ~0, and the
+    // concatenation rule above holds for finalised CRCs
+    return {c ^ 0xFFFFFFFFu, x};
+}
+
+// n >= 1 copies of a string
+__device__ __forceinline__ CrcPair crc_repeat(CrcPair base, uint32_t n)
+{
+    CrcPair r{0u, GF_ONE};                                                      // the empty string
+    for (;;) {
+        if (n & 1u) r = crc_cat(r, base);
+        n >>= 1;
+        if (!n) break;
+        base = crc_cat(base, base);
+    }
+    return r;
+}
+
+// ---- bit writer: DEFLATE packs bits LSB first; Huffman codes go in most-significant bit first, i.e. bit-reversed --------
+struct BitOut {
+    unsigned long long acc = 0;
+    uint32_t nb = 0;            // bits in acc
+    uint64_t total = 0;         // bits emitted so far
+    uint8_t* out = nullptr;     // nullptr: count only
+    __device__ __forceinline__ void put(uint32_t bits, uint32_t n)
+    {
+        acc |= (unsigned long long)bits << nb;
+        nb += n;
+        total += n;
+        while (nb >= 8u) {
+            if (out) *out++ = (uint8_t)acc;
+            acc >>= 8;
+            nb -= 8u;
+        }
+    }
+    __device__ __forceinline__ void align()                                     // zero bits up to the next byte boundary
+    {
+        if (nb) put(0u, 8u - nb);
+    }
+};
+
+__device__ __forceinline__ void put_literal(BitOut& o, uint32_t byte)           // bytes < 144: 8-bit code 0x30 + byte
+{
+    o.put(__brev(0x30u + byte) >> 24, 8u);
+}
+
+__device__ __forceinline__ void put_match(BitOut& o, uint32_t len, uint32_t dist)   // 3 <= len <= 258, 2 <= dist <= 12
+{
+    if (len == 258u) {
+        o.put(__brev(0xC5u) >> 24, 8u);                                          // symbol 285: 8-bit code 0xC0 + 5
+    } else {
+        const uint32_t t = len - 3u;
+        const uint32_t e = t < 8u ? 0u : (uint32_t)(31 - __clz((int)t)) - 2u;
+        const uint32_t sym = 257u + 4u * e + (e ? (t >> e) : t);
+        if (sym <= 279u) o.put(__brev(sym - 256u) >> 25, 7u);                    // 7-bit codes 0000000 .. 0010111
+        else o.put(__brev(0xC0u + (sym - 280u)) >> 24, 8u);
+        if (e) o.put(t & ((1u << e) - 1u), e);
+    }
+    uint32_t code, eb, ev;
+    if (dist <= 4u) { code = dist - 1u; eb = 0; ev = 0; }
+    else if (dist <= 8u) { code = 4u + ((dist - 5u) >> 1); eb = 1; ev = (dist - 5u) & 1u; }
+    else { code = 6u + ((dist - 9u) >> 2); eb = 2; ev = (dist - 9u) & 3u; }
+    o.put(__brev(code) >> 27, 5u);
+    if (eb) o.put(ev, eb);
+}
+
+// the tokens of n copies of a line
+__device__ __forceinline__ void put_run(BitOut& o, const Line& l, uint32_t n)
+{
+    const uint32_t w = l.w;
+    for (uint32_t k = 0; k < w; k++) put_literal(o, line_byte(l, k));
+    uint32_t rest = (n - 1u) * w;
+    while (rest >= 3u) {
+        uint32_t len = rest < 258u ? rest : 258u;
+        if (rest - len != 0u && rest - len < 3u) len = rest - 3u;                // never leave 1 or 2 bytes behind
+        put_match(o, len, w);
+        rest -= len;
+    }
+    for (uint32_t k = 0; k < rest; k++) put_literal(o, line_byte(l, k));        // (n - 1) w < 3: n == 2, w == 2... as literals
+}
+
+// One wave = one member of up to 64 tiles; lane t = tile t.  PASS 1: tile_bytes[], member totals + CRC; PASS 2: bytes.
+template <int PASS>
+__global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict__ depth, const uint64_t* __restrict__ member_elem,
+                                                      const uint32_t* __restrict__ member_n, uint32_t n_members,
+                                                      uint32_t* __restrict__ tile_bytes, uint32_t* __restrict__ member_bytes,
+                                                      uint32_t* __restrict__ member_crc, uint32_t* __restrict__ member_isize,
+                                                      const uint64_t* __restrict__ member_out, uint8_t* __restrict__ out, uint64_t cap)
+{
+    __shared__ int32_t run_v[RUNS][64];
+    __shared__ uint32_t run_n[RUNS][64];
+    const uint32_t m = blockIdx.x;
+    if (m >= n_members) return;
+    const int lane = threadIdx.x;
+    const uint64_t e0 = member_elem[m];
+    const uint32_t n_all = member_n[m];
+    const uint32_t first = (uint32_t)lane * TILE;
+    const uint32_t n = n_all > first ? min((uint32_t)TILE, n_all - first) : 0u;     // elements of this lane's tile
+    const int32_t* src = depth + e0 + first;
+
+    BitOut o;
+    uint64_t my_off = 0;
+    if (PASS == 2) {
+        // byte offset of this lane's tile stream inside the member: header + the tiles in front
+        uint32_t s = tile_bytes[(size_t)m * MEMBER_TILES + lane], incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += v; }
+        my_off = member_out[m] + 10ull + (incl - s);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64) + 20u;
+        if (member_out[m] + total > cap) return;                                      // caller sized the buffer from pass 1
+        o.out = out + my_off;
+        if (lane == 0) {
+            uint8_t* h = out + member_out[m];
+            h[0] = 0x1F; h[1] = 0x8B; h[2] = 8; h[3] = 0; h[4] = h[5] = h[6] = h[7] = 0; h[8] = 0; h[9] = 0xFF;
+            uint8_t* t = h + total - 10u;                                             // 03 00 | crc | isize
+            const uint32_t c = member_crc[m], z = member_isize[m];
+            t[0] = 0x03; t[1] = 0x00;
+            t[2] = (uint8_t)c; t[3] = (uint8_t)(c >> 8); t[4] = (uint8_t)(c >> 16); t[5] = (uint8_t)(c >> 24);
+            t[6] = (uint8_t)z; t[7] = (uint8_t)(z >> 8); t[8] = (uint8_t)(z >> 16); t[9] = (uint8_t)(z >> 24);
+        }
+    }
+    CrcPair tile{0u, GF_ONE};
+    uint32_t text_len = 0;
+    if (n) o.put(2u, 3u);                                                             // BFINAL = 0, BTYPE = 01 (fixed codes)
+
+    // walk: collect up to RUNS runs per lane, then all lanes encode their runs side by side
+    uint32_t pos = 0;
+    int32_t cur = 0;
+    uint32_t cnt = 0;                                                                 // the open run
+    bool done = n == 0;
+    while (__any(!done)) {
+        int k = 0;
+        while (!done && k < RUNS) {
+            if (pos == n) {                                                           // close the last run
+                if (cnt) { run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0; }
+                done = true;
+                break;
+            }
+            // four elements per load where the position allows (tiles start 16-byte aligned)
+            int32_t v[4];
+            uint32_t take;
+            if ((pos & 3u) == 0u && pos + 4u <= n) {
+                const int4 q = *reinterpret_cast<const int4*>(src + pos);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; take = 4;
+            } else { v[0] = src[pos]; v[1] = v[2] = v[3] = 0; take = 1; }
+            uint32_t used = 0;
+            for (uint32_t j = 0; j < take; j++) {
+                if (cnt && v[j] != cur) {
+                    if (k == RUNS) break;                                             // buffer full: come back to this element
+                    run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0;
+                }
+                cur = v[j]; cnt++; used++;
+            }
+            pos += used;
+            if (used < take) break;                                                   // full
+        }
+        const int kmax = k;
+        // encode: run r of every lane in the same iteration (the heavy arithmetic stays converged)
+        int wave_max = kmax;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wave_max = max(wave_max, __shfl_xor(wave_max, d, 64));
+        for (int r = 0; r < wave_max; r++) {
+            if (r < kmax) {
+                const uint32_t rn = run_n[r][lane];
+                const Line l = make_line((uint32_t)run_v[r][lane]);
+                if (PASS == 1) {
+                    tile = crc_cat(tile, crc_repeat(crc_line(l), rn));
+                    text_len += rn * l.w;
+                }
+                put_run(o, l, rn);
+            }
+        }
+    }
+    if (n) {
+        o.put(0u, 7u);                                                                // end of block (symbol 256)
+        o.put(0u, 3u);                                                                // empty stored block: BFINAL 0, BTYPE 00
+        o.align();
+        o.put(0x0000u, 16u);
+        o.put(0xFFFFu, 16u);
+    }
+    if (PASS == 1) {
+        const uint32_t bytes = (uint32_t)(o.total >> 3);
+        tile_bytes[(size_t)m * MEMBER_TILES + lane] = bytes;
+        uint32_t sum = bytes, len = text_len;
+        // ordered product of the 64 tiles (lane i absorbs lane i + d) and plain sums
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            CrcPair other{(uint32_t)__shfl_down((int)tile.c, d, 64), (uint32_t)__shfl_down((int)tile.x, d, 64)};
+            const uint32_t os = (uint32_t)__shfl_down((int)sum, d, 64), ol = (uint32_t)__shfl_down((int)len, d, 64);
+            if ((lane & (2 * d - 1)) == 0) { tile = crc_cat(tile, other); sum += os; len += ol; }
+        }
+        if (lane == 0) {
+            member_bytes[m] = sum + 20u;
+            member_crc[m] = tile.c;
+            member_isize[m] = len;
+        }
+    }
+}
+
+}  // namespace
+
+// PASS 1.  d_member_elem[m]: element offset of member m's first base in the track (a multiple of 4); d_member_n[m]: its
+// bases (<= 64 * 4096; a member never spans two contigs).  Writes d_tile_bytes[64 m + t], d_member_bytes / _crc / _isize.
+extern "C" int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, const uint64_t* d_member_elem, const uint32_t* d_member_n,
+                                      uint32_t n_members, uint32_t* d_tile_bytes, uint32_t* d_member_bytes, uint32_t* d_member_crc,
+                                      uint32_t* d_member_isize)
+{
+    if (!ctx || (n_members && (!d_depth || !d_member_elem || !d_member_n || !d_tile_bytes || !d_member_bytes || !d_member_crc ||
+                               !d_member_isize))) return GCI_E_INVALID;
+    if (n_members == 0) return GCI_OK;
+    hipLaunchKernelGGL(k_depth_deflate<1>, dim3(n_members), dim3(64), 0, ctx->stream, d_depth, d_member_elem, d_member_n, n_members,
+                       d_tile_bytes, d_member_bytes, d_member_crc, d_member_isize, (const uint64_t*)nullptr, (uint8_t*)nullptr, 0ull);
+    LAUNCHCHK("k_depth_deflate<1>");
+    return GCI_OK;
+}
+
+// PASS 2.  d_member_out[m]: byte offset of member m in d_out (exclusive scan of d_member_bytes, done by the caller).
+extern "C" int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* d_depth, const uint64_t* d_member_elem, const uint32_t* d_member_n,
+                                       uint32_t n_members, const uint32_t* d_tile_bytes, const uint32_t* d_member_crc,
+                                       const uint32_t* d_member_isize, const uint64_t* d_member_out, uint8_t* d_out, uint64_t cap)
+{
+    if (!ctx || (n_members && (!d_depth || !d_member_elem || !d_member_n || !d_tile_bytes || !d_member_crc || !d_member_isize ||
+                               !d_member_out || !d_out))) return GCI_E_INVALID;
+    if (n_members == 0) return GCI_OK;
+    hipLaunchKernelGGL(k_depth_deflate<2>, dim3(n_members), dim3(64), 0, ctx->stream, d_depth, d_member_elem, d_member_n, n_members,
+                       const_cast<uint32_t*>(d_tile_bytes), (uint32_t*)nullptr, const_cast<uint32_t*>(d_member_crc),
+                       const_cast<uint32_t*>(d_member_isize), d_member_out, d_out, cap);
+    LAUNCHCHK("k_depth_deflate<2>");
+    return GCI_OK;
+}

@@ -211,6 +211,40 @@ class Engine:
                 return out, count
             out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
 
+    # ---- R7 / N2: gzip members of the depth text, written on the device ----------------------------------------
+    MEMBER_BASES = 64 * 4096
+
+    def depth_deflate(self, track: torch.Tensor) -> List[bytes]:
+        """-> per contig of the layout, the bytes of the gzip members whose payload is that contig's depth lines
+        (f'{depth}\\n' per base, GCI.py:115-117; no '>' line).  gci_depth_deflate_size / _write."""
+        elem, cnt, first = [], [], [0]
+        for off, length in zip(self.offsets, self.lengths):
+            for g in range(0, int(length), self.MEMBER_BASES):
+                elem.append(int(off) + g)
+                cnt.append(min(self.MEMBER_BASES, int(length) - g))
+            first.append(len(elem))
+        nm = len(elem)
+        if nm == 0:
+            return [b"" for _ in self.lengths]
+        d_elem = self.to_device(np.asarray(elem, dtype=np.uint64))
+        d_cnt = self.to_device(np.asarray(cnt, dtype=np.uint32))
+        dev = self.device
+        tile_bytes = torch.empty(nm * 64, dtype=torch.int32, device=dev)
+        mb, crc, isz = (torch.empty(nm, dtype=torch.int32, device=dev) for _ in range(3))
+        self._chk(self.lib.gci_depth_deflate_size(self.ctx, self._p(track), self._p(d_elem), self._p(d_cnt), nm, self._p(tile_bytes),
+                                                  self._p(mb), self._p(crc), self._p(isz)), "gci_depth_deflate_size")
+        sizes = mb.cpu().numpy().view(np.uint32).astype(np.uint64)
+        offs = np.zeros(nm + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=offs[1:])
+        total = int(offs[nm])
+        out = torch.empty(total, dtype=torch.uint8, device=dev)
+        d_off = self.to_device(offs[:nm].copy())
+        self._chk(self.lib.gci_depth_deflate_write(self.ctx, self._p(track), self._p(d_elem), self._p(d_cnt), nm, self._p(tile_bytes),
+                                                   self._p(crc), self._p(isz), self._p(d_off), self._p(out), total),
+                  "gci_depth_deflate_write")
+        blob = out.cpu().numpy()
+        return [blob[int(offs[first[c]]):int(offs[first[c + 1]])].tobytes() for c in range(len(self.lengths))]
+
     def hash_bucket(self, recs: torch.Tensor, n_parts: int, part_cap: int, out: torch.Tensor,
                     next_out: Optional[torch.Tensor] = None) -> None:
         """out: int64 [n_parts * (part_cap + 1)]; word 0 of each bucket = its count.  next_out: the array the caller

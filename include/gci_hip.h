@@ -251,6 +251,23 @@ int gci_issue_scan_windows(gci_ctx* ctx, const int32_t* d_depth, const gci_windo
 int gci_depth_text_size(gci_ctx* ctx, const int32_t* d_depth, uint64_t* d_contig_off);
 int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_t* d_out, uint64_t cap);
 
+/* ---- R7 / N2: the depth text as gzip members, written by the GPU ------------------------------------------------
+ * write_depth (GCI.py:99-143) sends f'{depth}\n' per base through gzip; these two calls emit the same payload as
+ * DEFLATE without ever materialising the text: per constant-depth run the line's literals + length/distance pairs
+ * (distance = line length) in the fixed Huffman code, one block per 4096-base tile closed by an empty stored block,
+ * 64 tiles (one wave) = one gzip member with its CRC-32 and ISIZE (CRC of the virtual text by GF(2) polynomial
+ * arithmetic over the runs).  Any int32 track (fresh, gap-masked, two-type) with depths >= 0.
+ * A member m covers d_member_n[m] <= 64 * 4096 consecutive bases starting at element d_member_elem[m] (a multiple
+ * of 4; the caller cuts members so that none spans two contigs and writes the '>contig' lines as members of its own).
+ *   size:  d_tile_bytes[64 m + t], d_member_bytes[m] (header and trailer included), d_member_crc[m], d_member_isize[m]
+ *   write: d_member_out[m] = byte offset of member m in d_out (exclusive scan of d_member_bytes by the caller). */
+int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, const uint64_t* d_member_elem, const uint32_t* d_member_n,
+                           uint32_t n_members, uint32_t* d_tile_bytes, uint32_t* d_member_bytes, uint32_t* d_member_crc,
+                           uint32_t* d_member_isize);
+int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* d_depth, const uint64_t* d_member_elem, const uint32_t* d_member_n,
+                            uint32_t n_members, const uint32_t* d_tile_bytes, const uint32_t* d_member_crc,
+                            const uint32_t* d_member_isize, const uint64_t* d_member_out, uint8_t* d_out, uint64_t cap);
+
 /* ---- R15 ------------------------------------------------------------------------------------ */
 int gci_depth_sum(gci_ctx* ctx, const int32_t* d_depth, int64_t* d_sums /* n_contigs */);
 

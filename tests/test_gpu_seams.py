@@ -684,3 +684,43 @@ def test_name_join_randomised_dicts(engine, oracle, n_files, seed):
     ivl2, cnt2 = engine.name_join(inputs, 0.9, contig_map=cmap)
     got2 = sorted(map(tuple, ivl2[:int(cnt2.item()), :3].cpu().numpy().tolist()))
     assert got2 == [w for w in want if w[0] == 0]
+
+
+def test_depth_text_as_gzip_members_from_the_gpu(engine):
+    """gci_depth_deflate_size / _write: the gzip members the device writes straight from the track decompress (CRC and
+    length checked by Python's gzip) to exactly f'{depth}\\n' per base -- runs of every length and line width, contigs
+    that end inside a tile / a member, depths up to 2^31 - 1."""
+    import gzip
+    rng = np.random.default_rng(77)
+    lens = [1, 3, 4095, 4096, 4097, 64 * 4096 - 1, 64 * 4096, 64 * 4096 + 5, 300_001, 1_000_003]
+    engine.set_layout(lens)
+    track = engine.new_track()
+    host = np.zeros(engine.total, dtype=np.int32)
+    want = []
+    for c, (off, L) in enumerate(zip(engine.offsets, lens)):
+        if c % 3 == 0:        # long runs of small depths, like a real track
+            edges = np.sort(rng.choice(np.arange(1, max(L, 2)), size=min(L - 1, max(1, L // 900)), replace=False)) if L > 1 else np.zeros(0, int)
+            vals = rng.integers(0, 130, edges.shape[0] + 1)
+            d = np.repeat(vals, np.diff(np.concatenate(([0], edges, [L]))))
+        elif c % 3 == 1:      # every run length from 1 up, every line width
+            widths = rng.choice([0, 7, 42, 999, 1000, 65_536, 9_999_999, 123_456_789, 2_147_483_647], size=L)
+            rl = rng.integers(1, 6, size=L)
+            d = np.repeat(widths, rl)[:L]
+        else:                 # no two neighbours equal
+            d = (np.arange(L) * 7919 + c) % 1013
+        host[off:off + L] = d
+        want.append(b"".join(b"%d\n" % int(x) for x in d.tolist()) if L < 400_000 else ("\n".join(map(str, d.tolist())) + "\n").encode())
+    track.copy_(torch.from_numpy(host))
+    members = engine.depth_deflate(track)
+    assert len(members) == len(lens)
+    for c, blob in enumerate(members):
+        assert blob[:4] == b"\x1f\x8b\x08\x00"
+        assert gzip.decompress(blob) == want[c], c
+        assert blob.count(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff") >= -(-lens[c] // (64 * 4096))
+    # the long-run contigs compress about a hundredfold
+    assert len(members[9]) * 40 < len(want[9])
+    # and against the text kernels on the same track
+    text, off_t = engine.depth_text(track)
+    whole = text.cpu().numpy().tobytes()
+    for c in range(len(lens)):
+        assert gzip.decompress(members[c]) == whole[int(off_t[c]):int(off_t[c + 1])]
