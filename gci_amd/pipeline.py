@@ -397,7 +397,8 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     except GciError as e:
         _reraise_like_reference(e)
     track = engine.new_track()
-    fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=bool(write), want_sums=True,
+    text_on_device = bool(write) and DEPTH_GZ != "gpu"
+    fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=text_on_device, want_sums=True,
                                      issue=issue_hint, counted=True)
     depths = DepthTracks(engine, targets_length, track)
     depths._fresh_sums = fused["sums"]
@@ -407,7 +408,10 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     print(f"Filtering {log_reads_type} alignment files done!!!")
     if write:
         print(f'Writing depths into "{directory}/{prefix}.depth.gz" ...')
-        _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
+        if text_on_device:
+            _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
+        else:
+            _write_depth_members(directory, prefix, depths)
         print("Writing depths done!!!\n\n")
     return depths, targets_length
 
@@ -421,12 +425,33 @@ def _reraise_like_reference(e: GciError):
     raise e
 
 
+# How `{prefix}.depth.gz` is produced.  "gpu" (default): the device writes the gzip members straight from the track
+# (gci_depth_deflate_*: no text buffer, a few MB cross PCIe).  "host": the device renders the text, host threads gzip it.
+DEPTH_GZ = os.environ.get("GCI_DEPTH_GZ", "gpu")
+
+
 def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads=1) -> None:
-    """`{directory}/{prefix}.depth.gz`: '>contig' line then one decimal per line (GCI.py:99-143).
-    Text is rendered on the GPU; the host only frames it as gzip members."""
+    """`{directory}/{prefix}.depth.gz`: '>contig' line then one decimal per line (GCI.py:99-143), as a multi-member
+    gzip (any gzip whose payload equals the reference's text is a valid .depth.gz)."""
     depths._bind()
+    if DEPTH_GZ == "gpu":
+        _write_depth_members(directory, prefix, depths)
+        return
     text, offs = depths.engine.depth_text(depths.track)
     _write_depth_text(directory, prefix, depths, text, offs, threads)
+
+
+def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
+    """'>contig' member (host), then the contig's lines as the members the device wrote."""
+    from . import hostio
+    blobs = depths.engine.depth_deflate(depths.track)
+    path = f"{directory}/{prefix}.depth.gz"
+    if os.path.exists(path):
+        os.remove(path)
+    with open(path, "wb") as f:
+        for t, blob in zip(depths.targets, blobs):
+            f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
+            f.write(blob)
 
 
 def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, threads) -> None:
