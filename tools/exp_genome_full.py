@@ -79,13 +79,24 @@ a = np.clip(iv[:, 1] + 15, 0, L); b = np.clip(iv[:, 2] - 15 + 1, 0, L)
 want_sum = int(np.maximum(b - a, 0).sum())
 got_sum = int(np.asarray(fused["sums"]).sum())
 text_total = int(fused["text_off"][-1])
-# decimal text: one line per base
-tr_bytes = None
+# .depth.gz members written by the device (gci_depth_deflate_*)
+import gzip
+torch.cuda.synchronize(); t = time.perf_counter()
+blobs = e.depth_deflate(track)
+torch.cuda.synchronize(); deflate_s = time.perf_counter() - t
+small = int(np.argmin(lens)); mid = int(np.argsort(lens)[len(lens) // 3])
+off = e.offsets
+ok_gz = True
+for c in (small, mid):
+    d_c = track[off[c]:off[c] + int(lens[c])].cpu().numpy()
+    ok_gz = ok_gz and gzip.decompress(blobs[c]) == ("\n".join(map(str, d_c.tolist())) + "\n").encode()
 out = {"scale": scale, "contigs": len(contigs), "bases": int(lens.sum()), "records_per_file": [int(o.shape[0]) for o in offsets],
        "heads_bytes_per_file": [int(s.shape[0]) for s in streams], "aligned_bases_both_files": aligned, "intervals_after_join": K,
        "us_per_launch": pr, "kernel_sum_ms": round(sum(pr.values()) / 1e3, 3),
        "step_wall_ms": [round(w * 1e3, 2) for w in walls],
        "aligned_Gbases_per_s": round(aligned / min(walls) / 1e9, 1),
        "sum_depth_equals_sum_of_clipped_intervals": got_sum == want_sum, "sum_depth": got_sum, "text_bytes": text_total,
+       "depth_gz_members_bytes": int(sum(len(x) for x in blobs)), "depth_gz_device_s": round(deflate_s, 4),
+       "depth_gz_two_contigs_decompress_to_the_track": bool(ok_gz),
        "issue_runs": int(sum(len(r) for r in fused["runs"])) if fused["runs"] is not None else None}
 print(json.dumps(out))
