@@ -205,29 +205,42 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
     bool done = n == 0;
     while (__any(!done)) {
         int k = 0;
+        // one element into the open run; false: it would close a run and the buffer is full (the element stays unread)
+        auto feed = [&](int32_t x) -> bool {
+            if (cnt && x != cur) {
+                if (k == RUNS) return false;
+                run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0;
+            }
+            cur = x; cnt++;
+            return true;
+        };
         while (!done && k < RUNS) {
             if (pos == n) {                                                           // close the last run
                 if (cnt) { run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0; }
                 done = true;
                 break;
             }
-            // four elements per load where the position allows (tiles start 16-byte aligned)
-            int32_t v[4];
-            uint32_t take;
-            if ((pos & 3u) == 0u && pos + 4u <= n) {
-                const int4 q = *reinterpret_cast<const int4*>(src + pos);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; take = 4;
-            } else { v[0] = src[pos]; v[1] = v[2] = v[3] = 0; take = 1; }
-            uint32_t used = 0;
-            for (uint32_t j = 0; j < take; j++) {
-                if (cnt && v[j] != cur) {
-                    if (k == RUNS) break;                                             // buffer full: come back to this element
-                    run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0;
+            if ((pos & 31u) == 0u && pos + 32u <= n) {
+                // 32 elements per step, all eight 16-byte loads in flight together (the lanes of a wave read tiles 16 KB
+                // apart: nothing coalesces, so the walk is bound by round trips -- one per step instead of eight)
+                int4 q[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const int4*>(src + pos + 4 * i);
+                bool full = false;
+                uint32_t used = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int32_t x[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (!full) { if (feed(x[j])) used++; else full = true; }
                 }
-                cur = v[j]; cnt++; used++;
+                pos += used;
+                if (full) break;
+            } else {
+                if (!feed(src[pos])) break;
+                pos++;
             }
-            pos += used;
-            if (used < take) break;                                                   // full
         }
         const int kmax = k;
         // encode: run r of every lane in the same iteration (the heavy arithmetic stays converged)
