@@ -26,6 +26,7 @@ import torch
 
 from . import score
 from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
+from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
 from .formats import bam as bamfmt
 from .formats import depthfile, fasta
@@ -280,11 +281,18 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         return engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
 
     if ingest == "heads":
-        with hostio.bam_heads(np.asarray(raw), threads=nthreads) as heads:
-            hdr = bamfmt.parse_header(heads.stream)
-            d_bam, d_off = engine.to_device(heads.stream), engine.to_device(heads.offsets)
-        recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
-        return JoinInput(recs, d_bam, d_off, 36)
+        try:
+            heads = hostio.bam_heads(np.asarray(raw), threads=nthreads)
+        except GciError as e:
+            if e.status != _lib.GCI_E_NOMEM:
+                raise
+            heads = None              # the address-space reservation was refused (strict overcommit): whole-stream ingestion
+        if heads is not None:
+            with heads:
+                hdr = bamfmt.parse_header(heads.stream)
+                d_bam, d_off = engine.to_device(heads.stream), engine.to_device(heads.offsets)
+            recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
+            return JoinInput(recs, d_bam, d_off, 36)
 
     pos, isz = hostio.bgzf_blocks(np.asarray(raw))
     if int(isz.sum()) <= chunk_bytes:
