@@ -357,6 +357,9 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 #define TR(i) do {} while (0)
 #endif
     TR(0);
+#if defined(GCI_K1_TRACE) && defined(GCI_K1_WALL)
+    if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 14] = wall_clock64();
+#endif
     if (blockIdx.x == 0 && threadIdx.x < 4) lq.next_counters[threadIdx.x] = 0u;    // nobody reads that set during this call
     if (blockIdx.x == 0 && threadIdx.x == 4) *lq.next_status = ~0ull;
     __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
@@ -607,6 +610,9 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     return false;
     };
     const bool is_slow = live && fast_path();
+#if defined(GCI_K1_TRACE) && defined(GCI_K1_WALL)
+    if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
+#endif
     // ---- slow records of this wave, one after the other, by the whole wave (rare: NM beyond the staged window, htslib's
     // CG:B,I long-CIGAR restore, names >= 185 bytes); no second kernel launch for them
     for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {

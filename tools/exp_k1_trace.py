@@ -3,7 +3,7 @@ import sys, subprocess, os, ctypes, numpy as np, torch
 sys.path.insert(0, '.')
 from gci_amd import build, synth, _lib
 so = "/tmp/libgci_trace.so"
-subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGCI_K1_TRACE", "-o", so] + build.SOURCES, check=True)
+subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGCI_K1_TRACE", "-DGCI_K1_WALL", "-o", so] + build.SOURCES, check=True)
 _lib.LIB_PATH = so
 from gci_amd.device import Engine
 e = Engine(0)
@@ -38,5 +38,11 @@ print("blocks", nb, "kernel span (cycles)", int(tr[:, 7].max() - t0))
 for i in (1, 2, 8, 9, 10, 3, 4, 5, 6, 7):
     v = rel[ok][:, i]
     print("phase %d: median %8.0f  p90 %8.0f  max %8.0f cycles since block start" % (i, np.median(v), np.percentile(v, 90), v.max()))
-starts = np.sort(tr[:, 0] - t0)
-print("block start times: p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(starts, [10, 50, 90, 100]).astype(int)))
+# slots 14 / 15: wall_clock64() (100 MHz, one time base for the whole device) at block start / end
+w0, w1 = tr[:, 14], tr[:, 15]
+base = w0.min()
+st, en = (w0 - base) / 100.0, (w1 - base) / 100.0
+print("wall clock (us): block starts p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | ends p50 %.1f p99 %.1f max %.1f | life p50 %.1f p90 %.1f" % (
+    *np.percentile(st, [1, 10, 50, 90, 99, 100]), *np.percentile(en, [50, 99, 100]), *np.percentile(en - st, [50, 90])))
+hist, edges = np.histogram(st, bins=12)
+print("start histogram (us):", [(round(float(a), 1), int(h)) for a, h in zip(edges[:-1], hist)])
