@@ -20,15 +20,35 @@
 #include "gci_ctx.hpp"
 #include <stdlib.h>
 
-#define G 4                      // lanes per record on the fast path
+#ifndef G
+#define G 4                      // lanes per record on the fast path (2 or 4)
+#endif
 #define NSLOT 10                 // op codes 0..8 (M I D N S H P = X) + one slot for everything else
 #define LONG_OPS 512u
+#ifndef HEAD
 #define HEAD 224                 // staged bytes from the record start
+#endif
+#ifndef AUXB
 #define AUXB 112                 // staged bytes from the aux start
+#endif
 #define HEADP (HEAD + 16)        // staged from the 16-byte boundary below the record start
 #define AUXP (AUXB + 16)
 #define ROW (HEADP + AUXP)
-#define KB 128                    // threads per workgroup of the fast path (32 records)
+#ifndef KB
+#define KB 128                    // threads per workgroup of the fast path (KB / G records)
+#endif
+#ifndef NUP
+#define NUP 3                     // 16-byte pieces of the CIGAR tail a lane requests together
+#endif
+#ifndef K1_WAVES
+#define K1_WAVES 6
+#endif
+// sum / min over the G lanes of a record
+#if G == 4
+#define GRP_STEPS(op) do { op(1); op(2); } while (0)
+#else
+#define GRP_STEPS(op) do { op(1); } while (0)
+#endif
 
 #define PIECES 8                  // 16-byte pieces per lane of one CIGAR chunk
 #define CHUNK_DW (64 * PIECES * 4)   // aligned dwords (= CIGAR ops) per chunk: 2048 ops, 8 KiB
@@ -341,7 +361,7 @@ __device__ __forceinline__ void slow_record(
 }
 
 // 80 VGPRs (the compiler settles on 83 by itself) and 12 KB of LDS: 6 waves per SIMD instead of 5, -3.5 us on chr19
-__global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_bam_filter(
+__global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_bam_filter(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status,
@@ -486,15 +506,17 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     if (4u * c + j - d < cnt) add_op(v);
                 }
             };
-            // the first three chunks are requested together (a lane's share of a HiFi tail is ~6 ops: one round
-            // trip); longer tails continue with one new chunk at a time
+            // the first NUP chunks are requested together (with four lanes per record a lane's share of a HiFi tail is
+            // ~6 ops: one round trip); longer tails continue with one new chunk at a time
             const uint32_t nch = (sh + 4u * cnt + 15u) >> 4;
             const uint4 z = make_uint4(0, 0, 0, 0);
-            const uint4 c0 = ld(a), c1 = nch > 1 ? ld(a + 16) : z, c2 = nch > 2 ? ld(a + 32) : z;
-            take(c0, c1.x, 0);
-            if (nch > 1) take(c1, c2.x, 1);
-            uint4 lo = c2;
-            for (uint32_t c = 2; c < nch; c++) {
+            uint4 cu[NUP];
+#pragma unroll
+            for (int i = 0; i < NUP; i++) cu[i] = (uint32_t)i < nch ? ld(a + 16ull * i) : z;
+#pragma unroll
+            for (int i = 0; i + 1 < NUP; i++) if ((uint32_t)i < nch) take(cu[i], cu[i + 1].x, (uint32_t)i);
+            uint4 lo = cu[NUP - 1];
+            for (uint32_t c = NUP - 1; c < nch; c++) {
                 const uint4 hi = c + 1 < nch ? ld(a + 16ull * (c + 1)) : z;
                 take(lo, hi.x, c);
                 lo = hi;
@@ -569,8 +591,9 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             break;
         }
     }
-    nul = min(nul, (uint32_t)__shfl_xor((int)nul, 1, G));
-    nul = min(nul, (uint32_t)__shfl_xor((int)nul, 2, G));
+#define STEP_MIN(m) nul = min(nul, (uint32_t)__shfl_xor((int)nul, m, G))
+    GRP_STEPS(STEP_MIN);
+#undef STEP_MIN
     const uint32_t name_len = nul;
     uint64_t acc = 0;
     for (uint32_t k = gl; k * 8 < name_len; k += G) {
@@ -581,8 +604,9 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         if (keep < 8) w &= (1ull << (8 * keep)) - 1ull;
         acc += gci_hash_word(w, k);
     }
-    acc += (uint64_t)__shfl_xor((long long)acc, 1, G);
-    acc += (uint64_t)__shfl_xor((long long)acc, 2, G);
+#define STEP_ACC(m) acc += (uint64_t)__shfl_xor((long long)acc, m, G)
+    GRP_STEPS(STEP_ACC);
+#undef STEP_ACC
     r.name_hash = gci_hash_finish(acc, name_len);
     r.name_len = (uint16_t)name_len;
 
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         return false;
     }
     // the four lanes' shares -> every lane of the group holds the record's totals
-#define GRP_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, G); x += (unsigned long long)__shfl_xor((long long)x, 2, G); } while (0)
+#define GRP_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, G); if (G == 4) x += (unsigned long long)__shfl_xor((long long)x, 2, G); } while (0)
     GRP_SUM(sM); GRP_SUM(sI); GRP_SUM(sD); GRP_SUM(sN); GRP_SUM(sS);
 #undef GRP_SUM
     if (gl != 0) return false;  // the rest is scalar per record
