@@ -93,7 +93,7 @@ EXPORTS = [
     ("gci_depth_sum", c_int, [c_void_p, c_void_p, c_void_p]),
     ("gci_range_sums", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     ("gci_fasta_n_scan", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p]),
-    ("gci_paf_filter", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
+    ("gci_paf_filter", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, ctypes.c_double, c_int, c_void_p, c_void_p]),
     ("gci_paf_count", c_uint64, [c_void_p, c_int]),
     ("gci_paf_name_bytes", c_uint64, [c_void_p, c_int]),
     ("gci_paf_export", c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -245,9 +245,9 @@ extern "C" int gci_gzip_members(const uint8_t* h_text, uint64_t n, uint64_t chun
 
 namespace {
 
-struct PafAln { int64_t qlen, qs, qe, ts, te; double identity; };
-struct PafTarget { int32_t t; std::vector<PafAln> alns; };
-struct PafQuery { std::string name; std::vector<PafTarget> targets; bool hq = false; };
+// one alignment line that passed the filter, in file order
+struct PafHit { const uint8_t* qn; uint32_t qn_len; int32_t t; int64_t qlen, qs, qe, ts, te; double identity; uint32_t hq; uint32_t query; };
+struct PafQueryRef { uint64_t name_off; uint32_t name_len; bool hq; };
 struct PafEmit { uint32_t query; int32_t target; int64_t s, e, qlen; };
 
 // union of closed-touching blocks: covered length and the longest merged block (leftmost on ties)
@@ -289,104 +289,207 @@ bool parse_int(const uint8_t* a, const uint8_t* b, int64_t& v)
 }  // namespace
 
 struct gci_paf {
-    std::vector<PafQuery> queries;
+    std::vector<PafQueryRef> queries;       // first-appearance order
+    std::vector<uint8_t> names;             // their names back to back
     std::vector<std::vector<PafEmit>> per_file;
 };
 
+namespace {
+
+// What one thread found in its share of a file's lines
+struct PafSlice {
+    std::vector<PafHit> hits;
+    uint64_t lines = 0;
+    int status = GCI_OK;
+    uint64_t err_line = 0;                  // 1-based inside the slice
+};
+
+inline bool line_starts_at(const uint8_t* base, const uint8_t* p)     // universal newlines: \n, \r, \r\n
+{
+    if (p == base) return true;
+    return p[-1] == '\n' || (p[-1] == '\r' && *p != '\n');
+}
+
+// the lines that START in [lo, hi): tokenise, filter (GCI.py:218-239), keep what passes
+void paf_scan(const uint8_t* base, const uint8_t* lo, const uint8_t* hi, const uint8_t* end,
+              const std::unordered_map<std::string, int32_t>& tmap, int map_qual, int mq_cutoff, double iden_percent, PafSlice& out)
+{
+    const uint8_t* p = lo;
+    while (p < hi && !line_starts_at(base, p)) p++;
+    std::string key;
+    while (p < hi) {
+        // one line, stripped like str.strip()
+        const uint8_t* le = p;
+        while (le < end && *le != '\n' && *le != '\r') le++;
+        const uint8_t* next = le;
+        if (next < end) next += (*next == '\r' && next + 1 < end && next[1] == '\n') ? 2 : 1;
+        const uint8_t *a = p, *b = le;
+        p = next;
+        out.lines++;
+        while (a < b && is_space(*a)) a++;
+        while (b > a && is_space(b[-1])) b--;
+        const uint8_t* col[13];
+        int nc = 0;
+        col[0] = a;
+        for (const uint8_t* q = a; q < b && nc < 12; q++) if (*q == '\t') col[++nc] = q + 1;
+        auto col_end = [&](int k) { const uint8_t* q = col[k]; while (q < b && *q != '\t') q++; return q; };
+        if (nc < 5) { out.status = GCI_E_MALFORMED; out.err_line = out.lines; return; }                 // col[5]: IndexError
+        key.assign((const char*)col[5], (size_t)(col_end(5) - col[5]));
+        const auto ti = tmap.find(key);
+        if (ti == tmap.end()) continue;
+        int64_t v[12] = {0};
+        bool ok = nc >= 11;
+        for (int k : {1, 2, 3, 7, 8, 9, 10, 11}) ok = ok && parse_int(col[k], col_end(k), v[k]);
+        if (!ok) { out.status = GCI_E_MALFORMED; out.err_line = out.lines; return; }
+        if (v[10] == 0) { out.status = GCI_E_ZERO_DIV; out.err_line = out.lines; return; }                 // nmatch / alnlen
+        const double identity = (double)v[9] / (double)v[10];
+        if (v[11] >= map_qual && identity >= iden_percent)
+            out.hits.push_back(PafHit{col[0], (uint32_t)(col_end(0) - col[0]), ti->second, v[1], v[2], v[3], v[7], v[8], identity,
+                                      v[11] >= mq_cutoff ? 1u : 0u, 0u});
+    }
+}
+
+}  // namespace
+
+// threads: host threads for the tokenising pass and the per-query arithmetic (0 = one per hardware thread, at most 32)
 extern "C" int gci_paf_filter(const uint8_t* const* h_files, const uint64_t* n_bytes, int n_files, const char* const* targets,
-                              int n_targets, int map_qual, int mq_cutoff, double iden_percent, gci_paf** out, uint64_t* err_line)
+                              int n_targets, int map_qual, int mq_cutoff, double iden_percent, int threads, gci_paf** out,
+                              uint64_t* err_line)
 {
     if (!out || n_files < 0 || (n_files && (!h_files || !n_bytes)) || (n_targets && !targets)) return GCI_E_INVALID;
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); threads = threads < 1 ? 1 : threads > 32 ? 32 : threads; }
     gci_paf* R = new (std::nothrow) gci_paf();
     if (!R) return GCI_E_NOMEM;
     std::unordered_map<std::string, int32_t> tmap;
     for (int t = 0; t < n_targets; t++) tmap.emplace(targets[t], t);
-    std::unordered_map<std::string, uint32_t> qmap;
+    // all hits of all files so far, in file order (the reference never resets its table between files), and the
+    // queries in first-appearance order: open addressing on the 64-bit name hash, names verified
+    std::vector<PafHit> hits;
+    std::vector<const uint8_t*> qname_ptr;
+    std::vector<uint64_t> slot_hash;
+    std::vector<uint32_t> slot_query;
+    size_t n_slots = 1024;
+    slot_hash.assign(n_slots, 0); slot_query.assign(n_slots, 0xFFFFFFFFu);
+    auto grow = [&]() {
+        const size_t m = n_slots * 2;
+        std::vector<uint64_t> h2(m, 0); std::vector<uint32_t> q2(m, 0xFFFFFFFFu);
+        for (size_t i = 0; i < n_slots; i++) if (slot_query[i] != 0xFFFFFFFFu) {
+            size_t k = (size_t)(slot_hash[i] ^ (slot_hash[i] >> 29)) & (m - 1);
+            while (q2[k] != 0xFFFFFFFFu) k = (k + 1) & (m - 1);
+            h2[k] = slot_hash[i]; q2[k] = slot_query[i];
+        }
+        slot_hash.swap(h2); slot_query.swap(q2); n_slots = m;
+    };
     int status = GCI_OK;
     for (int f = 0; f < n_files && status == GCI_OK; f++) {
-        const uint8_t* p = h_files[f];
-        const uint8_t* end = p + n_bytes[f];
-        uint64_t line_no = 0;
-        while (p < end) {
-            // one line (universal newlines), stripped like str.strip()
-            const uint8_t* le = p;
-            while (le < end && *le != '\n' && *le != '\r') le++;
-            const uint8_t* next = le;
-            if (next < end) next += (*next == '\r' && next + 1 < end && next[1] == '\n') ? 2 : 1;
-            const uint8_t *a = p, *b = le;
-            p = next;
-            line_no++;
-            while (a < b && is_space(*a)) a++;
-            while (b > a && is_space(b[-1])) b--;
-            const uint8_t* col[13];
-            int nc = 0;
-            col[0] = a;
-            for (const uint8_t* q = a; q < b && nc < 12; q++) if (*q == '\t') col[++nc] = q + 1;
-            // col[k] .. col[k + 1] - 1 is column k for k < nc; the last found column runs to the next tab or b
-            auto col_end = [&](int k) { const uint8_t* q = col[k]; while (q < b && *q != '\t') q++; return q; };
-            if (nc < 5) { status = GCI_E_MALFORMED; if (err_line) *err_line = line_no; break; }       // col[5]: IndexError
-            const auto ti = tmap.find(std::string((const char*)col[5], (size_t)(col_end(5) - col[5])));
-            if (ti == tmap.end()) continue;
-            int64_t v[12] = {0};
-            bool ok = nc >= 11;
-            for (int k : {1, 2, 3, 7, 8, 9, 10, 11}) ok = ok && parse_int(col[k], col_end(k), v[k]);
-            if (!ok) { status = GCI_E_MALFORMED; if (err_line) *err_line = line_no; break; }
-            if (v[10] == 0) { status = GCI_E_ZERO_DIV; if (err_line) *err_line = line_no; break; }      // nmatch / alnlen
-            const double identity = (double)v[9] / (double)v[10];
-            if (v[11] >= map_qual && identity >= iden_percent) {
-                std::string qname((const char*)col[0], (size_t)(col_end(0) - col[0]));
-                auto qi = qmap.find(qname);
-                uint32_t qidx;
-                if (qi == qmap.end()) {
-                    qidx = (uint32_t)R->queries.size();
-                    qmap.emplace(qname, qidx);
-                    R->queries.emplace_back();
-                    R->queries.back().name = std::move(qname);
-                } else qidx = qi->second;
-                PafQuery& Q = R->queries[qidx];
-                PafTarget* T = nullptr;
-                for (auto& x : Q.targets) if (x.t == ti->second) { T = &x; break; }
-                if (!T) { Q.targets.push_back(PafTarget{ti->second, {}}); T = &Q.targets.back(); }
-                T->alns.push_back(PafAln{v[1], v[2], v[3], v[7], v[8], identity});
-                if (v[11] >= mq_cutoff) Q.hq = true;
-            }
+        const uint8_t* base = h_files[f];
+        const uint8_t* end = base + n_bytes[f];
+        // ---- pass 1 (parallel): every thread the lines that start in its byte range
+        const uint64_t n_slices = n_bytes[f] < (1u << 16) ? 1 : (uint64_t)threads * 4;
+        std::vector<PafSlice> slices(n_slices);
+        parallel_for(n_slices, threads, [&](uint64_t i) {
+            paf_scan(base, base + n_bytes[f] * i / n_slices, base + n_bytes[f] * (i + 1) / n_slices, end, tmap, map_qual, mq_cutoff,
+                     iden_percent, slices[i]);
+        });
+        uint64_t lines_before = 0;
+        for (const PafSlice& sl : slices) {                      // the first offending line in file order, as the reference's loop
+            if (sl.status != GCI_OK) { status = sl.status; if (err_line) *err_line = lines_before + sl.err_line; break; }
+            lines_before += sl.lines;
         }
         if (status != GCI_OK) break;
-        // every query seen so far, in first-appearance order
-        std::vector<PafEmit> emit;
-        emit.reserve(R->queries.size());
-        std::vector<std::pair<int64_t, int64_t>> pairs;
-        for (uint32_t qi = 0; qi < R->queries.size(); qi++) {
-            const PafQuery& Q = R->queries[qi];
-            bool have = false;
-            double best_rank = 0;
-            const char* best_name = nullptr;
-            PafEmit best{qi, -1, 0, 0, 0};
-            for (const PafTarget& T : Q.targets) {
-                pairs.clear();
-                for (const PafAln& x : T.alns) pairs.emplace_back(x.qs, x.qe);
-                int64_t covered, s, e;
-                merge_span(pairs, covered, s, e);
-                const int64_t qlen = T.alns[0].qlen;
-                if (qlen == 0) { status = GCI_E_ZERO_DIV; break; }
-                double total = 0.0;
-                for (const PafAln& x : T.alns) total = total + x.identity;          // file order, as sum() does
-                const double rank = total / (double)T.alns.size() * ((double)covered / (double)qlen);
-                const char* name = targets[T.t];
-                if (!have || rank > best_rank || (rank == best_rank && strcmp(name, best_name) > 0)) {
-                    pairs.clear();
-                    for (const PafAln& x : T.alns) pairs.emplace_back(x.ts, x.te);
-                    merge_span(pairs, covered, s, e);
-                    have = true; best_rank = rank; best_name = name;
-                    best = PafEmit{qi, T.t, s, e, qlen};
+        // ---- pass 2 (serial, cheap): query index of every hit
+        const size_t first_new = hits.size();
+        for (const PafSlice& sl : slices) hits.insert(hits.end(), sl.hits.begin(), sl.hits.end());
+        for (size_t i = first_new; i < hits.size(); i++) {
+            PafHit& h = hits[i];
+            if ((R->queries.size() + 1) * 2 > n_slots) grow();
+            const uint64_t hv = gci_name_hash(h.qn, h.qn_len) | 1ull;                 // never 0
+            size_t k = (size_t)(hv ^ (hv >> 29)) & (n_slots - 1);
+            for (;;) {
+                const uint32_t q = slot_query[k];
+                if (q == 0xFFFFFFFFu) {
+                    slot_hash[k] = hv; slot_query[k] = (uint32_t)R->queries.size();
+                    h.query = (uint32_t)R->queries.size();
+                    R->queries.push_back(PafQueryRef{0, h.qn_len, false});
+                    qname_ptr.push_back(h.qn);
+                    break;
                 }
+                if (slot_hash[k] == hv && R->queries[q].name_len == h.qn_len && memcmp(qname_ptr[q], h.qn, h.qn_len) == 0) { h.query = q; break; }
+                k = (k + 1) & (n_slots - 1);
             }
-            if (status != GCI_OK) break;
-            emit.push_back(best);
+            if (h.hq) R->queries[h.query].hq = true;
         }
+        // hits of a query side by side, file order kept (counting sort by query)
+        const size_t nq = R->queries.size();
+        std::vector<uint64_t> start(nq + 1, 0);
+        for (const PafHit& h : hits) start[h.query + 1]++;
+        for (size_t q = 0; q < nq; q++) start[q + 1] += start[q];
+        std::vector<uint32_t> order(hits.size());
+        {
+            std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+            for (size_t i = 0; i < hits.size(); i++) order[cur[hits[i].query]++] = (uint32_t)i;
+        }
+        // ---- pass 3 (parallel over queries): GCI.py:241-254
+        std::vector<PafEmit> emit(nq);
+        std::atomic<int> qstatus{GCI_OK};
+        const uint64_t q_slices = nq < 4096 ? 1 : (uint64_t)threads * 8;
+        parallel_for(q_slices, threads, [&](uint64_t si) {
+            std::vector<std::pair<int64_t, int64_t>> pairs;
+            std::vector<int32_t> seen;
+            for (size_t q = nq * si / q_slices; q < nq * (si + 1) / q_slices; q++) {
+                bool have = false;
+                double best_rank = 0;
+                const char* best_name = nullptr;
+                PafEmit best{(uint32_t)q, -1, 0, 0, 0};
+                seen.clear();
+                for (uint64_t a = start[q]; a < start[q + 1]; a++) {
+                    const int32_t t = hits[order[a]].t;
+                    bool dup = false;
+                    for (int32_t x : seen) dup = dup || x == t;
+                    if (dup) continue;
+                    seen.push_back(t);
+                    // this target's blocks, in file order
+                    pairs.clear();
+                    int64_t qlen = 0;
+                    double total = 0.0;
+                    uint64_t n_aln = 0;
+                    for (uint64_t c = a; c < start[q + 1]; c++) {
+                        const PafHit& x = hits[order[c]];
+                        if (x.t != t) continue;
+                        if (n_aln == 0) qlen = x.qlen;                                  // qlen of the first block
+                        pairs.emplace_back(x.qs, x.qe);
+                        total = total + x.identity;                                     // file order, as sum() does
+                        n_aln++;
+                    }
+                    int64_t covered, s0, e0;
+                    merge_span(pairs, covered, s0, e0);
+                    if (qlen == 0) { qstatus = GCI_E_ZERO_DIV; break; }
+                    const double rank = total / (double)n_aln * ((double)covered / (double)qlen);
+                    const char* name = targets[t];
+                    if (!have || rank > best_rank || (rank == best_rank && strcmp(name, best_name) > 0)) {
+                        pairs.clear();
+                        for (uint64_t c = a; c < start[q + 1]; c++) {
+                            const PafHit& x = hits[order[c]];
+                            if (x.t == t) pairs.emplace_back(x.ts, x.te);
+                        }
+                        merge_span(pairs, covered, s0, e0);
+                        have = true; best_rank = rank; best_name = name;
+                        best = PafEmit{(uint32_t)q, t, s0, e0, qlen};
+                    }
+                }
+                emit[q] = best;
+            }
+        });
+        if (qstatus.load() != GCI_OK) { status = qstatus.load(); break; }
         R->per_file.push_back(std::move(emit));
     }
     if (status != GCI_OK) { delete R; return status; }
+    // the result owns its names
+    uint64_t off = 0;
+    for (size_t q = 0; q < R->queries.size(); q++) { R->queries[q].name_off = off; off += R->queries[q].name_len; }
+    R->names.resize(off);
+    for (size_t q = 0; q < R->queries.size(); q++)
+        if (R->queries[q].name_len) memcpy(R->names.data() + R->queries[q].name_off, qname_ptr[q], R->queries[q].name_len);
     *out = R;
     return GCI_OK;
 }
@@ -400,7 +503,7 @@ extern "C" uint64_t gci_paf_name_bytes(const gci_paf* r, int file)
 {
     if (!r || file < 0 || (size_t)file >= r->per_file.size()) return 0;
     uint64_t n = 0;
-    for (const PafEmit& e : r->per_file[file]) n += r->queries[e.query].name.size();
+    for (const PafEmit& e : r->per_file[file]) n += r->queries[e.query].name_len;
     return n;
 }
 
@@ -411,26 +514,27 @@ extern "C" int gci_paf_export(const gci_paf* r, int file, gci_rec* h_recs, uint8
     const auto& em = r->per_file[file];
     if (em.size() && (!h_recs || !h_names)) {
         bool any_bytes = false;
-        for (const PafEmit& e : em) any_bytes = any_bytes || !r->queries[e.query].name.empty();
+        for (const PafEmit& e : em) any_bytes = any_bytes || r->queries[e.query].name_len != 0;
         if (!h_recs || (any_bytes && !h_names)) return GCI_E_INVALID;
     }
     uint64_t off = 0;
     for (size_t i = 0; i < em.size(); i++) {
         const PafEmit& e = em[i];
-        const PafQuery& Q = r->queries[e.query];
+        const PafQueryRef& Q = r->queries[e.query];
+        const uint8_t* qn = r->names.data() + Q.name_off;
         for (int64_t x : {e.s, e.e, e.qlen}) if (x > 0x7fffffffLL || x < -0x80000000LL) return GCI_E_INVALID;
-        if (Q.name.size() > 0xFFFF) return GCI_E_INVALID;
+        if (Q.name_len > 0xFFFF) return GCI_E_INVALID;
         gci_rec rec;
         memset(&rec, 0, sizeof rec);
-        rec.name_hash = gci_name_hash((const uint8_t*)Q.name.data(), (uint32_t)Q.name.size());
+        rec.name_hash = gci_name_hash(qn, Q.name_len);
         rec.contig = e.target; rec.start = (int32_t)e.s; rec.end = (int32_t)e.e; rec.qlen = (int32_t)e.qlen;
         rec.rec_idx = (uint32_t)i; rec.mapq = 0;
         rec.flags = (uint8_t)(GCI_REC_PASS | (Q.hq ? GCI_REC_HQ : 0));
-        rec.name_len = (uint16_t)Q.name.size();
+        rec.name_len = (uint16_t)Q.name_len;
         h_recs[i] = rec;
         h_name_off[i] = off;
-        if (!Q.name.empty()) memcpy(h_names + off, Q.name.data(), Q.name.size());
-        off += Q.name.size();
+        if (Q.name_len) memcpy(h_names + off, qn, Q.name_len);
+        off += Q.name_len;
     }
     h_name_off[em.size()] = off;
     return GCI_OK;

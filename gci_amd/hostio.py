@@ -172,7 +172,7 @@ def bam_heads(raw: np.ndarray, threads: int = 0, group_bytes: int = 0, check_crc
     return BamHeads(h, stream, offs, int(lib.gci_bam_heads_first(h)))
 
 
-def paf_filter(paths, targets, map_qual: int, mq_cutoff: int, iden_percent: float):
+def paf_filter(paths, targets, map_qual: int, mq_cutoff: int, iden_percent: float, threads: int = 0):
     """The PAF filter of filter() (GCI.py:211-254) in native code (gci_paf_filter): per PAF file, in command-line
     order, -> (records uint8 [n, 32] = gci_rec, names uint8 blob, int64 [n + 1] name offsets): one entry per query seen
     so far, in first-appearance order; the HQ flag carries the reference's high_qual set."""
@@ -185,7 +185,7 @@ def paf_filter(paths, targets, map_qual: int, mq_cutoff: int, iden_percent: floa
     tarr = (ctypes.c_char_p * max(len(tnames), 1))(*tnames)
     handle, line = ctypes.c_void_p(None), ctypes.c_uint64(0)
     st = lib.gci_paf_filter(ptrs, sizes, n, tarr, len(tnames), int(map_qual), int(mq_cutoff), float(iden_percent),
-                            ctypes.byref(handle), ctypes.byref(line))
+                            int(threads or default_threads()), ctypes.byref(handle), ctypes.byref(line))
     if st != 0:
         raise GciError(st, "gci_paf_filter: %s (line %d)" % (lib.gci_strerror(st).decode(), line.value))
     try:

@@ -337,10 +337,13 @@ int gci_gzip_members(const uint8_t* h_text, uint64_t n, uint64_t chunk, int leve
  * gci_rec.contig).  On success *out holds, per file, one compact record + name for every query seen so far in first-
  * appearance order (the reference's block table is created once, outside its per-file loop); GCI_REC_HQ marks the
  * names of the reference's high_qual set as it stands after the last file.  GCI_E_MALFORMED / GCI_E_ZERO_DIV: a line
- * the reference would raise IndexError / ValueError / ZeroDivisionError on; *err_line = its 1-based number. */
+ * the reference would raise IndexError / ValueError / ZeroDivisionError on; *err_line = its 1-based number.
+ * Lines are tokenised and filtered on `threads` host threads (byte ranges cut at line starts), queries are numbered in
+ * first-appearance order by one pass over the surviving lines, and the per-query arithmetic runs in parallel again. */
 typedef struct gci_paf gci_paf;
 int gci_paf_filter(const uint8_t* const* h_files, const uint64_t* n_bytes, int n_files, const char* const* targets,
-                   int n_targets, int map_qual, int mq_cutoff, double iden_percent, gci_paf** out, uint64_t* err_line);
+                   int n_targets, int map_qual, int mq_cutoff, double iden_percent, int threads /* 0 = automatic */,
+                   gci_paf** out, uint64_t* err_line);
 uint64_t gci_paf_count(const gci_paf* r, int file);
 uint64_t gci_paf_name_bytes(const gci_paf* r, int file);
 int gci_paf_export(const gci_paf* r, int file, gci_rec* h_recs, uint8_t* h_names, uint64_t* h_name_off /* count + 1 */);

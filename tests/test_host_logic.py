@@ -122,6 +122,44 @@ def test_native_paf_filter_randomised(oracle, tmp_path):
             for a, b, c in zip(got[0], py[0], want[0]):
                 assert list(a.items()) == list(b.items()) == list(c.items())
             assert len(got[0][2]) >= len(got[0][0]) > 20
+    # files large enough to be cut into many byte ranges (one per thread and more): same dicts in the same order as the
+    # line-by-line statement, whatever the thread count; and the first offending line is reported, not any
+    big = []
+    for f in range(2):
+        rows = []
+        for i in range(12_000):
+            q = "m64011_190830_220126/%d/ccs" % int(rng.integers(0, 7000))
+            qlen = int(rng.choice([9000, 15000, 21000]))
+            qs = int(rng.integers(0, 50)) * 100
+            qe = min(qlen, qs + int(rng.integers(10, 150)) * 100)
+            t = str(rng.choice(targets + ["other"]))
+            ts = int(rng.integers(0, 900)) * 100
+            aln = qe - qs
+            rows.append("\t".join(map(str, (q, qlen, qs, qe, "+", t, 100000, ts, ts + aln, int(aln * rng.choice([0.88, 0.93, 0.99])), aln,
+                                            int(rng.choice([0, 29, 30, 49, 50, 60])), "tp:A:P"))))
+        p = tmp_path / ("big%d.paf" % f)
+        p.write_bytes(("\r\n" if f else "\n").join(rows).encode() + b"\n")
+        assert p.stat().st_size > 600_000
+        big.append(str(p))
+    want_big = paf_filter_py(big, targets, 30, 50, 0.9)
+    from gci_amd import hostio
+    for th in (1, 3, 8):
+        native = hostio.paf_filter(big, targets, 30, 50, 0.9, threads=th)
+        ref1 = hostio.paf_filter(big, targets, 30, 50, 0.9, threads=1)
+        for (r1, n1, o1), (r2, n2, o2) in zip(native, ref1):
+            assert np.array_equal(r1, r2) and np.array_equal(n1, n2) and np.array_equal(o1, o2)
+    got_big = paf_filter(big, targets, 30, 50, 0.9)
+    assert got_big[1] == want_big[1]
+    for a, b in zip(got_big[0], want_big[0]):
+        assert list(a.items()) == list(b.items())
+    lines = open(big[0], "rb").read().split(b"\n")
+    lines[7000] = lines[7000].replace(b"\t", b" ", 20)                      # no tabs left: IndexError in the reference
+    lines[9000] = b"x"
+    (tmp_path / "bigbad.paf").write_bytes(b"\n".join(lines))
+    for th in (1, 8):
+        with pytest.raises(GciError) as err:
+            hostio.paf_filter([str(tmp_path / "bigbad.paf")], targets, 30, 50, 0.9, threads=th)
+        assert "line 7001" in str(err.value)
     bad = tmp_path / "bad.paf"
     for text in ("q\t100\t0\t50\t+\n", "q\t100\t0\t50\t+\tt0\t1000\t0\t50\t50\t0\t60\n",
                  "q\t100\t0\tx\t+\tt0\t1000\t0\t50\t50\t50\t60\n", "q\t100\t0\t50\t+\tt0\t1000\t0\t50\t50\t50\n"):
