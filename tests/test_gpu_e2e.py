@@ -130,8 +130,13 @@ def test_full_size_properties_chr19(engine, oracle):
     assert torch.equal(t1 + t2, track)
     # text round trip at full size
     text, toff = engine.depth_text(track)
-    back = oracle.parse_depth_text(b">chr19\n" + text.cpu().numpy().tobytes())["chr19"]
+    raw_text = text.cpu().numpy().tobytes()
+    back = oracle.parse_depth_text(b">chr19\n" + raw_text)["chr19"]
     assert np.array_equal(back, tr["chr19"])
+    # the gzip members the device writes for the same track (236 members, every CRC checked by gzip) hold the same text
+    members = engine.depth_deflate(track)
+    assert len(members) == 1 and len(members[0]) * 50 < len(raw_text)
+    assert gzip.decompress(members[0]) == raw_text
     # issue scan == oracle scan of the same depth
     assert pipeline.collapse_depth_range(tr, -1, 0, 15, 0)["chr19"] == oracle.collapse_contig(back, -1, 0, 15, 0)
     # gap mask idempotent, max2(x, x) == x
