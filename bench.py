@@ -4,10 +4,11 @@
 A "step" is one pass of the hot path over one batch of synthetic alignments whose inflated BAM
 bytes are already resident in HBM:
 
-    K1 record filter -> [N>1: RCCL all-gather of compact records + names] -> K3 name join
+    K1 record filter -> [N>1: exact cross-rank name check, one RCCL all-to-all of 8-byte name hashes; only if a name
+       is shared between ranks: all-gather of compact records + names and the replicated join] -> K3 name join
     -> K4/K5 depth build with, fused into the same two passes over the per-tile event buckets, the
        per-contig sums, the issue-scan run boundaries and the decimal depth text (K8 / K10 / R15)
-    -> [N>1: RCCL all-reduce of the int64 totals]
+    -> [N>1: RCCL all-reduce of the int64 sum of depth]
 
 Workload at N=1: BASELINE.json configs[1] -- CHM13 chr19 (61,707,364 bp), one 40x HiFi BAM.
 At N>1 (weak scaling) every rank owns one chr19-sized contig of an N-contig assembly and the
@@ -111,11 +112,11 @@ class Workload:
         self.keys = torch.empty(1 << 16, dtype=torch.int64, device=dev)
         self.nkeys = torch.zeros(1, dtype=torch.int32, device=dev)
         self.text_off = torch.zeros(2, dtype=torch.int64, device=dev)
-        # [sum of depth (written by the build: d_sums), bases of this rank, cross-rank name conflicts (low word: the int32
-        # counter of the name check)] -- one copy into `totals` and ONE all-reduce per step at N > 1
+        # [sum of depth (zeroed and written by every build: d_sums), bases of this rank, cross-rank name conflicts so far
+        # (low word: the int32 counter of the name check)].  At N > 1 the step all-reduces the sum IN PLACE (the global
+        # mean depth is that over the constant total of bases); the conflict count is all-reduced once, in check().
         self.totals_src = torch.zeros(3, dtype=torch.int64, device=dev)
         self.sums = self.totals_src[0:1]
-        self.totals = torch.zeros(3, dtype=torch.int64, device=dev)
         self.status = torch.zeros(2, dtype=torch.int64, device=dev)
         self.text = None
         self.rec_base = 0
@@ -197,9 +198,8 @@ class Workload:
             "gci_depth_build_finish")
         if self.exchange:
             import torch.distributed as dist
-            # ONE integer all-reduce per step: [sum of depth, bases, cross-rank name conflicts seen so far]
-            self.totals.copy_(self.totals_src)
-            dist.all_reduce(self.totals, op=dist.ReduceOp.SUM)      # global mean depth = totals[0] / totals[1]
+            # ONE integer all-reduce per step, in place: the genome-wide sum of depth (global mean depth = that / bases)
+            dist.all_reduce(self.sums, op=dist.ReduceOp.SUM)
 
     def check(self):
         """Record-level status of the last step + issue-key capacity."""
@@ -211,8 +211,12 @@ class Workload:
                 raise GciError(st, "%s failed on record %d" % (what, rec.value))
         if int(self.nkeys.item()) > self.keys.shape[0] or int(self.count.item()) > self.ivl.shape[0]:
             raise GciError(-8, "bench output buffers too small")
-        if self.exchange and not self.force_replicated and int(self.totals[2].item()) > 0:
-            return False          # a query name is shared between ranks: the speculative local joins were not exact
+        if self.exchange and not self.force_replicated:
+            import torch.distributed as dist
+            conf = self.totals_src[2:3].clone()                  # every rank's count of hashes seen from two ranks
+            dist.all_reduce(conf, op=dist.ReduceOp.SUM)
+            if int(conf.item()) > 0:
+                return False      # a query name is shared between ranks: the speculative local joins were not exact
         return True
 
 
