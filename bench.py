@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- aligned Gbases/s through the filter+depth pipeline (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic alignments whose inflated BAM
-bytes are already resident in HBM:
+A "step" is one pass of the hot path over one batch of synthetic alignments whose record bytes are already resident
+in HBM:
 
-    K1 record filter -> [N>1: exact cross-rank name check, one RCCL all-to-all of 8-byte name hashes; only if a name
-       is shared between ranks: all-gather of compact records + names and the replicated join] -> K3 name join
-    -> K4/K5 depth build with, fused into the same two passes over the per-tile event buckets, the
-       per-contig sums, the issue-scan run boundaries and the decimal depth text (K8 / K10 / R15)
-    -> [N>1: RCCL all-reduce of the int64 sum of depth]
+    K1 record filter, once per input file -> [N>1: exact cross-rank name check, one RCCL all-to-all of 8-byte name
+       hashes; only if a name is shared between ranks: all-gather of compact records + names, replicated join]
+    -> K3 name join over the files (the `-op` overlap join, GCI.py:272-301)
+    -> K4/K5 depth build with, fused into the same two passes over the per-tile event buckets, the per-contig sums,
+       the issue-scan run boundaries and the decimal depth text (K8 / K10 / R15)
+    -> [N>1: RCCL all-reduce of the int64 sums of depth]
 
-Workload at N=1: BASELINE.json configs[1] -- CHM13 chr19 (61,707,364 bp), one 40x HiFi BAM.
-At N>1 (weak scaling) every rank owns one chr19-sized contig of an N-contig assembly and the
-records of that contig; results are identical to a single-GPU run over the same N contigs.
+Workload at N=1 (default): BASELINE.json configs[2] -- CHM13 whole genome (25 contigs, 3.117 Gb), HiFi 40x aligned
+by two aligners (two BAM files of the same reads: the `-op` join has work to do), fed as heads streams (records
+without SEQ / QUAL: what `gci_bam_heads` makes of a BGZF file and what the command line uploads).
+`--workload chr19` keeps configs[1] (one chr19-sized contig, one 40x HiFi BAM, whole inflated stream in HBM).
+At N>1 (weak scaling) every rank owns one CHM13-sized haplotype of an N-haplotype assembly and the records of its
+contigs from both files.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -35,6 +39,8 @@ if ROOT not in sys.path:
 
 CHR19_LEN = 61_707_364
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FILTER = (30, 50, 0.1, 0.9)    # -mq, -mc, -cp, -ip defaults (GCI.py:1040-1069)
+OVLP, FLANK = 0.9, 15
 
 
 def parse_args():
@@ -42,16 +48,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="per-rank contig length (default chr19)")
+    ap.add_argument("--workload", choices=("genome", "chr19"), default="genome",
+                    help="genome: BASELINE configs[2] (default); chr19: configs[1], one contig and one BAM per rank")
+    ap.add_argument("--scale", type=float, default=1.0, help="genome workload: shrink every contig (testing only)")
+    ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="chr19 workload: per-rank contig length")
     ap.add_argument("--coverage", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip numbers (2) and (3) of SURVEY.md 8(d): the device pipeline incl. H2D / D2H and the "
+                         "command-line wall time on a chr19 BAM with realistic SEQ / QUAL entropy")
     ap.add_argument("--inflight", type=int, default=1,
-                    help="steps in flight (1 GPU only): N > 1 runs consecutive steps on N streams, each with its own library "
-                         "context and buffers -- the latency-bound filter / join of one step then overlaps the HBM-bound tile "
-                         "build of another.  Default 1: every kernel runs alone and the roofline figure is that of the kernel")
-    ap.add_argument("--heads", action="store_true",
-                    help="feed the filter the heads stream (records without SEQ / QUAL, what the command line uploads: "
-                         "gci_bam_heads + gci_bam_filter_heads) instead of the whole inflated stream")
+                    help="chr19 workload, 1 GPU: N > 1 runs consecutive steps on N streams with a context each")
+    ap.add_argument("--heads", action="store_true", help="chr19 workload: feed the heads stream instead of the whole stream")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU name check / exchange and the all-reduce even with one rank (self-test)")
     ap.add_argument("--force-replicated", action="store_true",
@@ -59,183 +67,470 @@ def parse_args():
     return ap.parse_args()
 
 
-class Workload:
-    """Per-rank resident inputs + preallocated outputs for one step."""
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
-    def __init__(self, eng, rank, world, contig_len, coverage, exchange=False, replicated=False, heads=False):
+
+class Workload:
+    """Per-rank resident inputs + preallocated outputs for one step over F input files."""
+
+    def __init__(self, eng, rank, world, contigs, files, heads, exchange=False, replicated=False, name="", algo=None):
+        """contigs: the (name, length) table of the WHOLE run (all ranks); `files`: this rank's slice of every input
+        file as (stream uint8, offsets uint64, name_bytes) host arrays whose BAM header lists `contigs`;
+        the rank owns the contigs `own` = indices into `contigs` (set by the caller through self.own before layout)."""
         import torch
-        from gci_amd import synth
         self.torch = torch
         self.eng, self.rank, self.world = eng, rank, world
-        names = ["chr19"] if world == 1 else ["chr19_%d" % r for r in range(world)]
-        self.contigs = tuple((n, contig_len) for n in names)
-        # this rank's slice of the BAM: the records of its own contig
-        own = ((names[rank], contig_len),)
-        rs = synth.simulate_reads(own, coverage, "hifi", seed=synth.seed_for(2, rank))
-        self.aligned_bases = rs.aligned_bases()
-        self.n_rec = len(rs)
-        self.name_bytes = int(np.char.str_len(rs.names).sum())
-        # the BAM header lists all N contigs; refID of this rank's records = rank
-        rs.ref_id[:] = rank
-        rs.contigs = self.contigs
-        stream, offs = synth.to_bam_stream(rs)
-        self.stream_bytes = int(stream.shape[0])
-        self.host_stream, self.host_offs = (stream, offs) if rank == 0 and world == 1 else (None, None)
-        self.heads = heads
-        if heads:                                          # through a BGZF file and the native host pipeline, as the CLI does
-            import tempfile
-            from gci_amd import hostio
-            from gci_amd.formats import bam as bamfmt
-            with tempfile.TemporaryDirectory(prefix="gci_bench_") as tmp:
-                path = os.path.join(tmp, "r%d.bam" % rank)
-                bamfmt.write_bam_stream(path, stream, level=1, threads=hostio.default_threads())
-                with hostio.bam_heads(np.fromfile(path, dtype=np.uint8)) as hd:
-                    assert hd.offsets.shape[0] == self.n_rec
-                    self.d_bam, self.d_off = eng.to_device(hd.stream), eng.to_device(hd.offsets)
-            self.stream_bytes = int(self.d_bam.shape[0])
-        else:
-            self.d_bam = eng.to_device(stream)
-            self.d_off = eng.to_device(offs)
-        del stream
-        self.ref_sel = eng.to_device(np.arange(world, dtype=np.int32))
-        eng.set_layout([contig_len])                       # local track: the contig this rank owns
-        cmap = np.full(world, -1, dtype=np.int32)
-        cmap[rank] = 0
+        self.contigs, self.heads, self.name = contigs, heads, name
+        self.algo = algo or {}
         self.exchange = exchange or world > 1
         self.force_replicated = replicated
-        self.contig_map = eng.to_device(cmap) if self.exchange else None
-        dev = eng.device
-        self.recs = torch.empty((self.n_rec, 32), dtype=torch.uint8, device=dev)
-        self.track = eng.new_track()
-        self.ivl = torch.empty((self.n_rec * (world if world > 1 else 1), 4), dtype=torch.int32, device=dev)
-        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.keys = torch.empty(1 << 16, dtype=torch.int64, device=dev)
-        self.nkeys = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.text_off = torch.zeros(2, dtype=torch.int64, device=dev)
-        # [sum of depth (zeroed and written by every build: d_sums), bases of this rank, cross-rank name conflicts so far
-        # (low word: the int32 counter of the name check)].  At N > 1 the step all-reduces the sum IN PLACE (the global
-        # mean depth is that over the constant total of bases); the conflict count is all-reduced once, in check().
-        self.totals_src = torch.zeros(3, dtype=torch.int64, device=dev)
-        self.sums = self.totals_src[0:1]
-        self.status = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.text = None
-        self.rec_base = 0
         self.replicated_steps = 0
+        dev = eng.device
+        self.d_bam, self.d_off, self.n_rec, self.stream_bytes, self.name_bytes = [], [], [], [], []
+        for stream, offs, nb in files:
+            self.d_bam.append(eng.to_device(stream))
+            self.d_off.append(eng.to_device(offs))
+            self.n_rec.append(int(offs.shape[0]))
+            self.stream_bytes.append(int(stream.shape[0]))
+            self.name_bytes.append(int(nb))
+        self.n_files = len(files)
+        self.total_rec = sum(self.n_rec)
+
+    def layout(self, own):
+        """own: indices (into self.contigs) of the contigs this rank builds, in header order."""
+        torch, eng, dev = self.torch, self.eng, self.eng.device
+        self.own = list(own)
+        self.own_lengths = [self.contigs[c][1] for c in self.own]
+        eng.set_layout(self.own_lengths)
+        nc = len(self.own)
+        n_all = len(self.contigs)
+        self.ref_sel = eng.to_device(np.arange(n_all, dtype=np.int32))      # K1: refID -> global contig index
+        cmap = np.full(n_all, -1, dtype=np.int32)
+        cmap[self.own] = np.arange(nc, dtype=np.int32)
+        # the join maps global contig -> local track index; entries < 0 drop the interval (contigs of other ranks)
+        self.contig_map = eng.to_device(cmap) if (self.exchange or nc != n_all) else None
+        self.recs = [torch.empty((max(n, 1), 32), dtype=torch.uint8, device=dev) for n in self.n_rec]
+        self.rec_base = [0] * self.n_files
+        self.track = eng.new_track()
+        self.ivl = torch.empty((max(self.total_rec, 1) * (self.world if self.exchange else 1), 4), dtype=torch.int32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.keys = torch.empty(1 << 18, dtype=torch.int64, device=dev)
+        self.nkeys = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.text_off = torch.zeros(nc + 1, dtype=torch.int64, device=dev)
+        # [per-contig sums of depth (zeroed and written by every build) | bases of this rank | cross-rank name conflicts]
+        self.totals = torch.zeros(nc + 2, dtype=torch.int64, device=dev)
+        self.sums = self.totals[0:nc]
+        self.totals[nc] = int(sum(self.own_lengths))
+        self.status = torch.zeros(self.n_files + 1, dtype=torch.int64, device=dev)
+        self.text = None
         from gci_amd._lib import BuildOpts
         o = BuildOpts()
-        o.flank, o.want_text, o.counted = 15, 1, 1          # counted: the join has done the build's counting pass
+        o.flank, o.want_text, o.counted = FLANK, 1, 1          # counted: the join has done the build's counting pass
         o.d_contig_text_off, o.d_sums = self.text_off.data_ptr(), self.sums.data_ptr()
         o.d_n_keys, o.d_keys, o.key_cap = self.nkeys.data_ptr(), self.keys.data_ptr(), int(self.keys.shape[0])
-        o.issue_flank, o.lo, o.hi = 15, -1.0, 0.0
+        o.issue_flank, o.lo, o.hi = FLANK, -1.0, 0.0
         self.opts = o
         if self.exchange:
             self._setup_exchange()
+        return self
 
-    # ---- multi-GPU: every rank needs every record's (hash, interval, name) for the join ----------
+    # ---- multi-GPU: exact name check every step; the replicated join only when a name is shared -------------------
     def _setup_exchange(self):
         from gci_amd import shard
-        self.ex = shard.RecordExchange(self.n_rec, self.name_bytes, self.eng.device)
-        self.rec_base = self.ex.rec_idx_base
-        self.recs = self.ex.send_recs                       # K1 writes straight into the send buffer
-        self.ivl = self.torch.empty((self.world * self.ex.max_n, 4), dtype=self.torch.int32, device=self.eng.device)
-        # Both collectives of the step are synchronous ops; the kernel trace shows their RCCL kernels on the hardware
-        # queue of the step's own kernels, in line with them.  (Tried: the name check on a side stream and the
-        # all-reduce as an async op next to the tile build -- both put the collective on another queue and made the
-        # step 20 - 45 us slower on this chip.)
-        self.check_names = shard.NameCheck(self.n_rec, self.eng.device, self.eng.hash_bucket, self.eng.hash_conflicts,
+        nc = len(self.own)
+        self.ex = [shard.RecordExchange(n, nb, self.eng.device) for n, nb in zip(self.n_rec, self.name_bytes)]
+        self.rec_base = [e.rec_idx_base for e in self.ex]
+        self.recs = [e.send_recs for e in self.ex]            # K1 writes straight into the send buffers
+        self.ivl = self.torch.empty((sum(self.world * e.max_n for e in self.ex), 4), dtype=self.torch.int32,
+                                    device=self.eng.device)
+        # Both collectives of the step are synchronous ops on the hardware queue of the step's own kernels (tried: the
+        # name check on a side stream, the all-reduce as an async op -- 20 - 45 us slower per step on this chip).
+        self.check_names = shard.NameCheck(self.total_rec, self.eng.device, self.eng.hash_bucket, self.eng.hash_conflicts,
                                            alternate=True)
-        self.check_names.n_conf = self.totals_src[2:3].view(self.torch.int32)[0:1]      # counted straight into the totals
-        self.totals_src[1] = self.contigs[self.rank][1]
-        self.replicated_steps = 0
-
-    def _p(self, t):
-        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        self.check_names.n_conf = self.totals[nc + 1:nc + 2].view(self.torch.int32)[0:1]   # counted straight into the totals
 
     def step(self):
         eng, lib, ctx = self.eng, self.eng.lib, self.eng.ctx
         from gci_amd._lib import JoinFile
         chk = eng._chk
         k1 = lib.gci_bam_filter_heads if self.heads else lib.gci_bam_filter
-        chk(k1(ctx, self._p(self.d_bam), self.stream_bytes, self._p(self.d_off), self.n_rec, self._p(self.ref_sel),
-               self.world, 30, 50, 0.1, 0.9, self.rec_base, self._p(self.recs), self._p(self.status[0:1])), "gci_bam_filter")
-        jf = (JoinFile * 1)()
-        if not self.exchange:
-            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
-            jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
-        elif not self.force_replicated:
-            # Exact cross-rank name test (hash all-to-all, 8 bytes per record), enqueued without a host sync: the
-            # step goes on SPECULATIVELY with the local join; check() reads the accumulated verdict after the
-            # timed region and main() redoes everything with the replicated join if any step saw a conflict.
-            self.check_names.enqueue(self.recs[:self.n_rec])          # adds to check_names.n_conf (device, local)
-            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
-            jf[0].d_name_base, jf[0].d_name_off = self.d_bam.data_ptr(), self.d_off.data_ptr()
-        else:
+        F = self.n_files
+        for f in range(F):
+            chk(k1(ctx, _p(self.d_bam[f]), self.stream_bytes[f], _p(self.d_off[f]), self.n_rec[f], _p(self.ref_sel),
+                   len(self.contigs), FILTER[0], FILTER[1], FILTER[2], FILTER[3], self.rec_base[f], _p(self.recs[f]),
+                   _p(self.status[f:f + 1])), "gci_bam_filter")
+        jf = (JoinFile * F)()
+        if self.exchange and self.force_replicated:
             # a name occurs on two ranks: replicate records + names and join everything everywhere
             self.replicated_steps += 1
-            ex = self.ex
-            loc = (JoinFile * 1)()
-            loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs.data_ptr(), self.n_rec, 36
-            loc[0].d_name_base = self.d_bam.data_ptr()
-            loc[0].d_name_off = self.d_off.data_ptr()
-            chk(lib.gci_pack_names(ctx, loc, self._p(ex.send_names), ex.name_cap, self._p(ex.send_off)),
-                "gci_pack_names")
-            g = ex.gather()
-            self._g = g                                     # keep the index tensor alive until the join ran
-            jf[0].d_recs, jf[0].n_recs, jf[0].name_delta = g.recs.data_ptr(), self.world * g.max_n, 0
-            jf[0].d_name_base, jf[0].d_name_off = g.names.data_ptr(), g.name_index.data_ptr()
+            self._g = []
+            for f in range(F):
+                ex = self.ex[f]
+                loc = (JoinFile * 1)()
+                loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs[f].data_ptr(), self.n_rec[f], 36
+                loc[0].d_name_base, loc[0].d_name_off = self.d_bam[f].data_ptr(), self.d_off[f].data_ptr()
+                chk(lib.gci_pack_names(ctx, loc, _p(ex.send_names), ex.name_cap, _p(ex.send_off)), "gci_pack_names")
+                g = ex.gather()
+                self._g.append(g)                                # keep the index tensors alive until the join ran
+                jf[f].d_recs, jf[f].n_recs, jf[f].name_delta = g.recs.data_ptr(), self.world * g.max_n, 0
+                jf[f].d_name_base, jf[f].d_name_off = g.names.data_ptr(), g.name_index.data_ptr()
+        else:
+            if self.exchange:
+                # Exact cross-rank name test (hash all-to-all, 8 bytes per record), enqueued without a host sync: the
+                # step goes on SPECULATIVELY with the local join; check() reads the accumulated verdict after the
+                # timed region and main() redoes everything with the replicated join if any step saw a conflict.
+                self.check_names.enqueue_files([self.recs[f][:self.n_rec[f]] for f in range(F)])
+            for f in range(F):
+                jf[f].d_recs, jf[f].n_recs, jf[f].name_delta = self.recs[f].data_ptr(), self.n_rec[f], 36
+                jf[f].d_name_base, jf[f].d_name_off = self.d_bam[f].data_ptr(), self.d_off[f].data_ptr()
         # the join also does the counting pass of the depth build over the intervals it emits (gci_name_join_count)
-        chk(lib.gci_name_join_count(ctx, jf, 1, 0.9, self._p(self.contig_map), self._p(self.ivl), int(self.ivl.shape[0]),
-                                    self._p(self.count), self._p(self.status[1:2]), int(self.opts.flank)), "gci_name_join_count")
+        chk(lib.gci_name_join_count(ctx, jf, F, OVLP, _p(self.contig_map), _p(self.ivl), int(self.ivl.shape[0]),
+                                    _p(self.count), _p(self.status[F:F + 1]), int(self.opts.flank)), "gci_name_join_count")
         # fused build: depth + per-contig sums + text byte offsets + issue-run boundaries from one pass over
         # the per-tile event buckets (no HBM re-read of the track), then depth + decimal text in the second
         o = self.opts
-        chk(lib.gci_depth_build_begin(ctx, self._p(self.ivl), self._p(self.count), int(self.ivl.shape[0]),
-                                      ctypes.byref(o)), "gci_depth_build_begin")
+        chk(lib.gci_depth_build_begin(ctx, _p(self.ivl), _p(self.count), int(self.ivl.shape[0]), ctypes.byref(o)),
+            "gci_depth_build_begin")
         if self.text is None:                              # first (warm-up) call sizes the text buffer
-            total = int(self.text_off[1].item())
+            total = int(self.text_off[len(self.own)].item())
             self.text = self.torch.empty(total + (total >> 4) + 4096, dtype=self.torch.uint8, device=eng.device)
-        chk(lib.gci_depth_build_finish(ctx, self._p(self.track), self._p(self.text), int(self.text.shape[0])),
+        chk(lib.gci_depth_build_finish(ctx, _p(self.track), _p(self.text), int(self.text.shape[0])),
             "gci_depth_build_finish")
         if self.exchange:
             import torch.distributed as dist
-            # ONE integer all-reduce per step, in place: the genome-wide sum of depth (global mean depth = that / bases)
+            # ONE integer all-reduce per step, in place: the sums of depth (global mean depth = their total / bases)
             dist.all_reduce(self.sums, op=dist.ReduceOp.SUM)
 
     def check(self):
-        """Record-level status of the last step + issue-key capacity."""
+        """Record-level status of the last step + output capacities; False when a name is shared between ranks."""
         from gci_amd._lib import GciError
-        for w, what in zip(self.status.cpu().numpy().view(np.uint64).tolist(), ("gci_bam_filter", "gci_name_join")):
+        what = ["gci_bam_filter[%d]" % f for f in range(self.n_files)] + ["gci_name_join"]
+        for w, name in zip(self.status.cpu().numpy().view(np.uint64).tolist(), what):
             rec = ctypes.c_uint32(0)
             st = self.eng.lib.gci_decode_status(w, ctypes.byref(rec))
             if st != 0:
-                raise GciError(st, "%s failed on record %d" % (what, rec.value))
+                raise GciError(st, "%s failed on record %d" % (name, rec.value))
         if int(self.nkeys.item()) > self.keys.shape[0] or int(self.count.item()) > self.ivl.shape[0]:
             raise GciError(-8, "bench output buffers too small")
         if self.exchange and not self.force_replicated:
             import torch.distributed as dist
-            conf = self.totals_src[2:3].clone()                  # every rank's count of hashes seen from two ranks
+            nc = len(self.own)
+            conf = self.totals[nc + 1:nc + 2].clone()            # every rank's count of hashes seen from two ranks
             dist.all_reduce(conf, op=dist.ReduceOp.SUM)
             if int(conf.item()) > 0:
                 return False      # a query name is shared between ranks: the speculative local joins were not exact
         return True
 
+    # ---- algorithmic bytes of one step (DESIGN.md section 5; SURVEY.md 8d) ------------------------------------------
+    def step_algorithmic_bytes(self):
+        K = int(self.count.item())
+        L = int(sum(self.own_lengths))
+        T = int(self.text_off[len(self.own)].item())
+        k1 = int(self.algo.get("k1_bytes", 0)) + 32 * self.total_rec
+        join = 16 * self.n_rec[0] + 48 * sum(self.n_rec[1:]) + 16 * K
+        build = 28 * K + 4 * L + T
+        return {"k1_record_filter": k1, "name_join": join, "depth_build_text": build, "total": k1 + join + build,
+                "intervals": K, "bases": L, "text_bytes": T}
 
-def cpu_baseline(w: Workload):
-    """The oracle's single-thread C/Python restatement of the same step on the same chr19 input,
-    timed on this host: filter -> dict -> slice-add depth -> run scan -> text -> sum."""
+
+def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
+    """configs[2]; at N>1 haplotype `rank` of an N-haplotype assembly (contig names h<r>_chrN, read names unique to the
+    rank).  The host arrays are generated BEFORE the HIP context exists (worker processes are forked)."""
+    from gci_amd import synth, workloads
+    base = synth.CHM13
+    inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0),
+                                procs=max(1, workloads_default_procs() // max(1, world)))
+    nper = len(inp.contigs)
+    if world > 1:
+        # one header for the whole run: rank r's contigs are entries [r * nper, (r + 1) * nper); shift the refIDs
+        from gci_amd.formats import bam as bamfmt
+        all_contigs = tuple(("h%d_%s" % (r, n), l) for r in range(world) for n, l in inp.contigs)
+        hdr = np.frombuffer(bamfmt.encode_header([n for n, _ in all_contigs], [l for _, l in all_contigs]), dtype=np.uint8)
+        for fobj in inp.files:
+            first = bamfmt.parse_header(fobj.stream).first_record
+            body = fobj.stream[first:]
+            offs = fobj.offsets - np.uint64(first)
+            ref = body[(offs[:, None] + np.arange(4, 8, dtype=np.uint64)[None, :]).astype(np.int64)].copy().view("<i4").reshape(-1)
+            ref = np.where(ref >= 0, ref + rank * nper, ref).astype("<i4")
+            body[(offs[:, None] + np.arange(4, 8, dtype=np.uint64)[None, :]).astype(np.int64)] = ref.view(np.uint8).reshape(-1, 4)
+            # read names unique to the rank: the prefix "m64011_gNN/" becomes "m6401R_gNN/" (same length)
+            body[(offs + np.uint64(36 + 5)).astype(np.int64)] = ord("0") + (rank % 10)
+            body[(offs + np.uint64(36 + 4)).astype(np.int64)] = ord("0") + (rank // 10 % 10)
+            fobj.stream = np.concatenate([hdr, body])
+            fobj.offsets = offs + np.uint64(hdr.shape[0])
+        contigs = all_contigs
+        own = list(range(rank * nper, (rank + 1) * nper))
+    else:
+        contigs, own = inp.contigs, list(range(nper))
+    eng = eng_factory()
+    files = [(f.stream, f.offsets, f.name_bytes) for f in inp.files]
+    w = Workload(eng, rank, world, contigs, files, heads=True, exchange=exchange, replicated=replicated,
+                 name="CHM13 whole genome (%d contigs, %d bp)%s, HiFi %gx by two aligners (2 BAM files as heads streams, "
+                      "-op join), filter x2 -> join -> depth -> issue scan -> depth text" % (
+                          nper, sum(l for _, l in inp.contigs), " x %d haplotypes" % world if world > 1 else "", args.coverage),
+                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)})
+    w.aligned_bases = inp.aligned_bases
+    w.inp = inp if (rank == 0 and world == 1) else None
+    if w.inp is None:
+        del inp
+    return eng, w.layout(own)
+
+
+def workloads_default_procs():
+    from gci_amd import hostio
+    return hostio.default_threads()
+
+
+def make_chr19_workload(eng_factory, rank, world, args, exchange, replicated, eng=None):
+    """configs[1]: rank r owns one chr19-sized contig of an N-contig assembly and the records of that contig."""
+    from gci_amd import synth
+    names = ["chr19"] if world == 1 else ["chr19_%d" % r for r in range(world)]
+    contigs = tuple((n, args.contig_len) for n in names)
+    rs = synth.simulate_reads(((names[rank], args.contig_len),), args.coverage, "hifi", seed=synth.seed_for(2, rank))
+    aligned = rs.aligned_bases()
+    name_bytes = int(np.char.str_len(rs.names).sum())
+    from gci_amd.workloads import _k1_algorithmic_bytes
+    k1b = _k1_algorithmic_bytes(rs)
+    rs.ref_id[:] = rank
+    rs.contigs = contigs
+    stream, offs = synth.to_bam_stream(rs)
+    host = (stream, offs) if rank == 0 and world == 1 else None
+    if args.heads:                                          # through a BGZF file and the native host pipeline, as the CLI does
+        import tempfile
+        from gci_amd import hostio
+        from gci_amd.formats import bam as bamfmt
+        with tempfile.TemporaryDirectory(prefix="gci_bench_") as tmp:
+            path = os.path.join(tmp, "r%d.bam" % rank)
+            bamfmt.write_bam_stream(path, stream, level=1, threads=hostio.default_threads())
+            with hostio.bam_heads(np.fromfile(path, dtype=np.uint8)) as hd:
+                assert hd.offsets.shape[0] == len(rs)
+                up = (hd.stream.copy(), hd.offsets.copy(), name_bytes)
+    else:
+        up = (stream, offs, name_bytes)
+    eng = eng or eng_factory()
+    w = Workload(eng, rank, world, contigs, [up], heads=args.heads, exchange=exchange, replicated=replicated,
+                 name="CHM13 chr19 (%d bp) x %d contig(s), one %gx HiFi BAM (%s), filter -> join -> depth -> issue scan -> "
+                      "depth text" % (args.contig_len, world, args.coverage,
+                                      "heads stream" if args.heads else "whole inflated stream"),
+                 algo={"k1_bytes": k1b})
+    w.aligned_bases = aligned
+    w.host = host
+    return eng, w.layout([rank])
+
+
+# ---- CPU legs (oracle = test infrastructure; rank 0, N = 1 only) ----------------------------------------------------
+
+def _track_contig(w, c):
+    o = w.eng.offsets[c]
+    return w.track[o:o + w.own_lengths[c]].cpu().numpy().astype(np.int64)
+
+
+def parity_genome(w, chosen=("chr14", "chr22", "chrM")):
+    """The timed result against the oracle on whole contigs at full size (exact: oracle.file1_on_contigs), plus
+    the genome-wide sum of depth against the sum of the clipped join intervals."""
+    from oracle import gci_oracle as O
+    from gci_amd import pipeline
+    O.build()
+    inp = w.inp
+    names = inp.names
+    chosen = [c for c in chosen if c in names]
+    bams = [(f.stream, f.offsets, names) for f in inp.files]
+    file1 = O.file1_on_contigs(bams, names, chosen, *FILTER, OVLP, heads=True)
+    tl = {c: inp.lengths[names.index(c)] for c in chosen}
+    depths = O.depth_build(file1, tl, FLANK)
+    bed = O.collapse_depth_range(depths, -1, 0, FLANK, 0)
+    nk = int(w.nkeys.item())
+    runs = w.eng._keys_to_runs(w.keys[:nk].cpu().numpy().view(np.uint64), len(names))
+    toff = w.text_off.cpu().numpy()
+    sums = w.sums.cpu().numpy()
+    ok = True
+    for c in chosen:
+        ci = names.index(c)
+        L = tl[c]
+        got = _track_contig(w, ci)
+        ok = ok and np.array_equal(got, depths[c])
+        a, b = pipeline._slice_bound(FLANK, L), pipeline._slice_bound(L - FLANK, L)
+        ok = ok and pipeline._issues_from_runs(runs[ci], max(0, b - a), L, FLANK, 0) == bed[c]
+        ok = ok and int(sums[ci]) == int(depths[c].sum())
+        ok = ok and w.text[int(toff[ci]):int(toff[ci + 1])].cpu().numpy().tobytes() == O.depth_text_contig(depths[c])
+    K = int(w.count.item())
+    iv = w.ivl[:K].cpu().numpy().astype(np.int64)
+    Ls = np.asarray(inp.lengths, dtype=np.int64)[iv[:, 0]]
+    a = np.clip(iv[:, 1] + FLANK, 0, Ls)
+    b = np.clip(iv[:, 2] - FLANK + 1, 0, Ls)
+    ok = ok and int(np.maximum(b - a, 0).sum()) == int(sums.sum())
+    return bool(ok), chosen
+
+
+def _cpu_filter_task(args):
+    f, c = args
+    from oracle import gci_oracle as O
+    inp, names = _CPU_CTX["inp"], _CPU_CTX["names"]
+    lo, hi = _CPU_CTX["ranges"][f][c]
+    fobj = inp.files[f]
+    return f, c, O.bam_file_dict(fobj.stream, fobj.offsets[lo:hi], names, names, *FILTER, heads=True)
+
+
+def _cpu_contig_task(args):
+    c, s, e = args
+    from oracle import gci_oracle as O
+    L = _CPU_CTX["inp"].lengths[c]
+    name = _CPU_CTX["names"][c]
+    d = np.zeros(L, dtype=np.int64)
+    O.lib().orc_depth_build(O._p(d), L, O._p(s), O._p(e), s.shape[0], FLANK)
+    bed = O.collapse_depth_range({name: d}, -1, 0, FLANK, 0)
+    return c, bed[name], len(O.depth_text_contig(d)), int(d.sum())
+
+
+_CPU_CTX = {}
+
+
+def cpu_baseline_genome(inp, target_cpu_s=20.0):
+    """The oracle's C/Python restatement (`kind: port`) of the same step on a bounded sample of the same workload --
+    the reference run with `--chrs <the last contigs of the header>` and `-t <cores>` -- with the reference's own
+    parallel structure: a process pool over contigs for the record filter (GCI.py:257-270: Pool.map(read_sam) + dict
+    merge in the parent), the join serial in the parent (GCI.py:272-301), a pool again for depth / scan / text."""
+    import multiprocessing as mp
+    from oracle import gci_oracle as O
+    O.build()
+    cores = workloads_default_procs()
+    names = inp.names
+    # sample: contigs from the end of the header until ~target_cpu_s of single-core work (2.7 aligned Gbases/s/core, r01)
+    want_bases = target_cpu_s * 2.7e9 / (40.0 * len(inp.files))
+    sample, acc = [], 0
+    for c in range(len(names) - 1, -1, -1):
+        sample.append(c)
+        acc += inp.lengths[c]
+        if acc >= want_bases:
+            break
+    sample.sort()
+    ranges = []
+    for fobj in inp.files:
+        ref = fobj.stream[(fobj.offsets[:, None] + np.arange(4, 8, dtype=np.uint64)[None, :]).astype(np.int64)].copy().view("<i4").reshape(-1)
+        ranges.append({c: (int(np.searchsorted(ref, c, "left")), int(np.searchsorted(ref, c, "right"))) for c in sample})
+    _CPU_CTX.update(inp=inp, names=names, ranges=ranges)
+    # metric numerator of the sample, counted like the GPU's: reference spans of its records with flag 0x4 clear
+    aligned = int(sum(int(f.aligned_per_contig[c]) for f in inp.files for c in sample))
+    t0 = time.perf_counter()
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        parts = pool.map_async(_cpu_filter_task, [(f, c) for f in range(len(inp.files)) for c in sample], chunksize=1).get(600)
+        dicts = [dict() for _ in inp.files]
+        hq = set()
+        for f, c, (d, h) in sorted(parts, key=lambda x: (x[0], x[1])):
+            dicts[f].update(d)
+            hq |= h
+        file1 = O.name_join(dicts, hq, OVLP)
+        by_c = {c: ([], []) for c in sample}
+        cidx = {names[c]: c for c in sample}
+        for seg in file1.values():
+            k = by_c[cidx[seg[0]]]
+            k[0].append(seg[1])
+            k[1].append(seg[2])
+        out = pool.map_async(_cpu_contig_task, [(c, np.asarray(by_c[c][0], dtype=np.int64), np.asarray(by_c[c][1], dtype=np.int64))
+                                                for c in sample], chunksize=1).get(600)
+    dt = time.perf_counter() - t0
+    _CPU_CTX.clear()
+    return {"seconds": dt, "cores": cores, "os_cpu_count": os.cpu_count(), "sample_contigs": [names[c] for c in sample],
+            "sample_bases": int(sum(inp.lengths[c] for c in sample)), "sample_aligned_bases": aligned,
+            "issue_runs": int(sum(len(x[1]) for x in out))}
+
+
+def cpu_baseline_chr19(w):
+    """configs[1]: the oracle's single-thread restatement of the same step on the same chr19 input."""
     from oracle import gci_oracle as O
     O.build()
     refs = [n for n, _ in w.contigs]
     tl = dict(w.contigs)
+    stream, offs = w.host
     t0 = time.perf_counter()
-    d, hq = O.bam_file_dict(w.host_stream, w.host_offs, refs, refs, 30, 50, 0.1, 0.9)
-    file1 = O.name_join([d], hq, 0.9)
-    depths = O.depth_build(file1, tl, 15)
-    bed = O.collapse_depth_range(depths, -1, 0, 15, 0)
+    d, hq = O.bam_file_dict(stream, offs, refs, refs, *FILTER)
+    file1 = O.name_join([d], hq, OVLP)
+    depths = O.depth_build(file1, tl, FLANK)
+    bed = O.collapse_depth_range(depths, -1, 0, FLANK, 0)
     text = O.depth_text(depths)
     mean = O.mean_depth(depths)
     dt = time.perf_counter() - t0
     return dt, depths, bed, text, mean
+
+
+def port_over_reference():
+    """Measured in the build container (tools/port_vs_reference.py imports the unmodified reference there; it cannot
+    travel): aligned Gbases/s of the oracle port / of the reference on configs[0]."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "port_vs_reference.json")))
+    except Exception:
+        return None
+
+
+# ---- SURVEY.md 8(d) numbers (2) and (3) ---------------------------------------------------------------------------
+
+def device_pipeline_number(eng, w):
+    """(2): the same step INCLUDING the H2D of the heads streams + offsets and the D2H of what leaves the device (the
+    issue-run keys and the .depth.gz members written by the GPU)."""
+    import torch
+    from gci_amd.device import JoinInput
+    inp = w.inp
+    best = None
+    ref_sel = w.ref_sel
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ins = []
+        for fobj in inp.files:
+            d_s, d_o = eng.to_device(fobj.stream), eng.to_device(fobj.offsets)
+            recs = eng.bam_filter(d_s, d_o, ref_sel, *FILTER, heads=True, check=False)
+            ins.append(JoinInput(recs, d_s, d_o, 36))
+        ivl, cnt = eng.name_join(ins, OVLP, count_flank=FLANK, check=False, out=w.ivl)
+        fused = eng.depth_build_fused(ivl, cnt, FLANK, w.track, want_text=False, want_sums=True, issue=(-1.0, 0.0, FLANK),
+                                      counted=True)
+        blobs = eng.depth_deflate(w.track)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        del ins
+    return {"seconds": best, "gbases_per_s": w.aligned_bases / best / 1e9,
+            "h2d_bytes": int(sum(f.stream.shape[0] + 8 * f.offsets.shape[0] for f in inp.files)),
+            "d2h_depth_gz_member_bytes": int(sum(len(b) for b in blobs)),
+            "note": "pageable host memory, one upload per file, no overlap of copy and compute"}
+
+
+def cli_number(coverage):
+    """(3): wall time of the drop-in command line (python GCI.py -r ref.fa --hifi x.bam) on a chr19 40x HiFi BAM whose
+    SEQ / QUAL have realistic entropy (synth.to_bam_stream(seq_qual='random')): BGZF inflate, FASTA scan, all kernels,
+    .depth.gz / .bed / .gci emission and file I/O.  Run in-process twice; the second run (warm page cache) is reported."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import torch
+    from gci_amd import cli, hostio, synth
+    from gci_amd.formats import bam as bamfmt
+    tmp = tempfile.mkdtemp(prefix="gci_cli_")
+    try:
+        rs = synth.simulate_reads(synth.CHR19, coverage, "hifi", seed=synth.seed_for(2, 0))
+        aligned, n_rec = rs.aligned_bases(), len(rs)
+        stream, _ = synth.to_bam_stream(rs, seq_qual="random", seed=7)
+        bam, fa = os.path.join(tmp, "hifi.bam"), os.path.join(tmp, "ref.fa")
+        bamfmt.write_bam_stream(bam, stream, level=1, threads=hostio.default_threads())
+        inflated = int(stream.shape[0])
+        del stream, rs
+        synth.write_reference_fasta(fa, synth.CHR19)
+        walls = []
+        for k in range(2):
+            od = os.path.join(tmp, "out%d" % k)
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                cli.main(["GCI.py", "-r", fa, "--hifi", bam, "-d", od, "-t", str(hostio.default_threads())])
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        return {"seconds": walls[-1], "first_run_seconds": walls[0], "gbases_per_s": aligned / walls[-1] / 1e9,
+                "workload": "chr19 61,707,364 bp, one %gx HiFi BAM, %d records" % (coverage, n_rec),
+                "bam_file_bytes": os.path.getsize(bam), "inflated_bytes": inflated,
+                "deflate_ratio": inflated / os.path.getsize(bam), "host_threads": hostio.default_threads()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -247,28 +542,31 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_exchange or args.force_replicated:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL logs to stdout: keep it off the channel on which rank 0 prints its ONE JSON line
-        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "WARN"):
-            os.environ.pop("NCCL_DEBUG")
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    exchange = args.force_exchange or args.force_replicated
 
     from gci_amd.build import build_hip, needs_build
-    if needs_build():
-        if local_rank == 0:
-            build_hip()
-        if world > 1:
-            dist.barrier()
+    if needs_build() and local_rank == 0:
+        build_hip()
+
+    def eng_factory():
+        """HIP context, process group and library context: created AFTER the host-side generation of the inputs."""
+        torch.cuda.set_device(local_rank)
+        if world > 1 or exchange:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # RCCL logs to stdout: keep it off the channel on which rank 0 prints its ONE JSON line
+            if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "WARN"):
+                os.environ.pop("NCCL_DEBUG")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()                                  # (also: rank 0 has finished building the library)
+        from gci_amd.device import Engine
+        return Engine(local_rank)
+
     from gci_amd import _lib
-    from gci_amd.device import Engine
-    eng = Engine(local_rank)
-    w = Workload(eng, rank, world, args.contig_len, args.coverage, exchange=args.force_exchange or args.force_replicated,
-                 replicated=args.force_replicated, heads=args.heads)
+    make = make_genome_workload if args.workload == "genome" else make_chr19_workload
+    eng, w = make(eng_factory, rank, world, args, exchange, args.force_replicated)
 
     def fence():
         torch.cuda.synchronize()
@@ -279,13 +577,14 @@ def main():
     # --inflight N: N - 1 more contexts on streams of their own; step k runs on context k % N
     lanes = [(eng, w, None)]
     if args.inflight > 1:
-        if world > 1 or w.exchange:
-            sys.exit("bench.py --inflight is for the single-GPU local path")
+        if world > 1 or w.exchange or args.workload != "chr19":
+            sys.exit("bench.py --inflight is for the single-GPU chr19 workload")
+        from gci_amd.device import Engine
         for _ in range(args.inflight - 1):
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 e2 = Engine(local_rank, stream=st)
-                w2 = Workload(e2, rank, world, args.contig_len, args.coverage, heads=args.heads)
+                _, w2 = make_chr19_workload(None, rank, world, args, False, False, eng=e2)
                 for _ in range(max(1, args.warmup)):
                     w2.step()
             lanes.append((e2, w2, st))
@@ -335,31 +634,33 @@ def main():
         aligned_total = int(ab.item())
     else:
         aligned_total = w.aligned_bases
+    ms_per_step = dt / args.steps * 1e3
 
+    # ---- roofline of the dominant kernel: k_tile_build writes the int32 track (4 B/base) and the decimal text; it
+    # reads only the event buckets.  Average launch time from HIP events on the ctx stream over the timed region.
     scan_ms, scan_n = prof.get("k_tile_build", (0.0, 0))
     scan_avg_ms = scan_ms / max(1, scan_n)
-    # k_tile_build writes the int32 track (4 B/base) and the decimal text; it reads only the event buckets
-    text_bytes = int(w.text_off[1].item())
-    algo_bytes = 4.0 * args.contig_len + text_bytes       # DESIGN.md "algorithmic bytes"
+    algo = w.step_algorithmic_bytes()
+    algo_bytes = 4.0 * algo["bases"] + algo["text_bytes"]
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+    step_achieved = algo["total"] / (ms_per_step * 1e-3) / 1e9
 
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected from inside
-    # this process: rocprofv3 wraps the command; see tools/prof_pmc.sh and profiles/)
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload (they cannot be
+    # collected from inside this process: rocprofv3 wraps the command; tools/prof_pmc.sh, profiles/)
     traffic = None
     try:
-        tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-        if tj and args.contig_len == CHR19_LEN and args.coverage == 40.0:
+        tag = "genome" if args.workload == "genome" else "chr19"
+        tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_%s_traffic.json" % tag))
+        if tj and args.scale == 1.0 and args.coverage == 40.0 and (args.workload == "genome" or args.contig_len == CHR19_LEN):
             traffic = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
 
-    breakdown = None
-    if True:
-        eng.profile_enable((1 << _lib.PROF_COUNT) - 1)
-        for _ in range(3):
-            w.step()
-        breakdown = {k: round(ms / n * 1e3, 2) for k, (ms, n) in eng.profile_read(reset=True).items()}   # us / launch
-        eng.profile_enable(0)
+    eng.profile_enable((1 << _lib.PROF_COUNT) - 1)
+    for _ in range(3):
+        w.step()
+    breakdown = {k: round(ms / n * 1e3, 2) for k, (ms, n) in eng.profile_read(reset=True).items()}   # us / launch
+    eng.profile_enable(0)
 
     out = {
         "metric": "aligned Gbases/s through filter+depth pipeline (CHM13, 40x HiFi)",
@@ -368,17 +669,17 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
-        "config": {"workload": "CHM13 chr19 (%d bp) x %d contig(s), one %gx HiFi BAM, filter -> join -> depth -> "
-                               "issue scan -> depth text" % (args.contig_len, world, args.coverage),
-                   "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
+        "config": {"workload": w.name + (" [scale %g]" % args.scale if args.workload == "genome" and args.scale != 1.0 else ""),
+                   "baseline_config": "configs[2]" if args.workload == "genome" else "configs[1]",
+                   "input_files_per_gpu": w.n_files, "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
                    "bam_input": "heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream",
-                   ("heads_bytes_per_gpu" if w.heads else "inflated_bam_bytes_per_gpu"): w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
+                   "input_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "steps_in_flight": len(lanes),
                    "join": ("local" if not w.exchange else
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
@@ -386,32 +687,64 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_tile_build (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
+        "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": step_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": algo},
         "kernel_us_per_launch": breakdown,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cdt, depths, bed, text, mean = cpu_baseline(w)
-        out["cpu_baseline"] = {"value": w.aligned_bases / cdt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-                               "sample": "one full step (all %d records, %d bp) through oracle/gci_oracle.{c,py}, "
-                                         "%.1f s" % (w.n_rec, args.contig_len, cdt)}
-        # the timed GPU result must equal the oracle's on the full-size input
-        from gci_amd import pipeline
-        tr = pipeline.DepthTracks(eng, dict(w.contigs), w.track)
-        ok = np.array_equal(tr["chr19"], depths["chr19"])
-        ok = ok and pipeline.collapse_depth_range(tr, -1, 0, 15, 0) == bed
-        nk = int(w.nkeys.item())                              # the fused issue keys of the last timed step
-        runs = eng._keys_to_runs(w.keys[:nk].cpu().numpy().view(np.uint64), 1)
-        ok = ok and pipeline._issues_from_runs(runs[0], args.contig_len - 30, args.contig_len, 15, 0) == bed["chr19"]
-        ok = ok and int(w.sums[0].item()) == int(depths["chr19"].sum())
-        n_text = int(w.text_off[1].item())
-        ok = ok and (b">chr19\n" + w.text[:n_text].cpu().numpy().tobytes()) == text
-        ok = ok and tr.mean() == mean
-        out["parity_vs_oracle_full_size"] = bool(ok)
-        if not ok:
-            print(json.dumps(out))
-            sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")
-    elif world == 1:
-        out["cpu_baseline"] = None
+    if rank == 0 and world == 1:
+        if args.workload == "genome":
+            ok, chosen = parity_genome(w)
+            out["parity_vs_oracle_full_size"] = ok
+            out["parity_contigs"] = chosen
+            if not ok:
+                print(json.dumps(out))
+                sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")
+            survey = {"1_kernels_only_gbases_per_s": out["value"]}
+            if not args.no_e2e:
+                survey["2_device_pipeline_incl_h2d_d2h"] = device_pipeline_number(eng, w)
+            if not args.no_cpu_baseline:
+                c = cpu_baseline_genome(w.inp)
+                frac = c["sample_bases"] / float(sum(w.inp.lengths))
+                sample_aligned = c["sample_aligned_bases"]
+                ratio = port_over_reference()
+                out["cpu_baseline"] = {
+                    "value": sample_aligned / c["seconds"] / 1e9, "unit": "Gbases/s", "cores": c["cores"], "kind": "port",
+                    "sample": "contigs %s (%d bp = %.1f %% of the workload, both files) through oracle/gci_oracle.{c,py} with the "
+                              "reference's structure (process pool over contigs for the filter, serial join, pool for depth / "
+                              "scan / text), %.1f s wall on %d processes (os.cpu_count() = %s)" % (
+                                  ",".join(c["sample_contigs"]), c["sample_bases"], 100.0 * frac, c["seconds"], c["cores"],
+                                  c["os_cpu_count"]),
+                    "port_over_reference": ratio}
+            else:
+                out["cpu_baseline"] = None
+            w.inp = None
+            if not args.no_e2e:
+                survey["3_command_line_chr19_realistic_bam"] = cli_number(args.coverage)
+            out["survey_8d"] = survey
+        elif not args.no_cpu_baseline:
+            cdt, depths, bed, text, mean = cpu_baseline_chr19(w)
+            out["cpu_baseline"] = {"value": w.aligned_bases / cdt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+                                   "sample": "one full step (all %d records, %d bp) through oracle/gci_oracle.{c,py}, "
+                                             "%.1f s" % (w.n_rec[0], args.contig_len, cdt),
+                                   "port_over_reference": port_over_reference()}
+            from gci_amd import pipeline
+            tr = pipeline.DepthTracks(eng, dict(w.contigs), w.track)
+            ok = np.array_equal(tr["chr19"], depths["chr19"])
+            ok = ok and pipeline.collapse_depth_range(tr, -1, 0, 15, 0) == bed
+            nk = int(w.nkeys.item())                              # the fused issue keys of the last timed step
+            runs = eng._keys_to_runs(w.keys[:nk].cpu().numpy().view(np.uint64), 1)
+            ok = ok and pipeline._issues_from_runs(runs[0], args.contig_len - 30, args.contig_len, 15, 0) == bed["chr19"]
+            ok = ok and int(w.sums[0].item()) == int(depths["chr19"].sum())
+            n_text = int(w.text_off[1].item())
+            ok = ok and (b">chr19\n" + w.text[:n_text].cpu().numpy().tobytes()) == text
+            ok = ok and tr.mean() == mean
+            out["parity_vs_oracle_full_size"] = bool(ok)
+            if not ok:
+                print(json.dumps(out))
+                sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")
+        else:
+            out["cpu_baseline"] = None
 
     if rank == 0:
         sys.stdout.flush()

@@ -138,6 +138,19 @@ class NameCheck:
         self.conflict_fn(self.recv, self.world, self.cap, self.n_conf)
         return self.n_conf
 
+    def enqueue_files(self, recs_per_file: Sequence[torch.Tensor]) -> torch.Tensor:
+        """enqueue() for a rank that holds records of several input files: the hashes of all of them go into the same
+        buckets (a name in two files of ONE rank is not a conflict: same source) and travel in ONE all-to-all.  Needs
+        alternate=True (the bucket counters then accumulate across the calls of one step)."""
+        if self.send_alt is None:
+            raise ValueError("NameCheck.enqueue_files needs alternate=True")
+        for recs in recs_per_file:
+            self.bucket_fn(recs, self.world, self.cap, self.send, self.send_alt)
+        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self.send, self.send_alt = self.send_alt, self.send
+        self.conflict_fn(self.recv, self.world, self.cap, self.n_conf)
+        return self.n_conf
+
     def conflicts(self, recs: torch.Tensor) -> int:
         """Synchronous, global verdict for one record set."""
         self.reset()

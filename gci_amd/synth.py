@@ -344,8 +344,28 @@ def _nm_bytes(nm: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return flat, ln
 
 
-def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] = None, heads: bool = False):
+def _hifi_qual_lut() -> np.ndarray:
+    """256-entry table: a uniform random byte -> a HiFi-like base quality (85 % of the bases at the Q93 cap, the rest
+    spread over Q2..Q92 with the mass towards the high end): ~1.5 bits of entropy per quality and 2 per base, so that
+    a BGZF-compressed file inflates about 3.5:1 like real HiFi data instead of 100:1."""
+    q = np.empty(256, dtype=np.uint8)
+    q[:218] = 93
+    rest = np.round(92.0 - 90.0 * (np.arange(38) / 37.0) ** 1.7).astype(np.uint8)
+    q[218:] = np.clip(rest, 2, 92)
+    return q
+
+
+_SEQ_NIBBLES = np.array([1, 2, 4, 8], dtype=np.uint8)                      # A C G T in BAM's 4-bit code
+_SEQ_LUT = (_SEQ_NIBBLES[:, None] << 4 | _SEQ_NIBBLES[None, :]).reshape(16).astype(np.uint8)
+
+
+def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] = None, heads: bool = False,
+                  seq_qual: str = "const", seed: int = 0):
     """-> (inflated BAM stream uint8[n], record offsets uint64[R]).
+
+    seq_qual = "const": SEQ / QUAL are 0xFF fill (the path never reads them; the file deflates 100:1).
+    seq_qual = "random": uniformly random bases and HiFi-like qualities (`_hifi_qual_lut`), so that BGZF inflate costs
+    what it costs on real data (bench.py's command-line timing).
 
     heads=True: the heads stream of the same file (gci_bam_heads: every record without its SEQ / QUAL bytes,
     l_seq unchanged) -- what a genome-scale experiment can hold in memory.
@@ -373,7 +393,16 @@ def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] 
     offs = np.zeros(R + 1, dtype=np.int64)
     np.cumsum(size, out=offs[1:])
     offs += hdr.shape[0]
-    out = np.full(int(offs[-1]), 0xFF, dtype=np.uint8)
+    if seq_qual == "random" and not heads:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        out = np.empty(int(offs[-1]), dtype=np.uint8)
+        qlut = _hifi_qual_lut()
+        step = 1 << 26
+        for a in range(0, out.shape[0], step):                  # everything gets quality-like bytes; SEQ is redone below
+            b = min(out.shape[0], a + step)
+            out[a:b] = qlut[rng.integers(0, 256, b - a, dtype=np.uint8)]
+    else:
+        out = np.full(int(offs[-1]), 0xFF, dtype=np.uint8)
     out[:hdr.shape[0]] = hdr
     span = np.maximum(rs.ref_span(), 1)
 
@@ -418,6 +447,12 @@ def to_bam_stream(rs: ReadSet, chunk: int = 1 << 18, header_text: Optional[str] 
             g = lo + r
             ph = np.array([(int(l_seq[g]) << 4) | OP_S, (int(span[g]) << 4) | OP_N], dtype="<u4").view(np.uint8)
             out[p_cig[r]:p_cig[r] + 8] = ph
+        if seq_qual == "random" and not heads:
+            p_seq = p_cig + 4 * n_cig_field[sl]
+            nb = (l_seq[sl] + 1) // 2
+            for r in range(hi - lo):
+                if nb[r]:
+                    out[p_seq[r]:p_seq[r] + nb[r]] = _SEQ_LUT[rng.integers(0, 16, int(nb[r]), dtype=np.uint8)]
         # aux
         p_aux = p_cig + 4 * n_cig_field[sl] + seq_bytes[sl]
         last = rs.nm_last[sl]

@@ -1,0 +1,146 @@
+"""Genome-scale synthetic inputs for BASELINE.json configs[2]: CHM13 geometry (25 contigs,
+3.117 Gb), two 40x HiFi alignment files of the same reads -- the second one perturbed the way another aligner's
+output differs (`synth.perturb`), which is what the `-op` join (GCI.py:272-301) exists for.
+
+The files are produced as HEADS STREAMS (the records without SEQ / QUAL, what `gci_bam_heads` makes of a BGZF file and
+what the command line uploads): the whole inflated files would be 2 x 190 GB.  Generation runs group by group of
+contigs (a read set of the whole genome would need ~60 GB of host memory), the groups in worker processes.
+
+Used by bench.py (the driver-timed workload), tests/test_gpu_genome.py and tools/.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import synth
+from .formats import bam as bamfmt
+
+
+@dataclass
+class AlignmentFile:
+    """One input file as its heads stream."""
+    stream: np.ndarray            # uint8: BAM header + records without SEQ / QUAL
+    offsets: np.ndarray           # uint64 [R]: offset of every record's block_size word
+    aligned_bases: int            # metric numerator: sum of reference spans of records with flag 0x4 clear
+    k1_bytes: int                 # algorithmic bytes K1 reads of it: 36 + l_read_name + 4 n_cigar + NM tag
+    name_bytes: int
+    aligned_per_contig: Optional[np.ndarray] = None   # int64 [n_contigs]: aligned_bases split by the record's contig
+
+
+@dataclass
+class GenomeInput:
+    contigs: Tuple[Tuple[str, int], ...]
+    files: List[AlignmentFile]
+
+    @property
+    def names(self) -> List[str]:
+        return [n for n, _ in self.contigs]
+
+    @property
+    def lengths(self) -> List[int]:
+        return [int(l) for _, l in self.contigs]
+
+    @property
+    def aligned_bases(self) -> int:
+        return sum(f.aligned_bases for f in self.files)
+
+
+def contig_groups(contigs: Sequence[Tuple[str, int]], max_bases: float) -> List[List[int]]:
+    """Consecutive contigs (header order) packed into groups of at most `max_bases`."""
+    groups, cur, acc = [], [], 0
+    for i, (_, l) in enumerate(contigs):
+        if cur and acc + l > max_bases:
+            groups.append(cur)
+            cur, acc = [], 0
+        cur.append(i)
+        acc += l
+    groups.append(cur)
+    return groups
+
+
+def _k1_algorithmic_bytes(rs: synth.ReadSet) -> int:
+    n_ops = np.diff(rs.cigar_off)
+    n_field = np.where(n_ops > 65535, 2, n_ops)
+    nm_sz = np.where(rs.nm < 256, 1, np.where(rs.nm < 65536, 2, 4))
+    return int((36 + np.char.str_len(rs.names) + 1 + 4 * n_field + 3 + nm_sz).sum())
+
+
+def _gen_group(args):
+    """Worker: the two files' records of one group of contigs -> per file (record bytes, offsets relative to the first
+    record, aligned bases, K1 bytes, name bytes).  Seeds: SURVEY.md 8d, config 3 (index of configs[2] counted from 1)."""
+    contigs, idx, g, coverage, kind, n_files = args
+    sub = tuple(contigs[i] for i in idx)
+    rs = synth.simulate_reads(sub, coverage, kind, seed=synth.seed_for(3, 0) + 7 * g, name_prefix="m64011_g%02d/" % g)
+    files = [rs] + [synth.perturb(rs, synth.seed_for(3, f) + 7 * g) for f in range(1, n_files)]
+    out = []
+    for r in files:
+        r.ref_id = (r.ref_id + idx[0]).astype(np.int32)          # the group's contigs are consecutive in the header
+        mapped = (r.flag & 4) == 0
+        per_contig = np.bincount(r.ref_id[mapped], weights=np.maximum(r.ref_span(), 1)[mapped].astype(np.float64),
+                                 minlength=len(contigs)).astype(np.int64)          # spans < 2^53: exact
+        aligned = int(per_contig.sum())
+        r.contigs = tuple(contigs)
+        s, o = synth.to_bam_stream(r, heads=True)
+        first = bamfmt.parse_header(s).first_record
+        out.append((s[first:].copy(), (o - np.uint64(first)).astype(np.uint64), aligned, _k1_algorithmic_bytes(r),
+                    int(np.char.str_len(r.names).sum()), per_contig))
+    return g, out
+
+
+def genome_dual(scale: float = 1.0, coverage: float = 40.0, contigs: Optional[Sequence[Tuple[str, int]]] = None,
+                n_files: int = 2, procs: Optional[int] = None, verbose: bool = False, kind: str = "hifi") -> GenomeInput:
+    """configs[2]: `n_files` alignment files of the same simulated reads over CHM13 (every contig scaled by `scale`,
+    at least 20 kb).  The result is deterministic (independent of `procs`)."""
+    base = tuple(contigs) if contigs is not None else synth.CHM13
+    ctg = tuple((n, max(20_000, int(l * scale))) for n, l in base) if scale != 1.0 else tuple(base)
+    total = sum(l for _, l in ctg)
+    groups = contig_groups(ctg, max(2.0e7, min(2.6e8, total / 12.0)))
+    if procs is None:
+        from . import hostio
+        procs = hostio.default_threads()
+    procs = max(1, min(int(procs), len(groups)))
+    tasks = [(ctg, idx, g, coverage, kind, n_files) for g, idx in enumerate(groups)]
+    t0 = time.time()
+    results = {}
+    if procs == 1:
+        for t in tasks:
+            g, out = _gen_group(t)
+            results[g] = out
+    else:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        # fork: the workers run numpy only (they never touch HIP, and leave through os._exit like DataLoader workers)
+        with ProcessPoolExecutor(procs, mp_context=mp.get_context("fork")) as ex:
+            for g, out in ex.map(_gen_group, sorted(tasks, key=lambda t: -sum(ctg[i][1] for i in t[1]))):
+                results[g] = out
+                if verbose:
+                    print("workload: group %d/%d done, %.0f s" % (len(results), len(groups), time.time() - t0),
+                          file=sys.stderr, flush=True)
+    hdr = np.frombuffer(bamfmt.encode_header([n for n, _ in ctg], [l for _, l in ctg]), dtype=np.uint8)
+    files = []
+    for f in range(n_files):
+        parts, offs, size = [hdr], [], int(hdr.shape[0])
+        aligned = k1 = nb = 0
+        per_contig = np.zeros(len(ctg), dtype=np.int64)
+        for g in range(len(groups)):
+            s, o, a, kb, n, pc = results[g][f]
+            per_contig += pc
+            parts.append(s)
+            offs.append(o + np.uint64(size))
+            size += int(s.shape[0])
+            aligned += a
+            k1 += kb
+            nb += n
+            results[g][f] = None
+        files.append(AlignmentFile(np.concatenate(parts), np.concatenate(offs) if offs else np.zeros(0, np.uint64),
+                                   aligned, k1, nb, per_contig))
+    if verbose:
+        print("workload: %d contigs, %d bp, records per file %s, %.0f s on %d processes" % (
+            len(ctg), total, [int(f.offsets.shape[0]) for f in files], time.time() - t0, procs), file=sys.stderr, flush=True)
+    return GenomeInput(ctg, files)

@@ -96,7 +96,7 @@ int orc_bam_filter(const uint8_t *bam, uint64_t n_bytes, const uint64_t *rec_off
                    const int32_t *ref_sel, int32_t n_ref,
                    int map_qual, int mq_cutoff, double clip_percent, double iden_percent,
                    uint8_t *pass, uint8_t *hq, int32_t *contig, int32_t *start, int32_t *end,
-                   int32_t *qlen, uint64_t *name_off, uint32_t *name_len, uint32_t *bad_rec)
+                   int32_t *qlen, uint64_t *name_off, uint32_t *name_len, uint32_t *bad_rec, int has_seq)
 {
     for (uint32_t i = 0; i < n_rec; i++) {
         pass[i] = 0; hq[i] = 0; contig[i] = -1; start[i] = 0; end[i] = 0; qlen[i] = 0;
@@ -115,7 +115,9 @@ int orc_bam_filter(const uint8_t *bam, uint64_t n_bytes, const uint64_t *rec_off
         const uint8_t *name = r + 36;
         const uint8_t *rec_end = r + 4 + block_size;
         const uint8_t *cig = name + l_read_name;
-        const uint8_t *aux = cig + 4 * (uint64_t)n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+        /* has_seq == 0: a heads stream (include/gci_hip.h, gci_bam_heads): the same records with the SEQ and QUAL
+         * bytes cut out (l_seq keeps its value) -- read_sam never looks at them (GCI.py:146-169) */
+        const uint8_t *aux = cig + 4 * (uint64_t)n_cigar + (has_seq ? ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq : 0);
         if (aux > rec_end) { *bad_rec = i; return ORC_E_MALFORMED; }
         uint32_t nl = 0;
         while (nl < l_read_name && name[nl]) nl++;

@@ -63,7 +63,7 @@ def lib():
         vp, u64, u32, i64, i32, dbl = (ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
                                        ctypes.c_int32, ctypes.c_double)
         L.orc_bam_filter.argtypes = [vp, u64, vp, u32, vp, i32, ctypes.c_int, ctypes.c_int, dbl, dbl,
-                                     vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int]
         L.orc_bam_filter.restype = ctypes.c_int
         L.orc_depth_build.argtypes = [vp, i64, vp, vp, u64, i64]
         L.orc_depth_build.restype = None
@@ -95,8 +95,9 @@ Segment = Tuple[str, int, int, int]          # (contig, start, end, query_length
 # ==============================================================================================
 
 def bam_filter_arrays(stream: np.ndarray, rec_off: np.ndarray, ref_sel: np.ndarray, map_qual: int,
-                      mq_cutoff: int, clip_percent: float, iden_percent: float) -> Dict[str, np.ndarray]:
-    """Per-record decision arrays from the C restatement (see orc_bam_filter)."""
+                      mq_cutoff: int, clip_percent: float, iden_percent: float, heads: bool = False) -> Dict[str, np.ndarray]:
+    """Per-record decision arrays from the C restatement (see orc_bam_filter).  heads: `stream` is a heads stream
+    (the records without their SEQ / QUAL bytes -- what a genome-scale test can hold in memory)."""
     R = int(rec_off.shape[0])
     stream = np.ascontiguousarray(stream, dtype=np.uint8)
     rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
@@ -108,7 +109,8 @@ def bam_filter_arrays(stream: np.ndarray, rec_off: np.ndarray, ref_sel: np.ndarr
     st = lib().orc_bam_filter(_p(stream), stream.shape[0], _p(rec_off), R, _p(ref_sel), ref_sel.shape[0],
                               int(map_qual), int(mq_cutoff), float(clip_percent), float(iden_percent),
                               _p(out["passed"]), _p(out["hq"]), _p(out["contig"]), _p(out["start"]), _p(out["end"]),
-                              _p(out["qlen"]), _p(out["name_off"]), _p(out["name_len"]), ctypes.byref(bad))
+                              _p(out["qlen"]), _p(out["name_off"]), _p(out["name_len"]), ctypes.byref(bad),
+                              0 if heads else 1)
     if st != 0:
         raise OracleRecordError(st, int(bad.value))
     return out
@@ -120,7 +122,7 @@ def read_names(stream: np.ndarray, name_off: np.ndarray, name_len: np.ndarray) -
 
 
 def bam_file_dict(stream: np.ndarray, rec_off: np.ndarray, references: Sequence[str], targets: Sequence[str],
-                  map_qual: int, mq_cutoff: int, clip_percent: float, iden_percent: float
+                  map_qual: int, mq_cutoff: int, clip_percent: float, iden_percent: float, heads: bool = False
                   ) -> Tuple[Dict[str, Segment], Set[str]]:
     """samfile_dicts[i] and the high-quality names one BAM contributes (GCI.py:257-270).
 
@@ -129,17 +131,53 @@ def bam_file_dict(stream: np.ndarray, rec_off: np.ndarray, references: Sequence[
     (dict.update at GCI.py:269, with -t 1 chunking)."""
     tindex = {t: i for i, t in enumerate(targets)}
     ref_sel = np.array([tindex.get(r, -1) for r in references], dtype=np.int32)
-    a = bam_filter_arrays(stream, rec_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
+    a = bam_filter_arrays(stream, rec_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, heads)
+    return _dict_from_arrays(stream, a, targets, None)
+
+
+def _dict_from_arrays(stream: np.ndarray, a: Dict[str, np.ndarray], targets: Sequence[str],
+                      keep: Optional[Set[str]]) -> Tuple[Dict[str, Segment], Set[str]]:
+    """The dict / set of GCI.py:166-168, 268-270 from the per-record decisions; keep != None: only those names."""
     idx = np.flatnonzero(a["passed"])
     order = idx[np.argsort(a["contig"][idx], kind="stable")]
     names = read_names(stream, a["name_off"][order], a["name_len"][order])
+    contig, start, end, qlen, is_hq = (a[k][order].tolist() for k in ("contig", "start", "end", "qlen", "hq"))
     d: Dict[str, Segment] = {}
     hq: Set[str] = set()
-    for k, i in enumerate(order.tolist()):
-        d[names[k]] = (targets[int(a["contig"][i])], int(a["start"][i]), int(a["end"][i]), int(a["qlen"][i]))
-        if a["hq"][i]:
-            hq.add(names[k])
+    for k, q in enumerate(names):
+        if keep is not None and q not in keep:
+            continue
+        d[q] = (targets[contig[k]], start[k], end[k], qlen[k])
+        if is_hq[k]:
+            hq.add(q)
     return d, hq
+
+
+def file1_on_contigs(bams, targets: Sequence[str], chosen: Sequence[str], map_qual: int, mq_cutoff: int,
+                     clip_percent: float, iden_percent: float, ovlp_percent: float, heads: bool = False) -> Dict[str, tuple]:
+    """filter()'s `file1` (GCI.py:272-301) restricted to the entries that lie on the contigs `chosen`, for inputs too
+    large to push every name through Python dicts: `bams` = [(stream, rec_off, references)].
+
+    Exact, because the join treats every query name independently: an entry of file1 on contig X can only come from
+    a name that has a passing record on X in some file, so it is enough to run the dict logic over ALL records (of all
+    files, on any contig) of the names seen on the chosen contigs."""
+    tindex = {t: i for i, t in enumerate(targets)}
+    want = np.array([tindex[c] for c in chosen], dtype=np.int32)
+    arrays = []
+    keep: Set[str] = set()
+    for stream, off, refs in bams:
+        ref_sel = np.array([tindex.get(r, -1) for r in refs], dtype=np.int32)
+        a = bam_filter_arrays(stream, off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, heads)
+        arrays.append(a)
+        on = np.flatnonzero((a["passed"] != 0) & np.isin(a["contig"], want))
+        keep.update(read_names(stream, a["name_off"][on], a["name_len"][on]))
+    dicts, hq = [], set()
+    for (stream, off, refs), a in zip(bams, arrays):
+        d, h = _dict_from_arrays(stream, a, targets, keep)
+        dicts.append(d)
+        hq |= h
+    cs = set(chosen)
+    return {q: seg for q, seg in name_join(dicts, hq, ovlp_percent).items() if seg[0] in cs}
 
 
 def bam_filter_record_py(rec, references: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int,

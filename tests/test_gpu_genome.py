@@ -1,0 +1,77 @@
+"""BASELINE configs[2] at full size through the whole device path, against the oracle:
+CHM13 geometry (25 contigs, 3.117 Gb), two 40x HiFi alignment files of the same reads (the second perturbed the way
+another aligner's output differs) as heads streams -> K1 x 2 -> `-op` join -> fused depth build (track, sums, issue
+runs, text), compared on chr1 (the longest contig), chr14 (starts past 2^31 elements of the track) and chrM (a
+contig shorter than a tile) with the oracle's exact restriction of the join to those contigs
+(oracle.file1_on_contigs), plus the genome-wide sum of depth against the clipped join intervals.
+
+GCI_TEST_GENOME_SCALE (default 1.0) shrinks every contig for a quick run."""
+import os
+
+import numpy as np
+import pytest
+
+from gci_amd import pipeline, workloads
+from gci_amd.device import JoinInput
+
+pytestmark = pytest.mark.gpu
+
+FILTER = (30, 50, 0.1, 0.9)
+OVLP, FLANK = 0.9, 15
+
+
+@pytest.fixture(scope="module")
+def genome():
+    return workloads.genome_dual(float(os.environ.get("GCI_TEST_GENOME_SCALE", "1.0")))
+
+
+@pytest.mark.parametrize("join_mode", ["auto"])
+def test_genome_dual_bam_full_path_matches_oracle(engine, oracle, genome, join_mode):
+    import torch
+    inp = genome
+    names, lens = inp.names, inp.lengths
+    engine.set_layout(lens)
+    assert engine.offsets[names.index("chr14")] + lens[names.index("chr14")] > 2 ** 31 or sum(lens) < 2 ** 31
+    ref_sel = engine.to_device(np.arange(len(names), dtype=np.int32))
+    ins = []
+    for f in inp.files:
+        d_s, d_o = engine.to_device(f.stream), engine.to_device(f.offsets)
+        recs = engine.bam_filter(d_s, d_o, ref_sel, *FILTER, heads=True)
+        ins.append(JoinInput(recs, d_s, d_o, 36))
+    ivl, cnt = engine.name_join(ins, OVLP, count_flank=FLANK)
+    track = engine.new_track()
+    fused = engine.depth_build_fused(ivl, cnt, FLANK, track, want_text=True, want_sums=True, issue=(-1.0, 0.0, FLANK),
+                                     counted=True)
+    K = int(cnt.item())
+    # genome-wide: the sum of depth is the sum of the clipped interval lengths
+    iv = ivl[:K].cpu().numpy().astype(np.int64)
+    L = np.asarray(lens, dtype=np.int64)[iv[:, 0]]
+    a, b = np.clip(iv[:, 1] + FLANK, 0, L), np.clip(iv[:, 2] - FLANK + 1, 0, L)
+    assert int(np.maximum(b - a, 0).sum()) == int(np.asarray(fused["sums"]).sum())
+
+    chosen = ["chr1", "chr14", "chrM"]
+    file1 = oracle.file1_on_contigs([(f.stream, f.offsets, names) for f in inp.files], names, chosen, *FILTER, OVLP, heads=True)
+    # the join itself: the same interval multiset on the chosen contigs
+    for c in chosen:
+        ci = names.index(c)
+        got = iv[iv[:, 0] == ci][:, 1:3]
+        want = np.asarray(sorted((s[1], s[2]) for s in file1.values() if s[0] == c), dtype=np.int64).reshape(-1, 2)
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert np.array_equal(got, want), c
+    tl = {c: lens[names.index(c)] for c in chosen}
+    toff = fused["text_off"]
+    for c in chosen:                                     # one contig at a time: chr1 is 2 GB as int64
+        ci = names.index(c)
+        want = oracle.depth_build({q: s for q, s in file1.items() if s[0] == c}, {c: tl[c]}, FLANK)[c]
+        o = engine.offsets[ci]
+        got = track[o:o + tl[c]].cpu().numpy()
+        assert np.array_equal(got, want), c
+        assert int(fused["sums"][ci]) == int(want.sum()), c
+        bed = oracle.collapse_depth_range({c: want}, -1, 0, FLANK, 0)[c]
+        lo, hi = pipeline._slice_bound(FLANK, tl[c]), pipeline._slice_bound(tl[c] - FLANK, tl[c])
+        assert pipeline._issues_from_runs(fused["runs"][ci], max(0, hi - lo), tl[c], FLANK, 0) == bed, c
+        text = fused["text"][int(toff[ci]):int(toff[ci + 1])].cpu().numpy().tobytes()
+        assert text == oracle.depth_text_contig(want), c
+        del want, got, text
+    del fused, track
+    torch.cuda.empty_cache()
