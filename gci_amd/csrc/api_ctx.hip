@@ -75,7 +75,7 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_cd, &ctx->tile_carry, &ctx->dense_flag, &ctx->d_tile_valid,
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
-                      &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->conflict_table, &ctx->win,
+                      &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->part_a, &ctx->part_b, &ctx->part_hist, &ctx->part_blk, &ctx->conflict_table, &ctx->win,
                       &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

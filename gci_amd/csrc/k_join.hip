@@ -1,6 +1,7 @@
 // k_join.hip -- K3: cross-file join by read name (/root/reference/GCI.py:272-301) and the dict
 // "last record wins" semantics (GCI.py:166, 269); names blob for the multi-GPU exchange.
 #include "gci_ctx.hpp"
+#include <stdlib.h>
 //
 // Open-addressing table keyed by the 64-bit name hash, one slot per DISTINCT name.  A slot holds
 // the id (file << 32 | index) of the record that claimed it; keys are compared through the
@@ -189,6 +190,439 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long 
     }
 }
 
+
+// =====================================================================================================================
+// Partitioned join (genome scale).  With 10^7 names the classic table above is ~1 GB of open addressing: every record
+// costs several random device-scope atomics that miss every cache (measured: 5 G/s, a third of the BASELINE configs[2]
+// step).  Here the passing records are first radix-partitioned by bits of the name hash -- two passes of
+// histogram / scan / scatter, sequential traffic only -- into buckets small enough that the whole dict logic of one
+// bucket (claim a slot per distinct name, last-record-wins per file, high-quality bit, then the fold over files) runs
+// in LDS.  What is left of the random traffic is what exactness needs: the name bytes of a record against those of
+// the slot's first claimant, and the 32-byte record of every (name, file) winner.  Same results as the classic path
+// (tests run both); chosen by size (GCI_JOIN=classic|partition overrides).
+//
+//   entry (16 B): key = name_len << 48 | hash & (2^48 - 1);  idx = position in its file;  meta = contig | file << 26 | hq << 30
+//   level 1: B1 = 2^b1 buckets by hash bits [47, 48 - b1); chunks of 4096 records of ONE file
+//   level 2: every level-1 bucket again by the next b2 bits; chunks never straddle level-1 buckets
+//   join   : one workgroup per final bucket, table in LDS: slot = {tag40 | claimant23 | hq} + one order key per file
+
+struct PartEntry { unsigned long long key; uint32_t idx; uint32_t meta; };
+static_assert(sizeof(PartEntry) == 16, "partition entry is 16 bytes");
+#define PART_CHUNK 4096
+#define PART_CONTIG_BITS 26
+#define PART_KEY_MASK 0xFFFFFFFFFFFFull
+struct PartFiles { uint32_t chunk_first[GCI_MAX_JOIN_FILES + 1]; };
+
+__device__ __forceinline__ bool part_entry_of(const gci_rec& r, int file, uint32_t i, PartEntry& e, unsigned long long* status)
+{
+    if (!(r.flags & GCI_REC_PASS)) return false;
+    if ((uint32_t)r.contig >> PART_CONTIG_BITS) {               // contig index beyond the entry's field (or negative)
+        atomicMin(status, ((unsigned long long)r.rec_idx << 8) | (unsigned)(-GCI_E_INVALID));
+        return false;
+    }
+    e.key = ((unsigned long long)r.name_len << 48) | (r.name_hash & PART_KEY_MASK);
+    e.idx = i;
+    e.meta = (uint32_t)r.contig | ((uint32_t)file << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u);
+    return true;
+}
+
+__device__ __forceinline__ int part_file_of(const PartFiles& P, int n, uint32_t chunk)
+{
+    int f = 0;
+    while (f + 1 < n && chunk >= P.chunk_first[f + 1]) f++;
+    return f;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_part1_hist(JoinFiles F, PartFiles P, int shift, uint32_t n_bins, uint32_t n_chunks,
+                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ reset_n_out,
+                                                      unsigned long long* __restrict__ status)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t t = threadIdx.x, chunk = blockIdx.x;
+    if (chunk == 0 && t == 0) *reset_n_out = 0;                   // (the status word was reset by a memset before this launch)
+    h[t] = 0;
+    __syncthreads();
+    const int f = part_file_of(P, F.n, chunk);
+    const uint32_t i0 = (chunk - P.chunk_first[f]) * PART_CHUNK, n = F.f[f].n_recs;
+    const gci_rec* __restrict__ recs = F.f[f].d_recs;
+#pragma unroll 4
+    for (int k = 0; k < PART_CHUNK / BLOCK; k++) {
+        const uint32_t i = i0 + k * BLOCK + t;
+        if (i < n) {
+            const gci_rec r = recs[i];
+            if ((r.flags & GCI_REC_PASS) && !((uint32_t)r.contig >> PART_CONTIG_BITS))
+                atomicAdd(&h[(uint32_t)((r.name_hash & PART_KEY_MASK) >> shift) & (n_bins - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    if (t < n_bins) hist[(size_t)t * n_chunks + chunk] = h[t];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_part1_scatter(JoinFiles F, PartFiles P, int shift, uint32_t n_bins, uint32_t n_chunks,
+                                                         const uint32_t* __restrict__ off, PartEntry* __restrict__ out,
+                                                         unsigned long long* __restrict__ status)
+{
+    __shared__ uint32_t cnt[256], base[256];
+    const uint32_t t = threadIdx.x, chunk = blockIdx.x;
+    cnt[t] = 0;
+    if (t < n_bins) base[t] = off[(size_t)t * n_chunks + chunk];
+    __syncthreads();
+    const int f = part_file_of(P, F.n, chunk);
+    const uint32_t i0 = (chunk - P.chunk_first[f]) * PART_CHUNK, n = F.f[f].n_recs;
+    const gci_rec* __restrict__ recs = F.f[f].d_recs;
+#pragma unroll 4
+    for (int k = 0; k < PART_CHUNK / BLOCK; k++) {
+        const uint32_t i = i0 + k * BLOCK + t;
+        if (i < n) {
+            const gci_rec r = recs[i];
+            PartEntry e;
+            if (part_entry_of(r, f, i, e, status)) {
+                const uint32_t d = (uint32_t)((e.key & PART_KEY_MASK) >> shift) & (n_bins - 1);
+                out[base[d] + atomicAdd(&cnt[d], 1u)] = e;
+            }
+        }
+    }
+}
+
+// Segment table of level 2 from the scanned level-1 histogram: seg[0 .. B1] = first entry of every level-1 bucket
+// (+ the total), seg[B1 + 1 .. 2 B1 + 1] = exclusive scan of their chunk counts.  One workgroup.
+__global__ __launch_bounds__(BLOCK) void k_part_mid(const uint32_t* __restrict__ off1, uint32_t n_bins, uint32_t n_chunks,
+                                                    uint32_t* __restrict__ seg)
+{
+    __shared__ uint32_t s[257], c[257];
+    const uint32_t t = threadIdx.x;
+    if (t <= n_bins) s[t] = off1[(size_t)t * n_chunks];          // t == n_bins: the grand total the scan wrote behind the table
+    if (t == 0 && n_bins == 256) s[256] = off1[(size_t)256 * n_chunks];
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (uint32_t d = 0; d < n_bins; d++) { c[d] = acc; acc += (s[d + 1] - s[d] + PART_CHUNK - 1) / PART_CHUNK; }
+        c[n_bins] = acc;
+    }
+    __syncthreads();
+    if (t <= n_bins) { seg[t] = s[t]; seg[n_bins + 1 + t] = c[t]; }
+    if (t == 0 && n_bins == 256) { seg[256] = s[256]; seg[513] = c[256]; }
+}
+
+// chunk w of level 2 -> (segment j, chunk k inside it); false when w is beyond the last chunk
+__device__ __forceinline__ bool part2_chunk(const uint32_t* sS, const uint32_t* sC, uint32_t n_seg, uint32_t w, uint32_t& j,
+                                            uint32_t& k, uint32_t& a, uint32_t& b, uint32_t& nch)
+{
+    if (w >= sC[n_seg]) return false;
+    uint32_t lo = 0, hi = n_seg;                                 // first index with sC[idx] > w lies in (lo, hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= w) lo = mid; else hi = mid; }
+    j = lo; k = w - sC[j]; nch = sC[j + 1] - sC[j];
+    a = sS[j] + k * PART_CHUNK;
+    b = min(sS[j + 1], a + PART_CHUNK);
+    return true;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_part2_hist(const PartEntry* __restrict__ in, const uint32_t* __restrict__ seg,
+                                                      uint32_t n_seg, int shift, uint32_t n_bins, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t sS[257], sC[257], h[256];
+    const uint32_t t = threadIdx.x, w = blockIdx.x;
+    for (uint32_t i = t; i <= n_seg; i += BLOCK) { sS[i] = seg[i]; sC[i] = seg[n_seg + 1 + i]; }
+    h[t] = 0;
+    __syncthreads();
+    uint32_t j, k, a, b, nch;
+    if (!part2_chunk(sS, sC, n_seg, w, j, k, a, b, nch)) {        // unused tail of the table: zero for the scan
+        if (t < n_bins) hist[(size_t)w * n_bins + t] = 0;
+        return;
+    }
+    for (uint32_t i = a + t; i < b; i += BLOCK)
+        atomicAdd(&h[(uint32_t)((in[i].key & PART_KEY_MASK) >> shift) & (n_bins - 1)], 1u);
+    __syncthreads();
+    if (t < n_bins) hist[(size_t)sC[j] * n_bins + (size_t)t * nch + k] = h[t];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_part2_scatter(const PartEntry* __restrict__ in, const uint32_t* __restrict__ seg,
+                                                         uint32_t n_seg, int shift, uint32_t n_bins,
+                                                         const uint32_t* __restrict__ off, PartEntry* __restrict__ out)
+{
+    __shared__ uint32_t sS[257], sC[257], cnt[256], base[256];
+    const uint32_t t = threadIdx.x, w = blockIdx.x;
+    for (uint32_t i = t; i <= n_seg; i += BLOCK) { sS[i] = seg[i]; sC[i] = seg[n_seg + 1 + i]; }
+    cnt[t] = 0;
+    __syncthreads();
+    uint32_t j, k, a, b, nch;
+    if (!part2_chunk(sS, sC, n_seg, w, j, k, a, b, nch)) return;
+    if (t < n_bins) base[t] = off[(size_t)sC[j] * n_bins + (size_t)t * nch + k];
+    __syncthreads();
+    for (uint32_t i = a + t; i < b; i += BLOCK) {
+        const PartEntry e = in[i];
+        const uint32_t d = (uint32_t)((e.key & PART_KEY_MASK) >> shift) & (n_bins - 1);
+        out[base[d] + atomicAdd(&cnt[d], 1u)] = e;
+    }
+}
+
+// len bytes at pa against len bytes at pb, through naturally aligned dword loads re-aligned in registers (an
+// unaligned vector load from global memory is ~100x slower here, and a byte loop with an early exit serialises its
+// loads: both names sit in HBM at random places, so the nine dwords of a 32-byte round are requested together);
+// nothing beyond the dword that holds the last byte of either name is touched.
+__device__ __forceinline__ bool names_equal(const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, uint32_t len)
+{
+    const uint32_t sa = (uint32_t)((uintptr_t)pa & 3u), sb = (uint32_t)((uintptr_t)pb & 3u);
+    const uint32_t* __restrict__ qa = reinterpret_cast<const uint32_t*>(pa - sa);
+    const uint32_t* __restrict__ qb = reinterpret_cast<const uint32_t*>(pb - sb);
+    const uint32_t na = (sa + len + 3u) >> 2, nb = (sb + len + 3u) >> 2;      // dwords that hold bytes of the name
+    uint32_t diff = 0;
+    for (uint32_t w0 = 0; 4u * w0 < len; w0 += 8) {
+        uint32_t a[9], b[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            a[k] = w0 + k < na ? qa[w0 + k] : 0u;
+            b[k] = w0 + k < nb ? qb[w0 + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t w = w0 + k;
+            if (4u * w < len) {
+                uint32_t x = __builtin_amdgcn_alignbyte(a[k + 1], a[k], sa) ^ __builtin_amdgcn_alignbyte(b[k + 1], b[k], sb);
+                const uint32_t left = len - 4u * w;
+                if (left < 4u) x &= (1u << (8u * left)) - 1u;
+                diff |= x;
+            }
+        }
+    }
+    return diff == 0;
+}
+
+struct PartJoinArgs {
+    const PartEntry* in; const uint32_t* seg; const uint32_t* off2;
+    uint32_t n_seg, n_bins2, slots, slot_shift;
+};
+
+// The fold of fold_slot() with the winners' records of all FN files requested TOGETHER (they are random 32-byte reads
+// of HBM; one after the other they were most of this kernel's time).  FN == 0: any number of files, one by one.
+template <int FN>
+__device__ __forceinline__ bool fold_bucket_slot(const JoinFiles& F, uint32_t slot, const unsigned long long* last, bool high,
+                                                 double ovlp_percent, const int32_t* __restrict__ contig_map,
+                                                 unsigned long long* __restrict__ status, gci_ivl& o)
+{
+    if constexpr (FN == 0) {
+        return fold_slot(F, slot, last, high, ovlp_percent, contig_map, status, o);
+    } else {
+        unsigned long long v[FN];
+        int4 ra[FN], rb[FN];                                         // the 32-byte records as two 16-byte halves
+        bool comm = true;
+#pragma unroll
+        for (int f = 0; f < FN; f++) { v[f] = last[(size_t)slot * FN + f]; comm = comm && v[f] != 0; }
+#pragma unroll
+        for (int f = 0; f < FN; f++) {
+            ra[f] = make_int4(0, 0, 0, 0); rb[f] = make_int4(0, 0, 0, 0);
+            if (v[f]) {
+                const int4* p = reinterpret_cast<const int4*>(F.f[f].d_recs + (uint32_t)(v[f] - 1));
+                ra[f] = p[0]; rb[f] = p[1];
+            }
+        }
+        // gci_rec: {hash lo, hash hi, contig, start} {end, qlen, rec_idx, mapq | flags << 8 | name_len << 16}
+        bool have = false, dead = false;                              // dead: the reference raised on this name
+        int32_t contig = -1, s = 0, e = 0;
+        if (v[0] && (FN == 1 || high || comm)) { have = true; contig = ra[0].z; s = ra[0].w; e = rb[0].x; }
+#pragma unroll
+        for (int f = 1; f < FN; f++) {                                // GCI.py:281-299 (no early exit: the loop stays unrolled)
+            const int32_t r_contig = ra[f].z, r_start = ra[f].w, r_end = rb[f].x, r_qlen = rb[f].y;
+            const bool present = v[f] != 0 && !dead;
+            if (present && have) {
+                if (r_contig == contig) {
+                    const int32_t ms = max(r_start, s), me = min(r_end, e);
+                    const int64_t ovlp = (int64_t)me - (int64_t)ms;
+                    if (r_qlen == 0) {                                // ZeroDivisionError at GCI.py:292
+                        atomicMin(status, ((unsigned long long)(uint32_t)rb[f].z << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                        dead = true;
+                    } else if ((double)ovlp / (double)r_qlen < ovlp_percent) have = false;
+                    else { s = ms; e = me; }
+                } else have = false;
+            } else if (present && high) {
+                have = true; contig = r_contig; s = r_start; e = r_end;
+            }
+        }
+        if (!have || dead) return false;
+        if (contig_map) { contig = contig_map[contig]; if (contig < 0) return false; }
+        o.contig = contig; o.start = s; o.end = e; o.pad = 0;
+        return true;
+    }
+}
+
+// One workgroup per final bucket.  LDS: meta[S] | last[S * F.n] | list of used slots.
+//   meta = tag (hash bits [39, 0]) << 24 | claimant (entry index inside the bucket) << 1 | high-quality bit; ~0 = empty
+template <int FN>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_join_part(JoinFiles F, PartJoinArgs A, double ovlp_percent,
+                                                     const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out, uint32_t cap,
+                                                     uint32_t* __restrict__ n_out, unsigned long long* __restrict__ status,
+                                                     const CountArgs cnt)
+{
+    extern __shared__ unsigned long long sm[];
+    __shared__ uint32_t wtot[BLOCK / 64];
+    __shared__ uint32_t s_base, s_used;
+    __shared__ int64_t s_len[COUNT_LDS], s_tf[COUNT_LDS];
+    const uint32_t S = A.slots;
+    unsigned long long* meta = sm;
+    unsigned long long* last = sm + S;
+    uint16_t* used = reinterpret_cast<uint16_t*>(sm + S + (size_t)S * F.n);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t j = blockIdx.x / A.n_bins2, d = blockIdx.x % A.n_bins2;
+    const uint32_t cj = A.seg[A.n_seg + 1 + j], nch = A.seg[A.n_seg + 2 + j] - cj;
+    if (nch == 0) return;                                        // empty level-1 bucket (uniform over the workgroup)
+    const uint32_t lo = A.off2[(size_t)cj * A.n_bins2 + (size_t)d * nch], hi = A.off2[(size_t)cj * A.n_bins2 + (size_t)(d + 1) * nch];
+    if (lo == hi) return;
+    const bool tables_in_lds = cnt.tile_cd && cnt.n_contigs <= COUNT_LDS;
+    if (tables_in_lds) for (int c = t; c < cnt.n_contigs; c += BLOCK) { s_len[c] = cnt.len[c]; s_tf[c] = cnt.tile_first[c]; }
+    for (uint32_t s = t; s < S; s += BLOCK) meta[s] = SLOT_EMPTY;
+    for (uint32_t s = t; s < S * (uint32_t)F.n; s += BLOCK) last[s] = 0ull;
+    if (t == 0) s_used = 0;
+    __syncthreads();
+    const PartEntry* __restrict__ in = A.in + lo;
+    const uint32_t n = hi - lo;
+    if (n >> 23) {                                               // claimant field: a bucket of 8 M entries and more (one name
+        if (t == 0) atomicMin(status, ((unsigned long long)in[0].idx << 8) | (unsigned)(-GCI_E_CAPACITY));   // repeated): classic path
+        return;
+    }
+    // ---- insert: one entry per thread and round --------------------------------------------------------------------
+    for (uint32_t i = t; i < n; i += BLOCK) {
+        const PartEntry e = in[i];
+        const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
+        const unsigned long long tag = e.key & 0xFFFFFFFFFFull;
+        const unsigned long long mine = (tag << 24) | ((unsigned long long)i << 1);
+        const uint32_t name_len = (uint32_t)(e.key >> 48);
+        uint32_t slot = (uint32_t)((e.key & PART_KEY_MASK) >> A.slot_shift) & (S - 1);
+        uint32_t probes = 0;
+        for (;;) {
+            unsigned long long m = meta[slot];
+            if (m == SLOT_EMPTY) {
+                m = atomicCAS(meta + slot, SLOT_EMPTY, mine);
+                if (m == SLOT_EMPTY) {                           // claimed: this entry is the slot's reference name
+                    used[atomicAdd(&s_used, 1u)] = (uint16_t)slot;
+                    break;
+                }
+            }
+            if ((m >> 24) == tag) {
+                const PartEntry c = in[(uint32_t)(m >> 1) & 0x7FFFFFu];
+                if (c.key == e.key &&
+                    names_equal(name_ptr(F.f[file], e.idx), name_ptr(F.f[(c.meta >> PART_CONTIG_BITS) & 15u], c.idx), name_len))
+                    break;
+            }
+            slot = (slot + 1) & (S - 1);
+            if (++probes >= S) { slot = 0xFFFFFFFFu; break; }    // more distinct names than slots
+        }
+        if (slot == 0xFFFFFFFFu) {
+            atomicMin(status, ((unsigned long long)e.idx << 8) | (unsigned)(-GCI_E_CAPACITY));
+            continue;
+        }
+        // order of dict insertion in the reference: contig by contig (header order), file order inside (GCI.py:269)
+        const unsigned long long ord = (((unsigned long long)(e.meta & ((1u << PART_CONTIG_BITS) - 1u)) << 32) | e.idx) + 1ull;
+        atomicMax(last + (size_t)slot * F.n + file, ord);
+        if (F.n > 1 && (e.meta >> 30 & 1u)) atomicOr(meta + slot, 1ull);
+    }
+    __syncthreads();
+    // ---- fold: one used slot (= one distinct name) per thread and round; survivors appended with one returning atomic
+    // per workgroup and round (a bucket holds ~200 names: one round) ------------------------------------------------
+    const uint32_t n_used = s_used;
+    for (uint32_t u0 = 0; u0 < n_used; u0 += BLOCK) {
+        const uint32_t u = u0 + t;
+        gci_ivl keep;
+        bool ok = false;
+        if (u < n_used) {
+            const uint32_t slot = used[u];
+            ok = fold_bucket_slot<FN>(F, slot, last, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) wtot[wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t pre = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
+        if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
+        __syncthreads();
+        if (ok) {
+            const uint32_t w = s_base + pre;
+            if (w < cap) out[w] = keep;
+            if (cnt.tile_cd) {
+                const IvlSpan sp = tables_in_lds ? span_of(keep, cnt.flank, s_len, s_tf, cnt.n_contigs)
+                                                 : span_of(keep, cnt.flank, cnt.len, cnt.tile_first, cnt.n_contigs);
+                if (sp.valid) count_span(sp, cnt.tile_cd);
+            }
+        }
+    }
+}
+
+static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t total, double ovlp_percent,
+                                 const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
+                                 uint64_t* d_status, const CountArgs& cnt, bool* done)
+{
+    *done = false;
+    // slots per bucket table: what fits ~28 KB of LDS with one order key per file (five workgroups per CU: the kernel
+    // lives on random reads of HBM and needs the waves)
+    uint32_t S = 1024;
+    while (S > 128 && (size_t)S * (8 + 8 * (size_t)F.n) > 28672) S >>= 1;
+    // buckets: a load of at most 0.63 in the worst case (every name distinct), 0.15 - 0.3 for two files of the same reads
+    uint64_t nb = 256;
+    while (nb * S * 5 < total * 8) nb <<= 1;
+    if (nb > 65536) return GCI_OK;                                            // beyond two 8-bit levels: classic path
+    int bits = 0;
+    while ((1ull << bits) < nb) bits++;
+    const int b1 = (bits + 1) / 2, b2 = bits - b1;
+    const uint32_t B1 = 1u << b1, B2 = 1u << b2;
+    int s_bits = 0;
+    while ((1u << s_bits) < S) s_bits++;
+    const int shift1 = 48 - b1, shift2 = 48 - b1 - b2, slot_shift = shift2 - s_bits;
+    PartFiles P;
+    uint32_t C1 = 0;
+    for (int f = 0; f < F.n; f++) { P.chunk_first[f] = C1; C1 += (F.f[f].n_recs + PART_CHUNK - 1) / PART_CHUNK; }
+    for (int f = F.n; f <= GCI_MAX_JOIN_FILES; f++) P.chunk_first[f] = C1;
+    const uint32_t C2 = (uint32_t)(total / PART_CHUNK) + B1 + 1;
+    const size_t n1 = (size_t)B1 * C1, n2 = (size_t)C2 * B2;
+    GCI_TRY(gci_ensure(ctx, ctx->part_a, total * sizeof(PartEntry) + 16));
+    GCI_TRY(gci_ensure(ctx, ctx->part_b, total * sizeof(PartEntry) + 16));
+    GCI_TRY(gci_ensure(ctx, ctx->part_hist, (n1 + 1 + n2 + 1 + 2 * (size_t)B1 + 2) * 4 + 64));
+    GCI_TRY(gci_ensure(ctx, ctx->part_blk, ((n1 > n2 ? n1 : n2) / TILE + 2) * 4));
+    uint32_t* hist1 = (uint32_t*)ctx->part_hist.p;
+    uint32_t* hist2 = hist1 + n1 + 1;
+    uint32_t* seg = hist2 + n2 + 1;
+    PartEntry* pa = (PartEntry*)ctx->part_a.p;
+    PartEntry* pb = (PartEntry*)ctx->part_b.p;
+    HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
+    {
+        ProfScope _ps(ctx, GCI_PROF_JOIN_INSERT);
+        hipLaunchKernelGGL(k_part1_hist, dim3(C1), dim3(BLOCK), 0, ctx->stream, F, P, shift1, B1, C1, hist1, d_n_out,
+                           (unsigned long long*)d_status);
+        LAUNCHCHK("k_part1_hist");
+        int r = device_exclusive_scan<uint32_t, uint32_t>(ctx, hist1, hist1, (uint32_t*)ctx->part_blk.p, (int64_t)n1, true);
+        if (r) return r;
+        hipLaunchKernelGGL(k_part1_scatter, dim3(C1), dim3(BLOCK), 0, ctx->stream, F, P, shift1, B1, C1, (const uint32_t*)hist1, pa,
+                           (unsigned long long*)d_status);
+        LAUNCHCHK("k_part1_scatter");
+        hipLaunchKernelGGL(k_part_mid, dim3(1), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)hist1, B1, C1, seg);
+        LAUNCHCHK("k_part_mid");
+        hipLaunchKernelGGL(k_part2_hist, dim3(C2), dim3(BLOCK), 0, ctx->stream, (const PartEntry*)pa, (const uint32_t*)seg, B1,
+                           shift2, B2, hist2);
+        LAUNCHCHK("k_part2_hist");
+        r = device_exclusive_scan<uint32_t, uint32_t>(ctx, hist2, hist2, (uint32_t*)ctx->part_blk.p, (int64_t)n2, true);
+        if (r) return r;
+        hipLaunchKernelGGL(k_part2_scatter, dim3(C2), dim3(BLOCK), 0, ctx->stream, (const PartEntry*)pa, (const uint32_t*)seg, B1,
+                           shift2, B2, (const uint32_t*)hist2, pb);
+        LAUNCHCHK("k_part2_scatter");
+    }
+    {
+        ProfScope _ps(ctx, GCI_PROF_JOIN_FOLD);
+        PartJoinArgs A;
+        A.in = pb; A.seg = seg; A.off2 = hist2; A.n_seg = B1; A.n_bins2 = B2; A.slots = S; A.slot_shift = (uint32_t)slot_shift;
+        const size_t lds = (size_t)S * (8 + 8 * (size_t)F.n) + (size_t)S * 2;      // + the list of used slots
+        const dim3 grid(B1 * B2), block(BLOCK);
+        switch (F.n) {
+        case 1: hipLaunchKernelGGL((k_join_part<1>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
+        case 2: hipLaunchKernelGGL((k_join_part<2>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
+        case 3: hipLaunchKernelGGL((k_join_part<3>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
+        case 4: hipLaunchKernelGGL((k_join_part<4>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
+        default: hipLaunchKernelGGL((k_join_part<0>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
+        }
+        LAUNCHCHK("k_join_part");
+    }
+    *done = true;
+    return GCI_OK;
+}
+
 static int name_join_impl(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
                           const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
                           uint64_t* d_status, const CountArgs& cnt)
@@ -200,6 +634,16 @@ static int name_join_impl(gci_ctx* ctx, const gci_join_file* h_files, int n_file
     F.n = n_files;
     uint64_t total = 0;
     for (int f = 0; f < n_files; f++) { F.f[f] = h_files[f]; total += h_files[f].n_recs; }
+    // genome scale: radix partition + per-bucket tables in LDS (GCI_JOIN=classic|partition overrides the size rule)
+    {
+        const char* m = getenv("GCI_JOIN");
+        const bool force_part = m && m[0] == 'p', force_classic = m && m[0] == 'c';
+        if (!force_classic && (force_part || total >= (1ull << 20)) && total > 0) {
+            bool done = false;
+            const int st = name_join_partitioned(ctx, F, total, ovlp_percent, d_contig_map, d_out, cap, d_n_out, d_status, cnt, &done);
+            if (st != GCI_OK || done) return st;
+        }
+    }
     uint64_t slots = 1024;
     while (slots < 2 * total) slots <<= 1;
     // The three tables are kept clean between calls (k_join_fold empties every slot it reads), whatever the slot count

@@ -7,6 +7,7 @@ the CPU; a missing library or GPU raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -182,7 +183,7 @@ class Engine:
 
     def name_join(self, files: Sequence[JoinInput], ovlp_percent: float, contig_map: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None, check: bool = True,
-                  count_flank: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  count_flank: Optional[int] = None, fallback: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (intervals int32 [cap, 4], device count).  With check=True the count is read back,
         capacity is grown if needed and the record-level status is raised.
 
@@ -205,7 +206,22 @@ class Engine:
             self._chk(st, "gci_name_join")
             if not check:
                 return out, count
-            self.check_status("gci_name_join")
+            try:
+                self.check_status("gci_name_join")
+            except GciError as e:
+                # the partitioned join (large inputs) found more distinct names in one hash bucket than its LDS table
+                # holds -- only adversarial names get there: redo on the classic global table
+                if e.status != _lib.GCI_E_CAPACITY or not fallback or os.environ.get("GCI_JOIN", "") == "classic":
+                    raise
+                prev = os.environ.get("GCI_JOIN")
+                os.environ["GCI_JOIN"] = "classic"
+                try:
+                    return self.name_join(files, ovlp_percent, contig_map, out, count, True, count_flank, False)
+                finally:
+                    if prev is None:
+                        del os.environ["GCI_JOIN"]
+                    else:
+                        os.environ["GCI_JOIN"] = prev
             n = int(count.item())
             if n <= out.shape[0]:
                 return out, count

@@ -77,8 +77,16 @@ def _join_gpu(engine, sets, targets, ovlp=0.9):
     return sorted(map(tuple, ivl[:n, :3].cpu().numpy().tolist()))
 
 
+@pytest.fixture(params=["classic", "partition"])
+def join_mode(request, monkeypatch):
+    """Both implementations of the join behind gci_name_join: the global open-addressing table and the radix-partitioned
+    one with per-bucket tables in LDS (chosen by size in production; GCI_JOIN forces one)."""
+    monkeypatch.setenv("GCI_JOIN", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("n_files", [1, 2, 3])
-def test_name_join_matches_oracle(engine, oracle, n_files):
+def test_name_join_matches_oracle(engine, oracle, n_files, join_mode):
     contigs = (("a", 900_000), ("b", 500_000))
     targets = ["a", "b"]
     base = synth.simulate_reads(contigs, 25, "hifi", seed=21)
@@ -457,7 +465,7 @@ def test_fasta_n_runs_on_gpu(engine, oracle, tmp_path):
     assert sum(len(v) for v in fasta.n_runs_device(engine, str(tmp_path / "lf60.fa"))[1].values()) > 20
 
 
-def test_counting_join_equals_join_then_count(engine, oracle):
+def test_counting_join_equals_join_then_count(engine, oracle, join_mode):
     """gci_name_join_count + gci_depth_build_begin(counted = 1) produce the same track, text, sums and issue runs as
     gci_name_join + a plain build; a counted build over other intervals or another flank is refused; a plain build after
     an unused counting join starts from a clean table."""
@@ -641,8 +649,8 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
     assert n_checked > 5
 
 
-@pytest.mark.parametrize("n_files,seed", [(1, 0), (2, 1), (3, 2), (4, 3), (5, 4)])
-def test_name_join_randomised_dicts(engine, oracle, n_files, seed):
+@pytest.mark.parametrize("n_files,seed", [(1, 0), (2, 1), (3, 2), (4, 3), (5, 4), (9, 5), (16, 6)])
+def test_name_join_randomised_dicts(engine, oracle, n_files, seed, join_mode):
     """The fold of GCI.py:279-299 on random per-file dicts drawn from a small name pool (many names in several
     files, on the same / different contigs, high-quality or not): exercises deletion, interval intersection, the
     ovlp / qlen-of-the-current-file test and resurrection by a later file with >= 3 files."""
@@ -724,3 +732,74 @@ def test_depth_text_as_gzip_members_from_the_gpu(engine):
     whole = text.cpu().numpy().tobytes()
     for c in range(len(lens)):
         assert gzip.decompress(members[c]) == whole[int(off_t[c]):int(off_t[c + 1])]
+
+
+def _forged_input(engine, names, hashes, contig, start, end, qlen, hq):
+    """A join input whose name hashes are given instead of computed (collision tests)."""
+    n = len(names)
+    r = np.zeros(n, dtype=REC_DTYPE)
+    r["name_hash"] = np.asarray(hashes, dtype=np.uint64)
+    r["contig"], r["start"], r["end"], r["qlen"] = contig, start, end, qlen
+    r["rec_idx"] = np.arange(n)
+    r["flags"] = 1 | (2 * np.asarray(hq, dtype=np.uint8))
+    r["name_len"] = [len(x) for x in names]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in names], out=off[1:])
+    blob = np.frombuffer(b"".join(names) or b"\x00", dtype=np.uint8)
+    return JoinInput(engine.to_device(r.view(np.uint8).reshape(n, 32)), engine.to_device(blob), engine.to_device(off), 0)
+
+
+def test_name_join_hash_collisions_and_repeats(engine, oracle, join_mode):
+    """Names are confirmed on their bytes: reads whose 64-bit hashes (and lengths) coincide stay different reads, on
+    both join paths; a name repeated thousands of times in one file keeps its last record (contig order first)."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    names = [b"coll%06d" % i for i in range(n)]                   # same length, forged to share hashes in groups of 3
+    hashes = (np.arange(n, dtype=np.uint64) // np.uint64(3)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
+    files = []
+    for f in range(2):
+        d = {}
+        for i in rng.permutation(n)[:2400]:
+            s = 30 * int(i) + int(rng.integers(0, 40))             # the two files mostly agree on where a read lies
+            d[names[i].decode()] = ("t0" if rng.random() < 0.95 else "t1", s, s + 9000 + f, 9000)
+        files.append(d)
+    hq = set(q for q in files[0] if rng.random() < 0.3) | set(q for q in files[1] if rng.random() < 0.3)
+    want = oracle.name_join(files, hq, 0.9)
+    want = sorted((0 if v[0] == "t0" else 1, v[1], v[2]) for v in want.values())
+    hmap = {nm.decode(): int(h) for nm, h in zip(names, hashes)}
+    inputs = []
+    for d in files:
+        qs = list(d)
+        inputs.append(_forged_input(engine, [q.encode() for q in qs], [hmap[q] for q in qs],
+                                    [0 if d[q][0] == "t0" else 1 for q in qs], [d[q][1] for q in qs], [d[q][2] for q in qs],
+                                    [d[q][3] for q in qs], [q in hq for q in qs]))
+    ivl, cnt = engine.name_join(inputs, 0.9)
+    got = sorted(map(tuple, ivl[:int(cnt.item()), :3].cpu().numpy().tolist()))
+    assert got == want and len(want) > 500
+    # one name 20000 times (on both contigs, shuffled) among 500 others, single file: the dict keeps the last record
+    # of the later contig
+    rep = [b"again"] * 20000 + [b"other%04d" % i for i in range(500)]
+    contig = np.concatenate([rng.integers(0, 2, 20000), np.zeros(500, dtype=np.int64)])
+    start = np.arange(len(rep))
+    one = _forged_input(engine, rep, name_hash_np(rep), contig, start, start + 100, np.full(len(rep), 100), np.zeros(len(rep)))
+    ivl, cnt = engine.name_join([one], 0.9)
+    got = sorted(map(tuple, ivl[:int(cnt.item()), :3].cpu().numpy().tolist()))
+    last1 = int(np.flatnonzero(contig[:20000] == 1)[-1])
+    assert got == sorted([(1, last1, last1 + 100)] + [(0, 20000 + i, 20100 + i) for i in range(500)])
+
+
+def test_partitioned_join_bucket_overflow_falls_back(engine, monkeypatch):
+    """More distinct names in one bucket than its LDS table holds (only forged hashes get there): the partitioned join
+    reports GCI_E_CAPACITY, Engine.name_join() retries on the classic table."""
+    from gci_amd import _lib
+    n = 5000
+    names = [b"ovf%05d" % i for i in range(n)]
+    hashes = np.uint64(0xABCD) << np.uint64(32) | np.arange(n, dtype=np.uint64)          # same bucket and slot bits
+    start = np.arange(n)
+    one = _forged_input(engine, names, hashes, np.zeros(n), start, start + 50, np.full(n, 50), np.zeros(n))
+    monkeypatch.setenv("GCI_JOIN", "partition")
+    with pytest.raises(GciErr) as e:
+        engine.name_join([one], 0.9, fallback=False)
+    assert e.value.status == _lib.GCI_E_CAPACITY
+    ivl, cnt = engine.name_join([one], 0.9)
+    assert sorted(map(tuple, ivl[:int(cnt.item()), :3].cpu().numpy().tolist())) == [(0, i, i + 50) for i in range(n)]

@@ -43,9 +43,10 @@ try:
            "reference_gbases_per_s_t1": aligned / walls[1] / 1e9, "reference_gbases_per_s_t8": aligned / walls[8] / 1e9,
            "port_gbases_per_s_1core": aligned / port / 1e9, "port_over_reference_t1": walls[1] / port,
            "port_over_reference_t8": walls[8] / port, "host": "build container, %d cores" % (os.cpu_count() or 0),
-           "note": "reference = /root/reference/GCI.py unmodified, GCI() whole run incl. write_depth, through tools/ref_shim "
-                   "(pysam stand-in: BAM decode is the shim's, not htslib's); port = oracle/gci_oracle.{c,py} run_path on the same file (port_seconds_1core includes reading the BGZF container with the repo's pure-Python reader; '
-                   '*_in_memory = from the inflated stream on, which is what bench.py's cpu_baseline times)"}
+           "note": ("reference = /root/reference/GCI.py unmodified, GCI() whole run incl. write_depth, through tools/ref_shim "
+                    "(pysam stand-in: BAM decode is the shim's, not htslib's); port = oracle/gci_oracle.{c,py} run_path on the "
+                    "same file; port_seconds_1core includes reading the BGZF container with the repo's pure-Python reader, "
+                    "*_in_memory = from the inflated stream on, which is what bench.py's cpu_baseline times")}
     json.dump(res, open(os.path.join(ROOT, "profiles", "port_vs_reference.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 finally:
