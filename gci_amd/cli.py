@@ -1,5 +1,11 @@
 """Drop-in command line: the flags, defaults, validation order, messages and output files of
-/root/reference/GCI.py:897-1113, driving the HIP path in gci_amd/pipeline.py.
+/root/reference/GCI.py:897-1113 (R14), driving the HIP path in gci_amd/pipeline.py.
+
+The contract with the reference is the user-visible behaviour -- option table, messages, the order in which checks
+fire, output names -- and it is pinned by transcripts of the unmodified reference (tests/golden/*/manifest.json,
+tests/golden/cli_errors.json).  The control flow here is this package's own: the options are a table, the input
+checks a list of small steps, and the three shapes of a run (HiFi only, ONT only, both) are one routine over
+"read types".
 
 `-p/--plot`: the numbers of the figures come from the GPU (gci_amd/plot.py), the drawing
 is matplotlib on the host as in the reference.
@@ -9,6 +15,8 @@ from __future__ import annotations
 import argparse
 import os
 import sys
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
 
 from . import pipeline
 from .plot import plot_depth
@@ -16,142 +24,42 @@ from .formats import bam as bamfmt
 from .formats import fasta
 
 VERSION = "GCI version 1.0"
+HELP_HINT = 'Please read the help message use "-h" or "--help"'
 
-
-def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50, iden_percent=0.9, ovlp_percent=0.9,
-        clip_percent=0.1, flank_len=15, threshold=0, plot=False, depth_min=0.1, depth_max=4.0, window_size=50000,
-        image_type="png", force=False, dist_percent=0.005, reference=None, regions=None, chrs=None, threads=1):
-    chrs_list = []
-    if chrs != None:  # noqa: E711
-        chrs_list = chrs.strip().split(",")
-
-    regions_bed = {}
-    if regions != None:  # noqa: E711
-        if os.path.exists(regions) and os.access(regions, os.R_OK):
-            with open(regions, "r") as f:
-                for line in f:
-                    target, start, end = line.strip().split("\t")
-                    regions_bed.setdefault(target, []).append((int(start), int(end)))
-        else:
-            sys.exit(f'ERROR!!! "{regions}" is not an available file')
-
-    if directory.endswith("/"):
-        directory = "/".join(directory.split("/")[:-1])
-    if os.path.exists(directory):
-        if not os.access(directory, os.R_OK):
-            sys.exit(f'ERROR!!! The path "{directory}" is unable to read')
-        if not os.access(directory, os.W_OK):
-            sys.exit(f'ERROR!!! The path "{directory}" is unable to write')
-    else:
-        os.makedirs(directory)
-
-    if prefix.endswith("/"):
-        sys.exit(f'ERROR!!! The prefix "{prefix}" is not allowed')
-
-    if plot == True:  # noqa: E712
-        if os.path.exists(f"{directory}/images"):
-            if not os.access(f"{directory}/images", os.R_OK):
-                sys.exit(f'ERROR!!! The path "{directory}/images" is unable to read')
-            if not os.access(f"{directory}/images", os.W_OK):
-                sys.exit(f'ERROR!!! The path "{directory}/images" is unable to write')
-        else:
-            os.makedirs(f"{directory}/images")
-        image_type = image_type.lower()
-
-    ref_refs = fasta.record_ids_indexed(reference)
-    if len(chrs_list) > 0:
-        for i in chrs_list:
-            if i not in ref_refs:
-                sys.exit(f'ERROR!!! Chromosome "{i}" provided by `--chrs` is not in the reference')
-    if len(regions_bed) > 0:
-        for i in regions_bed.keys():
-            if i not in ref_refs:
-                sys.exit(f'ERROR!!! Chromosome "{i}" provided by `--regions` is not in the reference')
-    if len(chrs_list) > 0 and len(regions_bed) > 0:
-        if not all(i in chrs_list for i in regions_bed.keys()):
-            sys.exit('ERROR!!! Chromosomes in the regions bed file are inconsistent with the provided list of '
-                     'chromosomes\nPlease read the help message use "-h" or "--help"')
-
-    def split(files):
-        bams, pafs, refs_lengths = [], [], {}
-        for file in files:
-            if file.endswith(".bam"):
-                bams.append(file)
-                h = bamfmt.read_header(file)
-                refs_lengths = {r: l for r, l in zip(h.references, h.lengths)}
-            else:
-                pafs.append(file)
-        return bams, pafs, refs_lengths
-
-    hifi_bam, hifi_paf, nano_bam, nano_paf = [], [], [], []
-    hifi_refs_lengths, nano_refs_lengths = {}, {}
-    if hifi != None:  # noqa: E711
-        hifi_bam, hifi_paf, hifi_refs_lengths = split(hifi)
-        if set(hifi_refs_lengths.keys()) != set(ref_refs):
-            sys.exit('ERROR!!! The targets in hifi alignment files are inconsistent with the reference file\n'
-                     'Please check both hifi alignment files and the reference')
-    if nano != None:  # noqa: E711
-        nano_bam, nano_paf, nano_refs_lengths = split(nano)
-        if set(nano_refs_lengths.keys()) != set(ref_refs):
-            sys.exit('ERROR!!! The targets in ont alignment files are inconsistent with the reference file\n'
-                     'Please check both ont alignment files and the reference')
-
-    print("Finding gaps ...")
-    Ns_bed, Ns_bed_file = pipeline.get_Ns_ref(reference, prefix, directory, force)
-    if Ns_bed_file != None:  # noqa: E711
-        print(f"Finding gaps done!!! The gaps are in {Ns_bed_file}\n\n")
-    else:
-        print("Finding gaps done!!! Awesome! No gaps were found!\n\n")
-
-    common = (map_qual, mq_cutoff, iden_percent, clip_percent, ovlp_percent, flank_len, directory, force)
-    hint = (-1, threshold, flank_len)          # the merge_depth() scan that follows every filter()
-    if nano == None:  # noqa: E711
-        depths, targets_length = pipeline.filter(hifi_paf, hifi_bam, prefix, *common, "HiFi", chrs_list, threads,
-                                                 issue_hint=hint)
-        depths = pipeline.merge_gaps_depths(depths, Ns_bed)
-        bed = pipeline.merge_depth(depths, prefix, threshold, flank_len, directory, force, "HiFi")
-        pipeline.compute_index(targets_length, prefix, directory, force, [bed], ["HiFi"], flank_len, dist_percent,
-                               regions_bed, [depths], threshold, chrs_list)
-        if plot == True:  # noqa: E712
-            plot_depth([depths], depth_min, depth_max, window_size, image_type, directory, prefix, force, targets_length,
-                       dist_percent, regions_bed, threshold)
-    elif hifi == None:  # noqa: E711
-        depths, targets_length = pipeline.filter(nano_paf, nano_bam, prefix, *common, "ONT", chrs_list, threads,
-                                                 issue_hint=hint)
-        depths = pipeline.merge_gaps_depths(depths, Ns_bed)
-        bed = pipeline.merge_depth(depths, prefix, threshold, flank_len, directory, force, "ONT")
-        pipeline.compute_index(targets_length, prefix, directory, force, [bed], ["Nano"], flank_len, dist_percent,
-                               regions_bed, [depths], threshold, chrs_list)
-        if plot == True:  # noqa: E712
-            plot_depth([depths], depth_min, depth_max, window_size, image_type, directory, prefix, force, targets_length,
-                       dist_percent, regions_bed, threshold)
-    else:
-        if set(hifi_refs_lengths.keys()) != set(nano_refs_lengths.keys()):
-            sys.exit('ERROR!!! The targets in hifi and nano alignment files are inconsistent\n'
-                     'Please check the reference used in mapping both hifi and ont reads')
-        for target, length in hifi_refs_lengths.items():
-            if length != nano_refs_lengths[target]:
-                sys.exit(f'ERROR!!! The element "{target}:{length}" in hifi alignment files are inconsistent with '
-                         f'that in ont alignment files which is "{target}:{nano_refs_lengths[target]}"\n'
-                         'Please check the reference used in mapping both hifi and ont reads')
-        hifi_depths, targets_length = pipeline.filter(hifi_paf, hifi_bam, prefix + "_hifi", *common, "HiFi", chrs_list,
-                                                      threads, issue_hint=hint)
-        hifi_depths = pipeline.merge_gaps_depths(hifi_depths, Ns_bed)
-        nano_depths, targets_length = pipeline.filter(nano_paf, nano_bam, prefix + "_nano", *common, "ONT", chrs_list,
-                                                      threads, issue_hint=hint)
-        nano_depths = pipeline.merge_gaps_depths(nano_depths, Ns_bed)
-        two = pipeline.merge_two_type_depth(hifi_depths, nano_depths, prefix + "_two_type", directory, force, threads)
-        two = pipeline.merge_gaps_depths(two, Ns_bed)
-        hb = pipeline.merge_depth(hifi_depths, prefix + "_hifi", threshold, flank_len, directory, force, "HiFi")
-        nb = pipeline.merge_depth(nano_depths, prefix + "_nano", threshold, flank_len, directory, force, "ONT")
-        tb = pipeline.merge_depth(two, prefix + "_two_type", threshold, flank_len, directory, force, "two_types")
-        pipeline.compute_index(targets_length, prefix, directory, force, [hb, nb, tb], ["HiFi", "Nano", "HiFi + Nano"],
-                               flank_len, dist_percent, regions_bed, [hifi_depths, nano_depths, two], threshold,
-                               chrs_list)
-        if plot == True:  # noqa: E712
-            plot_depth([hifi_depths, nano_depths], depth_min, depth_max, window_size, image_type, directory, prefix, force,
-                       targets_length, dist_percent, regions_bed, threshold)
-    print("GCI finished!!!\nBye!!!")
+# (group, flags, argparse keywords) -- GCI.py:1040-1069
+OPTIONS = (
+    ("Input/Output", ("-r", "--reference"), dict(metavar="FILE", help="The reference file")),
+    ("Input/Output", ("--hifi",), dict(nargs="+", metavar="", help="PacBio HiFi reads alignment files (at least one bam file)")),
+    ("Input/Output", ("--nano",), dict(nargs="+", metavar="", help="Oxford Nanopore long reads alignment files (at least one bam file)")),
+    ("Input/Output", ("--chrs",), dict(metavar="", help="A list of chromosomes separated by comma")),
+    ("Input/Output", ("-R", "--regions"), dict(metavar="FILE", help="Bed file containing regions\nBe cautious! If both specify `--chrs` and `--regions`, "
+                                                                    "chromosomes in regions bed file should be included in the chromosomes list")),
+    ("Input/Output", ("-ts", "--threshold"), dict(metavar="INT", type=int, default=0, help="The threshold of depth to be reported as issues [0]")),
+    ("Input/Output", ("-dp", "--dist-percent"), dict(metavar="FLOAT", type=float, default=0.005,
+                                                     help="The distance between the candidate gap intervals for combining in chromosome units [0.005]")),
+    ("Input/Output", ("-t", "--threads"), dict(metavar="INT", type=int, default=1, help="Number of threads [1]")),
+    ("Input/Output", ("-d",), dict(dest="directory", metavar="PATH", default=".", help="The directory of output files [.]")),
+    ("Input/Output", ("-o", "--output"), dict(dest="prefix", metavar="STR", default="GCI", help="Prefix of output files [GCI]")),
+    ("Filter Options", ("-mq", "--map-qual"), dict(metavar="INT", type=int, default=30, help="Minium mapping quality for alignments [30]")),
+    ("Filter Options", ("--mq-cutoff",), dict(metavar="INT", type=int, default=50,
+                                              help="The cutoff of mapping quality for keeping the alignment [50]\n"
+                                                   "(only used when inputting more than one alignment files)")),
+    ("Filter Options", ("-ip", "--iden-percent"), dict(metavar="FLOAT", type=float, default=0.9,
+                                                       help="Minimum identity (num_match_res/len_aln) of alignments [0.9]")),
+    ("Filter Options", ("-op", "--ovlp-percent"), dict(metavar="FLOAT", type=float, default=0.9,
+                                                       help="Minimum overlapping percentage of the same read alignment if inputting more than one alignment files [0.9]")),
+    ("Filter Options", ("-cp", "--clip-percent"), dict(metavar="FLOAT", type=float, default=0.1, help="Maximum clipped percentage of the alignment [0.1]")),
+    ("Filter Options", ("-fl", "--flank-len"), dict(metavar="INT", type=int, default=15, help="The flanking length of the clipped bases [15]")),
+    ("Plot Options", ("-p", "--plot"), dict(action="store_const", const=True, default=False,
+                                            help="Visualize the finally filtered whole genome (and regions if providing the option `-R`) depth [False]")),
+    ("Plot Options", ("-dmin", "--depth-min"), dict(metavar="FLOAT", type=float, default=0.1, help="Minimum depth in folds of mean coverage for plotting [0.1]")),
+    ("Plot Options", ("-dmax", "--depth-max"), dict(metavar="FLOAT", type=float, default=4.0, help="Maximum depth in folds of mean coverage for plotting [4.0]")),
+    ("Plot Options", ("-ws", "--window-size"), dict(metavar="INT", type=int, default=50000, help="The window size when plotting [50000]")),
+    ("Plot Options", ("-it", "--image-type"), dict(metavar="STR", default="png", help="The format of the output images: png or pdf [png]")),
+    ("Other Options", ("-f", "--force"), dict(action="store_const", const=True, default=False, help="Force rewriting of existing files [False]")),
+    ("Other Options", ("-h", "--help"), dict(action="help", help="Show this help message and exit")),
+    ("Other Options", ("-v", "--version"), dict(action="version", version=VERSION, help="Show program's version number and exit")),
+)
 
 
 def build_parser(prog: str) -> argparse.ArgumentParser:
@@ -159,70 +67,163 @@ def build_parser(prog: str) -> argparse.ArgumentParser:
                                      description="A program for assessing the T2T genome",
                                      epilog="Examples:\npython GCI.py -r ref.fa --hifi hifi.bam hifi.paf ... "
                                             "--nano nano.bam nano.paf ...")
-    io = parser.add_argument_group("Input/Output")
-    io.add_argument("-r", "--reference", metavar="FILE", help="The reference file")
-    io.add_argument("--hifi", nargs="+", metavar="", help="PacBio HiFi reads alignment files (at least one bam file)")
-    io.add_argument("--nano", nargs="+", metavar="",
-                    help="Oxford Nanopore long reads alignment files (at least one bam file)")
-    io.add_argument("--chrs", metavar="", help="A list of chromosomes separated by comma")
-    io.add_argument("-R", "--regions", metavar="FILE",
-                    help="Bed file containing regions\nBe cautious! If both specify `--chrs` and `--regions`, "
-                         "chromosomes in regions bed file should be included in the chromosomes list")
-    io.add_argument("-ts", "--threshold", metavar="INT", type=int,
-                    help="The threshold of depth to be reported as issues [0]", default=0)
-    io.add_argument("-dp", "--dist-percent", metavar="FLOAT", type=float,
-                    help="The distance between the candidate gap intervals for combining in chromosome units [0.005]",
-                    default=0.005)
-    io.add_argument("-t", "--threads", metavar="INT", type=int, help="Number of threads [1]", default=1)
-    io.add_argument("-d", dest="directory", metavar="PATH", help="The directory of output files [.]", default=".")
-    io.add_argument("-o", "--output", dest="prefix", metavar="STR", help="Prefix of output files [GCI]", default="GCI")
-    fo = parser.add_argument_group("Filter Options")
-    fo.add_argument("-mq", "--map-qual", metavar="INT", type=int, help="Minium mapping quality for alignments [30]",
-                    default=30)
-    fo.add_argument("--mq-cutoff", metavar="INT", type=int,
-                    help="The cutoff of mapping quality for keeping the alignment [50]\n"
-                         "(only used when inputting more than one alignment files)", default=50)
-    fo.add_argument("-ip", "--iden-percent", metavar="FLOAT", type=float,
-                    help="Minimum identity (num_match_res/len_aln) of alignments [0.9]", default=0.9)
-    fo.add_argument("-op", "--ovlp-percent", metavar="FLOAT", type=float,
-                    help="Minimum overlapping percentage of the same read alignment if inputting more than one "
-                         "alignment files [0.9]", default=0.9)
-    fo.add_argument("-cp", "--clip-percent", metavar="FLOAT", type=float,
-                    help="Maximum clipped percentage of the alignment [0.1]", default=0.1)
-    fo.add_argument("-fl", "--flank-len", metavar="INT", type=int,
-                    help="The flanking length of the clipped bases [15]", default=15)
-    po = parser.add_argument_group("Plot Options")
-    po.add_argument("-p", "--plot", action="store_const", const=True, default=False,
-                    help="Visualize the finally filtered whole genome (and regions if providing the option `-R`) "
-                         "depth [False]")
-    po.add_argument("-dmin", "--depth-min", metavar="FLOAT", type=float,
-                    help="Minimum depth in folds of mean coverage for plotting [0.1]", default=0.1)
-    po.add_argument("-dmax", "--depth-max", metavar="FLOAT", type=float,
-                    help="Maximum depth in folds of mean coverage for plotting [4.0]", default=4.0)
-    po.add_argument("-ws", "--window-size", metavar="INT", type=int, help="The window size when plotting [50000]",
-                    default=50000)
-    po.add_argument("-it", "--image-type", metavar="STR", help="The format of the output images: png or pdf [png]",
-                    default="png")
-    op = parser.add_argument_group("Other Options")
-    op.add_argument("-f", "--force", action="store_const", const=True, default=False,
-                    help="Force rewriting of existing files [False]")
-    op.add_argument("-h", "--help", action="help", help="Show this help message and exit")
-    op.add_argument("-v", "--version", action="version", version=VERSION,
-                    help="Show program's version number and exit")
+    groups: Dict[str, argparse._ArgumentGroup] = {}
+    for group, flags, kw in OPTIONS:
+        if group not in groups:
+            groups[group] = parser.add_argument_group(group)
+        groups[group].add_argument(*flags, **kw)
     return parser
 
 
-def _check_inputs(files, what):
-    bam_num = 0
-    for file in files:
-        if os.path.exists(file) and os.access(file, os.R_OK):
-            if file.endswith(".bam"):
-                bam_num += 1
-        else:
-            sys.exit(f'ERROR!!! "{file}" is not an available file')
-    if bam_num == 0:
-        sys.exit(f'ERROR!!! Please input at least one {what} bam file\n'
-                 'Please read the help message use "-h" or "--help"')
+def _die(message: str):
+    sys.exit("ERROR!!! " + message)
+
+
+def _readable(path: str) -> bool:
+    return os.path.exists(path) and os.access(path, os.R_OK)
+
+
+# ---- one read type of a run ---------------------------------------------------------------------------------------
+
+@dataclass
+class ReadType:
+    """The alignment files of one read type as the command line gave them (GCI.py:963-986)."""
+    log_name: str                  # "HiFi" / "ONT": the word filter() and merge_depth() print
+    index_name: str                # "HiFi" / "Nano": the label in the .gci file
+    suffix: str                    # "_hifi" / "_nano" in two-type runs
+    complaint: str                 # "hifi" / "ont" in the header-mismatch message
+    files: Optional[Sequence[str]] = None
+    bams: List[str] = field(default_factory=list)
+    pafs: List[str] = field(default_factory=list)
+    refs_lengths: Dict[str, int] = field(default_factory=dict)      # of the LAST BAM listed, as in the reference
+
+    @property
+    def given(self) -> bool:
+        return self.files is not None
+
+    def read_headers(self, ref_ids: Sequence[str]) -> None:
+        for path in self.files:
+            if path.endswith(".bam"):
+                self.bams.append(path)
+                h = bamfmt.read_header(path)
+                self.refs_lengths = dict(zip(h.references, h.lengths))
+            else:
+                self.pafs.append(path)
+        if set(self.refs_lengths) != set(ref_ids):
+            _die(f"The targets in {self.complaint} alignment files are inconsistent with the reference file\n"
+                 f"Please check both {self.complaint} alignment files and the reference")
+
+
+def _load_regions(path: Optional[str]) -> Dict[str, List[Tuple[int, int]]]:
+    regions: Dict[str, List[Tuple[int, int]]] = {}
+    if path is None:
+        return regions
+    if not _readable(path):
+        _die(f'"{path}" is not an available file')
+    with open(path, "r") as f:
+        for line in f:
+            target, start, end = line.strip().split("\t")
+            regions.setdefault(target, []).append((int(start), int(end)))
+    return regions
+
+
+def _usable_directory(path: str) -> None:
+    """Exists (created if not) and is readable and writable."""
+    if not os.path.exists(path):
+        os.makedirs(path)
+        return
+    for mode, word in ((os.R_OK, "read"), (os.W_OK, "write")):
+        if not os.access(path, mode):
+            _die(f'The path "{path}" is unable to {word}')
+
+
+def _check_names(ref_ids: Sequence[str], chrs_list: Sequence[str], regions: Dict[str, list]) -> None:
+    for option, names in (("--chrs", chrs_list), ("--regions", list(regions))):
+        for name in names:
+            if name not in ref_ids:
+                _die(f'Chromosome "{name}" provided by `{option}` is not in the reference')
+    if chrs_list and regions and not all(name in chrs_list for name in regions):
+        _die("Chromosomes in the regions bed file are inconsistent with the provided list of chromosomes\n" + HELP_HINT)
+
+
+def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50, iden_percent=0.9, ovlp_percent=0.9,
+        clip_percent=0.1, flank_len=15, threshold=0, plot=False, depth_min=0.1, depth_max=4.0, window_size=50000,
+        image_type="png", force=False, dist_percent=0.005, reference=None, regions=None, chrs=None, threads=1):
+    """Same signature, checks (in the same order) and outputs as the reference's GCI() (GCI.py:897-1028)."""
+    chrs_list = chrs.strip().split(",") if chrs is not None else []
+    regions_bed = _load_regions(regions)
+    if directory.endswith("/"):
+        directory = directory.rsplit("/", 1)[0]
+    _usable_directory(directory)
+    if prefix.endswith("/"):
+        _die(f'The prefix "{prefix}" is not allowed')
+    if plot:
+        _usable_directory(f"{directory}/images")
+        image_type = image_type.lower()
+
+    ref_ids = fasta.record_ids_indexed(reference)
+    _check_names(ref_ids, chrs_list, regions_bed)
+    kinds = [ReadType("HiFi", "HiFi", "_hifi", "hifi", hifi), ReadType("ONT", "Nano", "_nano", "ont", nano)]
+    for kind in kinds:
+        if kind.given:
+            kind.read_headers(ref_ids)
+
+    print("Finding gaps ...")
+    Ns_bed, Ns_bed_file = pipeline.get_Ns_ref(reference, prefix, directory, force)
+    if Ns_bed_file is not None:
+        print(f"Finding gaps done!!! The gaps are in {Ns_bed_file}\n\n")
+    else:
+        print("Finding gaps done!!! Awesome! No gaps were found!\n\n")
+
+    given = [k for k in kinds if k.given]
+    both = len(given) == 2
+    if both:
+        h, n = kinds
+        if set(h.refs_lengths) != set(n.refs_lengths):
+            _die("The targets in hifi and nano alignment files are inconsistent\n"
+                 "Please check the reference used in mapping both hifi and ont reads")
+        for target, length in h.refs_lengths.items():
+            if length != n.refs_lengths[target]:
+                _die(f'The element "{target}:{length}" in hifi alignment files are inconsistent with that in ont alignment '
+                     f'files which is "{target}:{n.refs_lengths[target]}"\n'
+                     "Please check the reference used in mapping both hifi and ont reads")
+
+    # every filter() is followed by the merge_depth() scan with these bounds: its run boundaries come out of the build
+    hint = (-1, threshold, flank_len)
+    tracks, prefixes, logs, labels = [], [], [], []
+    targets_length = None
+    for kind in given:                                               # filter + gap mask per read type (GCI.py:991-1016)
+        pfx = prefix + kind.suffix if both else prefix
+        depths, targets_length = pipeline.filter(kind.pafs, kind.bams, pfx, map_qual, mq_cutoff, iden_percent, clip_percent,
+                                                 ovlp_percent, flank_len, directory, force, kind.log_name, chrs_list, threads,
+                                                 issue_hint=hint)
+        tracks.append(pipeline.merge_gaps_depths(depths, Ns_bed))
+        prefixes.append(pfx)
+        logs.append(kind.log_name)
+        labels.append(kind.index_name)
+    plotted = list(tracks)
+    if both:                                                         # per-base maximum of the two masked tracks
+        two = pipeline.merge_two_type_depth(tracks[0], tracks[1], prefix + "_two_type", directory, force, threads)
+        tracks.append(pipeline.merge_gaps_depths(two, Ns_bed))
+        prefixes.append(prefix + "_two_type")
+        logs.append("two_types")
+        labels.append("HiFi + Nano")
+    beds = [pipeline.merge_depth(t, p, threshold, flank_len, directory, force, log) for t, p, log in zip(tracks, prefixes, logs)]
+    pipeline.compute_index(targets_length, prefix, directory, force, beds, labels, flank_len, dist_percent, regions_bed, tracks,
+                           threshold, chrs_list)
+    if plot:
+        plot_depth(plotted, depth_min, depth_max, window_size, image_type, directory, prefix, force, targets_length,
+                   dist_percent, regions_bed, threshold)
+    print("GCI finished!!!\nBye!!!")
+
+
+def _check_files(files: Sequence[str], what: str) -> None:
+    """Every listed file readable, at least one of them a BAM (GCI.py:1079-1099)."""
+    for path in files:
+        if not _readable(path):
+            _die(f'"{path}" is not an available file')
+    if not any(path.endswith(".bam") for path in files):
+        _die(f"Please input at least one {what} bam file\n" + HELP_HINT)
 
 
 def main(argv=None):
@@ -232,21 +233,19 @@ def main(argv=None):
     if len(argv) == 1:
         parser.print_help()
         sys.exit()
-    if (args["hifi"] == None) and (args["nano"] == None):  # noqa: E711
-        sys.exit('ERROR!!! Please input at least one type of TGS reads alignment files (PacBio HiFi and/or Oxford '
-                 'Nanopore long reads)\nPlease read the help message use "-h" or "--help"')
-    if args["hifi"] != None:  # noqa: E711
-        _check_inputs(args["hifi"], "PacBio HiFi reads")
-    if args["nano"] != None:  # noqa: E711
-        _check_inputs(args["nano"], "Oxford Nanopore long reads")
-    if args["reference"] == None:  # noqa: E711
-        sys.exit('ERROR!!! Please input the reference file\nPlease read the help message use "-h" or "--help"')
-    elif not (os.path.exists(args["reference"]) and os.access(args["reference"], os.R_OK)):
-        sys.exit(f'ERROR!!! "{args["reference"]}" is not an available file')
+    if args["hifi"] is None and args["nano"] is None:
+        _die("Please input at least one type of TGS reads alignment files (PacBio HiFi and/or Oxford Nanopore long "
+             "reads)\n" + HELP_HINT)
+    for key, what in (("hifi", "PacBio HiFi reads"), ("nano", "Oxford Nanopore long reads")):
+        if args[key] is not None:
+            _check_files(args[key], what)
+    if args["reference"] is None:
+        _die("Please input the reference file\n" + HELP_HINT)
+    if not _readable(args["reference"]):
+        _die(f'"{args["reference"]}" is not an available file')
     if args["map_qual"] > args["mq_cutoff"]:
         print(f'WARNING!!! The minium mapping quality ({args["map_qual"]}) is higher than the cutoff '
-              f'({args["mq_cutoff"]}), which means that wouldn\'t filter any reads\n'
-              'Please read the help message use "-h" or "--help"', file=sys.stderr)
+              f'({args["mq_cutoff"]}), which means that wouldn\'t filter any reads\n' + HELP_HINT, file=sys.stderr)
     print(f"Used arguments:{args}")
     GCI(**args)
 

@@ -295,7 +295,7 @@ class Engine:
     def depth_build_fused(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
                           want_text: bool = True, want_sums: bool = False,
                           issue: Optional[Tuple[float, float, int]] = None, max_n: Optional[int] = None,
-                          counted: bool = False):
+                          counted: bool = False, key_cap: int = 1 << 16):
         """Depth build that also returns what the reference derives from the fresh depths, computed in
         the same pass (no re-read of the track): decimal text, per-contig sums and -- only valid when
         no gap mask follows -- the raw issue runs for (lo, hi, flank).
@@ -312,7 +312,7 @@ class Engine:
         sums = torch.zeros(max(nc, 1), dtype=torch.int64, device=self.device) if want_sums else None
         o.d_contig_text_off = text_off.data_ptr() if want_text else None
         o.d_sums = sums.data_ptr() if want_sums else None
-        cap = 1 << 16
+        cap = int(key_cap)                                 # grown (and the first pass repeated) when more run boundaries turn up
         keys = None
         while True:
             if issue is not None:

@@ -158,10 +158,12 @@ def n_runs_device(engine, path: str) -> Tuple[List[str], Dict[str, List[Tuple[in
 
     runs: Dict[str, List[Tuple[int, int]]] = {}
     rec_of = np.searchsorted(bodies[:, 0], (keys >> np.uint64(1)).astype(np.int64), side="right") - 1
-    for r, (rid, b, e) in enumerate(spans):
-        mine = keys[rec_of == r]
-        if mine.shape[0] == 0:
-            continue
+    # keys are sorted by byte offset, hence grouped by record: one cut per record (not one mask over all keys per record),
+    # and only the records that hold a run are visited
+    cut = np.searchsorted(rec_of, np.arange(len(spans) + 1))
+    for r in np.unique(rec_of).tolist():
+        rid, b, e = spans[r]
+        mine = keys[cut[r]:cut[r + 1]]
         base = coord(b, r)
         pos = [coord(int(k >> np.uint64(1)), r) - base for k in mine]
         if len(pos) & 1:                                   # the run reaches the end of the record

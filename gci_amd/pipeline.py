@@ -247,6 +247,10 @@ def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
     return engine.to_device(stream), engine.to_device(offs), hdr
 
 
+# Every BGZF member's CRC-32 is verified while inflating, as htslib does (a corrupted block that still inflates to the
+# right size must not pass silently); GCI_BGZF_CRC=0 skips the check.
+BGZF_CRC = os.environ.get("GCI_BGZF_CRC", "1") != "0"
+
 # A BAM whose inflated stream exceeds this many bytes is streamed through the GPU chunk by chunk (K1 per chunk,
 # compact records + packed names kept, SEQ/QUAL bytes dropped): real 40x whole-genome BAMs inflate to hundreds of GB.
 BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
@@ -282,7 +286,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
 
     if ingest == "heads":
         try:
-            heads = hostio.bam_heads(np.asarray(raw), threads=nthreads)
+            heads = hostio.bam_heads(np.asarray(raw), threads=nthreads, check_crc=BGZF_CRC)
         except GciError as e:
             if e.status != _lib.GCI_E_NOMEM:
                 raise
@@ -296,7 +300,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
 
     pos, isz = hostio.bgzf_blocks(np.asarray(raw))
     if int(isz.sum()) <= chunk_bytes:
-        stream = hostio.bgzf_inflate(np.asarray(raw), threads=nthreads)
+        stream = hostio.bgzf_inflate(np.asarray(raw), threads=nthreads, check_crc=BGZF_CRC)
         hdr = bamfmt.parse_header(stream)
         offs, _ = hostio.bam_record_offsets(stream)
         d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
@@ -314,7 +318,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
 
     def inflate(g):
         lo, hi = g
-        return hostio.bgzf_inflate(np.asarray(raw[int(pos[lo]):int(pos[hi])]), threads=nthreads)
+        return hostio.bgzf_inflate(np.asarray(raw[int(pos[lo]):int(pos[hi])]), threads=nthreads, check_crc=BGZF_CRC)
 
     rec_parts, name_parts, off_parts = [], [], []
     carry = np.zeros(0, dtype=np.uint8)
@@ -390,7 +394,7 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     if len(paf_files) != 0:
         from . import hostio
         try:
-            native = hostio.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
+            native = hostio.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent, threads=hostio.pick_threads(threads))
         except GciError as e:
             _reraise_like_reference(e)
         for recs, names, off in native:                       # compact records + names, as K1 makes them from a BAM
@@ -457,7 +461,9 @@ def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
     if os.path.exists(path):
         os.remove(path)
     with open(path, "wb") as f:
-        for t, blob in zip(depths.targets, blobs):
+        for t, L, blob in zip(depths.targets, depths.lengths, blobs):
+            if L == 0:
+                continue              # the reference's chunk loop never runs for an empty contig: not even the '>' line
             f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
             f.write(blob)
 
@@ -473,6 +479,8 @@ def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, thread
     nthreads = hostio.pick_threads(threads)
     with open(path, "wb") as f:
         for c, t in enumerate(depths.targets):
+            if depths.lengths[c] == 0:
+                continue              # (as above)
             f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
             f.write(hostio.gzip_members(host[int(offs[c]):int(offs[c + 1])], threads=nthreads))
 
@@ -660,15 +668,18 @@ def compute_index(targets_length={}, prefix="GCI", directory=".", force=False, m
     if len(regions_bed) > 0:
         if os.path.exists(reg_path) and force == False:  # noqa: E712
             sys.exit(f'ERROR!!! The file "{reg_path}" exists\nPlease use "-f" or "--force" to rewrite')
+    # progress lines are printed where the work happens (same lines, same order as GCI.py:553-607)
     print("Computing Theoretical minimum N50 and contigs number ...")
+    rows, exp_n50, exp_ctg = score.expected_table(targets_length, chrs_list)
     print("Computing Theoretical minimum N50 and contigs number done!!!")
-    for t in type_list:
+    for t, bed in zip(type_list, merged_depths_bed_list):
         print(f"Computing Curated N50 and contigs number for {t} ...")
+        obs_n50, obs_ctg = score.curated_table(bed, targets_length, flank_len, dist_percent, rows[-1])
         print(f"Computing Curated N50 and contigs number for {t} done!!!")
         print(f"Writing results to {gci_path} ...")
+        with open(gci_path, "a") as f:
+            f.write(score.section_text(t, rows, exp_n50, exp_ctg, obs_n50, obs_ctg))
         print(f"Writing results to {gci_path} done!!!\n\n")
-    with open(gci_path, "w") as f:
-        f.write(score.index_text(targets_length, merged_depths_bed_list, type_list, flank_len, dist_percent, chrs_list))
     if len(regions_bed) > 0:
         print("Computing GCI scores for regions ...")
         flat = [(t, s, e) for t, segs in regions_bed.items() for s, e in segs]

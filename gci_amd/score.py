@@ -93,30 +93,49 @@ def gci_score(obs_n50, exp_n50, obs_num_ctg, exp_num_ctg):
     return round(100 * log2(obs_n50 / exp_n50 + 1) / log2(obs_num_ctg / exp_num_ctg + 1), 4)
 
 
-def index_text(targets_length: Dict[str, int], merged_depths_bed_list: Sequence[Bed], type_list: Sequence[str],
-               flank_len: int = 15, dist_percent: float = 0.005, chrs_list: Sequence[str] = ()) -> str:
-    """The `.gci` file body (GCI.py:553-607)."""
+def expected_table(targets_length: Dict[str, int], chrs_list: Sequence[str] = ()):
+    """GCI.py:553-565: per contig the theoretical maximum N50 (its length) and contig count (1), plus the genome row
+    ('Genome', or 'All_chromosomes' with --chrs).  -> (row labels, exp_n50, exp_ctg)"""
     genome = "Genome" if len(chrs_list) == 0 else "All_chromosomes"
     rows = list(targets_length.keys()) + [genome]
     exp_n50 = dict(targets_length)
     exp_n50[genome] = compute_n50(list(targets_length.values()))
     exp_ctg = {t: 1 for t in targets_length}
     exp_ctg[genome] = len(targets_length)
+    return rows, exp_n50, exp_ctg
+
+
+def curated_table(bed: Bed, targets_length: Dict[str, int], flank_len: int, dist_percent: float, genome: str):
+    """GCI.py:568-588: curated N50 from the complement of the issues as they are, curated contig count from the
+    complement of the dp-merged issues.  -> (obs_n50, obs_ctg), both with the genome row."""
+    free = complement_merged_depth(bed, targets_length, flank_len)
+    obs_n50 = {t: compute_n50(v) for t, v in free.items()}
+    obs_n50[genome] = compute_n50([x for v in free.values() for x in v])
+    merged = merge_merged_depth_bed(bed, targets_length, dist_percent, flank_len)
+    free2 = complement_merged_depth(merged, targets_length, flank_len)
+    obs_ctg = {t: len(v) for t, v in free2.items()}
+    obs_ctg[genome] = sum(len(v) for v in free2.values())
+    return obs_n50, obs_ctg
+
+
+def section_text(label: str, rows: Sequence[str], exp_n50, exp_ctg, obs_n50, obs_ctg) -> str:
+    """One read type's block of the `.gci` file (GCI.py:592-606)."""
+    parts = [f"{label}:\n", GCI_COLUMNS]
+    for t in rows:
+        parts.append(f"{t}\t{exp_n50[t]}\t{obs_n50[t]}\t{exp_ctg[t]}\t{obs_ctg[t]}\t"
+                     f"{gci_score(obs_n50[t], exp_n50[t], obs_ctg[t], exp_ctg[t])}\n")
+    parts.append(RULE)
+    return "".join(parts)
+
+
+def index_text(targets_length: Dict[str, int], merged_depths_bed_list: Sequence[Bed], type_list: Sequence[str],
+               flank_len: int = 15, dist_percent: float = 0.005, chrs_list: Sequence[str] = ()) -> str:
+    """The `.gci` file body (GCI.py:553-607)."""
+    rows, exp_n50, exp_ctg = expected_table(targets_length, chrs_list)
     parts: List[str] = []
     for label, bed in zip(type_list, merged_depths_bed_list):
-        free = complement_merged_depth(bed, targets_length, flank_len)
-        obs_n50 = {t: compute_n50(v) for t, v in free.items()}
-        obs_n50[genome] = compute_n50([x for v in free.values() for x in v])
-        merged = merge_merged_depth_bed(bed, targets_length, dist_percent, flank_len)
-        free2 = complement_merged_depth(merged, targets_length, flank_len)
-        obs_ctg = {t: len(v) for t, v in free2.items()}
-        obs_ctg[genome] = sum(len(v) for v in free2.values())
-        parts.append(f"{label}:\n")
-        parts.append(GCI_COLUMNS)
-        for t in rows:
-            parts.append(f"{t}\t{exp_n50[t]}\t{obs_n50[t]}\t{exp_ctg[t]}\t{obs_ctg[t]}\t"
-                         f"{gci_score(obs_n50[t], exp_n50[t], obs_ctg[t], exp_ctg[t])}\n")
-        parts.append(RULE)
+        obs_n50, obs_ctg = curated_table(bed, targets_length, flank_len, dist_percent, rows[-1])
+        parts.append(section_text(label, rows, exp_n50, exp_ctg, obs_n50, obs_ctg))
     return "".join(parts)
 
 

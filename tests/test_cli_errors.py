@@ -1,0 +1,53 @@
+"""R14: the command line's refusals, warnings and exit behaviour against transcripts of the UNMODIFIED reference run
+through its own `__main__` block (tests/golden/cli_errors.json, tools/make_golden.py::case_cli_errors): exit message or
+code, stdout and stderr of every scenario.  Everything that is refused before the first GPU call runs on the CPU; the
+scenarios that get as far as the pipeline are marked gpu."""
+import io
+import json
+import os
+import contextlib
+
+import pytest
+
+from golden_util import GOLDEN
+
+SCENARIOS = json.load(open(os.path.join(GOLDEN, "cli_errors.json")))
+INPUTS = os.path.join(GOLDEN, "cli_errors", "inputs")
+NEEDS_GPU = {"hifi_nano_lengths_differ", "mapq_warning_then_runs", "refuses_to_overwrite_depth", "refuses_to_overwrite_gaps", "refuses_to_overwrite_gaps_again"}
+
+
+def run_scenario(sc, out_root, monkeypatch):
+    from gci_amd import cli
+    monkeypatch.setenv("COLUMNS", "100")
+    sub = lambda t: t.replace("{IN}", INPUTS).replace("{OUT}", out_root)       # noqa: E731
+    norm = lambda t: t.replace(out_root, "{OUT}").replace(INPUTS, "{IN}")      # noqa: E731
+    so, se = io.StringIO(), io.StringIO()
+    code = "completed"
+    try:
+        with contextlib.redirect_stdout(so), contextlib.redirect_stderr(se):
+            cli.main(["GCI.py"] + [sub(a) for a in sc["argv"]])
+    except SystemExit as e:
+        code = e.code
+    got = {"exit": norm(code) if isinstance(code, str) else code, "stdout": norm(so.getvalue()), "stderr": norm(se.getvalue())}
+    want = {k: sc[k] for k in ("exit", "stdout", "stderr")}
+    assert got == want, sc["name"]
+
+
+@pytest.mark.parametrize("sc", [s for s in SCENARIOS if s["name"] not in NEEDS_GPU], ids=lambda s: s["name"])
+def test_refused_before_any_gpu_work(sc, tmp_path, monkeypatch):
+    run_scenario(sc, str(tmp_path / "out"), monkeypatch)
+    if "-d" in sc["argv"] and sc["name"] not in ("regions_missing",):
+        # the reference creates the output directory before it looks at the prefix / the reference (GCI.py:914-923)
+        assert os.path.isdir(str(tmp_path / "out"))
+
+
+@pytest.mark.gpu
+def test_warning_and_overwrite_guards(engine, tmp_path, monkeypatch):
+    from gci_amd import pipeline
+    pipeline._ENGINE = engine
+    ran = 0
+    for sc in SCENARIOS:                       # in file order: the overwrite scenarios re-use the directory of the run before
+        if sc["name"] in NEEDS_GPU:            # (hifi_nano_lengths_differ is refused after the gap scan, which runs on the GPU)
+            run_scenario(sc, str(tmp_path / "out"), monkeypatch)
+            ran += 1
+    assert ran == len(NEEDS_GPU)

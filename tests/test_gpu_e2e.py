@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, GOLDEN, cli_args, expected, images, read_outputs
+from golden_util import CASES, GOLDEN, cli_args, expected, images, manifest, read_outputs
 from gci_amd import pipeline, synth
 from gci_amd._lib import GciError
 from gci_amd.device import JoinInput, REC_DTYPE
@@ -32,8 +32,12 @@ def test_cli_reproduces_reference_files(engine, case, tmp_path, capsys):
     assert sorted(got_img) == sorted(want_img)
     for fn in want_img:
         assert got_img[fn].shape == want_img[fn].shape and np.array_equal(got_img[fn], want_img[fn]), fn
+    # R14: the transcript of GCI() equals the reference's (first line = main()'s echo of the arguments)
     stdout = capsys.readouterr().out
-    assert stdout.rstrip().endswith("GCI finished!!!\nBye!!!")
+    first, _, rest = stdout.partition("\n")
+    assert first.startswith("Used arguments:{")
+    inp = os.path.join(GOLDEN, case, "inputs")
+    assert rest.replace(out, "{OUT}").replace(inp, "{IN}") == manifest(case)["stdout"]
     # refuses to overwrite without -f, like the reference
     with pytest.raises(SystemExit) as e:
         cli.main(cli_args(case, out))

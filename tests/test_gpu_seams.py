@@ -803,3 +803,52 @@ def test_partitioned_join_bucket_overflow_falls_back(engine, monkeypatch):
     assert e.value.status == _lib.GCI_E_CAPACITY
     ivl, cnt = engine.name_join([one], 0.9)
     assert sorted(map(tuple, ivl[:int(cnt.item()), :3].cpu().numpy().tolist())) == [(0, i, i + 50) for i in range(n)]
+
+
+@pytest.mark.parametrize("counted", [False, True])
+def test_fused_build_grows_the_issue_key_buffer(engine, oracle, counted):
+    """More issue-run boundaries than the key buffer holds (a fragmented, low-coverage assembly): depth_build_fused
+    grows the buffer and runs its first pass again -- after a counting join, too, whose per-tile counts the first
+    attempt has used up.  Depth, sums, text and runs must come out as from the oracle."""
+    L = 400_000
+    contigs = (("frag", L), ("tail", 30_000))
+    lengths = [l for _, l in contigs]
+    engine.set_layout(lengths)
+    rng = np.random.default_rng(909)
+    starts = np.sort(rng.choice(np.arange(0, L - 400, 700), size=500, replace=False))     # 500 short reads: ~1000 boundaries
+    ivl_np = np.zeros((starts.shape[0], 4), dtype=np.int32)
+    ivl_np[:, 1], ivl_np[:, 2] = starts, starts + rng.integers(100, 600, starts.shape[0])
+    want = oracle.depth_build_py([("frag", int(s), int(e)) for _, s, e, _ in ivl_np.tolist()], dict(contigs), 15)
+    bed = oracle.collapse_depth_range(want, -1, 0, 15, 0)
+    assert len(bed["frag"]) > 300
+    if counted:
+        names = [b"r%05d" % i for i in range(ivl_np.shape[0])]
+        one = _forged_input(engine, names, name_hash_np(names), ivl_np[:, 0], ivl_np[:, 1], ivl_np[:, 2],
+                            np.full(len(names), 500), np.zeros(len(names)))
+        ivl, cnt = engine.name_join([one], 0.9, count_flank=15)
+    else:
+        ivl, cnt = engine.to_device(ivl_np), None
+    track = engine.new_track()
+    out = engine.depth_build_fused(ivl, cnt, 15, track, want_text=True, want_sums=True, issue=(-1, 0, 15), counted=counted,
+                                   key_cap=64)
+    tr = pipeline.DepthTracks(engine, dict(contigs), track)
+    for t in ("frag", "tail"):
+        assert np.array_equal(tr[t], want[t]), t
+    assert out["sums"].tolist() == [int(want[t].sum()) for t in ("frag", "tail")]
+    assert out["text"].cpu().numpy().tobytes() == b"".join(oracle.depth_text_contig(want[t]) for t in ("frag", "tail"))
+    got = {t: pipeline._issues_from_runs(out["runs"][c], lengths[c] - 30, lengths[c], 15, 0) for c, t in enumerate(("frag", "tail"))}
+    assert got == bed
+
+
+def test_depth_gz_skips_zero_length_contigs(engine, tmp_path):
+    """write_depth (GCI.py:99-143) writes nothing at all for a contig of length 0 -- its chunk loop never runs, so not
+    even the '>' line appears."""
+    import gzip
+    lengths = {"a": 5000, "empty": 0, "b": 4100}
+    engine.set_layout(list(lengths.values()))
+    track = engine.new_track()
+    track.zero_()
+    tr = pipeline.DepthTracks(engine, lengths, track)
+    pipeline.write_depth(str(tmp_path), "z", tr, 1)
+    text = gzip.open(str(tmp_path / "z.depth.gz"), "rb").read()
+    assert text == b">a\n" + b"0\n" * 5000 + b">b\n" + b"0\n" * 4100

@@ -69,8 +69,10 @@ def run_reference(case, args, hifi=None, nano=None, regions=False):
     out = io.StringIO()
     with contextlib.redirect_stdout(out):
         ref.GCI(**kw)
+    # R14: what GCI() printed, with the two directories that differ between runs replaced by placeholders
+    transcript = out.getvalue().replace(tmp, "{OUT}").replace(inp, "{IN}")
     manifest = {"args": {k: v for k, v in args.items()}, "hifi": hifi, "nano": nano, "regions": bool(regions),
-                "files": {}}
+                "files": {}, "stdout": transcript}
     for fn in sorted(os.listdir(tmp)):
         src = os.path.join(tmp, fn)
         if not os.path.isfile(src):
@@ -348,6 +350,95 @@ def case_plot():
     print("plot ->", sorted(os.listdir(os.path.join(out, "images"))))
 
 
+def case_cli_errors():
+    """R14: the reference's command line on inputs it refuses (and a few it accepts with a warning), run through its own
+    `__main__` block: exit message / code, stdout and stderr of every scenario -> tests/golden/cli_errors.json.
+    Inputs: tests/golden/cli_errors/inputs (tiny two-contig BAMs, a PAF, FASTA files with and without the BAMs' contigs,
+    BED files).  Not covered: the unreadable / unwritable directory exits (GCI.py:917-920, 929-932) -- the build
+    container runs as root, for which os.access() is always true."""
+    load_reference.load()                                  # puts the pysam / Bio stand-ins on sys.path
+    base = os.path.join(GOLDEN, "cli_errors")
+    inp = os.path.join(base, "inputs")
+    shutil.rmtree(base, ignore_errors=True)
+    os.makedirs(inp)
+    contigs = (("e1", 30_000), ("e2", 12_000))
+    h = synth.simulate_reads(contigs, 8, "hifi", seed=synth.seed_for(7, 0))
+    n = synth.simulate_reads(contigs, 8, "ont", seed=synth.seed_for(7, 1), long_cigar_frac=0.0)
+    n_short = synth.simulate_reads((("e1", 30_000), ("e2", 11_000)), 8, "ont", seed=synth.seed_for(7, 2), long_cigar_frac=0.0)
+    synth.write_bam_file(os.path.join(inp, "hifi.bam"), h, level=9, threads=2)
+    synth.write_bam_file(os.path.join(inp, "ont.bam"), n, level=9, threads=2)
+    synth.write_bam_file(os.path.join(inp, "ont_e2_short.bam"), n_short, level=9, threads=2)
+    paffmt.write(os.path.join(inp, "hifi.paf"), synth.to_paf_lines(h, synth.seed_for(7, 3), 0.05))
+    for fn in os.listdir(inp):
+        if fn.endswith(".bai"):
+            os.remove(os.path.join(inp, fn))
+    synth.write_reference_fasta(os.path.join(inp, "ref.fa"), contigs)
+    synth.write_reference_fasta(os.path.join(inp, "ref_gap.fa"), contigs, {"e1": [(5_000, 5_100)]})
+    synth.write_reference_fasta(os.path.join(inp, "ref_extra.fa"), contigs + (("e3", 5_000),))
+    for name, rows in (("regions_ok.bed", [("e1", 1000, 9000)]), ("regions_unknown.bed", [("zz", 0, 100)]),
+                       ("regions_e2.bed", [("e2", 10, 2000)])):
+        with open(os.path.join(inp, name), "w") as f:
+            for t, a, b in rows:
+                f.write(f"{t}\t{a}\t{b}\n")
+    I = "{IN}/"
+    scenarios = [
+        ("no_arguments", []),
+        ("version", ["-v"]),
+        ("no_alignment_type", ["-r", I + "ref.fa"]),
+        ("hifi_file_missing", ["-r", I + "ref.fa", "--hifi", I + "nope.bam"]),
+        ("hifi_without_bam", ["-r", I + "ref.fa", "--hifi", I + "hifi.paf"]),
+        ("nano_file_missing", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "--nano", I + "nope.bam"]),
+        ("nano_without_bam", ["-r", I + "ref.fa", "--nano", I + "hifi.paf"]),
+        ("no_reference", ["--hifi", I + "hifi.bam"]),
+        ("reference_missing", ["-r", I + "nope.fa", "--hifi", I + "hifi.bam"]),
+        ("regions_missing", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "-R", I + "nope.bed", "-d", "{OUT}"]),
+        ("prefix_with_slash", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "-o", "x/", "-d", "{OUT}"]),
+        ("chrs_unknown", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "--chrs", "e1,zz", "-d", "{OUT}"]),
+        ("regions_unknown", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "-R", I + "regions_unknown.bed", "-d", "{OUT}"]),
+        ("chrs_regions_inconsistent", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "--chrs", "e1", "-R", I + "regions_e2.bed", "-d", "{OUT}"]),
+        ("hifi_targets_vs_reference", ["-r", I + "ref_extra.fa", "--hifi", I + "hifi.bam", "-d", "{OUT}"]),
+        ("nano_targets_vs_reference", ["-r", I + "ref_extra.fa", "--nano", I + "ont.bam", "-d", "{OUT}"]),
+        ("hifi_nano_lengths_differ", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "--nano", I + "ont_e2_short.bam", "-d", "{OUT}"]),
+        ("mapq_warning_then_runs", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "-mq", "60", "--mq-cutoff", "50", "-d", "{OUT}/"]),
+        ("refuses_to_overwrite_depth", ["-r", I + "ref.fa", "--hifi", I + "hifi.bam", "-d", "{OUT}"]),            # second run, same place
+        ("refuses_to_overwrite_gaps", ["-r", I + "ref_gap.fa", "--hifi", I + "hifi.bam", "-d", "{OUT}2"]),
+        ("refuses_to_overwrite_gaps_again", ["-r", I + "ref_gap.fa", "--hifi", I + "hifi.bam", "-d", "{OUT}2"]),
+    ]
+    tmp = tempfile.mkdtemp(prefix="gci_cli_err_")
+    results = []
+    os.environ["COLUMNS"] = "100"
+    for name, argv_t in scenarios:
+        argv = ["GCI.py"] + [a.replace("{IN}", inp).replace("{OUT}", os.path.join(tmp, "out")) for a in argv_t]
+        so, se = io.StringIO(), io.StringIO()
+        old = sys.argv
+        sys.argv = argv
+        code = "completed"
+        try:
+            with contextlib.redirect_stdout(so), contextlib.redirect_stderr(se):
+                # as `python GCI.py ...` would: the file's code in a module registered as __main__ (its Pool pickles
+                # functions by that name).  Not runpy.run_path: it replaces argv[0], which argparse prints in the usage line.
+                import types
+                mod = types.ModuleType("__main__")
+                mod.__file__ = load_reference.REF
+                saved_main = sys.modules["__main__"]
+                sys.modules["__main__"] = mod
+                try:
+                    exec(compile(open(load_reference.REF).read(), load_reference.REF, "exec"), mod.__dict__)
+                finally:
+                    sys.modules["__main__"] = saved_main
+        except SystemExit as e:
+            code = e.code
+        finally:
+            sys.argv = old
+        norm = lambda t: t.replace(os.path.join(tmp, "out"), "{OUT}").replace(inp, "{IN}")      # noqa: E731
+        results.append({"name": name, "argv": argv_t, "exit": norm(code) if isinstance(code, str) else code,
+                        "stdout": norm(so.getvalue()), "stderr": norm(se.getvalue())})
+        print("cli_errors:", name, "->", repr(code)[:90])
+    shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(GOLDEN, "cli_errors.json"), "w") as f:
+        json.dump(results, f, indent=1)
+
+
 def copy_reference_example():
     """The reference's own data triple (example/MH63.*) -- data files, not source."""
     dst = os.path.join(GOLDEN, "MH63")
@@ -365,7 +456,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])
     todo = [("c1", case_single_bam), ("c3a", case_two_bam), ("c3b", case_three_bam_chrs), ("c4a", case_paf_bam),
             ("c4b", case_nano_only_long_cigar), ("c4c", case_two_paf), ("plot", case_plot), ("c6", case_cli_plot), ("c5", case_two_type), ("kats", make_kats),
-            ("mh63", copy_reference_example)]
+            ("mh63", copy_reference_example), ("cli", case_cli_errors)]
     for name, fn in todo:
         if not only or name in only:
             fn()
