@@ -1,0 +1,583 @@
+// k_paf.hip -- K2: the PAF path of filter() (/root/reference/GCI.py:211-254, helpers :49-61 and :64-96) on the GPU.
+//
+//   text of every PAF file (one device buffer, files back to back)
+//     -> line starts (universal newlines; count per 4096-byte tile, scan, write)
+//     -> one lane per line: str.strip() + split('\t'), the twelve columns the reference reads, int() of eight of them,
+//        target lookup, identity = nmatch / alnlen (IEEE f64), the mapq / identity filter (GCI.py:218-239)
+//     -> the lines that pass ("hits") compacted in file order, files appended to one another (the reference never
+//        resets its block table between files, GCI.py:214-215)
+//     -> queries numbered by an open-addressing table on the 64-bit name hash (names confirmed on their bytes); the hits
+//        of a query side by side (count, scan, scatter, then ordered by line)
+//     -> per file i, one lane per query over its hits of files <= i (GCI.py:241-254): per target the union of the query
+//        blocks (touching blocks merge), mean identity as a sequential f64 sum in file order, score = mean * covered / qlen
+//        (qlen of the first block), best target by (score, target name), its interval the longest merged target block
+//        (leftmost on ties) -> a compact gci_rec + where its name lies in the text.
+// Same IEEE operations in the same order as the reference (the library is built with -fno-fast-math -ffp-contract=off).
+// Errors are those of the native host filter (gci_paf_filter): the first line the reference would raise on.
+#include "gci_ctx.hpp"
+#include <stdlib.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct PafHitD {
+    uint64_t qn_off;          // byte offset of the query name in the text
+    uint64_t qhash;
+    int64_t qlen, qs, qe, ts, te;
+    double identity;
+    uint32_t qn_len;
+    int32_t t;                // index among the selected contigs
+    uint32_t hq;
+    uint32_t slot;            // its query's slot in the table (set by k_paf_insert)
+};
+
+struct PafTargets {
+    const int32_t* slot;      // open addressing on the name hash: target index or -1
+    const uint64_t* hash;     // hash of target t
+    const uint64_t* off;      // name bytes of target t: names[off[t] .. off[t + 1])
+    const uint8_t* names;
+    const int32_t* rank;      // position of target t in sorted(name) order: the tie break of GCI.py:252
+    uint32_t mask;
+};
+
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c; }
+
+// a line starts at p: the first byte of the file, or behind '\n', or behind a '\r' that is not followed by '\n'
+__device__ __forceinline__ bool line_starts_at(const uint8_t* __restrict__ text, uint64_t lo, uint64_t p)
+{
+    if (p == lo) return true;
+    const uint8_t prev = text[p - 1];
+    return prev == '\n' || (prev == '\r' && text[p] != '\n');
+}
+
+__global__ __launch_bounds__(BLOCK) void k_paf_count_lines(const uint8_t* __restrict__ text, uint64_t lo, uint64_t hi,
+                                                           uint32_t* __restrict__ tile_count)
+{
+    __shared__ uint32_t wtot[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t p0 = lo + (uint64_t)blockIdx.x * TILE + (uint64_t)t * 16;
+    uint32_t n = 0;
+    for (int i = 0; i < 16; i++) if (p0 + i < hi && line_starts_at(text, lo, p0 + i)) n++;
+    n = wave_sum<uint32_t>(n);
+    if (lane == 0) wtot[wave] = n;
+    __syncthreads();
+    if (t == 0) tile_count[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_paf_line_starts(const uint8_t* __restrict__ text, uint64_t lo, uint64_t hi,
+                                                           const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ starts)
+{
+    __shared__ uint32_t wtot[BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t p0 = lo + (uint64_t)blockIdx.x * TILE + (uint64_t)t * 16;
+    uint32_t mask = 0;
+    for (int i = 0; i < 16; i++) if (p0 + i < hi && line_starts_at(text, lo, p0 + i)) mask |= 1u << i;
+    const uint32_t n = (uint32_t)__builtin_popcount(mask);
+    const uint32_t inc = wave_inclusive<uint32_t>(n, lane);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t w = tile_off[blockIdx.x] + inc - n;
+    for (int k = 0; k < wave; k++) w += wtot[k];
+    for (uint32_t m = mask; m; m &= m - 1) starts[w++] = p0 + (uint32_t)__builtin_ctz(m);
+}
+
+// Python's int() on a column: optional blanks, optional sign, digits; false = ValueError
+__device__ __forceinline__ bool parse_int(const uint8_t* __restrict__ text, uint64_t a, uint64_t b, int64_t& v)
+{
+    while (a < b && is_space(text[a])) a++;
+    while (b > a && is_space(text[b - 1])) b--;
+    bool neg = false;
+    if (a < b && (text[a] == '+' || text[a] == '-')) { neg = text[a] == '-'; a++; }
+    if (a >= b) return false;
+    uint64_t x = 0;
+    for (; a < b; a++) {
+        const uint8_t c = text[a];
+        if (c < '0' || c > '9') return false;
+        if (x > (0x7fffffffffffffffULL - (uint64_t)(c - '0')) / 10) return false;
+        x = x * 10 + (uint64_t)(c - '0');
+    }
+    v = neg ? -(int64_t)x : (int64_t)x;
+    return true;
+}
+
+__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* __restrict__ p, uint32_t len)      // == gci_name_hash
+{
+    uint64_t acc = 0;
+    for (uint32_t k = 0; k * 8 < len; k++) {
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) if (k * 8 + b < len) w |= (uint64_t)p[k * 8 + b] << (8 * b);
+        acc += gci_hash_word(w, k);
+    }
+    return gci_hash_finish(acc, len);
+}
+
+__device__ __forceinline__ bool bytes_equal(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) if (a[i] != b[i]) return false;
+    return true;
+}
+
+// One lane per line.  flag[i]: 1 = the line passed the filter (hit[i] is valid), 0 = skipped.  An offending line
+// reports (line number << 8 | -status) into *status with atomicMin: the FIRST such line of the file is what the reference
+// raises on (its lines are read in order).
+__global__ __launch_bounds__(BLOCK) void k_paf_tokenise(const uint8_t* __restrict__ text, uint64_t hi, const uint64_t* __restrict__ starts,
+                                                        uint32_t n_lines, uint64_t line_base, PafTargets T, int map_qual, int mq_cutoff,
+                                                        double iden_percent, PafHitD* __restrict__ hit, uint32_t* __restrict__ flag,
+                                                        unsigned long long* __restrict__ status)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_lines) return;
+    flag[i] = 0;
+    uint64_t a = starts[i];
+    // the end of the line is only looked for when fewer than thirteen columns turn up before it
+    while (a < hi && text[a] != '\n' && text[a] != '\r' && is_space(text[a])) a++;               // lstrip
+    uint64_t col[12], cend[12];
+    int nc = 0;                                       // columns found so far - 1
+    col[0] = a;
+    uint64_t q = a;
+    bool eol = false;
+    for (;;) {
+        if (q >= hi || text[q] == '\n' || text[q] == '\r') { eol = true; break; }
+        if (text[q] == '\t') {
+            cend[nc] = q;
+            if (nc == 11) break;                      // column 11 ends at a tab: nothing behind it matters
+            col[++nc] = q + 1;
+        }
+        q++;
+    }
+    if (eol) {
+        // str.strip(): blanks (tabs too) at the end of the line go before it is split
+        uint64_t b = q;
+        while (b > a && is_space(text[b - 1])) b--;
+        while (nc > 0 && col[nc] > b) nc--;          // columns that were only trailing tabs
+        cend[nc] = b;
+        if (b == a) nc = 0;                           // ''.split('\t') == ['']: one empty column
+    }
+    const unsigned long long line_no = line_base + i + 1;                                        // 1-based, over the file
+    auto fail = [&](int code) { atomicMin(status, (line_no << 8) | (unsigned long long)(uint8_t)(-code)); };
+    if (nc < 5) { fail(GCI_E_MALFORMED); return; }                                              // col[5]: IndexError
+    // target among the selected contigs (GCI.py:220)
+    const uint32_t tlen = (uint32_t)(cend[5] - col[5]);
+    const uint64_t th = hash_bytes(text + col[5], tlen);
+    int32_t t = -1;
+    for (uint32_t s = (uint32_t)(th ^ (th >> 29)) & T.mask;; s = (s + 1) & T.mask) {
+        const int32_t c = T.slot[s];
+        if (c < 0) break;
+        if (T.hash[c] == th && T.off[c + 1] - T.off[c] == tlen && bytes_equal(T.names + T.off[c], text + col[5], tlen)) { t = c; break; }
+    }
+    if (t < 0) return;
+    if (nc < 11) { fail(GCI_E_MALFORMED); return; }                                             // IndexError further right
+    int64_t qlen, qs, qe, ts, te, nmatch, alnlen, mapq;
+    bool ok = parse_int(text, col[1], cend[1], qlen);
+    ok = ok && parse_int(text, col[2], cend[2], qs);
+    ok = ok && parse_int(text, col[3], cend[3], qe);
+    ok = ok && parse_int(text, col[7], cend[7], ts);
+    ok = ok && parse_int(text, col[8], cend[8], te);
+    ok = ok && parse_int(text, col[9], cend[9], nmatch);
+    ok = ok && parse_int(text, col[10], cend[10], alnlen);
+    ok = ok && parse_int(text, col[11], cend[11], mapq);
+    if (!ok) { fail(GCI_E_MALFORMED); return; }                                                 // ValueError
+    if (alnlen == 0) { fail(GCI_E_ZERO_DIV); return; }                                          // nmatch / alnlen
+    const double identity = (double)nmatch / (double)alnlen;
+    if (!(mapq >= map_qual && identity >= iden_percent)) return;
+    PafHitD h;
+    h.qn_off = col[0]; h.qn_len = (uint32_t)(cend[0] - col[0]);
+    h.qhash = hash_bytes(text + col[0], h.qn_len);
+    h.qlen = qlen; h.qs = qs; h.qe = qe; h.ts = ts; h.te = te; h.identity = identity;
+    h.t = t; h.hq = mapq >= mq_cutoff ? 1u : 0u; h.slot = 0;
+    hit[i] = h;
+    flag[i] = 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_paf_compact(const PafHitD* __restrict__ hit, const uint32_t* __restrict__ flag,
+                                                       const uint32_t* __restrict__ pos, uint32_t n_lines, PafHitD* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_lines && flag[i]) out[pos[i]] = hit[i];
+}
+
+#define QEMPTY 0xFFFFFFFFu
+// query table: slot = index of the hit that claimed it; per slot the number of hits and the high-quality bit
+__global__ __launch_bounds__(BLOCK) void k_paf_insert(const uint8_t* __restrict__ text, PafHitD* __restrict__ hits, uint32_t first,
+                                                      uint32_t n, uint32_t* __restrict__ table, uint32_t mask,
+                                                      uint32_t* __restrict__ count, uint32_t* __restrict__ hq)
+{
+    const uint32_t i = first + blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const PafHitD h = hits[i];
+    uint32_t s = (uint32_t)(h.qhash ^ (h.qhash >> 29)) & mask;
+    for (;;) {
+        uint32_t c = table[s];
+        if (c == QEMPTY) {
+            c = atomicCAS(table + s, QEMPTY, i);
+            if (c == QEMPTY) break;
+        }
+        const PafHitD o = hits[c];
+        if (o.qhash == h.qhash && o.qn_len == h.qn_len && bytes_equal(text + o.qn_off, text + h.qn_off, h.qn_len)) break;
+        s = (s + 1) & mask;
+    }
+    hits[i].slot = s;
+    atomicAdd(count + s, 1u);
+    if (h.hq) atomicOr(hq + s, 1u);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_paf_scatter(const PafHitD* __restrict__ hits, uint32_t n, const uint32_t* __restrict__ start,
+                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ order)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = hits[i].slot;
+    order[start[s] + atomicAdd(cursor + s, 1u)] = i;
+}
+
+// union of closed-touching blocks [a, b), sorted in place: covered length and the longest merged block (leftmost on ties)
+__device__ __forceinline__ void merge_span(int64_t* __restrict__ pa, int64_t* __restrict__ pb, uint32_t n, int64_t& covered, int64_t& bs,
+                                           int64_t& be)
+{
+    for (uint32_t i = 1; i < n; i++) {                                   // insertion sort by (a, b): the lists are short
+        const int64_t xa = pa[i], xb = pb[i];
+        uint32_t j = i;
+        while (j > 0 && (pa[j - 1] > xa || (pa[j - 1] == xa && pb[j - 1] > xb))) { pa[j] = pa[j - 1]; pb[j] = pb[j - 1]; j--; }
+        pa[j] = xa; pb[j] = xb;
+    }
+    covered = 0;
+    int64_t best = -1;
+    bs = be = 0;
+    int64_t lo = pa[0], hi = pb[0];
+    for (uint32_t i = 1; i <= n; i++) {
+        if (i < n && hi >= pa[i]) { hi = hi > pb[i] ? hi : pb[i]; continue; }
+        covered += hi - lo;
+        if (hi - lo > best) { best = hi - lo; bs = lo; be = hi; }
+        if (i < n) { lo = pa[i]; hi = pb[i]; }
+    }
+}
+
+// One lane per query (table slot) over its hits below `limit` (= the hits of files 0 .. i): GCI.py:241-254.
+__global__ __launch_bounds__(BLOCK) void k_paf_score(const PafHitD* __restrict__ hits, const uint32_t* __restrict__ table, uint32_t n_slots,
+                                                     const uint32_t* __restrict__ start, uint32_t* __restrict__ order, uint32_t limit,
+                                                     const uint32_t* __restrict__ hq, const int32_t* __restrict__ trank,
+                                                     int64_t* __restrict__ pa, int64_t* __restrict__ pb, int sort_lists,
+                                                     gci_rec* __restrict__ out, uint64_t* __restrict__ out_name_off,
+                                                     uint32_t* __restrict__ n_out, unsigned long long* __restrict__ status)
+{
+    const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
+    bool emit = false;
+    gci_rec r;
+    uint64_t name_off = 0;
+    if (s < n_slots && table[s] != QEMPTY) {
+        const uint32_t a0 = start[s], a1 = start[s + 1];
+        if (sort_lists) {                                                // once: the scatter handed the slots out in any order
+            for (uint32_t i = a0 + 1; i < a1; i++) {
+                const uint32_t x = order[i];
+                uint32_t j = i;
+                while (j > a0 && order[j - 1] > x) { order[j] = order[j - 1]; j--; }
+                order[j] = x;
+            }
+        }
+        uint32_t m = a0;
+        while (m < a1 && order[m] < limit) m++;                          // the query's hits in files 0 .. i
+        if (m > a0) {
+            bool have = false;
+            double best_rank = 0;
+            int32_t best_t = -1;
+            int64_t best_s = 0, best_e = 0, best_qlen = 0;
+            for (uint32_t a = a0; a < m; a++) {
+                const int32_t t = hits[order[a]].t;
+                bool dup = false;
+                for (uint32_t c = a0; c < a; c++) dup = dup || hits[order[c]].t == t;
+                if (dup) continue;
+                uint32_t n_aln = 0;
+                int64_t qlen = 0;
+                double total = 0.0;
+                for (uint32_t c = a; c < m; c++) {
+                    const PafHitD& x = hits[order[c]];
+                    if (x.t != t) continue;
+                    if (n_aln == 0) qlen = x.qlen;                       // qlen of the first block
+                    pa[a0 + n_aln] = x.qs; pb[a0 + n_aln] = x.qe;
+                    total = total + x.identity;                          // file order, as sum() does
+                    n_aln++;
+                }
+                int64_t covered, s0, e0;
+                merge_span(pa + a0, pb + a0, n_aln, covered, s0, e0);
+                if (qlen == 0) {                                         // aligned / qlen: ZeroDivisionError
+                    atomicMin(status, ((unsigned long long)order[a] << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                    have = false;
+                    break;
+                }
+                const double rank = total / (double)n_aln * ((double)covered / (double)qlen);
+                if (!have || rank > best_rank || (rank == best_rank && trank[t] > trank[best_t])) {
+                    uint32_t k = 0;
+                    for (uint32_t c = a; c < m; c++) {
+                        const PafHitD& x = hits[order[c]];
+                        if (x.t == t) { pa[a0 + k] = x.ts; pb[a0 + k] = x.te; k++; }
+                    }
+                    merge_span(pa + a0, pb + a0, k, covered, s0, e0);
+                    have = true; best_rank = rank; best_t = t; best_s = s0; best_e = e0; best_qlen = qlen;
+                }
+            }
+            if (have) {
+                const PafHitD& q0 = hits[table[s]];
+                if (best_s > 0x7fffffffLL || best_s < -0x80000000LL || best_e > 0x7fffffffLL || best_e < -0x80000000LL ||
+                    best_qlen > 0x7fffffffLL || best_qlen < -0x80000000LL || q0.qn_len > 0xFFFF) {
+                    atomicMin(status, ((unsigned long long)table[s] << 8) | (unsigned)(-GCI_E_INVALID));
+                } else {
+                    r.name_hash = q0.qhash; r.contig = best_t; r.start = (int32_t)best_s; r.end = (int32_t)best_e;
+                    r.qlen = (int32_t)best_qlen; r.rec_idx = s; r.mapq = 0;
+                    r.flags = (uint8_t)(GCI_REC_PASS | (hq[s] ? GCI_REC_HQ : 0)); r.name_len = (uint16_t)q0.qn_len;
+                    name_off = q0.qn_off;
+                    emit = true;
+                }
+            }
+        }
+    }
+    // one returning atomic per wave that emits anything
+    const unsigned long long bal = __ballot(emit);
+    if (bal) {
+        const int lane = threadIdx.x & 63, first = __builtin_ctzll(bal);
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(n_out, (uint32_t)__builtin_popcountll(bal));
+        base = (uint32_t)__shfl((int)base, first, 64);
+        if (emit) {
+            const uint32_t w = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            r.rec_idx = w;
+            out[w] = r;
+            out_name_off[w] = name_off;
+        }
+    }
+}
+
+}  // namespace
+
+struct gci_paf_dev {
+    gci_ctx* ctx = nullptr;
+    std::vector<void*> recs, name_off;       // per file (device)
+    std::vector<uint32_t> count;
+};
+
+static void paf_dev_release(gci_paf_dev* h)
+{
+    for (void* p : h->recs) if (p) (void)hipFree(p);
+    for (void* p : h->name_off) if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const uint64_t* h_file_end, int n_files,
+                                     const char* const* targets, int n_targets, int map_qual, int mq_cutoff, double iden_percent,
+                                     gci_paf_dev** out, uint64_t* err_line)
+{
+    if (!ctx || !out || n_files < 0 || (n_files && (!d_text || !h_file_end)) || (n_targets && !targets)) return GCI_E_INVALID;
+    *out = nullptr;
+    hipStream_t st = ctx->stream;
+    std::vector<void*> tmp;                                  // freed on every way out
+    auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
+    struct Cleanup { std::vector<void*>& v; ~Cleanup() { for (void* p : v) (void)hipFree(p); } } cleanup{tmp};
+#define PAF_ALLOC(var, type, count)                                       \
+    type* var = (type*)dalloc(sizeof(type) * (size_t)(count));            \
+    if (!var) return GCI_E_NOMEM
+    // ---- the selected contigs: hash table, names, sorted rank ------------------------------------------------------
+    uint32_t tslots = 16;
+    while (tslots < 2u * (uint32_t)n_targets + 2u) tslots <<= 1;
+    std::vector<int32_t> h_slot(tslots, -1), h_rank(n_targets > 0 ? n_targets : 1, 0);
+    std::vector<uint64_t> h_hash(n_targets > 0 ? n_targets : 1, 0), h_off(n_targets + 1, 0);
+    std::string names;
+    for (int t = 0; t < n_targets; t++) {
+        const std::string nm(targets[t]);
+        h_off[t] = names.size();
+        names += nm;
+        h_hash[t] = gci_name_hash((const uint8_t*)nm.data(), (uint32_t)nm.size());
+        bool dup = false;
+        for (uint32_t s = (uint32_t)(h_hash[t] ^ (h_hash[t] >> 29)) & (tslots - 1);; s = (s + 1) & (tslots - 1)) {
+            if (h_slot[s] < 0) { h_slot[s] = t; break; }
+            if (nm == targets[h_slot[s]]) { dup = true; break; }      // a name listed twice: the first index, as the host map does
+        }
+        (void)dup;
+    }
+    h_off[n_targets] = names.size();
+    {
+        std::vector<int32_t> idx(n_targets);
+        for (int t = 0; t < n_targets; t++) idx[t] = t;
+        std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return std::string(targets[a]) < std::string(targets[b]); });
+        for (int k = 0; k < n_targets; k++) h_rank[idx[k]] = k;
+        for (int k = 1; k < n_targets; k++)                              // equal names share a rank
+            if (std::string(targets[idx[k]]) == std::string(targets[idx[k - 1]])) h_rank[idx[k]] = h_rank[idx[k - 1]];
+    }
+    PAF_ALLOC(d_slot, int32_t, tslots);
+    PAF_ALLOC(d_thash, uint64_t, h_hash.size());
+    PAF_ALLOC(d_toff, uint64_t, h_off.size());
+    PAF_ALLOC(d_tnames, uint8_t, names.size() + 16);
+    PAF_ALLOC(d_trank, int32_t, h_rank.size());
+    HIPCHK(hipMemcpyAsync(d_slot, h_slot.data(), tslots * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_thash, h_hash.data(), h_hash.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_toff, h_off.data(), h_off.size() * 8, hipMemcpyHostToDevice, st));
+    if (!names.empty()) HIPCHK(hipMemcpyAsync(d_tnames, names.data(), names.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_trank, h_rank.data(), h_rank.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                        // the host vectors above may go out of scope safely
+    PafTargets T;
+    T.slot = d_slot; T.hash = d_thash; T.off = d_toff; T.names = d_tnames; T.rank = d_trank; T.mask = tslots - 1;
+    PAF_ALLOC(d_status, unsigned long long, 1);
+    PAF_ALLOC(d_n, uint32_t, 4);
+
+    // ---- per file: lines -> hits, appended to the hits of the files before --------------------------------------------
+    std::vector<PafHitD*> file_hits(n_files, nullptr);
+    std::vector<uint32_t> hits_upto(n_files + 1, 0);
+    int pending_status = GCI_OK, n_ok = n_files;
+    uint64_t pending_line = 0;
+    for (int f = 0; f < n_files; f++) {
+        const uint64_t lo = f ? h_file_end[f - 1] : 0, hi = h_file_end[f];
+        if (hi < lo) return GCI_E_INVALID;
+        hits_upto[f + 1] = hits_upto[f];
+        if (hi == lo) continue;
+        const uint64_t n_tiles64 = (hi - lo + TILE - 1) / TILE;
+        if (n_tiles64 > 0x7fffffffULL) return GCI_E_INVALID;
+        const uint32_t n_tiles = (uint32_t)n_tiles64;
+        PAF_ALLOC(d_tile, uint32_t, n_tiles + 1);
+        PAF_ALLOC(d_blk, uint32_t, n_tiles / TILE + 2);
+        hipLaunchKernelGGL(k_paf_count_lines, dim3(n_tiles), dim3(BLOCK), 0, st, d_text, lo, hi, d_tile);
+        LAUNCHCHK("k_paf_count_lines");
+        int r = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_tile, d_tile, d_blk, (int64_t)n_tiles, true);
+        if (r) return r;
+        uint32_t n_lines = 0;
+        HIPCHK(hipMemcpyAsync(&n_lines, d_tile + n_tiles, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (n_lines == 0) continue;
+        PAF_ALLOC(d_starts, uint64_t, n_lines);
+        hipLaunchKernelGGL(k_paf_line_starts, dim3(n_tiles), dim3(BLOCK), 0, st, d_text, lo, hi, (const uint32_t*)d_tile, d_starts);
+        LAUNCHCHK("k_paf_line_starts");
+        PAF_ALLOC(d_hit, PafHitD, n_lines);
+        PAF_ALLOC(d_flag, uint32_t, n_lines + 1);
+        PAF_ALLOC(d_blk2, uint32_t, n_lines / TILE + 2);
+        HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, st));
+        hipLaunchKernelGGL(k_paf_tokenise, dim3((n_lines + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_text, hi, (const uint64_t*)d_starts,
+                           n_lines, (uint64_t)0, T, map_qual, mq_cutoff, iden_percent, d_hit, d_flag, d_status);
+        LAUNCHCHK("k_paf_tokenise");
+        unsigned long long h_status = 0;
+        HIPCHK(hipMemcpyAsync(&h_status, d_status, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_status != ~0ull) {
+            // The reference reads and scores file after file: an error in the scoring of an EARLIER file comes first.
+            // Remember this one and score the files before it below.
+            pending_status = -(int)(h_status & 0xFF);
+            pending_line = h_status >> 8;
+            n_ok = f;
+            break;
+        }
+        PAF_ALLOC(d_pos, uint32_t, n_lines + 1);
+        r = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_flag, d_pos, d_blk2, (int64_t)n_lines, true);
+        if (r) return r;
+        uint32_t n_hits = 0;
+        HIPCHK(hipMemcpyAsync(&n_hits, d_pos + n_lines, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((uint64_t)hits_upto[f] + n_hits > 0x7fffffffULL) return GCI_E_INVALID;
+        hits_upto[f + 1] = hits_upto[f] + n_hits;
+        if (n_hits) {
+            PAF_ALLOC(d_dense, PafHitD, n_hits);
+            hipLaunchKernelGGL(k_paf_compact, dim3((n_lines + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hit,
+                               (const uint32_t*)d_flag, (const uint32_t*)d_pos, n_lines, d_dense);
+            LAUNCHCHK("k_paf_compact");
+            file_hits[f] = d_dense;
+        }
+    }
+    auto pending = [&]() { if (err_line) *err_line = pending_line; return pending_status; };
+    const uint32_t total = hits_upto[n_ok];
+    if (total > (1u << 29)) return GCI_E_INVALID;
+    gci_paf_dev* H = new (std::nothrow) gci_paf_dev();
+    if (!H) return GCI_E_NOMEM;
+    H->ctx = ctx;
+    H->recs.assign(n_files, nullptr); H->name_off.assign(n_files, nullptr); H->count.assign(n_files, 0);
+    if (total == 0) {
+        if (pending_status != GCI_OK) { paf_dev_release(H); return pending(); }
+        *out = H;
+        return GCI_OK;
+    }
+    // one array of all hits, files in command-line order
+    PafHitD* d_hits = (PafHitD*)dalloc(sizeof(PafHitD) * (size_t)total);
+    if (!d_hits) { paf_dev_release(H); return GCI_E_NOMEM; }
+    for (int f = 0; f < n_ok; f++)
+        if (file_hits[f]) {
+            hipError_t e = hipMemcpyAsync(d_hits + hits_upto[f], file_hits[f], sizeof(PafHitD) * (size_t)(hits_upto[f + 1] - hits_upto[f]),
+                                          hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { paf_dev_release(H); return gci_fail(ctx, e, "hipMemcpyAsync(hits)"); }
+        }
+    // ---- queries: table, lists ---------------------------------------------------------------------------------------
+    uint32_t n_slots = 1024;
+    while (n_slots < 2ull * total) n_slots <<= 1;
+    uint32_t* d_table = (uint32_t*)dalloc(4ull * n_slots);
+    uint32_t* d_count = (uint32_t*)dalloc(4ull * (n_slots + 1));
+    uint32_t* d_start = (uint32_t*)dalloc(4ull * (n_slots + 1));
+    uint32_t* d_hq = (uint32_t*)dalloc(4ull * n_slots);
+    uint32_t* d_cursor = (uint32_t*)dalloc(4ull * n_slots);
+    uint32_t* d_order = (uint32_t*)dalloc(4ull * total);
+    uint32_t* d_blk3 = (uint32_t*)dalloc(4ull * (n_slots / TILE + 2));
+    int64_t* d_pa = (int64_t*)dalloc(8ull * total);
+    int64_t* d_pb = (int64_t*)dalloc(8ull * total);
+    if (!d_table || !d_count || !d_start || !d_hq || !d_cursor || !d_order || !d_blk3 || !d_pa || !d_pb) { paf_dev_release(H); return GCI_E_NOMEM; }
+    int rc = GCI_OK;
+    auto bail = [&](int code) { paf_dev_release(H); return code; };
+    if (hipMemsetAsync(d_table, 0xFF, 4ull * n_slots, st) != hipSuccess || hipMemsetAsync(d_count, 0, 4ull * (n_slots + 1), st) != hipSuccess ||
+        hipMemsetAsync(d_hq, 0, 4ull * n_slots, st) != hipSuccess || hipMemsetAsync(d_cursor, 0, 4ull * n_slots, st) != hipSuccess)
+        return bail(GCI_E_HIP);
+    hipLaunchKernelGGL(k_paf_insert, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_text, d_hits, 0u, total, d_table, n_slots - 1,
+                       d_count, d_hq);
+    rc = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_count, d_start, d_blk3, (int64_t)n_slots, true);
+    if (rc) return bail(rc);
+    hipLaunchKernelGGL(k_paf_scatter, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, total,
+                       (const uint32_t*)d_start, d_cursor, d_order);
+    if (hipGetLastError() != hipSuccess) return bail(GCI_E_HIP);
+    // ---- per file: score the queries over the hits so far ------------------------------------------------------------
+    if (hipMemsetAsync(d_status, 0xFF, 8, st) != hipSuccess) return bail(GCI_E_HIP);
+    bool lists_sorted = false;
+    for (int f = 0; f < n_ok; f++) {
+        const uint32_t limit = hits_upto[f + 1];
+        if (limit == 0) continue;
+        void *p_recs = nullptr, *p_off = nullptr;
+        if (hipMalloc(&p_recs, sizeof(gci_rec) * (size_t)limit) != hipSuccess) return bail(GCI_E_NOMEM);
+        H->recs[f] = p_recs;
+        if (hipMalloc(&p_off, 8ull * limit) != hipSuccess) return bail(GCI_E_NOMEM);
+        H->name_off[f] = p_off;
+        if (hipMemsetAsync(d_n, 0, 4, st) != hipSuccess) return bail(GCI_E_HIP);
+        hipLaunchKernelGGL(k_paf_score, dim3((n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, (const uint32_t*)d_table,
+                           n_slots, (const uint32_t*)d_start, d_order, limit, (const uint32_t*)d_hq, (const int32_t*)d_trank, d_pa, d_pb,
+                           lists_sorted ? 0 : 1, (gci_rec*)p_recs, (uint64_t*)p_off, d_n, d_status);
+        if (hipGetLastError() != hipSuccess) return bail(GCI_E_HIP);
+        lists_sorted = true;
+        uint32_t n_q = 0;
+        unsigned long long h_status = 0;
+        if (hipMemcpyAsync(&n_q, d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&h_status, d_status, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return bail(GCI_E_HIP);
+        if (h_status != ~0ull) { if (err_line) *err_line = 0; return bail(-(int)(h_status & 0xFF)); }
+        H->count[f] = n_q;
+    }
+    if (pending_status != GCI_OK) { paf_dev_release(H); return pending(); }
+    *out = H;
+    return GCI_OK;
+#undef PAF_ALLOC
+}
+
+extern "C" uint64_t gci_paf_dev_count(const gci_paf_dev* h, int file)
+{
+    return h && file >= 0 && (size_t)file < h->count.size() ? h->count[file] : 0;
+}
+
+// copies file `file`'s records and name offsets into the caller's device buffers (gci_paf_dev_count() entries each)
+extern "C" int gci_paf_dev_export(const gci_paf_dev* h, int file, gci_rec* d_recs, uint64_t* d_name_off)
+{
+    if (!h || !h->ctx || file < 0 || (size_t)file >= h->count.size()) return GCI_E_INVALID;
+    gci_ctx* ctx = h->ctx;
+    const size_t n = h->count[file];
+    if (n == 0) return GCI_OK;
+    if (!d_recs || !d_name_off) return GCI_E_INVALID;
+    HIPCHK(hipMemcpyAsync(d_recs, h->recs[file], n * sizeof(gci_rec), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_name_off, h->name_off[file], n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return GCI_OK;
+}
+
+extern "C" int gci_paf_dev_free(gci_paf_dev* h)
+{
+    if (!h) return GCI_OK;
+    if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
+    paf_dev_release(h);
+    return GCI_OK;
+}

@@ -283,6 +283,40 @@ class Engine:
         self._chk(self.lib.gci_pack_names(self.ctx, arr, self._p(blob), total, self._p(off)), "gci_pack_names")
         return blob[:total], off
 
+    # ---- R3 / N4: the PAF path of filter() on the device (k_paf.hip) -----------------------------------------------
+    def paf_filter(self, paths: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int, iden_percent: float
+                   ) -> List[JoinInput]:
+        """gci_paf_filter_device over the PAF files `paths` (command-line order): -> one JoinInput per file, holding a
+        compact record per query seen so far (files < i included: the reference never resets its block table) and
+        pointing at the names inside the uploaded text.  Raises GciError with .rec = the 1-based line the reference
+        would have raised on (GCI_E_MALFORMED: IndexError / ValueError, GCI_E_ZERO_DIV: ZeroDivisionError)."""
+        bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
+        ends = np.cumsum([b.shape[0] for b in bufs], dtype=np.uint64) if bufs else np.zeros(0, np.uint64)
+        text = np.concatenate(bufs) if bufs and int(ends[-1]) else np.zeros(1, np.uint8)
+        d_text = self.to_device(text)
+        tnames = [t.encode() for t in targets]
+        tarr = (ctypes.c_char_p * max(len(tnames), 1))(*tnames)
+        handle, line = ctypes.c_void_p(None), ctypes.c_uint64(0)
+        st = self.lib.gci_paf_filter_device(self.ctx, self._p(d_text), ends.ctypes.data_as(ctypes.c_void_p), len(bufs), tarr,
+                                            len(tnames), int(map_qual), int(mq_cutoff), float(iden_percent), ctypes.byref(handle),
+                                            ctypes.byref(line))
+        if st != 0:
+            detail = self.lib.gci_last_error(self.ctx).decode() if st == _lib.GCI_E_HIP else ""
+            raise GciError(st, "gci_paf_filter_device: %s (line %d) %s" % (self.lib.gci_strerror(st).decode(), line.value, detail),
+                           rec=int(line.value))
+        try:
+            out = []
+            for f in range(len(bufs)):
+                n = int(self.lib.gci_paf_dev_count(handle, f))
+                recs = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+                off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+                self._chk(self.lib.gci_paf_dev_export(handle, f, self._p(recs), self._p(off)), "gci_paf_dev_export")
+                out.append(JoinInput(recs[:n], d_text, off[:n], 0))
+            self.sync()
+            return out
+        finally:
+            self.lib.gci_paf_dev_free(handle)
+
     # ---- R6 / R8 / R9 / R15 --------------------------------------------------------------------
     def depth_build(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
                     max_n: Optional[int] = None) -> torch.Tensor:

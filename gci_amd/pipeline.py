@@ -247,6 +247,9 @@ def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
     return engine.to_device(stream), engine.to_device(offs), hdr
 
 
+# Where the PAF path of filter() runs: "gpu" (default, k_paf.hip) or "host" (native threads, gci_paf_filter).
+PAF_FILTER = os.environ.get("GCI_PAF", "gpu")
+
 # Every BGZF member's CRC-32 is verified while inflating, as htslib does (a corrupted block that still inflates to the
 # right size must not pass silently); GCI_BGZF_CRC=0 skips the check.
 BGZF_CRC = os.environ.get("GCI_BGZF_CRC", "1") != "0"
@@ -392,13 +395,15 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     inputs: List[JoinInput] = []
     high_qual: Set[str] = set()
     if len(paf_files) != 0:
-        from . import hostio
         try:
-            native = hostio.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent, threads=hostio.pick_threads(threads))
+            if PAF_FILTER == "host":                          # the native host filter (host_io.cpp), kept as a switch
+                from . import hostio
+                native = hostio.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent, threads=hostio.pick_threads(threads))
+                inputs += [JoinInput(engine.to_device(r), engine.to_device(nm), engine.to_device(off), 0) for r, nm, off in native]
+            else:                                             # K2: tokeniser, grouping and scoring on the GPU
+                inputs += engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
         except GciError as e:
             _reraise_like_reference(e)
-        for recs, names, off in native:                       # compact records + names, as K1 makes them from a BAM
-            inputs.append(JoinInput(engine.to_device(recs), engine.to_device(names), engine.to_device(off), 0))
     for path in bam_files:
         try:
             inputs.append(bam_join_input(engine, path, targets, (map_qual, mq_cutoff, clip_percent, iden_percent), threads))

@@ -16,6 +16,7 @@
  *   gci_depth_sum       np.mean numerator             GCI.py:862-868
  *   gci_range_sums      sliding_window_average_depth  GCI.py:660-705 (window sums)
  *   gci_fasta_n_scan    get_Ns_ref                    GCI.py:27-35
+ *   gci_paf_filter_device   filter(), PAF path        GCI.py:211-254  (+ helpers 49-61, 64-96)
  *
  * Conventions
  *   - every export returns int: GCI_OK (0) or a negative gci_status; nothing throws, exits,
@@ -348,6 +349,21 @@ uint64_t gci_paf_count(const gci_paf* r, int file);
 uint64_t gci_paf_name_bytes(const gci_paf* r, int file);
 int gci_paf_export(const gci_paf* r, int file, gci_rec* h_recs, uint8_t* h_names, uint64_t* h_name_off /* count + 1 */);
 int gci_paf_free(gci_paf* r);
+
+/* ---- R3 / N4: the same PAF filter on the GPU (k_paf.hip) ----------------------------------------------------------------
+ * d_text: the bytes of all PAF files back to back in ONE device buffer, h_file_end[i] = end offset of file i (host array).
+ * Line starts, the tokeniser (str.strip + split, int() of the eight numeric columns, target lookup, identity and the
+ * mapq / identity filter), the grouping of the surviving lines by query and the per-query scoring (GCI.py:241-254) all run
+ * on the device; results and errors are those of gci_paf_filter (*err_line = 1-based line of the offending file, 0 for an
+ * error raised while scoring).  The call synchronises.  Per file the handle holds one compact record per query seen so
+ * far (order unspecified) and the byte offset of its name INSIDE d_text: join with d_name_base = d_text, name_delta = 0.
+ * gci_paf_dev_export copies them into the caller's device buffers (gci_paf_dev_count entries each), on the ctx stream. */
+typedef struct gci_paf_dev gci_paf_dev;
+int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const uint64_t* h_file_end, int n_files, const char* const* targets,
+                          int n_targets, int map_qual, int mq_cutoff, double iden_percent, gci_paf_dev** out, uint64_t* err_line);
+uint64_t gci_paf_dev_count(const gci_paf_dev* r, int file);
+int gci_paf_dev_export(const gci_paf_dev* r, int file, gci_rec* d_recs, uint64_t* d_name_off);
+int gci_paf_dev_free(gci_paf_dev* r);
 
 #ifdef __cplusplus
 }
