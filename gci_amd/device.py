@@ -283,6 +283,37 @@ class Engine:
         self._chk(self.lib.gci_pack_names(self.ctx, arr, self._p(blob), total, self._p(off)), "gci_pack_names")
         return blob[:total], off
 
+    # ---- N1: BGZF inflate + record walk on the device (k_inflate.hip) ---------------------------------------------------
+    def bgzf_inflate(self, raw: np.ndarray, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True) -> torch.Tensor:
+        """raw: the bytes of a BGZF file; pos (uint64, n + 1) / isize (uint64, n): its member table (hostio.bgzf_blocks).
+        -> the inflated bytes on the device.  Raises GciError(GCI_E_MALFORMED, rec = member) on a bad member / CRC."""
+        n = int(isize.shape[0])
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(isize, out=off[1:])
+        total = int(off[n])
+        d_raw = self.to_device(raw)
+        d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(d_raw), self._p(d_pos), self._p(d_off), n, self._p(out), total,
+                                                   int(check_crc), self._p(self._status)), "gci_bgzf_inflate_device")
+        self.check_status("gci_bgzf_inflate_device")
+        return out[:total]
+
+    def bam_record_offsets(self, d_stream: torch.Tensor, first_record: int, n_ref: int) -> Tuple[torch.Tensor, int, bool]:
+        """-> (int64 offsets of every record on the device, bytes consumed, chain_ok).  chain_ok False: a record the strict
+        format test rejects sits on the chain -- the caller walks the chain on the host instead."""
+        n = int(d_stream.shape[0])
+        res = torch.zeros(3, dtype=torch.int64, device=self.device)
+        cap = max(1024, n // 256)
+        while True:
+            offs = torch.empty(cap, dtype=torch.int64, device=self.device)
+            self._chk(self.lib.gci_bam_record_offsets_device(self.ctx, self._p(d_stream), n, int(first_record), int(n_ref), self._p(offs), cap,
+                                                             self._p(res)), "gci_bam_record_offsets_device")
+            n_rec, used, broken = (int(x) for x in res.cpu().tolist())
+            if n_rec <= cap:
+                return offs[:n_rec], used, broken == 0
+            cap = n_rec
+
     # ---- R3 / N4: the PAF path of filter() on the device (k_paf.hip) -----------------------------------------------
     def paf_filter(self, paths: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int, iden_percent: float
                    ) -> List[JoinInput]:

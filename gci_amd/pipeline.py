@@ -254,6 +254,9 @@ PAF_FILTER = os.environ.get("GCI_PAF", "gpu")
 # right size must not pass silently); GCI_BGZF_CRC=0 skips the check.
 BGZF_CRC = os.environ.get("GCI_BGZF_CRC", "1") != "0"
 
+# ingest = "gpu" keeps the whole inflated stream of a file on the device: only files up to this size go that way
+GPU_INFLATE_MAX = int(os.environ.get("GCI_GPU_INFLATE_MAX", str(32 << 30)))
+
 # A BAM whose inflated stream exceeds this many bytes is streamed through the GPU chunk by chunk (K1 per chunk,
 # compact records + packed names kept, SEQ/QUAL bytes dropped): real 40x whole-genome BAMs inflate to hundreds of GB.
 BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
@@ -273,8 +276,8 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
     from concurrent.futures import ThreadPoolExecutor
     from . import hostio
     ingest = ingest or ("full" if chunk_bytes else os.environ.get("GCI_BAM_INGEST", "heads"))
-    if ingest not in ("heads", "full"):
-        raise ValueError("ingest must be 'heads' or 'full'")
+    if ingest not in ("heads", "full", "gpu"):
+        raise ValueError("ingest must be 'heads', 'full' or 'gpu'")
     chunk_bytes = int(chunk_bytes or BAM_CHUNK_BYTES)
     nthreads = hostio.pick_threads(threads)
     raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
@@ -287,6 +290,24 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         tindex = {t: i for i, t in enumerate(targets)}
         return engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
 
+    if ingest == "gpu":
+        # N1 on the device: the file's bytes are uploaded as they are, every BGZF member is inflated by one wave
+        # (gci_bgzf_inflate_device, CRC verified), the record offsets come from a parallel walk
+        # (gci_bam_record_offsets_device) and K1 runs over the whole inflated stream.  Files whose inflated size exceeds
+        # GCI_GPU_INFLATE_MAX, and streams the parallel walk cannot follow, take the heads path below.
+        pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+        total = int(isz.sum())
+        if 0 < total <= GPU_INFLATE_MAX:
+            hdr = bamfmt.read_header(path)
+            d_bam = engine.bgzf_inflate(np.asarray(raw), pos, isz, check_crc=BGZF_CRC)
+            d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, len(hdr.references))
+            if ok:
+                if used != total:
+                    raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % (total - used))
+                recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent)
+                return JoinInput(recs, d_bam, d_off, 36)
+            del d_bam, d_off
+        ingest = "heads"
     if ingest == "heads":
         try:
             heads = hostio.bam_heads(np.asarray(raw), threads=nthreads, check_crc=BGZF_CRC)

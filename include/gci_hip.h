@@ -365,6 +365,24 @@ uint64_t gci_paf_dev_count(const gci_paf_dev* r, int file);
 int gci_paf_dev_export(const gci_paf_dev* r, int file, gci_rec* d_recs, uint64_t* d_name_off);
 int gci_paf_dev_free(gci_paf_dev* r);
 
+/* ---- N1 on the GPU: BGZF inflate and the BAM record walk (k_inflate.hip; replaces pysam / htslib at GCI.py:150-151) ---------
+ * gci_bgzf_inflate_device: d_raw = the bytes of a BGZF file (or of a run of its members) on the device; d_member_pos[m] =
+ * offset of member m in d_raw, n_members + 1 entries (the last = end of the run; gci_bgzf_blocks makes the table on the
+ * host); d_out_off[m] = where member m's output goes in d_out (exclusive scan of the members' ISIZE, n_members + 1 entries).
+ * One wave per member (window, tables and input in LDS); every member's length and -- check_crc != 0 -- CRC-32 are verified.
+ * *d_status: min over failing members of (member << 8 | -status), UINT64_MAX if none (decode with gci_decode_status).
+ *
+ * gci_bam_record_offsets_device: the byte offset of every record of an inflated BAM stream on the device, without the serial
+ * block_size chain: candidate record starts by a strict format test on every byte position, successor lookup, reachability
+ * from `first_record` (= end of the BAM header) by pointer doubling.  d_result (device, 3 x uint64): [0] records found (may
+ * exceed cap: nothing is written beyond it), [1] bytes consumed (n_bytes, or the offset of a partial last record when the
+ * stream is a chunk), [2] != 0: the chain broke at offset [1] (a record the strict test rejects: take the host walk).
+ * The call synchronises. */
+int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off,
+                            uint32_t n_members, uint8_t* d_out, uint64_t out_cap, int check_crc, uint64_t* d_status);
+int gci_bam_record_offsets_device(gci_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, uint64_t first_record, int32_t n_ref,
+                                  uint64_t* d_offs, uint64_t cap, uint64_t* d_result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,7 +186,8 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     want = oracle.depth_build(oracle.name_join([want_d], hq, 0.9), tl, 15)
     engine.set_layout([tl[t] for t in targets])
     # heads stream (the default), the whole inflated stream in one upload, and streamed in chunks
-    for chunk, ingest in ((None, None), (None, "full"), (9_000_001, None), (1_234_567, None), (300_000, None)):
+    # ... and inflated + walked on the device (ingest "gpu")
+    for chunk, ingest in ((None, None), (None, "full"), (None, "gpu"), (9_000_001, None), (1_234_567, None), (300_000, None)):
         ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk, ingest=ingest)
         assert ji.recs.shape[0] == len(rs)
         assert (ji.name_delta == 0) == (chunk is not None)
@@ -206,6 +207,10 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     monkeypatch.setattr(pipeline, "BAM_CHUNK_BYTES", 2_000_000)
     monkeypatch.setenv("GCI_BAM_INGEST", "full")
     depths, _ = pipeline.filter([], [p, p2], prefix="st", directory=str(tmp_path), engine=engine, threads=4)
+    for t in targets:
+        assert np.array_equal(depths[t], want2[t]), t
+    monkeypatch.setenv("GCI_BAM_INGEST", "gpu")
+    depths, _ = pipeline.filter([], [p, p2], prefix="sg", directory=str(tmp_path), engine=engine, threads=4)
     for t in targets:
         assert np.array_equal(depths[t], want2[t]), t
 

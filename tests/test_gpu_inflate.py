@@ -1,0 +1,102 @@
+"""N1 on the GPU (k_inflate.hip): gci_bgzf_inflate_device against zlib on members of every DEFLATE flavour (stored, fixed and
+dynamic Huffman codes, several blocks per member, codes longer than the primary tables, matches at the maximum distance),
+its length / CRC checks, and gci_bam_record_offsets_device against the serial block_size walk on whole streams and on
+chunks that end inside a record."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gci_amd import hostio, synth
+from gci_amd._lib import GciError, GCI_E_MALFORMED
+from gci_amd.formats import bam as bamfmt
+from gci_amd.formats import bgzf
+
+pytestmark = pytest.mark.gpu
+
+
+def member(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8, corrupt_crc=False) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
+    body = c.compress(payload) + c.flush()
+    bsize = 12 + 6 + len(body) + 8 - 1
+    assert bsize <= 0xFFFF
+    head = struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize)
+    crc = (zlib.crc32(payload) ^ (1 if corrupt_crc else 0)) & 0xFFFFFFFF
+    return head + body + struct.pack("<II", crc, len(payload))
+
+
+def inflate_gpu(engine, raw: bytes, check_crc=True):
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    pos, isz = hostio.bgzf_blocks(buf)
+    return engine.bgzf_inflate(buf, pos, isz, check_crc=check_crc).cpu().numpy().tobytes()
+
+
+def test_members_of_every_flavour(engine):
+    rng = np.random.default_rng(41)
+    qual = synth._hifi_qual_lut()[rng.integers(0, 256, 60000, dtype=np.uint8)].tobytes()
+    seq = synth._SEQ_LUT[rng.integers(0, 16, 30000, dtype=np.uint8)].tobytes()
+    text = (b"chr1\t12345\tACGTTGCA" * 4000)[:65000]
+    skew = bytes(rng.choice(np.arange(256, dtype=np.uint8), size=64000, p=np.r_[0.5, 0.25, np.full(254, 0.25 / 254)]))   # long codes
+    far = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    far = far + far[:258] + b"x" + far[1:700]                                    # matches at distance 32768 / 32767
+    payloads = [b"", b"a", b"ab" * 3, qual, seq + qual[:30000], text, skew, far, bytes(65280), rng.integers(0, 256, 65280, dtype=np.uint8).tobytes()]
+    members, want = [], []
+    for p in payloads:
+        for kw in (dict(level=1), dict(level=6), dict(level=9), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED),
+                   dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY), dict(level=9, mem_level=1)):      # mem_level 1: many small blocks
+            try:
+                members.append(member(p, **kw))
+            except AssertionError:
+                continue                                                    # does not fit a BGZF member at this setting
+            want.append(p)
+    raw = b"".join(members) + bgzf.BGZF_EOF
+    assert inflate_gpu(engine, raw) == b"".join(want)
+    assert inflate_gpu(engine, raw, check_crc=False) == b"".join(want)
+    assert len(members) > 50
+
+
+def test_bad_members_are_reported(engine):
+    good = member(b"hello world" * 500)
+    bad_crc = member(b"hello world" * 500, corrupt_crc=True)
+    for k, raw in enumerate((good + bad_crc + good, good + good[:-9] + b"\x00" + good[-8:] + good)):
+        buf = np.frombuffer(raw + bgzf.BGZF_EOF, dtype=np.uint8)
+        pos, isz = hostio.bgzf_blocks(buf)
+        with pytest.raises(GciError) as e:
+            engine.bgzf_inflate(buf, pos, isz)
+        assert e.value.status == GCI_E_MALFORMED and e.value.rec == 1
+    # a wrong CRC passes when the check is off (the payload is intact)
+    buf = np.frombuffer(good + bad_crc + bgzf.BGZF_EOF, dtype=np.uint8)
+    pos, isz = hostio.bgzf_blocks(buf)
+    assert engine.bgzf_inflate(buf, pos, isz, check_crc=False).cpu().numpy().tobytes() == b"hello world" * 1000
+
+
+@pytest.mark.parametrize("kind,cov,seq_qual", [("hifi", 20, "random"), ("ont", 12, "const")])
+def test_bam_file_inflate_and_record_walk(engine, tmp_path, kind, cov, seq_qual):
+    contigs = (("a", 900_000), ("b", 300_000))
+    rs = synth.simulate_reads(contigs, cov, kind, seed=77, **({"long_cigar_frac": 0.02} if kind == "ont" else {}))
+    stream, offs = synth.to_bam_stream(rs, seq_qual=seq_qual, seed=3)
+    path = str(tmp_path / "x.bam")
+    bamfmt.write_bam_stream(path, stream, level=6 if kind == "hifi" else 1, threads=4)
+    raw = np.fromfile(path, dtype=np.uint8)
+    pos, isz = hostio.bgzf_blocks(raw)
+    d = engine.bgzf_inflate(raw, pos, isz)
+    assert np.array_equal(d.cpu().numpy(), stream)
+    hdr = bamfmt.parse_header(stream)
+    got, used, ok = engine.bam_record_offsets(d, hdr.first_record, len(hdr.references))
+    assert ok and used == stream.shape[0]
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), offs)
+    # a chunk that ends inside a record: the complete records, and where the partial one begins
+    cut = int(offs[len(offs) // 2]) + 50
+    got, used, ok = engine.bam_record_offsets(d[:cut], hdr.first_record, len(hdr.references))
+    assert ok and used == int(offs[len(offs) // 2])
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), offs[:len(offs) // 2])
+    # ... and one that ends inside a record's first 36 bytes
+    cut = int(offs[10]) + 20
+    got, used, ok = engine.bam_record_offsets(d[:cut], hdr.first_record, len(hdr.references))
+    assert ok and used == int(offs[10]) and got.shape[0] == 10
+    # a record the strict format test rejects (l_seq < 0) breaks the chain: reported, not guessed around
+    broken = stream.copy()
+    broken[int(offs[5]) + 20:int(offs[5]) + 24] = np.frombuffer(np.int32(-7).tobytes(), dtype=np.uint8)
+    got, used, ok = engine.bam_record_offsets(engine.to_device(broken), hdr.first_record, len(hdr.references))
+    assert not ok and used == int(offs[4])
