@@ -130,7 +130,7 @@ def _load_regions(path: Optional[str]) -> Dict[str, List[Tuple[int, int]]]:
 def _usable_directory(path: str) -> None:
     """Exists (created if not) and is readable and writable."""
     if not os.path.exists(path):
-        os.makedirs(path)
+        os.makedirs(path, exist_ok=True)              # (exist_ok: the ranks of a multi-GPU run all get here)
         return
     for mode, word in ((os.R_OK, "read"), (os.W_OK, "write")):
         if not os.access(path, mode):
@@ -226,8 +226,50 @@ def _check_files(files: Sequence[str], what: str) -> None:
         _die(f"Please input at least one {what} bam file\n" + HELP_HINT)
 
 
+def _split_gpus(argv: Sequence[str]) -> Tuple[List[str], int]:
+    """`--gpus N` is this implementation's own switch: taken out of the arguments before the reference's parser sees
+    them (the echo of the arguments stays the reference's)."""
+    out, n, i = [], 0, 0
+    while i < len(argv):
+        if argv[i] == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+            i += 2
+            continue
+        if argv[i].startswith("--gpus="):
+            n = int(argv[i].split("=", 1)[1])
+            i += 1
+            continue
+        out.append(argv[i])
+        i += 1
+    return out, n
+
+
 def main(argv=None):
+    """`python GCI.py ...` as the reference; `--gpus N` (or a launch under torch.distributed.run) shards the contigs over
+    N GPUs of one node, one process per GPU: rank 0 prints and writes what a single process would."""
     argv = sys.argv if argv is None else argv
+    argv, gpus = _split_gpus(list(argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if gpus > 1 and world == 1:                                      # re-launch, one process per GPU
+        port = 29600 + os.getpid() % 2000
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + argv[1:])
+    if world > 1:
+        from . import shard
+        ctx = shard.Context()
+        if not ctx.root:
+            sys.stdout = open(os.devnull, "w")                        # one transcript: rank 0's
+        try:
+            _main_single(argv, ctx)
+        except SystemExit as e:
+            if ctx.root:
+                raise
+            sys.exit(0 if e.code in (None, 0) else 1)                 # same verdict, said once
+        return
+    _main_single(argv, None)
+
+
+def _main_single(argv, ctx):
     parser = build_parser(argv[0])
     args = vars(parser.parse_args(argv[1:]))
     if len(argv) == 1:
@@ -245,8 +287,21 @@ def main(argv=None):
         _die(f'"{args["reference"]}" is not an available file')
     if args["map_qual"] > args["mq_cutoff"]:
         print(f'WARNING!!! The minium mapping quality ({args["map_qual"]}) is higher than the cutoff '
-              f'({args["mq_cutoff"]}), which means that wouldn\'t filter any reads\n' + HELP_HINT, file=sys.stderr)
+              f'({args["mq_cutoff"]}), which means that wouldn\'t filter any reads\n' + HELP_HINT,
+              file=sys.stderr if ctx is None or ctx.root else open(os.devnull, "w"))
     print(f"Used arguments:{args}")
+    if ctx is not None:
+        import torch.distributed as dist
+        ctx.init()
+        pipeline.SHARD = ctx
+        try:
+            GCI(**args)
+            dist.barrier()
+        finally:
+            pipeline.SHARD = None
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        return
     GCI(**args)
 
 

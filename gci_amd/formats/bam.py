@@ -284,8 +284,104 @@ def decode_record(stream: np.ndarray, off: int, restore_long_cigar: bool = True)
 # the index: "all fetch() chunks of a contig" == "all records with that refID" (SURVEY.md 8a-R1).
 # ----------------------------------------------------------------------------------------------
 
-def write_bai(path: str, n_ref: int) -> None:
+BAI_PSEUDO_BIN = 37450        # samtools' per-reference metadata bin: chunk 0 = (ref_beg, ref_end) virtual offsets
+
+
+def write_bai(path: str, n_ref: int, bam_path: Optional[str] = None) -> None:
+    """`<bam>.bai` for a coordinate-sorted BAM written by write_bam_stream (SAM spec 5.2).  Per reference with records:
+    bin 0 holding one chunk [first record, end of its last record), the pseudo-bin 37450 samtools writes (chunk 0 = the
+    same range, chunk 1 = mapped / unmapped counts) and the 16 kb linear index.  Virtual offset = compressed offset of
+    the BGZF member << 16 | offset inside its payload.  Without bam_path: an index without entries."""
+    if bam_path is None:
+        with open(path, "wb") as f:
+            f.write(b"BAI\x01" + struct.pack("<i", n_ref))
+            for _ in range(n_ref):
+                f.write(struct.pack("<ii", 0, 0))
+        return
+    with open(bam_path, "rb") as f:
+        raw = f.read()
+    blocks = bgzf.scan_blocks(raw)
+    stream = bgzf.decompress(raw)
+    hdr = parse_header(stream)
+    offs = record_offsets(stream, hdr.first_record)
+    ustart = np.cumsum([0] + [b[2] for b in blocks])              # inflated offset of every member
+    cstart = np.asarray([b[0] for b in blocks] + [len(raw)], dtype=np.int64)
+
+    def voffset(u: int) -> int:
+        k = int(np.searchsorted(ustart, u, side="right")) - 1
+        while k + 1 < len(blocks) and blocks[k][2] == 0:
+            k += 1
+        if k >= len(blocks):
+            k = len(blocks) - 1
+        return (int(cstart[k]) << 16) | (u - int(ustart[k]))
+
+    o = offs.astype(np.int64)
+    ref = stream[(o[:, None] + np.arange(4, 8)[None, :])].copy().view("<i4").reshape(-1) if o.shape[0] else np.zeros(0, np.int32)
+    pos = stream[(o[:, None] + np.arange(8, 12)[None, :])].copy().view("<i4").reshape(-1) if o.shape[0] else np.zeros(0, np.int32)
+    flag = stream[(o[:, None] + np.arange(18, 20)[None, :])].copy().view("<u2").reshape(-1) if o.shape[0] else np.zeros(0, np.uint16)
+    ends = np.concatenate([o[1:], [stream.shape[0]]]) if o.shape[0] else np.zeros(0, np.int64)
     with open(path, "wb") as f:
         f.write(b"BAI\x01" + struct.pack("<i", n_ref))
+        for r in range(n_ref):
+            idx = np.flatnonzero(ref == r)
+            if idx.shape[0] == 0:
+                f.write(struct.pack("<ii", 0, 0))
+                continue
+            beg, end = voffset(int(o[idx[0]])), voffset(int(ends[idx[-1]]))
+            n_un = int(((flag[idx] & 4) != 0).sum())
+            f.write(struct.pack("<i", 2))
+            f.write(struct.pack("<Ii", 0, 1) + struct.pack("<QQ", beg, end))
+            f.write(struct.pack("<Ii", BAI_PSEUDO_BIN, 2) + struct.pack("<QQ", beg, end) + struct.pack("<QQ", idx.shape[0] - n_un, n_un))
+            n_win = int(hdr.lengths[r] + 16383) // 16384
+            first = np.full(n_win, -1, dtype=np.int64)
+            w = np.clip(pos[idx].astype(np.int64), 0, None) // 16384
+            w = np.minimum(w, n_win - 1)
+            order = np.arange(idx.shape[0])
+            np.minimum.at(first, w, order)                          # (records are sorted: the first record of a window)
+            f.write(struct.pack("<i", n_win))
+            last = 0
+            for k in range(n_win):
+                if first[k] >= 0 and first[k] < idx.shape[0]:
+                    last = voffset(int(o[idx[int(first[k])]]))
+                f.write(struct.pack("<Q", last))
+        f.write(struct.pack("<Q", 0))                               # n_no_coor
+
+
+def read_bai(path: str) -> Optional[List[Optional[Tuple[int, int]]]]:
+    """-> per reference (virtual offset of its first record, virtual offset behind its last record) or None when the
+    index lists nothing for it; None when there is no usable index file.  The range is the pseudo-bin's (37450) when
+    present, else the hull of all chunks."""
+    try:
+        with open(path, "rb") as f:
+            raw = f.read()
+    except OSError:
+        return None
+    if raw[:4] != b"BAI\x01":
+        return None
+    p = 4
+    try:
+        (n_ref,) = struct.unpack_from("<i", raw, p)
+        p += 4
+        out: List[Optional[Tuple[int, int]]] = []
         for _ in range(n_ref):
-            f.write(struct.pack("<ii", 0, 0))
+            (n_bin,) = struct.unpack_from("<i", raw, p)
+            p += 4
+            lo, hi, meta = None, None, None
+            for _b in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", raw, p)
+                p += 8
+                chunks = struct.unpack_from("<%dQ" % (2 * n_chunk), raw, p)
+                p += 16 * n_chunk
+                if b == BAI_PSEUDO_BIN:
+                    if n_chunk >= 1:
+                        meta = (chunks[0], chunks[1])
+                    continue
+                for k in range(n_chunk):
+                    lo = chunks[2 * k] if lo is None else min(lo, chunks[2 * k])
+                    hi = chunks[2 * k + 1] if hi is None else max(hi, chunks[2 * k + 1])
+            (n_intv,) = struct.unpack_from("<i", raw, p)
+            p += 4 + 8 * n_intv
+            out.append(meta if meta is not None else ((lo, hi) if lo is not None else None))
+        return out
+    except struct.error:
+        return None

@@ -32,12 +32,13 @@ from .formats import bam as bamfmt
 from .formats import depthfile, fasta
 
 _ENGINE: Optional[Engine] = None
+SHARD = None              # gci_amd.shard.Context of a multi-GPU run (set by cli.main), None for a single process
 
 
 def default_engine() -> Engine:
     global _ENGINE
     if _ENGINE is None:
-        _ENGINE = Engine(int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.device_count() > 1 else 0)
+        _ENGINE = Engine(SHARD.device_index if SHARD is not None else 0)
     return _ENGINE
 
 
@@ -56,6 +57,7 @@ class DepthTracks:
         self.targets = list(targets_length.keys())
         self.lengths = [int(targets_length[t]) for t in self.targets]
         self.track = track
+        self.all_targets = list(self.targets)      # contig-sharded run: every selected contig in header order (this rank holds `targets`)
         # by-products of the fused build, valid until the track is modified (gap mask)
         self._fresh_runs = None        # ((lo, hi, flank), per-contig raw runs)
         self._fresh_sums = None
@@ -94,13 +96,25 @@ class DepthTracks:
         return self.engine.depth_sum(self.track)
 
     def mean(self) -> float:
-        """np.mean over the concatenation of all contigs (GCI.py:862-868): integers, so exact."""
-        return float(int(self.sums().sum())) / float(sum(self.lengths))
+        """np.mean over the concatenation of all contigs (GCI.py:862-868): integers, so exact.  In a contig-sharded run
+        the numerator and denominator are ONE integer all-reduce over the ranks (RCCL over xGMI)."""
+        total, bases = int(self.sums().sum()), sum(self.lengths)
+        if SHARD is not None and SHARD.world > 1:
+            total, bases = SHARD.all_reduce_sum([total, bases])
+        return float(total) / float(bases)
 
 
 # ==============================================================================================
 # gaps
 # ==============================================================================================
+
+def _is_root() -> bool:
+    return SHARD is None or SHARD.root
+
+
+def _sharded() -> bool:
+    return SHARD is not None and SHARD.world > 1
+
 
 def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
     _, ns_bed = fasta.n_runs_device(default_engine(), reference)          # N4: the scan itself runs on the GPU
@@ -108,10 +122,11 @@ def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
         path = f"{directory}/{prefix}.gaps.bed"
         if os.path.exists(path) and force == False:  # noqa: E712
             sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
-        with open(path, "w") as f:
-            for target, segments in ns_bed.items():
-                for a, b in segments:
-                    f.write(f"{target}\t{a}\t{b}\n")
+        if _is_root():
+            with open(path, "w") as f:
+                for target, segments in ns_bed.items():
+                    for a, b in segments:
+                        f.write(f"{target}\t{a}\t{b}\n")
         return ns_bed, path
     return None, None
 
@@ -405,6 +420,9 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     if write and os.path.exists(f"{directory}/{prefix}.depth.gz") and force == False:  # noqa: E712
         sys.exit(f'ERROR!!! The file "{directory}/{prefix}.depth.gz" exists\nPlease use "-f" or "--force" to rewrite')
     print(f"Filtering {log_reads_type} alignment files ...")
+    if _sharded():
+        return _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_percent, clip_percent, ovlp_percent,
+                               flank_len, directory, log_reads_type, chrs_list, threads, engine, write, issue_hint)
 
     first = bamfmt.read_header(bam_files[0])
     pairs = [(r, l) for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)]
@@ -454,6 +472,137 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     return depths, targets_length
 
 
+# ==============================================================================================
+# contig-sharded run (one process per GPU)
+# ==============================================================================================
+
+def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], own: Sequence[str], filt, threads: int = 1) -> JoinInput:
+    """K1 over the records of the contigs `own` of one BAM file -- the part of the reference's fan-out over contigs
+    (GCI.py:257-270) that falls to this rank.  gci_rec.contig is the index in `targets` (all selected contigs).
+
+    With an index next to the file (`<bam>.bai`; the reference needs one for pysam's fetch) only the BGZF members
+    that hold those records are read and inflated: the pseudo-bin samtools writes per reference (or the hull of its
+    chunks) gives the virtual offsets of the contig's first record and of the end of its last one.  Without an index
+    the whole file is ingested and K1 drops the records of the other contigs."""
+    from . import hostio
+    map_qual, mq_cutoff, clip_percent, iden_percent = filt
+    hdr = bamfmt.read_header(path)
+    for t in targets:
+        if t not in hdr.references:
+            raise ValueError(f"invalid contig `{t}`")              # what pysam's fetch() raises
+    tindex = {t: i for i, t in enumerate(targets)}
+    own_set = set(own)
+    ref_sel = engine.to_device(np.asarray([tindex[r] if r in own_set else -1 for r in hdr.references], dtype=np.int32))
+    index = bamfmt.read_bai(path + ".bai")
+    dev = engine.device
+    nthreads = hostio.pick_threads(threads)
+    if index is None or len(index) != len(hdr.references):
+        raw = np.fromfile(path, dtype=np.uint8)
+        with hostio.bam_heads(raw, threads=nthreads, check_crc=BGZF_CRC) as heads:
+            d_bam, d_off = engine.to_device(heads.stream), engine.to_device(heads.offsets)
+        recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
+        return JoinInput(recs, d_bam, d_off, 36)
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+    cpos = pos[:isz.shape[0]].astype(np.int64)
+    rec_parts, name_parts, off_parts, name_base, n_done = [], [], [], 0, 0
+    for r, name in enumerate(hdr.references):
+        if name not in own_set or index[r] is None:
+            continue
+        beg, end = index[r]
+        a = int(np.searchsorted(cpos, beg >> 16, side="right")) - 1              # member of the first record
+        b = int(np.searchsorted(cpos, end >> 16, side="right")) - 1              # member where the range ends
+        if a < 0 or cpos[a] != (beg >> 16) or b < a or b >= cpos.shape[0] or cpos[b] != (end >> 16):
+            raise bamfmt.BAMError("index of %s does not match its BGZF members" % path)
+        last = b if (end & 0xFFFF) else b - 1                                    # (a range ending at offset 0 of a member stops before it)
+        if last < a:
+            continue
+        buf = hostio.bgzf_inflate(np.asarray(raw[int(pos[a]):int(pos[last + 1])]), threads=nthreads, check_crc=BGZF_CRC)
+        stop = int(isz[a:b].sum()) + (end & 0xFFFF)                              # end of the contig's last record inside buf
+        offs, _ = hostio.bam_chunk_offsets(buf[:stop], beg & 0xFFFF)
+        if offs.shape[0] == 0:
+            continue
+        d_buf, d_off = engine.to_device(buf[:stop]), engine.to_device(offs)
+        try:
+            recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=n_done)
+        except GciError as e:
+            if e.rec >= 0:
+                e.rec += n_done
+            raise
+        names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
+        rec_parts.append(recs.clone())
+        name_parts.append(names.clone())
+        off_parts.append(noff[:-1] + name_base)
+        name_base += int(names.shape[0])
+        n_done += int(offs.shape[0])
+    recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
+    names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
+    noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
+    return JoinInput(recs, names if names.shape[0] else torch.zeros(1, dtype=torch.uint8, device=dev), noff, 0)
+
+
+def _replicate(engine: Engine, ji: JoinInput) -> JoinInput:
+    """One file's compact records + names of every rank, on every rank (all-gather; RCCL over xGMI).  Rank r's records
+    keep their order and sit behind those of ranks < r: a contig's records come from one rank, so "the last record of a
+    name wins" (contig order first, then file order; GCI.py:269) is decided as in a single process."""
+    from . import shard
+    n = int(ji.recs.shape[0])
+    if n:
+        blob, off = engine.pack_names(ji)
+    else:
+        blob, off = torch.zeros(0, dtype=torch.uint8, device=engine.device), torch.zeros(1, dtype=torch.int64, device=engine.device)
+    ex = shard.RecordExchange(n, int(blob.shape[0]), engine.device, via_host=SHARD.backend != "nccl")
+    ex.send_recs[:n] = ji.recs
+    ex.send_names[:blob.shape[0]] = blob
+    ex.send_off[:n + 1] = off
+    g = ex.gather()
+    return JoinInput(g.recs, g.names, g.name_index, 0)
+
+
+def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_percent, clip_percent, ovlp_percent, flank_len,
+                    directory, log_reads_type, chrs_list, threads, engine: Engine, write, issue_hint):
+    """filter() of a contig-sharded run.  Contigs are dealt to the ranks (longest first onto the least loaded); depth
+    build, gap mask, two-type max, issue scan and depth text are contig-local.  The read-name join is not -- a read
+    aligned to contigs of two ranks must be dropped, a name repeated across contigs keeps its last record
+    (GCI.py:269, 296-297) -- so every rank filters the records of ITS contigs (K1), the 32-byte records + names are
+    replicated with one all-gather per file, every rank runs the whole join and keeps the intervals on its contigs.
+    PAF files are filtered whole on every rank (K2; they are a hundredth of the BAMs)."""
+    first = bamfmt.read_header(bam_files[0])
+    pairs = [(r, l) for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)]
+    targets_length = {r: l for r, l in pairs}
+    targets = list(targets_length.keys())
+    mine = SHARD.assign([targets_length[t] for t in targets])
+    if SHARD.world > len(targets):                  # (every rank sees this: rank 0 says it)
+        sys.exit(f"ERROR!!! {SHARD.world} GPUs for {len(targets)} contig(s): use at most one GPU per contig")
+    local_tl = {targets[c]: targets_length[targets[c]] for c in mine}
+    engine.set_layout(list(local_tl.values()))
+    cmap = np.full(max(len(targets), 1), -1, dtype=np.int32)
+    cmap[mine] = np.arange(len(mine), dtype=np.int32)
+    filt = (map_qual, mq_cutoff, clip_percent, iden_percent)
+    inputs: List[JoinInput] = []
+    try:
+        if len(paf_files) != 0:
+            inputs += engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
+        for path in bam_files:
+            inputs.append(_replicate(engine, bam_records_of_contigs(engine, path, targets, list(local_tl), filt, threads)))
+        ivl, count = engine.name_join(inputs, ovlp_percent, contig_map=engine.to_device(cmap), count_flank=flank_len)
+    except GciError as e:
+        _reraise_like_reference(e)
+    track = engine.new_track()
+    fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=False, want_sums=True, issue=issue_hint, counted=True)
+    depths = DepthTracks(engine, local_tl, track)
+    depths.all_targets = targets
+    depths._fresh_sums = fused["sums"]
+    if issue_hint is not None:
+        depths._fresh_runs = (tuple(float(x) for x in issue_hint[:2]) + (int(issue_hint[2]),), fused["runs"])
+    print(f"Filtering {log_reads_type} alignment files done!!!")
+    if write:
+        print(f'Writing depths into "{directory}/{prefix}.depth.gz" ...')
+        _write_depth_members(directory, prefix, depths)
+        print("Writing depths done!!!\n\n")
+    return depths, targets_length
+
+
 def _reraise_like_reference(e: GciError):
     from . import _lib
     if e.status == _lib.GCI_E_NO_NM:
@@ -472,7 +621,7 @@ def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads
     """`{directory}/{prefix}.depth.gz`: '>contig' line then one decimal per line (GCI.py:99-143), as a multi-member
     gzip (any gzip whose payload equals the reference's text is a valid .depth.gz)."""
     depths._bind()
-    if DEPTH_GZ == "gpu":
+    if DEPTH_GZ == "gpu" or _sharded():
         _write_depth_members(directory, prefix, depths)
         return
     text, offs = depths.engine.depth_text(depths.track)
@@ -480,14 +629,22 @@ def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads
 
 
 def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
-    """'>contig' member (host), then the contig's lines as the members the device wrote."""
+    """'>contig' member (host), then the contig's lines as the members the device wrote.  Contig-sharded run: every rank
+    deflates the contigs it owns, rank 0 gathers the members and writes them in header order."""
     from . import hostio
     blobs = depths.engine.depth_deflate(depths.track)
+    items = list(zip(depths.targets, depths.lengths, blobs))
+    if _sharded():
+        order = {t: i for i, t in enumerate(depths.all_targets)}
+        parts = SHARD.gather_objects(items)
+        items = sorted((x for part in parts for x in part), key=lambda x: order[x[0]])
+        if not SHARD.root:
+            return
     path = f"{directory}/{prefix}.depth.gz"
     if os.path.exists(path):
         os.remove(path)
     with open(path, "wb") as f:
-        for t, L, blob in zip(depths.targets, depths.lengths, blobs):
+        for t, L, blob in items:
             if L == 0:
                 continue              # the reference's chunk loop never runs for an empty contig: not even the '>' line
             f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
@@ -522,6 +679,7 @@ def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTrac
         raise KeyError("HiFi and ONT depth tracks cover different contigs")
     merged = DepthTracks(hifi_depths.engine, hifi_depths.targets_length,
                          hifi_depths.engine.max2(hifi_depths.track, nano_depths.track))
+    merged.all_targets = hifi_depths.all_targets
     if write:
         write_depth(directory, prefix, merged, threads)
     print("Merging HiFi and ONT depth file done!!!\n\n")
@@ -594,10 +752,16 @@ def merge_depth(depths: DepthTracks = None, prefix="GCI", threshold=0, flank_len
     if os.path.exists(path) and force == False:  # noqa: E712
         sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
     merged = collapse_depth_range(depths, -1, threshold, flank_len, 0)
-    with open(path, "w") as f:
-        for target, segments in merged.items():
-            for s, e in segments:
-                f.write(f"{target}\t{s}\t{e}\n")
+    if _sharded():                      # every rank scanned its contigs; the lists (<= 10^4 items) travel as objects
+        union = {}
+        for part in SHARD.gather_objects(merged):
+            union.update(part)
+        merged = {t: union[t] for t in depths.all_targets}          # header order
+    if _is_root():
+        with open(path, "w") as f:
+            for target, segments in merged.items():
+                for s, e in segments:
+                    f.write(f"{target}\t{s}\t{e}\n")
     print(f"Getting {log_reads_type} issues bed file done!!!\n\n")
     return merged
 
@@ -668,6 +832,8 @@ def pre_plot_base(depths_list: Sequence[DepthTracks], max_depths: Sequence[float
                                                     region[2] if region else None)
             averaged[i][target] = (pos, val)
             maxima[i].append(max(val))
+    if _sharded() and region is None:            # the axis limits span every contig: the few maxima of all ranks
+        maxima = [[x for part in parts for x in part] for parts in zip(*SHARD.gather_objects(maxima))]
     y_max = max(maxima[0]) + 10
     y_min = 0 if len(depths_list) == 1 else max(maxima[1]) + 10
     return averaged, y_min / (y_max + y_min), y_min, y_max
@@ -688,8 +854,9 @@ def compute_index(targets_length={}, prefix="GCI", directory=".", force=False, m
     gci_path = f"{directory}/{prefix}.gci"
     if os.path.exists(gci_path) and force == False:  # noqa: E712
         sys.exit(f'ERROR!!! The file "{gci_path}" exists\nPlease use "-f" or "--force" to rewrite')
-    with open(gci_path, "w"):
-        pass
+    if _is_root():
+        with open(gci_path, "w"):
+            pass
     reg_path = f"{directory}/{prefix}.regions.gci"
     if len(regions_bed) > 0:
         if os.path.exists(reg_path) and force == False:  # noqa: E712
@@ -703,17 +870,25 @@ def compute_index(targets_length={}, prefix="GCI", directory=".", force=False, m
         obs_n50, obs_ctg = score.curated_table(bed, targets_length, flank_len, dist_percent, rows[-1])
         print(f"Computing Curated N50 and contigs number for {t} done!!!")
         print(f"Writing results to {gci_path} ...")
-        with open(gci_path, "a") as f:
-            f.write(score.section_text(t, rows, exp_n50, exp_ctg, obs_n50, obs_ctg))
+        if _is_root():
+            with open(gci_path, "a") as f:
+                f.write(score.section_text(t, rows, exp_n50, exp_ctg, obs_n50, obs_ctg))
         print(f"Writing results to {gci_path} done!!!\n\n")
     if len(regions_bed) > 0:
         print("Computing GCI scores for regions ...")
         flat = [(t, s, e) for t, segs in regions_bed.items() for s, e in segs]
-        per_track = [collapse_regions(d, flat, -1, threshold) for d in depths_list]
-        lookup = {(i, r): per_track[i][k] for i in range(len(depths_list)) for k, r in enumerate(flat)}
-        text = score.regions_text(regions_bed, type_list, len(depths_list),
-                                  lambda i, t, s, e: lookup[(i, (t, s, e))], dist_percent,
-                                  warn=lambda m: print(m, file=sys.stderr))
-        with open(reg_path, "w") as f:
-            f.write(text)
+        mine = [r for r in flat if r[0] in depths_list[0]]                      # the regions on contigs this rank holds
+        per_track = [collapse_regions(d, mine, -1, threshold) for d in depths_list]
+        lookup = {(i, r): per_track[i][k] for i in range(len(depths_list)) for k, r in enumerate(mine)}
+        if _sharded():
+            merged_lookup = {}
+            for part in SHARD.gather_objects(lookup):
+                merged_lookup.update(part)
+            lookup = merged_lookup
+        if _is_root():
+            text = score.regions_text(regions_bed, type_list, len(depths_list),
+                                      lambda i, t, s, e: lookup[(i, (t, s, e))], dist_percent,
+                                      warn=lambda m: print(m, file=sys.stderr))
+            with open(reg_path, "w") as f:
+                f.write(text)
         print("Computing GCI scores for regions done!!!\n\n")

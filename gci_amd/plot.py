@@ -133,27 +133,43 @@ def plot_depth(depths_list: Sequence[pipeline.DepthTracks] = (), depth_min=0.1, 
         sys.exit("ERROR!!! The format of output images only supports pdf and png")
     mean_depths = [tracks.mean() for tracks in depths_list]              # np.mean over all contigs (GCI.py:862-868)
     max_depths = [m * depth_max for m in mean_depths]
-    targets = depths_list[0].targets
-    for target in targets:
+    targets = depths_list[0].targets                                     # (contig-sharded run: the contigs of this rank)
+    sharded, root = pipeline._sharded(), pipeline._is_root()
+    for target in depths_list[0].all_targets:
         path = f"{directory}/images/{prefix}.{target}.{image_type}"
         if os.path.exists(path) and force == False:  # noqa: E712
             sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
     print("Plotting whole genome depth ...")
     averaged, y_frac, y_min, y_max = pipeline.pre_plot_base(depths_list, max_depths, window_size, 0)
-    for target in targets:
-        render(figure_spec(depths_list, target, averaged, mean_depths, y_frac, 0, depth_min, dist_percent, y_min, y_max,
-                           image_type, directory, prefix, targets_length[target], False, threshold))
+    specs = [figure_spec(depths_list, target, averaged, mean_depths, y_frac, 0, depth_min, dist_percent, y_min, y_max,
+                         image_type, directory, prefix, targets_length[target], False, threshold) for target in targets]
+    if sharded:                                  # the numbers of every figure go to rank 0, which draws them in header order
+        order = {f"{directory}/images/{prefix}.{t}.{image_type}": i for i, t in enumerate(depths_list[0].all_targets)}
+        specs = sorted((x for part in pipeline.SHARD.gather_objects(specs) for x in part), key=lambda sp: order[sp.path])
+    if root:
+        for spec in specs:
+            render(spec)
     print("Plotting whole genome depth done!!!\n\n")
     if len(regions_bed) > 0:
         print("Plotting depth for regions ...")
+        specs = []
         for target, segments in regions_bed.items():
             for segment in segments:
                 start, end = segment[0], segment[1]
                 path = f"{directory}/images/{prefix}.{target}:{start}-{end}.{image_type}"
                 if os.path.exists(path) and force == False:  # noqa: E712
                     sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+                if target not in depths_list[0]:
+                    continue                                             # another rank holds that contig
                 averaged, y_frac, y_min, y_max = pipeline.pre_plot_base(depths_list, max_depths, window_size, start,
                                                                         region=(target, start, end))
-                render(figure_spec(depths_list, target, averaged, mean_depths, y_frac, start, depth_min, dist_percent, y_min,
-                                   y_max, image_type, directory, prefix, end, True, threshold))
+                specs.append(figure_spec(depths_list, target, averaged, mean_depths, y_frac, start, depth_min, dist_percent, y_min,
+                                         y_max, image_type, directory, prefix, end, True, threshold))
+        if sharded:
+            flat = [f"{directory}/images/{prefix}.{t}:{a}-{b}.{image_type}" for t, segs in regions_bed.items() for a, b in segs]
+            order = {pth: i for i, pth in enumerate(flat)}
+            specs = sorted((x for part in pipeline.SHARD.gather_objects(specs) for x in part), key=lambda sp: order[sp.path])
+        if root:
+            for spec in specs:
+                render(spec)
         print("Plotting depth for regions done!!!\n\n")

@@ -22,6 +22,69 @@ import torch
 import torch.distributed as dist
 
 
+class Context:
+    """One contig-sharded run of the command line: this process is rank `rank` of `world`, one process per GPU
+    (python -m torch.distributed.run --nproc-per-node N GCI.py ..., or GCI.py --gpus N which re-launches itself that way).
+    backend "nccl" = RCCL over xGMI; "gloo" (GCI_DIST_BACKEND=gloo) stages collectives through host memory, which is how
+    the two-rank tests run on a single GPU."""
+
+    def __init__(self):
+        import os
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("GCI_DIST_BACKEND", "nccl")
+        # the GPU of this rank: LOCAL_RANK, or GCI_DIST_DEVICE (all ranks on one device: tests)
+        self.device_index = int(os.environ.get("GCI_DIST_DEVICE", str(self.local_rank)))
+        self.owner: List[int] = []
+
+    @property
+    def root(self) -> bool:
+        return self.rank == 0
+
+    def init(self) -> None:
+        import os
+        if dist.is_initialized():
+            return
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "WARN"):
+            os.environ.pop("NCCL_DEBUG")                  # RCCL logs to stdout: keep the reference's transcript clean
+        if self.backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # single node: the container's hostname may not resolve
+        torch.cuda.set_device(self.device_index)
+        kw = dict(device_id=torch.device("cuda", self.device_index)) if self.backend == "nccl" else {}
+        dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+
+    def assign(self, lengths: Sequence[int]) -> List[int]:
+        """Longest-processing-time packing of the selected contigs; -> indices of the contigs this rank owns."""
+        self.owner = lpt_assign(lengths, self.world)
+        return [c for c, o in enumerate(self.owner) if o == self.rank]
+
+    def gather_objects(self, obj) -> list:
+        out: List[Optional[object]] = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def all_gather_bytes(self, t: torch.Tensor) -> torch.Tensor:
+        """all_gather_into_tensor of equally shaped device tensors; through host memory with the gloo backend."""
+        if self.backend == "nccl":
+            out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t.contiguous())
+            return out
+        h = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(self.world)]
+        dist.all_gather(parts, h)
+        return torch.cat(parts).to(t.device)
+
+    def all_reduce_sum(self, values: Sequence[int]) -> List[int]:
+        dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [int(x) for x in t.cpu().tolist()]
+
+
 def lpt_assign(lengths: Sequence[int], world: int) -> List[int]:
     """Owner rank of each contig: longest first onto the least loaded rank (ties -> lowest rank)."""
     load = [0] * world
@@ -63,12 +126,14 @@ class RecordExchange:
     Rank r's record i travels as global index r * max_n + i; K1 is called with
     rec_idx_base = r * max_n so `gci_rec.rec_idx` already is that global index."""
 
-    def __init__(self, n_local: int, name_bytes_local: int, device: torch.device, group=None):
+    def __init__(self, n_local: int, name_bytes_local: int, device: torch.device, group=None, via_host: bool = False):
+        """via_host: the collectives run on host copies (gloo backend with device tensors)."""
         self.group = group
+        self.via_host = via_host
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device
-        sizes = torch.tensor([n_local, name_bytes_local], dtype=torch.int64, device=device)
+        sizes = torch.tensor([n_local, name_bytes_local], dtype=torch.int64, device="cpu" if via_host else device)
         allsz = [torch.zeros_like(sizes) for _ in range(self.world)]
         dist.all_gather(allsz, sizes, group=group)
         self.counts = [int(s[0].item()) for s in allsz]
@@ -86,9 +151,16 @@ class RecordExchange:
 
     def gather(self) -> Gathered:
         """Call after filling send_recs[:n], send_names and send_off[:n + 1]."""
-        dist.all_gather_into_tensor(self.g_recs, self.send_recs, group=self.group)
-        dist.all_gather_into_tensor(self.g_names, self.send_names, group=self.group)
-        dist.all_gather_into_tensor(self.g_off, self.send_off, group=self.group)
+        if self.via_host:
+            for dst, src in ((self.g_recs, self.send_recs), (self.g_names, self.send_names), (self.g_off, self.send_off)):
+                h = src.cpu()
+                parts = [torch.empty_like(h) for _ in range(self.world)]
+                dist.all_gather(parts, h, group=self.group)
+                dst.copy_(torch.cat(parts).to(dst.device))
+        else:
+            dist.all_gather_into_tensor(self.g_recs, self.send_recs, group=self.group)
+            dist.all_gather_into_tensor(self.g_names, self.send_names, group=self.group)
+            dist.all_gather_into_tensor(self.g_off, self.send_off, group=self.group)
         goff = self.g_off + self._chunk_base
         idx = goff.view(self.world, self.max_n + 1)[:, :self.max_n].reshape(-1).contiguous()
         return Gathered(self.g_recs, self.g_names, idx, self.max_n)

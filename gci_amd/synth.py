@@ -526,7 +526,7 @@ def cig_lead_clip(rs: ReadSet, i: int) -> int:
 def write_bam_file(path: str, rs: ReadSet, level: int = 1, threads: int = 4) -> None:
     stream, _ = to_bam_stream(rs)
     bamfmt.write_bam_stream(path, stream, level=level, threads=threads)
-    bamfmt.write_bai(path + ".bai", len(rs.contigs))
+    bamfmt.write_bai(path + ".bai", len(rs.contigs), bam_path=path)
 
 
 def write_reference_fasta(path: str, contigs: Sequence[Tuple[str, int]], gaps: Optional[Dict[str, List[Tuple[int, int]]]] = None,

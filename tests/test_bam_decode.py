@@ -115,3 +115,34 @@ def test_bgzf_and_container_round_trip(tmp_path):
     assert bgzf.decompress(bgzf.compress(big, threads=3), threads=3, check_crc=True).tobytes() == big
     r = bam.decode_record(s, offs[12])
     assert len(r.cigar) == 3 and "CG" not in r.aux and r.n_cigar_field == 2
+
+
+def test_bai_written_and_read_back(tmp_path):
+    """write_bai / read_bai (SAM spec 5.2): per reference the virtual offsets of its first record and of the end of its
+    last one -- what the contig-sharded ingestion uses to inflate only a rank's share of a file."""
+    from gci_amd import synth
+    from gci_amd.formats import bgzf
+    contigs = (("a", 300_000), ("nothing_here", 40_000), ("b", 100_000), ("c", 5_000))
+    rs = synth.simulate_reads((("a", 300_000), ("b", 100_000), ("c", 5_000)), 15, "hifi", seed=4)
+    rs.ref_id = np.where(rs.ref_id >= 1, rs.ref_id + 1, rs.ref_id).astype(np.int32)        # contig 1 has no records
+    rs.contigs = contigs
+    p = str(tmp_path / "x.bam")
+    synth.write_bam_file(p, rs, level=6, threads=2)
+    idx = bam.read_bai(p + ".bai")
+    raw = open(p, "rb").read()
+    stream = bgzf.decompress(raw)
+    hdr = bam.parse_header(stream)
+    offs = bam.record_offsets(stream, hdr.first_record)
+    blocks = bgzf.scan_blocks(raw)
+    ustart = np.cumsum([0] + [b[2] for b in blocks])
+    cpos = [b[0] for b in blocks]
+    to_u = lambda v: int(ustart[cpos.index(v >> 16)]) + (v & 0xFFFF)        # noqa: E731
+    ref = np.array([int(stream[o + 4:o + 8].view(np.int32)[0]) for o in offs.tolist()])
+    assert len(idx) == 4 and idx[1] is None
+    for r in (0, 2, 3):
+        ii = np.flatnonzero(ref == r)
+        assert to_u(idx[r][0]) == offs[ii[0]]
+        assert to_u(idx[r][1]) == (offs[ii[-1] + 1] if ii[-1] + 1 < len(offs) else stream.shape[0])
+    assert bam.read_bai(str(tmp_path / "missing.bai")) is None
+    bam.write_bai(str(tmp_path / "empty.bai"), 3)
+    assert bam.read_bai(str(tmp_path / "empty.bai")) == [None, None, None]

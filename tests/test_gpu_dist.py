@@ -1,0 +1,52 @@
+"""The contig-sharded command line with two ranks: `python -m torch.distributed.run --nproc-per-node 2
+GCI.py ...` must write the files -- and rank 0 print the transcript -- of a single process, i.e. of the reference
+(tests/golden/*).  Run on ONE GPU: both ranks use device 0 (GCI_DIST_DEVICE) and the collectives go through host memory
+(GCI_DIST_BACKEND=gloo; RCCL refuses two ranks on one device), so every kernel, the per-contig ingestion through the
+BAM index, the record all-gather, the replicated join with its ownership filter, the gathered outputs and the integer
+all-reduce of the mean depth run for real."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, cli_args, expected, images, manifest, read_outputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_two_ranks(argv, port):
+    env = dict(os.environ, GCI_DIST_BACKEND="gloo", GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "GCI.py")] + argv[1:]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.parametrize("k,case", list(enumerate(["c3_two_bam", "c3_three_bam_chrs", "c4_two_paf", "c5_two_type", "c6_plot"])))
+def test_two_ranks_reproduce_the_reference(k, case, tmp_path):
+    out = str(tmp_path / "out")
+    r = run_two_ranks(cli_args(case, out), 29710 + k)
+    if r.returncode != 0:                                   # keep the whole story of both ranks
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "dist_%s.err" % case), "w").write(r.stderr)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got, want = read_outputs(out), expected(case)
+    assert sorted(got) == sorted(want)
+    for fn in want:
+        assert got[fn] == want[fn], fn
+    got_img, want_img = images(out), images(os.path.join(GOLDEN, case, "expected"))
+    assert sorted(got_img) == sorted(want_img)
+    for fn in want_img:
+        assert np.array_equal(got_img[fn], want_img[fn]), fn
+    stdout = "".join(l for l in r.stdout.splitlines(True) if not l.startswith("[Gloo]"))      # the gloo backend's own chatter
+    first, _, rest = stdout.partition("\n")
+    assert first.startswith("Used arguments:{")
+    inp = os.path.join(GOLDEN, case, "inputs")
+    assert rest.replace(out, "{OUT}").replace(inp, "{IN}") == manifest(case)["stdout"]
+
+
+def test_more_ranks_than_contigs_is_refused(tmp_path):
+    r = run_two_ranks(cli_args("c1_single_bam", str(tmp_path / "out")), 29731)
+    assert r.returncode != 0 and "2 GPUs for 1 contig(s)" in r.stderr
