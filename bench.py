@@ -60,6 +60,16 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=1,
                     help="chr19 workload, 1 GPU: N > 1 runs consecutive steps on N streams with a context each")
     ap.add_argument("--heads", action="store_true", help="chr19 workload: feed the heads stream instead of the whole stream")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend: nccl = RCCL over xGMI (one GPU per rank); gloo stages the collectives through "
+                         "host memory and lets several ranks share one GPU (GCI_DIST_DEVICE): correctness runs only")
+    ap.add_argument("--shared-names", type=float, default=0.0,
+                    help="N > 1, genome workload: this fraction of every rank's second file carries read names of the NEXT rank "
+                         "(a read aligned to contigs of two ranks): the name check then finds conflicts and every step takes "
+                         "the replicated join.  Default 0: names are unique to their rank")
+    ap.add_argument("--verify-oracle", action="store_true",
+                    help="N > 1, small --scale only: rank 0 collects every rank's input and three of its contigs' tracks and holds "
+                         "them against the oracle run over the whole (all ranks') files")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU name check / exchange and the all-reduce even with one rank (self-test)")
     ap.add_argument("--force-replicated", action="store_true",
@@ -69,6 +79,19 @@ def parse_args():
 
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+VIA_HOST = False      # --backend gloo: collectives on host copies
+
+
+def all_reduce(t, op):
+    import torch.distributed as dist
+    if not VIA_HOST:
+        dist.all_reduce(t, op=op)
+        return
+    h = t.cpu()
+    dist.all_reduce(h, op=op)
+    t.copy_(h)
 
 
 class Workload:
@@ -139,7 +162,7 @@ class Workload:
     def _setup_exchange(self):
         from gci_amd import shard
         nc = len(self.own)
-        self.ex = [shard.RecordExchange(n, nb, self.eng.device) for n, nb in zip(self.n_rec, self.name_bytes)]
+        self.ex = [shard.RecordExchange(n, nb, self.eng.device, via_host=VIA_HOST) for n, nb in zip(self.n_rec, self.name_bytes)]
         self.rec_base = [e.rec_idx_base for e in self.ex]
         self.recs = [e.send_recs for e in self.ex]            # K1 writes straight into the send buffers
         self.ivl = self.torch.empty((sum(self.world * e.max_n for e in self.ex), 4), dtype=self.torch.int32,
@@ -147,7 +170,7 @@ class Workload:
         # Both collectives of the step are synchronous ops on the hardware queue of the step's own kernels (tried: the
         # name check on a side stream, the all-reduce as an async op -- 20 - 45 us slower per step on this chip).
         self.check_names = shard.NameCheck(self.total_rec, self.eng.device, self.eng.hash_bucket, self.eng.hash_conflicts,
-                                           alternate=True)
+                                           alternate=True, via_host=VIA_HOST)
         self.check_names.n_conf = self.totals[nc + 1:nc + 2].view(self.torch.int32)[0:1]   # counted straight into the totals
 
     def step(self):
@@ -200,7 +223,7 @@ class Workload:
         if self.exchange:
             import torch.distributed as dist
             # ONE integer all-reduce per step, in place: the sums of depth (global mean depth = their total / bases)
-            dist.all_reduce(self.sums, op=dist.ReduceOp.SUM)
+            all_reduce(self.sums, dist.ReduceOp.SUM)
 
     def check(self):
         """Record-level status of the last step + output capacities; False when a name is shared between ranks."""
@@ -217,7 +240,7 @@ class Workload:
             import torch.distributed as dist
             nc = len(self.own)
             conf = self.totals[nc + 1:nc + 2].clone()            # every rank's count of hashes seen from two ranks
-            dist.all_reduce(conf, op=dist.ReduceOp.SUM)
+            all_reduce(conf, dist.ReduceOp.SUM)
             if int(conf.item()) > 0:
                 return False      # a query name is shared between ranks: the speculative local joins were not exact
         return True
@@ -254,9 +277,15 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
             ref = body[(offs[:, None] + np.arange(4, 8, dtype=np.uint64)[None, :]).astype(np.int64)].copy().view("<i4").reshape(-1)
             ref = np.where(ref >= 0, ref + rank * nper, ref).astype("<i4")
             body[(offs[:, None] + np.arange(4, 8, dtype=np.uint64)[None, :]).astype(np.int64)] = ref.view(np.uint8).reshape(-1, 4)
-            # read names unique to the rank: the prefix "m64011_gNN/" becomes "m6401R_gNN/" (same length)
-            body[(offs + np.uint64(36 + 5)).astype(np.int64)] = ord("0") + (rank % 10)
-            body[(offs + np.uint64(36 + 4)).astype(np.int64)] = ord("0") + (rank // 10 % 10)
+            # read names unique to the rank: the prefix "m64011_gNN/" becomes "m64RR_gNN/" with RR = the rank (same length)
+            owner = np.full(offs.shape[0], rank, dtype=np.int64)
+            if args.shared_names > 0 and fobj is inp.files[-1]:
+                # ... except that this fraction of the LAST file's records are reads of the next rank (every rank generated
+                # the same reads, so the name exists there): aligned to contigs of two ranks -> the join must drop them
+                rng = np.random.Generator(np.random.PCG64(977 + rank))
+                owner[rng.random(offs.shape[0]) < args.shared_names] = (rank + 1) % world
+            body[(offs + np.uint64(36 + 5)).astype(np.int64)] = (ord("0") + owner % 10).astype(np.uint8)
+            body[(offs + np.uint64(36 + 4)).astype(np.int64)] = (ord("0") + owner // 10 % 10).astype(np.uint8)
             fobj.stream = np.concatenate([hdr, body])
             fobj.offsets = offs + np.uint64(hdr.shape[0])
         contigs = all_contigs
@@ -271,7 +300,7 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
                           nper, sum(l for _, l in inp.contigs), " x %d haplotypes" % world if world > 1 else "", args.coverage),
                  algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)})
     w.aligned_bases = inp.aligned_bases
-    w.inp = inp if (rank == 0 and world == 1) else None
+    w.inp = inp if ((rank == 0 and world == 1) or args.verify_oracle) else None
     if w.inp is None:
         del inp
     return eng, w.layout(own)
@@ -464,6 +493,46 @@ def port_over_reference():
         return None
 
 
+def verify_against_oracle_multi_rank(w, args):
+    """--verify-oracle (N > 1): the oracle over the concatenation of all ranks' files (one global header, rank r's
+    records on its own contigs) against three contigs of every rank's track.  -> bool on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    from gci_amd.formats import bam as bamfmt
+    nper = len(w.own)
+    pick = [c for c in (nper - 1, nper - 4, nper - 5) if 0 <= c < nper]           # chrM, chr22, chr21 of this rank
+    mine = {"files": [], "tracks": {w.own[c]: _track_contig(w, c) for c in pick}}
+    for f in w.inp.files:
+        first = bamfmt.parse_header(f.stream).first_record
+        mine["files"].append((f.stream[first:].copy(), (f.offsets - np.uint64(first)).astype(np.uint64)))
+    parts = [None] * w.world
+    dist.all_gather_object(parts, mine)
+    if w.rank != 0:
+        return None
+    from oracle import gci_oracle as O
+    O.build()
+    names = [n for n, _ in w.contigs]
+    hdr = np.frombuffer(bamfmt.encode_header(names, [l for _, l in w.contigs]), dtype=np.uint8)
+    dicts, hq = [], set()
+    for k in range(len(mine["files"])):
+        bodies, offs, size = [hdr], [], int(hdr.shape[0])
+        for p in parts:
+            b, o = p["files"][k]
+            bodies.append(b)
+            offs.append(o + np.uint64(size))
+            size += int(b.shape[0])
+        d, h = O.bam_file_dict(np.concatenate(bodies), np.concatenate(offs), names, names, *FILTER, heads=True)
+        dicts.append(d)
+        hq |= h
+    file1 = O.name_join(dicts, hq, OVLP)
+    ok = True
+    for p in parts:
+        for c, got in p["tracks"].items():
+            t, L = w.contigs[c]
+            want = O.depth_build({q: s for q, s in file1.items() if s[0] == t}, {t: L}, FLANK)[t]
+            ok = ok and np.array_equal(got, want)
+    return bool(ok)
+
+
 # ---- SURVEY.md 8(d) numbers (2) and (3) ---------------------------------------------------------------------------
 
 def device_pipeline_number(eng, w):
@@ -548,9 +617,13 @@ def main():
     if needs_build() and local_rank == 0:
         build_hip()
 
+    global VIA_HOST
+    VIA_HOST = args.backend == "gloo"
+    device_index = int(os.environ.get("GCI_DIST_DEVICE", str(local_rank)))
+
     def eng_factory():
         """HIP context, process group and library context: created AFTER the host-side generation of the inputs."""
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device_index)
         if world > 1 or exchange:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             # RCCL logs to stdout: keep it off the channel on which rank 0 prints its ONE JSON line
@@ -559,10 +632,14 @@ def main():
             os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if args.backend == "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
             dist.barrier()                                  # (also: rank 0 has finished building the library)
         from gci_amd.device import Engine
-        return Engine(local_rank)
+        return Engine(device_index)
 
     from gci_amd import _lib
     make = make_genome_workload if args.workload == "genome" else make_chr19_workload
@@ -583,7 +660,7 @@ def main():
         for _ in range(args.inflight - 1):
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
-                e2 = Engine(local_rank, stream=st)
+                e2 = Engine(device_index, stream=st)
                 _, w2 = make_chr19_workload(None, rank, world, args, False, False, eng=e2)
                 for _ in range(max(1, args.warmup)):
                     w2.step()
@@ -627,10 +704,10 @@ def main():
             sys.exit("bench: a query name became shared between ranks during the timed region")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
         ab = torch.tensor([w.aligned_bases], dtype=torch.int64, device=eng.device)
-        dist.all_reduce(ab, op=dist.ReduceOp.SUM)
+        all_reduce(ab, dist.ReduceOp.SUM)
         aligned_total = int(ab.item())
     else:
         aligned_total = w.aligned_bases
@@ -692,6 +769,13 @@ def main():
         "kernel_us_per_launch": breakdown,
     }
 
+    if world > 1 and args.verify_oracle and args.workload == "genome":
+        ok = verify_against_oracle_multi_rank(w, args)
+        if rank == 0:
+            out["parity_vs_oracle_all_ranks"] = ok
+            if not ok:
+                print(json.dumps(out))
+                sys.exit("PARITY FAILURE: the multi-rank result differs from the oracle over all ranks' files")
     if rank == 0 and world == 1:
         if args.workload == "genome":
             ok, chosen = parity_genome(w)

@@ -178,13 +178,16 @@ class NameCheck:
     `bucket_fn(recs, n_parts, cap, out)` and `conflict_fn(buckets, n_parts, cap, n_conflicts)` are the two device
     operations (Engine.hash_bucket / Engine.hash_conflicts on the GPU)."""
 
-    def __init__(self, n_local: int, device: torch.device, bucket_fn, conflict_fn, group=None, alternate: bool = False):
+    def __init__(self, n_local: int, device: torch.device, bucket_fn, conflict_fn, group=None, alternate: bool = False,
+                 via_host: bool = False):
         """alternate: two send arrays used in turn, bucket_fn(recs, n_parts, cap, out, next_out) zeroes the count
-        words of the one the next call fills (Engine.hash_bucket: no clearing launch per step)."""
+        words of the one the next call fills (Engine.hash_bucket: no clearing launch per step).
+        via_host: the all-to-all runs on host copies (gloo backend with device tensors: two-rank tests on one GPU)."""
         self.group = group
+        self.via_host = via_host
         self.world = dist.get_world_size(group)
         self.bucket_fn, self.conflict_fn = bucket_fn, conflict_fn
-        n = torch.tensor([n_local], dtype=torch.int64, device=device)
+        n = torch.tensor([n_local], dtype=torch.int64, device="cpu" if via_host else device)
         alln = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(alln, n, group=group)
         max_n = max(int(x.item()) for x in alln)
@@ -204,11 +207,20 @@ class NameCheck:
             self.bucket_fn(recs, self.world, self.cap, self.send, self.send_alt)
         else:
             self.bucket_fn(recs, self.world, self.cap, self.send)
-        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self._all_to_all()
         if self.send_alt is not None:
             self.send, self.send_alt = self.send_alt, self.send
         self.conflict_fn(self.recv, self.world, self.cap, self.n_conf)
         return self.n_conf
+
+    def _all_to_all(self) -> None:
+        if not self.via_host:
+            dist.all_to_all_single(self.recv, self.send, group=self.group)
+            return
+        h_send = self.send.cpu()
+        h_recv = torch.empty_like(h_send)
+        dist.all_to_all_single(h_recv, h_send, group=self.group)
+        self.recv.copy_(h_recv)
 
     def enqueue_files(self, recs_per_file: Sequence[torch.Tensor]) -> torch.Tensor:
         """enqueue() for a rank that holds records of several input files: the hashes of all of them go into the same
@@ -218,7 +230,7 @@ class NameCheck:
             raise ValueError("NameCheck.enqueue_files needs alternate=True")
         for recs in recs_per_file:
             self.bucket_fn(recs, self.world, self.cap, self.send, self.send_alt)
-        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self._all_to_all()
         self.send, self.send_alt = self.send_alt, self.send
         self.conflict_fn(self.recv, self.world, self.cap, self.n_conf)
         return self.n_conf
