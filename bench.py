@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--verify-oracle", action="store_true",
                     help="N > 1, small --scale only: rank 0 collects every rank's input and three of its contigs' tracks and holds "
                          "them against the oracle run over the whole (all ranks') files")
+    ap.add_argument("--count-in-build", action="store_true",
+                    help="A/B: the join does not do the depth build's counting pass (gci_name_join instead of gci_name_join_count)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU name check / exchange and the all-reduce even with one rank (self-test)")
     ap.add_argument("--force-replicated", action="store_true",
@@ -208,8 +210,12 @@ class Workload:
                 jf[f].d_recs, jf[f].n_recs, jf[f].name_delta = self.recs[f].data_ptr(), self.n_rec[f], 36
                 jf[f].d_name_base, jf[f].d_name_off = self.d_bam[f].data_ptr(), self.d_off[f].data_ptr()
         # the join also does the counting pass of the depth build over the intervals it emits (gci_name_join_count)
-        chk(lib.gci_name_join_count(ctx, jf, F, OVLP, _p(self.contig_map), _p(self.ivl), int(self.ivl.shape[0]),
-                                    _p(self.count), _p(self.status[F:F + 1]), int(self.opts.flank)), "gci_name_join_count")
+        if self.opts.counted:
+            chk(lib.gci_name_join_count(ctx, jf, F, OVLP, _p(self.contig_map), _p(self.ivl), int(self.ivl.shape[0]),
+                                        _p(self.count), _p(self.status[F:F + 1]), int(self.opts.flank)), "gci_name_join_count")
+        else:
+            chk(lib.gci_name_join(ctx, jf, F, OVLP, _p(self.contig_map), _p(self.ivl), int(self.ivl.shape[0]),
+                                  _p(self.count), _p(self.status[F:F + 1])), "gci_name_join")
         # fused build: depth + per-contig sums + text byte offsets + issue-run boundaries from one pass over
         # the per-tile event buckets (no HBM re-read of the track), then depth + decimal text in the second
         o = self.opts
@@ -644,6 +650,8 @@ def main():
     from gci_amd import _lib
     make = make_genome_workload if args.workload == "genome" else make_chr19_workload
     eng, w = make(eng_factory, rank, world, args, exchange, args.force_replicated)
+    if args.count_in_build:
+        w.opts.counted = 0
 
     def fence():
         torch.cuda.synchronize()
