@@ -1,16 +1,21 @@
 // k_inflate.hip -- N1 on the GPU: BGZF members inflated by the device and the BAM record walk without its serial chain
 // (what pysam / htslib do for the reference at GCI.py:150-151).
 //
-// gci_bgzf_inflate_device: one wave per BGZF member (a gzip member of at most 64 KiB of payload, RFC 1951 / 1952).  DEFLATE
-// is a serial bit stream, so the parallelism is across members (56 k for a chr19 40x HiFi file, millions for a genome); inside
-// a member the wave decodes symbol by symbol (every lane holds the same state, so the LDS reads are broadcasts) and the
-// lanes share what is parallel: building the decode tables, copying a match, moving finished output to HBM.
-//   LDS per wave (= workgroup): a 32 KiB sliding window of the output (DEFLATE's maximum distance; a half is written
-//   to global memory with aligned 16-byte stores as soon as it is complete), 4 KiB of the member's input (refilled
-//   half by half, so the 32-bit bit-buffer refills never leave LDS), a 10-bit primary table for the literal / length code
-//   and an 8-bit one for distances; longer codes (rare) are decoded bit by bit from the canonical first-code tables.
-//   CRC-32 of the output is verified per member (as htslib does): every lane the CRC of its share of a 16 KiB half,
-//   the shares concatenated with the GF(2) rule crc(A||B) = crc(A) * x^(8|B|) + crc(B).
+// gci_bgzf_inflate_device.  DEFLATE is a serial bit stream: the parallelism of a BGZF file is ACROSS its members (gzip
+// members of at most 64 KiB, RFC 1951 / 1952: 56 k for a chr19 40x HiFi file, millions for a genome).  A first version gave
+// every member a whole wave (window and tables in LDS, every lane holding the same decoder state): correct, and bound by
+// instruction issue on one lane's worth of work -- ~50 instructions per symbol, one wave per SIMD because of the 32 KiB
+// window -- i.e. no faster than 32 host threads (5.9 GB/s).  This version gives every member ONE LANE:
+//   * decoder state (bit buffer, positions) in registers; the lane's decode tables in LDS (9-bit primary table for
+//     literals / lengths, 7-bit for distances, canonical first-code tables for the longer codes: 2.5 KB per member,
+//     INF_LANES members per workgroup);
+//   * no window: the output buffer in HBM is the window (a member's matches only reach back into its own output; a wave's
+//     memory operations are issued in order, so a lane reads back what it has just written);
+//   * the compressed bytes through naturally aligned dword loads re-aligned in registers.
+// Lanes diverge (literal / match, code lengths), but every wave instruction now serves INF_LANES members, and a CU holds
+// 3 x INF_LANES of them.  Stored, fixed and dynamic blocks.  Every member's output length is checked here, its CRC-32 by
+// k_bgzf_crc: one wave per member over the finished output, every lane the CRC register of its share, the shares
+// concatenated with the GF(2) rule crc(A||B) = crc(A) * x^(8|B|) + crc(B) (as htslib verifies every block).
 //
 // gci_bam_record_offsets_device: the offsets of the records of an inflated BAM stream WITHOUT walking the block_size
 // chain serially (137 k dependent loads of ~1 us each at chr19): every byte position is tested for "a record could
@@ -24,11 +29,7 @@
 
 namespace {
 
-#define INF_WIN 32768u
-#define INF_HALF 16384u
-#define INF_IN 2048u
-#define LIT_BITS 10
-#define DIST_BITS 8
+#define LIT_BITS 8
 
 __constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -50,319 +51,387 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)   // a * b mo
     return r;
 }
 
-// Canonical Huffman code of one alphabet: per length the first code and the index of its first symbol in `sorted`
-// (RFC 1951 3.2.2), and a primary table indexed by the next PRIMARY bits of the stream (codes are packed starting from
-// their most significant bit, i.e. bit reversed in the LSB-first bit buffer): entry = symbol | length << 9, 0 = the code is
-// longer than PRIMARY bits (or unused).
-struct Canon { uint16_t count[16], first_code[16], first_idx[16], next[16]; };
+// Canonical Huffman code of one alphabet (RFC 1951 3.2.2), without a loop over the code lengths: with c = the next 15 bits
+// read as a code (first bit highest), the codes of length l are exactly limit[l-1] <= c < limit[l], limit[l] = (first code
+// of length l + their number) << (15 - l) -- non-decreasing in l -- so the length is 1 + the number of limits <= c (16: no
+// such code), and the symbol is sorted[off[l] + (c >> (15 - l))], off[l] = index of the first symbol of length l in
+// `sorted` - its code.  next[l]: one past the last symbol of length l in `sorted`.
+// The literal / length alphabet also has a primary table indexed by the next LIT_BITS bits of the stream (codes are packed
+// from their most significant bit, i.e. bit reversed in the LSB-first bit buffer): entry = symbol | length << 9, 0 = the
+// code is longer (or unused).
+struct alignas(16) Canon { uint16_t limit[16]; int16_t off[16]; uint16_t next[16]; };
+
+// What one member's decoder keeps in LDS: 1.3 KB, which is what bounds the members a CU decodes at a time.  The code
+// lengths of a block are only needed until its codes are built and share the primary table's space.
+struct alignas(16) LaneTabs {
+    union {
+        uint16_t lit_tab[1 << LIT_BITS];
+        uint8_t lens[352];          // [0, 19): the code-length code; [32, 32 + 286 + 30): both alphabets
+    };
+    uint16_t lit_sorted[288], dist_sorted[32];
+    Canon lit_cn, dist_cn;
+};
+static_assert(sizeof(uint16_t) << LIT_BITS >= 352, "the code lengths must fit under the primary table");
 
 __device__ __forceinline__ uint32_t bit_reverse(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
-// Every lane runs this with the same arguments (lane 0 writes): lens[0 .. n) in LDS -> canon, sorted symbols, primary table.
-// false: over-subscribed code.  (An incomplete code is accepted as zlib accepts it for a single distance code.)
-template <int PRIMARY>
-__device__ bool build_code(const uint8_t* lens, int n, Canon& cn, uint16_t* sorted, uint16_t* table, int lane)
+// lens[0 .. n) -> limits, offsets and the symbols sorted by code; false: over-subscribed code
+__device__ bool build_code(const uint8_t* lens, int n, Canon& cn, uint16_t* sorted)
 {
-    for (int i = lane; i < (1 << PRIMARY); i += 64) table[i] = 0;
-    if (lane < 16) { cn.count[lane] = 0; }
-    __syncthreads();
-    if (lane == 0) {
-        for (int i = 0; i < n; i++) cn.count[lens[i]]++;
-        cn.count[0] = 0;
-        uint32_t code = 0, idx = 0;
-        for (int l = 1; l < 16; l++) {
-            code = (code + cn.count[l - 1]) << 1;
-            cn.first_code[l] = (uint16_t)code;
-            cn.first_idx[l] = (uint16_t)idx;
-            idx += cn.count[l];
-        }
-    }
-    __syncthreads();
-    // over-subscription: sum count[l] * 2^(15 - l) must not exceed 2^15
-    uint32_t left = 1u << 15;
+    for (int l = 0; l < 16; l++) cn.next[l] = 0;
+    for (int i = 0; i < n; i++) cn.next[lens[i]]++;
+    uint32_t code = 0, idx = 0, left = 1u << 15, prev = 0;
     bool ok = true;
-    for (int l = 1; l < 16; l++) { const uint32_t need = (uint32_t)cn.count[l] << (15 - l); if (need > left) ok = false; else left -= need; }
-    if (!ok) return false;
-    if (lane == 0) {
-        for (int l = 0; l < 16; l++) cn.next[l] = 0;
-        for (int s = 0; s < n; s++) {
-            const int l = lens[s];
-            if (!l) continue;
-            const uint32_t rank = cn.next[l]++;
-            sorted[cn.first_idx[l] + rank] = (uint16_t)s;
-            if (l <= PRIMARY) {
-                const uint32_t rev = bit_reverse(cn.first_code[l] + rank, l);
-                for (uint32_t k = rev; k < (1u << PRIMARY); k += 1u << l) table[k] = (uint16_t)(s | (l << 9));
-            }
-        }
+    cn.limit[0] = 0; cn.off[0] = 0; cn.next[0] = 0;
+    for (int l = 1; l < 16; l++) {
+        const uint32_t cnt = cn.next[l];
+        code = (code + prev) << 1;
+        cn.limit[l] = (uint16_t)((code + cnt) << (15 - l));
+        cn.off[l] = (int16_t)((int)idx - (int)code);
+        cn.next[l] = (uint16_t)idx;
+        idx += cnt; prev = cnt;
+        const uint32_t need = cnt << (15 - l);                           // sum count[l] * 2^(15 - l) must not exceed 2^15
+        if (need > left) ok = false; else left -= need;
     }
-    __syncthreads();
+    if (!ok) return false;
+    for (int s = 0; s < n; s++) {
+        const int l = lens[s];
+        if (l) sorted[cn.next[l]++] = (uint16_t)s;
+    }
     return true;
 }
 
-struct Bits {
-    unsigned long long bb;      // bit buffer, next bit = bit 0
-    int bn;                     // valid bits
-    uint32_t ip;                // next payload byte to take (offset inside the payload)
-};
-
-}  // namespace
-
-// One workgroup = one wave = one member.
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
-                                                     const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
-                                                     uint64_t out_cap, int check_crc, unsigned long long* __restrict__ status)
+// the primary table of the codes of at most LIT_BITS bits, from the sorted symbols (the code lengths are gone by now)
+__device__ void build_table(const Canon& cn, const uint16_t* sorted, uint16_t* table)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t win[INF_WIN];
-    __shared__ __attribute__((aligned(16))) uint8_t inb[INF_IN + 16];
-    __shared__ uint16_t lit_tab[1 << LIT_BITS], dist_tab[1 << DIST_BITS];
-    __shared__ uint16_t lit_sorted[288], dist_sorted[32];
-    __shared__ uint8_t lens[384];                                 // [0, 19): code-length code; [32, 32 + 286 + 30): both alphabets
-    __shared__ Canon lit_cn, dist_cn, cl_cn;
-    __shared__ uint16_t cl_tab[1 << 7], cl_sorted[19];
-    __shared__ uint32_t crc_tab[16];                              // CRC-32 a nibble at a time (LDS is needed for the window)
-    const int lane = threadIdx.x;
-    const uint32_t m = blockIdx.x;
-    if (m >= n_members) return;
-    const uint64_t pos = member_pos[m], pos_next = member_pos[m + 1];
-    const uint64_t o0 = out_off[m];
-    const uint32_t isize = (uint32_t)(out_off[m + 1] - o0);
-    auto fail = [&](int code) __attribute__((always_inline)) { if (lane == 0) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-code)); };
-    if (pos_next < pos + 26 || o0 + isize > out_cap || isize > 65536u) { fail(GCI_E_MALFORMED); return; }
-    const uint32_t xlen = (uint32_t)raw[pos + 10] | ((uint32_t)raw[pos + 11] << 8);
-    const uint64_t pay0 = pos + 12 + xlen;
-    if (pay0 + 8 > pos_next || raw[pos] != 0x1f || raw[pos + 1] != 0x8b || raw[pos + 2] != 8) { fail(GCI_E_MALFORMED); return; }
-    const uint32_t pay_len = (uint32_t)(pos_next - 8 - pay0);
-    const uint8_t* __restrict__ pay = raw + pay0;
-    if (check_crc && lane < 16) {
-        uint32_t c = (uint32_t)lane;
-        for (int k = 0; k < 4; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
-        crc_tab[lane] = c;
-    }
-    // ---- input window: inb holds payload bytes [in_base, in_base + INF_IN) ---------------------------------------------
-    uint32_t in_base = 0;
-    auto load_in = [&](uint32_t from, uint32_t to_slot, uint32_t n) __attribute__((always_inline)) {          // payload[from .. from + n) -> inb[to_slot ..]
-        for (uint32_t i = lane; i < n; i += 64) inb[to_slot + i] = from + i < pay_len ? pay[from + i] : 0;
-    };
-    load_in(0, 0, INF_IN + 16);
-    __syncthreads();
-    Bits B;
-    B.bb = 0; B.bn = 0; B.ip = 0;
-    bool bad = false;
-    // at least 32 valid bits (zero bits past the end of the payload: an over-read is caught by the ip check at the end)
-    auto need32 = [&]() __attribute__((always_inline)) {
-        if (B.bn < 32) {
-            if (B.ip - in_base > INF_IN - 8) {                                 // slide: the upper half moves down, a new half comes in
-                const uint32_t keep_from = (B.ip - in_base) & ~15u;            // 16-byte granules keep the copies aligned
-                for (uint32_t i = lane * 16u; keep_from + i < INF_IN + 16; i += 64 * 16u)
-                    *reinterpret_cast<uint4*>(inb + i) = *reinterpret_cast<const uint4*>(inb + keep_from + i);
-                __syncthreads();
-                const uint32_t have = INF_IN + 16 - keep_from;
-                in_base += keep_from;
-                load_in(in_base + have, have, keep_from);
-                __syncthreads();
-            }
-            uint32_t w;
-            __builtin_memcpy(&w, inb + (B.ip - in_base), 4);
-            B.bb |= (unsigned long long)w << B.bn;
-            B.ip += 4; B.bn += 32;
+    for (int i = 0; i < (1 << LIT_BITS); i++) table[i] = 0;
+    uint32_t idx = 0;
+    for (int l = 1; l <= LIT_BITS; l++) {
+        const uint32_t end = cn.next[l];
+        const int off = cn.off[l];
+        for (; idx < end; idx++) {
+            const uint32_t e = (uint32_t)sorted[idx] | ((uint32_t)l << 9);
+            for (uint32_t k = bit_reverse((uint32_t)((int)idx - off), l); k < (1u << LIT_BITS); k += 1u << l) table[k] = (uint16_t)e;
         }
-    };
-    auto take = [&](int n) __attribute__((always_inline)) -> uint32_t { const uint32_t v = (uint32_t)(B.bb & ((1ull << n) - 1ull)); B.bb >>= n; B.bn -= n; return v; };
-    // one symbol of a code: primary table, else bit by bit along the canonical first codes (codes of PRIMARY + 1 .. 15 bits)
-    auto decode = [&](const uint16_t* table, int primary, const Canon& cn, const uint16_t* sorted) __attribute__((always_inline)) -> int {
-        const uint32_t e = table[(uint32_t)B.bb & ((1u << primary) - 1u)];
-        if (e) { const int l = (int)(e >> 9); B.bb >>= l; B.bn -= l; return (int)(e & 0x1FFu); }
-        uint32_t code = 0;
-        for (int l = 1; l < 16; l++) {
-            code = (code << 1) | (uint32_t)((B.bb >> (l - 1)) & 1ull);
-            const uint32_t rel = code - cn.first_code[l];
-            if (l > primary && cn.count[l] && rel < cn.count[l]) { B.bb >>= l; B.bn -= l; return (int)sorted[cn.first_idx[l] + rel]; }
-        }
-        return -1;
-    };
-    uint32_t op = 0;                                            // bytes of output so far
-    uint32_t flushed = 0;                                       // ... of which in global memory
-    uint32_t crc = 0;                                           // finalised CRC-32 of the flushed output
-    uint8_t* __restrict__ dst = out + o0;
-    // a complete part [flushed, upto) of the window -> global memory (+ its CRC); parts end at INF_HALF boundaries or at the end
-    auto flush = [&](uint32_t upto) __attribute__((always_inline)) {
-        __syncthreads();
-        const uint32_t n = upto - flushed;
-        // head bytes up to the next 16-byte boundary of the DESTINATION, then aligned 16-byte stores, then the tail
-        const uint64_t d0 = (uint64_t)(uintptr_t)(dst + flushed);
-        uint32_t head = (uint32_t)((16 - (d0 & 15)) & 15);
-        if (head > n) head = n;
-        for (uint32_t i = lane; i < head; i += 64) dst[flushed + i] = win[(flushed + i) & (INF_WIN - 1)];
-        const uint32_t body = (n - head) & ~15u;
-        for (uint32_t i = lane * 16u; i < body; i += 64 * 16u) {
-            const uint32_t s = flushed + head + i;
-            uint32_t w[4];                                                     // (a part never wraps around the window: it ends at a half boundary)
-#pragma unroll
-            for (int k = 0; k < 4; k++) __builtin_memcpy(&w[k], win + ((s & (INF_WIN - 1)) + 4 * k), 4);
-            *reinterpret_cast<uint4*>(dst + s) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        for (uint32_t i = head + body + lane; i < n; i += 64) dst[flushed + i] = win[(flushed + i) & (INF_WIN - 1)];
-        if (check_crc && n) {
-            // lane l: the CRC register of its share, started at 0 (pure polynomial remainder); shares concatenate as
-            // reg(A||B) = reg(A) * x^(8|B|) + reg(B); the running value `crc` is kept finalised-free the same way
-            const uint32_t per = (n + 63) / 64;
-            const uint32_t a = min(n, (uint32_t)lane * per), b = min(n, a + per);
-            uint32_t c = 0;
-            for (uint32_t i = a; i < b; i++) {
-                c ^= win[(flushed + i) & (INF_WIN - 1)];
-                c = crc_tab[c & 0xFu] ^ (c >> 4);
-                c = crc_tab[c & 0xFu] ^ (c >> 4);
-            }
-            // x^(8 len) for len = b - a, by square and multiply on x^8
-            uint32_t xp = 0x80000000u, base = 0x00800000u;                    // x^0, x^8 (reflected)
-            for (uint32_t e = b - a; e; e >>= 1) { if (e & 1u) xp = gf_mul(xp, base); base = gf_mul(base, base); }
-            // ordered product over the lanes (tree): (c, x) . (c', x') = (c * x' + c', x * x')
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t oc = (uint32_t)__shfl_down((int)c, d, 64), ox = (uint32_t)__shfl_down((int)xp, d, 64);
-                if ((lane & (2 * d - 1)) == 0) { c = gf_mul(c, ox) ^ oc; xp = gf_mul(xp, ox); }
-            }
-            const uint32_t part_c = (uint32_t)__shfl((int)c, 0, 64), part_x = (uint32_t)__shfl((int)xp, 0, 64);
-            crc = gf_mul(crc, part_x) ^ part_c;
-        }
-        flushed = upto;
-        __syncthreads();
-    };
-    auto emit_literal = [&](uint32_t v) __attribute__((always_inline)) {
-        if (lane == 0) win[op & (INF_WIN - 1)] = (uint8_t)v;
-        op++;
-        if ((op & (INF_HALF - 1)) == 0) flush(op);
-    };
-    // ---- blocks ------------------------------------------------------------------------------------------------------
-    for (bool last = false; !last && !bad;) {
-        need32();
-        last = take(1) != 0;
-        const uint32_t type = take(2);
-        if (type == 0) {                                                     // stored
-            take(B.bn & 7);                                                  // to the byte boundary
-            need32();
-            const uint32_t len = take(16), nlen = take(16);
-            if ((len ^ 0xFFFFu) != nlen || op + len > isize) { bad = true; break; }
-            // the bytes still in the bit buffer first, then straight from the payload
-            uint32_t done = 0;
-            while (done < len && B.bn >= 8) { emit_literal(take(8)); done++; }
-            if (done < len) {                                                // the bit buffer is empty (it held whole bytes): from the payload
-                B.bb = 0; B.bn = 0;
-                while (done < len) {
-                    const uint32_t room = INF_HALF - (op & (INF_HALF - 1));  // up to the next half boundary
-                    const uint32_t n = min(len - done, room);
-                    if (B.ip + n > pay_len) { bad = true; break; }
-                    for (uint32_t i = lane; i < n; i += 64) win[(op + i) & (INF_WIN - 1)] = pay[B.ip + i];
-                    B.ip += n; op += n; done += n;
-                    if ((op & (INF_HALF - 1)) == 0) flush(op);
-                }
-                // the input window no longer matches ip: reload it
-                in_base = B.ip & ~15u;
-                __syncthreads();
-                load_in(in_base, 0, INF_IN + 16);
-                __syncthreads();
-            }
-            continue;
-        }
-        if (type == 3) { bad = true; break; }
-        if (type == 1) {                                                     // fixed code (RFC 1951 3.2.6)
-            for (int i = lane; i < 288; i += 64) lens[32 + i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-            for (int i = lane; i < 30; i += 64) lens[32 + 288 + i] = 5;
-            __syncthreads();
-            if (!build_code<LIT_BITS>(lens + 32, 288, lit_cn, lit_sorted, lit_tab, lane) ||
-                !build_code<DIST_BITS>(lens + 32 + 288, 30, dist_cn, dist_sorted, dist_tab, lane)) { bad = true; break; }
-        } else {                                                             // dynamic code (3.2.7)
-            need32();
-            const int hlit = (int)take(5) + 257, hdist = (int)take(5) + 1, hclen = (int)take(4) + 4;
-            if (hlit > 286 || hdist > 30) { bad = true; break; }
-            if (lane < 19) lens[lane] = 0;
-            __syncthreads();
-            for (int i = 0; i < hclen; i++) { need32(); const uint32_t v = take(3); if (lane == 0) lens[c_clen_order[i]] = (uint8_t)v; }
-            __syncthreads();
-            if (!build_code<7>(lens, 19, cl_cn, cl_sorted, cl_tab, lane)) { bad = true; break; }
-            // the code lengths of both alphabets, run-length coded; lens[32 ..] so that lens[0 .. 19) stays the code-length code
-            int n = 0, prev = 0;
-            uint8_t* ll = lens + 32;
-            while (n < hlit + hdist) {
-                need32();
-                const int sym = decode(cl_tab, 7, cl_cn, cl_sorted);
-                if (sym < 0) { bad = true; break; }
-                int rep = 1, val = sym;
-                if (sym == 16) { if (n == 0) { bad = true; break; } val = prev; rep = 3 + (int)take(2); }
-                else if (sym == 17) { val = 0; rep = 3 + (int)take(3); }
-                else if (sym == 18) { val = 0; rep = 11 + (int)take(7); }
-                if (n + rep > hlit + hdist) { bad = true; break; }
-                for (int i = lane; i < rep; i += 64) ll[n + i] = (uint8_t)val;
-                n += rep; prev = val;
-            }
-            if (bad) break;
-            __syncthreads();
-            if (ll[256] == 0) { bad = true; break; }                          // no end-of-block code
-            if (!build_code<LIT_BITS>(ll, hlit, lit_cn, lit_sorted, lit_tab, lane) ||
-                !build_code<DIST_BITS>(ll + hlit, hdist, dist_cn, dist_sorted, dist_tab, lane)) { bad = true; break; }
-        }
-        // ---- symbols of the block ------------------------------------------------------------------------------------------
-        for (;;) {
-            need32();
-            const int sym = decode(lit_tab, LIT_BITS, lit_cn, lit_sorted);
-            if (sym < 0 || sym > 285) { bad = true; break; }
-            if (sym < 256) {
-                if (op >= isize) { bad = true; break; }
-                emit_literal((uint32_t)sym);
-                continue;
-            }
-            if (sym == 256) break;
-            const uint32_t len = c_len_base[sym - 257] + take(c_len_extra[sym - 257]);
-            need32();
-            const int ds = decode(dist_tab, DIST_BITS, dist_cn, dist_sorted);
-            if (ds < 0 || ds > 29) { bad = true; break; }
-            const uint32_t dist = c_dist_base[ds] + take(c_dist_extra[ds]);
-            if (dist > op || op + len > isize) { bad = true; break; }
-            // the match, at most up to the next half boundary at a time; byte i comes from i mod dist when it overlaps
-            __syncthreads();
-            uint32_t done = 0;
-            while (done < len) {
-                const uint32_t room = INF_HALF - (op & (INF_HALF - 1));
-                const uint32_t n = min(len - done, room);
-                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    uint8_t v = 0;
-                    // a chunk of 64 bytes may only read what is already written: split at multiples of dist when dist < 64
-                    if (i < n) v = win[(op - dist + ((done + i) % dist) - done) & (INF_WIN - 1)];
-                    __syncthreads();
-                    if (i < n) win[(op + i) & (INF_WIN - 1)] = v;
-                    __syncthreads();
-                }
-                op += n; done += n;
-                if ((op & (INF_HALF - 1)) == 0) flush(op);
-            }
-        }
-    }
-    if (!bad && op != isize) bad = true;
-    if (!bad && B.ip - (uint32_t)(B.bn >> 3) > pay_len) bad = true;            // the stream ran past the payload
-    if (bad) { fail(GCI_E_MALFORMED); return; }
-    if (flushed < op) flush(op);
-    if (check_crc) {
-        // `crc` is the remainder of the message polynomial; the CRC-32 of n bytes is that of the message with the first 32
-        // bits complemented, complemented: crc32(M) = reg_ff(M) ^ ~0 with reg_ff(M) = reg_0(M) ^ (0xFFFFFFFF * x^(8n))
-        uint32_t xp = 0x80000000u, base = 0x00800000u;
-        for (uint32_t e = isize; e; e >>= 1) { if (e & 1u) xp = gf_mul(xp, base); base = gf_mul(base, base); }
-        const uint32_t got = crc ^ gf_mul(0xFFFFFFFFu, xp) ^ 0xFFFFFFFFu;
-        const uint64_t tp = pos_next - 8;
-        const uint32_t want = (uint32_t)raw[tp] | ((uint32_t)raw[tp + 1] << 8) | ((uint32_t)raw[tp + 2] << 16) | ((uint32_t)raw[tp + 3] << 24);
-        if (got != want) fail(GCI_E_MALFORMED);
     }
 }
 
+// The compressed bytes arrive as naturally aligned 16-byte loads, one block AHEAD of the one being consumed (the load
+// issued when a block is taken up is needed 16 payload bytes later), and move into the bit buffer a dword at a time.
+struct Bits {
+    unsigned long long bb;      // bit buffer, next bit = bit 0
+    int bn;                     // valid bits
+    uint4 res;                  // the block being consumed (lowest dword first)
+    int rn;                     // dwords left in res
+    uint4 nxt;                  // the block after it
+    const uint4* q;             // the block after nxt
+    const uint4* qlim;          // the block holding the member's last byte: nothing is loaded beyond it
+    uint32_t taken;             // dwords moved out of res so far
+};
+
+__device__ __forceinline__ void next_dword(Bits& B)
+{
+    B.res.x = B.res.y; B.res.y = B.res.z; B.res.z = B.res.w;
+    B.rn--; B.taken++;
+    if (B.rn == 0) {
+        B.res = B.nxt; B.rn = 4;
+        B.nxt = *B.q;
+        B.q = B.q < B.qlim ? B.q + 1 : B.q;
+    }
+}
+
+// at least 32 valid bits (bits past the payload are caught by the position check at the end of the member)
+__device__ __forceinline__ void need32(Bits& B)
+{
+    if (B.bn < 32) {
+        B.bb |= (unsigned long long)B.res.x << B.bn;
+        B.bn += 32;
+        next_dword(B);
+    }
+}
+
+// eight bytes at any address (the target handles unaligned global accesses)
+__device__ __forceinline__ unsigned long long ld8(const uint8_t* p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void st8(uint8_t* p, unsigned long long v) { __builtin_memcpy(p, &v, 8); }
+
+__device__ __forceinline__ uint32_t take(Bits& B, int n)
+{
+    const uint32_t v = (uint32_t)(B.bb & ((1ull << n) - 1ull));
+    B.bb >>= n; B.bn -= n;
+    return v;
+}
+
+// one symbol: the primary table (PRIMARY > 0), else the limits of the lengths PRIMARY + 1 .. MAXL (16-byte LDS reads)
+template <int PRIMARY, int MAXL>
+__device__ __forceinline__ int decode(Bits& B, const uint16_t* table, const Canon& cn, const uint16_t* sorted)
+{
+    if (PRIMARY) {
+        const uint32_t e = table[(uint32_t)B.bb & ((1u << PRIMARY) - 1u)];
+        if (e) { const int l = (int)(e >> 9); B.bb >>= l; B.bn -= l; return (int)(e & 0x1FFu); }
+    }
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (PRIMARY + 1 < 8) { const uint4 v = *reinterpret_cast<const uint4*>(&cn.limit[0]); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    if (MAXL >= 8) { const uint4 v = *reinterpret_cast<const uint4*>(&cn.limit[8]); w[4] = v.x; w[5] = v.y; w[6] = v.z; w[7] = v.w; }
+    const uint32_t c = __brev((uint32_t)B.bb) >> 17;
+    int l = PRIMARY + 1;
+#pragma unroll
+    for (int k = PRIMARY + 1; k <= MAXL; k++) l += c >= ((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) ? 1 : 0;
+    if (l > MAXL) return -1;
+    const int at = (int)cn.off[l] + (int)(c >> (15 - l));
+    B.bb >>= l; B.bn -= l;
+    return (int)sorted[at];
+}
+
+}  // namespace
+
+// One lane = one member; INF_LANES members per workgroup (one wave; its other lanes leave at once).
+template <int INF_LANES>
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
+                                                     const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
+                                                     uint64_t out_cap, unsigned long long* __restrict__ status)
+{
+    __shared__ LaneTabs tabs[INF_LANES];
+    const int lane = threadIdx.x;
+    if (lane >= INF_LANES) return;
+    const uint32_t m = blockIdx.x * INF_LANES + lane;
+    if (m >= n_members) return;
+    LaneTabs& T = tabs[lane];
+    const uint64_t pos = member_pos[m], pos_next = member_pos[m + 1];
+    const uint64_t o0 = out_off[m];
+    const uint32_t isize = (uint32_t)(out_off[m + 1] - o0);
+    bool bad = pos_next < pos + 26 || o0 + isize > out_cap || isize > 65536u;
+    uint32_t pay_len = 0, head = 0;
+    Bits B;
+    B.bb = 0; B.bn = 0; B.rn = 4; B.taken = 0;
+    if (!bad) {
+        const uint32_t xlen = (uint32_t)raw[pos + 10] | ((uint32_t)raw[pos + 11] << 8);
+        const uint64_t pay0 = pos + 12 + xlen;
+        bad = pay0 + 8 > pos_next || raw[pos] != 0x1f || raw[pos + 1] != 0x8b || raw[pos + 2] != 8;
+        if (!bad) {
+            pay_len = (uint32_t)(pos_next - 8 - pay0);
+            const uintptr_t a0 = (uintptr_t)(raw + pay0);
+            head = (uint32_t)(a0 & 15u);
+            const uint4* base = reinterpret_cast<const uint4*>(a0 - head);
+            B.qlim = reinterpret_cast<const uint4*>((uintptr_t)(raw + pos_next - 1) & ~(uintptr_t)15);
+            B.res = base[0];
+            B.q = base < B.qlim ? base + 1 : base;
+            B.nxt = *B.q;
+            B.q = B.q < B.qlim ? B.q + 1 : B.q;
+            for (uint32_t k = 0; k < (head >> 2); k++) next_dword(B);          // the bytes in front of the payload
+            need32(B);
+            B.bb >>= (head & 3u) * 8; B.bn -= (int)(head & 3u) * 8;
+        }
+    }
+    uint8_t* __restrict__ dst = out + o0;
+    uint8_t* const dst_end = dst + isize;
+    // output: literals gather in a register and leave as one 8-byte store (any address).  A partial group is stored as 8
+    // bytes as well where that stays inside the member's output: what lies behind `op` is overwritten before it is read.
+    unsigned long long ob = 0;
+    uint32_t oc = 0, op = 0;
+    auto flush = [&]() __attribute__((always_inline)) {
+        uint8_t* at = dst + op - oc;
+        if (oc && at + 8 <= dst_end) st8(at, ob);
+        else for (uint32_t i = 0; i < oc; i++) at[i] = (uint8_t)(ob >> (8 * i));
+        ob = 0; oc = 0;
+    };
+    auto emit = [&](uint32_t byte) __attribute__((always_inline)) {
+        ob |= (unsigned long long)byte << (8 * oc);
+        oc++; op++;
+        if (oc == 8) { st8(dst + op - 8, ob); ob = 0; oc = 0; }
+    };
+    for (bool last = false; !last && !bad;) {
+        need32(B);
+        last = take(B, 1) != 0;
+        const uint32_t type = take(B, 2);
+        if (type == 0) {                                                     // stored
+            take(B, B.bn & 7);                                               // to the byte boundary
+            need32(B);
+            const uint32_t len = take(B, 16), nlen = take(B, 16);
+            if ((len ^ 0xFFFFu) != nlen || op + len > isize) { bad = true; break; }
+            for (uint32_t i = 0; i < len; i++) { need32(B); emit(take(B, 8)); }
+            continue;
+        }
+        if (type == 3) { bad = true; break; }
+        uint8_t* ll = T.lens + 32;
+        if (type == 1) {                                                     // fixed code (RFC 1951 3.2.6)
+            for (int i = 0; i < 288; i++) ll[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            for (int i = 0; i < 30; i++) ll[288 + i] = 5;
+            if (!build_code(ll, 288, T.lit_cn, T.lit_sorted) || !build_code(ll + 288, 30, T.dist_cn, T.dist_sorted)) { bad = true; break; }
+        } else {                                                             // dynamic code (3.2.7)
+            need32(B);
+            const int hlit = (int)take(B, 5) + 257, hdist = (int)take(B, 5) + 1, hclen = (int)take(B, 4) + 4;
+            if (hlit > 286 || hdist > 30) { bad = true; break; }
+            for (int i = 0; i < 19; i++) T.lens[i] = 0;
+            for (int i = 0; i < hclen; i++) { need32(B); T.lens[c_clen_order[i]] = (uint8_t)take(B, 3); }
+            // the code-length code: 19 symbols of at most 7 bits, decoded bit by bit (dist_cn / dist_sorted are free until below)
+            if (!build_code(T.lens, 19, T.dist_cn, T.dist_sorted)) { bad = true; break; }
+            int n = 0, prev = 0;
+            while (n < hlit + hdist) {
+                need32(B);
+                const int sym = decode<0, 7>(B, nullptr, T.dist_cn, T.dist_sorted);
+                if (sym < 0) { bad = true; break; }
+                int rep = 1, val = sym;
+                if (sym == 16) { if (n == 0) { bad = true; break; } val = prev; rep = 3 + (int)take(B, 2); }
+                else if (sym == 17) { val = 0; rep = 3 + (int)take(B, 3); }
+                else if (sym == 18) { val = 0; rep = 11 + (int)take(B, 7); }
+                if (n + rep > hlit + hdist) { bad = true; break; }
+                for (int i = 0; i < rep; i++) ll[n + i] = (uint8_t)val;
+                n += rep; prev = val;
+            }
+            if (bad) break;
+            if (ll[256] == 0) { bad = true; break; }                          // no end-of-block code
+            if (!build_code(ll, hlit, T.lit_cn, T.lit_sorted) || !build_code(ll + hlit, hdist, T.dist_cn, T.dist_sorted)) { bad = true; break; }
+        }
+        build_table(T.lit_cn, T.lit_sorted, T.lit_tab);
+        // ---- symbols of the block: runs of literals (the lanes of the wave meet again at their next match) -------------------
+        for (;;) {
+            int sym;
+            for (;;) {
+                need32(B);
+                sym = decode<LIT_BITS, 15>(B, T.lit_tab, T.lit_cn, T.lit_sorted);
+                if (sym < 0 || sym >= 256) break;
+                if (op >= isize) { sym = -1; break; }
+                emit((uint32_t)sym);
+            }
+            if (sym < 0 || sym > 285) { bad = true; break; }
+            if (sym == 256) break;
+            uint32_t len = c_len_base[sym - 257] + take(B, c_len_extra[sym - 257]);
+            need32(B);
+            const int ds = decode<0, 15>(B, nullptr, T.dist_cn, T.dist_sorted);
+            if (ds < 0 || ds > 29) { bad = true; break; }
+            const uint32_t dist = c_dist_base[ds] + take(B, c_dist_extra[ds]);
+            if (dist > op || op + len > isize) { bad = true; break; }
+            // the copy reads this member's own output back from memory (a lane's stores and loads stay in order)
+            flush();
+            const uint8_t* src = dst + op - dist;
+            uint8_t* to = dst + op;
+            op += len;
+            if (dist >= 8) {
+                // up to four 8-byte pieces per round trip: as many as lie wholly in front of what the round itself writes
+                while (len) {
+                    const uint32_t nb = min(min(4u, dist >> 3), (len + 7u) >> 3);
+                    unsigned long long v[4];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) v[i] = i < nb ? ld8(src + 8 * i) : 0ull;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        if (i >= nb) continue;
+                        uint8_t* t = to + 8 * i;
+                        if (t + 8 <= dst_end) st8(t, v[i]);
+                        else for (uint32_t k = 0; 8 * i + k < len; k++) t[k] = (uint8_t)(v[i] >> (8 * k));
+                    }
+                    const uint32_t adv = min(len, 8u * nb);
+                    src += adv; to += adv; len -= adv;
+                }
+            } else {
+                // a short period: its bytes once, made periodic over eight bytes, stored in steps of whole periods
+                unsigned long long pat = 0;
+                if (op - len >= 8) pat = ld8(to - 8) >> (8 * (8 - dist));
+                else {
+#pragma unroll
+                    for (int i = 0; i < 7; i++) pat |= (unsigned long long)((uint32_t)i < dist ? src[i] : (uint8_t)0) << (8 * i);
+                }
+                pat &= ~0ull >> (8 * (8 - dist));
+                if (dist < 8) pat |= pat << (8 * dist);
+                if (dist < 4) pat |= pat << (16 * dist);
+                if (dist < 2) pat |= pat << 32;
+                const uint32_t step = dist * (8u / dist);
+                while (len) {
+                    const uint32_t adv = min(len, step);
+                    if (to + 8 <= dst_end) st8(to, pat);
+                    else for (uint32_t k = 0; k < adv; k++) to[k] = (uint8_t)(pat >> (8 * k));
+                    to += adv; len -= adv;
+                }
+            }
+        }
+    }
+    flush();
+    if (!bad && op != isize) bad = true;
+    if (!bad) {                                                                // the stream may not run past the payload
+        const long long bits = 32ll * B.taken - 8ll * head - B.bn;
+        if (bits > 8ll * pay_len) bad = true;
+    }
+    if (bad) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
+}
+
+// CRC-32 of every member's output against its trailer: one wave per member.
+__global__ __launch_bounds__(BLOCK) void k_bgzf_crc(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
+                                                    const uint64_t* __restrict__ out_off, uint32_t n_members, const uint8_t* __restrict__ out,
+                                                    unsigned long long* __restrict__ status)
+{
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        crc_tab[i] = c;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t m = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (m >= n_members) return;
+    const uint64_t o0 = out_off[m];
+    const uint32_t n = (uint32_t)(out_off[m + 1] - o0);
+    // lane l: the CRC register (started at 0: the pure polynomial remainder) of its share of the output; the shares are cut
+    // at 16-byte addresses and read as whole uint4 (the first lane takes the bytes in front of the first boundary as well)
+    const uint8_t* p0 = out + o0;
+    const uint8_t* pe = p0 + n;
+    const uint8_t* pa = reinterpret_cast<const uint8_t*>(((uintptr_t)p0 + 15) & ~(uintptr_t)15);
+    if (pa > pe) pa = pe;
+    const uint32_t per = (((uint32_t)(pe - pa) + 63) / 64 + 15) & ~15u;
+    const uint8_t* a = lane ? pa + min((uint32_t)(pe - pa), (uint32_t)lane * per) : p0;
+    const uint8_t* b = pa + min((uint32_t)(pe - pa), (uint32_t)(lane + 1) * per);
+    const uint32_t share = (uint32_t)(b - a);
+    uint32_t c = 0;
+    for (; a < b && ((uintptr_t)a & 15u); a++) c = crc_tab[(c ^ *a) & 0xFFu] ^ (c >> 8);
+    for (; a + 16 <= b; a += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c ^= w[k];
+#pragma unroll
+            for (int j = 0; j < 4; j++) c = crc_tab[c & 0xFFu] ^ (c >> 8);
+        }
+    }
+    for (; a < b; a++) c = crc_tab[(c ^ *a) & 0xFFu] ^ (c >> 8);
+    uint32_t xp = 0x80000000u, base = 0x00800000u;                            // x^0, x^8 (reflected); xp = x^(8 (b - a))
+    for (uint32_t e = share; e; e >>= 1) { if (e & 1u) xp = gf_mul(xp, base); base = gf_mul(base, base); }
+    for (int d = 1; d < 64; d <<= 1) {                                        // ordered product: (c, x) . (c', x') = (c x' + c', x x')
+        const uint32_t oc = (uint32_t)__shfl_down((int)c, d, 64), ox = (uint32_t)__shfl_down((int)xp, d, 64);
+        if ((lane & (2 * d - 1)) == 0) { c = gf_mul(c, ox) ^ oc; xp = gf_mul(xp, ox); }
+    }
+    if (lane == 0) {
+        // crc32(M) = reg_ff(M) ^ ~0 with reg_ff(M) = reg_0(M) ^ (0xFFFFFFFF * x^(8 n)): the all-ones start value is a term of its own
+        const uint32_t got = c ^ gf_mul(0xFFFFFFFFu, xp) ^ 0xFFFFFFFFu;
+        const uint64_t tp = member_pos[m + 1] - 8;
+        const uint32_t want = (uint32_t)raw[tp] | ((uint32_t)raw[tp + 1] << 8) | ((uint32_t)raw[tp + 2] << 16) | ((uint32_t)raw[tp + 3] << 24);
+        if (got != want) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
+    }
+}
+
+// d_raw must be readable up to 8 bytes past its last member (the decoder loads whole aligned dwords).
 extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off,
                                        uint32_t n_members, uint8_t* d_out, uint64_t out_cap, int check_crc, uint64_t* d_status)
 {
     if (!ctx || !d_status || (n_members && (!d_raw || !d_member_pos || !d_out_off || !d_out))) return GCI_E_INVALID;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
     if (n_members) {
-        hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_members), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, n_members, d_out,
-                           out_cap, check_crc, (unsigned long long*)d_status);
+        // members per wave: fewer = more waves per SIMD to overlap the memory round trips, more = fewer instructions issued
+        static const int lanes = [] { const char* e = getenv("GCI_INFLATE_LANES"); return e ? atoi(e) : 8; }();
+        auto launch = [&](auto kern, int per) {
+            hipLaunchKernelGGL(kern, dim3((n_members + per - 1) / per), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, n_members,
+                               d_out, out_cap, (unsigned long long*)d_status);
+        };
+        if (lanes == 4) launch(k_bgzf_inflate<4>, 4);
+        else if (lanes == 16) launch(k_bgzf_inflate<16>, 16);
+        else if (lanes == 32) launch(k_bgzf_inflate<32>, 32);
+        else launch(k_bgzf_inflate<8>, 8);
         LAUNCHCHK("k_bgzf_inflate");
+        if (check_crc) {
+            hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, ctx->stream, d_raw, d_member_pos,
+                               d_out_off, n_members, (const uint8_t*)d_out, (unsigned long long*)d_status);
+            LAUNCHCHK("k_bgzf_crc");
+        }
     }
     return GCI_OK;
 }

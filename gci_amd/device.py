@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -284,20 +285,31 @@ class Engine:
         return blob[:total], off
 
     # ---- N1: BGZF inflate + record walk on the device (k_inflate.hip) ---------------------------------------------------
-    def bgzf_inflate(self, raw: np.ndarray, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True) -> torch.Tensor:
-        """raw: the bytes of a BGZF file; pos (uint64, n + 1) / isize (uint64, n): its member table (hostio.bgzf_blocks).
-        -> the inflated bytes on the device.  Raises GciError(GCI_E_MALFORMED, rec = member) on a bad member / CRC."""
+    def bgzf_inflate(self, raw: np.ndarray, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True,
+                     prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """raw: the bytes of a BGZF file (or of a run of its members); pos (uint64, n + 1) / isize (uint64, n): its member
+        table (hostio.bgzf_blocks), pos relative to raw.  -> the inflated bytes on the device, behind the bytes of `prefix`
+        (the partial record a previous run of members ended in).  Raises GciError(GCI_E_MALFORMED, rec = member) on a bad
+        member / CRC."""
         n = int(isize.shape[0])
         off = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum(isize, out=off[1:])
         total = int(off[n])
-        d_raw = self.to_device(raw)
+        n_raw, n_pre = int(raw.shape[0]), (int(prefix.shape[0]) if prefix is not None else 0)
+        # 16 readable bytes behind the last member: the decoder takes its input as whole aligned 16-byte blocks
+        d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
+        d_raw[n_raw:].zero_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)         # a read-only memmap is only read
+            d_raw[:n_raw].copy_(torch.from_numpy(np.asarray(raw)))
         d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
-        out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
-        self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(d_raw), self._p(d_pos), self._p(d_off), n, self._p(out), total,
+        out = torch.empty(max(n_pre + total, 1), dtype=torch.uint8, device=self.device)
+        if n_pre:
+            out[:n_pre].copy_(prefix)
+        self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(d_raw), self._p(d_pos), self._p(d_off), n, ctypes.c_void_p(out.data_ptr() + n_pre), total,
                                                    int(check_crc), self._p(self._status)), "gci_bgzf_inflate_device")
         self.check_status("gci_bgzf_inflate_device")
-        return out[:total]
+        return out[:n_pre + total]
 
     def bam_record_offsets(self, d_stream: torch.Tensor, first_record: int, n_ref: int) -> Tuple[torch.Tensor, int, bool]:
         """-> (int64 offsets of every record on the device, bytes consumed, chain_ok).  chain_ok False: a record the strict

@@ -277,20 +277,91 @@ GPU_INFLATE_MAX = int(os.environ.get("GCI_GPU_INFLATE_MAX", str(32 << 30)))
 BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
 
 
+def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int
+                        ) -> Optional[JoinInput]:
+    """ingest = "gpu".  A file whose inflated stream fits GCI_GPU_INFLATE_MAX stays on the device whole (the join reads
+    the names inside it); a larger one goes through run by run of members (at most chunk_bytes inflated each): inflate,
+    record walk, K1, and only the 32-byte records and the packed names are kept -- the partial record a run ends in is
+    put in front of the next one.  None: the parallel record walk lost the chain (the caller takes the host path)."""
+    map_qual, mq_cutoff, clip_percent, iden_percent = filt
+    hdr = bamfmt.read_header(path)
+    ref_sel = ref_sel_for(hdr)
+    n_ref = len(hdr.references)
+    total = int(isz.sum())
+    if total <= GPU_INFLATE_MAX:
+        d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC)
+        d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, n_ref)
+        if not ok:
+            return None
+        if used != total:
+            raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % (total - used))
+        recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
+        return JoinInput(recs, d_bam, d_off, 36)
+    groups, a, acc = [], 0, 0
+    for i, sz in enumerate(isz.tolist()):
+        if acc and acc + sz > chunk_bytes:
+            groups.append((a, i))
+            a, acc = i, 0
+        acc += sz
+    groups.append((a, len(isz)))
+    rec_parts, name_parts, off_parts = [], [], []
+    carry, start, n_done, name_base = None, hdr.first_record, 0, 0
+    for lo, hi in groups:
+        p0 = int(pos[lo])
+        try:
+            d_buf = engine.bgzf_inflate(raw[p0:int(pos[hi])], pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry)
+        except GciError as e:
+            if e.rec >= 0:
+                e.rec += lo
+            raise
+        if int(d_buf.shape[0]) <= start:                  # still inside the header
+            carry, start = None, start - int(d_buf.shape[0])
+            continue
+        d_off, used, ok = engine.bam_record_offsets(d_buf, start, n_ref)
+        if not ok:
+            return None
+        carry, start = (d_buf[used:].clone() if used < int(d_buf.shape[0]) else None), 0
+        if int(d_off.shape[0]) == 0:
+            continue
+        try:
+            recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=n_done)
+        except GciError as e:
+            if e.rec >= 0:
+                e.rec += n_done
+            raise
+        names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
+        rec_parts.append(recs.clone())
+        name_parts.append(names.clone())
+        off_parts.append(noff[:-1] + name_base)
+        name_base += int(names.shape[0])
+        n_done += int(d_off.shape[0])
+        del d_buf, d_off
+    if carry is not None:
+        raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % int(carry.shape[0]))
+    dev = engine.device
+    recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
+    names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
+    noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
+    return JoinInput(recs, names if names.shape[0] else torch.zeros(1, dtype=torch.uint8, device=dev), noff, 0)
+
+
 def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
                    threads: int = 1, chunk_bytes: Optional[int] = None, ingest: Optional[str] = None) -> JoinInput:
     """K1 over one BAM file -> the file's join input (compact records + where their names are).
 
-    ingest = "heads" (default; GCI_BAM_INGEST overrides): the native host pipeline (gci_bam_heads) inflates the file
-    group by group and keeps every record without its SEQ / QUAL bytes; only that heads stream (about 400 B of a
-    27 KB HiFi record) is uploaded and filtered (gci_bam_filter_heads); names stay addressable inside it.
-    ingest = "full" (or an explicit chunk_bytes): the whole inflated stream goes to the device.  Small files: one
-    upload.  Large files: groups of BGZF members are inflated into a host buffer (the next group on a background
-    thread while the GPU works on the current one), the partial record at the end of a group is carried over, K1
-    runs per chunk and only the 32-byte records and the packed names (gci_pack_names) are kept on the device."""
+    ingest = "gpu" (default; GCI_BAM_INGEST overrides): the file's bytes are uploaded as they are and inflated on the
+    device, the record offsets come from the parallel walk (_bam_join_input_gpu); a stream that walk cannot follow
+    takes the next path.
+    ingest = "heads": the native host pipeline (gci_bam_heads) inflates the file group by group and keeps every record
+    without its SEQ / QUAL bytes; only that heads stream (about 400 B of a 27 KB HiFi record) is uploaded and filtered
+    (gci_bam_filter_heads); names stay addressable inside it.
+    ingest = "full" (or an explicit chunk_bytes): the whole stream, inflated on the host, goes to the device.  Small
+    files: one upload.  Large files: groups of BGZF members are inflated into a host buffer (the next group on a
+    background thread while the GPU works on the current one), the partial record at the end of a group is carried
+    over, K1 runs per chunk and only the 32-byte records and the packed names (gci_pack_names) are kept on the device."""
     from concurrent.futures import ThreadPoolExecutor
     from . import hostio
-    ingest = ingest or ("full" if chunk_bytes else os.environ.get("GCI_BAM_INGEST", "heads"))
+    ingest = ingest or ("full" if chunk_bytes else os.environ.get("GCI_BAM_INGEST", "gpu"))
     if ingest not in ("heads", "full", "gpu"):
         raise ValueError("ingest must be 'heads', 'full' or 'gpu'")
     chunk_bytes = int(chunk_bytes or BAM_CHUNK_BYTES)
@@ -306,22 +377,15 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         return engine.to_device(np.asarray([tindex.get(r, -1) for r in hdr.references], dtype=np.int32))
 
     if ingest == "gpu":
-        # N1 on the device: the file's bytes are uploaded as they are, every BGZF member is inflated by one wave
+        # N1 on the device: the file's bytes are uploaded as they are, the BGZF members are inflated there
         # (gci_bgzf_inflate_device, CRC verified), the record offsets come from a parallel walk
-        # (gci_bam_record_offsets_device) and K1 runs over the whole inflated stream.  Files whose inflated size exceeds
-        # GCI_GPU_INFLATE_MAX, and streams the parallel walk cannot follow, take the heads path below.
+        # (gci_bam_record_offsets_device) and K1 runs over the inflated stream.  A stream the parallel walk cannot follow
+        # takes the heads path below.
         pos, isz = hostio.bgzf_blocks(np.asarray(raw))
-        total = int(isz.sum())
-        if 0 < total <= GPU_INFLATE_MAX:
-            hdr = bamfmt.read_header(path)
-            d_bam = engine.bgzf_inflate(np.asarray(raw), pos, isz, check_crc=BGZF_CRC)
-            d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, len(hdr.references))
-            if ok:
-                if used != total:
-                    raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % (total - used))
-                recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent)
-                return JoinInput(recs, d_bam, d_off, 36)
-            del d_bam, d_off
+        if int(isz.sum()) > 0:
+            ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes)
+            if ji is not None:
+                return ji
         ingest = "heads"
     if ingest == "heads":
         try:

@@ -44,6 +44,7 @@ class Context:
 
     def init(self) -> None:
         import os
+        import sys
         if dist.is_initialized():
             return
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -55,7 +56,20 @@ class Context:
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # single node: the container's hostname may not resolve
         torch.cuda.set_device(self.device_index)
         kw = dict(device_id=torch.device("cuda", self.device_index)) if self.backend == "nccl" else {}
-        dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+        if self.backend == "gloo":
+            # gloo reports its connections on file descriptor 1 when they are first made: the transcript of the run stays
+            # the reference's, so that chatter is sent to stderr (and the connections are made here, by a barrier)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+                dist.barrier()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+        else:
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
 
     def assign(self, lengths: Sequence[int]) -> List[int]:
         """Longest-processing-time packing of the selected contigs; -> indices of the contigs this rank owns."""

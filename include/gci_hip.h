@@ -369,7 +369,9 @@ int gci_paf_dev_free(gci_paf_dev* r);
  * gci_bgzf_inflate_device: d_raw = the bytes of a BGZF file (or of a run of its members) on the device; d_member_pos[m] =
  * offset of member m in d_raw, n_members + 1 entries (the last = end of the run; gci_bgzf_blocks makes the table on the
  * host); d_out_off[m] = where member m's output goes in d_out (exclusive scan of the members' ISIZE, n_members + 1 entries).
- * One wave per member (window, tables and input in LDS); every member's length and -- check_crc != 0 -- CRC-32 are verified.
+ * One lane per member (decode tables in LDS, the output buffer is the window); every member's length and -- check_crc != 0,
+ * by a second kernel, one wave per member -- CRC-32 are verified.  d_raw must be readable for 8 bytes past its last member
+ * (the decoder fetches whole aligned dwords).
  * *d_status: min over failing members of (member << 8 | -status), UINT64_MAX if none (decode with gci_decode_status).
  *
  * gci_bam_record_offsets_device: the byte offset of every record of an inflated BAM stream on the device, without the serial

@@ -5,6 +5,7 @@ GCI.py ...` must write the files -- and rank 0 print the transcript -- of a sing
 BAM index, the record all-gather, the replicated join with its ownership filter, the gathered outputs and the integer
 all-reduce of the mean depth run for real."""
 import os
+import re
 import subprocess
 import sys
 
@@ -40,7 +41,8 @@ def test_two_ranks_reproduce_the_reference(k, case, tmp_path):
     assert sorted(got_img) == sorted(want_img)
     for fn in want_img:
         assert np.array_equal(got_img[fn], want_img[fn]), fn
-    stdout = "".join(l for l in r.stdout.splitlines(True) if not l.startswith("[Gloo]"))      # the gloo backend's own chatter
+    # the gloo backend's own chatter, written by both ranks past Python's buffering (its pieces can interleave)
+    stdout = re.sub(r"\[Gloo\] Rank \d+ is connected to| \d+ peer ranks\. Expected number of connected peer ranks is : \d+\n", "", r.stdout)
     first, _, rest = stdout.partition("\n")
     assert first.startswith("Used arguments:{")
     inp = os.path.join(GOLDEN, case, "inputs")

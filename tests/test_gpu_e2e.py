@@ -185,18 +185,30 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     want_d, hq = oracle.bam_file_dict(stream, offs, targets, targets, *filt)
     want = oracle.depth_build(oracle.name_join([want_d], hq, 0.9), tl, 15)
     engine.set_layout([tl[t] for t in targets])
-    # heads stream (the default), the whole inflated stream in one upload, and streamed in chunks
-    # ... and inflated + walked on the device (ingest "gpu")
-    for chunk, ingest in ((None, None), (None, "full"), (None, "gpu"), (9_000_001, None), (1_234_567, None), (300_000, None)):
-        ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk, ingest=ingest)
+    # inflated + walked on the device (ingest "gpu", the default) whole and run by run of members; the heads stream of the
+    # host pipeline; the whole inflated stream in one upload, and streamed in chunks from the host
+    cases = [(None, None, None), (None, "gpu", 0), (None, "heads", None), (None, "full", None),
+             (9_000_001, None, None), (1_234_567, None, None), (300_000, None, None)]
+    for chunk, ingest, gpu_max in cases:
+        packed = chunk is not None
+        if gpu_max is not None:                       # force the run-by-run device path with small runs
+            for run in (1_234_567, 300_000):
+                monkeypatch.setattr(pipeline, "GPU_INFLATE_MAX", gpu_max)
+                monkeypatch.setattr(pipeline, "BAM_CHUNK_BYTES", run)
+                ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, ingest=ingest)
+                assert ji.name_delta == 0 and ji.recs.shape[0] == len(rs)
+            monkeypatch.undo()
+            packed = True
+        else:
+            ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk, ingest=ingest)
         assert ji.recs.shape[0] == len(rs)
-        assert (ji.name_delta == 0) == (chunk is not None)
+        assert (ji.name_delta == 0) == packed
         ivl, cnt = engine.name_join([ji], 0.9)
         track = engine.new_track()
         engine.depth_build(ivl, cnt, 15, track)
         tr = pipeline.DepthTracks(engine, tl, track)
         for t in targets:
-            assert np.array_equal(tr[t], want[t]), (chunk, t)
+            assert np.array_equal(tr[t], want[t]), (chunk, ingest, t)
     # and through filter() with the environment knob, including a second (perturbed) file and the join
     rs2 = synth.perturb(rs, 92)
     p2 = str(tmp_path / "s2.bam")
@@ -209,10 +221,13 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
     depths, _ = pipeline.filter([], [p, p2], prefix="st", directory=str(tmp_path), engine=engine, threads=4)
     for t in targets:
         assert np.array_equal(depths[t], want2[t]), t
-    monkeypatch.setenv("GCI_BAM_INGEST", "gpu")
-    depths, _ = pipeline.filter([], [p, p2], prefix="sg", directory=str(tmp_path), engine=engine, threads=4)
-    for t in targets:
-        assert np.array_equal(depths[t], want2[t]), t
+    for knob, kw in (("gpu", {}), ("gpu", {"GPU_INFLATE_MAX": 0, "BAM_CHUNK_BYTES": 700_000}), ("heads", {})):
+        monkeypatch.setenv("GCI_BAM_INGEST", knob)
+        for k, v in kw.items():
+            monkeypatch.setattr(pipeline, k, v)
+        depths, _ = pipeline.filter([], [p, p2], prefix="s" + knob[0] + str(len(kw)), directory=str(tmp_path), engine=engine, threads=4)
+        for t in targets:
+            assert np.array_equal(depths[t], want2[t]), (knob, kw, t)
 
 
 def test_genome_scale_layout_chm13(engine, oracle):
