@@ -43,6 +43,7 @@ struct gci_ctx {
     DevBuf evt_off;                         // uint32: bucket offsets (n_tiles + 1)
     DevBuf d_tile_valid;                    // int32 per tile: elements of the tile inside its contig (TILE but for the last)
     DevBuf dense_flag;                      // uint8 per tile: pass 2 left it to the dense kernel
+    DevBuf dense_list;                      // uint32: [0] = number of flagged tiles, [1 ..] their indices (k_dense_list)
     int32_t sparse_max = 62;                // tiles with more events take the dense path (GCI_FORCE_DENSE=1: all of them)
     bool join_dirty = false;                // the join tables are not in their clean state (a join was cut short)
     uint32_t k1_parity = 0;                 // which of the two K1 counter sets the next gci_bam_filter uses

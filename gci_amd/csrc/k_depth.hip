@@ -788,7 +788,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int32_t* __restrict__ tile_valid, int64_t n_tiles, int32_t* __restrict__ depth,
     const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
-    uint8_t* __restrict__ dense_flag, int32_t sparse_max, uint32_t* __restrict__ cd_words
+    uint8_t* __restrict__ dense_flag, uint32_t* __restrict__ dense_list, int32_t sparse_max, uint32_t* __restrict__ cd_words
 #ifdef GCI_TILE_TRACE
     , unsigned long long* __restrict__ trace
 #endif
@@ -801,6 +801,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const int64_t tile = gw / SHARE;
     const uint32_t wi = (uint32_t)(gw % SHARE);
     if (tile >= n_tiles) return;
+    if (gw == 0 && lane == 0) dense_list[0] = 0u;                             // k_dense_list (next on the stream) counts from here
 #ifdef GCI_TILE_TRACE
     unsigned long long* g_tt = trace + tile * 8;
     TT(0);
@@ -812,34 +813,42 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     if ((int64_t)(e1 - e0) <= sparse_max)
         done = tile_sparse2(tile, e0, e1 - e0, events, carry_in, valid, depth, T0, text, text_cap, lane, wi, SHARE TT_ARG);
     if (lane == 0 && wi == 0) {
-        dense_flag[tile] = done ? 0 : 1;                                     // k_tile_dense<2> takes the rest
+        dense_flag[tile] = done ? 0 : 1;                                     // k_tile_dense takes the rest
         cd_words[2 * tile + 1] = 0u;                                         // the coarse difference has been consumed: table clean again
     }
     TT(7);
 }
 
-// The dense tiles: those with more than sparse_max events and (pass 2) those the sparse kernel flagged.  One
-// workgroup looks at DENSE_SPAN consecutive tiles, so that the launch stays small when (as usual) none is dense.
+// The dense tiles: those k_tile_build flagged (more than sparse_max events, or a shape its sparse path declined).
+// k_dense_list: a workgroup looks at the flags of BLOCK consecutive tiles, leaves when (as usual) none is set, and appends
+// the flagged ones to a list (order irrelevant: tiles are independent).
+__global__ __launch_bounds__(BLOCK) void k_dense_list(const uint8_t* __restrict__ dense_flag, int64_t n_tiles, uint32_t* __restrict__ list)
+{
+    const int64_t mine = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (mine < n_tiles && dense_flag[mine]) list[1 + atomicAdd(&list[0], 1u)] = (uint32_t)mine;
+}
+
+// One workgroup per DENSE_SPAN entries of that list; the grid is sized for "every tile is dense", and a workgroup beyond
+// the list's end costs one scalar load.
 #define DENSE_SPAN 8
-template <int PASS>
 __global__ __launch_bounds__(BLOCK) void k_tile_dense(
-    const uint8_t* __restrict__ dense_flag, int32_t sparse_max, int64_t n_tiles,
+    const uint32_t* __restrict__ list,
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs,
-    long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, IssueArgs iss,
     int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
     const uint32_t* __restrict__ g_lut)
 {
+    const uint32_t n = list[0];
+    IssueArgs none;
+    memset(&none, 0, sizeof none);
     // (written out rather than looped: a loop around tile_dense doubles its register count)
-#define DENSE_ONE(k)                                                                                                         \
-    {                                                                                                                        \
-        const int64_t tile = (int64_t)blockIdx.x * DENSE_SPAN + (k);                                                         \
-        if (tile >= n_tiles) return;                                                                                         \
-        if ((int64_t)(evt_off[tile + 1] - evt_off[tile]) > sparse_max || (PASS == 2 && dense_flag[tile])) {                  \
-            tile_dense<PASS>(tile, events, evt_off, tile_carry, tile_first, len, n_contigs, tile_sum, tile_bytes, iss, depth, \
-                             tile_text_off, text, text_cap, g_lut);                                                          \
-            __syncthreads();                                                                                                 \
-        }                                                                                                                    \
+#define DENSE_ONE(k)                                                                                                       \
+    {                                                                                                                      \
+        const uint32_t at = blockIdx.x * DENSE_SPAN + (k);                                                                 \
+        if (at >= n) return;                                                                                               \
+        tile_dense<2>((int64_t)list[1 + at], events, evt_off, tile_carry, tile_first, len, n_contigs, nullptr, nullptr, none, depth, \
+                      tile_text_off, text, text_cap, g_lut);                                                               \
+        __syncthreads();                                                                                                   \
     }
     DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3) DENSE_ONE(4) DENSE_ONE(5) DENSE_ONE(6) DENSE_ONE(7)
 #undef DENSE_ONE
@@ -865,10 +874,10 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
     const int64_t per = BLOCK / 64;
     const dim3 grid((uint32_t)((ctx->n_tiles + per - 1) / per));
     const dim3 grid2((uint32_t)((ctx->n_tiles * SHARE + per - 1) / per));
+    const dim3 list_grid((uint32_t)((ctx->n_tiles + BLOCK - 1) / BLOCK));
     const dim3 dense_grid((uint32_t)((ctx->n_tiles + DENSE_SPAN - 1) / DENSE_SPAN));
-    uint8_t* flag = (uint8_t*)ctx->dense_flag.p;          // written by k_tile_build for every tile, read by k_tile_dense<2>
-    IssueArgs none;
-    memset(&none, 0, sizeof none);
+    uint8_t* flag = (uint8_t*)ctx->dense_flag.p;          // written by k_tile_build for every tile, read by k_dense_list
+    uint32_t* list = (uint32_t*)ctx->dense_list.p;        // its counter is zeroed by k_tile_build
     if (pass == 1) {
         ProfScope _ps(ctx, GCI_PROF_TILE_PASS1);
         hipLaunchKernelGGL(k_tile_pass1, grid, block, 0, ctx->stream, ev, eo, tc, tf, ln, ctx->n_contigs, ctx->n_tiles,
@@ -880,14 +889,14 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
         {
             ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
             hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
-                               (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, ctx->sparse_max,
+                               (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, list, ctx->sparse_max,
                                (uint32_t*)ctx->tile_cd.p TILE_TRACE_ARG);
             LAUNCHCHK("k_tile_build");
         }
         ProfScope _ps(ctx, GCI_PROF_TILE_DENSE);
-        hipLaunchKernelGGL(k_tile_dense<2>, dense_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->sparse_max, ctx->n_tiles,
-                           ev, eo, tc, tf, ln, ctx->n_contigs, (long long*)nullptr, (uint32_t*)nullptr, none, d_depth,
-                           (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, (const uint32_t*)ctx->text_lut.p);
+        hipLaunchKernelGGL(k_dense_list, list_grid, block, 0, ctx->stream, (const uint8_t*)flag, ctx->n_tiles, list);
+        hipLaunchKernelGGL(k_tile_dense, dense_grid, block, 0, ctx->stream, (const uint32_t*)list, ev, eo, tc, tf, ln,
+                           ctx->n_contigs, d_depth, (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, (const uint32_t*)ctx->text_lut.p);
     }
     LAUNCHCHK("k_tile_dense");
     return GCI_OK;

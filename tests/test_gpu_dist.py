@@ -25,7 +25,7 @@ def run_two_ranks(argv, port):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("k,case", list(enumerate(["c3_two_bam", "c3_three_bam_chrs", "c4_two_paf", "c5_two_type", "c6_plot"])))
+@pytest.mark.parametrize("k,case", list(enumerate(["c3_two_bam", "c3_three_bam_chrs", "c4_two_paf", "c5_two_type", "c6_plot", "c7_t2t_geometry"])))
 def test_two_ranks_reproduce_the_reference(k, case, tmp_path):
     out = str(tmp_path / "out")
     r = run_two_ranks(cli_args(case, out), 29710 + k)

@@ -316,6 +316,26 @@ def case_cli_plot():
                   hifi=["hifi.mm2.bam"], nano=["ont.mm2.bam"], regions=True)
 
 
+def case_t2t_geometry():
+    """BASELINE.json configs[3] / [4] in small: the 25 contigs of CHM13 at 1/1250 of their lengths (chrM at its minimum),
+    both read types with two files each (BAM + PAF of another aligner's view of the same reads), gaps, -R regions over
+    several contigs and -p.  Also the case the two-rank runs shard over many contigs of very different lengths."""
+    contigs = tuple((n, max(9_000, l // 1250)) for n, l in synth.CHM13)
+    gaps = {"chr1": [(50_000, 50_400)], "chr9": [(0, 300), (60_000, 60_001)], "chrX": [(100_000, 101_000)]}
+    h = synth.simulate_reads(contigs, 30, "hifi", seed=synth.seed_for(8, 0))
+    h2 = synth.perturb(h, synth.seed_for(8, 1))
+    n = synth.simulate_reads(contigs, 24, "ont", seed=synth.seed_for(8, 2), long_cigar_frac=0.0)
+    n2 = synth.perturb(n, synth.seed_for(8, 3))
+    regions = [("chr1", 0, 150_000), ("chr2", 20_000, 180_000), ("chr9", 0, 110_000), ("chr21", 1_000, 30_000),
+               ("chrX", 0, 123_000), ("chrM", 0, 9_000), ("chr2", 30_000, 31_000)]
+    write_inputs(os.path.join(GOLDEN, "c7_t2t_geometry"), contigs,
+                 {"hifi.wm2.bam": h, "hifi.mm2.paf": synth.to_paf_lines(h2, synth.seed_for(8, 4), 0.05),
+                  "ont.wm2.bam": n, "ont.mm2.paf": synth.to_paf_lines(n2, synth.seed_for(8, 5), 0.05)},
+                 gaps=gaps, regions=regions)
+    run_reference("c7_t2t_geometry", {"plot": True, "window_size": 2000, "threshold": 1},
+                  hifi=["hifi.wm2.bam", "hifi.mm2.paf"], nano=["ont.wm2.bam", "ont.mm2.paf"], regions=True)
+
+
 def case_plot():
     """N3 end to end: the figures the reference's plot_base draws for a small one-type and a small two-type input
     (tests/golden/plot/*.png) together with the depth arrays they were drawn from (inputs.npz)."""
@@ -455,7 +475,7 @@ if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
     todo = [("c1", case_single_bam), ("c3a", case_two_bam), ("c3b", case_three_bam_chrs), ("c4a", case_paf_bam),
-            ("c4b", case_nano_only_long_cigar), ("c4c", case_two_paf), ("plot", case_plot), ("c6", case_cli_plot), ("c5", case_two_type), ("kats", make_kats),
+            ("c4b", case_nano_only_long_cigar), ("c4c", case_two_paf), ("plot", case_plot), ("c6", case_cli_plot), ("c5", case_two_type), ("c7", case_t2t_geometry), ("kats", make_kats),
             ("mh63", copy_reference_example), ("cli", case_cli_errors)]
     for name, fn in todo:
         if not only or name in only:
