@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -49,6 +50,8 @@ struct gci_ctx {
     uint32_t k1_parity = 0;                 // which of the two K1 counter sets the next gci_bam_filter uses
     int cd_state = 0;                       // tile_cd: 0 clean, 1 counted by gci_name_join_count, 2 in use / left over
     int counted_flank = 0;                  // the flank gci_name_join_count counted with
+    bool count_deferred = false;            // cd_state == 1 without counts: the build buckets the events itself (gci_evp_wanted)
+    DevBuf evp_items, evp_hist, evp_blk;    // large inputs: the events partitioned by tile range (k_evp_*)
     DevBuf events;                          // uint16 per event: local position << 1 | is_minus
     DevBuf blk_a, blk_b;                    // block totals of the two scans
     DevBuf tile_sum;                        // int64: sum of depth per tile
@@ -135,6 +138,18 @@ __device__ __forceinline__ int32_t contig_of_tile(const int64_t* __restrict__ ti
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ int32_t ld_i32(const uint8_t* p) { int32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint16_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+// Large inputs bucket their events by radix partition instead of one device-scope atomic per event (k_depth.hip, k_evp_*);
+// gci_name_join_count then leaves the counting to the build.  GCI_EVENTS=atomic|radix overrides the size rule.
+#define EVP_MAX_TILES (int64_t(1) << 23)
+static inline bool gci_evp_wanted(const gci_ctx* ctx, uint64_t n_items)
+{
+    if (ctx->n_tiles == 0 || ctx->n_tiles > EVP_MAX_TILES) return false;
+    const char* e = getenv("GCI_EVENTS");
+    if (e && !strcmp(e, "atomic")) return false;
+    if (e && !strcmp(e, "radix")) return true;
+    return n_items >= (1u << 20);
+}
 
 // ---- interval -> tile events (shared by k_evt_count / k_evt_scatter and the counting join) -------------------------
 struct IvlSpan { int64_t tile_a, tile_b; uint32_t pos_a, pos_b; bool valid, has_b; int64_t tile_bc; };

@@ -702,9 +702,21 @@ extern "C" int gci_name_join_count(gci_ctx* ctx, const gci_join_file* h_files, i
 {
     if (!ctx) return GCI_E_INVALID;
     if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    // large inputs: the build buckets its events by radix partition and counts on the way (gci_depth_build_begin)
+    uint64_t total = 0;
+    for (int f = 0; f < n_files; f++) total += h_files ? h_files[f].n_recs : 0;
+    if (gci_evp_wanted(ctx, total)) {
+        if (ctx->cd_state != 0) HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(ctx->n_tiles + 1) * 8, ctx->stream));
+        CountArgs none;
+        memset(&none, 0, sizeof none);
+        const int st = name_join_impl(ctx, h_files, n_files, ovlp_percent, d_contig_map, d_out, cap, d_n_out, d_status, none);
+        if (st == GCI_OK) { ctx->cd_state = 1; ctx->counted_flank = flank; ctx->count_deferred = true; }
+        return st;
+    }
     if (ctx->n_tiles && ctx->cd_state != 0)
         HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(ctx->n_tiles + 1) * 8, ctx->stream));
     ctx->cd_state = 2;
+    ctx->count_deferred = false;
     CountArgs cnt;
     cnt.tile_cd = ctx->n_tiles ? (unsigned long long*)ctx->tile_cd.p : nullptr;
     cnt.len = (const int64_t*)ctx->d_len.p; cnt.tile_first = (const int64_t*)ctx->d_tile_first.p;

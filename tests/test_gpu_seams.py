@@ -85,6 +85,14 @@ def join_mode(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=["atomic", "radix"])
+def events_mode(request, monkeypatch):
+    """Both ways a depth build buckets its events by tile: one device-scope atomic per event, and (chosen by size in
+    production; GCI_EVENTS forces one) the radix partition by tile range with the counting in LDS."""
+    monkeypatch.setenv("GCI_EVENTS", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("n_files", [1, 2, 3])
 def test_name_join_matches_oracle(engine, oracle, n_files, join_mode):
     contigs = (("a", 900_000), ("b", 500_000))
@@ -113,7 +121,7 @@ def test_name_join_matches_oracle(engine, oracle, n_files, join_mode):
 _concat = synth.concat
 
 
-def test_depth_build_slice_semantics(engine, oracle):
+def test_depth_build_slice_semantics(engine, oracle, events_mode):
     rng = np.random.default_rng(5)
     lengths = {"x": 10_000, "y": 4096, "z": 4097, "w": 50, "v": 123_457}
     targets = list(lengths)
@@ -218,7 +226,7 @@ def test_gap_mask_max2_text(engine, oracle):
     assert two.mean() == oracle.mean_depth(want2)
 
 
-def test_fused_build_equals_seams_and_oracle(engine, oracle):
+def test_fused_build_equals_seams_and_oracle(engine, oracle, events_mode):
     """gci_depth_build_begin/finish: depth, text, sums and issue runs from the fused passes equal the
     separate seams (and therefore the oracle) -- including contig ends on / off tile boundaries."""
     rng = np.random.default_rng(17)
@@ -257,7 +265,7 @@ def test_fused_build_equals_seams_and_oracle(engine, oracle):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed):
+def test_fused_byproducts_sparse_and_dense_tiles(engine, oracle, seed, events_mode):
     """Pass 1 derives sums / text sizes / issue-run boundaries from the event list of a tile when the tile holds few
     events and from the dense difference array otherwise: low coverage with many short runs, runs crossing tile and
     window edges, pile-ups (> 63 events in a tile) next to empty tiles, contigs ending on and off tile boundaries."""
@@ -351,7 +359,7 @@ def test_dense_path_equals_event_list_path(engine, monkeypatch):
     assert len(a[1]) > 400_000
 
 
-def test_build_begin_twice_then_finish(engine):
+def test_build_begin_twice_then_finish(engine, events_mode):
     """A build that is begun again before it was finished (the wrapper does that when the issue-key buffer was too
     small) must not see the first attempt's per-tile counters: the table is re-zeroed."""
     import ctypes
@@ -465,7 +473,7 @@ def test_fasta_n_runs_on_gpu(engine, oracle, tmp_path):
     assert sum(len(v) for v in fasta.n_runs_device(engine, str(tmp_path / "lf60.fa"))[1].values()) > 20
 
 
-def test_counting_join_equals_join_then_count(engine, oracle, join_mode):
+def test_counting_join_equals_join_then_count(engine, oracle, join_mode, events_mode):
     """gci_name_join_count + gci_depth_build_begin(counted = 1) produce the same track, text, sums and issue runs as
     gci_name_join + a plain build; a counted build over other intervals or another flank is refused; a plain build after
     an unused counting join starts from a clean table."""
@@ -806,7 +814,7 @@ def test_partitioned_join_bucket_overflow_falls_back(engine, monkeypatch):
 
 
 @pytest.mark.parametrize("counted", [False, True])
-def test_fused_build_grows_the_issue_key_buffer(engine, oracle, counted):
+def test_fused_build_grows_the_issue_key_buffer(engine, oracle, counted, events_mode):
     """More issue-run boundaries than the key buffer holds (a fragmented, low-coverage assembly): depth_build_fused
     grows the buffer and runs its first pass again -- after a counting join, too, whose per-tile counts the first
     attempt has used up.  Depth, sums, text and runs must come out as from the oracle."""
