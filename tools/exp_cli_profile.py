@@ -1,30 +1,30 @@
 #!/usr/bin/env python3
-"""Where the drop-in command line spends its time at chr19 / 40x (cProfile of the second, warm run)."""
-import cProfile, contextlib, io, os, pstats, shutil, sys, tempfile, time
+"""Where the wall time of the drop-in command line goes (bench.py number 3: chr19 40x HiFi BAM with realistic SEQ / QUAL
+entropy): cProfile of the second in-process run, by cumulative time.  GPU work is asynchronous: kernels show up at the
+call that waits for them.  Usage: exp_cli_profile.py [scale]"""
+import contextlib, cProfile, io, os, pstats, shutil, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gci_amd import synth, cli
+from gci_amd import cli, hostio, synth
 from gci_amd.formats import bam as bamfmt
-
-threads = os.cpu_count() or 1
-tmp = tempfile.mkdtemp(prefix="gci_prof_")
-rs = synth.simulate_reads(synth.CHR19, 40, "hifi", seed=synth.seed_for(2, 0))
-stream, offs = synth.to_bam_stream(rs)
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+contigs = (("chr19", int(61_707_364 * scale)),)
+tmp = tempfile.mkdtemp(prefix="gci_cliprof_")
+rs = synth.simulate_reads(contigs, 40, "hifi", seed=synth.seed_for(2, 0))
+stream, _ = synth.to_bam_stream(rs, seq_qual="random", seed=7)
 bam, fa = os.path.join(tmp, "hifi.bam"), os.path.join(tmp, "ref.fa")
-bamfmt.write_bam_stream(bam, stream, level=1, threads=threads)
-synth.write_reference_fasta(fa, synth.CHR19)
-del stream
-for k in range(3):
-    od = os.path.join(tmp, "o%d" % k)
-    pr = cProfile.Profile() if k == 2 else None
-    t = time.perf_counter()
+bamfmt.write_bam_stream(bam, stream, level=1, threads=hostio.default_threads())
+del stream, rs
+synth.write_reference_fasta(fa, contigs)
+def run(k):
+    od = os.path.join(tmp, "out%d" % k)
+    t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        if pr:
-            pr.enable()
-        cli.main(["GCI.py", "-r", fa, "--hifi", bam, "-d", od, "-t", str(threads)])
-        torch.cuda.synchronize()
-        if pr:
-            pr.disable()
-    print("run %d: %.3f s" % (k, time.perf_counter() - t))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
-shutil.rmtree(tmp)
+        cli.main(["GCI.py", "-r", fa, "--hifi", bam, "-d", od, "-t", str(hostio.default_threads())])
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+print("run 0: %.3f s" % run(0)); print("run 1: %.3f s" % run(1))
+pr = cProfile.Profile(); pr.enable(); w = run(2); pr.disable()
+print("run 2 (profiled): %.3f s" % w)
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+shutil.rmtree(tmp, ignore_errors=True)
