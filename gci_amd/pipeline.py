@@ -546,8 +546,9 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
 
     With an index next to the file (`<bam>.bai`; the reference needs one for pysam's fetch) only the BGZF members
     that hold those records are read and inflated: the pseudo-bin samtools writes per reference (or the hull of its
-    chunks) gives the virtual offsets of the contig's first record and of the end of its last one.  Without an index
-    the whole file is ingested and K1 drops the records of the other contigs."""
+    chunks) gives the virtual offsets of the contig's first record and of the end of its last one; that run of members
+    is inflated and walked on the device (GCI_BAM_INGEST=gpu, the default) or on host threads.  Without an index the
+    whole file is ingested and K1 drops the records of the other contigs."""
     from . import hostio
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
     hdr = bamfmt.read_header(path)
@@ -569,6 +570,7 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
     raw = np.memmap(path, dtype=np.uint8, mode="r")
     pos, isz = hostio.bgzf_blocks(np.asarray(raw))
     cpos = pos[:isz.shape[0]].astype(np.int64)
+    on_device = os.environ.get("GCI_BAM_INGEST", "gpu") == "gpu"
     rec_parts, name_parts, off_parts, name_base, n_done = [], [], [], 0, 0
     for r, name in enumerate(hdr.references):
         if name not in own_set or index[r] is None:
@@ -581,12 +583,27 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
         last = b if (end & 0xFFFF) else b - 1                                    # (a range ending at offset 0 of a member stops before it)
         if last < a:
             continue
-        buf = hostio.bgzf_inflate(np.asarray(raw[int(pos[a]):int(pos[last + 1])]), threads=nthreads, check_crc=BGZF_CRC)
-        stop = int(isz[a:b].sum()) + (end & 0xFFFF)                              # end of the contig's last record inside buf
-        offs, _ = hostio.bam_chunk_offsets(buf[:stop], beg & 0xFFFF)
-        if offs.shape[0] == 0:
+        stop = int(isz[a:b].sum()) + (end & 0xFFFF)                              # end of the contig's last record inside the run
+        d_buf = d_off = None
+        if on_device and int(isz[a:last + 1].sum()) <= GPU_INFLATE_MAX:
+            # the run's members inflated and walked on the device (N1, as in bam_join_input)
+            p0 = int(pos[a])
+            try:
+                d_run = engine.bgzf_inflate(raw[p0:int(pos[last + 1])], pos[a:last + 2] - np.uint64(p0), isz[a:last + 1], check_crc=BGZF_CRC)
+            except GciError as e:
+                if e.rec >= 0:
+                    e.rec += a
+                raise
+            d_off, used, ok = engine.bam_record_offsets(d_run[:stop], beg & 0xFFFF, len(hdr.references))
+            if ok and used == stop:
+                d_buf = d_run[:stop]
+            del d_run
+        if d_buf is None:
+            buf = hostio.bgzf_inflate(np.asarray(raw[int(pos[a]):int(pos[last + 1])]), threads=nthreads, check_crc=BGZF_CRC)
+            offs, _ = hostio.bam_chunk_offsets(buf[:stop], beg & 0xFFFF)
+            d_buf, d_off = engine.to_device(buf[:stop]), engine.to_device(offs)
+        if d_off.shape[0] == 0:
             continue
-        d_buf, d_off = engine.to_device(buf[:stop]), engine.to_device(offs)
         try:
             recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=n_done)
         except GciError as e:
@@ -598,7 +615,7 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
         name_parts.append(names.clone())
         off_parts.append(noff[:-1] + name_base)
         name_base += int(names.shape[0])
-        n_done += int(offs.shape[0])
+        n_done += int(d_off.shape[0])
     recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
     names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
     noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
