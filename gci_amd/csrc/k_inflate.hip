@@ -240,6 +240,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__
         if (oc == 8) { st8(dst + op - 8, ob); ob = 0; oc = 0; }
     };
     for (bool last = false; !last && !bad;) {
+        // every block header must lie inside the payload (a damaged stream of empty non-final blocks would never end otherwise:
+        // everything else in a block is bounded by the member's output length)
+        if (32ll * B.taken - 8ll * head - B.bn + 3 > 8ll * pay_len) { bad = true; break; }
         need32(B);
         last = take(B, 1) != 0;
         const uint32_t type = take(B, 2);

@@ -285,23 +285,30 @@ class Engine:
         return blob[:total], off
 
     # ---- N1: BGZF inflate + record walk on the device (k_inflate.hip) ---------------------------------------------------
-    def bgzf_inflate(self, raw: np.ndarray, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True,
-                     prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """raw: the bytes of a BGZF file (or of a run of its members); pos (uint64, n + 1) / isize (uint64, n): its member
-        table (hostio.bgzf_blocks), pos relative to raw.  -> the inflated bytes on the device, behind the bytes of `prefix`
-        (the partial record a previous run of members ended in).  Raises GciError(GCI_E_MALFORMED, rec = member) on a bad
-        member / CRC."""
+    def upload_padded(self, raw: np.ndarray) -> torch.Tensor:
+        """The bytes of a BGZF file on the device with 16 readable bytes behind them (gci_bgzf_inflate_device takes its
+        input as whole aligned 16-byte blocks)."""
+        n_raw = int(raw.shape[0])
+        with torch.cuda.stream(self.stream), warnings.catch_warnings():      # (may be called from a helper thread)
+            warnings.simplefilter("ignore", UserWarning)                     # a read-only memmap is only read
+            d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
+            d_raw[n_raw:].zero_()
+            d_raw[:n_raw].copy_(torch.from_numpy(np.asarray(raw)))
+        return d_raw
+
+    def bgzf_inflate(self, raw: Optional[np.ndarray], pos: np.ndarray, isize: np.ndarray, check_crc: bool = True,
+                     prefix: Optional[torch.Tensor] = None, d_raw: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """raw: the bytes of a BGZF file (or of a run of its members) -- or d_raw, the same already on the device
+        (upload_padded); pos (uint64, n + 1) / isize (uint64, n): its member table (hostio.bgzf_blocks), pos relative to
+        raw.  -> the inflated bytes on the device, behind the bytes of `prefix` (the partial record a previous run of
+        members ended in).  Raises GciError(GCI_E_MALFORMED, rec = member) on a bad member / CRC."""
         n = int(isize.shape[0])
         off = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum(isize, out=off[1:])
         total = int(off[n])
-        n_raw, n_pre = int(raw.shape[0]), (int(prefix.shape[0]) if prefix is not None else 0)
-        # 16 readable bytes behind the last member: the decoder takes its input as whole aligned 16-byte blocks
-        d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
-        d_raw[n_raw:].zero_()
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", UserWarning)         # a read-only memmap is only read
-            d_raw[:n_raw].copy_(torch.from_numpy(np.asarray(raw)))
+        n_pre = int(prefix.shape[0]) if prefix is not None else 0
+        if d_raw is None:
+            d_raw = self.upload_padded(raw)
         d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
         out = torch.empty(max(n_pre + total, 1), dtype=torch.uint8, device=self.device)
         if n_pre:

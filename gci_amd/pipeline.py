@@ -277,8 +277,8 @@ GPU_INFLATE_MAX = int(os.environ.get("GCI_GPU_INFLATE_MAX", str(32 << 30)))
 BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
 
 
-def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int
-                        ) -> Optional[JoinInput]:
+def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int,
+                        d_raw: Optional[torch.Tensor] = None) -> Optional[JoinInput]:
     """ingest = "gpu".  A file whose inflated stream fits GCI_GPU_INFLATE_MAX stays on the device whole (the join reads
     the names inside it); a larger one goes through run by run of members (at most chunk_bytes inflated each): inflate,
     record walk, K1, and only the 32-byte records and the packed names are kept -- the partial record a run ends in is
@@ -289,7 +289,8 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     n_ref = len(hdr.references)
     total = int(isz.sum())
     if total <= GPU_INFLATE_MAX:
-        d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC)
+        d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC, d_raw=d_raw)
+        del d_raw
         d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, n_ref)
         if not ok:
             return None
@@ -297,6 +298,7 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
             raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % (total - used))
         recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
         return JoinInput(recs, d_bam, d_off, 36)
+    del d_raw
     groups, a, acc = [], 0, 0
     for i, sz in enumerate(isz.tolist()):
         if acc and acc + sz > chunk_bytes:
@@ -381,9 +383,22 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         # (gci_bgzf_inflate_device, CRC verified), the record offsets come from a parallel walk
         # (gci_bam_record_offsets_device) and K1 runs over the inflated stream.  A stream the parallel walk cannot follow
         # takes the heads path below.
-        pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+        # (the member table is made on the host while the file's bytes are on their way to the device; a file that may not
+        # fit -- BGZF deflates BAM 2.4 - 4 : 1 -- is uploaded run by run instead)
+        upload = None
+        if 0 < raw.shape[0] <= GPU_INFLATE_MAX // 8:
+            upload = ThreadPoolExecutor(1)
+            d_raw = upload.submit(engine.upload_padded, raw)
+        try:
+            pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+        finally:
+            if upload is not None:
+                try:
+                    d_raw = d_raw.result()
+                finally:
+                    upload.shutdown()
         if int(isz.sum()) > 0:
-            ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes)
+            ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, d_raw if upload is not None else None)
             if ji is not None:
                 return ji
         ingest = "heads"

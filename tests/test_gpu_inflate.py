@@ -56,6 +56,60 @@ def test_members_of_every_flavour(engine):
     assert len(members) > 50
 
 
+def test_match_shapes(engine):
+    """Every way a match is copied: periods 1 .. 7 and distances 8 .. 40 against lengths 3 .. 258, at the start of a
+    member, in its middle and ending exactly at its end (where the 8-byte stores must not run over into the next member)."""
+    rng = np.random.default_rng(5)
+    payloads = []
+    for dist in list(range(1, 41)) + [63, 64, 65, 257, 258, 259, 4096, 32768]:
+        seed = rng.integers(0, 256, dist, dtype=np.uint8).tobytes()
+        for length in (3, 4, 7, 8, 9, 15, 16, 17, 31, 32, 33, 257, 258):
+            rep = (seed * (length // dist + 2))[:length]
+            lead = rng.integers(0, 256, int(rng.integers(0, 24)), dtype=np.uint8).tobytes()
+            payloads.append(lead + seed + rep)                                   # the member ends with the match
+            payloads.append(seed + rep + lead)
+    members = [member(p, level=9) for p in payloads] + [member(p, level=6, strategy=zlib.Z_FIXED) for p in payloads[::7]]
+    want = payloads + payloads[::7]
+    raw = b"".join(members) + bgzf.BGZF_EOF
+    assert inflate_gpu(engine, raw) == b"".join(want)
+
+
+def test_damaged_payloads(engine):
+    """One flipped bit (or a cut) in the compressed bytes of one member of a file: the call reports that member whenever
+    zlib cannot reproduce the payload from the damaged bytes -- and never runs away (a stream of empty blocks ends at the
+    payload's end)."""
+    rng = np.random.default_rng(8)
+    text = (b"m64011_190830_220126/%d/ccs\t" * 700) % tuple(range(700))
+    base = [rng.integers(0, 64, 5000, dtype=np.uint8).tobytes(), text[:20000], bytes(3000), synth._hifi_qual_lut()[rng.integers(0, 256, 9000, dtype=np.uint8)].tobytes()]
+    good = [member(p, level=int(rng.integers(1, 10))) for p in base * 2]
+    reported = 0
+    for trial in range(60):
+        j = int(rng.integers(0, len(good)))
+        m = bytearray(good[j])
+        body = slice(18, len(m) - 8)
+        if trial % 6 == 5:                                                       # the payload replaced by empty stored blocks
+            fill = (b"\x00\x00\x00\xff\xff" * (len(m) // 5 + 1))[:body.stop - body.start]
+            m[body] = fill
+        else:
+            k = int(rng.integers(body.start, body.stop))
+            m[k] ^= 1 << int(rng.integers(0, 8))
+        try:
+            ok = zlib.decompress(bytes(m[body]), -15) == (base * 2)[j]
+        except zlib.error:
+            ok = False
+        raw = b"".join(good[:j]) + bytes(m) + b"".join(good[j + 1:]) + bgzf.BGZF_EOF
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        pos, isz = hostio.bgzf_blocks(buf)
+        if ok:
+            assert engine.bgzf_inflate(buf, pos, isz).cpu().numpy().tobytes() == b"".join(base * 2)
+        else:
+            with pytest.raises(GciError) as e:
+                engine.bgzf_inflate(buf, pos, isz)
+            assert e.value.status == GCI_E_MALFORMED and e.value.rec == j
+            reported += 1
+    assert reported > 40
+
+
 def test_bad_members_are_reported(engine):
     good = member(b"hello world" * 500)
     bad_crc = member(b"hello world" * 500, corrupt_crc=True)
