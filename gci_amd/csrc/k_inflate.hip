@@ -444,35 +444,53 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
 // =====================================================================================================================
 namespace {
 
-// "a BAM record could start at p" -- every field a well-formed record constrains (SAM spec 4.2)
-__device__ __forceinline__ bool plausible(const uint8_t* c /* 36 bytes */, int32_t n_ref)
+// "A BAM record could start at p": every field a well-formed record constrains (SAM spec 4.2) -- block_size >= 32, refID and
+// next_refID in [-1, n_ref), pos and next_pos >= -1, l_read_name >= 1, l_seq >= 0, and the fixed part + name + CIGAR + SEQ +
+// QUAL fit in block_size.
+// One thread looks at 16 consecutive byte positions of the stream: their 52 bytes as four aligned 16-byte loads (`s_al` is the
+// stream's address rounded down to 16 bytes, `delta` what was cut off), every field re-aligned in registers.  refID is
+// tested first: SEQ / QUAL bytes and text almost never form a value in [-1, n_ref), so the full test runs for few positions.
+__device__ __forceinline__ uint4 cand_load(const uint8_t* __restrict__ s_al, uint64_t q, uint64_t n_phys)
 {
-    int32_t w[9];
-    __builtin_memcpy(w, c, 36);
-    const int32_t block_size = w[0], ref_id = w[1], pos = w[2], l_seq = w[5], next_ref = w[6], next_pos = w[7];
-    const uint32_t l_read_name = (uint32_t)w[3] & 0xFFu, n_cigar = (uint32_t)w[4] & 0xFFFFu;
-    if (block_size < 32 || ref_id < -1 || ref_id >= n_ref || pos < -1 || l_read_name < 1 || l_seq < 0 || next_ref < -1 || next_ref >= n_ref ||
-        next_pos < -1)
-        return false;
-    const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
-    return need <= (uint64_t)(uint32_t)block_size;
+    if (q + 16 <= n_phys) return *reinterpret_cast<const uint4*>(s_al + q);
+    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int k = 0; k < 16; k++)
+        if (q + k < n_phys) w[k >> 2] = (w[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)s_al[q + k] << (8 * (k & 3)));
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-#define CAND_HALO 48
-__global__ __launch_bounds__(BLOCK) void k_rec_candidates(const uint8_t* __restrict__ s, uint64_t lo, uint64_t n, int32_t n_ref,
+__global__ __launch_bounds__(BLOCK) void k_rec_candidates(const uint8_t* __restrict__ s_al, uint32_t delta, uint64_t lo, uint64_t n, int32_t n_ref,
                                                           const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_count,
                                                           uint64_t* __restrict__ cand)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t buf[TILE + CAND_HALO];
     __shared__ uint32_t wtot[BLOCK / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint64_t base = lo + (uint64_t)blockIdx.x * TILE;
-    for (uint32_t i = t; i < TILE + CAND_HALO; i += BLOCK) buf[i] = base + i < n ? s[base + i] : 0xFF;
-    __syncthreads();
+    const uint64_t n_phys = n + delta;
+    const uint64_t q0 = (uint64_t)blockIdx.x * TILE + (uint64_t)t * 16;      // physical offset of this thread's first position
+    uint32_t d[17];
+    {
+        const uint4 v0 = cand_load(s_al, q0, n_phys), v1 = cand_load(s_al, q0 + 16, n_phys), v2 = cand_load(s_al, q0 + 32, n_phys),
+                    v3 = cand_load(s_al, q0 + 48, n_phys);
+        const uint32_t tmp[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = tmp[k];
+        d[16] = 0xFFFFFFFFu;
+    }
     uint32_t mask = 0;
+#pragma unroll
     for (int i = 0; i < 16; i++) {
-        const uint64_t p = base + (uint64_t)t * 16 + i;
-        if (p + 36 <= n && plausible(buf + t * 16 + i, n_ref)) mask |= 1u << i;
+        // dword k of the record that would start at byte i of the window
+#define FIELD(k) ((int32_t)__builtin_amdgcn_alignbyte(d[((i) >> 2) + (k) + 1], d[((i) >> 2) + (k)], (i) & 3))
+        const int32_t ref_id = FIELD(1);
+        if (ref_id < -1 || ref_id >= n_ref) continue;
+        const uint64_t q = q0 + i;
+        if (q < lo + delta || q + 36 > n_phys) continue;
+        const int32_t block_size = FIELD(0), pos = FIELD(2), l_seq = FIELD(5), next_ref = FIELD(6), next_pos = FIELD(7);
+        const uint32_t l_read_name = (uint32_t)FIELD(3) & 0xFFu, n_cigar = (uint32_t)FIELD(4) & 0xFFFFu;
+#undef FIELD
+        if (block_size < 32 || pos < -1 || l_read_name < 1 || l_seq < 0 || next_ref < -1 || next_ref >= n_ref || next_pos < -1) continue;
+        const uint64_t need = 32ull + l_read_name + 4ull * n_cigar + (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq;
+        if (need <= (uint64_t)(uint32_t)block_size) mask |= 1u << i;
     }
     const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
     const uint32_t inc = wave_inclusive<uint32_t>(cnt, lane);
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void k_rec_candidates(const uint8_t* __restr
     }
     uint32_t w = tile_off[blockIdx.x] + inc - cnt;
     for (int k = 0; k < wave; k++) w += wtot[k];
-    for (uint32_t m = mask; m; m &= m - 1) cand[w++] = base + (uint64_t)t * 16 + (uint32_t)__builtin_ctz(m);
+    for (uint32_t m = mask; m; m &= m - 1) cand[w++] = q0 + (uint32_t)__builtin_ctz(m) - delta;
 }
 
 #define NODE_END 0xFFFFFFFEu          // the record ends exactly at the end of the stream
@@ -569,14 +587,16 @@ extern "C" int gci_bam_record_offsets_device(gci_ctx* ctx, const uint8_t* d_stre
         GCI_TRY(gci_upload_small(ctx, d_result, init, sizeof init));
     }
     if (n_bytes - first_record < 36) return GCI_OK;                            // no complete record head: everything is tail
-    const uint64_t span = n_bytes - first_record;
-    const uint64_t n_tiles64 = (span + TILE - 1) / TILE;
+    // the candidate test walks the stream in tiles of TILE bytes counted from its address rounded down to 16 bytes
+    const uint32_t delta = (uint32_t)((uintptr_t)d_stream & 15u);
+    const uint8_t* s_al = d_stream - delta;
+    const uint64_t n_tiles64 = (n_bytes + delta + TILE - 1) / TILE;
     if (n_tiles64 > 0x7fffffffULL) return GCI_E_INVALID;
     const uint32_t n_tiles = (uint32_t)n_tiles64;
     GCI_TRY(gci_ensure(ctx, ctx->part_hist, (size_t)(n_tiles + 2) * 4));
     GCI_TRY(gci_ensure(ctx, ctx->part_blk, (size_t)(n_tiles / TILE + 2) * 4));
     uint32_t* d_tile = (uint32_t*)ctx->part_hist.p;
-    hipLaunchKernelGGL(k_rec_candidates, dim3(n_tiles), dim3(BLOCK), 0, st, d_stream, first_record, n_bytes, n_ref, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL(k_rec_candidates, dim3(n_tiles), dim3(BLOCK), 0, st, s_al, delta, first_record, n_bytes, n_ref, (const uint32_t*)nullptr,
                        d_tile, (uint64_t*)nullptr);
     LAUNCHCHK("k_rec_candidates(count)");
     int r = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_tile, d_tile, (uint32_t*)ctx->part_blk.p, (int64_t)n_tiles, true);
@@ -595,7 +615,7 @@ extern "C" int gci_bam_record_offsets_device(gci_ctx* ctx, const uint8_t* d_stre
     uint32_t* d_mark = d_jb + (nc + 1);
     uint32_t* d_flag = d_mark + (nc + 1);
     uint32_t* d_pos = d_flag + (nc + 1);
-    hipLaunchKernelGGL(k_rec_candidates, dim3(n_tiles), dim3(BLOCK), 0, st, d_stream, first_record, n_bytes, n_ref, (const uint32_t*)d_tile,
+    hipLaunchKernelGGL(k_rec_candidates, dim3(n_tiles), dim3(BLOCK), 0, st, s_al, delta, first_record, n_bytes, n_ref, (const uint32_t*)d_tile,
                        (uint32_t*)nullptr, d_cand);
     LAUNCHCHK("k_rec_candidates(write)");
     const dim3 grid((nc + BLOCK - 1) / BLOCK);

@@ -140,6 +140,11 @@ def test_bam_file_inflate_and_record_walk(engine, tmp_path, kind, cov, seq_qual)
     got, used, ok = engine.bam_record_offsets(d, hdr.first_record, len(hdr.references))
     assert ok and used == stream.shape[0]
     assert np.array_equal(got.cpu().numpy().view(np.uint64), offs)
+    # a stream that does not start at a 16-byte address (the candidate test reads aligned blocks)
+    for skip in (1, 5, 15):
+        got, used, ok = engine.bam_record_offsets(d[skip:], hdr.first_record - skip, len(hdr.references))
+        assert ok and used == stream.shape[0] - skip
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), offs - np.uint64(skip))
     # a chunk that ends inside a record: the complete records, and where the partial one begins
     cut = int(offs[len(offs) // 2]) + 50
     got, used, ok = engine.bam_record_offsets(d[:cut], hdr.first_record, len(hdr.references))
