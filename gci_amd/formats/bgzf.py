@@ -14,7 +14,7 @@ from __future__ import annotations
 import struct
 import zlib
 from concurrent.futures import ThreadPoolExecutor
-from typing import Iterable, List, Tuple
+from typing import List, Tuple
 
 import numpy as np
 
@@ -128,8 +128,3 @@ def read_file(path: str, threads: int = 1) -> np.ndarray:
 def write_file(path: str, data: bytes, level: int = 1, threads: int = 1) -> None:
     with open(path, "wb") as f:
         f.write(compress(data, level=level, threads=threads))
-
-
-def iter_members(raw: bytes) -> Iterable[bytes]:
-    for pos, size, _ in scan_blocks(raw):
-        yield raw[pos:pos + size]

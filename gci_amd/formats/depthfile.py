@@ -16,7 +16,7 @@ import gzip
 import hashlib
 import zlib
 from concurrent.futures import ThreadPoolExecutor
-from typing import Dict, Iterable, Iterator, List, Tuple
+from typing import Dict, Iterable, Iterator, Tuple
 
 import numpy as np
 
@@ -77,21 +77,4 @@ def read_depth_gz(path: str) -> Dict[str, np.ndarray]:
     for a, b in zip(bounds[:-1], bounds[1:]):
         name = bytes(data[starts[a] + 1:nl[a]]).decode()
         out[name] = vals[a + 1:b].copy()
-    return out
-
-
-def write_bed(path: str, rows: Iterable[Tuple[str, int, int]]) -> None:
-    with open(path, "w") as f:
-        for t, s, e in rows:
-            f.write("%s\t%d\t%d\n" % (t, s, e))
-
-
-def read_bed(path: str) -> List[Tuple[str, int, int]]:
-    out = []
-    with open(path) as f:
-        for line in f:
-            if not line.strip():
-                continue
-            t, s, e = line.rstrip("\n").split("\t")[:3]
-            out.append((t, int(s), int(e)))
     return out

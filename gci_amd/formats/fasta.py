@@ -49,10 +49,6 @@ def record_ids(path: str) -> List[str]:
     return [rid for rid, _ in _records(load(path))]
 
 
-def record_lengths(path: str) -> Dict[str, int]:
-    return {rid: int(np.count_nonzero(~_DROP[body])) for rid, body in _records(load(path))}
-
-
 def n_runs(path: str) -> Tuple[List[str], Dict[str, List[Tuple[int, int]]]]:
     """-> (record ids in file order, {id: [(start, end), ...]} only for ids that have runs).
 

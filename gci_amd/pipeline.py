@@ -29,7 +29,7 @@ from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
 from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
 from .formats import bam as bamfmt
-from .formats import depthfile, fasta
+from .formats import fasta
 
 _ENGINE: Optional[Engine] = None
 SHARD = None              # gci_amd.shard.Context of a multi-GPU run (set by cli.main), None for a single process
@@ -250,16 +250,6 @@ def _paf_join_input(engine: Engine, d: Dict[str, Tuple[str, int, int, int]], hig
     blob = np.frombuffer(b"".join(names) or b"\x00", dtype=np.uint8)
     return JoinInput(engine.to_device(recs.view(np.uint8).reshape(n, 32) if n else np.zeros((0, 32), np.uint8)),
                      engine.to_device(blob), engine.to_device(off), 0)
-
-
-def load_bam_to_device(engine: Engine, path: str, threads: int = 1):
-    """Inflate (native host threads), find record boundaries (the one serial step), upload."""
-    from . import hostio
-    stream = hostio.read_bgzf_file(path, threads=hostio.pick_threads(threads))
-    hdr = bamfmt.parse_header(stream)
-    offs, first = hostio.bam_record_offsets(stream)
-    assert first == hdr.first_record
-    return engine.to_device(stream), engine.to_device(offs), hdr
 
 
 # Where the PAF path of filter() runs: "gpu" (default, k_paf.hip) or "host" (native threads, gci_paf_filter).
@@ -817,12 +807,6 @@ def collapse_depth_range(depths: DepthTracks = None, leftmost=-1, rightmost=0, f
         a, b = _slice_bound(flank_len, L), _slice_bound(L - flank_len, L)
         out[t] = _issues_from_runs(runs[c], max(0, b - a), L, flank_len, start_pos)
     return out
-
-
-def collapse_region(depths: DepthTracks, target: str, start: int, end: int, leftmost, rightmost
-                    ) -> List[Tuple[int, int]]:
-    """collapse_depth_range({target: depths[target][start:end]}, leftmost, rightmost, 0, start)."""
-    return collapse_regions(depths, [(target, start, end)], leftmost, rightmost)[0]
 
 
 def collapse_regions(depths: DepthTracks, regions: Sequence[Tuple[str, int, int]], leftmost, rightmost

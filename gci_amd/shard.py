@@ -81,17 +81,6 @@ class Context:
         dist.all_gather_object(out, obj)
         return out
 
-    def all_gather_bytes(self, t: torch.Tensor) -> torch.Tensor:
-        """all_gather_into_tensor of equally shaped device tensors; through host memory with the gloo backend."""
-        if self.backend == "nccl":
-            out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t.contiguous())
-            return out
-        h = t.detach().cpu().contiguous()
-        parts = [torch.empty_like(h) for _ in range(self.world)]
-        dist.all_gather(parts, h)
-        return torch.cat(parts).to(t.device)
-
     def all_reduce_sum(self, values: Sequence[int]) -> List[int]:
         dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)

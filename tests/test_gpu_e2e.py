@@ -230,23 +230,30 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
             assert np.array_equal(depths[t], want2[t]), (knob, kw, t)
 
 
-def test_genome_scale_layout_chm13(engine, oracle):
+@pytest.mark.parametrize("layout,events", [("chm13", "atomic"), ("diploid", "radix")])
+def test_genome_scale_layout_chm13(engine, oracle, layout, events, monkeypatch):
     """BASELINE configs[2] geometry: CHM13 (25 contigs, 3.117 Gb => 761 k tiles, > 2^31 elements in one track).
     Intervals are generated directly (5x); checks that no 32-bit index is hiding anywhere: per-contig sums equal the
     sum of trimmed interval lengths, the fused by-products equal the stand-alone kernels, three whole contigs
-    (first, last = chrM, one in the middle past the 2^31st element) equal the oracle bit for bit, text sizes add up."""
+    (first, last = chrM, one in the middle past the 2^31st element) equal the oracle bit for bit, text sizes add up.
+    "diploid" (configs[4] geometry): both haplotypes + a contig of exactly three tiles, 6.2 Gb => 1.5 M tiles, with the
+    events bucketed by radix partition (tile ranges of 2048 tiles) instead of one atomic per event."""
+    monkeypatch.setenv("GCI_EVENTS", events)
     contigs = synth.CHM13
+    if layout == "diploid":
+        contigs = tuple(("mat_" + n, l) for n, l in synth.CHM13[:24]) + (("blk", 3 * 4096),) + tuple(("pat_" + n, l) for n, l in synth.CHM13)
     lens = np.array([l for _, l in contigs], dtype=np.int64)
     assert lens.sum() > 2**31
     rng = np.random.default_rng(2025)
     n = 900_000
     c = np.searchsorted(np.cumsum(lens), rng.integers(0, lens.sum(), n), side="right").astype(np.int32)
-    c[:200] = 24                                                     # some reads on chrM (16,569 bp)
+    c[:200] = 24                                                     # some reads on chrM (16,569 bp) / the three-tile contig
     L = lens[c]
     span = np.minimum(np.clip(rng.normal(18_000, 2_500, n), 5_000, 30_000).astype(np.int64), np.maximum(L - 1, 1))
     s = (rng.random(n) * (L - span)).astype(np.int64)
     e = s + span
     e[::1000] = L[::1000]                                            # reads reaching the contig end exactly
+    e[:50] = L[:50] + 100                                            # ... and beyond it: the slice [s + fl, e - fl + 1) stops at the end
     ivl = np.stack([c, s.astype(np.int32), e.astype(np.int32), np.zeros(n, np.int32)], axis=1).astype(np.int32)
     offs = engine.set_layout(lens.tolist())
     assert engine.total > 2**31 and offs[12] * 1 > 0
@@ -263,7 +270,7 @@ def test_genome_scale_layout_chm13(engine, oracle):
     tl = {nme: int(l) for nme, l in contigs}
     tr = pipeline.DepthTracks(engine, tl, track)
     names = [nme for nme, _ in contigs]
-    for ci in (0, 13, 24):                                           # chr1, chr14 (starts beyond 2^31 elements), chrM
+    for ci in ((0, 13, 24) if layout == "chm13" else (24, 30, len(contigs) - 1)):   # chr1, chr14 (starts beyond 2^31 elements), chrM
         assert ci != 13 or offs[ci] > 2**31
         sel = c == ci
         want = oracle.depth_build({i: (names[ci], int(s[i]), int(e[i])) for i in np.flatnonzero(sel)}, {names[ci]: tl[names[ci]]}, fl)[names[ci]]
