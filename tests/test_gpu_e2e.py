@@ -289,6 +289,6 @@ def test_genome_scale_layout_chm13(engine, oracle, layout, events, monkeypatch):
     text2, off2 = engine.depth_text(track)
     assert np.array_equal(off2, out["text_off"]) and torch.equal(text2, out["text"])
     # total text bytes = sum over bases of (digits + 1): recompute from the per-depth histogram of one big contig
-    h = np.bincount(tr["chr2"])
+    h = np.bincount(tr[names[1]])
     digits = np.array([len(str(v)) + 1 for v in range(h.shape[0])])
     assert int((h * digits).sum()) == int(out["text_off"][2] - out["text_off"][1])
