@@ -179,7 +179,9 @@ int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, doubl
 /* The same join, fused with the first pass of the depth build: the kernel that emits an interval also counts it into
  * the per-tile tables of the layout (flank = the build's --flank-len), so a gci_depth_build_begin over exactly this
  * output with opts.counted = 1 skips that pass (one dependent launch and one read of the intervals less).  Needs
- * gci_layout_set; if *d_n_out exceeds cap, call it again with more room before building. */
+ * gci_layout_set; if *d_n_out exceeds cap, call it again with more room before building.  From 2^20 records up the
+ * build buckets its events by radix partition and counts on the way (GCI_EVENTS=atomic|radix overrides): the call is then
+ * the plain join, and opts.counted = 1 still says "these are the intervals of that join". */
 int gci_name_join_count(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
                         const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
                         uint64_t* d_status, int flank);
