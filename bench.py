@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="genome workload: shrink every contig (testing only)")
     ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="chr19 workload: per-rank contig length")
     ap.add_argument("--coverage", type=float, default=40.0)
+    ap.add_argument("--reads", choices=["hifi", "ont"], default="hifi",
+                    help="genome workload: read type of the simulated files (ont: 2 900 CIGAR ops per record on average, "
+                         "the chunked long-CIGAR path; use with --scale: a whole-genome ONT heads stream is 40 GB per file)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip numbers (2) and (3) of SURVEY.md 8(d): the device pipeline incl. H2D / D2H and the "
@@ -268,7 +271,7 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
     rank).  The host arrays are generated BEFORE the HIP context exists (worker processes are forked)."""
     from gci_amd import synth, workloads
     base = synth.CHM13
-    inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0),
+    inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0), kind=args.reads,
                                 procs=max(1, workloads_default_procs() // max(1, world)))
     nper = len(inp.contigs)
     if world > 1:
@@ -303,7 +306,8 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
     w = Workload(eng, rank, world, contigs, files, heads=True, exchange=exchange, replicated=replicated,
                  name="CHM13 whole genome (%d contigs, %d bp)%s, HiFi %gx by two aligners (2 BAM files as heads streams, "
                       "-op join), filter x2 -> join -> depth -> issue scan -> depth text" % (
-                          nper, sum(l for _, l in inp.contigs), " x %d haplotypes" % world if world > 1 else "", args.coverage),
+                          nper, sum(l for _, l in inp.contigs), " x %d haplotypes" % world if world > 1 else "", args.coverage)
+                      + ("" if args.reads == "hifi" else " [ONT reads]"),
                  algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)})
     w.aligned_bases = inp.aligned_bases
     w.inp = inp if ((rank == 0 and world == 1) or args.verify_oracle) else None
