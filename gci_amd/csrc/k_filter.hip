@@ -91,30 +91,37 @@ __device__ __forceinline__ void report(unsigned long long* status, uint32_t rec,
 
 __device__ __forceinline__ bool has_zero_byte(uint32_t x) { return ((x - 0x01010101u) & ~x & 0x80808080u) != 0; }
 
-// The decision of GCI.py:163-168 from the op totals; fills r and returns a gci_status (GCI_OK also when filtered).
-// M = bases under M, = and X together.
-__device__ __forceinline__ int decide(gci_rec& r, int64_t M, int64_t I, int64_t D, int64_t N, int64_t S, bool have_nm,
-                                      bool nm_bad_type, int64_t NM, int32_t pos, int32_t contig, int32_t l_seq,
-                                      uint32_t n_cigar_field, int mapq, int mq_cutoff, double clip_percent,
-                                      double iden_percent)
+// The decision of GCI.py:163-168; fills r and returns a gci_status (GCI_OK also when filtered).  With M = bases under M, =
+// and X together, the op totals enter it only as S, den1 = M + I + S, den2 = M + I + D and rlen = M + D + N
+// (mm = NM - (I + D), GCI.py:164, appears as M - mm = den2 - NM).
+__device__ __forceinline__ int decide4(gci_rec& r, int64_t S, int64_t den1, int64_t den2, int64_t rlen, bool have_nm,
+                                       bool nm_bad_type, int64_t NM, int32_t pos, int32_t contig, int32_t l_seq,
+                                       uint32_t n_cigar_field, int mapq, int mq_cutoff, double clip_percent,
+                                       double iden_percent)
 {
     if (!have_nm) return GCI_E_NO_NM;                                              // get_tag('NM'): KeyError
     if (nm_bad_type) return GCI_E_BAD_NM_TYPE;
-    const int64_t mm = NM - (I + D);                                               // GCI.py:164
-    const int64_t den1 = M + I + S, den2 = M + I + D;
     if (den1 == 0) return GCI_E_ZERO_DIV;
     // Python's `and` short-circuits: the identity division only runs when the clip test passed
     if (!((double)S / (double)den1 <= clip_percent)) return GCI_OK;                // GCI.py:165
     if (den2 == 0) return GCI_E_ZERO_DIV;
-    if (!((double)(M - mm) / (double)den2 >= iden_percent)) return GCI_OK;
+    if (!((double)(den2 - NM) / (double)den2 >= iden_percent)) return GCI_OK;
     if (n_cigar_field == 0) return GCI_E_NO_END;
-    const int64_t rlen = M + D + N;
     r.contig = contig;
     r.start = pos;
     r.end = (int32_t)((int64_t)pos + (rlen > 0 ? rlen : 1));                        // bam_endpos
     r.qlen = l_seq;                                                                // query_length
     r.flags = GCI_REC_PASS | (mapq >= mq_cutoff ? GCI_REC_HQ : 0);                 // GCI.py:166-168
     return GCI_OK;
+}
+
+__device__ __forceinline__ int decide(gci_rec& r, int64_t M, int64_t I, int64_t D, int64_t N, int64_t S, bool have_nm,
+                                      bool nm_bad_type, int64_t NM, int32_t pos, int32_t contig, int32_t l_seq,
+                                      uint32_t n_cigar_field, int mapq, int mq_cutoff, double clip_percent,
+                                      double iden_percent)
+{
+    return decide4(r, S, M + I + S, M + I + D, M + D + N, have_nm, nm_bad_type, NM, pos, contig, l_seq, n_cigar_field, mapq, mq_cutoff,
+                   clip_percent, iden_percent);
 }
 
 // integer value of an NM tag whose type byte is at t (value follows); false if the type is not an integer
@@ -470,17 +477,17 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     const bool long_cigar = n_cigar > LONG_OPS;                // its totals are computed by k_cigar_chunks
     const bool odd = odd_name || long_cigar;
     const uint32_t staged_ops = odd ? 0u : min(n_cigar, (HEAD - cig_at) / 4u);
-    // CIGAR base totals of this lane's share of the ops, in registers: M/=/X, I, D, N, S (get_cigar_stats()[0],
-    // GCI.py:157-162; the other op codes do not enter the decision)
-    unsigned long long sM = 0, sI = 0, sD = 0, sN = 0, sS = 0;
+    // CIGAR base totals (get_cigar_stats()[0], GCI.py:157-162) of this lane's share of the ops, in registers -- not per op
+    // code but as the four sums the decision uses (decide4): S, den1 = M + I + S, den2 = M + I + D, rlen = M + D + N.  Which
+    // of them an op code feeds is a nibble of a constant (bit 0: S, 1: den1, 2: den2, 3: rlen; M, = and X feed the last three).
+    unsigned long long sS = 0, sQ = 0, sA = 0, sR = 0;
     auto add_op = [&](uint32_t v) {
-        const uint32_t op = v & 0xFu;
-        const unsigned long long len = v >> 4;
-        sM += ((0x181u >> op) & 1u) ? len : 0ull;
-        sI += op == 1u ? len : 0ull;
-        sD += op == 2u ? len : 0ull;
-        sN += op == 3u ? len : 0ull;
-        sS += op == 4u ? len : 0ull;
+        const uint32_t nib = (uint32_t)(0x0000000EE0038C6Eull >> (4u * (v & 0xFu)));
+        const uint32_t len = v >> 4;
+        sS += len & (0u - (nib & 1u));
+        sQ += len & (0u - ((nib >> 1) & 1u));
+        sA += len & (0u - ((nib >> 2) & 1u));
+        sR += len & (0u - ((nib >> 3) & 1u));
     };
     if (!odd) {
         // CIGAR words behind the staged head, straight from global memory.  Unaligned vector loads from global
@@ -623,11 +630,11 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     }
     // the four lanes' shares -> every lane of the group holds the record's totals
 #define GRP_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, G); if (G == 4) x += (unsigned long long)__shfl_xor((long long)x, 2, G); } while (0)
-    GRP_SUM(sM); GRP_SUM(sI); GRP_SUM(sD); GRP_SUM(sN); GRP_SUM(sS);
+    GRP_SUM(sS); GRP_SUM(sQ); GRP_SUM(sA); GRP_SUM(sR);
 #undef GRP_SUM
     if (gl != 0) return false;  // the rest is scalar per record
-    const int st = decide(r, (int64_t)sM, (int64_t)sI, (int64_t)sD, (int64_t)sN, (int64_t)sS, have_nm, nm_bad, NM, pos, contig, l_seq,
-                          n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
+    const int st = decide4(r, (int64_t)sS, (int64_t)sQ, (int64_t)sA, (int64_t)sR, have_nm, nm_bad, NM, pos, contig, l_seq,
+                           n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
     if (st != GCI_OK) report(lq.status_in, rec, st);
     out[rec] = r;
     TR(7);
