@@ -116,12 +116,21 @@ def _sharded() -> bool:
     return SHARD is not None and SHARD.world > 1
 
 
+def refuse_overwrite(path: str, force) -> None:
+    """The reference's guard in front of every output file (`-f` / `--force`).  In a contig-sharded run rank 0 looks -- another
+    rank could find what rank 0 has written in the meantime -- and all ranks leave together."""
+    hit = os.path.exists(path) and force == False  # noqa: E712
+    if _sharded():
+        hit = SHARD.all_reduce_sum([1 if (hit and _is_root()) else 0])[0] > 0
+    if hit:
+        sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+
+
 def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
     _, ns_bed = fasta.n_runs_device(default_engine(), reference)          # N4: the scan itself runs on the GPU
     if len(ns_bed) > 0:
         path = f"{directory}/{prefix}.gaps.bed"
-        if os.path.exists(path) and force == False:  # noqa: E712
-            sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+        refuse_overwrite(path, force)
         if _is_root():
             with open(path, "w") as f:
                 for target, segments in ns_bed.items():
@@ -486,8 +495,8 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     its run boundaries are then detected in the same pass that builds the depth (used as long as no gap
     mask modifies the track first)."""
     engine = engine or default_engine()
-    if write and os.path.exists(f"{directory}/{prefix}.depth.gz") and force == False:  # noqa: E712
-        sys.exit(f'ERROR!!! The file "{directory}/{prefix}.depth.gz" exists\nPlease use "-f" or "--force" to rewrite')
+    if write:
+        refuse_overwrite(f"{directory}/{prefix}.depth.gz", force)
     print(f"Filtering {log_reads_type} alignment files ...")
     if _sharded():
         return _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_percent, clip_percent, ovlp_percent,
@@ -757,8 +766,8 @@ def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, thread
 def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTracks = None, prefix="GCI_two_type",
                          directory=".", force=False, threads=1, write=True) -> DepthTracks:
     print("Merging HiFi and ONT depth file ...")
-    if write and os.path.exists(f"{directory}/{prefix}.depth.gz") and force == False:  # noqa: E712
-        sys.exit(f'ERROR!!! The file "{directory}/{prefix}.depth.gz" exists\nPlease use "-f" or "--force" to rewrite')
+    if write:
+        refuse_overwrite(f"{directory}/{prefix}.depth.gz", force)
     hifi_depths._bind()
     if nano_depths.targets != hifi_depths.targets or nano_depths.lengths != hifi_depths.lengths:
         # the reference indexes nano by the HiFi dict's keys; GCI() has already checked both headers agree
@@ -829,8 +838,7 @@ def merge_depth(depths: DepthTracks = None, prefix="GCI", threshold=0, flank_len
                 log_reads_type=""):
     print(f"Getting {log_reads_type} issues bed file detected by GCI ...")
     path = f"{directory}/{prefix}.{threshold}.depth.bed"
-    if os.path.exists(path) and force == False:  # noqa: E712
-        sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+    refuse_overwrite(path, force)
     merged = collapse_depth_range(depths, -1, threshold, flank_len, 0)
     if _sharded():                      # every rank scanned its contigs; the lists (<= 10^4 items) travel as objects
         union = {}
@@ -932,15 +940,13 @@ def compute_index(targets_length={}, prefix="GCI", directory=".", force=False, m
                   type_list=[], flank_len=15, dist_percent=0.005, regions_bed={}, depths_list=[], threshold=0,
                   chrs_list=[]):
     gci_path = f"{directory}/{prefix}.gci"
-    if os.path.exists(gci_path) and force == False:  # noqa: E712
-        sys.exit(f'ERROR!!! The file "{gci_path}" exists\nPlease use "-f" or "--force" to rewrite')
+    refuse_overwrite(gci_path, force)
     if _is_root():
         with open(gci_path, "w"):
             pass
     reg_path = f"{directory}/{prefix}.regions.gci"
     if len(regions_bed) > 0:
-        if os.path.exists(reg_path) and force == False:  # noqa: E712
-            sys.exit(f'ERROR!!! The file "{reg_path}" exists\nPlease use "-f" or "--force" to rewrite')
+        refuse_overwrite(reg_path, force)
     # progress lines are printed where the work happens (same lines, same order as GCI.py:553-607)
     print("Computing Theoretical minimum N50 and contigs number ...")
     rows, exp_n50, exp_ctg = score.expected_table(targets_length, chrs_list)

@@ -137,8 +137,7 @@ def plot_depth(depths_list: Sequence[pipeline.DepthTracks] = (), depth_min=0.1, 
     sharded, root = pipeline._sharded(), pipeline._is_root()
     for target in depths_list[0].all_targets:
         path = f"{directory}/images/{prefix}.{target}.{image_type}"
-        if os.path.exists(path) and force == False:  # noqa: E712
-            sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+        pipeline.refuse_overwrite(path, force)
     print("Plotting whole genome depth ...")
     averaged, y_frac, y_min, y_max = pipeline.pre_plot_base(depths_list, max_depths, window_size, 0)
     specs = [figure_spec(depths_list, target, averaged, mean_depths, y_frac, 0, depth_min, dist_percent, y_min, y_max,
@@ -157,8 +156,7 @@ def plot_depth(depths_list: Sequence[pipeline.DepthTracks] = (), depth_min=0.1, 
             for segment in segments:
                 start, end = segment[0], segment[1]
                 path = f"{directory}/images/{prefix}.{target}:{start}-{end}.{image_type}"
-                if os.path.exists(path) and force == False:  # noqa: E712
-                    sys.exit(f'ERROR!!! The file "{path}" exists\nPlease use "-f" or "--force" to rewrite')
+                pipeline.refuse_overwrite(path, force)
                 if target not in depths_list[0]:
                     continue                                             # another rank holds that contig
                 averaged, y_frac, y_min, y_max = pipeline.pre_plot_base(depths_list, max_depths, window_size, start,

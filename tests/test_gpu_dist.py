@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run_two_ranks(argv, port):
     env = dict(os.environ, GCI_DIST_BACKEND="gloo", GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "GCI.py")] + argv[1:]
+           "--master-port", str(port)] + (["--tee", "3", "--log-dir", os.environ["GCI_TEST_TLOG"]] if os.environ.get("GCI_TEST_TLOG") else []) + [
+           os.path.join(ROOT, "GCI.py")] + argv[1:]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
 
