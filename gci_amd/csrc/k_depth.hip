@@ -609,8 +609,86 @@ __device__ __forceinline__ void tile_dense(
     int32_t* __restrict__ depth, const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
     const uint32_t* __restrict__ g_lut);
 
-// One workgroup, four tiles: every wave does its own tile from the event list; a tile with too many events is then
-// done densely by the whole workgroup (no second launch: a dependent launch costs ~4.6 us even when it finds nothing).
+// The same by-products for TWO tiles per wave, 32 lanes each: a tile of 40x long-read data holds ~20 events, so a whole wave
+// per tile leaves two thirds of its lanes idle, and the pass is bound by instruction issue.  Everything that is per tile is
+// per lane here (uniform over a half); ranks come through ds_bpermute instead of v_readlane, scans stop at 32 lanes (the DPP
+// sequence without its last step), the 64-bit sum is two 32-bit ones (sum of segment lengths <= 4096: length * low / high
+// half of the depth cannot overflow).  For tiles with at most HALF_MAX events.
+#define HALF_MAX 30       // + the null event of the half's first lane + one lane for the padding behind a contig end
+
+__device__ __forceinline__ int32_t half_inclusive_i32(int32_t v)
+{
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);
+    return v;
+}
+
+__device__ __forceinline__ void tile_sparse1_half(
+    int64_t tile, uint32_t e0, uint32_t n_ev, uint32_t n_ev_max, const uint16_t* __restrict__ events, int32_t carry_in, int32_t c,
+    int64_t elem0, int64_t L, long long* __restrict__ tile_sum, uint32_t* __restrict__ tile_bytes, const IssueArgs& iss, int lane)
+{
+    const int hl = lane & 31, hb = lane & 32;
+    const int32_t valid = (int32_t)min((int64_t)TILE, L - elem0);
+    // first lane of the half: a null event at position 0; lanes 1 .. n_ev: the events
+    const bool has = hl >= 1 && (uint32_t)hl <= n_ev;
+    const uint32_t ev = has ? (uint32_t)events[e0 + hl - 1] : 0u;
+    const uint32_t key = hl == 0 ? 0u : has ? ((ev >> 1) << 7) | (uint32_t)hl : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j <= n_ev_max; j++)
+        rank += (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hb + j) << 2), (int)key) < key ? 1u : 0u;
+    const int32_t delta = has ? ((ev & 1u) ? -1 : 1) : 0;
+    const uint32_t packed = ((has ? ev >> 1 : hl == 0 ? 0u : (uint32_t)TILE) << 2) | (uint32_t)(delta + 1);
+    const uint32_t dst = (uint32_t)hl <= n_ev ? (uint32_t)hb + rank : (uint32_t)lane;
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)packed);
+    const int32_t p = min((int32_t)(got >> 2), valid);
+    const int32_t d = carry_in + half_inclusive_i32((int32_t)(got & 3u) - 1);
+    int32_t p_next = __shfl_down(p, 1, 64);
+    if (hl == 31) p_next = valid;
+    p_next = min(p_next, valid);
+    const int32_t seg = p_next - p;
+    const int32_t s_lo = half_inclusive_i32(seg * (int32_t)((uint32_t)d & 0xFFFFu));
+    const int32_t s_hi = half_inclusive_i32(seg * (d >> 16));
+    const int32_t bytes = half_inclusive_i32(seg * (int32_t)(ndigits_fast((uint32_t)d) + 1u));
+    if (hl == 31) { tile_sum[tile] = (long long)s_hi * 65536ll + (long long)s_lo; tile_bytes[tile] = (uint32_t)bytes; }
+    if (!iss.keys) return;
+    // ---- issue-run boundaries (the rules of tile_sparse1, masks cut to the half) ----------------------------------------
+    const int64_t wa = gci_slice_bound(iss.flank, L);
+    int64_t wb = gci_slice_bound(L - iss.flank, L);
+    if (wb < wa) wb = wa;
+    const bool low = d >= iss.lo && d <= iss.hi;
+    const bool nonempty = seg > 0;
+    const uint32_t m_ne = (uint32_t)(__ballot(nonempty) >> hb), m_low = (uint32_t)(__ballot(nonempty && low) >> hb);
+    const uint32_t below = hl ? m_ne & ((1u << hl) - 1u) : 0u;
+    const uint32_t above = hl < 31 ? m_ne >> (hl + 1) : 0u;
+    const bool first = below == 0u;
+    const bool prev_in_window = elem0 - 1 >= wa && elem0 - 1 < wb;
+    const bool low_prev = first ? (prev_in_window && carry_in >= iss.lo && carry_in <= iss.hi)
+                                : ((m_low >> (31 - __builtin_clz(below))) & 1u) != 0u;
+    const bool has_next = above != 0u;
+    const bool low_next = has_next && ((m_low >> (hl + 1 + __builtin_ctz(above))) & 1u) != 0u;
+    if (!nonempty) return;
+    const int64_t A = elem0 + p, B = elem0 + p_next;
+    const int64_t a = max(A, wa), b = min(B, wb);
+    auto put = [&](int64_t rel, bool is_end) {
+        const uint32_t slot = atomicAdd(iss.n_keys, 1u);
+        if (slot < iss.cap) iss.keys[slot] = issue_key((uint32_t)c, rel, is_end);
+    };
+    if (low && a < b) {
+        if (A <= wa || !low_prev) put(a - wa, false);
+        if (b == wb) put(wb - wa, true);
+        else if (has_next && !low_next) put(b - wa, true);
+    } else if (first && low_prev && A < wb) {
+        put(A - wa, true);
+    }
+}
+
+// One workgroup, eight tiles: every wave does two tiles from their event lists (together when both are small, else one after
+// the other); a tile with too many events is then done densely by the whole workgroup (no second launch: a dependent launch
+// costs ~4.6 us even when it finds nothing).
+#define PASS1_TILES (2 * (BLOCK / 64))
 __global__ __launch_bounds__(BLOCK) void k_tile_pass1(
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int64_t* __restrict__ tile_first, const int64_t* __restrict__ len, int32_t n_contigs, int64_t n_tiles,
@@ -618,27 +696,40 @@ __global__ __launch_bounds__(BLOCK) void k_tile_pass1(
     const uint32_t* __restrict__ g_lut)
 {
     const int lane = threadIdx.x & 63;
-    // the wave index is uniform: say so, and everything per tile (bounds, carry, offsets, loop counts) lives in SGPRs
-    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (tile < n_tiles) {
-        const uint32_t e0 = evt_off[tile], e1 = evt_off[tile + 1];
-        if ((int64_t)(e1 - e0) <= sparse_max) {
-            const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
-            tile_sparse1(tile, e0, e1 - e0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum, tile_bytes,
-                         iss, lane);
+    // the wave index is uniform: say so, and everything per tile of the one-tile path (bounds, carry, offsets, loop counts) lives in SGPRs
+    const int64_t t0 = ((int64_t)blockIdx.x * (BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 2;
+    if (t0 < n_tiles) {
+        const bool pair = t0 + 1 < n_tiles;
+        const int64_t mine = min(t0 + (lane >> 5), n_tiles - 1);            // the tile of this lane's half
+        const uint32_t e0 = evt_off[mine], n_ev = evt_off[mine + 1] - e0;
+        if (pair && __all((int64_t)n_ev <= (int64_t)min(sparse_max, HALF_MAX))) {
+            const int32_t c = contig_of_tile(tile_first, n_contigs, mine);
+            const uint32_t n_max = max((uint32_t)__builtin_amdgcn_readlane((int)n_ev, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_ev, 32));
+            tile_sparse1_half(mine, e0, n_ev, n_max, events, tile_carry[mine], c, (mine - tile_first[c]) * TILE, len[c], tile_sum, tile_bytes,
+                              iss, lane);
+        } else {
+            for (int k = 0; k < (pair ? 2 : 1); k++) {
+                const int64_t tile = t0 + k;
+                const uint32_t f0 = evt_off[tile], f1 = evt_off[tile + 1];
+                if ((int64_t)(f1 - f0) <= sparse_max) {
+                    const int32_t c = contig_of_tile(tile_first, n_contigs, tile);
+                    tile_sparse1(tile, f0, f1 - f0, events, tile_carry[tile], c, (tile - tile_first[c]) * TILE, len[c], tile_sum, tile_bytes,
+                                 iss, lane);
+                }
+            }
         }
     }
     // (written out rather than looped: a loop around tile_dense doubles its register count)
 #define DENSE_ONE(k)                                                                                                        \
     {                                                                                                                       \
-        const int64_t td = (int64_t)blockIdx.x * (BLOCK / 64) + (k);                                                        \
+        const int64_t td = (int64_t)blockIdx.x * PASS1_TILES + (k);                                                         \
         if (td < n_tiles && (int64_t)(evt_off[td + 1] - evt_off[td]) > sparse_max) {                                        \
             __syncthreads();                                                                                                \
             tile_dense<1>(td, events, evt_off, tile_carry, tile_first, len, n_contigs, tile_sum, tile_bytes, iss, nullptr,  \
                           nullptr, nullptr, 0, g_lut);                                                                      \
         }                                                                                                                   \
     }
-    DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3)
+    DENSE_ONE(0) DENSE_ONE(1) DENSE_ONE(2) DENSE_ONE(3) DENSE_ONE(4) DENSE_ONE(5) DENSE_ONE(6) DENSE_ONE(7)
 #undef DENSE_ONE
 }
 
@@ -965,7 +1056,7 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
     const int64_t* ln = (const int64_t*)ctx->d_len.p;
     const int32_t* tv = (const int32_t*)ctx->d_tile_valid.p;
     const int64_t per = BLOCK / 64;
-    const dim3 grid((uint32_t)((ctx->n_tiles + per - 1) / per));
+    const dim3 grid((uint32_t)((ctx->n_tiles + PASS1_TILES - 1) / PASS1_TILES));
     const dim3 grid2((uint32_t)((ctx->n_tiles * SHARE + per - 1) / per));
     const dim3 list_grid((uint32_t)((ctx->n_tiles + BLOCK - 1) / BLOCK));
     const dim3 dense_grid((uint32_t)((ctx->n_tiles + DENSE_SPAN - 1) / DENSE_SPAN));
