@@ -1,0 +1,41 @@
+"""The driver's contract of bench.py on one GPU, at a scale that takes seconds: ONE JSON line on stdout with the metric of
+BASELINE.json, the roofline of the dominant kernel from HIP events over the timed region, the step-level roofline, the CPU
+baseline object, the three numbers of SURVEY.md 8(d) and the full-size parity verdict."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.02", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Gbases/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["aligned_bases_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches"] == 4
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["avg_launch_ms"] < d["ms_per_step"]
+    assert 0 < d["step_roofline"]["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Gbases/s" and cb["sample"]
+    assert d["parity_vs_oracle_full_size"] is True
+    s8 = d["survey_8d"]
+    assert s8["1_kernels_only_gbases_per_s"] == d["value"]
+    assert s8["2_device_pipeline_incl_h2d_d2h"]["seconds"] > 0 and s8["3_command_line_chr19_realistic_bam"]["seconds"] > 0
+    two = d["two_steps_in_flight"]
+    assert two["status_ok"] and two["same_track_as_one_in_flight"]
