@@ -31,11 +31,6 @@ namespace {
 
 #define LIT_BITS 8
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
-                                         4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 constexpr uint32_t CRC_POLY = 0xEDB88320u;      // reflected: bit 31 holds x^0
@@ -118,14 +113,18 @@ __device__ void build_table(const Canon& cn, const uint16_t* sorted, uint16_t* t
 
 // The compressed bytes arrive as naturally aligned 16-byte loads, one block AHEAD of the one being consumed (the load
 // issued when a block is taken up is needed 16 payload bytes later), and move into the bit buffer a dword at a time.
+// 16 bytes in the global address space (a generic pointer kept in a struct becomes flat loads, which also count as LDS traffic)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gu4;
+__device__ __forceinline__ uint4 ld_block(const gu4* p) { const u32x4 v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
 struct Bits {
     unsigned long long bb;      // bit buffer, next bit = bit 0
     int bn;                     // valid bits
     uint4 res;                  // the block being consumed (lowest dword first)
     int rn;                     // dwords left in res
     uint4 nxt;                  // the block after it
-    const uint4* q;             // the block after nxt
-    const uint4* qlim;          // the block holding the member's last byte: nothing is loaded beyond it
+    const gu4* q;               // the block after nxt
+    const gu4* qlim;            // the block holding the member's last byte: nothing is loaded beyond it
     uint32_t taken;             // dwords moved out of res so far
 };
 
@@ -135,7 +134,7 @@ __device__ __forceinline__ void next_dword(Bits& B)
     B.rn--; B.taken++;
     if (B.rn == 0) {
         B.res = B.nxt; B.rn = 4;
-        B.nxt = *B.q;
+        B.nxt = ld_block(B.q);
         B.q = B.q < B.qlim ? B.q + 1 : B.q;
     }
 }
@@ -211,11 +210,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__
             pay_len = (uint32_t)(pos_next - 8 - pay0);
             const uintptr_t a0 = (uintptr_t)(raw + pay0);
             head = (uint32_t)(a0 & 15u);
-            const uint4* base = reinterpret_cast<const uint4*>(a0 - head);
-            B.qlim = reinterpret_cast<const uint4*>((uintptr_t)(raw + pos_next - 1) & ~(uintptr_t)15);
-            B.res = base[0];
+            const gu4* base = (const gu4*)(a0 - head);
+            B.qlim = (const gu4*)((uintptr_t)(raw + pos_next - 1) & ~(uintptr_t)15);
+            B.res = ld_block(base);
             B.q = base < B.qlim ? base + 1 : base;
-            B.nxt = *B.q;
+            B.nxt = ld_block(B.q);
             B.q = B.q < B.qlim ? B.q + 1 : B.q;
             for (uint32_t k = 0; k < (head >> 2); k++) next_dword(B);          // the bytes in front of the payload
             need32(B);
@@ -298,11 +297,16 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__
             }
             if (sym < 0 || sym > 285) { bad = true; break; }
             if (sym == 256) break;
-            uint32_t len = c_len_base[sym - 257] + take(B, c_len_extra[sym - 257]);
+            // length and distance codes (RFC 1951 3.2.5) by arithmetic: a table in constant memory is a vector-memory load
+            // and a wait per look-up here
+            const uint32_t lc = (uint32_t)sym - 257u;
+            const uint32_t le = lc < 8u || lc == 28u ? 0u : (lc >> 2) - 1u;
+            uint32_t len = (lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << le)) + take(B, (int)le);
             need32(B);
             const int ds = decode<0, 15>(B, nullptr, T.dist_cn, T.dist_sorted);
             if (ds < 0 || ds > 29) { bad = true; break; }
-            const uint32_t dist = c_dist_base[ds] + take(B, c_dist_extra[ds]);
+            const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+            const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
             if (dist > op || op + len > isize) { bad = true; break; }
             // the copy reads this member's own output back from memory (a lane's stores and loads stay in order)
             flush();
