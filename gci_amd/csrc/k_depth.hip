@@ -981,7 +981,12 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const int lane = threadIdx.x & 63;
     // the wave index is uniform: say so, and everything per tile (bounds, carry, offsets, loop counts) lives in SGPRs
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t gw = (int64_t)blockIdx.x * (BLOCK / 64) + wv;               // SHARE consecutive waves share a tile
+    // Workgroups go to the 8 XCDs round robin: give every XCD a contiguous eighth of the tiles, so that each of them streams
+    // its own stretch of the track and the text instead of all eight interleaving 16 KiB pieces of one front
+    // (3.33 instead of 3.55 - 4.6 ms at genome scale, and the same from run to run).
+    const uint32_t per8 = gridDim.x / 8;
+    const uint32_t bx = blockIdx.x < per8 * 8 ? (blockIdx.x % 8) * per8 + blockIdx.x / 8 : blockIdx.x;
+    const int64_t gw = (int64_t)bx * (BLOCK / 64) + wv;                       // SHARE consecutive waves share a tile
     const int64_t tile = gw / SHARE;
     const uint32_t wi = (uint32_t)(gw % SHARE);
     if (tile >= n_tiles) return;
