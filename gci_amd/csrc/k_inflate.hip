@@ -6,15 +6,17 @@
 // every member a whole wave (window and tables in LDS, every lane holding the same decoder state): correct, and bound by
 // instruction issue on one lane's worth of work -- ~50 instructions per symbol, one wave per SIMD because of the 32 KiB
 // window -- i.e. no faster than 32 host threads (5.9 GB/s).  This version gives every member ONE LANE:
-//   * decoder state (bit buffer, positions) in registers; the lane's decode tables in LDS (9-bit primary table for
-//     literals / lengths, 7-bit for distances, canonical first-code tables for the longer codes: 2.5 KB per member,
-//     INF_LANES members per workgroup);
+//   * decoder state (bit buffer, positions) in registers; the lane's decode tables in LDS (8-bit primary table for
+//     literals / lengths -- the block's code lengths share its space until the codes are built --, the symbols sorted by
+//     code and 16 "limits" per alphabet for the longer codes and the distances: 1.3 KB per member, L members per
+//     workgroup of one wave);
 //   * no window: the output buffer in HBM is the window (a member's matches only reach back into its own output; a wave's
 //     memory operations are issued in order, so a lane reads back what it has just written);
-//   * the compressed bytes through naturally aligned dword loads re-aligned in registers.
-// Lanes diverge (literal / match, code lengths), but every wave instruction now serves INF_LANES members, and a CU holds
-// 3 x INF_LANES of them.  Stored, fixed and dynamic blocks.  Every member's output length is checked here, its CRC-32 by
-// k_bgzf_crc: one wave per member over the finished output, every lane the CRC register of its share, the shares
+//   * the compressed bytes as naturally aligned 16-byte blocks, moved into the bit buffer a dword at a time; literals
+//     gathered in a register and stored eight at a time; matches copied in 8-byte pieces (any address).
+// Lanes diverge (literal / match, code lengths), but every wave instruction now serves L members, and a CU holds 112 of
+// them (L = 8: 14 workgroups).  Stored, fixed and dynamic blocks.  Every member's output length is checked here, its CRC-32
+// by k_bgzf_crc: one wave per member over the finished output, every lane the CRC register of its share, the shares
 // concatenated with the GF(2) rule crc(A||B) = crc(A) * x^(8|B|) + crc(B) (as htslib verifies every block).
 //
 // gci_bam_record_offsets_device: the offsets of the records of an inflated BAM stream WITHOUT walking the block_size
