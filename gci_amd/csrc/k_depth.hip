@@ -7,12 +7,14 @@
 //                  event in tile(b), and adds +1 / -1 to a coarse per-tile table (one int per 4096 bases).
 //   k_scan2_*      exclusive scans of both per-tile tables: bucket offsets and every tile's carry-in.
 //   k_evt_scatter  writes each event (12-bit position in its tile + sign) into its tile's bucket.
-//   k_tile_build   one workgroup per tile: zero a 16 KiB difference array in LDS, LDS-atomicAdd the tile's
-//                  events (about 2 * coverage * 4096 / read length of them: ~20 at 40x HiFi), wave/workgroup
-//                  prefix sum seeded with the carry-in, and
-//                    pass 1 (by-products, no HBM write of depth): per-tile sum, decimal-text byte count,
-//                            optionally the issue-scan run boundaries;
-//                    pass 2: the depth track (16-byte coalesced stores) and, optionally, its decimal text.
+//   k_evp_*        the same bucketing for large inputs by radix partition over tile ranges (no device-scope atomics).
+//   k_tile_pass1   by-products without any HBM write of depth: per-tile sum, decimal-text byte count, optionally the
+//                  issue-scan run boundaries.  A tile of long-read data holds ~20 events, so it is never materialised:
+//                  the events are ranked by position and every lane owns one constant-depth segment (two tiles per wave).
+//   k_tile_build   the depth track (16-byte stores) and, optionally, its decimal text, again from the segments; four
+//                  waves per tile, workgroups mapped to tiles so that every XCD owns a contiguous part of the genome.
+//   k_tile_dense   tiles with many events (short reads, pile-ups) or four-digit depths: a workgroup zeroes a 16 KiB
+//                  difference array in LDS, LDS-atomicAdds the tile's events, prefix-sums it seeded with the carry-in.
 //
 // HBM traffic of the depth build is therefore its OUTPUT only: 4 B/base (+ text bytes), instead of
 // memset 4 + scan read 4 + write 4 (+ 4 to count text + 4 to render it + 4 to scan issues + 4 to sum).
