@@ -124,15 +124,21 @@ __global__ __launch_bounds__(BLOCK) void k_evp_part(const gci_ivl* __restrict__ 
 template <int PLACE>
 __global__ __launch_bounds__(BLOCK) void k_evp_tiles(const uint32_t* __restrict__ items, const uint32_t* __restrict__ hist, uint32_t n_wg,
                                                      int sh, int64_t n_tiles, unsigned long long* __restrict__ tile_cd,
-                                                     const uint32_t* __restrict__ evt_off, uint16_t* __restrict__ events)
+                                                     const uint32_t* __restrict__ evt_off, uint16_t* __restrict__ events, uint32_t stage_cap)
 {
-    extern __shared__ unsigned long long evp_lds[];                 // 2^sh entries
+    extern __shared__ unsigned long long evp_lds[];                 // 2^sh entries (+ PLACE: stage_cap events)
     const uint32_t per = 1u << sh;
     const int64_t t0 = (int64_t)blockIdx.x << sh;
     const uint32_t nt = (uint32_t)min((int64_t)per, n_tiles - t0);
     uint32_t* cur = reinterpret_cast<uint32_t*>(evp_lds);
+    // PLACE: the range's events form one contiguous stretch of the bucket array; when it fits (stage_cap events, the usual
+    // case) it is put together in LDS behind the cursors and leaves as one coalesced copy -- 2-byte stores scattered over
+    // the stretch cost 19 bytes of HBM writes per byte.
+    uint16_t* stage = reinterpret_cast<uint16_t*>(evp_lds + per);
+    const uint32_t e_lo = PLACE ? evt_off[t0] : 0u, e_hi = PLACE ? evt_off[t0 + nt] : 0u;
+    const bool staged = PLACE && e_hi - e_lo <= stage_cap;
     for (uint32_t i = threadIdx.x; i < nt; i += BLOCK) {
-        if (PLACE) cur[i] = evt_off[t0 + i];
+        if (PLACE) cur[i] = evt_off[t0 + i] - (staged ? e_lo : 0u);
         else evp_lds[i] = 0ull;
     }
     __syncthreads();
@@ -140,10 +146,26 @@ __global__ __launch_bounds__(BLOCK) void k_evp_tiles(const uint32_t* __restrict_
     for (uint32_t i = a + threadIdx.x; i < b; i += BLOCK) {
         const uint32_t w = items[i], tl = w >> 14, kind = w & 3u;
         if (PLACE) {
-            if (kind < 2u) events[atomicAdd(&cur[tl], 1u)] = (uint16_t)((((w >> 2) & 0xFFFu) << 1) | kind);
+            if (kind < 2u) {
+                const uint16_t v = (uint16_t)((((w >> 2) & 0xFFFu) << 1) | kind);
+                const uint32_t at = atomicAdd(&cur[tl], 1u);
+                if (staged) stage[at] = v; else events[at] = v;
+            }
         } else {
             atomicAdd(&evp_lds[tl], kind == 0u ? (1ull | (1ull << 32)) : kind == 1u ? (1ull | (0xFFFFFFFFull << 32)) : (0xFFFFFFFFull << 32));
         }
+    }
+    __syncthreads();
+    if (staged) {
+        // dwords where the stretch allows (it starts at an even or odd event index), single events at its ends
+        uint16_t* out = events + e_lo;
+        const uint32_t n_e = e_hi - e_lo, head = (e_lo & 1u) && n_e ? 1u : 0u;
+        if (head && threadIdx.x == 0) out[0] = stage[0];
+        const uint32_t pairs = (n_e - head) >> 1;
+        uint32_t* out32 = reinterpret_cast<uint32_t*>(out + head);
+        for (uint32_t i = threadIdx.x; i < pairs; i += BLOCK)
+            out32[i] = (uint32_t)stage[head + 2 * i] | ((uint32_t)stage[head + 2 * i + 1] << 16);
+        if (((n_e - head) & 1u) && threadIdx.x == 0) out[n_e - 1] = stage[n_e - 1];
     }
     __syncthreads();
     if (PLACE) {
@@ -1142,7 +1164,7 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
                            ctx->n_contigs, evp_sh, evp_nb, evp_wg, hist, items);
         LAUNCHCHK("k_evp_part<scatter>");
         hipLaunchKernelGGL(k_evp_tiles<0>, dim3(evp_nb), dim3(BLOCK), sizeof(unsigned long long) << evp_sh, ctx->stream,
-                           (const uint32_t*)items, (const uint32_t*)hist, evp_wg, evp_sh, nt, cd, (const uint32_t*)off, (uint16_t*)nullptr);
+                           (const uint32_t*)items, (const uint32_t*)hist, evp_wg, evp_sh, nt, cd, (const uint32_t*)off, (uint16_t*)nullptr, 0u);
         LAUNCHCHK("k_evp_tiles<count>");
     } else if (!counted && ctx->cd_state != 0) {
         HIPCHK(hipMemsetAsync(cd, 0, (size_t)(nt + 1) * 8, ctx->stream));
@@ -1173,9 +1195,12 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     }
     if (radix) {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
-        hipLaunchKernelGGL(k_evp_tiles<1>, dim3(evp_nb), dim3(BLOCK), sizeof(unsigned long long) << evp_sh, ctx->stream,
+        // (a workgroup may have 64 KiB of LDS: what the cursors leave is the staging area of the range's events)
+        const size_t cursors = sizeof(unsigned long long) << evp_sh;
+        const uint32_t stage_cap = (uint32_t)((65536 - cursors) / sizeof(uint16_t));
+        hipLaunchKernelGGL(k_evp_tiles<1>, dim3(evp_nb), dim3(BLOCK), cursors + stage_cap * sizeof(uint16_t), ctx->stream,
                            (const uint32_t*)ctx->evp_items.p, (const uint32_t*)ctx->evp_hist.p, evp_wg, evp_sh, nt, cd,
-                           (const uint32_t*)off, (uint16_t*)ctx->events.p);
+                           (const uint32_t*)off, (uint16_t*)ctx->events.p, stage_cap);
         LAUNCHCHK("k_evp_tiles<place>");
     } else if (max_n) {
         ProfScope _ps(ctx, GCI_PROF_DEPTH_DIFF);
