@@ -50,6 +50,27 @@ def test_two_ranks_reproduce_the_reference(k, case, tmp_path):
     assert rest.replace(out, "{OUT}").replace(inp, "{IN}") == manifest(case)["stdout"]
 
 
+def test_two_ranks_fragmented_assembly(tmp_path):
+    """2 500 scaffolds over two ranks (tests/frag_util.py): the sharded run writes the files of the one-process run (which
+    tests/test_gpu_e2e.py holds against the oracle) -- LPT packing of thousands of contigs, the per-contig ingestion through
+    the index for 1 250 contigs per rank, gathers of thousands of small pieces."""
+    import frag_util
+    inp = str(tmp_path / "in")
+    _, args = frag_util.write_inputs(inp)
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "GCI.py")] + args + ["-d", one], capture_output=True, text=True, timeout=900,
+                        env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = run_two_ranks(["GCI.py"] + args + ["-d", two], 29790)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    a, b = read_outputs(one), read_outputs(two)
+    assert sorted(a) == sorted(b) and len(a) == 8
+    for fn in a:
+        assert a[fn] == b[fn], fn
+    strip = lambda t: re.sub(r"\[Gloo\][^\n]*\n", "", t)      # noqa: E731
+    assert strip(r2.stdout).replace(two, "{OUT}") == r1.stdout.replace(one, "{OUT}")
+
+
 def test_more_ranks_than_contigs_is_refused(tmp_path):
     r = run_two_ranks(cli_args("c1_single_bam", str(tmp_path / "out")), 29731)
     assert r.returncode != 0 and "2 GPUs for 1 contig(s)" in r.stderr

@@ -292,3 +292,35 @@ def test_genome_scale_layout_chm13(engine, oracle, layout, events, monkeypatch):
     h = np.bincount(tr[names[1]])
     digits = np.array([len(str(v)) + 1 for v in range(h.shape[0])])
     assert int((h * digits).sum()) == int(out["text_off"][2] - out["text_off"][1])
+
+
+def test_fragmented_assembly_two_types(engine, oracle, tmp_path, capsys):
+    """A fragmented assembly (tests/frag_util.py) through the command line against the oracle's whole path."""
+    import frag_util
+    from gci_amd import cli
+    from gci_amd.formats import bam as bamfmt
+    from gci_amd.formats import fasta
+    inp = str(tmp_path / "in")
+    contigs, args = frag_util.write_inputs(inp)
+    out = str(tmp_path / "out")
+    cli.main(["GCI.py"] + args + ["-d", out])
+    capsys.readouterr()
+
+    def kind(names):
+        d = {"paf": [], "bam": []}
+        for nm in names:
+            p = os.path.join(inp, nm)
+            if nm.endswith(".bam"):
+                stream, hdr, offs = bamfmt.read_bam(p, threads=4)
+                d["bam"].append((stream, offs, list(hdr.references)))
+            else:
+                d["paf"].append(p)
+        return d
+
+    _, ns_bed = fasta.n_runs(os.path.join(inp, "ref.fa"))
+    want = oracle.run_path(hifi=kind(["h.bam", "h.paf"]), nano=kind(["n.paf", "n.bam"]), references=[c for c, _ in contigs],
+                           lengths=[l for _, l in contigs], ns_bed=ns_bed or None, threshold=1)
+    got = read_outputs(out)
+    assert sorted(got) == sorted(want)
+    for fn in want:
+        assert got[fn] == want[fn], fn
