@@ -50,6 +50,21 @@ def test_two_ranks_reproduce_the_reference(k, case, tmp_path):
     assert rest.replace(out, "{OUT}").replace(inp, "{IN}") == manifest(case)["stdout"]
 
 
+def test_gpus_switch_relaunches_itself(tmp_path):
+    """`python GCI.py --gpus 2 ...` (this implementation's own switch): the process re-launches itself under
+    torch.distributed.run, one process per GPU, and writes the reference's files."""
+    case = "c3_two_bam"
+    out = str(tmp_path / "out")
+    argv = cli_args(case, out)
+    env = dict(os.environ, GCI_DIST_BACKEND="gloo", GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "GCI.py"), "--gpus", "2"] + argv[1:], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got, want = read_outputs(out), expected(case)
+    assert sorted(got) == sorted(want)
+    for fn in want:
+        assert got[fn] == want[fn], fn
+
+
 def test_two_ranks_fragmented_assembly(tmp_path):
     """2 500 scaffolds over two ranks (tests/frag_util.py): the sharded run writes the files of the one-process run (which
     tests/test_gpu_e2e.py holds against the oracle) -- LPT packing of thousands of contigs, the per-contig ingestion through
