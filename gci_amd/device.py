@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 import warnings
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -317,6 +318,77 @@ class Engine:
                                                    int(check_crc), self._p(self._status)), "gci_bgzf_inflate_device")
         self.check_status("gci_bgzf_inflate_device")
         return out[:n_pre + total]
+
+    def start_upload(self, raw: np.ndarray, parts: int = 2):
+        """Begin uploading the bytes of a BGZF file in `parts` pieces on a copy stream of its own (a helper thread: the
+        copies come from pageable memory and block their caller) -> a handle for bgzf_inflate_uploaded, which starts
+        inflating the members of a piece as soon as that piece has arrived."""
+        from concurrent.futures import ThreadPoolExecutor
+        n_raw = int(raw.shape[0])
+        cuts = sorted({min(n_raw, (n_raw * (k + 1) // parts + 15) & ~15) for k in range(parts)} | {n_raw})
+        d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
+        copy_stream = torch.cuda.Stream(device=self.device)
+        copy_stream.wait_stream(self.stream)                     # (the allocation may recycle memory still in use on the main stream)
+        events = [torch.cuda.Event() for _ in cuts]
+        queued = [threading.Event() for _ in cuts]               # (a CUDA event that was never recorded counts as complete)
+
+        def run():
+            with torch.cuda.stream(copy_stream), warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)     # a read-only memmap is only read
+                d_raw[n_raw:].zero_()
+                lo = 0
+                for k, hi in enumerate(cuts):
+                    if hi > lo:
+                        d_raw[lo:hi].copy_(torch.from_numpy(np.asarray(raw[lo:hi])))
+                    events[k].record(copy_stream)
+                    queued[k].set()
+                    lo = hi
+            return True
+
+        pool = ThreadPoolExecutor(1)
+        return dict(d_raw=d_raw, cuts=cuts, events=events, queued=queued, future=pool.submit(run), pool=pool, stream=copy_stream)
+
+    def bgzf_inflate_uploaded(self, up, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True) -> torch.Tensor:
+        """bgzf_inflate over a file whose upload start_upload began: one launch per uploaded piece, over the members that lie
+        wholly inside what has arrived (and the 16 bytes the decoder may read behind a member)."""
+        n = int(isize.shape[0])
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(isize, out=off[1:])
+        total = int(off[n])
+        d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        ends = np.asarray(pos[1:n + 1], dtype=np.uint64)
+        n_raw = int(up["d_raw"].shape[0]) - 16
+        status = torch.zeros(len(up["cuts"]), dtype=torch.int64, device=self.device)
+        m_lo, bases = 0, []
+        try:
+            for k, (cut, ev) in enumerate(zip(up["cuts"], up["events"])):
+                m_hi = n if cut >= n_raw else int(np.searchsorted(ends, np.uint64(max(0, cut - 16)), side="right"))
+                m_hi = max(m_hi, m_lo)
+                while not up["queued"][k].wait(0.05):
+                    if up["future"].done():
+                        up["future"].result()                    # the upload failed: its exception, not a hang
+                        break
+                self.stream.wait_event(ev)
+                bases.append(m_lo)
+                if m_hi > m_lo:
+                    self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(up["d_raw"]), ctypes.c_void_p(d_pos.data_ptr() + 8 * m_lo),
+                                                               ctypes.c_void_p(d_off.data_ptr() + 8 * m_lo), m_hi - m_lo, self._p(out), total,
+                                                               int(check_crc), ctypes.c_void_p(status.data_ptr() + 8 * k)), "gci_bgzf_inflate_device")
+                else:
+                    status[k] = -1
+                m_lo = m_hi
+            up["future"].result()
+        finally:
+            up["pool"].shutdown()
+        for k, w in enumerate(status.cpu().numpy().view(np.uint64).tolist()):
+            rec = ctypes.c_uint32(0)
+            st = self.lib.gci_decode_status(int(w) & _M64, ctypes.byref(rec))
+            if st != 0:
+                raise GciError(st, "gci_bgzf_inflate_device: %s (record %d)" % (self.lib.gci_strerror(st).decode(), rec.value + bases[k]),
+                               rec=int(rec.value) + bases[k])
+        self.stream.wait_stream(up["stream"])
+        return out[:total]
 
     def bam_record_offsets(self, d_stream: torch.Tensor, first_record: int, n_ref: int) -> Tuple[torch.Tensor, int, bool]:
         """-> (int64 offsets of every record on the device, bytes consumed, chain_ok).  chain_ok False: a record the strict

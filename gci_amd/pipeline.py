@@ -277,7 +277,7 @@ BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
 
 
 def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int,
-                        d_raw: Optional[torch.Tensor] = None) -> Optional[JoinInput]:
+                        upload=None) -> Optional[JoinInput]:
     """ingest = "gpu".  A file whose inflated stream fits GCI_GPU_INFLATE_MAX stays on the device whole (the join reads
     the names inside it); a larger one goes through run by run of members (at most chunk_bytes inflated each): inflate,
     record walk, K1, and only the 32-byte records and the packed names are kept -- the partial record a run ends in is
@@ -288,8 +288,11 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     n_ref = len(hdr.references)
     total = int(isz.sum())
     if total <= GPU_INFLATE_MAX:
-        d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC, d_raw=d_raw)
-        del d_raw
+        if upload is not None:
+            d_bam = engine.bgzf_inflate_uploaded(upload, pos, isz, check_crc=BGZF_CRC)
+            upload = None
+        else:
+            d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC)
         d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, n_ref)
         if not ok:
             return None
@@ -297,7 +300,10 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
             raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % (total - used))
         recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
         return JoinInput(recs, d_bam, d_off, 36)
-    del d_raw
+    if upload is not None:                                  # larger than it looked: uploaded run by run instead
+        upload["future"].result()
+        upload["pool"].shutdown()
+        upload = None
     groups, a, acc = [], 0, 0
     for i, sz in enumerate(isz.tolist()):
         if acc and acc + sz > chunk_bytes:
@@ -386,20 +392,19 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         # fit -- BGZF deflates BAM 2.4 - 4 : 1 -- is uploaded run by run instead)
         upload = None
         if 0 < raw.shape[0] <= GPU_INFLATE_MAX // 8:
-            upload = ThreadPoolExecutor(1)
-            d_raw = upload.submit(engine.upload_padded, raw)
+            upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1)
         try:
             pos, isz = hostio.bgzf_blocks(np.asarray(raw))
-        finally:
+        except BaseException:
             if upload is not None:
-                try:
-                    d_raw = d_raw.result()
-                finally:
-                    upload.shutdown()
+                upload["pool"].shutdown()
+            raise
         if int(isz.sum()) > 0:
-            ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, d_raw if upload is not None else None)
+            ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, upload)
             if ji is not None:
                 return ji
+        elif upload is not None:
+            upload["pool"].shutdown()
         ingest = "heads"
     if ingest == "heads":
         try:
