@@ -27,4 +27,5 @@ print("run 0: %.3f s" % run(0)); print("run 1: %.3f s" % run(1))
 pr = cProfile.Profile(); pr.enable(); w = run(2); pr.disable()
 print("run 2 (profiled): %.3f s" % w)
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s2 = io.StringIO(); pstats.Stats(pr, stream=s2).sort_stats("tottime").print_stats(18); print(s2.getvalue()[:4000])
 shutil.rmtree(tmp, ignore_errors=True)
