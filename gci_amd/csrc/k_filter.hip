@@ -2,14 +2,14 @@
 //
 // The decode is bound by vector-memory address processing, not by bytes: a wave that parses 16 scattered
 // records with 4-byte loads issues ~47 load instructions that each touch 16 different cache lines.  So the
-// record is STAGED: four lanes per record pull its first 256 bytes (core, name, first CIGAR words) and the
-// first 128 bytes of its aux block into LDS with 16-byte loads (6 load instructions per wave), and all
-// parsing -- core fields, NUL search, name hash, the aux walk for NM / CG, most of the CIGAR -- runs out
+// record is STAGED: four lanes per record pull its first 144 bytes (core, name, first CIGAR words) and the
+// first 128 bytes of its aux block into LDS with 16-byte loads (five load instructions per wave), and the
+// parsing -- core fields, NUL search, name hash, the aux walk for NM / CG, the first CIGAR words -- runs out
 // of LDS (gfx950 serves unaligned ds_read_b32 / b64; checked by tools/hwtests/lds_unaligned.hip).
 //
 //   fast path (k_bam_filter), 16 records per wave:
 //     flag / MAPQ tests (GCI.py:152-156) -> query_name (first NUL) + 64-bit name hash -> first NM tag
-//     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162) in five per-lane register
+//     (bam_aux_get semantics) -> CIGAR base totals (get_cigar_stats, GCI.py:157-162) in four per-lane register
 //     sums, added over the four lanes of the record -> the two IEEE f64 divisions of GCI.py:165 -> 32-byte
 //     compact record.
 //   slow path (slow_record, at the end of the same kernel), one wave per record, everything from global memory with
@@ -26,7 +26,9 @@
 #define NSLOT 10                 // op codes 0..8 (M I D N S H P = X) + one slot for everything else
 #define LONG_OPS 512u
 #ifndef HEAD
-#define HEAD 224                 // staged bytes from the record start
+#define HEAD 128                 // staged bytes from the record start: core, name (up to 88 bytes on the fast path) and the first
+                                 // CIGAR words.  224 staged more of the CIGAR and was 6 % slower (more staging loads per wave); 112
+                                 // is another 2 % faster and sends names of 73+ bytes to the slow path
 #endif
 #ifndef AUXB
 #define AUXB 112                 // staged bytes from the aux start
@@ -367,7 +369,7 @@ __device__ __forceinline__ void slow_record(
 
 }
 
-// 80 VGPRs (the compiler settles on 83 by itself) and 12 KB of LDS: 6 waves per SIMD instead of 5, -3.5 us on chr19
+// 80 VGPRs (the compiler settles on 83 by itself) and 9 KB of LDS: 6 waves per SIMD instead of 5, -3.5 us on chr19
 __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1_WAVES))) void k_bam_filter(
     const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     }
     TR(8);
     // ---- second (and last) dependent round trip: the refID -> selected-contig entry, the aux head and the CIGAR
-    // words behind the staged head.  (The table is not kept in LDS: workgroups of 12 KB fit twelve to a CU, 6 waves per SIMD.)
+    // words behind the staged head.  (The table is not kept in LDS: the waves per SIMD are what this kernel lives on.)
     const int32_t contig = ref_sel[ref_id];
     const uint32_t cig_at = 36 + l_read_name;                       // byte offset of the CIGAR in the record
     {
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
 #endif
     // ---- slow records of this wave, one after the other, by the whole wave (rare: NM beyond the staged window, htslib's
-    // CG:B,I long-CIGAR restore, names >= 185 bytes); no second kernel launch for them
+    // CG:B,I long-CIGAR restore, names of 89 bytes and more); no second kernel launch for them
     for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
         const uint32_t rs = (uint32_t)__shfl((int)rec, __builtin_ctzll(m), 64);
         slow_record(bam, n_bytes, rec_off, ref_sel, rs, t & 63, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, out);
