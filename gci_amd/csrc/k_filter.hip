@@ -40,7 +40,8 @@
 #define KB 128                    // threads per workgroup of the fast path (KB / G records)
 #endif
 #ifndef NUP
-#define NUP 3                     // 16-byte pieces of the CIGAR tail a lane requests together
+#define NUP 8                     // 16-byte pieces of the CIGAR tail a lane requests together: a HiFi record's share of the
+                                  // tail in one round trip (3: +5 % time; 10 spills registers)
 #endif
 #ifndef K1_WAVES
 #define K1_WAVES 6
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
                 }
             };
             // the first NUP chunks are requested together (with four lanes per record a lane's share of a HiFi tail is
-            // ~6 ops: one round trip); longer tails continue with one new chunk at a time
+            // ~16 ops: one round trip); longer tails continue with one new chunk at a time
             const uint32_t nch = (sh + 4u * cnt + 15u) >> 4;
             const uint4 z = make_uint4(0, 0, 0, 0);
             uint4 cu[NUP];
