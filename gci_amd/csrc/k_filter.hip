@@ -2,8 +2,8 @@
 //
 // The decode is bound by vector-memory address processing, not by bytes: a wave that parses 16 scattered
 // records with 4-byte loads issues ~47 load instructions that each touch 16 different cache lines.  So the
-// record is STAGED: four lanes per record pull its first 144 bytes (core, name, first CIGAR words) and the
-// first 128 bytes of its aux block into LDS with 16-byte loads (five load instructions per wave), and the
+// record is STAGED: four lanes per record pull its first 128 bytes (core, name, first CIGAR words) and the
+// first 128 bytes of its aux block into LDS with 16-byte loads (four load instructions per wave), and the
 // parsing -- core fields, NUL search, name hash, the aux walk for NM / CG, the first CIGAR words -- runs out
 // of LDS (gfx950 serves unaligned ds_read_b32 / b64; checked by tools/hwtests/lds_unaligned.hip).
 //
@@ -26,9 +26,9 @@
 #define NSLOT 10                 // op codes 0..8 (M I D N S H P = X) + one slot for everything else
 #define LONG_OPS 512u
 #ifndef HEAD
-#define HEAD 128                 // staged bytes from the record start: core, name (up to 88 bytes on the fast path) and the first
-                                 // CIGAR words.  224 staged more of the CIGAR and was 6 % slower (more staging loads per wave); 112
-                                 // is another 2 % faster and sends names of 73+ bytes to the slow path
+#define HEAD 112                 // staged bytes from the record start: core, name (up to 72 bytes on the fast path) and the first
+                                 // CIGAR words -- with the 16 bytes of alignment slack eight 16-byte pieces, two per lane.  224
+                                 // staged more of the CIGAR and was 8 % slower (more staging loads per wave); 352: +41 %
 #endif
 #ifndef AUXB
 #define AUXB 112                 // staged bytes from the aux start
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
 #endif
     // ---- slow records of this wave, one after the other, by the whole wave (rare: NM beyond the staged window, htslib's
-    // CG:B,I long-CIGAR restore, names of 89 bytes and more); no second kernel launch for them
+    // CG:B,I long-CIGAR restore, names of 73 bytes and more); no second kernel launch for them
     for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
         const uint32_t rs = (uint32_t)__shfl((int)rec, __builtin_ctzll(m), 64);
         slow_record(bam, n_bytes, rec_off, ref_sel, rs, t & 63, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, out);
