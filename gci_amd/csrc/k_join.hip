@@ -202,13 +202,13 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long 
 // (tests run both); chosen by size (GCI_JOIN=classic|partition overrides).
 //
 //   entry (16 B): key = name_len << 48 | hash & (2^48 - 1);  idx = position in its file;  meta = contig | file << 26 | hq << 30
-//   level 1: B1 = 2^b1 buckets by hash bits [47, 48 - b1); chunks of 4096 records of ONE file
+//   level 1: B1 = 2^b1 buckets by hash bits [47, 48 - b1); chunks of 8192 records of ONE file
 //   level 2: every level-1 bucket again by the next b2 bits; chunks never straddle level-1 buckets
 //   join   : one workgroup per final bucket, table in LDS: slot = {tag40 | claimant23 | hq} + one order key per file
 
 struct PartEntry { unsigned long long key; uint32_t idx; uint32_t meta; };
 static_assert(sizeof(PartEntry) == 16, "partition entry is 16 bytes");
-#define PART_CHUNK 4096
+#define PART_CHUNK 8192
 #define PART_CONTIG_BITS 26
 #define PART_KEY_MASK 0xFFFFFFFFFFFFull
 struct PartFiles { uint32_t chunk_first[GCI_MAX_JOIN_FILES + 1]; };
