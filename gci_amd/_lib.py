@@ -18,7 +18,7 @@ GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, G
 GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
 REC_PASS, REC_HQ = 1, 2
-PROF_COUNT = 15
+PROF_COUNT = 17
 PROF_DEPTH_SCAN = 5          # k_tile_build: the pass that writes the depth track (+ text)
 PROF_TILE_PASS1 = 13
 PROF_TILE_DENSE = 14         # k_tile_dense<1>, <2>: the tiles the event-list kernels left over
@@ -73,6 +73,7 @@ EXPORTS = [
     ("gci_pack_names", c_int, [c_void_p, POINTER(JoinFile), c_void_p, c_uint64, c_void_p]),
     ("gci_name_join", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
                               c_void_p]),
+    ("gci_join_mode", c_int, [c_void_p, c_int]),
     ("gci_name_join_count", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
                               c_void_p, c_int]),
     ("gci_depth_deflate_size", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),

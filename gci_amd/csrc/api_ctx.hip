@@ -46,6 +46,7 @@ extern "C" int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx*
     if (!ctx) return GCI_E_NOMEM;
     ctx->device = device;
     { const char* fd = getenv("GCI_FORCE_DENSE"); if (fd && fd[0] == '1') ctx->sparse_max = -1; }   // testing / A-B timing
+    { const char* m = getenv("GCI_JOIN"); ctx->join_mode = m && m[0] == 'c' ? 1 : m && m[0] == 'p' ? 2 : 0; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete ctx; return GCI_E_HIP; }
     if (!own_stream) { ctx->stream = (hipStream_t)stream; }    // NULL = the device's default stream
@@ -114,7 +115,8 @@ extern "C" const char* gci_last_error(gci_ctx* ctx) { return ctx ? ctx->err.c_st
 
 static const char* const PROF_NAMES[GCI_PROF_COUNT] = {
     "k_bam_filter", "k_join_insert", "k_join_fold", "k_evt_count+scatter", "k_scan2", "k_tile_build", "k_gap_mask",
-    "k_max2", "k_issue_scan", "k_text_count", "k_text_write", "k_depth_sum", "memset", "k_tile_pass1", "k_tile_dense"};
+    "k_max2", "k_issue_scan", "k_text_count", "k_text_write", "k_depth_sum", "memset", "k_tile_pass1", "k_tile_dense",
+    "k_part1+k_part2 (radix partition of the join)", "k_join_part"};
 
 extern "C" int gci_profile_enable(gci_ctx* ctx, int mask)
 {

@@ -47,6 +47,7 @@ struct gci_ctx {
     DevBuf dense_list;                      // uint32: [0] = number of flagged tiles, [1 ..] their indices (k_dense_list)
     int32_t sparse_max = 62;                // tiles with more events take the dense path (GCI_FORCE_DENSE=1: all of them)
     bool join_dirty = false;                // the join tables are not in their clean state (a join was cut short)
+    int join_mode = 0;                      // gci_join_mode: 0 by size, 1 classic table, 2 radix-partitioned
     uint32_t k1_parity = 0;                 // which of the two K1 counter sets the next gci_bam_filter uses
     int cd_state = 0;                       // tile_cd: 0 clean, 1 counted by gci_name_join_count, 2 in use / left over
     int counted_flank = 0;                  // the flank gci_name_join_count counted with

@@ -197,33 +197,53 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long 
 // step).  Here the passing records are first radix-partitioned by bits of the name hash -- two passes of
 // histogram / scan / scatter, sequential traffic only -- into buckets small enough that the whole dict logic of one
 // bucket (claim a slot per distinct name, last-record-wins per file, high-quality bit, then the fold over files) runs
-// in LDS.  What is left of the random traffic is what exactness needs: the name bytes of a record against those of
-// the slot's first claimant, and the 32-byte record of every (name, file) winner.  Same results as the classic path
-// (tests run both); chosen by size (GCI_JOIN=classic|partition overrides).
+// in LDS.
 //
-//   entry (16 B): key = name_len << 48 | hash & (2^48 - 1);  idx = position in its file;  meta = contig | file << 26 | hq << 30
+// Round 3: the entry carries everything the fold needs (contig, start, end, qlen: the record's interval travels with
+// its hash through both scatters) and where its name bytes are, so the join kernel reads its bucket SEQUENTIALLY and
+// never goes back to the record arrays (round 2 fetched a 128-byte line per (name, file) winner: 8x the algorithmic
+// bytes, profiles/r02t_pmc_summary.txt).  What is left of the random traffic is what exactness needs -- the name bytes
+// of an entry against those of the slot's claimant -- and it is no longer inside the probe loop: the insert trusts the
+// 48 hash bits, the name comparisons of a bucket are issued afterwards, all independent of each other, and a bucket in
+// which two DIFFERENT names share their hash bits (one in ~10 genome-scale joins has such a pair) is redone by its
+// workgroup with the names compared inside the probe loop.  Same results as the classic path (tests run both);
+// chosen by size (gci_join_mode / GCI_JOIN=classic|partition override).
+//
+//   entry (32 B): key = hash48 | name_len << 48 | (name offset & 15) << 60;  idx = position in its file;
+//                 meta = contig | file << 26 | hq << 30;  start, end, qlen;  name offset >> 4
 //   level 1: B1 = 2^b1 buckets by hash bits [47, 48 - b1); chunks of 8192 records of ONE file
 //   level 2: every level-1 bucket again by the next b2 bits; chunks never straddle level-1 buckets
 //   join   : one workgroup per final bucket, table in LDS: slot = {tag40 | claimant23 | hq} + one order key per file
 
-struct PartEntry { unsigned long long key; uint32_t idx; uint32_t meta; };
-static_assert(sizeof(PartEntry) == 16, "partition entry is 16 bytes");
+struct __attribute__((aligned(16))) PartEntry {
+    unsigned long long key;
+    uint32_t idx;
+    uint32_t meta;
+    int32_t start, end, qlen;
+    uint32_t name_off16;
+};
+static_assert(sizeof(PartEntry) == 32, "partition entry is 32 bytes");
 #define PART_CHUNK 8192
 #define PART_CONTIG_BITS 26
-#define PART_KEY_MASK 0xFFFFFFFFFFFFull
+#define PART_KEY_MASK 0xFFFFFFFFFFFFull            // the hash bits of a key
+#define PART_CMP_MASK 0x0FFFFFFFFFFFFFFFull         // hash bits + name length
+#define PART_MAX_NAME 4095u
+#define PART_WIN (1ull << 63)                       // order-key word of a (slot, file) once its winner is known: WIN | entry index
+#define PART_NONE 0xFFFFFFFFu
 struct PartFiles { uint32_t chunk_first[GCI_MAX_JOIN_FILES + 1]; };
 
-__device__ __forceinline__ bool part_entry_of(const gci_rec& r, int file, uint32_t i, PartEntry& e, unsigned long long* status)
+// A record takes part in the partition iff this holds (histogram and scatter must agree on it).
+__device__ __forceinline__ bool part_takes(const gci_rec& r)
 {
-    if (!(r.flags & GCI_REC_PASS)) return false;
-    if ((uint32_t)r.contig >> PART_CONTIG_BITS) {               // contig index beyond the entry's field (or negative)
-        atomicMin(status, ((unsigned long long)r.rec_idx << 8) | (unsigned)(-GCI_E_INVALID));
-        return false;
-    }
-    e.key = ((unsigned long long)r.name_len << 48) | (r.name_hash & PART_KEY_MASK);
-    e.idx = i;
-    e.meta = (uint32_t)r.contig | ((uint32_t)file << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u);
-    return true;
+    return (r.flags & GCI_REC_PASS) && !((uint32_t)r.contig >> PART_CONTIG_BITS) && r.name_len <= PART_MAX_NAME;
+}
+
+// A passing record the entry format cannot hold (contig index beyond 26 bits, a name of 4 KiB and more, name bytes
+// beyond 64 GiB from their base): the caller takes the classic table.  Reported with record index 0, so that it wins
+// the min over whatever else this (abandoned) join reports.
+__device__ __forceinline__ void part_refuse(unsigned long long* status)
+{
+    atomicMin(status, (unsigned long long)(unsigned)(-GCI_E_CAPACITY));
 }
 
 __device__ __forceinline__ int part_file_of(const PartFiles& P, int n, uint32_t chunk)
@@ -231,6 +251,29 @@ __device__ __forceinline__ int part_file_of(const PartFiles& P, int n, uint32_t 
     int f = 0;
     while (f + 1 < n && chunk >= P.chunk_first[f + 1]) f++;
     return f;
+}
+
+__device__ __forceinline__ const uint8_t* entry_name(const JoinFiles& F, const PartEntry& e)
+{
+    return F.f[(e.meta >> PART_CONTIG_BITS) & 15u].d_name_base + (((uint64_t)e.name_off16 << 4) | (uint64_t)(e.key >> 60));
+}
+
+__device__ __forceinline__ void store_entry(PartEntry* __restrict__ dst, const PartEntry& e)
+{
+    int4* d = reinterpret_cast<int4*>(dst);
+    d[0] = make_int4((int)(uint32_t)e.key, (int)(uint32_t)(e.key >> 32), (int)e.idx, (int)e.meta);
+    d[1] = make_int4(e.start, e.end, e.qlen, (int)e.name_off16);
+}
+
+__device__ __forceinline__ PartEntry load_entry(const PartEntry* __restrict__ src)
+{
+    const int4* s = reinterpret_cast<const int4*>(src);
+    const int4 a = s[0], b = s[1];
+    PartEntry e;
+    e.key = (unsigned long long)(uint32_t)a.x | ((unsigned long long)(uint32_t)a.y << 32);
+    e.idx = (uint32_t)a.z; e.meta = (uint32_t)a.w;
+    e.start = b.x; e.end = b.y; e.qlen = b.z; e.name_off16 = (uint32_t)b.w;
+    return e;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_part1_hist(JoinFiles F, PartFiles P, int shift, uint32_t n_bins, uint32_t n_chunks,
@@ -250,8 +293,8 @@ __global__ __launch_bounds__(BLOCK) void k_part1_hist(JoinFiles F, PartFiles P, 
         const uint32_t i = i0 + k * BLOCK + t;
         if (i < n) {
             const gci_rec r = recs[i];
-            if ((r.flags & GCI_REC_PASS) && !((uint32_t)r.contig >> PART_CONTIG_BITS))
-                atomicAdd(&h[(uint32_t)((r.name_hash & PART_KEY_MASK) >> shift) & (n_bins - 1)], 1u);
+            if (part_takes(r)) atomicAdd(&h[(uint32_t)((r.name_hash & PART_KEY_MASK) >> shift) & (n_bins - 1)], 1u);
+            else if (r.flags & GCI_REC_PASS) part_refuse(status);
         }
     }
     __syncthreads();
@@ -270,15 +313,24 @@ __global__ __launch_bounds__(BLOCK) void k_part1_scatter(JoinFiles F, PartFiles 
     const int f = part_file_of(P, F.n, chunk);
     const uint32_t i0 = (chunk - P.chunk_first[f]) * PART_CHUNK, n = F.f[f].n_recs;
     const gci_rec* __restrict__ recs = F.f[f].d_recs;
+    const uint64_t* __restrict__ noff = F.f[f].d_name_off;
+    const uint64_t delta = F.f[f].name_delta;
 #pragma unroll 4
     for (int k = 0; k < PART_CHUNK / BLOCK; k++) {
         const uint32_t i = i0 + k * BLOCK + t;
         if (i < n) {
             const gci_rec r = recs[i];
-            PartEntry e;
-            if (part_entry_of(r, f, i, e, status)) {
+            if (part_takes(r)) {
+                const uint64_t at = noff[i] + delta;                  // name bytes relative to the file's name base
+                if (at >> 36) part_refuse(status);
+                PartEntry e;
+                e.key = (r.name_hash & PART_KEY_MASK) | ((unsigned long long)r.name_len << 48) | ((unsigned long long)(at & 15ull) << 60);
+                e.idx = i;
+                e.meta = (uint32_t)r.contig | ((uint32_t)f << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u);
+                e.start = r.start; e.end = r.end; e.qlen = r.qlen;
+                e.name_off16 = (uint32_t)(at >> 4);
                 const uint32_t d = (uint32_t)((e.key & PART_KEY_MASK) >> shift) & (n_bins - 1);
-                out[base[d] + atomicAdd(&cnt[d], 1u)] = e;
+                store_entry(out + base[d] + atomicAdd(&cnt[d], 1u), e);
             }
         }
     }
@@ -350,9 +402,9 @@ __global__ __launch_bounds__(BLOCK) void k_part2_scatter(const PartEntry* __rest
     if (t < n_bins) base[t] = off[(size_t)sC[j] * n_bins + (size_t)t * nch + k];
     __syncthreads();
     for (uint32_t i = a + t; i < b; i += BLOCK) {
-        const PartEntry e = in[i];
+        const PartEntry e = load_entry(in + i);
         const uint32_t d = (uint32_t)((e.key & PART_KEY_MASK) >> shift) & (n_bins - 1);
-        out[base[d] + atomicAdd(&cnt[d], 1u)] = e;
+        store_entry(out + base[d] + atomicAdd(&cnt[d], 1u), e);
     }
 }
 
@@ -393,43 +445,80 @@ struct PartJoinArgs {
     uint32_t n_seg, n_bins2, slots, slot_shift;
 };
 
-// The fold of fold_slot() with the winners' records of all FN files requested TOGETHER (they are random 32-byte reads
-// of HBM; one after the other they were most of this kernel's time).  FN == 0: any number of files, one by one.
-template <int FN>
-__device__ __forceinline__ bool fold_bucket_slot(const JoinFiles& F, uint32_t slot, const unsigned long long* last, bool high,
-                                                 double ovlp_percent, const int32_t* __restrict__ contig_map,
-                                                 unsigned long long* __restrict__ status, gci_ivl& o)
+// Slot of entry e (index i inside its bucket) in the bucket's LDS table.  CLAIM: take an empty slot for a name not seen yet.
+// exact == false: entries whose 40 tag bits (and, being in one bucket, all 48 hash bits) agree share a slot -- their names are
+// compared afterwards (k_join_part).  exact == true: a tag match counts only if the full key and the name bytes equal those of
+// the slot's claimant.  PART_NONE: table full (CLAIM) / name not in the table (cannot happen after an insert of the same entry).
+template <bool CLAIM>
+__device__ __forceinline__ uint32_t part_probe(unsigned long long* meta, uint32_t S, uint32_t slot_shift, const PartEntry& e, uint32_t i,
+                                               const PartEntry* __restrict__ in, const JoinFiles& F, bool exact, uint16_t* used,
+                                               uint32_t* s_used)
 {
-    if constexpr (FN == 0) {
-        return fold_slot(F, slot, last, high, ovlp_percent, contig_map, status, o);
-    } else {
-        unsigned long long v[FN];
-        int4 ra[FN], rb[FN];                                         // the 32-byte records as two 16-byte halves
+    const unsigned long long tag = e.key & 0xFFFFFFFFFFull;
+    uint32_t slot = (uint32_t)((e.key & PART_KEY_MASK) >> slot_shift) & (S - 1);
+    for (uint32_t probes = 0; probes < S; probes++) {
+        unsigned long long m = meta[slot];
+        if (m == SLOT_EMPTY) {
+            if (!CLAIM) return PART_NONE;
+            m = atomicCAS(meta + slot, SLOT_EMPTY, (tag << 24) | ((unsigned long long)i << 1));
+            if (m == SLOT_EMPTY) {                               // claimed: this entry is the slot's reference name
+                used[atomicAdd(s_used, 1u)] = (uint16_t)slot;
+                return slot;
+            }
+        }
+        if ((m >> 24) == tag) {
+            if (!exact) return slot;
+            const uint32_t c = (uint32_t)(m >> 1) & 0x7FFFFFu;
+            if (c == i) return slot;
+            const PartEntry ce = load_entry(in + c);
+            if (((ce.key ^ e.key) & PART_CMP_MASK) == 0 &&
+                names_equal(entry_name(F, e), entry_name(F, ce), (uint32_t)(e.key >> 48) & 0xFFFu))
+                return slot;
+        }
+        slot = (slot + 1) & (S - 1);
+    }
+    return PART_NONE;
+}
+
+// The fold of fold_slot() (GCI.py:279-299) over the winners' ENTRIES: their intervals came along with the hashes, so the
+// fold reads the bucket it has just streamed (L2) and nothing else.  FN == 0: any number of files, one by one.
+template <int FN>
+__device__ __forceinline__ bool fold_bucket_slot(const JoinFiles& F, const PartEntry* __restrict__ in, uint32_t slot,
+                                                 const unsigned long long* last, bool high, double ovlp_percent,
+                                                 const int32_t* __restrict__ contig_map, unsigned long long* __restrict__ status,
+                                                 gci_ivl& o)
+{
+    constexpr int NF = FN ? FN : 1;
+    const int Fn = FN ? FN : F.n;
+    bool have = false, dead = false;                              // dead: the reference raised on this name
+    int32_t contig = -1, s = 0, e = 0;
+    const uint32_t cmask = (1u << PART_CONTIG_BITS) - 1u;
+    if constexpr (FN != 0) {
+        unsigned long long v[NF];
+        int4 ra[NF], rb[NF];                                     // the winners' entries as two 16-byte halves, requested together
         bool comm = true;
 #pragma unroll
-        for (int f = 0; f < FN; f++) { v[f] = last[(size_t)slot * FN + f]; comm = comm && v[f] != 0; }
+        for (int f = 0; f < NF; f++) { v[f] = last[(size_t)slot * NF + f]; comm = comm && v[f] != 0; }
 #pragma unroll
-        for (int f = 0; f < FN; f++) {
+        for (int f = 0; f < NF; f++) {
             ra[f] = make_int4(0, 0, 0, 0); rb[f] = make_int4(0, 0, 0, 0);
             if (v[f]) {
-                const int4* p = reinterpret_cast<const int4*>(F.f[f].d_recs + (uint32_t)(v[f] - 1));
+                const int4* p = reinterpret_cast<const int4*>(in + (uint32_t)(v[f] & 0x7FFFFFull));
                 ra[f] = p[0]; rb[f] = p[1];
             }
         }
-        // gci_rec: {hash lo, hash hi, contig, start} {end, qlen, rec_idx, mapq | flags << 8 | name_len << 16}
-        bool have = false, dead = false;                              // dead: the reference raised on this name
-        int32_t contig = -1, s = 0, e = 0;
-        if (v[0] && (FN == 1 || high || comm)) { have = true; contig = ra[0].z; s = ra[0].w; e = rb[0].x; }
+        // entry: {key lo, key hi, idx, meta} {start, end, qlen, name offset}
+        if (v[0] && (FN == 1 || high || comm)) { have = true; contig = (int32_t)((uint32_t)ra[0].w & cmask); s = rb[0].x; e = rb[0].y; }
 #pragma unroll
-        for (int f = 1; f < FN; f++) {                                // GCI.py:281-299 (no early exit: the loop stays unrolled)
-            const int32_t r_contig = ra[f].z, r_start = ra[f].w, r_end = rb[f].x, r_qlen = rb[f].y;
+        for (int f = 1; f < NF; f++) {                            // GCI.py:281-299 (no early exit: the loop stays unrolled)
+            const int32_t r_contig = (int32_t)((uint32_t)ra[f].w & cmask), r_start = rb[f].x, r_end = rb[f].y, r_qlen = rb[f].z;
             const bool present = v[f] != 0 && !dead;
             if (present && have) {
                 if (r_contig == contig) {
                     const int32_t ms = max(r_start, s), me = min(r_end, e);
                     const int64_t ovlp = (int64_t)me - (int64_t)ms;
-                    if (r_qlen == 0) {                                // ZeroDivisionError at GCI.py:292
-                        atomicMin(status, ((unsigned long long)(uint32_t)rb[f].z << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                    if (r_qlen == 0) {                            // ZeroDivisionError at GCI.py:292
+                        atomicMin(status, ((unsigned long long)F.f[f].d_recs[(uint32_t)ra[f].z].rec_idx << 8) | (unsigned)(-GCI_E_ZERO_DIV));
                         dead = true;
                     } else if ((double)ovlp / (double)r_qlen < ovlp_percent) have = false;
                     else { s = ms; e = me; }
@@ -438,15 +527,46 @@ __device__ __forceinline__ bool fold_bucket_slot(const JoinFiles& F, uint32_t sl
                 have = true; contig = r_contig; s = r_start; e = r_end;
             }
         }
-        if (!have || dead) return false;
-        if (contig_map) { contig = contig_map[contig]; if (contig < 0) return false; }
-        o.contig = contig; o.start = s; o.end = e; o.pad = 0;
-        return true;
+    } else {
+        bool comm = true;
+        for (int f = 0; f < Fn; f++) comm = comm && last[(size_t)slot * Fn + f] != 0;
+        for (int f = 0; f < Fn && !dead; f++) {
+            const unsigned long long v = last[(size_t)slot * Fn + f];
+            if (!v) continue;
+            if (f == 0) {                                         // file1 = entries of files[0] in high_qual | comm (GCI.py:279-280)
+                if (Fn == 1 || high || comm) {
+                    const PartEntry r = load_entry(in + (uint32_t)(v & 0x7FFFFFull));
+                    have = true; contig = (int32_t)(r.meta & cmask); s = r.start; e = r.end;
+                }
+                continue;
+            }
+            if (!have && !high) continue;
+            const PartEntry r = load_entry(in + (uint32_t)(v & 0x7FFFFFull));
+            const int32_t r_contig = (int32_t)(r.meta & cmask);
+            if (have) {
+                if (r_contig == contig) {
+                    const int32_t ms = max(r.start, s), me = min(r.end, e);
+                    const int64_t ovlp = (int64_t)me - (int64_t)ms;
+                    if (r.qlen == 0) {
+                        atomicMin(status, ((unsigned long long)F.f[f].d_recs[r.idx].rec_idx << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                        dead = true;
+                    } else if ((double)ovlp / (double)r.qlen < ovlp_percent) have = false;
+                    else { s = ms; e = me; }
+                } else have = false;
+            } else {
+                have = true; contig = r_contig; s = r.start; e = r.end;
+            }
+        }
     }
+    if (!have || dead) return false;
+    if (contig_map) { contig = contig_map[contig]; if (contig < 0) return false; }
+    o.contig = contig; o.start = s; o.end = e; o.pad = 0;
+    return true;
 }
 
 // One workgroup per final bucket.  LDS: meta[S] | last[S * F.n] | list of used slots.
 //   meta = tag (hash bits [39, 0]) << 24 | claimant (entry index inside the bucket) << 1 | high-quality bit; ~0 = empty
+//   last = per (slot, file) the largest order key (contig, file position) + 1 seen, then WIN | index of the entry that has it
 template <int FN>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_join_part(JoinFiles F, PartJoinArgs A, double ovlp_percent,
                                                      const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out, uint32_t cap,
@@ -455,12 +575,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) v
 {
     extern __shared__ unsigned long long sm[];
     __shared__ uint32_t wtot[BLOCK / 64];
-    __shared__ uint32_t s_base, s_used;
+    __shared__ uint32_t s_base, s_used, s_bad;
     __shared__ int64_t s_len[COUNT_LDS], s_tf[COUNT_LDS];
     const uint32_t S = A.slots;
+    const int Fn = FN ? FN : F.n;
     unsigned long long* meta = sm;
     unsigned long long* last = sm + S;
-    uint16_t* used = reinterpret_cast<uint16_t*>(sm + S + (size_t)S * F.n);
+    uint16_t* used = reinterpret_cast<uint16_t*>(sm + S + (size_t)S * Fn);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t j = blockIdx.x / A.n_bins2, d = blockIdx.x % A.n_bins2;
     const uint32_t cj = A.seg[A.n_seg + 1 + j], nch = A.seg[A.n_seg + 2 + j] - cj;
@@ -469,55 +590,57 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) v
     if (lo == hi) return;
     const bool tables_in_lds = cnt.tile_cd && cnt.n_contigs <= COUNT_LDS;
     if (tables_in_lds) for (int c = t; c < cnt.n_contigs; c += BLOCK) { s_len[c] = cnt.len[c]; s_tf[c] = cnt.tile_first[c]; }
-    for (uint32_t s = t; s < S; s += BLOCK) meta[s] = SLOT_EMPTY;
-    for (uint32_t s = t; s < S * (uint32_t)F.n; s += BLOCK) last[s] = 0ull;
-    if (t == 0) s_used = 0;
-    __syncthreads();
     const PartEntry* __restrict__ in = A.in + lo;
     const uint32_t n = hi - lo;
     if (n >> 23) {                                               // claimant field: a bucket of 8 M entries and more (one name
-        if (t == 0) atomicMin(status, ((unsigned long long)in[0].idx << 8) | (unsigned)(-GCI_E_CAPACITY));   // repeated): classic path
+        if (t == 0) part_refuse(status);                         // repeated): classic path
         return;
     }
-    // ---- insert: one entry per thread and round --------------------------------------------------------------------
-    for (uint32_t i = t; i < n; i += BLOCK) {
-        const PartEntry e = in[i];
-        const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
-        const unsigned long long tag = e.key & 0xFFFFFFFFFFull;
-        const unsigned long long mine = (tag << 24) | ((unsigned long long)i << 1);
-        const uint32_t name_len = (uint32_t)(e.key >> 48);
-        uint32_t slot = (uint32_t)((e.key & PART_KEY_MASK) >> A.slot_shift) & (S - 1);
-        uint32_t probes = 0;
-        for (;;) {
-            unsigned long long m = meta[slot];
-            if (m == SLOT_EMPTY) {
-                m = atomicCAS(meta + slot, SLOT_EMPTY, mine);
-                if (m == SLOT_EMPTY) {                           // claimed: this entry is the slot's reference name
-                    used[atomicAdd(&s_used, 1u)] = (uint16_t)slot;
-                    break;
+    const uint32_t cmask = (1u << PART_CONTIG_BITS) - 1u;
+    bool exact = false;
+    for (;;) {
+        for (uint32_t s = t; s < S; s += BLOCK) meta[s] = SLOT_EMPTY;
+        for (uint32_t s = t; s < S * (uint32_t)Fn; s += BLOCK) last[s] = 0ull;
+        if (t == 0) { s_used = 0; s_bad = 0; }
+        __syncthreads();
+        // ---- insert: one entry per thread and round; LDS only (exact: plus the names against the claimant's) ---------------
+        for (uint32_t i = t; i < n; i += BLOCK) {
+            const PartEntry e = load_entry(in + i);
+            const uint32_t slot = part_probe<true>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
+            if (slot == PART_NONE) { part_refuse(status); continue; }     // more distinct names than slots
+            const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
+            // order of dict insertion in the reference: contig by contig (header order), file order inside (GCI.py:269)
+            const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
+            atomicMax(last + (size_t)slot * Fn + file, ord);
+            if (Fn > 1 && (e.meta >> 30 & 1u)) atomicOr(meta + slot, 1ull);
+        }
+        __syncthreads();
+        // ---- winners: the entry that holds its (slot, file)'s largest order key leaves its index there; and, when the insert
+        // trusted the hash bits, every entry's name against its slot's claimant (independent random reads, all in flight together)
+        for (uint32_t i = t; i < n; i += BLOCK) {
+            const PartEntry e = load_entry(in + i);
+            const uint32_t slot = part_probe<false>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
+            if (slot == PART_NONE) continue;                             // refused by the insert
+            const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
+            const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
+            if (last[(size_t)slot * Fn + file] == ord) last[(size_t)slot * Fn + file] = PART_WIN | i;
+            if (!exact) {
+                const uint32_t c = (uint32_t)(meta[slot] >> 1) & 0x7FFFFFu;
+                if (c != i) {
+                    const PartEntry ce = load_entry(in + c);
+                    if (((ce.key ^ e.key) & PART_CMP_MASK) != 0 ||
+                        !names_equal(entry_name(F, e), entry_name(F, ce), (uint32_t)(e.key >> 48) & 0xFFFu))
+                        s_bad = 1u;                                      // two names, one hash: redo this bucket exactly
                 }
             }
-            if ((m >> 24) == tag) {
-                const PartEntry c = in[(uint32_t)(m >> 1) & 0x7FFFFFu];
-                if (c.key == e.key &&
-                    names_equal(name_ptr(F.f[file], e.idx), name_ptr(F.f[(c.meta >> PART_CONTIG_BITS) & 15u], c.idx), name_len))
-                    break;
-            }
-            slot = (slot + 1) & (S - 1);
-            if (++probes >= S) { slot = 0xFFFFFFFFu; break; }    // more distinct names than slots
         }
-        if (slot == 0xFFFFFFFFu) {
-            atomicMin(status, ((unsigned long long)e.idx << 8) | (unsigned)(-GCI_E_CAPACITY));
-            continue;
-        }
-        // order of dict insertion in the reference: contig by contig (header order), file order inside (GCI.py:269)
-        const unsigned long long ord = (((unsigned long long)(e.meta & ((1u << PART_CONTIG_BITS) - 1u)) << 32) | e.idx) + 1ull;
-        atomicMax(last + (size_t)slot * F.n + file, ord);
-        if (F.n > 1 && (e.meta >> 30 & 1u)) atomicOr(meta + slot, 1ull);
+        __syncthreads();
+        if (exact || !s_bad) break;
+        exact = true;
+        __syncthreads();                                         // everybody has read s_bad before it is reset
     }
-    __syncthreads();
     // ---- fold: one used slot (= one distinct name) per thread and round; survivors appended with one returning atomic
-    // per workgroup and round (a bucket holds ~200 names: one round) ------------------------------------------------
+    // per workgroup and round (a bucket holds a few hundred names: one or two rounds) ---------------------------------
     const uint32_t n_used = s_used;
     for (uint32_t u0 = 0; u0 < n_used; u0 += BLOCK) {
         const uint32_t u = u0 + t;
@@ -525,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) v
         bool ok = false;
         if (u < n_used) {
             const uint32_t slot = used[u];
-            ok = fold_bucket_slot<FN>(F, slot, last, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
+            ok = fold_bucket_slot<FN>(F, in, slot, last, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
         }
         const unsigned long long bal = __ballot(ok);
         if (lane == 0) wtot[wave] = (uint32_t)__builtin_popcountll(bal);
@@ -584,7 +707,7 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
     PartEntry* pb = (PartEntry*)ctx->part_b.p;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
     {
-        ProfScope _ps(ctx, GCI_PROF_JOIN_INSERT);
+        ProfScope _ps(ctx, GCI_PROF_PARTITION);
         hipLaunchKernelGGL(k_part1_hist, dim3(C1), dim3(BLOCK), 0, ctx->stream, F, P, shift1, B1, C1, hist1, d_n_out,
                            (unsigned long long*)d_status);
         LAUNCHCHK("k_part1_hist");
@@ -605,7 +728,7 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
         LAUNCHCHK("k_part2_scatter");
     }
     {
-        ProfScope _ps(ctx, GCI_PROF_JOIN_FOLD);
+        ProfScope _ps(ctx, GCI_PROF_JOIN_PART);
         PartJoinArgs A;
         A.in = pb; A.seg = seg; A.off2 = hist2; A.n_seg = B1; A.n_bins2 = B2; A.slots = S; A.slot_shift = (uint32_t)slot_shift;
         const size_t lds = (size_t)S * (8 + 8 * (size_t)F.n) + (size_t)S * 2;      // + the list of used slots
@@ -636,8 +759,7 @@ static int name_join_impl(gci_ctx* ctx, const gci_join_file* h_files, int n_file
     for (int f = 0; f < n_files; f++) { F.f[f] = h_files[f]; total += h_files[f].n_recs; }
     // genome scale: radix partition + per-bucket tables in LDS (GCI_JOIN=classic|partition overrides the size rule)
     {
-        const char* m = getenv("GCI_JOIN");
-        const bool force_part = m && m[0] == 'p', force_classic = m && m[0] == 'c';
+        const bool force_part = ctx->join_mode == 2, force_classic = ctx->join_mode == 1;
         if (!force_classic && (force_part || total >= (1ull << 20)) && total > 0) {
             bool done = false;
             const int st = name_join_partitioned(ctx, F, total, ovlp_percent, d_contig_map, d_out, cap, d_n_out, d_status, cnt, &done);
@@ -682,6 +804,15 @@ static int name_join_impl(gci_ctx* ctx, const gci_join_file* h_files, int n_file
         LAUNCHCHK("k_join_fold");
     }
     ctx->join_dirty = false;
+    return GCI_OK;
+}
+
+// 0: by size (the radix-partitioned join from 2^20 records up), 1: always the classic table, 2: always partitioned.
+// A context starts with what GCI_JOIN=classic|partition says (default 0).
+extern "C" int gci_join_mode(gci_ctx* ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return GCI_E_INVALID;
+    ctx->join_mode = mode;
     return GCI_OK;
 }
 

@@ -83,6 +83,8 @@ class Engine:
         self.total = 0
         self._status = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        m = os.environ.get("GCI_JOIN", "")
+        self.join_mode = 1 if m.startswith("c") else 2 if m.startswith("p") else 0    # what gci_ctx_create read
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
@@ -173,6 +175,11 @@ class Engine:
                            rec=int(rec.value))
 
     # ---- R5 ----------------------------------------------------------------------------------
+    def set_join_mode(self, mode: str = "auto") -> None:
+        """'auto' (by size), 'classic' (open-addressing table in HBM) or 'partition' (radix partition + tables in LDS)."""
+        self.join_mode = {"auto": 0, "classic": 1, "partition": 2}[mode]
+        self._chk(self.lib.gci_join_mode(self.ctx, self.join_mode), "gci_join_mode")
+
     def _join_files(self, files: Sequence[JoinInput]):
         arr = (JoinFile * len(files))()
         for i, f in enumerate(files):
@@ -213,17 +220,13 @@ class Engine:
             except GciError as e:
                 # the partitioned join (large inputs) found more distinct names in one hash bucket than its LDS table
                 # holds -- only adversarial names get there: redo on the classic global table
-                if e.status != _lib.GCI_E_CAPACITY or not fallback or os.environ.get("GCI_JOIN", "") == "classic":
+                if e.status != _lib.GCI_E_CAPACITY or not fallback:
                     raise
-                prev = os.environ.get("GCI_JOIN")
-                os.environ["GCI_JOIN"] = "classic"
+                self._chk(self.lib.gci_join_mode(self.ctx, 1), "gci_join_mode")
                 try:
                     return self.name_join(files, ovlp_percent, contig_map, out, count, True, count_flank, False)
                 finally:
-                    if prev is None:
-                        del os.environ["GCI_JOIN"]
-                    else:
-                        os.environ["GCI_JOIN"] = prev
+                    self._chk(self.lib.gci_join_mode(self.ctx, self.join_mode), "gci_join_mode")
             n = int(count.item())
             if n <= out.shape[0]:
                 return out, count

@@ -130,7 +130,8 @@ int gci_memset(gci_ctx* ctx, void* d_dst, int byte, size_t bytes);              
 enum {
     GCI_PROF_BAM_FILTER = 0, GCI_PROF_JOIN_INSERT, GCI_PROF_JOIN_FOLD, GCI_PROF_DEPTH_DIFF, GCI_PROF_SCAN_TILES,
     GCI_PROF_DEPTH_SCAN, GCI_PROF_GAP_MASK, GCI_PROF_MAX2, GCI_PROF_ISSUE_SCAN, GCI_PROF_TEXT_COUNT,
-    GCI_PROF_TEXT_WRITE, GCI_PROF_DEPTH_SUM, GCI_PROF_MEMSET, GCI_PROF_TILE_PASS1, GCI_PROF_TILE_DENSE, GCI_PROF_COUNT
+    GCI_PROF_TEXT_WRITE, GCI_PROF_DEPTH_SUM, GCI_PROF_MEMSET, GCI_PROF_TILE_PASS1, GCI_PROF_TILE_DENSE, GCI_PROF_PARTITION,
+    GCI_PROF_JOIN_PART, GCI_PROF_COUNT
 };
 int gci_profile_enable(gci_ctx* ctx, int mask);
 int gci_profile_read(gci_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, int reset);
@@ -176,6 +177,12 @@ int gci_pack_names(gci_ctx* ctx, const gci_join_file* h_file, uint8_t* d_out_nam
 int gci_name_join(gci_ctx* ctx, const gci_join_file* h_files, int n_files, double ovlp_percent,
                   const int32_t* d_contig_map, gci_ivl* d_out, uint32_t cap, uint32_t* d_n_out,
                   uint64_t* d_status);
+/* Which implementation gci_name_join / gci_name_join_count use: 0 = by size (an open-addressing table in HBM below 2^20
+ * records, the radix-partitioned join with per-bucket tables in LDS from there up), 1 = always the table, 2 = always
+ * partitioned.  Same results either way.  The partitioned join reports GCI_E_CAPACITY (record 0) in *d_status for inputs its
+ * 32-byte entries cannot hold (a bucket with more distinct names than its table has slots -- forged hashes only --, a name of
+ * 4 KiB and more, name bytes beyond 64 GiB from d_name_base): the caller then sets mode 1 and joins again. */
+int gci_join_mode(gci_ctx* ctx, int mode);
 /* The same join, fused with the first pass of the depth build: the kernel that emits an interval also counts it into
  * the per-tile tables of the layout (flank = the build's --flank-len), so a gci_depth_build_begin over exactly this
  * output with opts.counted = 1 skips that pass (one dependent launch and one read of the intervals less).  Needs

@@ -78,11 +78,12 @@ def _join_gpu(engine, sets, targets, ovlp=0.9):
 
 
 @pytest.fixture(params=["classic", "partition"])
-def join_mode(request, monkeypatch):
+def join_mode(request, engine):
     """Both implementations of the join behind gci_name_join: the global open-addressing table and the radix-partitioned
-    one with per-bucket tables in LDS (chosen by size in production; GCI_JOIN forces one)."""
-    monkeypatch.setenv("GCI_JOIN", request.param)
-    return request.param
+    one with per-bucket tables in LDS (chosen by size in production; gci_join_mode forces one)."""
+    engine.set_join_mode(request.param)
+    yield request.param
+    engine.set_join_mode("auto")
 
 
 @pytest.fixture(params=["atomic", "radix"])
@@ -805,11 +806,14 @@ def test_partitioned_join_bucket_overflow_falls_back(engine, monkeypatch):
     hashes = np.uint64(0xABCD) << np.uint64(32) | np.arange(n, dtype=np.uint64)          # same bucket and slot bits
     start = np.arange(n)
     one = _forged_input(engine, names, hashes, np.zeros(n), start, start + 50, np.full(n, 50), np.zeros(n))
-    monkeypatch.setenv("GCI_JOIN", "partition")
-    with pytest.raises(GciErr) as e:
-        engine.name_join([one], 0.9, fallback=False)
-    assert e.value.status == _lib.GCI_E_CAPACITY
-    ivl, cnt = engine.name_join([one], 0.9)
+    engine.set_join_mode("partition")
+    try:
+        with pytest.raises(GciErr) as e:
+            engine.name_join([one], 0.9, fallback=False)
+        assert e.value.status == _lib.GCI_E_CAPACITY
+        ivl, cnt = engine.name_join([one], 0.9)
+    finally:
+        engine.set_join_mode("auto")
     assert sorted(map(tuple, ivl[:int(cnt.item()), :3].cpu().numpy().tolist())) == [(0, i, i + 50) for i in range(n)]
 
 
