@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=1,
                     help="chr19 workload, 1 GPU: N > 1 runs consecutive steps on N streams with a context each")
     ap.add_argument("--heads", action="store_true", help="chr19 workload: feed the heads stream instead of the whole stream")
+    ap.add_argument("--k1", choices=("pages", "stream"), default="pages",
+                    help="record filter input: pages = RECORD PAGES (gci_bam_pages_*: what the command line's ingestion leaves on "
+                         "the device; gci_bam_filter_pages), stream = the heads / inflated stream + offset table (gci_bam_filter[_heads])")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend: nccl = RCCL over xGMI (one GPU per rank); gloo stages the collectives through "
                          "host memory and lets several ranks share one GPU (GCI_DIST_DEVICE): correctness runs only")
@@ -102,7 +105,7 @@ def all_reduce(t, op):
 class Workload:
     """Per-rank resident inputs + preallocated outputs for one step over F input files."""
 
-    def __init__(self, eng, rank, world, contigs, files, heads, exchange=False, replicated=False, name="", algo=None):
+    def __init__(self, eng, rank, world, contigs, files, heads, exchange=False, replicated=False, name="", algo=None, k1="pages"):
         """contigs: the (name, length) table of the WHOLE run (all ranks); `files`: this rank's slice of every input
         file as (stream uint8, offsets uint64, name_bytes) host arrays whose BAM header lists `contigs`;
         the rank owns the contigs `own` = indices into `contigs` (set by the caller through self.own before layout)."""
@@ -124,6 +127,16 @@ class Workload:
             self.name_bytes.append(int(nb))
         self.n_files = len(files)
         self.total_rec = sum(self.n_rec)
+        # record pages: made on the device from the uploaded stream, once (ingestion, outside the timed step: it is the
+        # last step of the walk over the inflated file); the stream itself is dropped
+        self.k1 = k1
+        self.pages = None
+        if k1 == "pages":
+            self.pages = [eng.bam_pages(b, o, not heads) for b, o in zip(self.d_bam, self.d_off)]
+            self.d_bam = [p.buf for p in self.pages]
+            self.d_off = [torch.empty(max(n, 1), dtype=torch.int64, device=dev) for n in self.n_rec]   # K1 writes the name offsets
+            self.stream_bytes = [int(p.buf.shape[0]) for p in self.pages]
+        self.name_delta = 0 if k1 == "pages" else 36
 
     def layout(self, own):
         """own: indices (into self.contigs) of the contigs this rank builds, in header order."""
@@ -185,6 +198,13 @@ class Workload:
         k1 = lib.gci_bam_filter_heads if self.heads else lib.gci_bam_filter
         F = self.n_files
         for f in range(F):
+            if self.pages is not None:
+                pg = self.pages[f]
+                chk(lib.gci_bam_filter_pages(ctx, _p(pg.buf), self.stream_bytes[f], pg.page_bytes, pg.n_pages, self.n_rec[f],
+                                             _p(self.ref_sel), len(self.contigs), FILTER[0], FILTER[1], FILTER[2], FILTER[3],
+                                             self.rec_base[f], _p(self.recs[f]), _p(self.d_off[f]), _p(self.status[f:f + 1])),
+                    "gci_bam_filter_pages")
+                continue
             chk(k1(ctx, _p(self.d_bam[f]), self.stream_bytes[f], _p(self.d_off[f]), self.n_rec[f], _p(self.ref_sel),
                    len(self.contigs), FILTER[0], FILTER[1], FILTER[2], FILTER[3], self.rec_base[f], _p(self.recs[f]),
                    _p(self.status[f:f + 1])), "gci_bam_filter")
@@ -196,7 +216,7 @@ class Workload:
             for f in range(F):
                 ex = self.ex[f]
                 loc = (JoinFile * 1)()
-                loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs[f].data_ptr(), self.n_rec[f], 36
+                loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs[f].data_ptr(), self.n_rec[f], self.name_delta
                 loc[0].d_name_base, loc[0].d_name_off = self.d_bam[f].data_ptr(), self.d_off[f].data_ptr()
                 chk(lib.gci_pack_names(ctx, loc, _p(ex.send_names), ex.name_cap, _p(ex.send_off)), "gci_pack_names")
                 g = ex.gather()
@@ -210,7 +230,7 @@ class Workload:
                 # timed region and main() redoes everything with the replicated join if any step saw a conflict.
                 self.check_names.enqueue_files([self.recs[f][:self.n_rec[f]] for f in range(F)])
             for f in range(F):
-                jf[f].d_recs, jf[f].n_recs, jf[f].name_delta = self.recs[f].data_ptr(), self.n_rec[f], 36
+                jf[f].d_recs, jf[f].n_recs, jf[f].name_delta = self.recs[f].data_ptr(), self.n_rec[f], self.name_delta
                 jf[f].d_name_base, jf[f].d_name_off = self.d_bam[f].data_ptr(), self.d_off[f].data_ptr()
         # the join also does the counting pass of the depth build over the intervals it emits (gci_name_join_count)
         if self.opts.counted:
@@ -308,7 +328,7 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
                       "-op join), filter x2 -> join -> depth -> issue scan -> depth text" % (
                           nper, sum(l for _, l in inp.contigs), " x %d haplotypes" % world if world > 1 else "", args.coverage)
                       + ("" if args.reads == "hifi" else " [ONT reads]"),
-                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)})
+                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)}, k1=args.k1)
     w.aligned_bases = inp.aligned_bases
     w.inp = inp if ((rank == 0 and world == 1) or args.verify_oracle) else None
     if w.inp is None:
@@ -352,7 +372,7 @@ def make_chr19_workload(eng_factory, rank, world, args, exchange, replicated, en
                  name="CHM13 chr19 (%d bp) x %d contig(s), one %gx HiFi BAM (%s), filter -> join -> depth -> issue scan -> "
                       "depth text" % (args.contig_len, world, args.coverage,
                                       "heads stream" if args.heads else "whole inflated stream"),
-                 algo={"k1_bytes": k1b})
+                 algo={"k1_bytes": k1b}, k1=args.k1)
     w.aligned_bases = aligned
     w.host = host
     return eng, w.layout([rank])
@@ -586,7 +606,7 @@ def two_in_flight(eng, w, args, device_index):
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         e2 = Engine(device_index, stream=st)
-        w2 = Workload(e2, 0, 1, w.contigs, [(f.stream, f.offsets, f.name_bytes) for f in w.inp.files], heads=True, name=w.name)
+        w2 = Workload(e2, 0, 1, w.contigs, [(f.stream, f.offsets, f.name_bytes) for f in w.inp.files], heads=True, name=w.name, k1=w.k1)
         w2.layout(w.own)
         for _ in range(max(1, args.warmup)):
             w2.step()
@@ -808,7 +828,8 @@ def main():
         "config": {"workload": w.name + (" [scale %g]" % args.scale if args.workload == "genome" and args.scale != 1.0 else ""),
                    "baseline_config": "configs[2]" if args.workload == "genome" else "configs[1]",
                    "input_files_per_gpu": w.n_files, "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
-                   "bam_input": "heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream",
+                   "bam_input": ("record pages (gci_bam_pages_*: %d-byte pages made on the device from the " % w.pages[0].page_bytes if w.pages else "")
+                                + ("heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream") + (")" if w.pages else ""),
                    "input_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "steps_in_flight": len(lanes),
                    "join": ("local" if not w.exchange else

@@ -17,6 +17,7 @@ GCI_OK, GCI_E_INVALID, GCI_E_HIP, GCI_E_NO_NM, GCI_E_ZERO_DIV = 0, -1, -2, -3, -
 GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, GCI_E_NO_LAYOUT = -5, -6, -7, -8, -9, -10
 GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
+PAGE_MAX_REC, PAGE_MAX_BYTES, PAGE_BYTES_DEFAULT = 1024, 32768, 24576
 REC_PASS, REC_HQ = 1, 2
 PROF_COUNT = 17
 PROF_DEPTH_SCAN = 5          # k_tile_build: the pass that writes the depth track (+ text)
@@ -68,6 +69,10 @@ EXPORTS = [
                                c_double, c_double, c_uint32, c_void_p, c_void_p]),
     ("gci_bam_filter_heads", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_int32, c_int, c_int,
                                      c_double, c_double, c_uint32, c_void_p, c_void_p]),
+    ("gci_bam_pages_size", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_int, c_uint32, c_void_p]),
+    ("gci_bam_pages_write", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_int, c_void_p, c_uint64]),
+    ("gci_bam_filter_pages", c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p, c_int32, c_int, c_int,
+                                     c_double, c_double, c_uint32, c_void_p, c_void_p, c_void_p]),
     ("gci_decode_status", c_int, [c_uint64, POINTER(c_uint32)]),
     ("gci_name_hash", c_uint64, [c_void_p, c_uint32]),
     ("gci_pack_names", c_int, [c_void_p, POINTER(JoinFile), c_void_p, c_uint64, c_void_p]),

@@ -68,6 +68,9 @@ struct gci_ctx {
     uint32_t conflict_parity = 0;           // which one the next call inserts into (the other one is clean by then)
     DevBuf text_lut;                        // uint32[TEXT_LUT]: decimal characters of 0..999
     DevBuf long_items;                      // K1: queue of long-CIGAR records + its counter
+    DevBuf pg_cost, pg_scan, pg_first;      // record pages: per-record cost / blob bytes, their scans, first record of a page
+    uint32_t pg_n_rec = 0, pg_page_bytes = 0, pg_n_pages = 0;
+    uint64_t pg_blob_off = 0;
     // issue-scan windows
     DevBuf win, win_tile_first;
     int win_flank = INT32_MIN;              // flank the cached per-contig windows were built for

@@ -290,14 +290,16 @@ __device__ __forceinline__ int64_t aux_value_size(const uint8_t* p, const uint8_
 }
 
 // One record, one wave (all 64 lanes): called by k_bam_filter for the records its staged window could not answer.
+// QUEUE_ALL (the paged filter): every CIGAR goes to the chunk queue, so that the rare path's registers (ten 64-bit sums,
+// eight 16-byte pieces in flight) do not set the occupancy of a kernel that lives on its waves per SIMD.
+template <bool QUEUE_ALL = false>
 __device__ __forceinline__ void slow_record(
-    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
+    const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t off,
     const int32_t* __restrict__ ref_sel, uint32_t rec, int lane, const LongQueue& lq, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out)
 {
     // the fast path has already validated the record's bounds and passed its flag / MAPQ tests;
     // every lane parses the scalar part redundantly (same addresses: one transaction per load)
-    const uint64_t off = rec_off[rec];
     const uint8_t* p = bam + off;
     const int32_t block_size = (int32_t)rd32b(p);
     const int32_t ref_id = (int32_t)rd32b(p + 4);
@@ -349,7 +351,7 @@ __device__ __forceinline__ void slow_record(
     gci_rec r;
     r.name_hash = gci_hash_finish(acc, name_len); r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0;
     r.rec_idx = rec + rec_idx_base; r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = (uint16_t)name_len;
-    if (n_ops > LONG_OPS) {                 // summed chunk by chunk like the fast path's long CIGARs
+    if (n_ops > (QUEUE_ALL ? 0u : LONG_OPS)) {   // summed chunk by chunk like the fast path's long CIGARs
         LongItem li;
         li.ops_off = (uint64_t)(ops - bam); li.n_ops = n_ops; li.rec = rec;
         li.nm = nm_p ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
@@ -360,7 +362,10 @@ __device__ __forceinline__ void slow_record(
         return;
     }
     int64_t tot[NSLOT];
-    cigar_totals_wave(bam, n_bytes, (uint64_t)(ops - bam), n_ops, lane, tot);
+    if constexpr (QUEUE_ALL) {
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) tot[k] = 0;         // no operations at all
+    } else cigar_totals_wave(bam, n_bytes, (uint64_t)(ops - bam), n_ops, lane, tot);
     if (lane == 0) {
         const int st = decide(r, tot[0] + tot[7] + tot[8], tot[1], tot[2], tot[3], tot[4], nm_p != nullptr, nm_bad, NM, pos,
                               contig, l_seq, n_cigar, mapq, mq_cutoff, clip_percent, iden_percent);
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     // CG:B,I long-CIGAR restore, names of 73 bytes and more); no second kernel launch for them
     for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
         const uint32_t rs = (uint32_t)__shfl((int)rec, __builtin_ctzll(m), 64);
-        slow_record(bam, n_bytes, rec_off, ref_sel, rs, t & 63, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, out);
+        slow_record(bam, n_bytes, rec_off[rs], ref_sel, rs, t & 63, lq, mq_cutoff, clip_percent, iden_percent, rec_idx_base, out);
     }
 }
 
@@ -757,25 +762,256 @@ __global__ __launch_bounds__(BLOCK) void k_cigar_finish(const LongQueue lq, int 
     }
 }
 
-static int bam_filter_impl(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
-                           uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
-                           double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
-                           uint64_t* d_status, bool has_seq)
+// =====================================================================================================================
+// The paged record filter (round 3).  Input: RECORD PAGES (k_pages.hip: the bytes read_sam looks at, copied once into
+// fixed-size pages while the inflated stream is walked; every record and every CIGAR 16-byte aligned, a small directory
+// per page).  One workgroup per page: ONE round of coalesced 16-byte loads brings the page into LDS -- no offset table,
+// no second and third dependent round trip, no re-aligning of dwords in registers -- and four lanes per record parse it
+// there: core fields, NUL search + name hash, the whole aux walk (bam_aux_get semantics, CG:B,I restore included), the
+// CIGAR as aligned ds_read_b128 pieces.  Same decisions, same 32-byte records, same status word as k_bam_filter.
+//   kind 1 (CIGAR in the blob: ONT) -> the chunk queue of k_cigar_chunks, which reads the blob;
+//   kind 2 (the whole record in the blob: CG:B,I with 65536+ operations, kilobytes of tags) -> slow_record over the blob.
+#define PGK 256                    // threads per workgroup: 64 records per pass
+#define PG_KIND_EXT 1u
+#define PG_KIND_OVERSIZE 2u
+#define PG_KIND_MALFORMED 4u
+#define PG_MAGIC 0x31504347u
+
+struct PagesArgs {
+    const uint8_t* buf; uint64_t total_bytes; uint32_t page_bytes, n_pages, n_rec;
+    const int32_t* ref_sel; int32_t n_ref; int map_qual, mq_cutoff; double clip_percent, iden_percent;
+    uint32_t rec_idx_base; gci_rec* out; uint64_t* name_off;
+};
+
+#ifndef PG_WAVES
+#define PG_WAVES 6
+#endif
+__global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, PG_WAVES))) void k_bam_filter_pages(const PagesArgs A, const LongQueue lq)
 {
-    if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
-    // scratch: [2 x (n_slow u32, pad, n_long u64)][2 x status u64][pad][slow_list u32 x n_rec (+pad)][long items][chunk queue][chunk sums].
-    // A long item has more than LONG_OPS ops = 4 * LONG_OPS bytes of stream of its own and a chunk covers
-    // 4 * CHUNK_DW bytes: that bounds both queues
+    extern __shared__ __attribute__((aligned(16))) uint8_t page[];
+    __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0 && t < 4) lq.next_counters[t] = 0u;                 // nobody reads that set during this call
+    if (blockIdx.x == 0 && t == 4) *lq.next_status = ~0ull;
+    const uint32_t P = A.page_bytes;
+    const uint64_t page_at = (uint64_t)blockIdx.x * P;
+    {
+        // the whole page, requested up front (P is a multiple of 4096 = one 16-byte piece per thread and round)
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(A.buf + page_at);
+        const uint32_t rounds = P / (16u * PGK);
+        for (uint32_t r0 = 0; r0 < rounds; r0 += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = r0 + u < rounds ? src[(r0 + u) * PGK + t] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (r0 + u < rounds) reinterpret_cast<uint4*>(page)[(r0 + u) * PGK + t] = v[u];
+        }
+    }
+    for (int i = t; i < 256; i += PGK) {
+        const char c = (char)i;
+        aux_sz[i] = (c == 'A' || c == 'c' || c == 'C') ? 1 : (c == 's' || c == 'S') ? 2 : (c == 'i' || c == 'I' || c == 'f') ? 4 : 0;
+    }
+    __syncthreads();
+    const uint32_t* ph = reinterpret_cast<const uint32_t*>(page);
+    uint32_t n_recs = ph[0];
+    const uint32_t first_rec = ph[1];
+    if (ph[3] != PG_MAGIC || n_recs > (P - 16u) / 50u || (uint64_t)first_rec + n_recs > A.n_rec) {       // not a page of ours
+        if (t == 0) report(lq.status_in, first_rec < A.n_rec ? first_rec : 0u, GCI_E_MALFORMED);
+        n_recs = 0;
+    }
+    const int gl = t & 3, grp = t >> 2;
+    for (uint32_t j0 = 0; j0 < n_recs; j0 += PGK / 4) {
+        const uint32_t j = j0 + grp;
+        const uint32_t rec = first_rec + j;
+        uint64_t slow_off = 0;
+        auto fast_path = [&]() -> bool {
+            uint32_t base = (uint32_t)reinterpret_cast<const uint16_t*>(page + 16)[j] << 4;
+            if (base > P - 48u) base = P - 48u;                                    // (never, in a page of ours)
+            const uint8_t* hd = page + base;
+            const uint4 c0 = *reinterpret_cast<const uint4*>(hd);                  // size | refID | pos | l_read_name, mapq, kind
+            const uint4 c1 = *reinterpret_cast<const uint4*>(hd + 16);             // n_cigar, flag | l_seq | aux_len | blob offset lo
+            const uint32_t blob_hi = *reinterpret_cast<const uint32_t*>(hd + 32);
+            const uint32_t size = c0.x, kind = c0.w >> 16, l_read_name = c0.w & 0xFFu, n_cigar = c1.x & 0xFFFFu, flag = c1.x >> 16;
+            const int32_t ref_id = (int32_t)c0.y, pos = (int32_t)c0.z, l_seq = (int32_t)c1.y;
+            const int mapq = (int)((c0.w >> 8) & 0xFFu);
+            const uint32_t aux_len = c1.z;
+            const uint64_t blob_at = (uint64_t)c1.w | ((uint64_t)blob_hi << 32);
+            gci_rec r;
+            r.name_hash = 0; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + A.rec_idx_base;
+            r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = 0;
+            if (gl == 0 && A.name_off) A.name_off[rec] = (kind == PG_KIND_OVERSIZE ? blob_at : page_at + base) + 36u;
+            const bool ext = kind == PG_KIND_EXT;
+            const uint32_t cig_at = (36u + l_read_name + 15u) & ~15u;
+            const uint32_t aux_at = cig_at + (ext ? 16u : 4u * n_cigar);
+            if ((kind & PG_KIND_MALFORMED) || (kind != PG_KIND_OVERSIZE && ((uint64_t)aux_at + aux_len > size || base + size > P))) {
+                if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); A.out[rec] = r; }
+                return false;
+            }
+            if (ref_id < 0 || ref_id >= A.n_ref || (flag & (0x4u | 0x100u | 0x800u)) || mapq < A.map_qual) {   // GCI.py:152-156
+                if (gl == 0) A.out[rec] = r;
+                return false;
+            }
+            const int32_t contig = A.ref_sel[ref_id];
+            // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
+            if (contig < 0) {
+                if (gl == 0) A.out[rec] = r;
+                return false;
+            }
+            if (kind == PG_KIND_OVERSIZE) {
+                if (blob_at + 36 > A.total_bytes) { if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); A.out[rec] = r; } return false; }
+                slow_off = blob_at;
+                return true;
+            }
+            // ---- aux walk (bam_aux_get semantics): first NM; first CG when the CIGAR is htslib's long-CIGAR placeholder
+            const uint8_t* ax = hd + aux_at;
+            const uint32_t op0 = lds_u32(hd + cig_at);
+            const bool want_cg = n_cigar > 0 && pos >= 0 && (op0 & 0xFu) == 4u && (op0 >> 4) == (uint32_t)l_seq;
+            bool have_nm = false, nm_bad = false;
+            int64_t NM = 0;
+            uint32_t cg_q = 0xFFFFFFFFu;
+            for (uint32_t q = 0; q + 3 <= aux_len;) {
+                const uint32_t w = lds_u32(ax + q);                                // tag[2] | type | first value byte
+                const uint32_t tag = w & 0xFFFFu;
+                const uint8_t ty = (uint8_t)(w >> 16);
+                uint32_t sz = aux_sz[ty];
+                if (sz == 0) {
+                    if (ty == 'Z' || ty == 'H') {
+                        uint32_t e = q + 3;
+                        while (e < aux_len && ax[e]) e++;
+                        if (e >= aux_len) break;
+                        sz = e - (q + 3) + 1;
+                    } else if (ty == 'B') {
+                        if (q + 8 > aux_len) break;
+                        const uint8_t sub = ax[q + 3];
+                        const uint32_t es = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u
+                                          : (sub == 'i' || sub == 'I' || sub == 'f') ? 4u : 0u;
+                        const uint64_t s64 = 5ull + (uint64_t)lds_u32(ax + q + 4) * es;
+                        if (es == 0 || s64 > aux_len) break;
+                        sz = (uint32_t)s64;
+                    } else break;
+                }
+                if (q + 3 + sz > aux_len) break;
+                if (tag == (uint32_t)('N' | ('M' << 8)) && !have_nm) {
+                    have_nm = true;
+                    nm_bad = !nm_value(ax + q + 2, NM);
+                    if (!want_cg || cg_q != 0xFFFFFFFFu) break;
+                }
+                if (want_cg && tag == (uint32_t)('C' | ('G' << 8)) && cg_q == 0xFFFFFFFFu) {
+                    cg_q = q + 2;
+                    if (have_nm) break;
+                }
+                q += 3 + sz;
+            }
+            // htslib moves a long CIGAR back from CG:B,I when op0 == <l_seq>S
+            const uint8_t* cg_ops = nullptr;
+            uint32_t n_ops = n_cigar;
+            if (cg_q != 0xFFFFFFFFu && ax[cg_q] == 'B' && (ax[cg_q + 1] == 'I' || ax[cg_q + 1] == 'i')) {
+                const uint32_t cg_len = lds_u32(ax + cg_q + 2);
+                if (cg_len >= n_cigar && cg_len < (1u << 29)) { cg_ops = ax + cg_q + 6; n_ops = cg_len; }
+            }
+            // ---- CIGAR base totals (get_cigar_stats()[0], GCI.py:157-162) as the four sums the decision uses (decide4):
+            // S, den1 = M + I + S, den2 = M + I + D, rlen = M + D + N (M, = and X together); which of them an op code
+            // feeds is one bit of a constant per sum
+            unsigned long long sS = 0, sQ = 0, sA = 0, sR = 0;
+            auto add_op = [&](uint32_t v, uint32_t& pS, uint32_t& pQ, uint32_t& pA, uint32_t& pR) {
+                const uint32_t op = v & 0xFu, len = v >> 4;
+                pS += len & (uint32_t)__builtin_amdgcn_sbfe(0x010, op, 1);
+                pQ += len & (uint32_t)__builtin_amdgcn_sbfe(0x193, op, 1);
+                pA += len & (uint32_t)__builtin_amdgcn_sbfe(0x187, op, 1);
+                pR += len & (uint32_t)__builtin_amdgcn_sbfe(0x18D, op, 1);
+            };
+            const bool queued = ext && !cg_ops;                        // its totals come from k_cigar_chunks
+            if (cg_ops) {
+                for (uint32_t k = gl; k < n_ops; k += 4) {
+                    uint32_t pS = 0, pQ = 0, pA = 0, pR = 0;
+                    add_op(lds_u32(cg_ops + 4 * k), pS, pQ, pA, pR);
+                    sS += pS; sQ += pQ; sA += pA; sR += pR;
+                }
+            } else if (!ext) {
+                const uint8_t* cg = hd + cig_at;
+                for (uint32_t p = gl; 4u * p < n_cigar; p += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(cg + 16u * p);
+                    const uint32_t valid = n_cigar - 4u * p;           // >= 1; ops beyond the CIGAR are aux bytes or padding
+                    uint32_t pS = 0, pQ = 0, pA = 0, pR = 0;
+                    add_op(v.x, pS, pQ, pA, pR);
+                    if (valid > 1) add_op(v.y, pS, pQ, pA, pR);
+                    if (valid > 2) add_op(v.z, pS, pQ, pA, pR);
+                    if (valid > 3) add_op(v.w, pS, pQ, pA, pR);
+                    sS += pS; sQ += pQ; sA += pA; sR += pR;
+                }
+            }
+            // ---- query_name: bytes up to the first NUL, 64-bit hash of its 8-byte words -----------------------------------
+            const uint8_t* name = hd + 36;
+            uint32_t nul = l_read_name;
+            for (uint32_t i = gl * 4; i < l_read_name; i += 16) {
+                if (has_zero_byte(lds_u32(name + i))) {
+                    for (uint32_t b = i; b < i + 4 && b < l_read_name; b++) if (name[b] == 0) { nul = min(nul, b); break; }
+                    break;
+                }
+            }
+            nul = min(nul, (uint32_t)__shfl_xor((int)nul, 1, 4));
+            nul = min(nul, (uint32_t)__shfl_xor((int)nul, 2, 4));
+            const uint32_t name_len = nul;
+            uint64_t acc = 0;
+            for (uint32_t k = gl; k * 8 < name_len; k += 4) {
+                const uint32_t b0 = k * 8;
+                uint64_t w;
+                __builtin_memcpy(&w, name + b0, 8);                                    // stays inside the page (zero padding behind)
+                const uint32_t keep = name_len - b0;                                   // bytes of this word inside the name
+                if (keep < 8) w &= (1ull << (8 * keep)) - 1ull;
+                acc += gci_hash_word(w, k);
+            }
+            acc += (uint64_t)__shfl_xor((long long)acc, 1, 4);
+            acc += (uint64_t)__shfl_xor((long long)acc, 2, 4);
+            r.name_hash = gci_hash_finish(acc, name_len);
+            r.name_len = (uint16_t)name_len;
+            if (queued) {                    // the parse is complete: only the CIGAR totals + decision are left to k_cigar_chunks / _finish
+                LongItem it;
+                it.ops_off = blob_at; it.n_ops = n_cigar; it.rec = rec;
+                it.nm = have_nm ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
+                it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
+                it.mapq = (uint32_t)mapq;
+                if (gl == 0) A.out[rec] = r;
+                const bool in_blob = blob_at + 4ull * n_cigar <= A.total_bytes;
+                if (!in_blob) { if (gl == 0) report(lq.status_in, rec, GCI_E_MALFORMED); return false; }
+                if (!enqueue_long<4>(lq, it, gl) && gl == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
+                return false;
+            }
+#define PG_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, 4); x += (unsigned long long)__shfl_xor((long long)x, 2, 4); } while (0)
+            PG_SUM(sS); PG_SUM(sQ); PG_SUM(sA); PG_SUM(sR);
+#undef PG_SUM
+            if (gl != 0) return false;
+            const int st = decide4(r, (int64_t)sS, (int64_t)sQ, (int64_t)sA, (int64_t)sR, have_nm, nm_bad, NM, pos, contig, l_seq,
+                                   n_cigar, mapq, A.mq_cutoff, A.clip_percent, A.iden_percent);
+            if (st != GCI_OK) report(lq.status_in, rec, st);
+            A.out[rec] = r;
+            return false;
+        };
+        const bool is_slow = j < n_recs && fast_path();
+        // records whose bytes live in the blob (kind 2), one after the other, by the whole wave
+        for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
+            const int l = __builtin_ctzll(m);
+            const uint32_t rs = (uint32_t)__shfl((int)rec, l, 64);
+            const uint64_t so = (uint64_t)__shfl((long long)slow_off, l, 64);
+            slow_record<true>(A.buf, A.total_bytes, so, A.ref_sel, rs, t & 63, lq, A.mq_cutoff, A.clip_percent, A.iden_percent, A.rec_idx_base, A.out);
+        }
+    }
+}
+
+// Scratch of one K1 call: [2 x (n_slow u32, pad, n_long u64)][2 x status u64][pad][slow_list u32 x n_rec (+pad)][long items]
+// [chunk queue][chunk sums].  A queued item has at least min_item_bytes of CIGAR of its own inside the long_bytes that can
+// hold such CIGARs, and a chunk covers 4 * CHUNK_DW bytes: that bounds both queues.
+static int k1_prepare(gci_ctx* ctx, uint32_t n_rec, uint64_t long_bytes, uint32_t min_item_bytes, bool has_seq, LongQueue& lq)
+{
     const size_t list_bytes = ((size_t)n_rec * 4 + 15) & ~(size_t)15;
-    const uint64_t by_bytes = n_bytes / (4ull * LONG_OPS) + 1;
+    const uint64_t by_bytes = long_bytes / min_item_bytes + 1;
     const uint32_t cap_items = (uint32_t)(by_bytes < n_rec ? by_bytes : n_rec);
-    const uint64_t cap_chunks64 = n_bytes / (4ull * CHUNK_DW) + 2ull * cap_items + 1;
+    const uint64_t cap_chunks64 = long_bytes / (4ull * CHUNK_DW) + 2ull * cap_items + 1;
     if (cap_chunks64 > 0xFFFFFFFFull) return GCI_E_INVALID;
     const uint32_t cap_chunks = (uint32_t)cap_chunks64;
     const size_t cap_before = ctx->long_items.cap;
     GCI_TRY(gci_ensure(ctx, ctx->long_items, 64 + list_bytes + (size_t)cap_items * sizeof(LongItem) +
                                              (size_t)cap_chunks * (8 + sizeof(ChunkSums))));
-    LongQueue lq;
     // two sets of counters [n_slow u32, pad, n_long u64], used alternately: the fast kernel of one call zeroes the set of
     // the next, so no memset is launched per call (a fill costs a whole dependent launch, ~4.6 us)
     if (ctx->long_items.cap != cap_before) {
@@ -795,6 +1031,30 @@ static int bam_filter_impl(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes,
     lq.sums = (ChunkSums*)(lq.chunks + cap_chunks);
     lq.cap_items = cap_items; lq.cap_chunks = cap_chunks;
     lq.has_seq = has_seq ? 1u : 0u;
+    return GCI_OK;
+}
+
+// the two kernels behind the fast one: long CIGARs chunk by chunk, then their decisions
+static int k1_finish(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const LongQueue& lq, int mq_cutoff, double clip_percent,
+                     double iden_percent, gci_rec* d_out, uint64_t* d_status)
+{
+    hipLaunchKernelGGL(k_cigar_chunks, dim3(lq.cap_chunks < 8192u ? (lq.cap_chunks + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream,
+                       d_bam, n_bytes, lq, (unsigned long long*)d_status);
+    LAUNCHCHK("k_cigar_chunks");
+    hipLaunchKernelGGL(k_cigar_finish, dim3(lq.cap_items < 65536u ? (lq.cap_items + BLOCK - 1) / BLOCK : 256u), dim3(BLOCK), 0,
+                       ctx->stream, lq, mq_cutoff, clip_percent, iden_percent, d_out, (unsigned long long*)d_status);
+    LAUNCHCHK("k_cigar_finish");
+    return GCI_OK;
+}
+
+static int bam_filter_impl(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,
+                           uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                           double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                           uint64_t* d_status, bool has_seq)
+{
+    if (!ctx || !d_out || !d_status || (n_rec && (!d_bam || !d_rec_off || !d_ref_sel))) return GCI_E_INVALID;
+    LongQueue lq;
+    GCI_TRY(k1_prepare(ctx, n_rec, n_bytes, 4u * LONG_OPS, has_seq, lq));
     if (n_rec == 0) { HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream)); return GCI_OK; }
     ctx->k1_parity ^= 1u;                   // the fast kernel below zeroes the other set for the next call
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
@@ -807,13 +1067,32 @@ static int bam_filter_impl(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes,
 #endif
                        );
     LAUNCHCHK("k_bam_filter");
-    hipLaunchKernelGGL(k_cigar_chunks, dim3(cap_chunks < 8192u ? (cap_chunks + 3) / 4 : 2048u), dim3(BLOCK), 0, ctx->stream,
-                       d_bam, n_bytes, lq, (unsigned long long*)d_status);
-    LAUNCHCHK("k_cigar_chunks");
-    hipLaunchKernelGGL(k_cigar_finish, dim3(cap_items < 65536u ? (cap_items + BLOCK - 1) / BLOCK : 256u), dim3(BLOCK), 0,
-                       ctx->stream, lq, mq_cutoff, clip_percent, iden_percent, d_out, (unsigned long long*)d_status);
-    LAUNCHCHK("k_cigar_finish");
-    return GCI_OK;
+    return k1_finish(ctx, d_bam, n_bytes, lq, mq_cutoff, clip_percent, iden_percent, d_out, d_status);
+}
+
+// The paged record filter: same outputs and status word as gci_bam_filter; d_name_off (nullable) receives, per record,
+// the offset of its query name inside the pages buffer (the join's d_name_off with d_name_base = d_pages, name_delta = 0).
+extern "C" int gci_bam_filter_pages(gci_ctx* ctx, const uint8_t* d_pages, uint64_t total_bytes, uint32_t page_bytes, uint32_t n_pages,
+                                    uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                                    double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                                    uint64_t* d_name_off, uint64_t* d_status)
+{
+    if (!ctx || !d_out || !d_status || (n_rec && (!d_pages || !d_ref_sel))) return GCI_E_INVALID;
+    if (page_bytes < 8192 || page_bytes > GCI_PAGE_MAX_BYTES || (page_bytes & 4095u)) return GCI_E_INVALID;
+    if ((uint64_t)n_pages * page_bytes + 16 > total_bytes && n_pages) return GCI_E_INVALID;
+    LongQueue lq;
+    // every queued CIGAR lies in the blob; the shortest one that does not fit a page record has ~180 operations
+    GCI_TRY(k1_prepare(ctx, n_rec, total_bytes - (uint64_t)n_pages * page_bytes, 512u, false, lq));
+    if (n_rec == 0 || n_pages == 0) { HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream)); return GCI_OK; }
+    ctx->k1_parity ^= 1u;
+    ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
+    PagesArgs A;
+    A.buf = d_pages; A.total_bytes = total_bytes; A.page_bytes = page_bytes; A.n_pages = n_pages; A.n_rec = n_rec;
+    A.ref_sel = d_ref_sel; A.n_ref = n_ref; A.map_qual = map_qual; A.mq_cutoff = mq_cutoff;
+    A.clip_percent = clip_percent; A.iden_percent = iden_percent; A.rec_idx_base = rec_idx_base; A.out = d_out; A.name_off = d_name_off;
+    hipLaunchKernelGGL(k_bam_filter_pages, dim3(n_pages), dim3(PGK), page_bytes, ctx->stream, A, lq);
+    LAUNCHCHK("k_bam_filter_pages");
+    return k1_finish(ctx, d_pages, total_bytes, lq, mq_cutoff, clip_percent, iden_percent, d_out, d_status);
 }
 
 extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const uint64_t* d_rec_off,

@@ -21,7 +21,7 @@
 //     +36 read_name, zero padded so that the CIGAR starts at align16(36 + l_read_name); aux bytes right behind the
 //         CIGAR; zero padded to 16.
 //   A record that does not fit 1024 bytes keeps its CIGAR words in the blob (kind 1: ONT reads, 10^3 - 10^5 operations,
-//   summed chunk by chunk by k_cigar_chunks anyway); one that still does not fit (a CG:B,I tag, long Z tags) leaves its
+//   summed chunk by chunk by k_cigar_chunks anyway; 16 bytes with the first operation stand in for them); one that still does not fit (a CG:B,I tag, long Z tags) leaves its
 //   48-byte core in the page and its bytes -- the heads form: the record without SEQ / QUAL -- in the blob (kind 2).
 //   No record straddles a page, nothing in a page needs the offset table, every CIGAR is 16-byte aligned: the filter
 //   loads a page with one round of coalesced 16-byte loads and parses it out of LDS.
@@ -68,8 +68,8 @@ __device__ __forceinline__ PgRec pg_measure(const uint8_t* __restrict__ bam, uin
     const uint32_t cig_at = a16(36 + lrn);
     if (aux_len <= PG_MAX_REC && a16(cig_at + 4 * n_cig + (uint32_t)aux_len) <= PG_MAX_REC) {
         r.kind = 0; r.size = a16(cig_at + 4 * n_cig + (uint32_t)aux_len); r.aux_len = (uint32_t)aux_len;
-    } else if (aux_len <= PG_MAX_REC && a16(cig_at + (uint32_t)aux_len) <= PG_MAX_REC) {
-        r.kind = PG_EXT; r.size = a16(cig_at + (uint32_t)aux_len); r.blob = a16(4 * n_cig); r.aux_len = (uint32_t)aux_len;
+    } else if (aux_len <= PG_MAX_REC && a16(cig_at + 16 + (uint32_t)aux_len) <= PG_MAX_REC) {
+        r.kind = PG_EXT; r.size = a16(cig_at + 16 + (uint32_t)aux_len); r.blob = a16(4 * n_cig); r.aux_len = (uint32_t)aux_len;
     } else {
         r.kind = PG_OVERSIZE; r.size = 48; r.aux_len = (uint32_t)aux_len;
         r.blob = (uint32_t)((36 + lrn + 4ull * n_cig + aux_len + 15ull) & ~15ull);
@@ -100,23 +100,24 @@ __global__ __launch_bounds__(BLOCK) void k_pg_first(const unsigned long long* __
     page_first[k] = lo;
 }
 
-// the aligned dword at byte offset `at` (a multiple of 4) of the stream; bytes past its end read as zero
-__device__ __forceinline__ uint32_t pg_ldw(const uint8_t* __restrict__ bam, uint64_t at, uint64_t n_bytes)
+// the naturally aligned dword at address q of the stream [bam, end); bytes past the end read as zero
+__device__ __forceinline__ uint32_t pg_ldw(const uint8_t* q, const uint8_t* end)
 {
-    if (at + 4 <= n_bytes) return *reinterpret_cast<const uint32_t*>(bam + at);
+    if (q + 4 <= end) return *reinterpret_cast<const uint32_t*>(q);
     uint32_t w = 0;
-    for (int b = 0; b < 4; b++) if (at + b < n_bytes) w |= (uint32_t)bam[at + b] << (8 * b);
+    for (int b = 0; b < 4; b++) if (q + b < end) w |= (uint32_t)q[b] << (8 * b);
     return w;
 }
 
-// dword d of the `len` bytes that start at stream offset `src` (any alignment); bytes beyond len read as zero
+// dword d of the `len` bytes that start at stream offset `src` (any alignment); bytes beyond len read as zero.  Two naturally
+// aligned loads re-aligned in registers (an unaligned vector load from global memory is ~100x slower on gfx950).
 __device__ __forceinline__ uint32_t pg_src_dword(const uint8_t* __restrict__ bam, uint64_t n_bytes, uint64_t src, uint32_t len, uint32_t d)
 {
-    const uint64_t p = src + 4ull * d;
-    const uint32_t sh = (uint32_t)(p & 3ull);
-    const uint64_t a = p & ~3ull;
-    const uint32_t lo = pg_ldw(bam, a, n_bytes);
-    const uint32_t hi = sh ? pg_ldw(bam, a + 4, n_bytes) : 0u;
+    const uint8_t* p = bam + src + 4ull * d;
+    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+    const uint8_t* end = bam + n_bytes;
+    const uint32_t lo = pg_ldw(p - sh, end);
+    const uint32_t hi = sh ? pg_ldw(p - sh + 4, end) : 0u;
     uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
     const uint32_t left = len - 4u * d;
     if (left < 4u) w &= (1u << (8u * left)) - 1u;
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
             for (uint32_t d = gl; d < r.n_cig; d += PG_LANES)
                 *reinterpret_cast<uint32_t*>(dst + c + 4 * d) = pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, d);
             c += 4 * r.n_cig;
+        } else {                                                   // kind 1: the first operation stays visible in the page
+            if (gl == 0) *reinterpret_cast<uint32_t*>(dst + c) = pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, 0);
+            c += 16;
         }
         for (uint32_t d = gl; 4u * d < r.aux_len; d += PG_LANES)
             *reinterpret_cast<uint32_t*>(dst + c + 4 * d) = pg_src_dword(A.bam, A.n_bytes, r.aux_off, r.aux_len, d);
@@ -218,7 +222,7 @@ extern "C" int gci_bam_pages_size(gci_ctx* ctx, const uint8_t* d_stream, uint64_
                                   int has_seq, uint32_t page_bytes, uint64_t* h_out)
 {
     if (!ctx || !h_out || (n_rec && (!d_stream || !d_rec_off))) return GCI_E_INVALID;
-    if (page_bytes < 8192 || page_bytes > 65536 || (page_bytes & 4095u)) return GCI_E_INVALID;
+    if (page_bytes < 8192 || page_bytes > GCI_PAGE_MAX_BYTES || (page_bytes & 4095u)) return GCI_E_INVALID;
     h_out[0] = h_out[1] = h_out[2] = 0;
     ctx->pg_n_rec = n_rec; ctx->pg_page_bytes = page_bytes; ctx->pg_n_pages = 0; ctx->pg_blob_off = 0;
     if (n_rec == 0) { h_out[1] = 16; return GCI_OK; }
@@ -269,7 +273,6 @@ extern "C" int gci_bam_pages_write(gci_ctx* ctx, const uint8_t* d_stream, uint64
     A.S = S; A.B = B; A.page_first = (const uint32_t*)ctx->pg_first.p; A.page_bytes = ctx->pg_page_bytes;
     A.blob_off = ctx->pg_blob_off; A.out = d_out;
     if (cap < ctx->pg_blob_off + 16) return GCI_E_CAPACITY;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pg_write), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     hipLaunchKernelGGL(k_pg_write, dim3(ctx->pg_n_pages), dim3(BLOCK), ctx->pg_page_bytes, ctx->stream, A);
     LAUNCHCHK("k_pg_write");
     // the 16 readable bytes behind the blob (k_cigar_chunks fetches whole 16-byte pieces)

@@ -62,6 +62,16 @@ class JoinInput:
     name_delta: int               # 36 for BAM records, 0 for a names blob
 
 
+@dataclass
+class Pages:
+    """Record pages of one alignment file on the device (gci_bam_pages_write)."""
+    buf: torch.Tensor             # uint8: pages | blob | 16 zero bytes
+    n_pages: int
+    page_bytes: int
+    blob_off: int
+    n_rec: int
+
+
 class Engine:
     """A gci_ctx bound to torch's current stream on `device`."""
 
@@ -165,6 +175,38 @@ class Engine:
         if check:
             self.check_status("gci_bam_filter")
         return out[:n]
+
+    # ---- R1 over record pages (include/gci_hip.h: gci_bam_pages_*, gci_bam_filter_pages) -------------------------------
+    def bam_pages(self, d_stream: torch.Tensor, d_rec_off: torch.Tensor, has_seq: bool, page_bytes: int = 0) -> "Pages":
+        """The records of an inflated BAM stream (has_seq) or of a heads stream laid out as record pages: the bytes read_sam
+        looks at, 16-byte aligned, no offset table -- what the record filter is fastest on."""
+        page_bytes = int(page_bytes or os.environ.get("GCI_PAGE_BYTES", 0) or _lib.PAGE_BYTES_DEFAULT)
+        n = int(d_rec_off.shape[0])
+        h = (ctypes.c_uint64 * 3)()
+        self._chk(self.lib.gci_bam_pages_size(self.ctx, self._p(d_stream), int(d_stream.shape[0]), self._p(d_rec_off), n, int(has_seq),
+                                              page_bytes, h), "gci_bam_pages_size")
+        buf = torch.empty(int(h[1]), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.gci_bam_pages_write(self.ctx, self._p(d_stream), int(d_stream.shape[0]), self._p(d_rec_off), n, int(has_seq),
+                                               self._p(buf), int(h[1])), "gci_bam_pages_write")
+        return Pages(buf, int(h[0]), page_bytes, int(h[2]), n)
+
+    def bam_filter_pages(self, pages: "Pages", d_ref_sel: torch.Tensor, map_qual: int, mq_cutoff: int, clip_percent: float,
+                         iden_percent: float, out: Optional[torch.Tensor] = None, name_off: Optional[torch.Tensor] = None,
+                         check: bool = True, rec_idx_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (records uint8 [n, 32], name offsets int64 [n] into pages.buf)."""
+        n = pages.n_rec
+        if out is None:
+            out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+        if name_off is None:
+            name_off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        st = self.lib.gci_bam_filter_pages(self.ctx, self._p(pages.buf), int(pages.buf.shape[0]), pages.page_bytes, pages.n_pages, n,
+                                           self._p(d_ref_sel), int(d_ref_sel.shape[0]), int(map_qual), int(mq_cutoff),
+                                           float(clip_percent), float(iden_percent), int(rec_idx_base), self._p(out),
+                                           self._p(name_off), self._p(self._status))
+        self._chk(st, "gci_bam_filter_pages")
+        if check:
+            self.check_status("gci_bam_filter_pages")
+        return out[:n], name_off[:n]
 
     def check_status(self, what: str) -> None:
         w = int(self._status.item()) & _M64

@@ -160,6 +160,39 @@ int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes,
                          uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
                          double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
                          uint64_t* d_status);
+/* ---- R1 over RECORD PAGES (round 3): the layout the record filter is fastest on --------------------------------
+ * read_sam (GCI.py:146-169) looks at ~400 of a HiFi record's 27 000 bytes.  gci_bam_pages_size / _write copy exactly
+ * those bytes -- once, on the device, as the last step of the ingestion that walks the inflated stream anyway -- into
+ * fixed-size pages in which every record and every CIGAR is 16-byte aligned and nothing needs an offset table:
+ *
+ *   buffer = [page 0] ... [page n_pages - 1] [blob] [16 zero bytes]
+ *   page   = u32 n_recs | u32 first_rec | u32 used_bytes | u32 magic "GCP1" | u16 dir[n_recs] (record start / 16) | records
+ *   record = the BAM record without SEQ / QUAL, its fixed 36 bytes kept except: block_size -> size of the record in the
+ *            page (a multiple of 16, <= GCI_PAGE_MAX_REC); bin -> kind; next_refID -> aux_len; next_pos, tlen -> blob
+ *            offset (u64, from the buffer start).  read_name at +36, zero padded so that the CIGAR starts at
+ *            align16(36 + l_read_name); the aux bytes right behind the CIGAR.
+ *            kind 1: the CIGAR words are in the blob (a record that does not fit: ONT), 16 bytes with the first
+ *            operation stand in for them; kind 2: core only, the record's bytes (heads form) are in the blob (CG:B,I
+ *            long-CIGAR records, kilobytes of tags); kind 4: a record the stream filter reports GCI_E_MALFORMED for.
+ *   Record i goes to page floor(S_i / (page_bytes - GCI_PAGE_MAX_REC - 48)), S = exclusive scan of (size + 2).
+ *
+ * gci_bam_pages_size: d_stream / d_rec_off as for gci_bam_filter (has_seq != 0) or gci_bam_filter_heads (has_seq == 0);
+ *   h_out[0] = n_pages, h_out[1] = bytes of the buffer to allocate, h_out[2] = offset of the blob.  Synchronises.
+ * gci_bam_pages_write: fills d_out (cap >= h_out[1]) for the input the size call measured.
+ * gci_bam_filter_pages: the filter over such a buffer -- same records, same status word as gci_bam_filter over the
+ *   stream the pages were made from; d_name_off (nullable, n_rec entries) receives where every record's query name lies
+ *   in the buffer (gci_join_file: d_name_base = d_pages, d_name_off, name_delta = 0). */
+#define GCI_PAGE_MAX_REC 1024
+#define GCI_PAGE_MAX_BYTES 32768
+#define GCI_PAGE_BYTES_DEFAULT 24576
+int gci_bam_pages_size(gci_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, const uint64_t* d_rec_off, uint32_t n_rec,
+                       int has_seq, uint32_t page_bytes, uint64_t* h_out);
+int gci_bam_pages_write(gci_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, const uint64_t* d_rec_off, uint32_t n_rec,
+                        int has_seq, uint8_t* d_out, uint64_t cap);
+int gci_bam_filter_pages(gci_ctx* ctx, const uint8_t* d_pages, uint64_t total_bytes, uint32_t page_bytes, uint32_t n_pages,
+                         uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
+                         double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
+                         uint64_t* d_name_off, uint64_t* d_status);
 int gci_decode_status(uint64_t status_word, uint32_t* rec_idx);   /* -> gci_status */
 /* The name hash K1 uses, for hosts that build gci_rec themselves (PAF path). */
 uint64_t gci_name_hash(const uint8_t* h_name, uint32_t len);

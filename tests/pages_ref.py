@@ -33,8 +33,8 @@ def _measure(stream, off, n_bytes, has_seq):
     full = a16(cig_at + 4 * n_cig + aux_len)
     if full <= MAX_REC:
         d.update(kind=0, size=full, blob=0)
-    elif a16(cig_at + aux_len) <= MAX_REC:
-        d.update(kind=F_EXT, size=a16(cig_at + aux_len), blob=a16(4 * n_cig))
+    elif a16(cig_at + 16 + aux_len) <= MAX_REC:
+        d.update(kind=F_EXT, size=a16(cig_at + 16 + aux_len), blob=a16(4 * n_cig))
     else:
         heads_len = 36 + lrn + 4 * n_cig + aux_len
         d.update(kind=F_OVERSIZE, size=48, blob=a16(heads_len))
@@ -87,6 +87,8 @@ def build_pages(stream, offsets, has_seq, page_bytes):
                     if r["kind"] == F_EXT:
                         q = blob_off + B[i]
                         buf[q:q + len(r["cigar"])] = r["cigar"]
+                        buf[c:c + 4] = r["cigar"][:4]          # the first operation stays visible in the page
+                        c += 16
                     else:
                         buf[c:c + len(r["cigar"])] = r["cigar"]
                         c += len(r["cigar"])

@@ -34,6 +34,10 @@ def _filter_case(engine, oracle, rs, targets=None, mq=30, cut=50, cp=0.1, ip=0.9
     via_heads = engine.bam_filter(engine.to_device(np.frombuffer(h_bytes, dtype=np.uint8)), engine.to_device(h_offs),
                                   engine.to_device(ref_sel), mq, cut, cp, ip, heads=True)
     assert torch.equal(via_heads, full)
+    # ... and as record pages (gci_bam_pages_*, gci_bam_filter_pages), made from either stream
+    _via_pages(engine, d_bam, d_off, True, ref_sel, mq, cut, cp, ip, full, stream)
+    h_np = np.frombuffer(h_bytes, dtype=np.uint8)
+    _via_pages(engine, engine.to_device(h_np), engine.to_device(h_offs), False, ref_sel, mq, cut, cp, ip, full, h_np, page_bytes=8192)
     p = want["passed"].astype(bool)
     assert np.array_equal((got["flags"] & 1).astype(bool), p)
     assert np.array_equal(((got["flags"] & 2) != 0), want["hq"].astype(bool))
@@ -44,6 +48,22 @@ def _filter_case(engine, oracle, rs, targets=None, mq=30, cut=50, cp=0.1, ip=0.9
     assert np.array_equal(got["name_hash"][p], name_hash_np(names))
     assert np.array_equal(got["rec_idx"], np.arange(len(rs)))
     return stream, offs, d_bam, d_off, got, p.sum()
+
+
+def _via_pages(engine, d_stream, d_off, has_seq, ref_sel, mq, cut, cp, ip, full, host_stream, page_bytes=0):
+    """The paged record filter over the pages made of this stream: the same 32 bytes per record, and name offsets that
+    point at the names inside the pages buffer."""
+    pages = engine.bam_pages(d_stream, d_off, has_seq, page_bytes)
+    recs, noff = engine.bam_filter_pages(pages, engine.to_device(ref_sel), mq, cut, cp, ip)
+    assert torch.equal(recs, full)
+    got = _recs_np(recs)
+    buf = pages.buf.cpu().numpy()
+    no = noff.cpu().numpy()
+    offs = d_off.cpu().numpy().view(np.uint64)
+    for i in np.flatnonzero(got["flags"] & 1)[::37]:
+        n = int(got["name_len"][i])
+        assert bytes(buf[int(no[i]):int(no[i]) + n]) == bytes(host_stream[int(offs[i]) + 36:int(offs[i]) + 36 + n])
+    return pages
 
 
 @pytest.mark.parametrize("kind,seed,cov", [("hifi", 11, 20), ("hifi", 12, 20), ("ont", 13, 15)])
@@ -640,6 +660,9 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
                     engine.bam_filter(d_heads, engine.to_device(h_offs[keep]), engine.to_device(ref_sel), 30, 50, cp, ip,
                                       heads=True)
                 assert (gh.value.status, gh.value.rec) == (e.status, e.rec)
+                with pytest.raises(GciErr) as gp:                       # ... and through record pages
+                    engine.bam_filter_pages(engine.bam_pages(d_bam, engine.to_device(o_sub), True), engine.to_device(ref_sel), 30, 50, cp, ip)
+                assert (gp.value.status, gp.value.rec) == (e.status, e.rec)
                 keep[np.flatnonzero(keep)[e.rec]] = False
                 n_checked += 1
         full = engine.bam_filter(d_bam, engine.to_device(o_sub), engine.to_device(ref_sel), 30, 50, cp, ip).clone()
@@ -647,6 +670,10 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
         via_heads = engine.bam_filter(d_heads, engine.to_device(h_offs[keep]), engine.to_device(ref_sel), 30, 50, cp, ip,
                                       heads=True)
         assert torch.equal(via_heads, full)                              # records without SEQ / QUAL: same 32 bytes out
+        h_np = np.frombuffer(h_bytes, dtype=np.uint8)
+        for pb in (8192, 16384, 32768):                                   # record pages of every size, from either stream
+            _via_pages(engine, d_bam, engine.to_device(o_sub), True, ref_sel, 30, 50, cp, ip, full, stream, page_bytes=pb)
+        _via_pages(engine, d_heads, engine.to_device(h_offs[keep]), False, ref_sel, 30, 50, cp, ip, full, h_np)
         p = want["passed"].astype(bool)
         assert np.array_equal((got["flags"] & 1).astype(bool), p)
         assert np.array_equal((got["flags"] & 2) != 0, want["hq"].astype(bool))
