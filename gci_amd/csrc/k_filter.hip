@@ -776,6 +776,7 @@ __global__ __launch_bounds__(BLOCK) void k_cigar_finish(const LongQueue lq, int 
 #define PG_KIND_OVERSIZE 2u
 #define PG_KIND_MALFORMED 4u
 #define PG_MAGIC 0x31504347u
+#define PG_REF_LDS 1024
 
 struct PagesArgs {
     const uint8_t* buf; uint64_t total_bytes; uint32_t page_bytes, n_pages, n_rec;
@@ -790,7 +791,10 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t page[];
     __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
-    const int t = threadIdx.x;
+    __shared__ int32_t s_ref_sel[PG_REF_LDS];                               // refID -> selected contig, when the table is small:
+    const int t = threadIdx.x;                                              // a gather from global memory in the middle of the
+    const bool ref_in_lds = A.n_ref <= PG_REF_LDS;                          // parse would be a second round trip per page
+    if (ref_in_lds) for (int i = t; i < A.n_ref; i += PGK) s_ref_sel[i] = A.ref_sel[i];
     if (blockIdx.x == 0 && t < 4) lq.next_counters[t] = 0u;                 // nobody reads that set during this call
     if (blockIdx.x == 0 && t == 4) *lq.next_status = ~0ull;
     const uint32_t P = A.page_bytes;
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 if (gl == 0) A.out[rec] = r;
                 return false;
             }
-            const int32_t contig = A.ref_sel[ref_id];
+            const int32_t contig = ref_in_lds ? s_ref_sel[ref_id] : A.ref_sel[ref_id];
             // fetch(contig=target) only ever yields records of selected contigs (GCI.py:151, 260)
             if (contig < 0) {
                 if (gl == 0) A.out[rec] = r;

