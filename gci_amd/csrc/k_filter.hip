@@ -97,6 +97,24 @@ __device__ __forceinline__ bool has_zero_byte(uint32_t x) { return ((x - 0x01010
 // The decision of GCI.py:163-168; fills r and returns a gci_status (GCI_OK also when filtered).  With M = bases under M, =
 // and X together, the op totals enter it only as S, den1 = M + I + S, den2 = M + I + D and rlen = M + D + N
 // (mm = NM - (I + D), GCI.py:164, appears as M - mm = den2 - NM).
+// (double)a / (double)b  <=  c  (le) or  >=  c  (!le), b != 0: the reference's IEEE f64 division and comparison (GCI.py:165),
+// bit for bit.  An f64 division is ~40 instructions a wave executes for all its lanes, and almost no record is anywhere near a
+// threshold: a single-precision quotient (relative error < 1e-6) decides whenever it is further than 1e-4 from the threshold --
+// rounding is monotonic, so the f64 quotient falls on the same side -- and only the records in between take the division.
+__device__ __forceinline__ bool ratio_cmp(int64_t a, int64_t b, double c, bool le)
+{
+    if (((a < 0 ? -a : a) | b) >> 30 == 0) {                     // both convert to f32 through the 32-bit path
+        const float x = (float)(int32_t)a * __builtin_amdgcn_rcpf((float)(int32_t)b);
+        const float cf = (float)c, m = 1e-4f * fmaxf(1.0f, fabsf(x));
+        if (c == c && fabs(c) < 1e30) {                          // (a NaN or absurd threshold: the exact comparison below)
+            if (x < cf - m) return le;
+            if (x > cf + m) return !le;
+        }
+    }
+    const double q = (double)a / (double)b;
+    return le ? q <= c : q >= c;
+}
+
 __device__ __forceinline__ int decide4(gci_rec& r, int64_t S, int64_t den1, int64_t den2, int64_t rlen, bool have_nm,
                                        bool nm_bad_type, int64_t NM, int32_t pos, int32_t contig, int32_t l_seq,
                                        uint32_t n_cigar_field, int mapq, int mq_cutoff, double clip_percent,
@@ -106,9 +124,9 @@ __device__ __forceinline__ int decide4(gci_rec& r, int64_t S, int64_t den1, int6
     if (nm_bad_type) return GCI_E_BAD_NM_TYPE;
     if (den1 == 0) return GCI_E_ZERO_DIV;
     // Python's `and` short-circuits: the identity division only runs when the clip test passed
-    if (!((double)S / (double)den1 <= clip_percent)) return GCI_OK;                // GCI.py:165
+    if (!ratio_cmp(S, den1, clip_percent, true)) return GCI_OK;                    // GCI.py:165
     if (den2 == 0) return GCI_E_ZERO_DIV;
-    if (!((double)(den2 - NM) / (double)den2 >= iden_percent)) return GCI_OK;
+    if (!ratio_cmp(den2 - NM, den2, iden_percent, false)) return GCI_OK;
     if (n_cigar_field == 0) return GCI_E_NO_END;
     r.contig = contig;
     r.start = pos;
@@ -846,7 +864,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             if (gl == 0 && A.name_off) A.name_off[rec] = (kind == PG_KIND_OVERSIZE ? blob_at : page_at + base) + 36u;
             const bool ext = kind == PG_KIND_EXT;
             const uint32_t cig_at = (36u + l_read_name + 15u) & ~15u;
-            const uint32_t aux_at = cig_at + (ext ? 16u : 4u * n_cigar);
+            const uint32_t aux_at = cig_at + (ext ? 16u : (4u * n_cigar + 15u) & ~15u);
             if ((kind & PG_KIND_MALFORMED) || (kind != PG_KIND_OVERSIZE && ((uint64_t)aux_at + aux_len > size || base + size > P))) {
                 if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); A.out[rec] = r; }
                 return false;
@@ -865,6 +883,27 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 if (blob_at + 36 > A.total_bytes) { if (gl == 0) { report(lq.status_in, rec, GCI_E_MALFORMED); A.out[rec] = r; } return false; }
                 slow_off = blob_at;
                 return true;
+            }
+            // ---- CIGAR base totals (get_cigar_stats()[0], GCI.py:157-162) as the four sums the decision uses (decide4):
+            // S, den1 = M + I + S, den2 = M + I + D, rlen = M + D + N (M, = and X together); which of them an op code feeds
+            // is one bit of a constant per sum.  The CIGAR is 16-byte aligned and zero padded to 16 bytes (0 = "0M": feeds
+            // nothing), so a lane takes whole ds_read_b128 pieces without a mask; lengths below 2^24 (checked on the way: `big`)
+            // go through v_mad_u32_u24 into 32-bit sums -- at most 64 operations per lane, no overflow.
+            uint32_t sS = 0, sQ = 0, sA = 0, sR = 0, big = 0;
+            auto add_op = [&](uint32_t v) {
+                const uint32_t op = v & 0xFu, len = v >> 4;
+                sS = __umul24(len, __builtin_amdgcn_ubfe(0x010u, op, 1)) + sS;
+                sQ = __umul24(len, __builtin_amdgcn_ubfe(0x193u, op, 1)) + sQ;
+                sA = __umul24(len, __builtin_amdgcn_ubfe(0x187u, op, 1)) + sA;
+                sR = __umul24(len, __builtin_amdgcn_ubfe(0x18Du, op, 1)) + sR;
+            };
+            if (!ext) {
+                const uint8_t* cg = hd + cig_at;
+                for (uint32_t p = gl; 4u * p < n_cigar; p += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(cg + 16u * p);
+                    big |= v.x | v.y | v.z | v.w;
+                    add_op(v.x); add_op(v.y); add_op(v.z); add_op(v.w);
+                }
             }
             // ---- aux walk (bam_aux_get semantics): first NM; first CG when the CIGAR is htslib's long-CIGAR placeholder
             const uint8_t* ax = hd + aux_at;
@@ -906,42 +945,14 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 }
                 q += 3 + sz;
             }
-            // htslib moves a long CIGAR back from CG:B,I when op0 == <l_seq>S
-            const uint8_t* cg_ops = nullptr;
-            uint32_t n_ops = n_cigar;
+            // htslib moves a long CIGAR back from CG:B,I when op0 == <l_seq>S (rare: the sums are redone over the tag's payload)
+            bool restored = false;
             if (cg_q != 0xFFFFFFFFu && ax[cg_q] == 'B' && (ax[cg_q + 1] == 'I' || ax[cg_q + 1] == 'i')) {
                 const uint32_t cg_len = lds_u32(ax + cg_q + 2);
-                if (cg_len >= n_cigar && cg_len < (1u << 29)) { cg_ops = ax + cg_q + 6; n_ops = cg_len; }
-            }
-            // ---- CIGAR base totals (get_cigar_stats()[0], GCI.py:157-162) as the four sums the decision uses (decide4):
-            // S, den1 = M + I + S, den2 = M + I + D, rlen = M + D + N (M, = and X together); which of them an op code
-            // feeds is one bit of a constant per sum
-            unsigned long long sS = 0, sQ = 0, sA = 0, sR = 0;
-            auto add_op = [&](uint32_t v, uint32_t& pS, uint32_t& pQ, uint32_t& pA, uint32_t& pR) {
-                const uint32_t op = v & 0xFu, len = v >> 4;
-                pS += len & (uint32_t)__builtin_amdgcn_sbfe(0x010, op, 1);
-                pQ += len & (uint32_t)__builtin_amdgcn_sbfe(0x193, op, 1);
-                pA += len & (uint32_t)__builtin_amdgcn_sbfe(0x187, op, 1);
-                pR += len & (uint32_t)__builtin_amdgcn_sbfe(0x18D, op, 1);
-            };
-            const bool queued = ext && !cg_ops;                        // its totals come from k_cigar_chunks
-            if (cg_ops) {
-                for (uint32_t k = gl; k < n_ops; k += 4) {
-                    uint32_t pS = 0, pQ = 0, pA = 0, pR = 0;
-                    add_op(lds_u32(cg_ops + 4 * k), pS, pQ, pA, pR);
-                    sS += pS; sQ += pQ; sA += pA; sR += pR;
-                }
-            } else if (!ext) {
-                const uint8_t* cg = hd + cig_at;
-                for (uint32_t p = gl; 4u * p < n_cigar; p += 4) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(cg + 16u * p);
-                    const uint32_t valid = n_cigar - 4u * p;           // >= 1; ops beyond the CIGAR are aux bytes or padding
-                    uint32_t pS = 0, pQ = 0, pA = 0, pR = 0;
-                    add_op(v.x, pS, pQ, pA, pR);
-                    if (valid > 1) add_op(v.y, pS, pQ, pA, pR);
-                    if (valid > 2) add_op(v.z, pS, pQ, pA, pR);
-                    if (valid > 3) add_op(v.w, pS, pQ, pA, pR);
-                    sS += pS; sQ += pQ; sA += pA; sR += pR;
+                if (cg_len >= n_cigar && cg_len < (1u << 29)) {
+                    restored = true;
+                    sS = sQ = sA = sR = 0; big = 0;
+                    for (uint32_t k = gl; k < cg_len; k += 4) { const uint32_t v = lds_u32(ax + cg_q + 6 + 4 * k); big |= v; add_op(v); }
                 }
             }
             // ---- query_name: bytes up to the first NUL, 64-bit hash of its 8-byte words -----------------------------------
@@ -969,23 +980,38 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             acc += (uint64_t)__shfl_xor((long long)acc, 2, 4);
             r.name_hash = gci_hash_finish(acc, name_len);
             r.name_len = (uint16_t)name_len;
-            if (queued) {                    // the parse is complete: only the CIGAR totals + decision are left to k_cigar_chunks / _finish
+            // an operation of 2^24 bases and more (its sums above would be wrong): the exact chunk path takes the CIGAR -- where
+            // it lies in the pages buffer, 16-byte aligned
+            big |= (uint32_t)__shfl_xor((int)big, 1, 4);
+            big |= (uint32_t)__shfl_xor((int)big, 2, 4);
+            const bool wide = (big >> 28) != 0 && !restored;
+            if ((ext && !restored) || wide) {   // the parse is complete: only the CIGAR totals + decision are left to k_cigar_chunks / _finish
                 LongItem it;
-                it.ops_off = blob_at; it.n_ops = n_cigar; it.rec = rec;
+                it.ops_off = ext ? blob_at : page_at + base + cig_at; it.n_ops = n_cigar; it.rec = rec;
                 it.nm = have_nm ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
                 it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
                 it.mapq = (uint32_t)mapq;
                 if (gl == 0) A.out[rec] = r;
-                const bool in_blob = blob_at + 4ull * n_cigar <= A.total_bytes;
-                if (!in_blob) { if (gl == 0) report(lq.status_in, rec, GCI_E_MALFORMED); return false; }
+                if (it.ops_off + 4ull * n_cigar > A.total_bytes) { if (gl == 0) report(lq.status_in, rec, GCI_E_MALFORMED); return false; }
                 if (!enqueue_long<4>(lq, it, gl) && gl == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
                 return false;
             }
+            unsigned long long tS = sS, tQ = sQ, tA = sA, tR = sR;
+            if ((big >> 28) != 0) {            // a CG:B,I payload with such an operation: exact sums, one operation at a time
+                tS = tQ = tA = tR = 0;
+                const uint32_t cg_len = lds_u32(ax + cg_q + 2);
+                for (uint32_t k = gl; k < cg_len; k += 4) {
+                    const uint32_t v = lds_u32(ax + cg_q + 6 + 4 * k), op = v & 0xFu;
+                    const unsigned long long len = v >> 4;
+                    tS += len & (0ull - ((0x010u >> op) & 1u)); tQ += len & (0ull - ((0x193u >> op) & 1u));
+                    tA += len & (0ull - ((0x187u >> op) & 1u)); tR += len & (0ull - ((0x18Du >> op) & 1u));
+                }
+            }
 #define PG_SUM(x) do { x += (unsigned long long)__shfl_xor((long long)x, 1, 4); x += (unsigned long long)__shfl_xor((long long)x, 2, 4); } while (0)
-            PG_SUM(sS); PG_SUM(sQ); PG_SUM(sA); PG_SUM(sR);
+            PG_SUM(tS); PG_SUM(tQ); PG_SUM(tA); PG_SUM(tR);
 #undef PG_SUM
             if (gl != 0) return false;
-            const int st = decide4(r, (int64_t)sS, (int64_t)sQ, (int64_t)sA, (int64_t)sR, have_nm, nm_bad, NM, pos, contig, l_seq,
+            const int st = decide4(r, (int64_t)tS, (int64_t)tQ, (int64_t)tA, (int64_t)tR, have_nm, nm_bad, NM, pos, contig, l_seq,
                                    n_cigar, mapq, A.mq_cutoff, A.clip_percent, A.iden_percent);
             if (st != GCI_OK) report(lq.status_in, rec, st);
             A.out[rec] = r;

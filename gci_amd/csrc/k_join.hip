@@ -515,6 +515,7 @@ __device__ __forceinline__ bool names_equal(const uint8_t* __restrict__ pa, cons
 struct PartJoinArgs {
     const PartEntry* in; const uint32_t* seg; const uint32_t* off2;
     uint32_t n_seg, n_bins2, slots, slot_shift;
+    uint32_t no_verify;          // GCI_JOIN_NOVERIFY=1 (timing experiments: what the name comparisons cost; results not exact)
 };
 
 // Slot of entry e (index i inside its bucket) in the bucket's LDS table.  CLAIM: take an empty slot for a name not seen yet.
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
         const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
         if (last[(size_t)slot * Fn + file] == ord) last[(size_t)slot * Fn + file] = PART_WIN | i;
-        if (!exact && ((uint32_t)(meta[slot] >> 1) & 0x7FFFFFu) != i) {
+        if (!exact && !A.no_verify && ((uint32_t)(meta[slot] >> 1) & 0x7FFFFFu) != i) {
             const unsigned long long cw = cname[slot];
             const uint32_t len = (uint32_t)(e.key >> 48) & 0xFFFu;
             const uint8_t* cn = F.f[(cw >> 48) & 15u].d_name_base + (((cw & 0xFFFFFFFFull) << 4) | ((cw >> 32) & 15ull));
@@ -912,6 +913,7 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
         ProfScope _ps(ctx, GCI_PROF_JOIN_PART);
         PartJoinArgs A;
         A.in = pb; A.seg = seg; A.off2 = hist2; A.n_seg = B1; A.n_bins2 = B2; A.slots = S; A.slot_shift = (uint32_t)slot_shift;
+        { const char* nv = getenv("GCI_JOIN_NOVERIFY"); A.no_verify = nv && nv[0] == '1' ? 1u : 0u; }
         const size_t lds = (size_t)S * (16 + 8 * (size_t)F.n) + (size_t)S * 2;     // + the list of used slots
         const dim3 grid(B1 * B2), block(JB);
         switch (F.n) {

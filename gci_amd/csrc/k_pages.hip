@@ -18,8 +18,8 @@
 //     +16 n_cigar_op, flag, l_seq        (as in BAM)
 //     +24 u32 aux_len                    (BAM: next_refID)
 //     +28 u64 blob offset, from the buffer start   (BAM: next_pos, tlen)
-//     +36 read_name, zero padded so that the CIGAR starts at align16(36 + l_read_name); aux bytes right behind the
-//         CIGAR; zero padded to 16.
+//     +36 read_name, zero padded so that the CIGAR starts at align16(36 + l_read_name); the CIGAR zero padded to 16
+//         bytes (a zero word is "0M": it adds nothing to any total); the aux bytes behind it; zero padded to 16.
 //   A record that does not fit 1024 bytes keeps its CIGAR words in the blob (kind 1: ONT reads, 10^3 - 10^5 operations,
 //   summed chunk by chunk by k_cigar_chunks anyway; 16 bytes with the first operation stand in for them); one that still does not fit (a CG:B,I tag, long Z tags) leaves its
 //   48-byte core in the page and its bytes -- the heads form: the record without SEQ / QUAL -- in the blob (kind 2).
@@ -66,8 +66,8 @@ __device__ __forceinline__ PgRec pg_measure(const uint8_t* __restrict__ bam, uin
     r.lrn = lrn; r.n_cig = n_cig; r.aux_off = aux_off;
     const uint64_t aux_len = rec_end - aux_off;
     const uint32_t cig_at = a16(36 + lrn);
-    if (aux_len <= PG_MAX_REC && a16(cig_at + 4 * n_cig + (uint32_t)aux_len) <= PG_MAX_REC) {
-        r.kind = 0; r.size = a16(cig_at + 4 * n_cig + (uint32_t)aux_len); r.aux_len = (uint32_t)aux_len;
+    if (aux_len <= PG_MAX_REC && 4ull * n_cig <= PG_MAX_REC && a16(cig_at + a16(4 * n_cig) + (uint32_t)aux_len) <= PG_MAX_REC) {
+        r.kind = 0; r.size = a16(cig_at + a16(4 * n_cig) + (uint32_t)aux_len); r.aux_len = (uint32_t)aux_len;
     } else if (aux_len <= PG_MAX_REC && a16(cig_at + 16 + (uint32_t)aux_len) <= PG_MAX_REC) {
         r.kind = PG_EXT; r.size = a16(cig_at + 16 + (uint32_t)aux_len); r.blob = a16(4 * n_cig); r.aux_len = (uint32_t)aux_len;
     } else {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
         if (r.kind == 0) {
             for (uint32_t d = gl; d < r.n_cig; d += PG_LANES)
                 *reinterpret_cast<uint32_t*>(dst + c + 4 * d) = pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, d);
-            c += 4 * r.n_cig;
+            c += a16(4 * r.n_cig);
         } else {                                                   // kind 1: the first operation stays visible in the page
             if (gl == 0) *reinterpret_cast<uint32_t*>(dst + c) = pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, 0);
             c += 16;

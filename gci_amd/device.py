@@ -320,6 +320,28 @@ class Engine:
         self._chk(self.lib.gci_hash_conflicts(self.ctx, self._p(buckets), int(n_parts), int(part_cap),
                                               self._p(n_conflicts)), "gci_hash_conflicts")
 
+    # ---- multi-GPU: buckets of the name-hash-sharded join (gci_route_*; the collectives are shard.ShardedJoin's) ----------
+    def route_records(self, f: JoinInput, n_parts: int, cap: int, out_recs: torch.Tensor, out_names: torch.Tensor,
+                      status: torch.Tensor) -> None:
+        """out_recs uint8 [n_parts * (cap + 1), 32], out_names uint8 [n_parts * cap * ROUTE_NAME], status int64 [1]."""
+        self._chk(self.lib.gci_route_records(self.ctx, self._join_files([f]), int(n_parts), int(cap), self._p(out_recs),
+                                             self._p(out_names), self._p(status)), "gci_route_records")
+
+    def route_seal_records(self, recs: torch.Tensor, n_parts: int, cap: int, status: torch.Tensor) -> None:
+        self._chk(self.lib.gci_route_seal_records(self.ctx, self._p(recs), int(n_parts), int(cap), self._p(status)),
+                  "gci_route_seal_records")
+
+    def route_intervals(self, ivl: torch.Tensor, count: torch.Tensor, owner: torch.Tensor, n_parts: int, cap: int,
+                        out: torch.Tensor, status: torch.Tensor) -> None:
+        """owner int32 [n_contigs]: rank of every contig; out int32 [n_parts * (cap + 1), 4]."""
+        self._chk(self.lib.gci_route_intervals(self.ctx, self._p(ivl), self._p(count), int(ivl.shape[0]), self._p(owner),
+                                               int(owner.shape[0]), int(n_parts), int(cap), self._p(out), self._p(status)),
+                  "gci_route_intervals")
+
+    def route_seal_intervals(self, ivl: torch.Tensor, n_parts: int, cap: int, cmap: torch.Tensor, status: torch.Tensor) -> None:
+        self._chk(self.lib.gci_route_seal_intervals(self.ctx, self._p(ivl), int(n_parts), int(cap), self._p(cmap),
+                                                    int(cmap.shape[0]), self._p(status)), "gci_route_seal_intervals")
+
     def pack_names(self, f: JoinInput) -> Tuple[torch.Tensor, torch.Tensor]:
         n = int(f.recs.shape[0])
         off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)

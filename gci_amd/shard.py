@@ -4,10 +4,12 @@ exchange step.
 * Depth build, gap mask, two-type max, issue scan, text and per-contig scoring are independent
   per contig -> each rank owns a set of contigs (longest-processing-time packing).
 * The read-name join is NOT contig-local (a read aligned to different contigs in two files must
-  be dropped, GCI.py:296-297; a repeated name keeps only its last record, GCI.py:269), so every
-  rank decodes a slice of each file's records (K1) and the 32-byte compact records plus the
-  name bytes are replicated with an RCCL all-gather; every rank then runs the full join and
-  keeps the intervals of the contigs it owns (`contig_map`).
+  be dropped, GCI.py:296-297; a repeated name keeps only its last record, GCI.py:269) but it is
+  independent per NAME: every rank filters the records of its contigs (K1), routes them by name hash
+  to the rank that owns the name (one RCCL all-to-all of 32-byte records and one of names per file),
+  joins the names it owns, and routes the surviving 16-byte intervals to the owners of their contigs
+  (`ShardedJoin`).  `RecordExchange` (all-gather, every rank joins everything) is the round-2 way, kept
+  for names too long for a routed slot.
 * Genome-wide totals (sum of depth, bases) are one integer all-reduce: exact in any order.
 
 Everything here is device-agnostic torch (`nccl` == RCCL on the GPUs, `gloo` in the CPU tests).
@@ -260,3 +262,106 @@ def gather_interval_lists(local: List[Tuple[int, int, int]], group=None) -> List
     out: List[Optional[list]] = [None] * dist.get_world_size(group)
     dist.all_gather_object(out, list(local), group=group)
     return sorted(x for part in out for x in part)
+
+
+class ShardedJoin:
+    """The name-hash-sharded join of a contig-sharded run (gci_route_* in include/gci_hip.h, k_shard.hip).
+
+    Per step, with F input files:  F x [route the rank's passing records by (name hash >> 33) % world -> all-to-all of the
+    record buckets -> all-to-all of the name slots -> seal]  ->  gci_name_join over what arrived (the names this rank owns,
+    from every contig)  ->  route the intervals by the owner of their contig -> all-to-all -> seal (global contig -> index in
+    this rank's track layout).  Bucket capacities are fixed at construction (1.3 x the even share + slack): the collectives
+    have one shape for every step and nothing is sized on the host per step; an overflow or a name longer than a routed
+    slot sets `status` (GCI_E_CAPACITY) and the caller grows the buckets (`grow()`) or takes the replicated join.
+
+    `ops` provides the device operations: route_records, route_seal_records, route_intervals, route_seal_intervals and
+    name_join (an `Engine`; the CPU tests pass numpy stand-ins)."""
+
+    ROUTE_NAME = 48
+
+    def __init__(self, ops, n_local: Sequence[int], owner: Sequence[int], device: torch.device, group=None,
+                 via_host: bool = False, slack: float = 1.3):
+        self.ops, self.group, self.via_host, self.device = ops, group, via_host, device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_files = len(n_local)
+        n = torch.tensor([int(x) for x in n_local], dtype=torch.int64, device="cpu" if via_host else device)
+        alln = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(alln, n, group=group)
+        per_file_max = [max(int(a[f].item()) for a in alln) for f in range(self.n_files)]
+        per_file_sum = [sum(int(a[f].item()) for a in alln) for f in range(self.n_files)]
+        self.owner_np = np.asarray(owner, dtype=np.int32)
+        cmap, self.mine = contig_map_for(owner, self.rank)
+        self.owner = torch.from_numpy(self.owner_np.copy()).to(device)
+        self.cmap = torch.from_numpy(cmap).to(device)
+        self._alloc([int(m * slack / self.world) + 1024 for m in per_file_max],
+                    int(max(per_file_sum + [1]) * slack * 1.25 / (self.world * self.world)) + 1024)
+
+    def _alloc(self, rec_caps: Sequence[int], ivl_cap: int) -> None:
+        dev, W = self.device, self.world
+        self.rec_cap = [int(c) for c in rec_caps]
+        self.ivl_cap = int(ivl_cap)
+        z = lambda *shape, dt=torch.uint8: torch.zeros(shape, dtype=dt, device=dev)            # noqa: E731
+        self.send_recs = [z(W * (c + 1), 32) for c in self.rec_cap]
+        self.recv_recs = [z(W * (c + 1), 32) for c in self.rec_cap]
+        self.send_names = [z(W * c * self.ROUTE_NAME) for c in self.rec_cap]
+        self.recv_names = [z(W * c * self.ROUTE_NAME) for c in self.rec_cap]
+        self.name_off = []
+        for c in self.rec_cap:
+            i = torch.arange(W * (c + 1), dtype=torch.int64, device=dev)
+            d, k = i // (c + 1), i % (c + 1) - 1
+            self.name_off.append(((d * c + k.clamp(min=0)) * self.ROUTE_NAME).contiguous())
+        total = sum(W * (c + 1) for c in self.rec_cap)
+        self.ivl = z(max(total, 1), 4, dt=torch.int32)                      # what the local join emits (global contig indices)
+        self.count = z(1, dt=torch.int32)
+        self.send_ivl = z(W * (self.ivl_cap + 1), 4, dt=torch.int32)
+        self.recv_ivl = z(W * (self.ivl_cap + 1), 4, dt=torch.int32)
+        self.status = torch.full((2 * self.n_files + 3,), -1, dtype=torch.int64, device=dev)   # route / seal per file, join, route, seal
+
+    def grow(self, factor: float = 2.0) -> None:
+        self._alloc([int(c * factor) for c in self.rec_cap], int(self.ivl_cap * factor))
+
+    def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        if not self.via_host:
+            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+            return
+        h = send.reshape(-1).cpu()
+        r = torch.empty_like(h)
+        dist.all_to_all_single(r, h, group=self.group)
+        recv.view(-1).copy_(r)
+
+    def exchange_file(self, f: int, ji) -> "object":
+        """One file's records of this rank -> the records (of every rank) whose names this rank owns, as a join input."""
+        from .device import JoinInput
+        cap, W = self.rec_cap[f], self.world
+        self.ops.route_records(ji, W, cap, self.send_recs[f], self.send_names[f], self.status[2 * f:2 * f + 1])
+        self._all_to_all(self.recv_recs[f], self.send_recs[f])
+        self._all_to_all(self.recv_names[f], self.send_names[f])
+        self.ops.route_seal_records(self.recv_recs[f], W, cap, self.status[2 * f + 1:2 * f + 2])
+        return JoinInput(self.recv_recs[f], self.recv_names[f], self.name_off[f], 0)
+
+    def join(self, inputs: Sequence["object"], ovlp_percent: float) -> Tuple[torch.Tensor, int]:
+        """inputs: what exchange_file returned for every file, in the reference's file order (a PAF input whose records already
+        sit on the rank that owns their name is passed as it is).  -> (intervals int32 [W * (cap + 1), 4] on the contigs of THIS
+        rank, contig = index in its track layout or -1 for an empty slot; their number of slots)."""
+        F, W = self.n_files, self.world
+        self.ops.name_join(inputs, ovlp_percent, None, self.ivl, self.count, False, None, status=self.status[2 * F:2 * F + 1])
+        self.ops.route_intervals(self.ivl, self.count, self.owner, W, self.ivl_cap, self.send_ivl, self.status[2 * F + 1:2 * F + 2])
+        self._all_to_all(self.recv_ivl, self.send_ivl)
+        self.ops.route_seal_intervals(self.recv_ivl, W, self.ivl_cap, self.cmap, self.status[2 * F + 2:2 * F + 3])
+        return self.recv_ivl, int(self.recv_ivl.shape[0])
+
+    def bytes_per_step(self) -> int:
+        """What this rank sends to the OTHER ranks per step (fixed bucket shapes)."""
+        W = self.world
+        per = sum((c + 1) * 32 + c * self.ROUTE_NAME for c in self.rec_cap) + (self.ivl_cap + 1) * 16
+        return per * (W - 1)
+
+    def check(self, decode) -> None:
+        """Raises through `decode(word, what)` for the first status word that reports something (read after a sync)."""
+        what = []
+        for f in range(self.n_files):
+            what += ["gci_route_records[%d]" % f, "gci_route_seal_records[%d]" % f]
+        what += ["gci_name_join", "gci_route_intervals", "gci_route_seal_intervals"]
+        for w, name in zip(self.status.cpu().numpy().view(np.uint64).tolist(), what):
+            decode(w, name)

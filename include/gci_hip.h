@@ -170,7 +170,7 @@ int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes,
  *   record = the BAM record without SEQ / QUAL, its fixed 36 bytes kept except: block_size -> size of the record in the
  *            page (a multiple of 16, <= GCI_PAGE_MAX_REC); bin -> kind; next_refID -> aux_len; next_pos, tlen -> blob
  *            offset (u64, from the buffer start).  read_name at +36, zero padded so that the CIGAR starts at
- *            align16(36 + l_read_name); the aux bytes right behind the CIGAR.
+ *            align16(36 + l_read_name); the CIGAR zero padded to 16 bytes; the aux bytes behind it.
  *            kind 1: the CIGAR words are in the blob (a record that does not fit: ONT), 16 bytes with the first
  *            operation stand in for them; kind 2: core only, the record's bytes (heads form) are in the blob (CG:B,I
  *            long-CIGAR records, kilobytes of tags); kind 4: a record the stream filter reports GCI_E_MALFORMED for.
@@ -239,6 +239,32 @@ int gci_hash_bucket(gci_ctx* ctx, const gci_rec* d_recs, uint32_t n, uint32_t n_
                     uint64_t* d_out, uint64_t* d_next_out);
 int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint32_t n_parts, uint32_t part_cap,
                        uint32_t* d_n_conflicts);
+
+/* ---- multi-GPU: the name-hash-sharded join ---------------------------------------------------------
+ * Contigs are sharded over the ranks, the join (GCI.py:272-301) is by read name and independent per name: every passing
+ * record goes to rank (name_hash >> 33) % n_parts, each rank joins the names it owns (gci_name_join over what arrived),
+ * the surviving intervals go to the rank that owns their contig.  These calls fill / finish the fixed-shape buckets of the
+ * three all-to-alls (the host side does the collectives: RCCL through torch.distributed, gci_amd/shard.py):
+ *   gci_route_records   one file's records -> n_parts buckets of (cap + 1) gci_rec slots (slot 0: header, name_hash = number
+ *                       of records routed to the part, flags = 0; then the records in FILE ORDER -- the routing is stable)
+ *                       and n_parts * cap name slots of GCI_ROUTE_NAME bytes (zero padded)
+ *   gci_route_seal_records   on the receiving side: slots beyond a bucket's count get flags = 0, so the whole receive buffer
+ *                       is one gci_rec array in file order (source rank after source rank) for gci_name_join; the name of
+ *                       slot d * (cap + 1) + 1 + k is at (d * cap + k) * GCI_ROUTE_NAME of the received names
+ *   gci_route_intervals intervals (contig = index among ALL selected contigs) -> buckets by d_owner[contig] (< 0: dropped);
+ *                       slot 0 of a bucket = {contig = -1, start = count}
+ *   gci_route_seal_intervals  receiving side: contig -> d_cmap[contig] (the rank's track layout), -1 beyond the count: the
+ *                       buffer of n_parts * (cap + 1) intervals goes to gci_depth_build_* as it is
+ * A count beyond cap or a name longer than GCI_ROUTE_NAME sets *d_status to GCI_E_CAPACITY (grow the buckets / take the
+ * replicated join). */
+#define GCI_ROUTE_NAME 48
+int gci_route_records(gci_ctx* ctx, const gci_join_file* h_file, uint32_t n_parts, uint32_t cap, gci_rec* d_out_recs,
+                      uint8_t* d_out_names, uint64_t* d_status);
+int gci_route_seal_records(gci_ctx* ctx, gci_rec* d_recs, uint32_t n_parts, uint32_t cap, uint64_t* d_status);
+int gci_route_intervals(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, const int32_t* d_owner,
+                        int32_t n_contigs, uint32_t n_parts, uint32_t cap, gci_ivl* d_out, uint64_t* d_status);
+int gci_route_seal_intervals(gci_ctx* ctx, gci_ivl* d_ivl, uint32_t n_parts, uint32_t cap, const int32_t* d_cmap,
+                             int32_t n_contigs, uint64_t* d_status);
 
 /* ---- R6: depth build ------------------------------------------------------------------------
  * depth[c][start+flank : end-flank+1] += 1 with Python/NumPy slice semantics, for n intervals

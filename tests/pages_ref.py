@@ -30,7 +30,7 @@ def _measure(stream, off, n_bytes, has_seq):
     d = dict(core=core, lrn=lrn, n_cig=n_cig, aux_len=aux_len, name=bytes(stream[name0:name0 + lrn]),
              cigar=bytes(stream[cig0:cig0 + 4 * n_cig]), aux=bytes(stream[aux_off:rec_end]), short=False)
     cig_at = a16(36 + lrn)
-    full = a16(cig_at + 4 * n_cig + aux_len)
+    full = a16(cig_at + a16(4 * n_cig) + aux_len)
     if full <= MAX_REC:
         d.update(kind=0, size=full, blob=0)
     elif a16(cig_at + 16 + aux_len) <= MAX_REC:
@@ -91,7 +91,7 @@ def build_pages(stream, offsets, has_seq, page_bytes):
                         c += 16
                     else:
                         buf[c:c + len(r["cigar"])] = r["cigar"]
-                        c += len(r["cigar"])
+                        c += a16(len(r["cigar"]))
                     buf[c:c + r["aux_len"]] = r["aux"]
             at += r["size"]
         struct.pack_into("<IIII", buf, base, len(idx), (idx[0] if idx else 0) & 0xFFFFFFFF, at if idx else 16, MAGIC)
