@@ -69,6 +69,11 @@ def parse_args():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend: nccl = RCCL over xGMI (one GPU per rank); gloo stages the collectives through "
                          "host memory and lets several ranks share one GPU (GCI_DIST_DEVICE): correctness runs only")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1, genome workload.  strong (default): the SAME CHM13 workload as N = 1, its contigs dealt to the ranks "
+                         "(longest first onto the least loaded), every rank filters the records of its contigs, the join is sharded by "
+                         "name hash (two all-to-alls per file + one of intervals) -- the split that replaces the reference's "
+                         "Pool(threads).map(read_sam) (GCI.py:257-270).  weak: every rank one CHM13-sized haplotype of its own")
     ap.add_argument("--shared-names", type=float, default=0.0,
                     help="N > 1, genome workload: this fraction of every rank's second file carries read names of the NEXT rank "
                          "(a read aligned to contigs of two ranks): the name check then finds conflicts and every step takes "
@@ -105,7 +110,8 @@ def all_reduce(t, op):
 class Workload:
     """Per-rank resident inputs + preallocated outputs for one step over F input files."""
 
-    def __init__(self, eng, rank, world, contigs, files, heads, exchange=False, replicated=False, name="", algo=None, k1="pages"):
+    def __init__(self, eng, rank, world, contigs, files, heads, exchange=False, replicated=False, name="", algo=None, k1="pages",
+                 sharded=False):
         """contigs: the (name, length) table of the WHOLE run (all ranks); `files`: this rank's slice of every input
         file as (stream uint8, offsets uint64, name_bytes) host arrays whose BAM header lists `contigs`;
         the rank owns the contigs `own` = indices into `contigs` (set by the caller through self.own before layout)."""
@@ -114,7 +120,8 @@ class Workload:
         self.eng, self.rank, self.world = eng, rank, world
         self.contigs, self.heads, self.name = contigs, heads, name
         self.algo = algo or {}
-        self.exchange = exchange or world > 1
+        self.sharded = bool(sharded)                     # strong scaling: the join sharded by name hash (shard.ShardedJoin)
+        self.exchange = (exchange or world > 1) and not self.sharded
         self.force_replicated = replicated
         self.replicated_steps = 0
         dev = eng.device
@@ -150,7 +157,7 @@ class Workload:
         cmap = np.full(n_all, -1, dtype=np.int32)
         cmap[self.own] = np.arange(nc, dtype=np.int32)
         # the join maps global contig -> local track index; entries < 0 drop the interval (contigs of other ranks)
-        self.contig_map = eng.to_device(cmap) if (self.exchange or nc != n_all) else None
+        self.contig_map = eng.to_device(cmap) if (self.exchange or nc != n_all) and not self.sharded else None
         self.recs = [torch.empty((max(n, 1), 32), dtype=torch.uint8, device=dev) for n in self.n_rec]
         self.rec_base = [0] * self.n_files
         self.track = eng.new_track()
@@ -163,6 +170,7 @@ class Workload:
         self.totals = torch.zeros(nc + 2, dtype=torch.int64, device=dev)
         self.sums = self.totals[0:nc]
         self.totals[nc] = int(sum(self.own_lengths))
+        self.sum_total = torch.zeros(1, dtype=torch.int64, device=dev)    # sharded mode: this rank's sum of depth -> all-reduced
         self.status = torch.zeros(self.n_files + 1, dtype=torch.int64, device=dev)
         self.text = None
         from gci_amd._lib import BuildOpts
@@ -174,6 +182,10 @@ class Workload:
         self.opts = o
         if self.exchange:
             self._setup_exchange()
+        if self.sharded:
+            from gci_amd import shard
+            self.opts.counted = 0                        # the intervals of the build arrive through an all-to-all, uncounted
+            self.sj = shard.ShardedJoin(eng, self.n_rec, self.owner_of_contig, eng.device, via_host=VIA_HOST)
         return self
 
     # ---- multi-GPU: exact name check every step; the replicated join only when a name is shared -------------------
@@ -208,6 +220,8 @@ class Workload:
             chk(k1(ctx, _p(self.d_bam[f]), self.stream_bytes[f], _p(self.d_off[f]), self.n_rec[f], _p(self.ref_sel),
                    len(self.contigs), FILTER[0], FILTER[1], FILTER[2], FILTER[3], self.rec_base[f], _p(self.recs[f]),
                    _p(self.status[f:f + 1])), "gci_bam_filter")
+        if self.sharded:
+            return self._step_sharded()
         jf = (JoinFile * F)()
         if self.exchange and self.force_replicated:
             # a name occurs on two ranks: replicate records + names and join everything everywhere
@@ -254,6 +268,25 @@ class Workload:
             # ONE integer all-reduce per step, in place: the sums of depth (global mean depth = their total / bases)
             all_reduce(self.sums, dist.ReduceOp.SUM)
 
+    def _step_sharded(self):
+        """Strong scaling: records of this rank's contigs -> by name hash to the rank that owns the name (two all-to-alls per
+        file) -> join of the names owned here -> intervals to the owners of their contigs (one all-to-all) -> build."""
+        import torch.distributed as dist
+        from gci_amd.device import JoinInput
+        eng, lib, ctx, chk, sj = self.eng, self.eng.lib, self.eng.ctx, self.eng._chk, self.sj
+        inputs = [sj.exchange_file(f, JoinInput(self.recs[f][:self.n_rec[f]], self.d_bam[f], self.d_off[f], self.name_delta))
+                  for f in range(self.n_files)]
+        ivl, n_slots = sj.join(inputs, OVLP)
+        self.ivl_in_build, self.count_in_build = ivl, None
+        o = self.opts
+        chk(lib.gci_depth_build_begin(ctx, _p(ivl), None, n_slots, ctypes.byref(o)), "gci_depth_build_begin")
+        if self.text is None:                              # first (warm-up) call sizes the text buffer
+            total = int(self.text_off[len(self.own)].item())
+            self.text = self.torch.empty(total + (total >> 4) + 4096, dtype=self.torch.uint8, device=eng.device)
+        chk(lib.gci_depth_build_finish(ctx, _p(self.track), _p(self.text), int(self.text.shape[0])), "gci_depth_build_finish")
+        self.torch.sum(self.sums, dim=0, keepdim=True, out=self.sum_total)
+        all_reduce(self.sum_total, dist.ReduceOp.SUM)      # the genome-wide sum of depth: ONE integer all-reduce per step
+
     def check(self):
         """Record-level status of the last step + output capacities; False when a name is shared between ranks."""
         from gci_amd._lib import GciError
@@ -263,6 +296,16 @@ class Workload:
             st = self.eng.lib.gci_decode_status(w, ctypes.byref(rec))
             if st != 0:
                 raise GciError(st, "%s failed on record %d" % (name, rec.value))
+        if self.sharded:
+            def decode(w, name):
+                rec = ctypes.c_uint32(0)
+                st = self.eng.lib.gci_decode_status(w, ctypes.byref(rec))
+                if st != 0:
+                    raise GciError(st, "%s: status %d (record %d) on rank %d" % (name, st, rec.value, self.rank))
+            self.sj.check(decode)
+            if int(self.nkeys.item()) > self.keys.shape[0]:
+                raise GciError(-8, "bench output buffers too small")
+            return True
         if int(self.nkeys.item()) > self.keys.shape[0] or int(self.count.item()) > self.ivl.shape[0]:
             raise GciError(-8, "bench output buffers too small")
         if self.exchange and not self.force_replicated:
@@ -294,7 +337,36 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
     inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0), kind=args.reads,
                                 procs=max(1, workloads_default_procs() // max(1, world)))
     nper = len(inp.contigs)
-    if world > 1:
+    owner = None
+    if world > 1 and args.scaling == "strong":
+        # the same genome as N = 1: contigs dealt to the ranks, every rank keeps the records of ITS contigs (what its
+        # index-driven ingestion would read of each file: pipeline.bam_records_of_contigs)
+        from gci_amd import shard
+        from gci_amd.formats import bam as bamfmt
+        owner = shard.lpt_assign(inp.lengths, world)
+        own = [c for c, o in enumerate(owner) if o == rank]
+        mine = np.zeros(nper, dtype=bool)
+        mine[own] = True
+        for fobj in inp.files:
+            first = bamfmt.parse_header(fobj.stream).first_record
+            offs = fobj.offsets.astype(np.int64)
+            ends = np.concatenate([offs[1:], [fobj.stream.shape[0]]])
+            ref = fobj.stream[(offs[:, None] + np.arange(4, 8)[None, :])].copy().view("<i4").reshape(-1)
+            keep = (ref >= 0) & mine[np.clip(ref, 0, nper - 1)]
+            # records are sorted by contig: the kept ones are a few contiguous runs
+            edges = np.flatnonzero(np.diff(np.concatenate([[0], keep.astype(np.int8), [0]])))
+            parts, new_offs, size = [fobj.stream[:first]], [], first
+            for a, b in zip(edges[0::2], edges[1::2]):
+                lo, hi = int(offs[a]), int(ends[b - 1])
+                parts.append(fobj.stream[lo:hi])
+                new_offs.append(offs[a:b] - lo + size)
+                size += hi - lo
+            fobj.aligned_bases = int(fobj.aligned_per_contig[own].sum())
+            fobj.k1_bytes = int(fobj.k1_bytes * (keep.sum() / max(1, keep.shape[0])))      # (share of the records: an estimate)
+            fobj.stream = np.concatenate(parts)
+            fobj.offsets = (np.concatenate(new_offs) if new_offs else np.zeros(0, np.int64)).astype(np.uint64)
+        contigs = inp.contigs
+    elif world > 1:
         # one header for the whole run: rank r's contigs are entries [r * nper, (r + 1) * nper); shift the refIDs
         from gci_amd.formats import bam as bamfmt
         all_contigs = tuple(("h%d_%s" % (r, n), l) for r in range(world) for n, l in inp.contigs)
@@ -321,14 +393,21 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
         own = list(range(rank * nper, (rank + 1) * nper))
     else:
         contigs, own = inp.contigs, list(range(nper))
+    full = None
+    if owner is not None and args.verify_oracle and rank == 0:
+        full = workloads.genome_dual(args.scale, args.coverage, contigs=base, kind=args.reads,
+                                     procs=max(1, workloads_default_procs() // max(1, world)))     # the undivided files, for the oracle
     eng = eng_factory()
     files = [(f.stream, f.offsets, f.name_bytes) for f in inp.files]
     w = Workload(eng, rank, world, contigs, files, heads=True, exchange=exchange, replicated=replicated,
                  name="CHM13 whole genome (%d contigs, %d bp)%s, HiFi %gx by two aligners (2 BAM files as heads streams, "
                       "-op join), filter x2 -> join -> depth -> issue scan -> depth text" % (
-                          nper, sum(l for _, l in inp.contigs), " x %d haplotypes" % world if world > 1 else "", args.coverage)
+                          nper, sum(l for _, l in inp.contigs),
+                          (" x %d haplotypes" % world if owner is None else " over %d GPUs" % world) if world > 1 else "", args.coverage)
                       + ("" if args.reads == "hifi" else " [ONT reads]"),
-                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)}, k1=args.k1)
+                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)}, k1=args.k1, sharded=owner is not None)
+    w.owner_of_contig = owner
+    w.full_input = full
     w.aligned_bases = inp.aligned_bases
     w.inp = inp if ((rank == 0 and world == 1) or args.verify_oracle) else None
     if w.inp is None:
@@ -560,6 +639,33 @@ def verify_against_oracle_multi_rank(w, args):
             t, L = w.contigs[c]
             want = O.depth_build({q: s for q, s in file1.items() if s[0] == t}, {t: L}, FLANK)[t]
             ok = ok and np.array_equal(got, want)
+    return bool(ok)
+
+
+def verify_strong_against_oracle(w):
+    """--verify-oracle with --scaling strong (N > 1, small --scale): the oracle over the UNDIVIDED files (rank 0 generated them
+    a second time) against every contig of every rank's track, and the all-reduced sum of depth against the oracle's total."""
+    import torch.distributed as dist
+    mine = {w.own[c]: _track_contig(w, c) for c in range(len(w.own))}
+    parts = [None] * w.world
+    dist.all_gather_object(parts, mine)
+    if w.rank != 0:
+        return None
+    from oracle import gci_oracle as O
+    O.build()
+    inp = w.full_input
+    names = inp.names
+    dicts, hq = [], set()
+    for f in inp.files:
+        d, h = O.bam_file_dict(f.stream, f.offsets, names, names, *FILTER, heads=True)
+        dicts.append(d)
+        hq |= h
+    want = O.depth_build(O.name_join(dicts, hq, OVLP), dict(inp.contigs), FLANK)
+    ok = len(set(c for p in parts for c in p)) == len(names)
+    for p in parts:
+        for c, got in p.items():
+            ok = ok and np.array_equal(got, want[names[c]])
+    ok = ok and int(w.sum_total.item()) == int(sum(int(v.sum()) for v in want.values()))
     return bool(ok)
 
 
@@ -821,7 +927,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if w.sharded else "weak",
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
@@ -832,7 +938,9 @@ def main():
                                 + ("heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream") + (")" if w.pages else ""),
                    "input_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "steps_in_flight": len(lanes),
-                   "join": ("local" if not w.exchange else
+                   "join": ("sharded by name hash: per file one all-to-all of 32-byte records and one of 48-byte name slots, then one of "
+                            "16-byte intervals to the owners of their contigs; %d bytes leave this rank per step" % w.sj.bytes_per_step()
+                            if w.sharded else "local" if not w.exchange else
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
         "roofline": {"bound": "hbm", "kernel": "k_tile_build (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -844,7 +952,7 @@ def main():
     }
 
     if world > 1 and args.verify_oracle and args.workload == "genome":
-        ok = verify_against_oracle_multi_rank(w, args)
+        ok = verify_strong_against_oracle(w) if w.sharded else verify_against_oracle_multi_rank(w, args)
         if rank == 0:
             out["parity_vs_oracle_all_ranks"] = ok
             if not ok:

@@ -18,7 +18,6 @@ GCI_E_BAD_NM_TYPE, GCI_E_NO_END, GCI_E_MALFORMED, GCI_E_CAPACITY, GCI_E_NOMEM, G
 GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
 PAGE_MAX_REC, PAGE_MAX_BYTES, PAGE_BYTES_DEFAULT = 1024, 32768, 24576
-ROUTE_NAME = 48
 REC_PASS, REC_HQ = 1, 2
 PROF_COUNT = 17
 PROF_DEPTH_SCAN = 5          # k_tile_build: the pass that writes the depth track (+ text)
@@ -87,7 +86,7 @@ EXPORTS = [
                                         c_void_p, c_uint64]),
     ("gci_hash_bucket", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_void_p]),
     ("gci_hash_conflicts", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
-    ("gci_route_records", c_int, [c_void_p, POINTER(JoinFile), c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]),
+    ("gci_route_records", c_int, [c_void_p, POINTER(JoinFile), c_uint32, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p]),
     ("gci_route_seal_records", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]),
     ("gci_route_intervals", c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int32, c_uint32, c_uint32, c_void_p, c_void_p]),
     ("gci_route_seal_intervals", c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p, c_int32, c_void_p]),

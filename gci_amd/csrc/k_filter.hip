@@ -774,8 +774,9 @@ __global__ __launch_bounds__(BLOCK) void k_cigar_finish(const LongQueue lq, int 
         }
         gci_rec r = out[x.rec];
         const int st = decide(r, t[0], t[1], t[2], t[3], t[4], x.nm != INT64_MAX, x.nm == INT64_MIN, x.nm, x.pos, x.contig,
-                              x.l_seq, (uint32_t)x.n_cigar_field, (int)x.mapq, mq_cutoff, clip_percent, iden_percent);
+                              x.l_seq, (uint32_t)x.n_cigar_field, (int)(x.mapq & 0xFFu), mq_cutoff, clip_percent, iden_percent);
         if (st != GCI_OK) report(status, x.rec, st);
+        if (r.flags) r.flags |= (uint8_t)(x.mapq >> 8);                 // (GCI_REC_NAME16 of a record queued by the paged filter)
         out[x.rec] = r;
     }
 }
@@ -897,6 +898,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 sA = __umul24(len, __builtin_amdgcn_ubfe(0x187u, op, 1)) + sA;
                 sR = __umul24(len, __builtin_amdgcn_ubfe(0x18Du, op, 1)) + sR;
             };
+#ifndef PGX_NO_CIGAR
             if (!ext) {
                 const uint8_t* cg = hd + cig_at;
                 for (uint32_t p = gl; 4u * p < n_cigar; p += 4) {
@@ -905,6 +907,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                     add_op(v.x); add_op(v.y); add_op(v.z); add_op(v.w);
                 }
             }
+#endif
             // ---- aux walk (bam_aux_get semantics): first NM; first CG when the CIGAR is htslib's long-CIGAR placeholder
             const uint8_t* ax = hd + aux_at;
             const uint32_t op0 = lds_u32(hd + cig_at);
@@ -912,6 +915,9 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             bool have_nm = false, nm_bad = false;
             int64_t NM = 0;
             uint32_t cg_q = 0xFFFFFFFFu;
+#ifdef PGX_NO_AUX
+            have_nm = true; NM = (int64_t)(lds_u32(ax) & 0xFF);
+#else
             for (uint32_t q = 0; q + 3 <= aux_len;) {
                 const uint32_t w = lds_u32(ax + q);                                // tag[2] | type | first value byte
                 const uint32_t tag = w & 0xFFFFu;
@@ -945,6 +951,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 }
                 q += 3 + sz;
             }
+#endif
             // htslib moves a long CIGAR back from CG:B,I when op0 == <l_seq>S (rare: the sums are redone over the tag's payload)
             bool restored = false;
             if (cg_q != 0xFFFFFFFFu && ax[cg_q] == 'B' && (ax[cg_q + 1] == 'I' || ax[cg_q + 1] == 'i')) {
@@ -958,6 +965,11 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             // ---- query_name: bytes up to the first NUL, 64-bit hash of its 8-byte words -----------------------------------
             const uint8_t* name = hd + 36;
             uint32_t nul = l_read_name;
+#ifdef PGX_NO_HASH
+            const uint32_t name_len = l_read_name - 1;
+            r.name_hash = lds_u32(name) + ((uint64_t)lds_u32(name + 8) << 32);
+            (void)nul;
+#else
             for (uint32_t i = gl * 4; i < l_read_name; i += 16) {
                 if (has_zero_byte(lds_u32(name + i))) {
                     for (uint32_t b = i; b < i + 4 && b < l_read_name; b++) if (name[b] == 0) { nul = min(nul, b); break; }
@@ -979,7 +991,10 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             acc += (uint64_t)__shfl_xor((long long)acc, 1, 4);
             acc += (uint64_t)__shfl_xor((long long)acc, 2, 4);
             r.name_hash = gci_hash_finish(acc, name_len);
+#endif
             r.name_len = (uint16_t)name_len;
+            // in a page: at 16 k + 4, NUL and zero padding up to the CIGAR's 16-byte boundary
+            const uint8_t name16 = name_len + 1u == l_read_name ? GCI_REC_NAME16 : 0;
             // an operation of 2^24 bases and more (its sums above would be wrong): the exact chunk path takes the CIGAR -- where
             // it lies in the pages buffer, 16-byte aligned
             big |= (uint32_t)__shfl_xor((int)big, 1, 4);
@@ -990,7 +1005,8 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 it.ops_off = ext ? blob_at : page_at + base + cig_at; it.n_ops = n_cigar; it.rec = rec;
                 it.nm = have_nm ? (nm_bad ? INT64_MIN : NM) : INT64_MAX;
                 it.pos = pos; it.contig = contig; it.l_seq = l_seq; it.n_cigar_field = (int32_t)n_cigar;
-                it.mapq = (uint32_t)mapq;
+                it.mapq = (uint32_t)mapq | ((uint32_t)name16 << 8);
+                r.flags = 0;
                 if (gl == 0) A.out[rec] = r;
                 if (it.ops_off + 4ull * n_cigar > A.total_bytes) { if (gl == 0) report(lq.status_in, rec, GCI_E_MALFORMED); return false; }
                 if (!enqueue_long<4>(lq, it, gl) && gl == 0) report(lq.status_in, rec, GCI_E_CAPACITY);
@@ -1011,9 +1027,14 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             PG_SUM(tS); PG_SUM(tQ); PG_SUM(tA); PG_SUM(tR);
 #undef PG_SUM
             if (gl != 0) return false;
+#ifdef PGX_NO_DECIDE
+            r.start = pos; r.end = pos + (int32_t)tR; r.qlen = (int32_t)(tS + tQ + tA + NM); r.contig = contig; r.flags = have_nm && !nm_bad ? 1 : 0;
+#else
             const int st = decide4(r, (int64_t)tS, (int64_t)tQ, (int64_t)tA, (int64_t)tR, have_nm, nm_bad, NM, pos, contig, l_seq,
                                    n_cigar, mapq, A.mq_cutoff, A.clip_percent, A.iden_percent);
             if (st != GCI_OK) report(lq.status_in, rec, st);
+#endif
+            if (r.flags) r.flags |= name16;
             A.out[rec] = r;
             return false;
         };

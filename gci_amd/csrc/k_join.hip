@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) void k_join_fold(JoinFiles F, unsigned long 
 // chosen by size (gci_join_mode / GCI_JOIN=classic|partition override).
 //
 //   entry (32 B): key = hash48 | name_len << 48 | (name offset & 15) << 60;  idx = position in its file;
-//                 meta = contig | file << 26 | hq << 30;  start, end, qlen;  name offset >> 4
+//                 meta = contig | file << 26 | hq << 30 | name16 << 31;  start, end, qlen;  name offset >> 4
 //   level 1: B1 = 2^b1 buckets by hash bits [47, 48 - b1); chunks of 8192 records of ONE file
 //   level 2: every level-1 bucket again by the next b2 bits; chunks never straddle level-1 buckets
 //   join   : one workgroup per final bucket, table in LDS: slot = {tag40 | claimant23 | hq} + one order key per file
@@ -386,7 +386,8 @@ __global__ __launch_bounds__(BLOCK) void k_part1_scatter(JoinFiles F, PartFiles 
                     if (at >> 36) part_refuse(status);
                     e[k].key = (r.name_hash & PART_KEY_MASK) | ((unsigned long long)r.name_len << 48) | ((unsigned long long)(at & 15ull) << 60);
                     e[k].idx = i;
-                    e[k].meta = (uint32_t)r.contig | ((uint32_t)f << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u);
+                    e[k].meta = (uint32_t)r.contig | ((uint32_t)f << PART_CONTIG_BITS) | ((r.flags & GCI_REC_HQ) ? 1u << 30 : 0u) |
+                                ((r.flags & GCI_REC_NAME16) ? 1u << 31 : 0u);
                     e[k].start = r.start; e[k].end = r.end; e[k].qlen = r.qlen;
                     e[k].name_off16 = (uint32_t)(at >> 4);
                     d[k] = (int)((uint32_t)((e[k].key & PART_KEY_MASK) >> shift) & (n_bins - 1));
@@ -510,6 +511,27 @@ __device__ __forceinline__ bool names_equal(const uint8_t* __restrict__ pa, cons
         }
     }
     return diff == 0;
+}
+
+// Two names that both carry GCI_REC_NAME16 (inside record pages / routed slots: at 0 or 4 mod 16, zero bytes behind them up
+// to the next 16-byte boundary), of the same length and the same phase: equal iff the 16-byte pieces they lie in are equal
+// from the name's first dword on -- three aligned 16-byte loads per name, all six requested together (the dword compare
+// above issues a dozen loads per name and a second round trip from 33 bytes on; per wave that is 64 cache lines per load
+// instruction: the address path, not the bytes, is what the comparisons cost).  len <= 44.
+__device__ __forceinline__ bool names_equal16(const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, uint32_t len)
+{
+    const uint32_t s = (uint32_t)((uintptr_t)pa & 15u);                  // == pb & 15, 0 or 4
+    const uint4* __restrict__ qa = reinterpret_cast<const uint4*>(pa - s);
+    const uint4* __restrict__ qb = reinterpret_cast<const uint4*>(pb - s);
+    const uint32_t end = s + len;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 a0 = qa[0], b0 = qb[0];
+    const uint4 a1 = end > 16 ? qa[1] : z, b1 = end > 16 ? qb[1] : z;
+    const uint4 a2 = end > 32 ? qa[2] : z, b2 = end > 32 ? qb[2] : z;
+    uint32_t d = (s ? 0u : a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w);
+    d |= (a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w);
+    d |= (a2.x ^ b2.x) | (a2.y ^ b2.y) | (a2.z ^ b2.z) | (a2.w ^ b2.w);
+    return d == 0;
 }
 
 struct PartJoinArgs {
@@ -682,7 +704,7 @@ __device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEn
 
 // One workgroup per final bucket.  LDS: meta[S] | cname[S] | last[S * F.n] | list of used slots.
 //   meta  = tag (hash bits [39, 0]) << 24 | claimant (entry index inside the bucket) << 1 | high-quality bit; ~0 = empty
-//   cname = where the claimant's name is: offset >> 4 | (offset & 15) << 32 | length << 36 | file << 48
+//   cname = where the claimant's name is: offset >> 4 | (offset & 15) << 32 | length << 36 | file << 48 | name16 << 52
 //   last  = per (slot, file) the largest order key (contig, file position) + 1 seen, then WIN | index of the entry that has it
 // A bucket of up to PART_E * JB = 1024 entries (all but forged inputs) stays in REGISTERS from its one coalesced read to the
 // fold: insert (LDS only) -> winners + every non-claimant's name against its claimant's (two independent random reads per
@@ -732,7 +754,7 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     auto name_word = [](const PartEntry& e) -> unsigned long long {
         return (unsigned long long)e.name_off16 | ((e.key >> 60) << 32) | (((e.key >> 48) & 0xFFFull) << 36) |
-               ((unsigned long long)((e.meta >> PART_CONTIG_BITS) & 15u) << 48);
+               ((unsigned long long)((e.meta >> PART_CONTIG_BITS) & 15u) << 48) | ((unsigned long long)(e.meta >> 31) << 52);
     };
     // one entry through the insert; -> its slot
     auto insert = [&](const PartEntry& e, uint32_t i, bool exact) -> uint32_t {
@@ -755,7 +777,13 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const unsigned long long cw = cname[slot];
             const uint32_t len = (uint32_t)(e.key >> 48) & 0xFFFu;
             const uint8_t* cn = F.f[(cw >> 48) & 15u].d_name_base + (((cw & 0xFFFFFFFFull) << 4) | ((cw >> 32) & 15ull));
-            if (((uint32_t)(cw >> 36) & 0xFFFu) != len || !names_equal(entry_name(F, e), cn, len)) s_bad = 1u;   // two names, one hash
+            const uint8_t* mn = entry_name(F, e);
+            bool same;
+            if (((uint32_t)(cw >> 36) & 0xFFFu) != len) same = false;
+            else if ((e.meta >> 31) && ((cw >> 52) & 1ull) && len <= 44u && (((uintptr_t)mn ^ (uintptr_t)cn) & 15u) == 0)
+                same = names_equal16(mn, cn, len);
+            else same = names_equal(mn, cn, len);
+            if (!same) s_bad = 1u;                                       // two names, one hash
         }
     };
     bool exact = false;

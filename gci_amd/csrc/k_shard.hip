@@ -6,14 +6,15 @@
 // last record (GCI.py:269).  The join treats every name independently, so it shards by name: every passing record goes
 // to rank (name hash >> 33) % N (one all-to-all of 32-byte records and one of their names per input file), each rank joins
 // the names it owns with the same kernels as a single GPU, and the surviving 16-byte intervals go to the rank that owns
-// their contig (one more all-to-all).  Per step and rank that is (32 + 48) * R * (N - 1) / N^2 bytes out for R records in
+// their contig (one more all-to-all).  Per step and rank that is (32 + name slot) * R * (N - 1) / N^2 bytes out for R records in
 // the job, against (32 + name) * R * (N - 1) / N of the replicated join of round 2.
 //
 // Buckets have a fixed capacity (the collectives keep one shape from step to step, nothing is sized on the host per step):
 //   records:   n_parts buckets of (cap + 1) gci_rec slots; slot 0 is a header (name_hash = number of records routed here,
 //              flags = 0), slots 1 .. hold the records IN FILE ORDER (the routing is stable: among records of one file with
 //              the same name on the same contig the last one must stay the last one);
-//              names: n_parts * cap slots of GCI_ROUTE_NAME bytes, zero padded;
+//              names: n_parts * cap slots of name_slot bytes (a multiple of 16 the caller picks: at least the longest
+//              name), zero padded;
 //   intervals: n_parts buckets of (cap + 1) gci_ivl slots, slot 0 = {contig = -1, start = count}.
 // A count beyond the capacity (or a name longer than a slot) is reported as GCI_E_CAPACITY: the caller grows the buckets.
 #include "gci_ctx.hpp"
@@ -76,7 +77,7 @@ __device__ __forceinline__ uint32_t route_name_dword(const uint8_t* p, uint32_t 
 template <bool IVL>
 __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint32_t n_parts, uint32_t n_chunks, uint32_t cap,
                                                          const uint32_t* __restrict__ off, uint8_t* __restrict__ out,
-                                                         uint8_t* __restrict__ out_names, unsigned long long* __restrict__ status)
+                                                         uint8_t* __restrict__ out_names, uint32_t name_slot, unsigned long long* __restrict__ status)
 {
     __shared__ uint32_t run[ROUTE_MAX_PARTS], wcnt[BLOCK / 64][ROUTE_MAX_PARTS];
     const uint32_t t = threadIdx.x, chunk = blockIdx.x, lane = t & 63, wave = t >> 6;
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint3
             const size_t slot = (size_t)d * (cap + 1) + 1 + pos;
             if (IVL) reinterpret_cast<gci_ivl*>(out)[slot] = S.ivl[i];
             else {
-                const gci_rec r = S.recs[i];
+                gci_rec r = S.recs[i];
+                r.flags |= GCI_REC_NAME16;                        // a routed name slot: 16-byte aligned, zero padded
                 reinterpret_cast<gci_rec*>(out)[slot] = r;
-                uint32_t* nd = reinterpret_cast<uint32_t*>(out_names + ((size_t)d * cap + pos) * GCI_ROUTE_NAME);
-                if (r.name_len > GCI_ROUTE_NAME) atomicMin(status, (unsigned long long)(unsigned)(-GCI_E_CAPACITY));
+                uint32_t* nd = reinterpret_cast<uint32_t*>(out_names + ((size_t)d * cap + pos) * name_slot);
+                if (r.name_len > name_slot) atomicMin(status, (unsigned long long)(unsigned)(-GCI_E_CAPACITY));
                 const uint8_t* src = S.name_base + S.name_off[i] + S.name_delta;
-                const uint32_t len = r.name_len < GCI_ROUTE_NAME ? r.name_len : GCI_ROUTE_NAME;
-#pragma unroll
-                for (int w = 0; w < GCI_ROUTE_NAME / 4; w++) nd[w] = route_name_dword(src, len, (uint32_t)w);
+                const uint32_t len = r.name_len < name_slot ? r.name_len : name_slot;
+                for (uint32_t w = 0; w < name_slot / 4; w++) nd[w] = route_name_dword(src, len, w);
             }
         }
         __syncthreads();
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint3
 }
 
 static int route_impl(gci_ctx* ctx, const RouteSrc& S, bool ivl, uint32_t n_parts, uint32_t cap, uint8_t* d_out, uint8_t* d_out_names,
-                      uint64_t* d_status)
+                      uint32_t name_slot, uint64_t* d_status)
 {
     if (n_parts == 0 || n_parts > ROUTE_MAX_PARTS || !d_out || !d_status) return GCI_E_INVALID;
     const uint32_t n_chunks = S.n ? (S.n + ROUTE_CHUNK - 1) / ROUTE_CHUNK : 1;
@@ -149,23 +150,24 @@ static int route_impl(gci_ctx* ctx, const RouteSrc& S, bool ivl, uint32_t n_part
     int r = device_exclusive_scan<uint32_t, uint32_t>(ctx, tab, tab, (uint32_t*)ctx->part_blk.p, (int64_t)n_tab, true);
     if (r) return r;
     if (ivl) hipLaunchKernelGGL((k_route_scatter<true>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, cap,
-                                (const uint32_t*)tab, d_out, d_out_names, (unsigned long long*)d_status);
+                                (const uint32_t*)tab, d_out, d_out_names, name_slot, (unsigned long long*)d_status);
     else hipLaunchKernelGGL((k_route_scatter<false>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, cap,
-                            (const uint32_t*)tab, d_out, d_out_names, (unsigned long long*)d_status);
+                            (const uint32_t*)tab, d_out, d_out_names, name_slot, (unsigned long long*)d_status);
     LAUNCHCHK("k_route_scatter");
     return GCI_OK;
 }
 
 extern "C" int gci_route_records(gci_ctx* ctx, const gci_join_file* h_file, uint32_t n_parts, uint32_t cap, gci_rec* d_out_recs,
-                                 uint8_t* d_out_names, uint64_t* d_status)
+                                 uint8_t* d_out_names, uint32_t name_slot, uint64_t* d_status)
 {
+    if (name_slot < 16 || name_slot > 65536 || (name_slot & 15u)) return GCI_E_INVALID;
     if (!ctx || !h_file || !d_out_names || (h_file->n_recs && (!h_file->d_recs || !h_file->d_name_base || !h_file->d_name_off)))
         return GCI_E_INVALID;
     RouteSrc S;
     memset(&S, 0, sizeof S);
     S.recs = h_file->d_recs; S.name_base = h_file->d_name_base; S.name_off = h_file->d_name_off; S.name_delta = h_file->name_delta;
     S.n = h_file->n_recs;
-    return route_impl(ctx, S, false, n_parts, cap, (uint8_t*)d_out_recs, d_out_names, d_status);
+    return route_impl(ctx, S, false, n_parts, cap, (uint8_t*)d_out_recs, d_out_names, name_slot, d_status);
 }
 
 extern "C" int gci_route_intervals(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, const int32_t* d_owner,
@@ -175,7 +177,7 @@ extern "C" int gci_route_intervals(gci_ctx* ctx, const gci_ivl* d_ivl, const uin
     RouteSrc S;
     memset(&S, 0, sizeof S);
     S.ivl = d_ivl; S.d_n = d_n; S.owner = d_owner; S.n_owner = n_contigs; S.n = max_n;
-    return route_impl(ctx, S, true, n_parts, cap, (uint8_t*)d_out, nullptr, d_status);
+    return route_impl(ctx, S, true, n_parts, cap, (uint8_t*)d_out, nullptr, 16, d_status);
 }
 
 // ---- after the all-to-all: what arrived beyond a bucket's count is not data ---------------------------------------------

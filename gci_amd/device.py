@@ -234,7 +234,8 @@ class Engine:
 
     def name_join(self, files: Sequence[JoinInput], ovlp_percent: float, contig_map: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None, check: bool = True,
-                  count_flank: Optional[int] = None, fallback: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                  count_flank: Optional[int] = None, fallback: bool = True,
+                  status: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (intervals int32 [cap, 4], device count).  With check=True the count is read back,
         capacity is grown if needed and the record-level status is raised.
 
@@ -246,13 +247,14 @@ class Engine:
         if count is None:
             count = torch.zeros(1, dtype=torch.int32, device=self.device)
         arr = self._join_files(files)
+        st_word = self._status if status is None else status          # status: the caller reads the word later (check=False)
         while True:
             if count_flank is None:
                 st = self.lib.gci_name_join(self.ctx, arr, len(files), float(ovlp_percent), self._p(contig_map),
-                                            self._p(out), int(out.shape[0]), self._p(count), self._p(self._status))
+                                            self._p(out), int(out.shape[0]), self._p(count), self._p(st_word))
             else:
                 st = self.lib.gci_name_join_count(self.ctx, arr, len(files), float(ovlp_percent), self._p(contig_map),
-                                                  self._p(out), int(out.shape[0]), self._p(count), self._p(self._status),
+                                                  self._p(out), int(out.shape[0]), self._p(count), self._p(st_word),
                                                   int(count_flank))
             self._chk(st, "gci_name_join")
             if not check:
@@ -322,10 +324,10 @@ class Engine:
 
     # ---- multi-GPU: buckets of the name-hash-sharded join (gci_route_*; the collectives are shard.ShardedJoin's) ----------
     def route_records(self, f: JoinInput, n_parts: int, cap: int, out_recs: torch.Tensor, out_names: torch.Tensor,
-                      status: torch.Tensor) -> None:
-        """out_recs uint8 [n_parts * (cap + 1), 32], out_names uint8 [n_parts * cap * ROUTE_NAME], status int64 [1]."""
+                      name_slot: int, status: torch.Tensor) -> None:
+        """out_recs uint8 [n_parts * (cap + 1), 32], out_names uint8 [n_parts * cap * name_slot], status int64 [1]."""
         self._chk(self.lib.gci_route_records(self.ctx, self._join_files([f]), int(n_parts), int(cap), self._p(out_recs),
-                                             self._p(out_names), self._p(status)), "gci_route_records")
+                                             self._p(out_names), int(name_slot), self._p(status)), "gci_route_records")
 
     def route_seal_records(self, recs: torch.Tensor, n_parts: int, cap: int, status: torch.Tensor) -> None:
         self._chk(self.lib.gci_route_seal_records(self.ctx, self._p(recs), int(n_parts), int(cap), self._p(status)),

@@ -277,11 +277,12 @@ class ShardedJoin:
     `ops` provides the device operations: route_records, route_seal_records, route_intervals, route_seal_intervals and
     name_join (an `Engine`; the CPU tests pass numpy stand-ins)."""
 
-    ROUTE_NAME = 48
-
     def __init__(self, ops, n_local: Sequence[int], owner: Sequence[int], device: torch.device, group=None,
-                 via_host: bool = False, slack: float = 1.3):
+                 via_host: bool = False, slack: float = 1.3, name_slot: int = 48):
+        """name_slot: bytes of a routed name slot, a multiple of 16 and at least the longest query name of the run (the same on
+        every rank)."""
         self.ops, self.group, self.via_host, self.device = ops, group, via_host, device
+        self.ROUTE_NAME = int(name_slot)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n_files = len(n_local)
@@ -334,7 +335,7 @@ class ShardedJoin:
         """One file's records of this rank -> the records (of every rank) whose names this rank owns, as a join input."""
         from .device import JoinInput
         cap, W = self.rec_cap[f], self.world
-        self.ops.route_records(ji, W, cap, self.send_recs[f], self.send_names[f], self.status[2 * f:2 * f + 1])
+        self.ops.route_records(ji, W, cap, self.send_recs[f], self.send_names[f], self.ROUTE_NAME, self.status[2 * f:2 * f + 1])
         self._all_to_all(self.recv_recs[f], self.send_recs[f])
         self._all_to_all(self.recv_names[f], self.send_names[f])
         self.ops.route_seal_records(self.recv_recs[f], W, cap, self.status[2 * f + 1:2 * f + 2])

@@ -75,6 +75,10 @@ typedef struct gci_rec {
 } gci_rec;
 #define GCI_REC_PASS 1u        /* record reaches GCI.py:166 */
 #define GCI_REC_HQ 2u          /* ... and mapq >= mq_cutoff (GCI.py:167) */
+#define GCI_REC_NAME16 4u      /* where its query name lies (gci_join_file): at an address = 0 or 4 (mod 16), followed by zero
+                                * bytes up to the next 16-byte boundary -- names inside record pages (gci_bam_filter_pages) and
+                                * routed name slots (gci_route_records).  The join then compares two such names as whole 16-byte
+                                * pieces (three loads per name instead of a dozen) */
 
 /* Interval on a selected contig, 16 bytes. */
 typedef struct gci_ivl {
@@ -247,19 +251,17 @@ int gci_hash_conflicts(gci_ctx* ctx, const uint64_t* d_buckets, uint32_t n_parts
  * three all-to-alls (the host side does the collectives: RCCL through torch.distributed, gci_amd/shard.py):
  *   gci_route_records   one file's records -> n_parts buckets of (cap + 1) gci_rec slots (slot 0: header, name_hash = number
  *                       of records routed to the part, flags = 0; then the records in FILE ORDER -- the routing is stable)
- *                       and n_parts * cap name slots of GCI_ROUTE_NAME bytes (zero padded)
+ *                       and n_parts * cap name slots of name_slot bytes (a multiple of 16, at least the longest name; zero padded)
  *   gci_route_seal_records   on the receiving side: slots beyond a bucket's count get flags = 0, so the whole receive buffer
  *                       is one gci_rec array in file order (source rank after source rank) for gci_name_join; the name of
- *                       slot d * (cap + 1) + 1 + k is at (d * cap + k) * GCI_ROUTE_NAME of the received names
+ *                       slot d * (cap + 1) + 1 + k is at (d * cap + k) * name_slot of the received names
  *   gci_route_intervals intervals (contig = index among ALL selected contigs) -> buckets by d_owner[contig] (< 0: dropped);
  *                       slot 0 of a bucket = {contig = -1, start = count}
  *   gci_route_seal_intervals  receiving side: contig -> d_cmap[contig] (the rank's track layout), -1 beyond the count: the
  *                       buffer of n_parts * (cap + 1) intervals goes to gci_depth_build_* as it is
- * A count beyond cap or a name longer than GCI_ROUTE_NAME sets *d_status to GCI_E_CAPACITY (grow the buckets / take the
- * replicated join). */
-#define GCI_ROUTE_NAME 48
+ * A count beyond cap or a name longer than name_slot sets *d_status to GCI_E_CAPACITY (grow the buckets). */
 int gci_route_records(gci_ctx* ctx, const gci_join_file* h_file, uint32_t n_parts, uint32_t cap, gci_rec* d_out_recs,
-                      uint8_t* d_out_names, uint64_t* d_status);
+                      uint8_t* d_out_names, uint32_t name_slot, uint64_t* d_status);
 int gci_route_seal_records(gci_ctx* ctx, gci_rec* d_recs, uint32_t n_parts, uint32_t cap, uint64_t* d_status);
 int gci_route_intervals(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, const int32_t* d_owner,
                         int32_t n_contigs, uint32_t n_parts, uint32_t cap, gci_ivl* d_out, uint64_t* d_status);
