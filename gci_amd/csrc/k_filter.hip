@@ -918,7 +918,20 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
 #ifdef PGX_NO_AUX
             have_nm = true; NM = (int64_t)(lds_u32(ax) & 0xFF);
 #else
-            for (uint32_t q = 0; q + 3 <= aux_len;) {
+            // Four lanes walk the same tags, and a wave walks as long as its slowest record: the loop that finds NM among
+            // fixed-size tags (A c C s S i I f: what aligners write around it) is kept to one tag word, one table byte and a
+            // handful of instructions per tag; a Z / H / B value in front of NM, or the CG search, takes the general loop below
+            uint32_t q = 0;
+            bool general = want_cg;
+            while (!general && q + 3 <= aux_len) {
+                const uint32_t w = lds_u32(ax + q);                                // tag[2] | type | first value byte
+                const uint32_t sz = aux_sz[(w >> 16) & 0xFFu];
+                if (sz == 0) { general = true; break; }                            // a variable-size (or unknown) type: general loop
+                if (q + 3 + sz > aux_len) break;                                   // value cut off: bam_aux_get stops here
+                if ((w & 0xFFFFu) == (uint32_t)('N' | ('M' << 8))) { have_nm = true; nm_bad = !nm_value(ax + q + 2, NM); break; }
+                q += 3 + sz;
+            }
+            for (; general && q + 3 <= aux_len;) {
                 const uint32_t w = lds_u32(ax + q);                                // tag[2] | type | first value byte
                 const uint32_t tag = w & 0xFFFFu;
                 const uint8_t ty = (uint8_t)(w >> 16);

@@ -660,10 +660,10 @@ __device__ __forceinline__ bool fold_bucket_slot(const JoinFiles& F, const PartE
 }
 
 // The fold (GCI.py:279-299) of one name by the thread that holds, in registers, the winning entry of the LOWEST file the
-// name occurs in: the winners of the later files are the only entries read again (the bucket was streamed a moment ago).
+// name occurs in; what it needs of the later files' winners -- contig, start, end, qlen -- those left in LDS when they won.
 template <int FN>
 __device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEntry* __restrict__ in, const PartEntry& mine, int f0,
-                                                uint32_t slot, const unsigned long long* last, bool high, double ovlp_percent,
+                                                uint32_t slot, const unsigned long long* last, const int4* pay, bool high, double ovlp_percent,
                                                 const int32_t* __restrict__ contig_map, unsigned long long* __restrict__ status, gci_ivl& o)
 {
     const int Fn = FN ? FN : F.n;
@@ -679,21 +679,22 @@ __device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEn
         const unsigned long long v = last[(size_t)slot * Fn + f];
         if (!v) continue;
         if (!have && !high) continue;
-        const PartEntry r = load_entry(in + (uint32_t)(v & 0x7FFFFFull));
-        const int32_t r_contig = (int32_t)(r.meta & cmask);
+        const int4 r = pay[(size_t)slot * Fn + f];                           // {contig, start, end, qlen} of that file's winner
+        const int32_t r_contig = r.x;
         if (have) {
             if (r_contig == contig) {
-                const int32_t ms = max(r.start, s), me = min(r.end, e);
+                const int32_t ms = max(r.y, s), me = min(r.z, e);
                 const int64_t ovlp = (int64_t)me - (int64_t)ms;
-                if (r.qlen == 0) {                                           // ZeroDivisionError at GCI.py:292
-                    atomicMin(status, ((unsigned long long)F.f[f].d_recs[r.idx].rec_idx << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+                if (r.w == 0) {                                              // ZeroDivisionError at GCI.py:292
+                    const uint32_t idx = in[(uint32_t)(v & 0x7FFFFFull)].idx;
+                    atomicMin(status, ((unsigned long long)F.f[f].d_recs[idx].rec_idx << 8) | (unsigned)(-GCI_E_ZERO_DIV));
                     return false;
                 }
-                if ((double)ovlp / (double)r.qlen < ovlp_percent) have = false;
+                if ((double)ovlp / (double)r.w < ovlp_percent) have = false;
                 else { s = ms; e = me; }
             } else have = false;
         } else {
-            have = true; contig = r_contig; s = r.start; e = r.end;
+            have = true; contig = r_contig; s = r.y; e = r.z;
         }
     }
     if (!have) return false;
@@ -702,10 +703,11 @@ __device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEn
     return true;
 }
 
-// One workgroup per final bucket.  LDS: meta[S] | cname[S] | last[S * F.n] | list of used slots.
+// One workgroup per final bucket.  LDS: meta[S] | cname[S] | last[S * F.n] | pay[S * F.n] | list of used slots.
 //   meta  = tag (hash bits [39, 0]) << 24 | claimant (entry index inside the bucket) << 1 | high-quality bit; ~0 = empty
 //   cname = where the claimant's name is: offset >> 4 | (offset & 15) << 32 | length << 36 | file << 48 | name16 << 52
 //   last  = per (slot, file) the largest order key (contig, file position) + 1 seen, then WIN | index of the entry that has it
+//   pay   = per (slot, file) what the fold needs of that entry: {contig, start, end, qlen}
 // A bucket of up to PART_E * JB = 1024 entries (all but forged inputs) stays in REGISTERS from its one coalesced read to the
 // fold: insert (LDS only) -> winners + every non-claimant's name against its claimant's (two independent random reads per
 // entry, addresses from registers and LDS: nothing in front of them) -> fold.  Larger buckets re-read their entries per phase.
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                      uint32_t* __restrict__ n_out, unsigned long long* __restrict__ status,
                                                      const CountArgs cnt)
 {
-    extern __shared__ unsigned long long sm[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
     __shared__ uint32_t wtot[JB / 64];
     __shared__ uint32_t s_base, s_used, s_bad;
     __shared__ int64_t s_len[COUNT_LDS], s_tf[COUNT_LDS];
@@ -726,7 +728,8 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     unsigned long long* meta = sm;
     unsigned long long* cname = sm + S;
     unsigned long long* last = sm + 2 * (size_t)S;
-    uint16_t* used = reinterpret_cast<uint16_t*>(sm + 2 * (size_t)S + (size_t)S * Fn);
+    int4* pay = reinterpret_cast<int4*>(sm + 2 * (size_t)S + (size_t)S * Fn);
+    uint16_t* used = reinterpret_cast<uint16_t*>(sm + 2 * (size_t)S + 3 * (size_t)S * Fn);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t j = blockIdx.x / A.n_bins2, d = blockIdx.x % A.n_bins2;
     const uint32_t cj = A.seg[A.n_seg + 1 + j], nch = A.seg[A.n_seg + 2 + j] - cj;
@@ -772,7 +775,10 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     auto settle = [&](const PartEntry& e, uint32_t i, uint32_t slot, bool exact) {
         const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
         const unsigned long long ord = (((unsigned long long)(e.meta & cmask) << 32) | e.idx) + 1ull;
-        if (last[(size_t)slot * Fn + file] == ord) last[(size_t)slot * Fn + file] = PART_WIN | i;
+        if (last[(size_t)slot * Fn + file] == ord) {
+            last[(size_t)slot * Fn + file] = PART_WIN | i;
+            pay[(size_t)slot * Fn + file] = make_int4((int)(e.meta & cmask), e.start, e.end, e.qlen);
+        }
         if (!exact && !A.no_verify && ((uint32_t)(meta[slot] >> 1) & 0x7FFFFFu) != i) {
             const unsigned long long cw = cname[slot];
             const uint32_t len = (uint32_t)(e.key >> 48) & 0xFFFu;
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const int file = (int)((e.meta >> PART_CONTIG_BITS) & 15u);
         if (last[(size_t)slot * Fn + file] != (PART_WIN | i)) return false;
         for (int f = 0; f < file; f++) if (last[(size_t)slot * Fn + f] != 0) return false;      // an earlier file has the name
-        return fold_from_entry<FN>(F, in, e, file, slot, last, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
+        return fold_from_entry<FN>(F, in, e, file, slot, last, pay, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
     };
     auto emit = [&](const gci_ivl& keep, uint32_t w) {
         if (w < cap) out[w] = keep;
@@ -885,10 +891,10 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
                                  uint64_t* d_status, const CountArgs& cnt, bool* done)
 {
     *done = false;
-    // slots per bucket table: what fits ~36 KB of LDS with one order key per file (four workgroups per CU: the kernel
-    // lives on random reads of HBM and needs the waves)
+    // slots per bucket table: what fits 64 KB of LDS with one order key and one 16-byte payload per file (two 512-thread
+    // workgroups per CU, which is what their registers allow anyway)
     uint32_t S = 1024;
-    while (S > 128 && (size_t)S * (16 + 8 * (size_t)F.n) > 36864) S >>= 1;
+    while (S > 128 && (size_t)S * (16 + 24 * (size_t)F.n) > 65536) S >>= 1;
     // buckets: a load of at most 0.63 in the worst case (every name distinct), 0.15 - 0.3 for two files of the same reads
     uint64_t nb = 256;
     while (nb * S * 5 < total * 8) nb <<= 1;
@@ -942,8 +948,11 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
         PartJoinArgs A;
         A.in = pb; A.seg = seg; A.off2 = hist2; A.n_seg = B1; A.n_bins2 = B2; A.slots = S; A.slot_shift = (uint32_t)slot_shift;
         { const char* nv = getenv("GCI_JOIN_NOVERIFY"); A.no_verify = nv && nv[0] == '1' ? 1u : 0u; }
-        const size_t lds = (size_t)S * (16 + 8 * (size_t)F.n) + (size_t)S * 2;     // + the list of used slots
+        const size_t lds = (size_t)S * (16 + 24 * (size_t)F.n) + (size_t)S * 2;    // + the list of used slots
         const dim3 grid(B1 * B2), block(JB);
+        const void* kfn = F.n == 1 ? (const void*)k_join_part<1> : F.n == 2 ? (const void*)k_join_part<2> : F.n == 3 ? (const void*)k_join_part<3>
+                        : F.n == 4 ? (const void*)k_join_part<4> : (const void*)k_join_part<0>;
+        HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         switch (F.n) {
         case 1: hipLaunchKernelGGL((k_join_part<1>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
         case 2: hipLaunchKernelGGL((k_join_part<2>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;

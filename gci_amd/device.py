@@ -48,8 +48,9 @@ def name_hash_np(names: Sequence[bytes]) -> np.ndarray:
     with np.errstate(over="ignore"):
         for k in range(width // 8):
             use = (k * 8) < lens
-            key = np.uint64((0x9E3779B97F4A7C15 * (k + 1)) & _M64)
-            acc = acc + np.where(use, mix(words[:, k] ^ key), np.uint64(0))
+            key = (0x9E3779B97F4A7C15 * (k + 1)) & _M64
+            mul = np.uint64(((key >> 1) ^ 0xbf58476d1ce4e5b9) | 1)
+            acc = acc + np.where(use, (words[:, k] ^ np.uint64(key)) * mul, np.uint64(0))
         return mix(acc ^ (lens.astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)))
 
 

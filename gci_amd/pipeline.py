@@ -16,6 +16,7 @@ interval algebra (gci_amd/score.py) and writes files.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -335,6 +336,7 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
         except GciError as e:
             if e.rec >= 0:
                 e.rec += n_done
+            e.contig = tindex[name]                 # (the ranks agree on the error of the earliest contig: _agree_on_error)
             raise
         names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
         rec_parts.append(recs.clone())
@@ -587,17 +589,28 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
         recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
         return JoinInput(recs, d_bam, d_off, 36)
     raw = np.memmap(path, dtype=np.uint8, mode="r")
-    pos, isz = hostio.bgzf_blocks(np.asarray(raw))
-    cpos = pos[:isz.shape[0]].astype(np.int64)
+    n_raw = int(raw.shape[0])
     on_device = os.environ.get("GCI_BAM_INGEST", "gpu") == "gpu"
     rec_parts, name_parts, off_parts, name_base, n_done = [], [], [], 0, 0
     for r, name in enumerate(hdr.references):
         if name not in own_set or index[r] is None:
             continue
         beg, end = index[r]
-        a = int(np.searchsorted(cpos, beg >> 16, side="right")) - 1              # member of the first record
-        b = int(np.searchsorted(cpos, end >> 16, side="right")) - 1              # member where the range ends
-        if a < 0 or cpos[a] != (beg >> 16) or b < a or b >= cpos.shape[0] or cpos[b] != (end >> 16):
+        # the member table of THIS contig's run only: from the member of its first record (beg >> 16) to the member its range
+        # ends in (end >> 16), hopping BSIZE from header to header -- a rank never touches the members of the other ranks'
+        # contigs (round 2 scanned the whole file on every rank: N x the file's pages through the page cache)
+        c_beg, c_end = beg >> 16, end >> 16
+        if not (0 <= c_beg <= c_end and c_end + 18 <= n_raw and bytes(raw[c_end:c_end + 4]) == b"\x1f\x8b\x08\x04"):
+            raise bamfmt.BAMError("index of %s does not match its BGZF members" % path)
+        run_end = c_end + int(raw[c_end + 16]) + (int(raw[c_end + 17]) << 8) + 1    # BSIZE of the last member
+        try:
+            pos, isz = hostio.bgzf_blocks(np.asarray(raw[c_beg:min(run_end, n_raw)]))
+        except Exception as e:                                                    # noqa: BLE001
+            raise bamfmt.BAMError("index of %s does not match its BGZF members" % path) from e
+        pos = pos + np.uint64(c_beg)
+        cpos = pos[:isz.shape[0]].astype(np.int64)
+        a, b = 0, int(isz.shape[0]) - 1
+        if b < 0 or cpos[a] != c_beg or cpos[b] != c_end:
             raise bamfmt.BAMError("index of %s does not match its BGZF members" % path)
         last = b if (end & 0xFFFF) else b - 1                                    # (a range ending at offset 0 of a member stops before it)
         if last < a:
@@ -659,14 +672,40 @@ def _replicate(engine: Engine, ji: JoinInput) -> JoinInput:
     return JoinInput(g.recs, g.names, g.name_index, 0)
 
 
+def _own_names_only(engine: Engine, ji: JoinInput, world: int, rank: int) -> JoinInput:
+    """Records every rank holds alike (PAF files are filtered whole on every rank): keep those whose NAME this rank owns --
+    (hash >> 33) % world, the rule of gci_route_records -- so that they meet the routed BAM records of the same names."""
+    if int(ji.recs.shape[0]) == 0:
+        return ji
+    h = ji.recs[:, 0:8].contiguous().view(torch.int64).reshape(-1)
+    dest = ((h >> 33) & 0x7FFFFFFF) % world
+    recs = ji.recs.clone()
+    recs[dest != rank, 29] = 0                       # gci_rec.flags
+    return JoinInput(recs, ji.name_base, ji.name_off, ji.name_delta)
+
+
+def _agree_on_error(err: Optional[GciError], contig: int = 1 << 30) -> None:
+    """A contig-sharded run fails as ONE run: every rank learns whether any rank's record filter / join raised, and all of them
+    raise the error of the earliest contig (the one the reference's loop over contigs would have met first) -- a rank that
+    went on alone would wait in the next collective for ever."""
+    code = 0 if err is None else -int(err.status)
+    key = (min(int(contig), (1 << 30)) << 8 | code) if code else (1 << 40)
+    best = -SHARD.all_reduce_max([-key])[0]
+    if best >= (1 << 40):
+        return
+    _reraise_like_reference(err if (err is not None and key == best) else GciError(-(best & 0xFF), "record filter / join failed on another rank"))
+
+
 def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_percent, clip_percent, ovlp_percent, flank_len,
                     directory, log_reads_type, chrs_list, threads, engine: Engine, write, issue_hint):
     """filter() of a contig-sharded run.  Contigs are dealt to the ranks (longest first onto the least loaded); depth
     build, gap mask, two-type max, issue scan and depth text are contig-local.  The read-name join is not -- a read
     aligned to contigs of two ranks must be dropped, a name repeated across contigs keeps its last record
-    (GCI.py:269, 296-297) -- so every rank filters the records of ITS contigs (K1), the 32-byte records + names are
-    replicated with one all-gather per file, every rank runs the whole join and keeps the intervals on its contigs.
-    PAF files are filtered whole on every rank (K2; they are a hundredth of the BAMs)."""
+    (GCI.py:269, 296-297) -- but it is independent per NAME: every rank filters the records of ITS contigs (K1), routes them
+    by name hash to the rank that owns the name (two all-to-alls per file), joins the names it owns and routes the surviving
+    intervals to the owners of their contigs (shard.ShardedJoin; round 2 replicated every record on every rank).
+    PAF files are filtered whole on every rank (K2; they are a hundredth of the BAMs); a rank keeps the names it owns."""
+    from . import shard
     first = bamfmt.read_header(bam_files[0])
     pairs = [(r, l) for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)]
     targets_length = {r: l for r, l in pairs}
@@ -676,20 +715,45 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
         sys.exit(f"ERROR!!! {SHARD.world} GPUs for {len(targets)} contig(s): use at most one GPU per contig")
     local_tl = {targets[c]: targets_length[targets[c]] for c in mine}
     engine.set_layout(list(local_tl.values()))
-    cmap = np.full(max(len(targets), 1), -1, dtype=np.int32)
-    cmap[mine] = np.arange(len(mine), dtype=np.int32)
     filt = (map_qual, mq_cutoff, clip_percent, iden_percent)
-    inputs: List[JoinInput] = []
+    paf_inputs: List[JoinInput] = []
+    local: List[JoinInput] = []
+    err, err_contig = None, 1 << 30
     try:
         if len(paf_files) != 0:
-            inputs += engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
+            paf_inputs = [_own_names_only(engine, ji, SHARD.world, SHARD.rank)
+                          for ji in engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)]
         for path in bam_files:
-            inputs.append(_replicate(engine, bam_records_of_contigs(engine, path, targets, list(local_tl), filt, threads)))
-        ivl, count = engine.name_join(inputs, ovlp_percent, contig_map=engine.to_device(cmap), count_flank=flank_len)
+            local.append(bam_records_of_contigs(engine, path, targets, list(local_tl), filt, threads))
     except GciError as e:
-        _reraise_like_reference(e)
+        err, err_contig = e, getattr(e, "contig", 0)
+    _agree_on_error(err, err_contig)
+    # routed name slots: as long as the longest query name of the run (a multiple of 16, the same on every rank)
+    longest = max([int(ji.recs[:, 30:32].contiguous().view(torch.int16).max().item()) if int(ji.recs.shape[0]) else 0 for ji in local] + [1])
+    slot = (SHARD.all_reduce_max([longest])[0] + 15) // 16 * 16
+    sj = shard.ShardedJoin(engine, [int(ji.recs.shape[0]) for ji in local], SHARD.owner, engine.device,
+                           via_host=SHARD.backend != "nccl", name_slot=max(16, slot))
+    while True:
+        inputs = paf_inputs + [sj.exchange_file(f, ji) for f, ji in enumerate(local)]
+        ivl, n_slots = sj.join(inputs, ovlp_percent)
+        err = None
+        try:
+            def decode(w, what):
+                rec = ctypes.c_uint32(0)
+                st = engine.lib.gci_decode_status(w, ctypes.byref(rec))
+                if st != 0:
+                    raise GciError(st, "%s: %s" % (what, engine.lib.gci_strerror(st).decode()), rec=int(rec.value))
+            sj.check(decode)
+        except GciError as e:
+            err = e
+        grow = SHARD.all_reduce_max([1 if (err is not None and err.status == _lib.GCI_E_CAPACITY) else 0])[0]
+        if grow:                                    # a bucket overflowed somewhere (names hash unevenly): larger buckets, again
+            sj.grow()
+            continue
+        _agree_on_error(err)
+        break
     track = engine.new_track()
-    fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=False, want_sums=True, issue=issue_hint, counted=True)
+    fused = engine.depth_build_fused(ivl, None, flank_len, track, want_text=False, want_sums=True, issue=issue_hint, counted=False)
     depths = DepthTracks(engine, local_tl, track)
     depths.all_targets = targets
     depths._fresh_sums = fused["sums"]
@@ -736,10 +800,10 @@ def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
     items = list(zip(depths.targets, depths.lengths, blobs))
     if _sharded():
         order = {t: i for i, t in enumerate(depths.all_targets)}
-        parts = SHARD.gather_objects(items)
-        items = sorted((x for part in parts for x in part), key=lambda x: order[x[0]])
+        parts = SHARD.gather_to_root(items)             # to rank 0 only: the members of a genome are GBs
         if not SHARD.root:
             return
+        items = sorted((x for part in parts for x in part), key=lambda x: order[x[0]])
     path = f"{directory}/{prefix}.depth.gz"
     if os.path.exists(path):
         os.remove(path)

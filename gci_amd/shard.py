@@ -83,6 +83,19 @@ class Context:
         dist.all_gather_object(out, obj)
         return out
 
+    def gather_to_root(self, obj) -> Optional[list]:
+        """obj of every rank on rank 0 (in rank order); None elsewhere.  For what only rank 0 writes (the .depth.gz members of
+        a genome are GBs: every rank holding every rank's would be world x that)."""
+        out: Optional[List[Optional[object]]] = [None] * self.world if self.root else None
+        dist.gather_object(obj, out, dst=0)
+        return out
+
+    def all_reduce_max(self, values: Sequence[int]) -> List[int]:
+        dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [int(x) for x in t.cpu().tolist()]
+
     def all_reduce_sum(self, values: Sequence[int]) -> List[int]:
         dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)

@@ -137,3 +137,153 @@ def test_world2_gloo_exchange_and_sharding():
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+# ---- the name-hash-sharded join (shard.ShardedJoin) with numpy stand-ins for the five device operations -------------------
+
+class _NumpyOps:
+    """What an Engine does for ShardedJoin, restated with numpy / the oracle: the bucket layouts of include/gci_hip.h."""
+
+    def __init__(self, O, targets, rec_dtype):
+        self.O, self.targets, self.dt = O, targets, rec_dtype
+
+    def route_records(self, ji, n_parts, cap, out_recs, out_names, slot, status):
+        recs = ji.recs.numpy().reshape(-1).view(self.dt)
+        o = out_recs.numpy().reshape(-1).view(self.dt).reshape(n_parts, cap + 1)
+        names = out_names.numpy().reshape(n_parts, cap, slot)
+        names[:] = 0
+        cnt = [0] * n_parts
+        base, off = ji.name_base.numpy(), ji.name_off.numpy()
+        for i, r in enumerate(recs):
+            if not (r["flags"] & 1):
+                continue
+            d = (int(r["name_hash"]) >> 33) % n_parts
+            k = cnt[d]
+            cnt[d] += 1
+            if k < cap:
+                o[d, 1 + k] = r
+                o[d, 1 + k]["flags"] |= 4
+                a = int(off[i]) + ji.name_delta
+                names[d, k, :int(r["name_len"])] = base[a:a + int(r["name_len"])]
+        for d in range(n_parts):
+            o[d, 0] = np.zeros((), dtype=self.dt)
+            o[d, 0]["name_hash"], o[d, 0]["contig"] = cnt[d], -1
+        status[0] = -1 if max(cnt) <= cap else 8
+
+    def route_seal_records(self, recs, n_parts, cap, status):
+        o = recs.numpy().reshape(-1).view(self.dt).reshape(n_parts, cap + 1)
+        status[0] = -1
+        for d in range(n_parts):
+            c = int(o[d, 0]["name_hash"])
+            o[d, 0]["flags"] = 0
+            o[d, 1 + min(c, cap):]["flags"] = 0
+
+    def name_join(self, inputs, ovlp, contig_map, out, count, check, count_flank, status=None):
+        dicts, hq = [], set()
+        for ji in inputs:
+            recs = ji.recs.numpy().reshape(-1).view(self.dt)
+            base, off = ji.name_base.numpy(), ji.name_off.numpy()
+            order = sorted((int(r["contig"]), i) for i, r in enumerate(recs) if r["flags"] & 1)
+            d = {}
+            for _, i in order:
+                r = recs[i]
+                a = int(off[i]) + ji.name_delta
+                q = bytes(base[a:a + int(r["name_len"])]).decode()
+                d[q] = (self.targets[int(r["contig"])], int(r["start"]), int(r["end"]), int(r["qlen"]))
+                if r["flags"] & 2:
+                    hq.add(q)
+            dicts.append(d)
+        res = self.O.name_join(dicts, hq, ovlp)
+        o = out.numpy()
+        for k, (t, s, e) in enumerate(res.values()):
+            o[k] = (self.targets.index(t), s, e, 0)
+        count[0] = len(res)
+        if status is not None:
+            status[0] = -1
+
+    def route_intervals(self, ivl, count, owner, n_parts, cap, out, status):
+        o = out.numpy().reshape(n_parts, cap + 1, 4)
+        cnt = [0] * n_parts
+        for c, s, e, _ in ivl.numpy()[:int(count[0])].tolist():
+            d = int(owner[c])
+            if cnt[d] < cap:
+                o[d, 1 + cnt[d]] = (c, s, e, 0)
+            cnt[d] += 1
+        for d in range(n_parts):
+            o[d, 0] = (-1, cnt[d], 0, 0)
+        status[0] = -1 if max(cnt) <= cap else 8
+
+    def route_seal_intervals(self, ivl, n_parts, cap, cmap, status):
+        o = ivl.numpy().reshape(n_parts, cap + 1, 4)
+        status[0] = -1
+        for d in range(n_parts):
+            c = int(o[d, 0, 1])
+            for k in range(1, cap + 1):
+                o[d, k, 0] = int(cmap[o[d, k, 0]]) if k <= min(c, cap) else -1
+
+
+def _worker_sharded_join(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gci_amd import shard, synth
+        from gci_amd.device import REC_DTYPE, JoinInput, name_hash_np
+        from oracle import gci_oracle as O
+        contigs = (("a", 260_000), ("b", 200_000), ("c", 150_000), ("d", 60_000))
+        targets = [n for n, _ in contigs]
+        base = synth.simulate_reads(contigs, 12, "hifi", seed=91)
+        sets = [base, synth.perturb(base, 92), synth.perturb(base, 93)]          # three files: reads move between contigs / ranks
+        owner = shard.lpt_assign([l for _, l in contigs], world)
+        ops = _NumpyOps(O, targets, REC_DTYPE)
+        local, dicts, hq = [], [], set()
+        for rs in sets:
+            stream, offs = synth.to_bam_stream(rs)
+            a = O.bam_filter_arrays(stream, offs, np.arange(len(targets), dtype=np.int32), 30, 50, 0.1, 0.9)
+            d, h = O.bam_file_dict(stream, offs, targets, targets, 30, 50, 0.1, 0.9)
+            dicts.append(d)
+            hq |= h
+            mine = np.flatnonzero(np.asarray(owner)[np.clip(a["contig"], 0, len(targets) - 1)] == rank)    # the records of this rank's contigs
+            n = mine.shape[0]
+            names = [bytes(stream[int(o):int(o) + int(l)]) for o, l in zip(a["name_off"][mine], a["name_len"][mine])]
+            recs = np.zeros(n, dtype=REC_DTYPE)
+            recs["name_hash"] = name_hash_np(names)
+            for f in ("contig", "start", "end", "qlen", "name_len"):
+                recs[f] = a[f][mine]
+            recs["flags"] = a["passed"][mine] | (a["hq"][mine] << 1)
+            recs["rec_idx"] = np.arange(n)
+            local.append(JoinInput(torch.from_numpy(recs.view(np.uint8).reshape(n, 32).copy()), torch.from_numpy(stream.copy()),
+                                   torch.from_numpy(a["name_off"][mine].astype(np.int64)), 0))
+        sj = shard.ShardedJoin(ops, [int(ji.recs.shape[0]) for ji in local], owner, torch.device("cpu"))
+        inputs = [sj.exchange_file(f, ji) for f, ji in enumerate(local)]
+        ivl, n_slots = sj.join(inputs, 0.9)
+        assert n_slots == ivl.shape[0] and sj.bytes_per_step() > 0
+        sj.check(lambda w, what: None if w == (1 << 64) - 1 else (_ for _ in ()).throw(AssertionError((what, w))))
+        cmap, mine_c = shard.contig_map_for(owner, rank)
+        got = sorted((mine_c[c], s, e) for c, s, e, _ in ivl.numpy().tolist() if c >= 0)
+        want = sorted((targets.index(t), s, e) for t, s, e in O.name_join(dicts, hq, 0.9).values() if owner[targets.index(t)] == rank)
+        assert got == want and len(want) > 50, (len(got), len(want))
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_name_hash_sharded_join():
+    """shard.ShardedJoin over gloo, two ranks: records routed by name hash, joined where their name is owned, intervals routed
+    to the owner of their contig -- every rank ends with exactly the single-process join's intervals on ITS contigs."""
+    from oracle import gci_oracle
+    gci_oracle.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_sharded_join, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

@@ -91,20 +91,25 @@ def test_more_ranks_than_contigs_is_refused(tmp_path):
     assert r.returncode != 0 and "2 GPUs for 1 contig(s)" in r.stderr
 
 
-@pytest.mark.parametrize("shared", [0.0, 0.02])
-def test_bench_two_ranks_against_the_oracle(shared, tmp_path):
-    """bench.py's N > 1 step with two ranks on one GPU (gloo staging): K1 x 2 files, the cross-rank name check (hash
-    all-to-all + conflict kernel), the speculative local join or -- with read names shared between the ranks -- the
-    replicated join over gathered records + names, the fused build and the integer all-reduce; every rank's result held
-    against the oracle run over the files of both ranks."""
+@pytest.mark.parametrize("scaling,shared", [("strong", 0.0), ("weak", 0.0), ("weak", 0.02)])
+def test_bench_two_ranks_against_the_oracle(scaling, shared, tmp_path):
+    """bench.py's N > 1 step with two ranks on one GPU (gloo staging).  strong (what `--gpus N` runs): ONE genome, its contigs
+    dealt to the ranks, the join sharded by name hash (gci_route_* + three kinds of all-to-all) -- every contig of every rank
+    against the oracle over the undivided files.  weak (round 2): a haplotype per rank, the cross-rank name check (hash
+    all-to-all + conflict kernel), the speculative local join or -- with read names shared between the ranks -- the replicated
+    join over gathered records + names; in every case the fused build and the integer all-reduce."""
     import json
     env = dict(os.environ, GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    port = 29750 + int(shared * 100) + (7 if scaling == "strong" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29750 + int(shared * 100)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--scale", "0.01", "--backend", "gloo", "--verify-oracle", "--shared-names", str(shared)]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--scale", "0.01", "--backend", "gloo", "--verify-oracle", "--shared-names", str(shared), "--scaling", scaling]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["parity_vs_oracle_all_ranks"] is True
-    assert ("replicated" in out["config"]["join"]) == (shared > 0)
+    assert out["n_gpus"] == 2 and out["parity_vs_oracle_all_ranks"] is True and out["scaling"] == scaling
+    if scaling == "strong":
+        assert "sharded by name hash" in out["config"]["join"]
+    else:
+        assert ("replicated" in out["config"]["join"]) == (shared > 0)
