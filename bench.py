@@ -48,8 +48,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("genome", "chr19"), default="genome",
-                    help="genome: BASELINE configs[2] (default); chr19: configs[1], one contig and one BAM per rank")
+    ap.add_argument("--workload", choices=("genome", "chr19", "genome4", "diploid"), default="genome",
+                    help="genome: BASELINE configs[2] (default); chr19: configs[1], one contig and one BAM per rank; genome4: configs[3] "
+                         "on ONE GPU (CHM13, --hifi + --nano, per read type one BAM + one PAF: two filters, max, three issue scans, three "
+                         "tracks); diploid: configs[4] on ONE GPU (mat + pat, 46 contigs, 6.2 Gb, HiFi 100x + ONT, 20 N gaps, -R regions)")
+    ap.add_argument("--coverage-ont", type=float, default=None, help="genome4 / diploid: ONT coverage (default 40 / 20)")
     ap.add_argument("--scale", type=float, default=1.0, help="genome workload: shrink every contig (testing only)")
     ap.add_argument("--contig-len", type=int, default=CHR19_LEN, help="chr19 workload: per-rank contig length")
     ap.add_argument("--coverage", type=float, default=40.0)
@@ -233,6 +236,7 @@ class Workload:
                 loc[0].d_recs, loc[0].n_recs, loc[0].name_delta = self.recs[f].data_ptr(), self.n_rec[f], self.name_delta
                 loc[0].d_name_base, loc[0].d_name_off = self.d_bam[f].data_ptr(), self.d_off[f].data_ptr()
                 chk(lib.gci_pack_names(ctx, loc, _p(ex.send_names), ex.name_cap, _p(ex.send_off)), "gci_pack_names")
+                self.recs[f][:, 29] &= 3                       # the names travel packed: no longer GCI_REC_NAME16
                 g = ex.gather()
                 self._g.append(g)                                # keep the index tensors alive until the join ran
                 jf[f].d_recs, jf[f].n_recs, jf[f].name_delta = g.recs.data_ptr(), self.world * g.max_n, 0
@@ -327,6 +331,147 @@ class Workload:
         build = 28 * K + 4 * L + T
         return {"k1_record_filter": k1, "name_join": join, "depth_build_text": build, "total": k1 + join + build,
                 "intervals": K, "bases": L, "text_bytes": T}
+
+
+class TwoTypeWorkload:
+    """configs[3] / configs[4] on one GPU: what GCI() does with `--hifi` AND `--nano` (GCI.py:1007-1026).  A step =
+    per read type [PAF filter on the device (K2) + paged record filter (K1) -> join (PAF first, GCI.py:272) -> fused depth
+    build with sums and, when no gap mask follows, the issue runs] -> gap masks (GCI.py:315-329) -> per-base max of the two
+    tracks (GCI.py:350) -> issue scans of the three tracks (GCI.py:356-419) -> `-R` regions scans (GCI.py:610-657)."""
+
+    def __init__(self, eng, inp, name):
+        import torch
+        self.torch, self.eng, self.inp, self.name = torch, eng, inp, name
+        self.rank, self.world, self.sharded, self.exchange, self.replicated_steps = 0, 1, False, False, 0
+        self.contigs = inp.contigs
+        names, lens = inp.names, inp.lengths
+        eng.set_layout(lens)
+        self.own, self.own_lengths = list(range(len(names))), lens
+        self.ref_sel = eng.to_device(np.arange(len(names), dtype=np.int32))
+        dev = eng.device
+        self.types = []
+        for t in (inp.hifi, inp.nano):
+            d_s, d_o = eng.to_device(t.bam.stream), eng.to_device(t.bam.offsets)
+            pages = eng.bam_pages(d_s, d_o, False)
+            del d_s, d_o
+            n = int(t.bam.offsets.shape[0])
+            d = dict(pages=pages, n_rec=n, recs=torch.empty((max(n, 1), 32), dtype=torch.uint8, device=dev),
+                     name_off=torch.empty(max(n, 1), dtype=torch.int64, device=dev),
+                     paf=eng.to_device(t.paf) if t.paf is not None else None,
+                     paf_end=np.asarray([t.paf.shape[0]], dtype=np.uint64) if t.paf is not None else None,
+                     track=eng.new_track(), ivl=torch.empty((2 * max(n, 1) + 16, 4), dtype=torch.int32, device=dev),
+                     count=torch.zeros(1, dtype=torch.int32, device=dev), k1_bytes=t.bam.k1_bytes)
+            self.types.append(d)
+        self.two = eng.new_track()
+        self.gaps = None
+        if inp.gaps:
+            g = [(names.index(c), a, b, 0) for c, segs in inp.gaps.items() for a, b in segs]
+            self.gaps = eng.to_device(np.asarray(g, dtype=np.int32))
+        offs = eng.offsets
+        self.windows = [(offs[names.index(c)] + a, offs[names.index(c)] + b) for c, a, b in inp.regions]
+        self.aligned_bases = inp.aligned_bases
+        self.stream_bytes = [int(d["pages"].buf.shape[0]) for d in self.types]
+        self.n_rec = [d["n_rec"] for d in self.types]
+        self.n_files = 2 + sum(1 for d in self.types if d["paf"] is not None)
+        self.heads, self.pages = True, [d["pages"] for d in self.types]
+        self.last = {}
+
+    def step(self):
+        eng = self.eng
+        from gci_amd.device import JoinInput
+        names = self.inp.names
+        runs = []
+        for d in self.types:
+            inputs = eng.paf_filter_text(d["paf"], d["paf_end"], names, FILTER[0], FILTER[1], FILTER[3]) if d["paf"] is not None else []
+            recs, noff = eng.bam_filter_pages(d["pages"], self.ref_sel, *FILTER, out=d["recs"], name_off=d["name_off"], check=False)
+            d["status"] = eng._status.clone()
+            inputs.append(JoinInput(recs, d["pages"].buf, noff, 0))
+            ivl, cnt = eng.name_join(inputs, OVLP, out=d["ivl"], count=d["count"], check=False, count_flank=FLANK)
+            d["jstatus"] = eng._status.clone()
+            d["fused"] = eng.depth_build_fused(ivl, cnt, FLANK, d["track"], want_text=False, want_sums=True,
+                                               issue=None if self.gaps is not None else (-1.0, 0.0, FLANK), counted=True)
+            if self.gaps is not None:
+                eng.gap_mask(d["track"], self.gaps)
+        eng.max2(self.types[0]["track"], self.types[1]["track"], out=self.two)
+        for d in self.types:
+            runs.append(d["fused"]["runs"] if self.gaps is None else eng.issue_scan(d["track"], -1.0, 0.0, FLANK))
+        runs.append(eng.issue_scan(self.two, -1.0, 0.0, FLANK))
+        reg = [eng.issue_scan_windows(t, self.windows, -1.0, 0.0) for t in (self.types[0]["track"], self.types[1]["track"], self.two)] \
+            if self.windows else None
+        self.last = dict(runs=runs, regions=reg)
+
+    def check(self):
+        from gci_amd._lib import GciError
+        for d in self.types:
+            for w, what in ((d["status"], "gci_bam_filter_pages"), (d["jstatus"], "gci_name_join")):
+                rec = ctypes.c_uint32(0)
+                st = self.eng.lib.gci_decode_status(int(w.item()) & ((1 << 64) - 1), ctypes.byref(rec))
+                if st != 0:
+                    raise GciError(st, "%s failed on record %d" % (what, rec.value))
+            if int(d["count"].item()) > d["ivl"].shape[0]:
+                raise GciError(-8, "bench output buffers too small")
+        return True
+
+    def step_algorithmic_bytes(self):
+        L = int(sum(self.own_lengths))
+        K = [int(d["count"].item()) for d in self.types]
+        k1 = sum(d["k1_bytes"] + 32 * d["n_rec"] for d in self.types)
+        paf = sum(int(d["paf"].shape[0]) for d in self.types if d["paf"] is not None)
+        join = sum(48 * d["n_rec"] + 16 * k for d, k in zip(self.types, K))
+        build = sum(28 * k + 4 * L for k in K)
+        rest = 12 * L + 4 * L + (2 * 4 * L if self.gaps is not None else 0)     # max2; scan of the merged track; scans of masked tracks
+        return {"k1_record_filter": k1, "paf_text": paf, "name_join": join, "depth_build": build, "max_and_scans": rest,
+                "total": k1 + paf + join + build + rest, "intervals": K, "bases": L, "text_bytes": 0}
+
+
+def parity_two_type(w, chosen):
+    """The timed result of a two-type workload against the oracle on whole contigs at full size: per read type the exact
+    restriction of filter() to those contigs (oracle.file1_on_contigs_mixed), the gap mask, the max, the three issue lists."""
+    from oracle import gci_oracle as O
+    from gci_amd import pipeline
+    O.build()
+    inp = w.inp
+    names = inp.names
+    chosen = [c for c in chosen if c in names]
+    tl = {c: inp.lengths[names.index(c)] for c in chosen}
+    ok = True
+    tracks = []
+    for t, d in zip((inp.hifi, inp.nano), w.types):
+        file1 = O.file1_on_contigs_mixed([t.paf.tobytes()] if t.paf is not None else [], [(t.bam.stream, t.bam.offsets, names)], names, chosen,
+                                         FILTER[0], FILTER[1], FILTER[2], FILTER[3], OVLP, heads=True)
+        depths = O.depth_build(file1, tl, FLANK)
+        O.merge_gaps_depths(depths, {c: v for c, v in inp.gaps.items() if c in tl} or None)
+        tracks.append(depths)
+    two = O.max2(tracks[0], tracks[1])
+    for k, (want, got_track) in enumerate(zip(tracks + [two], [w.types[0]["track"], w.types[1]["track"], w.two])):
+        bed = O.collapse_depth_range(want, -1, 0, FLANK, 0)
+        for c in chosen:
+            ci = names.index(c)
+            o, L = w.eng.offsets[ci], tl[c]
+            ok = ok and np.array_equal(got_track[o:o + L].cpu().numpy(), want[c])
+            a, b = pipeline._slice_bound(FLANK, L), pipeline._slice_bound(L - FLANK, L)
+            ok = ok and pipeline._issues_from_runs(w.last["runs"][k][ci], max(0, b - a), L, FLANK, 0) == bed[c]
+        if w.last["regions"] is not None:
+            for (c, a, b), got in zip(inp.regions, w.last["regions"][k]):
+                if c in tl:
+                    ok = ok and [tuple(x) for x in (np.asarray(got) + a).tolist()] == O.collapse_contig(want[c][a:b], -1, 0, 0, a)
+    return bool(ok), chosen
+
+
+def make_two_type_workload(eng_factory, rank, world, args, exchange, replicated):
+    from gci_amd import workloads
+    if world > 1:
+        sys.exit("bench.py --workload %s runs on one GPU (configs[3] / configs[4] at full size fit its 288 GB)" % args.workload)
+    config = 4 if args.workload == "genome4" else 5
+    cov_h = args.coverage if args.workload == "genome4" else (args.coverage if args.coverage != 40.0 else 100.0)
+    cov_o = args.coverage_ont if args.coverage_ont is not None else (40.0 if config == 4 else 20.0)
+    inp = workloads.genome_two_type(config, args.scale, cov_h, cov_o, verbose=True)
+    eng = eng_factory()
+    name = ("CHM13 whole genome (25 contigs, %d bp), --hifi %gx + --nano %gx, per read type one BAM (record pages) + one PAF" if config == 4 else
+            "diploid mat + pat (46 contigs, %d bp), --hifi %gx + --nano %gx, one BAM (record pages) per read type, 20 N gaps, -R regions") % (
+                sum(inp.lengths), cov_h, cov_o)
+    w = TwoTypeWorkload(eng, inp, name + ": 2 x (filters -> join -> depth build) -> gap mask -> max -> 3 issue scans")
+    return eng, w
 
 
 def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
@@ -819,9 +964,10 @@ def main():
         return Engine(device_index)
 
     from gci_amd import _lib
-    make = make_genome_workload if args.workload == "genome" else make_chr19_workload
+    two_type = args.workload in ("genome4", "diploid")
+    make = make_two_type_workload if two_type else make_genome_workload if args.workload == "genome" else make_chr19_workload
     eng, w = make(eng_factory, rank, world, args, exchange, args.force_replicated)
-    if args.count_in_build:
+    if args.count_in_build and not two_type:
         w.opts.counted = 0
 
     def fence():
@@ -931,8 +1077,9 @@ def main():
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
-        "config": {"workload": w.name + (" [scale %g]" % args.scale if args.workload == "genome" and args.scale != 1.0 else ""),
-                   "baseline_config": "configs[2]" if args.workload == "genome" else "configs[1]",
+        "config": {"workload": w.name + (" [scale %g]" % args.scale if args.workload != "chr19" and args.scale != 1.0 else ""),
+                   "baseline_config": {"genome": "configs[2]", "chr19": "configs[1]", "genome4": "configs[3] on one GPU",
+                                       "diploid": "configs[4] on one GPU"}[args.workload],
                    "input_files_per_gpu": w.n_files, "records_per_gpu": w.n_rec, "aligned_bases_per_step": aligned_total,
                    "bam_input": ("record pages (gci_bam_pages_*: %d-byte pages made on the device from the " % w.pages[0].page_bytes if w.pages else "")
                                 + ("heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream") + (")" if w.pages else ""),
@@ -958,7 +1105,20 @@ def main():
             if not ok:
                 print(json.dumps(out))
                 sys.exit("PARITY FAILURE: the multi-rank result differs from the oracle over all ranks' files")
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and two_type:
+        names = w.inp.names
+        chosen = ["chr14", "chr22", "chrM"] if args.workload == "genome4" else ["mat_chr14", "pat_chr21", "pat_chr22"]
+        hit = [c for c, segs in w.inp.gaps.items() if c in names]                     # a contig with a gap, one with a -R region
+        chosen += [c for c in (hit[:1] + [r[0] for r in w.inp.regions[:1]]) if c not in chosen and w.inp.lengths[names.index(c)] < 1.2e8]
+        ok, chosen = parity_two_type(w, chosen)
+        out["parity_vs_oracle_full_size"] = ok
+        out["parity_contigs"] = chosen
+        out["roofline"]["kernel"] = "k_tile_build (depth write; no text in this workload)"
+        out["cpu_baseline"] = None
+        if not ok:
+            print(json.dumps(out))
+            sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")
+    elif rank == 0 and world == 1:
         if args.workload == "genome":
             ok, chosen = parity_genome(w)
             out["parity_vs_oracle_full_size"] = ok

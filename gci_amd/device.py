@@ -485,7 +485,14 @@ class Engine:
         bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
         ends = np.cumsum([b.shape[0] for b in bufs], dtype=np.uint64) if bufs else np.zeros(0, np.uint64)
         text = np.concatenate(bufs) if bufs and int(ends[-1]) else np.zeros(1, np.uint8)
-        d_text = self.to_device(text)
+        return self.paf_filter_text(self.to_device(text), ends, targets, map_qual, mq_cutoff, iden_percent)
+
+    def paf_filter_text(self, d_text: torch.Tensor, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
+                        iden_percent: float) -> List[JoinInput]:
+        """paf_filter() over PAF text that is on the device already: the bytes of all files back to back, ends[i] = end offset
+        of file i."""
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        bufs = list(range(int(ends.shape[0])))
         tnames = [t.encode() for t in targets]
         tarr = (ctypes.c_char_p * max(len(tnames), 1))(*tnames)
         handle, line = ctypes.c_void_p(None), ctypes.c_uint64(0)

@@ -666,6 +666,7 @@ def _replicate(engine: Engine, ji: JoinInput) -> JoinInput:
         blob, off = torch.zeros(0, dtype=torch.uint8, device=engine.device), torch.zeros(1, dtype=torch.int64, device=engine.device)
     ex = shard.RecordExchange(n, int(blob.shape[0]), engine.device, via_host=SHARD.backend != "nccl")
     ex.send_recs[:n] = ji.recs
+    ex.send_recs[:n, 29] &= 3                          # the names travel packed: no longer GCI_REC_NAME16
     ex.send_names[:blob.shape[0]] = blob
     ex.send_off[:n + 1] = off
     g = ex.gather()

@@ -512,6 +512,80 @@ def to_paf_lines(rs: ReadSet, seed: int, split_frac: float = 0.02) -> List[str]:
     return lines
 
 
+def to_paf_text(rs: ReadSet, seed: int, split_frac: float = 0.02) -> np.ndarray:
+    """The PAF view of a read set as the file's bytes (uint8), built column by column with numpy -- to_paf_lines() formats
+    one Python string per line, minutes at genome scale.  The same kind of content: mapped, non-secondary records; `split_frac`
+    of the reads as 2 - 3 collinear blocks; `tp:A:P` behind the twelve mandatory columns."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    keep = np.flatnonzero(((rs.flag & 0x4) == 0) & ((rs.flag & 0x100) == 0))
+    n_ops = np.diff(rs.cigar_off)
+    tot = rs.op_totals()[keep]
+    span = rs.ref_span()[keep]
+    first = rs.cigar[np.minimum(rs.cigar_off[:-1], max(rs.cigar.shape[0] - 1, 0))][keep].astype(np.int64) if rs.cigar.shape[0] else np.zeros(keep.shape[0], np.int64)
+    q0 = np.where((n_ops[keep] > 0) & np.isin(first & 0xF, (OP_S, OP_H)), first >> 4, 0)          # leading clip (one op in these reads)
+    qlen = tot[:, OP_M] + tot[:, OP_I] + tot[:, OP_S] + tot[:, OP_EQ] + tot[:, OP_X] + tot[:, OP_H]
+    aln_q = tot[:, OP_M] + tot[:, OP_I] + tot[:, OP_EQ] + tot[:, OP_X]
+    alnlen = tot[:, OP_M] + tot[:, OP_I] + tot[:, OP_D] + tot[:, OP_EQ] + tot[:, OP_X]
+    ts = rs.pos[keep].astype(np.int64)
+    te = ts + span
+    nm = rs.nm[keep].astype(np.int64)
+    parts = np.where((rng.random(keep.shape[0]) < split_frac) & (span > 3000), rng.integers(2, 4, keep.shape[0]), 1)
+    row = np.repeat(np.arange(keep.shape[0]), parts)                # one PAF line per block
+    b = np.arange(row.shape[0]) - np.repeat(np.cumsum(parts) - parts, parts)
+    p = parts[row]
+    cut = lambda lo, hi, k: lo + (hi - lo) * k // p                  # noqa: E731
+    c_ts, c_te = cut(ts[row], te[row], b), cut(ts[row], te[row], b + 1)
+    c_qs, c_qe = cut(q0[row], (q0 + aln_q)[row], b), cut(q0[row], (q0 + aln_q)[row], b + 1)
+    c_al = np.where(p == 1, alnlen[row], c_te - c_ts)
+    c_nm = np.maximum(0, c_al - nm[row] // p)
+    ref = rs.ref_id[keep][row].astype(np.int64)
+    tlen = np.asarray([l for _, l in rs.contigs], dtype=np.int64)[ref]
+    tnames = [n.encode() for n, _ in rs.contigs]
+    tn_len = np.asarray([len(x) for x in tnames], dtype=np.int64)[ref]
+    tn_w = max(len(x) for x in tnames)
+    tn_mat = np.zeros((len(tnames), tn_w), dtype=np.uint8)
+    for i, x in enumerate(tnames):
+        tn_mat[i, :len(x)] = np.frombuffer(x, dtype=np.uint8)
+    names = rs.names[keep][row]
+    nw = names.dtype.itemsize
+    name_mat = np.frombuffer(names.tobytes(), dtype=np.uint8).reshape(-1, nw) if row.shape[0] else np.zeros((0, 1), np.uint8)
+    qn_len = np.char.str_len(names).astype(np.int64)
+    strand = np.where((rs.flag[keep][row] & 0x10) != 0, ord("-"), ord("+")).astype(np.uint8)
+    mapq = rs.mapq[keep][row].astype(np.int64)
+    nums = [qlen[row], c_qs, c_qe, None, None, tlen, c_ts, c_te, c_nm, c_al, mapq]     # columns 1..11 (None: strand, tname)
+    ndig = lambda v: np.where(v == 0, 1, np.floor(np.log10(np.maximum(v, 1))).astype(np.int64) + 1)     # noqa: E731
+    widths = [qn_len] + [ndig(v) if v is not None else None for v in nums]
+    widths[4], widths[5] = np.ones_like(qn_len), tn_len
+    tail = np.frombuffer(b"\ttp:A:P\n", dtype=np.uint8)
+    line_len = sum(widths) + 11 + tail.shape[0]
+    off = np.cumsum(line_len) - line_len
+    out = np.full(int(line_len.sum()), ord("\t"), dtype=np.uint8)
+    at = off.copy()
+    for k in range(nw):                                             # qname
+        m = qn_len > k
+        out[at[m] + k] = name_mat[m, k]
+    at = at + qn_len + 1
+    for col in range(1, 12):
+        v = nums[col - 1]
+        if col == 4:
+            out[at] = strand
+        elif col == 5:
+            for k in range(tn_w):
+                m = tn_len > k
+                out[at[m] + k] = tn_mat[ref[m], k]
+        else:
+            w, x = widths[col], v.copy()
+            for d in range(int(w.max()) if w.shape[0] else 0):      # digit d from the right
+                m = w > d
+                out[at[m] + w[m] - 1 - d] = (ord("0") + x[m] % 10).astype(np.uint8)
+                x //= 10
+        at = at + widths[col] + 1
+    at -= 1                                                          # the tab behind column 11 is the tail's own
+    for k in range(tail.shape[0]):
+        out[at + k] = tail[k]
+    return out
+
+
 def cig_lead_clip(rs: ReadSet, i: int) -> int:
     ops = rs.cigar[rs.cigar_off[i]:rs.cigar_off[i + 1]]
     q = 0

@@ -144,3 +144,139 @@ def genome_dual(scale: float = 1.0, coverage: float = 40.0, contigs: Optional[Se
         print("workload: %d contigs, %d bp, records per file %s, %.0f s on %d processes" % (
             len(ctg), total, [int(f.offsets.shape[0]) for f in files], time.time() - t0, procs), file=sys.stderr, flush=True)
     return GenomeInput(ctg, files)
+
+
+# ---- BASELINE configs[3] / configs[4]: two read types, BAM + PAF inputs ---------------------------------------------------------
+
+@dataclass
+class ReadTypeInput:
+    """One read type's inputs (`--hifi` or `--nano`): one BAM (heads stream) and, optionally, one PAF (the file's bytes) of the
+    same reads as another aligner reports them."""
+    bam: AlignmentFile
+    paf: Optional[np.ndarray]            # uint8: the PAF text
+    paf_aligned_bases: int               # sum of (tend - tstart) over its lines (the metric's numerator counts PAF lines so)
+    n_reads: int
+
+
+@dataclass
+class TwoTypeInput:
+    contigs: Tuple[Tuple[str, int], ...]
+    hifi: ReadTypeInput
+    nano: ReadTypeInput
+    gaps: dict                            # contig -> [(start, end)] N runs of the assembly (configs[4]: 20 of them)
+    regions: List[Tuple[str, int, int]]   # -R regions (configs[4])
+
+    @property
+    def names(self) -> List[str]:
+        return [n for n, _ in self.contigs]
+
+    @property
+    def lengths(self) -> List[int]:
+        return [int(l) for _, l in self.contigs]
+
+    @property
+    def aligned_bases(self) -> int:
+        return sum(t.bam.aligned_bases + t.paf_aligned_bases for t in (self.hifi, self.nano))
+
+
+def diploid_contigs(scale: float = 1.0) -> Tuple[Tuple[str, int], ...]:
+    """configs[4] geometry: two haplotype copies of the 23 nuclear CHM13 contigs with +-0.5 % length
+    jitter, `mat_chrN` / `pat_chrN` -- 46 contigs, ~6.2 Gb."""
+    rng = np.random.Generator(np.random.PCG64(synth.seed_for(5, 99)))
+    out = []
+    for hap in ("mat", "pat"):
+        for n, l in synth.CHM13[:23]:
+            out.append(("%s_%s" % (hap, n), max(20_000, int(l * scale * (1.0 + rng.uniform(-0.005, 0.005))))))
+    return tuple(out)
+
+
+def _gen_group_two(args):
+    """Worker: one group of contigs -> per read type (BAM heads bytes, offsets, aligned, k1 bytes, name bytes, per-contig
+    aligned, PAF text, PAF aligned, reads)."""
+    contigs, idx, g, cov, config, want_paf = args
+    sub = tuple(contigs[i] for i in idx)
+    out = []
+    for t, (kind, c) in enumerate((("hifi", cov[0]), ("ont", cov[1]))):
+        rs = synth.simulate_reads(sub, c, kind, seed=synth.seed_for(config, 2 * t) + 7 * g, long_cigar_frac=0.0005 if kind == "ont" else 0.0,
+                                  name_prefix=("m64011_g%02d/" % g) if kind == "hifi" else None)
+        if kind == "ont":                                       # names unique across groups (the generator numbers from 0)
+            rs.names = np.char.add(("g%02d-" % g).encode(), rs.names).astype("S")
+        rs.ref_id = (rs.ref_id + idx[0]).astype(np.int32)
+        rs.contigs = tuple(contigs)
+        mapped = (rs.flag & 4) == 0
+        per_contig = np.bincount(rs.ref_id[mapped], weights=np.maximum(rs.ref_span(), 1)[mapped].astype(np.float64),
+                                 minlength=len(contigs)).astype(np.int64)
+        s, o = synth.to_bam_stream(rs, heads=True)
+        first = bamfmt.parse_header(s).first_record
+        paf, paf_al = None, 0
+        if want_paf:
+            other = synth.perturb(rs, synth.seed_for(config, 2 * t + 1) + 7 * g)
+            other.contigs = tuple(contigs)
+            paf = synth.to_paf_text(other, synth.seed_for(config, 10 + t) + g)
+            keep = ((other.flag & 0x4) == 0) & ((other.flag & 0x100) == 0)
+            paf_al = int(other.ref_span()[keep].sum())
+        out.append((s[first:].copy(), (o - np.uint64(first)).astype(np.uint64), int(per_contig.sum()), _k1_algorithmic_bytes(rs),
+                    int(np.char.str_len(rs.names).sum()), per_contig, paf, paf_al, len(rs)))
+    return g, out
+
+
+def genome_two_type(config: int = 4, scale: float = 1.0, cov_hifi: float = 40.0, cov_ont: float = 40.0, procs: Optional[int] = None,
+                    verbose: bool = False) -> TwoTypeInput:
+    """config 4 = BASELINE configs[3]: CHM13, `--hifi` + `--nano`, per read type one BAM and one PAF (4 inputs).
+    config 5 = BASELINE configs[4]: diploid mat + pat (46 contigs), per read type one BAM, 20 N gaps, `-R` regions."""
+    ctg = (tuple((n, max(20_000, int(l * scale))) for n, l in synth.CHM13) if scale != 1.0 else tuple(synth.CHM13)) if config == 4 \
+        else diploid_contigs(scale)
+    total = sum(l for _, l in ctg)
+    groups = contig_groups(ctg, max(2.0e7, min(2.6e8, total / 12.0)))
+    if procs is None:
+        from . import hostio
+        procs = max(1, min(hostio.default_threads(), 8))       # ONT groups are GBs each: a handful of workers at a time
+    procs = max(1, min(int(procs), len(groups)))
+    tasks = [(ctg, idx, g, (cov_hifi, cov_ont), config, config == 4) for g, idx in enumerate(groups)]
+    t0 = time.time()
+    results = {}
+    if procs == 1:
+        for t in tasks:
+            g, out = _gen_group_two(t)
+            results[g] = out
+    else:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(procs, mp_context=mp.get_context("fork")) as ex:
+            for g, out in ex.map(_gen_group_two, sorted(tasks, key=lambda t: -sum(ctg[i][1] for i in t[1]))):
+                results[g] = out
+                if verbose:
+                    print("workload: group %d/%d done, %.0f s" % (len(results), len(groups), time.time() - t0), file=sys.stderr, flush=True)
+    hdr = np.frombuffer(bamfmt.encode_header([n for n, _ in ctg], [l for _, l in ctg]), dtype=np.uint8)
+    types = []
+    for t in range(2):
+        parts, offs, pafs, size = [hdr], [], [], int(hdr.shape[0])
+        aligned = k1 = nb = paf_al = reads = 0
+        per_contig = np.zeros(len(ctg), dtype=np.int64)
+        for g in range(len(groups)):
+            s, o, a, kb, n, pc, paf, pal, nr = results[g][t]
+            parts.append(s)
+            offs.append(o + np.uint64(size))
+            size += int(s.shape[0])
+            aligned, k1, nb, paf_al, reads = aligned + a, k1 + kb, nb + n, paf_al + pal, reads + nr
+            per_contig += pc
+            if paf is not None:
+                pafs.append(paf)
+            results[g][t] = None
+        bam = AlignmentFile(np.concatenate(parts), np.concatenate(offs) if offs else np.zeros(0, np.uint64), aligned, k1, nb, per_contig)
+        types.append(ReadTypeInput(bam, np.concatenate(pafs) if pafs else None, paf_al, reads))
+    gaps, regions = {}, []
+    if config == 5:
+        rng = np.random.Generator(np.random.PCG64(synth.seed_for(5, 77)))
+        for c in rng.choice(len(ctg), size=min(20, len(ctg)), replace=False):
+            n, l = ctg[int(c)]
+            a = int(rng.integers(l // 10, l // 2))
+            gaps.setdefault(n, []).append((a, a + int(rng.integers(1, 50_000))))
+        for c in sorted(rng.choice(len(ctg), size=min(12, len(ctg)), replace=False).tolist()):
+            n, l = ctg[c]
+            a = int(rng.integers(0, l // 2))
+            regions.append((n, a, min(l, a + int(rng.integers(10_000, max(20_000, l // 3))))))
+    if verbose:
+        print("workload: %d contigs, %d bp, reads hifi %d ont %d, %.0f s on %d processes" % (
+            len(ctg), total, types[0].n_reads, types[1].n_reads, time.time() - t0, procs), file=sys.stderr, flush=True)
+    return TwoTypeInput(ctg, types[0], types[1], gaps, regions)

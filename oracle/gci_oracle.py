@@ -638,6 +638,47 @@ def mean_depth(depths: Dict[str, np.ndarray]) -> float:
     return float(tot) / n
 
 
+def file1_on_contigs_mixed(paf_texts: Sequence[bytes], bams, targets: Sequence[str], chosen: Sequence[str], map_qual: int,
+                           mq_cutoff: int, clip_percent: float, iden_percent: float, ovlp_percent: float, heads: bool = False,
+                           tmp_dir: Optional[str] = None) -> Dict[str, tuple]:
+    """file1_on_contigs() for one filter() call that has PAF files as well (GCI.py:211-254, 272-301): `paf_texts` = the files'
+    bytes, `bams` = [(stream, rec_off, references)].  Exact for the same reason: the PAF scoring treats every query
+    independently (all lines of the query, in file order) and so does the join, so it is enough to push through the dict
+    logic every PAF line and every BAM record of the names that show up on the chosen contigs."""
+    import tempfile
+    tindex = {t: i for i, t in enumerate(targets)}
+    want = np.array([tindex[c] for c in chosen], dtype=np.int32)
+    cs = set(chosen)
+    keep: Set[str] = set()
+    arrays = []
+    for stream, off, refs in bams:
+        ref_sel = np.array([tindex.get(r, -1) for r in refs], dtype=np.int32)
+        a = bam_filter_arrays(stream, off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, heads)
+        arrays.append(a)
+        on = np.flatnonzero((a["passed"] != 0) & np.isin(a["contig"], want))
+        keep.update(read_names(stream, a["name_off"][on], a["name_len"][on]))
+    split = [t.decode().splitlines(keepends=True) for t in paf_texts]
+    for lines in split:
+        for ln in lines:
+            c = ln.split("\t", 6)
+            if len(c) > 5 and c[5] in cs:
+                keep.add(c[0])
+    with tempfile.TemporaryDirectory(prefix="gci_oracle_", dir=tmp_dir) as tmp:
+        paths = []
+        for k, lines in enumerate(split):
+            path = os.path.join(tmp, "f%d.paf" % k)
+            with open(path, "w") as f:
+                f.writelines(ln for ln in lines if ln.split("\t", 1)[0] in keep)
+            paths.append(path)
+        paf_dicts, hq = paf_filter(paths, targets, map_qual, mq_cutoff, iden_percent) if paths else ([], set())
+    dicts = list(paf_dicts)
+    for (stream, off, refs), a in zip(bams, arrays):
+        d, h = _dict_from_arrays(stream, a, targets, keep)
+        dicts.append(d)
+        hq |= h
+    return {q: seg for q, seg in name_join(dicts, hq, ovlp_percent).items() if seg[0] in cs}
+
+
 # ==============================================================================================
 # R14: the whole path as GCI() strings it together (GCI.py:991-1026), in memory
 # ==============================================================================================
