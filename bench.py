@@ -482,14 +482,14 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
     inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0), kind=args.reads,
                                 procs=max(1, workloads_default_procs() // max(1, world)))
     nper = len(inp.contigs)
-    owner = None
+    contig_owner = None
     if world > 1 and args.scaling == "strong":
         # the same genome as N = 1: contigs dealt to the ranks, every rank keeps the records of ITS contigs (what its
         # index-driven ingestion would read of each file: pipeline.bam_records_of_contigs)
         from gci_amd import shard
         from gci_amd.formats import bam as bamfmt
-        owner = shard.lpt_assign(inp.lengths, world)
-        own = [c for c, o in enumerate(owner) if o == rank]
+        contig_owner = shard.lpt_assign(inp.lengths, world)
+        own = [c for c, o in enumerate(contig_owner) if o == rank]
         mine = np.zeros(nper, dtype=bool)
         mine[own] = True
         for fobj in inp.files:
@@ -539,7 +539,7 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
     else:
         contigs, own = inp.contigs, list(range(nper))
     full = None
-    if owner is not None and args.verify_oracle and rank == 0:
+    if contig_owner is not None and args.verify_oracle and rank == 0:
         full = workloads.genome_dual(args.scale, args.coverage, contigs=base, kind=args.reads,
                                      procs=max(1, workloads_default_procs() // max(1, world)))     # the undivided files, for the oracle
     eng = eng_factory()
@@ -548,11 +548,14 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
                  name="CHM13 whole genome (%d contigs, %d bp)%s, HiFi %gx by two aligners (2 BAM files as heads streams, "
                       "-op join), filter x2 -> join -> depth -> issue scan -> depth text" % (
                           nper, sum(l for _, l in inp.contigs),
-                          (" x %d haplotypes" % world if owner is None else " over %d GPUs" % world) if world > 1 else "", args.coverage)
+                          (" x %d haplotypes" % world if contig_owner is None else " over %d GPUs" % world) if world > 1 else "", args.coverage)
                       + ("" if args.reads == "hifi" else " [ONT reads]"),
-                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)}, k1=args.k1, sharded=owner is not None)
-    w.owner_of_contig = owner
+                 algo={"k1_bytes": sum(f.k1_bytes for f in inp.files)}, k1=args.k1, sharded=contig_owner is not None)
+    w.owner_of_contig = contig_owner
     w.full_input = full
+    if rank == 0:
+        print("bench: world %d, scaling %s, join %s" % (world, args.scaling if world > 1 else "-", "sharded by name hash" if w.sharded else
+              "name check + local / replicated" if w.exchange else "local"), file=sys.stderr, flush=True)
     w.aligned_bases = inp.aligned_bases
     w.inp = inp if ((rank == 0 and world == 1) or args.verify_oracle) else None
     if w.inp is None:

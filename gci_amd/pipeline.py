@@ -277,6 +277,55 @@ GPU_INFLATE_MAX = int(os.environ.get("GCI_GPU_INFLATE_MAX", str(32 << 30)))
 BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
 
 
+# What the record filter runs over.  "pages" (default): the records are laid out as RECORD PAGES on the device first
+# (gci_bam_pages_*: the ~400 bytes of a record read_sam looks at, 16-byte aligned, no offset table) and filtered there
+# (gci_bam_filter_pages) -- the kernel bench.py times; the inflated stream (SEQ / QUAL: 98 % of it) is released as soon as its
+# pages exist, the names stay addressable inside the pages.  "stream": gci_bam_filter[_heads] over the stream itself.
+K1_MODE = os.environ.get("GCI_K1", "pages")
+
+
+def _filter_stream(engine: Engine, d_stream: torch.Tensor, d_off: torch.Tensor, has_seq: bool, ref_sel: torch.Tensor, filt,
+                   rec_idx_base: int = 0) -> JoinInput:
+    """K1 over the records of an inflated BAM stream (has_seq) or a heads stream -> join input (records + where their names are)."""
+    map_qual, mq_cutoff, clip_percent, iden_percent = filt
+    if K1_MODE == "pages":
+        pages = engine.bam_pages(d_stream, d_off, has_seq)
+        recs, noff = engine.bam_filter_pages(pages, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base)
+        return JoinInput(recs, pages.buf, noff, 0)
+    recs = engine.bam_filter(d_stream, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base,
+                             heads=not has_seq)
+    return JoinInput(recs, d_stream, d_off, 36)
+
+
+def _keep_part(engine: Engine, ji: JoinInput) -> JoinInput:
+    """What is kept of one run of a file that goes through the device run by run: the records and their names -- the pages
+    as they are (they ARE the compact form), or, of a whole stream, the names packed (gci_pack_names)."""
+    if ji.name_delta == 0:
+        return JoinInput(ji.recs.clone(), ji.name_base, ji.name_off.clone(), 0)
+    names, noff = engine.pack_names(ji)
+    recs = ji.recs.clone()
+    return JoinInput(recs, names.clone(), noff[:-1].clone(), 0)
+
+
+def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
+    dev = engine.device
+    if not parts:
+        return JoinInput(torch.zeros((0, 32), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.uint8, device=dev),
+                         torch.zeros(1, dtype=torch.int64, device=dev), 0)
+    if len(parts) == 1:
+        return parts[0]
+    offs, base = [], 0
+    for p in parts:
+        offs.append(p.name_off + base)
+        base += (int(p.name_base.shape[0]) + 15) // 16 * 16            # (pages keep their 16-byte phase: GCI_REC_NAME16)
+    names = torch.zeros(max(base, 1), dtype=torch.uint8, device=dev)
+    at = 0
+    for p in parts:
+        names[at:at + int(p.name_base.shape[0])] = p.name_base
+        at += (int(p.name_base.shape[0]) + 15) // 16 * 16
+    return JoinInput(torch.cat([p.recs for p in parts]), names, torch.cat(offs), 0)
+
+
 def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int,
                         upload=None) -> Optional[JoinInput]:
     """ingest = "gpu".  A file whose inflated stream fits GCI_GPU_INFLATE_MAX stays on the device whole (the join reads
@@ -299,8 +348,7 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
             return None
         if used != total:
             raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % (total - used))
-        recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent)
-        return JoinInput(recs, d_bam, d_off, 36)
+        return _filter_stream(engine, d_bam, d_off, True, ref_sel, filt)
     if upload is not None:                                  # larger than it looked: uploaded run by run instead
         upload["future"].result()
         upload["pool"].shutdown()
@@ -312,8 +360,8 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
             a, acc = i, 0
         acc += sz
     groups.append((a, len(isz)))
-    rec_parts, name_parts, off_parts = [], [], []
-    carry, start, n_done, name_base = None, hdr.first_record, 0, 0
+    parts: List[JoinInput] = []
+    carry, start, n_done = None, hdr.first_record, 0
     for lo, hi in groups:
         p0 = int(pos[lo])
         try:
@@ -332,26 +380,17 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
         if int(d_off.shape[0]) == 0:
             continue
         try:
-            recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=n_done)
+            ji = _filter_stream(engine, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
         except GciError as e:
             if e.rec >= 0:
                 e.rec += n_done
-            e.contig = tindex[name]                 # (the ranks agree on the error of the earliest contig: _agree_on_error)
             raise
-        names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
-        rec_parts.append(recs.clone())
-        name_parts.append(names.clone())
-        off_parts.append(noff[:-1] + name_base)
-        name_base += int(names.shape[0])
+        parts.append(_keep_part(engine, ji))
         n_done += int(d_off.shape[0])
-        del d_buf, d_off
+        del d_buf, d_off, ji
     if carry is not None:
         raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % int(carry.shape[0]))
-    dev = engine.device
-    recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
-    names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
-    noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
-    return JoinInput(recs, names if names.shape[0] else torch.zeros(1, dtype=torch.uint8, device=dev), noff, 0)
+    return _concat_parts(engine, parts)
 
 
 def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
@@ -419,8 +458,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
             with heads:
                 hdr = bamfmt.parse_header(heads.stream)
                 d_bam, d_off = engine.to_device(heads.stream), engine.to_device(heads.offsets)
-            recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
-            return JoinInput(recs, d_bam, d_off, 36)
+            return _filter_stream(engine, d_bam, d_off, False, ref_sel_for(hdr), filt)
 
     pos, isz = hostio.bgzf_blocks(np.asarray(raw))
     if int(isz.sum()) <= chunk_bytes:
@@ -428,8 +466,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         hdr = bamfmt.parse_header(stream)
         offs, _ = hostio.bam_record_offsets(stream)
         d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
-        recs = engine.bam_filter(d_bam, d_off, ref_sel_for(hdr), map_qual, mq_cutoff, clip_percent, iden_percent)
-        return JoinInput(recs, d_bam, d_off, 36)
+        return _filter_stream(engine, d_bam, d_off, True, ref_sel_for(hdr), filt)
 
     # ---- streamed ------------------------------------------------------------------------------------------
     groups, a, acc = [], 0, 0
@@ -444,9 +481,9 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         lo, hi = g
         return hostio.bgzf_inflate(np.asarray(raw[int(pos[lo]):int(pos[hi])]), threads=nthreads, check_crc=BGZF_CRC)
 
-    rec_parts, name_parts, off_parts = [], [], []
+    parts: List[JoinInput] = []
     carry = np.zeros(0, dtype=np.uint8)
-    n_done, name_base, hdr, ref_sel = 0, 0, None, None
+    n_done, hdr, ref_sel = 0, None, None
     with ThreadPoolExecutor(1) as ex:
         nxt = ex.submit(inflate, groups[0])
         for k in range(len(groups)):
@@ -468,28 +505,19 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
                 continue
             d_buf, d_off = engine.to_device(buf[:used]), engine.to_device(offs)
             try:
-                recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent,
-                                         rec_idx_base=n_done)
+                ji = _filter_stream(engine, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
             except GciError as e:
                 if e.rec >= 0:
                     e.rec += n_done
                 raise
-            names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
-            rec_parts.append(recs.clone())
-            name_parts.append(names.clone())
-            off_parts.append(noff[:-1] + name_base)
-            name_base += int(names.shape[0])
+            parts.append(_keep_part(engine, ji))
             n_done += int(offs.shape[0])
-            del d_buf, d_off
+            del d_buf, d_off, ji
     if carry.shape[0]:
         raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % carry.shape[0])
     if hdr is None:
         raise bamfmt.BAMError("no BAM header in %s" % path)
-    dev = engine.device
-    recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
-    names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
-    noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
-    return JoinInput(recs, names if names.shape[0] else torch.zeros(1, dtype=torch.uint8, device=dev), noff, 0)
+    return _concat_parts(engine, parts)
 
 
 def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, iden_percent=0.9,  # noqa: A001
@@ -586,12 +614,12 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
         raw = np.fromfile(path, dtype=np.uint8)
         with hostio.bam_heads(raw, threads=nthreads, check_crc=BGZF_CRC) as heads:
             d_bam, d_off = engine.to_device(heads.stream), engine.to_device(heads.offsets)
-        recs = engine.bam_filter(d_bam, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, heads=True)
-        return JoinInput(recs, d_bam, d_off, 36)
+        return _filter_stream(engine, d_bam, d_off, False, ref_sel, filt)
     raw = np.memmap(path, dtype=np.uint8, mode="r")
     n_raw = int(raw.shape[0])
     on_device = os.environ.get("GCI_BAM_INGEST", "gpu") == "gpu"
-    rec_parts, name_parts, off_parts, name_base, n_done = [], [], [], 0, 0
+    parts: List[JoinInput] = []
+    n_done = 0
     for r, name in enumerate(hdr.references):
         if name not in own_set or index[r] is None:
             continue
@@ -637,21 +665,16 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
         if d_off.shape[0] == 0:
             continue
         try:
-            recs = engine.bam_filter(d_buf, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=n_done)
+            ji = _filter_stream(engine, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
         except GciError as e:
             if e.rec >= 0:
                 e.rec += n_done
+            e.contig = tindex[name]                 # (the ranks agree on the error of the earliest contig: _agree_on_error)
             raise
-        names, noff = engine.pack_names(JoinInput(recs, d_buf, d_off, 36))
-        rec_parts.append(recs.clone())
-        name_parts.append(names.clone())
-        off_parts.append(noff[:-1] + name_base)
-        name_base += int(names.shape[0])
+        parts.append(_keep_part(engine, ji))
         n_done += int(d_off.shape[0])
-    recs = torch.cat(rec_parts) if rec_parts else torch.zeros((0, 32), dtype=torch.uint8, device=dev)
-    names = torch.cat(name_parts) if name_parts else torch.zeros(1, dtype=torch.uint8, device=dev)
-    noff = torch.cat(off_parts) if off_parts else torch.zeros(1, dtype=torch.int64, device=dev)
-    return JoinInput(recs, names if names.shape[0] else torch.zeros(1, dtype=torch.uint8, device=dev), noff, 0)
+        del d_buf, d_off, ji
+    return _concat_parts(engine, parts)
 
 
 def _replicate(engine: Engine, ji: JoinInput) -> JoinInput:

@@ -75,3 +75,32 @@ def test_genome_dual_bam_full_path_matches_oracle(engine, oracle, genome, join_m
         del want, got, text
     del fused, track
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("config", [4, 5])
+def test_two_read_types_bam_and_paf_match_oracle(engine, oracle, config):
+    """BASELINE configs[3] (CHM13, --hifi + --nano, per read type one BAM + one PAF) and configs[4] (diploid mat + pat, 46
+    contigs, HiFi 100x + ONT, 20 N gaps, -R regions) through the device path of one GPU -- bench.py's TwoTypeWorkload: K2 on
+    the device, the paged record filter on HiFi and on ONT (CIGARs in the blob, chunk queue), PAF-then-BAM joins, two builds,
+    gap masks, per-base max, three issue scans, region scans -- against the oracle's exact restriction to whole contigs
+    (oracle.file1_on_contigs_mixed), tracks, issue lists and region lists.
+
+    GCI_TEST_TWO_TYPE_SCALE (default 0.1) scales every contig; `python bench.py --workload genome4 | diploid` runs the same at
+    full size (profiles/)."""
+    import bench
+    scale = float(os.environ.get("GCI_TEST_TWO_TYPE_SCALE", "0.1"))
+    inp = workloads.genome_two_type(config, scale, 40.0 if config == 4 else 100.0, 40.0 if config == 4 else 20.0)
+    assert len(inp.contigs) == (25 if config == 4 else 46) and (inp.hifi.paf is not None) == (config == 4)
+    w = bench.TwoTypeWorkload(engine, inp, "test")
+    w.step()
+    assert w.check()
+    names = inp.names
+    chosen = ["chr14", "chr22", "chrM"] if config == 4 else ["mat_chr14", "pat_chr21", "pat_chr22"]
+    chosen += [c for c in (list(inp.gaps)[:1] + [r[0] for r in inp.regions[:1]]) if c not in chosen]
+    ok, used = bench.parity_two_type(w, chosen)
+    assert ok and len(used) >= 3
+    # every long ONT CIGAR went through the blob and the chunk queue: ONT records pass the filter at all
+    assert int(w.types[1]["count"].item()) > 0.3 * inp.nano.n_reads
+    del w
+    import torch
+    torch.cuda.empty_cache()
