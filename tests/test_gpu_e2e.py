@@ -167,10 +167,14 @@ def test_empty_and_ragged_inputs(engine, oracle, tmp_path):
     assert gzip.open(str(tmp_path / "e.depth.gz"), "rb").read() == oracle.depth_text(host)
 
 
-def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("k1", ["pages", "stream"])
+def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkeypatch, k1):
     """A BAM larger than the chunk budget is streamed: groups of BGZF members, partial records carried over, K1 per
-    chunk, packed names.  Same join input content, same depth, for chunk sizes that cut records at every phase."""
+    chunk, the record pages of every run kept (k1 = pages, the default) or the names packed (GCI_K1=stream: the record
+    filter over the inflated stream itself).  Same join input content, same depth, for chunk sizes that cut records at
+    every phase."""
     from gci_amd.formats import bam
+    monkeypatch.setattr(pipeline, "K1_MODE", k1)
     contigs = (("a", 600_000), ("b", 250_000))
     rs = synth.simulate_reads(contigs, 12, "hifi", seed=91)
     dup = rs.take(np.arange(0, len(rs), 11))                        # repeated names far apart in the file
@@ -198,11 +202,12 @@ def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkey
                 ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, ingest=ingest)
                 assert ji.name_delta == 0 and ji.recs.shape[0] == len(rs)
             monkeypatch.undo()
+            monkeypatch.setattr(pipeline, "K1_MODE", k1)
             packed = True
         else:
             ji = pipeline.bam_join_input(engine, p, targets, filt, threads=4, chunk_bytes=chunk, ingest=ingest)
         assert ji.recs.shape[0] == len(rs)
-        assert (ji.name_delta == 0) == packed
+        assert (ji.name_delta == 0) == (packed or k1 == "pages")
         ivl, cnt = engine.name_join([ji], 0.9)
         track = engine.new_track()
         engine.depth_build(ivl, cnt, 15, track)

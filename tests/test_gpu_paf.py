@@ -9,7 +9,7 @@ import pytest
 from golden_util import inputs, manifest
 from gci_amd._lib import GciError, GCI_E_MALFORMED, GCI_E_ZERO_DIV, REC_HQ
 from gci_amd.device import REC_DTYPE
-from gci_amd.pipeline import paf_filter_py
+from paf_ref import paf_filter_py
 
 pytestmark = pytest.mark.gpu
 

@@ -93,7 +93,8 @@ def test_native_paf_filter_randomised(oracle, tmp_path):
     """gci_paf_filter (native) against the plain-Python statement and the oracle: many queries over few targets so
     that rank ties and touching / nested blocks happen, three files (the block table is never reset), CRLF line ends,
     extra columns, names the targets list does not hold; and the lines the reference would raise on."""
-    from gci_amd.pipeline import paf_filter, paf_filter_py
+    from gci_amd.pipeline import paf_filter
+    from paf_ref import paf_filter_py
     from gci_amd._lib import GciError
     rng = np.random.default_rng(11)
     targets = ["t%d" % i for i in range(6)]
