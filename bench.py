@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip numbers (2) and (3) of SURVEY.md 8(d): the device pipeline incl. H2D / D2H and the "
                          "command-line wall time on a chr19 BAM with realistic SEQ / QUAL entropy")
+    ap.add_argument("--ingest-gb", type=float, default=64.0,
+                    help="survey_8d.3b: GB of realistic-entropy BGZF streamed from host RAM through the command line's ingestion "
+                         "(0: skip)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="chr19 workload, 1 GPU: N > 1 runs consecutive steps on N streams with a context each")
     ap.add_argument("--heads", action="store_true", help="chr19 workload: feed the heads stream instead of the whole stream")
@@ -206,7 +209,11 @@ class Workload:
                                            alternate=True, via_host=VIA_HOST)
         self.check_names.n_conf = self.totals[nc + 1:nc + 2].view(self.torch.int32)[0:1]   # counted straight into the totals
 
-    def step(self):
+    def step_records(self):
+        """The record side of a step alone: K1 per file and the join (with the build's counting pass)."""
+        self.step(records_only=True)
+
+    def step(self, records_only=False):
         eng, lib, ctx = self.eng, self.eng.lib, self.eng.ctx
         from gci_amd._lib import JoinFile
         chk = eng._chk
@@ -257,6 +264,8 @@ class Workload:
         else:
             chk(lib.gci_name_join(ctx, jf, F, OVLP, _p(self.contig_map), _p(self.ivl), int(self.ivl.shape[0]),
                                   _p(self.count), _p(self.status[F:F + 1])), "gci_name_join")
+        if records_only:
+            return
         # fused build: depth + per-contig sums + text byte offsets + issue-run boundaries from one pass over
         # the per-tile event buckets (no HBM re-read of the track), then depth + decimal text in the second
         o = self.opts
@@ -821,20 +830,38 @@ def verify_strong_against_oracle(w):
 
 def device_pipeline_number(eng, w):
     """(2): the same step INCLUDING the H2D of the heads streams + offsets and the D2H of what leaves the device (the
-    issue-run keys and the .depth.gz members written by the GPU)."""
+    issue-run keys and the .depth.gz members written by the GPU).  The host buffers are pinned (page-locked once, outside the
+    window: what a host that streams files through fixed staging buffers has), the uploads run on a copy stream of their own,
+    and file f + 1 travels while file f is laid out as record pages and filtered."""
     import torch
     from gci_amd.device import JoinInput
     inp = w.inp
     best = None
     ref_sel = w.ref_sel
+    t_pin = time.perf_counter()
+    pinned = [(torch.from_numpy(f.stream).pin_memory(), torch.from_numpy(f.offsets.view(np.int64)).pin_memory()) for f in inp.files]
+    t_pin = time.perf_counter() - t_pin
+    copy = torch.cuda.Stream()
+    dev = eng.device
     for _ in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        ups = []
+        with torch.cuda.stream(copy):
+            for h_s, h_o in pinned:
+                d_s = torch.empty(h_s.shape, dtype=torch.uint8, device=dev)
+                d_o = torch.empty(h_o.shape, dtype=torch.int64, device=dev)
+                d_s.copy_(h_s, non_blocking=True)
+                d_o.copy_(h_o, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy)
+                ups.append((d_s, d_o, ev))
         ins = []
-        for fobj in inp.files:
-            d_s, d_o = eng.to_device(fobj.stream), eng.to_device(fobj.offsets)
-            recs = eng.bam_filter(d_s, d_o, ref_sel, *FILTER, heads=True, check=False)
-            ins.append(JoinInput(recs, d_s, d_o, 36))
+        for d_s, d_o, ev in ups:
+            torch.cuda.current_stream().wait_event(ev)
+            pg = eng.bam_pages(d_s, d_o, False)
+            recs, noff = eng.bam_filter_pages(pg, ref_sel, *FILTER, check=False)
+            ins.append(JoinInput(recs, pg.buf, noff, 0))
         ivl, cnt = eng.name_join(ins, OVLP, count_flank=FLANK, check=False, out=w.ivl)
         fused = eng.depth_build_fused(ivl, cnt, FLANK, w.track, want_text=False, want_sums=True, issue=(-1.0, 0.0, FLANK),
                                       counted=True)
@@ -842,11 +869,47 @@ def device_pipeline_number(eng, w):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-        del ins
-    return {"seconds": best, "gbases_per_s": w.aligned_bases / best / 1e9,
-            "h2d_bytes": int(sum(f.stream.shape[0] + 8 * f.offsets.shape[0] for f in inp.files)),
-            "d2h_depth_gz_member_bytes": int(sum(len(b) for b in blobs)),
-            "note": "pageable host memory, one upload per file, no overlap of copy and compute"}
+        del ins, ups
+    h2d = int(sum(f.stream.shape[0] + 8 * f.offsets.shape[0] for f in inp.files))
+    del pinned
+    return {"seconds": best, "gbases_per_s": w.aligned_bases / best / 1e9, "h2d_bytes": h2d, "h2d_gb_per_s_if_all_of_it": h2d / best / 1e9,
+            "d2h_depth_gz_member_bytes": int(sum(len(b) for b in blobs)), "pinning_seconds_outside_the_window": t_pin,
+            "note": "pinned host memory, uploads on a copy stream: file 2 travels while file 1 is paged + filtered; record pages are "
+                    "made on the device inside the window (gci_bam_pages_*); PCIe Gen5 x16 bounds it (63 GB/s spec)"}
+
+
+def cli_shaped_step(eng, w, steps):
+    """The step as the command line runs it (GCI.py:99-143 through gci_amd/pipeline.py): no decimal text in HBM -- `.depth.gz`
+    leaves the device as the gzip members the GPU writes from the track (gci_depth_deflate_*), D2H of those members included.
+    The headline step keeps the text (the harder output)."""
+    import torch
+    o = w.opts
+    keep = o.want_text
+    o.want_text = 0
+    try:
+        def one():
+            chk, lib, ctx = eng._chk, eng.lib, eng.ctx
+            w.step_records()
+            chk(lib.gci_depth_build_begin(ctx, _p(w.ivl), _p(w.count), int(w.ivl.shape[0]), ctypes.byref(o)), "gci_depth_build_begin")
+            chk(lib.gci_depth_build_finish(ctx, _p(w.track), None, 0), "gci_depth_build_finish")
+            return eng.depth_deflate(w.track)
+        blobs = one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            blobs = one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        o.want_text = keep
+    L = int(sum(w.own_lengths))
+    members = int(sum(len(b) for b in blobs))
+    algo = w.step_algorithmic_bytes()
+    total = algo["k1_record_filter"] + algo["name_join"] + 28 * algo["intervals"] + 4 * L + 2 * 4 * L + members
+    return {"ms_per_step": dt * 1e3, "gbases_per_s": w.aligned_bases / dt / 1e9, "depth_gz_member_bytes": members,
+            "algorithmic_bytes_per_step": total, "hbm_frac": total / dt / 1e9 / HBM_PEAK_GBS,
+            "note": "filter x2 -> join -> depth build without text -> .depth.gz members written by the GPU from the track (two reads "
+                    "of it) and copied to the host"}
 
 
 def two_in_flight(eng, w, args, device_index):
@@ -888,6 +951,71 @@ def two_in_flight(eng, w, args, device_index):
     del w2, e2
     return {"ms_per_step": dt / args.steps * 1e3, "gbases_per_s": w.aligned_bases * args.steps / dt / 1e9,
             "k_tile_build_avg_launch_ms": ms / max(1, n), "status_ok": bool(ok), "same_track_as_one_in_flight": same}
+
+
+def ingest_number(coverage, gb):
+    """(3b): the ingestion at the size the metric is quoted on.  `gb` GB of BGZF with realistic SEQ / QUAL entropy in host RAM
+    (the members of a chr19 40x HiFi BAM repeated: header once, its 3.66 GB of records as members of their own, k times) go
+    through what the command line does with a file too large to inflate whole (pipeline._bam_join_input_gpu: runs of members
+    uploaded, inflated on the device with the CRC checked, the records walked, laid out as record pages and filtered; the
+    partial record a run ends in carried to the next) -- GB/s in and out, and the projection for the two 40x CHM13 files."""
+    import shutil
+    import tempfile
+    import torch
+    from gci_amd import hostio, pipeline, synth
+    from gci_amd.formats import bam as bamfmt, bgzf
+    from gci_amd.device import Engine
+    rs = synth.simulate_reads(synth.CHR19, coverage, "hifi", seed=synth.seed_for(2, 0))
+    stream, _ = synth.to_bam_stream(rs, seq_qual="random", seed=7)
+    n_rec = len(rs)
+    del rs
+    first = bamfmt.parse_header(stream).first_record
+    thr = hostio.default_threads()
+    head = np.frombuffer(bgzf.compress(stream[:first].tobytes(), 1, 1)[:-len(bgzf.BGZF_EOF)], dtype=np.uint8)
+    body = np.frombuffer(bgzf.compress(stream[first:].tobytes(), 1, thr)[:-len(bgzf.BGZF_EOF)], dtype=np.uint8)
+    body_inflated = int(stream.shape[0]) - first
+    del stream
+    k = max(1, int(round(gb * 1e9 / body.shape[0])))
+    raw = np.empty(head.shape[0] + k * body.shape[0] + len(bgzf.BGZF_EOF), dtype=np.uint8)
+    raw[:head.shape[0]] = head
+    for i in range(k):
+        raw[head.shape[0] + i * body.shape[0]:head.shape[0] + (i + 1) * body.shape[0]] = body
+    raw[-len(bgzf.BGZF_EOF):] = np.frombuffer(bgzf.BGZF_EOF, dtype=np.uint8)
+    tmp = tempfile.mkdtemp(prefix="gci_ingest_")
+    try:
+        hp = os.path.join(tmp, "header.bam")                     # (the run-by-run path reads the BAM header from the file)
+        with open(hp, "wb") as f:
+            f.write(head.tobytes() + bgzf.BGZF_EOF)
+        eng = Engine(0)
+        targets = ["chr19"]
+
+        def ref_sel_for(hdr):
+            return eng.to_device(np.zeros(1, dtype=np.int32))
+        t0 = time.perf_counter()
+        pos, isz = hostio.bgzf_blocks(raw)
+        t_table = time.perf_counter() - t0
+        keep = pipeline.GPU_INFLATE_MAX
+        pipeline.GPU_INFLATE_MAX = 0                             # run by run, as for a file of this size
+        try:
+            t0 = time.perf_counter()
+            ji = pipeline._bam_join_input_gpu(eng, hp, raw, pos, isz, ref_sel_for, FILTER, pipeline.BAM_CHUNK_BYTES)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            pipeline.GPU_INFLATE_MAX = keep
+        got = int(ji.recs.shape[0])
+        inflated = k * body_inflated + first
+        out = {"seconds": dt, "member_table_seconds": t_table, "bgzf_bytes": int(raw.shape[0]), "inflated_bytes": inflated,
+               "records": got, "records_expected": k * n_rec, "gb_per_s_in": raw.shape[0] / dt / 1e9, "gb_per_s_out": inflated / dt / 1e9,
+               "kept_on_device_bytes": int(ji.name_base.shape[0] + ji.recs.shape[0] * 32 + ji.name_off.shape[0] * 8),
+               "deflate_ratio": inflated / raw.shape[0],
+               "projected_seconds_configs2_two_40x_files": 2 * 190e9 / (inflated / dt),
+               "note": "pageable host memory; runs of %d MiB inflated, each: upload -> inflate + CRC on the device -> record walk -> "
+                       "record pages -> paged filter; no overlap between the runs yet" % (pipeline.BAM_CHUNK_BYTES >> 20)}
+        del ji, eng
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cli_number(coverage):
@@ -1052,12 +1180,14 @@ def main():
 
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload (they cannot be
     # collected from inside this process: rocprofv3 wraps the command; tools/prof_pmc.sh, profiles/)
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         tag = "genome" if args.workload == "genome" else "chr19"
         tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_%s_traffic.json" % tag))
         if tj and args.scale == 1.0 and args.coverage == 40.0 and (args.workload == "genome" or args.contig_len == CHR19_LEN):
             traffic = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))["hbm_bytes_per_launch"]
+            traffic_source = "profiles/%s (stored: the PMC passes of an earlier run of this workload -- rocprofv3 wraps the command, this " \
+                             "process cannot collect them)" % tj[-1]
     except Exception:
         traffic = None
 
@@ -1094,7 +1224,7 @@ def main():
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
         "roofline": {"bound": "hbm", "kernel": "k_tile_build (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
         "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": algo},
@@ -1132,6 +1262,7 @@ def main():
             survey = {"1_kernels_only_gbases_per_s": out["value"]}
             if not args.no_e2e and args.inflight == 1:
                 out["two_steps_in_flight"] = two_in_flight(eng, w, args, device_index)
+            out["cli_shaped_step"] = cli_shaped_step(eng, w, max(3, args.steps // 2))
             if not args.no_e2e:
                 survey["2_device_pipeline_incl_h2d_d2h"] = device_pipeline_number(eng, w)
             if not args.no_cpu_baseline:
@@ -1152,6 +1283,9 @@ def main():
             w.inp = None
             if not args.no_e2e:
                 survey["3_command_line_chr19_realistic_bam"] = cli_number(args.coverage)
+                if args.ingest_gb > 0:
+                    torch.cuda.empty_cache()
+                    survey["3b_ingest_genome"] = ingest_number(args.coverage, args.ingest_gb)
             out["survey_8d"] = survey
         elif not args.no_cpu_baseline:
             cdt, depths, bed, text, mean = cpu_baseline_chr19(w)

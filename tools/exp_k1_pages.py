@@ -54,6 +54,9 @@ def main():
     del inp
     for v in variants:
         env = dict(os.environ, GCI_VARIANT=v)
+        v, _, pb = v.partition("@")                              # name@page_bytes
+        if pb:
+            env["GCI_PAGE_BYTES"] = pb
         if v != "product":
             env["GCI_LIB_PATH"] = os.path.join(ROOT, "gci_amd", "csrc", "libgci_hip_%s.so" % v)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, check=False)
