@@ -143,10 +143,15 @@ def load() -> ctypes.CDLL:
             raise GciError(GCI_E_INVALID, "libgci_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` -- there is no CPU fallback" % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
+        # GCI_HOST_ONLY=1: a build of the host-side entry points alone (host_io.cpp through g++ with the sanitizers,
+        # tools/asan_host.sh): the device exports are absent, nothing that needs them can run
+        host_only = os.environ.get("GCI_HOST_ONLY") == "1"
         for name, res, args in EXPORTS:
+            if host_only and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)           # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.gci_abi_version() != 1:
+        if not host_only and lib.gci_abi_version() != 1:
             raise GciError(GCI_E_INVALID, "libgci_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -249,11 +249,17 @@ def main(argv=None):
     N GPUs of one node, one process per GPU: rank 0 prints and writes what a single process would."""
     argv = sys.argv if argv is None else argv
     argv, gpus = _split_gpus(list(argv))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # A contig-sharded run is opted into: by --gpus, or by a launch under torch.distributed.run (which sets RANK, LOCAL_RANK and
+    # MASTER_ADDR for every process) -- a WORLD_SIZE left in the environment by a scheduler does not make one.
+    launched = all(k in os.environ for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     if gpus > 1 and world == 1:                                      # re-launch, one process per GPU
         port = 29600 + os.getpid() % 2000
+        entry = os.path.abspath(argv[0])
+        if not os.path.isfile(entry) or os.path.basename(entry) == "cli.py":     # (started as `python -m gci_amd.cli`)
+            entry = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "GCI.py")
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + argv[1:])
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), entry] + argv[1:])
     if world > 1:
         from . import shard
         ctx = shard.Context()
