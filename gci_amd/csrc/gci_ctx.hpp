@@ -64,6 +64,8 @@ struct gci_ctx {
     DevBuf join_table, join_last, join_hq;
     DevBuf part_a, part_b, part_hist, part_blk;   // partitioned join: entry ping-pong, histograms + segment table, scan totals
     DevBuf route_tab;                       // gci_route_*: per (part, chunk) counts and their scan
+    DevBuf deflate_nruns, deflate_runs;     // gci_depth_deflate_*: per tile its constant-depth runs (k_depth_runs)
+    uint32_t deflate_members = 0;           // ... of the members the last size call measured
     DevBuf conflict_table;                  // gci_hash_conflicts' own open-addressing tables (two, used alternately)
     uint64_t conflict_slots = 0;            // slots per table
     uint32_t conflict_parity = 0;           // which one the next call inserts into (the other one is clean by then)

@@ -154,13 +154,69 @@ __device__ __forceinline__ void put_run(BitOut& o, const Line& l, uint32_t n)
     for (uint32_t k = 0; k < rest; k++) put_literal(o, line_byte(l, k));        // (n - 1) w < 3: n == 2, w == 2... as literals
 }
 
+// ---- the runs of every tile, found by a whole wave --------------------------------------------------------------------
+// A lane that walks its tile alone reads 16 KiB in sixteen dependent round trips of addresses no other lane shares: the two
+// encode passes took 50 ms at genome scale for 25 GB of reads (0.5 TB/s).  The walk is therefore done ONCE, by a wave per tile
+// with coalesced 16-byte loads: a base starts a run where it differs from the base in front of it (the neighbour lane's last
+// element through DPP), the starts are ranked with a wave scan and land in LDS, and the tile's runs -- {depth, length},
+// ~20 of them in long-read data -- go to a list the encode passes read instead of the track.  A tile with more than
+// RUN_MAX runs (short reads, pile-ups) keeps the lane's own walk.
+constexpr int RUN_MAX = 64;
+constexpr uint32_t RUNS_WALK = 0xFFFFFFFFu;      // tile_nruns: not in the list, walk the track
+
+__global__ __launch_bounds__(BLOCK) void k_depth_runs(const int32_t* __restrict__ depth, const uint64_t* __restrict__ member_elem,
+                                                      const uint32_t* __restrict__ member_n, uint32_t n_members,
+                                                      uint32_t* __restrict__ tile_nruns, int2* __restrict__ tile_runs)
+{
+    __shared__ uint32_t starts[BLOCK / 64][RUN_MAX + 1];
+    __shared__ int32_t vals[BLOCK / 64][RUN_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t g = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;                       // tile = (member, tile of the member)
+    const uint32_t m = (uint32_t)(g / MEMBER_TILES), t = (uint32_t)(g % MEMBER_TILES);
+    if (m >= n_members) return;
+    const uint32_t n_all = member_n[m], first = t * TILE;
+    const uint32_t n = n_all > first ? min((uint32_t)TILE, n_all - first) : 0u;
+    if (n == 0) { if (lane == 0) tile_nruns[g] = 0u; return; }
+    const int4* __restrict__ src = reinterpret_cast<const int4*>(depth + member_elem[m] + first);
+    uint32_t total = 0;
+    int32_t carry = 0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < TILE / 256; k++) {
+        const uint32_t e = 4u * (k * 64u + (uint32_t)lane);
+        const int4 q = e < n ? src[k * 64u + lane] : make_int4(0, 0, 0, 0);              // (a tile's padding is readable: zeros)
+        int32_t prev = __shfl_up(q.w, 1, 64);
+        if (lane == 0) prev = carry;
+        const bool s0 = e < n && (e == 0 || q.x != prev), s1 = e + 1 < n && q.y != q.x, s2 = e + 2 < n && q.z != q.y,
+                   s3 = e + 3 < n && q.w != q.z;
+        const uint32_t cnt = (uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3;
+        const uint32_t inc = wave_inclusive<uint32_t>(cnt, lane);
+        uint32_t r = total + inc - cnt;
+        if (s0) { if (r < RUN_MAX) { starts[wave][r] = e; vals[wave][r] = q.x; } r++; }
+        if (s1) { if (r < RUN_MAX) { starts[wave][r] = e + 1; vals[wave][r] = q.y; } r++; }
+        if (s2) { if (r < RUN_MAX) { starts[wave][r] = e + 2; vals[wave][r] = q.z; } r++; }
+        if (s3) { if (r < RUN_MAX) { starts[wave][r] = e + 3; vals[wave][r] = q.w; } r++; }
+        total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        carry = __builtin_amdgcn_readlane(q.w, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (total > RUN_MAX) { if (lane == 0) tile_nruns[g] = RUNS_WALK; return; }
+    if ((uint32_t)lane < total) {
+        const uint32_t a = starts[wave][lane], b = (uint32_t)lane + 1 < total ? starts[wave][lane + 1] : n;
+        tile_runs[g * RUN_MAX + lane] = make_int2(vals[wave][lane], (int)(b - a));
+    }
+    if (lane == 0) tile_nruns[g] = total;
+}
+
 // One wave = one member of up to 64 tiles; lane t = tile t.  PASS 1: tile_bytes[], member totals + CRC; PASS 2: bytes.
 template <int PASS>
 __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict__ depth, const uint64_t* __restrict__ member_elem,
                                                       const uint32_t* __restrict__ member_n, uint32_t n_members,
                                                       uint32_t* __restrict__ tile_bytes, uint32_t* __restrict__ member_bytes,
                                                       uint32_t* __restrict__ member_crc, uint32_t* __restrict__ member_isize,
-                                                      const uint64_t* __restrict__ member_out, uint8_t* __restrict__ out, uint64_t cap)
+                                                      const uint64_t* __restrict__ member_out, uint8_t* __restrict__ out, uint64_t cap,
+                                                      const uint32_t* __restrict__ tile_nruns, const int2* __restrict__ tile_runs)
 {
     __shared__ int32_t run_v[RUNS][64];
     __shared__ uint32_t run_n[RUNS][64];
@@ -203,8 +259,20 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
     int32_t cur = 0;
     uint32_t cnt = 0;                                                                 // the open run
     bool done = n == 0;
+    // the tile's runs from the list k_depth_runs made (the usual case), else the walk below
+    const uint64_t g = (uint64_t)m * MEMBER_TILES + lane;
+    const uint32_t listed = tile_nruns ? tile_nruns[g] : RUNS_WALK;
+    const int2* __restrict__ my_runs = tile_runs + g * RUN_MAX;
     while (__any(!done)) {
         int k = 0;
+        if (listed != RUNS_WALK) {
+            while (!done && k < RUNS) {
+                if (pos == listed) { done = true; break; }
+                const int2 rr = my_runs[pos++];
+                run_v[k][lane] = rr.x; run_n[k][lane] = (uint32_t)rr.y; k++;
+            }
+            if (pos == listed) done = true;
+        }
         // one element into the open run; false: it would close a run and the buffer is full (the element stays unread)
         auto feed = [&](int32_t x) -> bool {
             if (cnt && x != cur) {
@@ -214,7 +282,7 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
             cur = x; cnt++;
             return true;
         };
-        while (!done && k < RUNS) {
+        while (listed == RUNS_WALK && !done && k < RUNS) {
             if (pos == n) {                                                           // close the last run
                 if (cnt) { run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0; }
                 done = true;
@@ -296,8 +364,16 @@ extern "C" int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, cons
     if (!ctx || (n_members && (!d_depth || !d_member_elem || !d_member_n || !d_tile_bytes || !d_member_bytes || !d_member_crc ||
                                !d_member_isize))) return GCI_E_INVALID;
     if (n_members == 0) return GCI_OK;
+    const uint64_t n_tiles = (uint64_t)n_members * MEMBER_TILES;
+    GCI_TRY(gci_ensure(ctx, ctx->deflate_nruns, n_tiles * 4));
+    GCI_TRY(gci_ensure(ctx, ctx->deflate_runs, n_tiles * RUN_MAX * sizeof(int2)));
+    ctx->deflate_members = n_members;
+    hipLaunchKernelGGL(k_depth_runs, dim3((uint32_t)((n_tiles + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, ctx->stream, d_depth,
+                       d_member_elem, d_member_n, n_members, (uint32_t*)ctx->deflate_nruns.p, (int2*)ctx->deflate_runs.p);
+    LAUNCHCHK("k_depth_runs");
     hipLaunchKernelGGL(k_depth_deflate<1>, dim3(n_members), dim3(64), 0, ctx->stream, d_depth, d_member_elem, d_member_n, n_members,
-                       d_tile_bytes, d_member_bytes, d_member_crc, d_member_isize, (const uint64_t*)nullptr, (uint8_t*)nullptr, 0ull);
+                       d_tile_bytes, d_member_bytes, d_member_crc, d_member_isize, (const uint64_t*)nullptr, (uint8_t*)nullptr, 0ull,
+                       (const uint32_t*)ctx->deflate_nruns.p, (const int2*)ctx->deflate_runs.p);
     LAUNCHCHK("k_depth_deflate<1>");
     return GCI_OK;
 }
@@ -312,7 +388,10 @@ extern "C" int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* d_depth, con
     if (n_members == 0) return GCI_OK;
     hipLaunchKernelGGL(k_depth_deflate<2>, dim3(n_members), dim3(64), 0, ctx->stream, d_depth, d_member_elem, d_member_n, n_members,
                        const_cast<uint32_t*>(d_tile_bytes), (uint32_t*)nullptr, const_cast<uint32_t*>(d_member_crc),
-                       const_cast<uint32_t*>(d_member_isize), d_member_out, d_out, cap);
+                       const_cast<uint32_t*>(d_member_isize), d_member_out, d_out, cap,
+                       // the run lists of the size call over the same track and members (else: the lanes walk the track)
+                       ctx->deflate_members == n_members ? (const uint32_t*)ctx->deflate_nruns.p : (const uint32_t*)nullptr,
+                       (const int2*)ctx->deflate_runs.p);
     LAUNCHCHK("k_depth_deflate<2>");
     return GCI_OK;
 }

@@ -711,8 +711,13 @@ __device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEn
 // A bucket of up to PART_E * JB = 1024 entries (all but forged inputs) stays in REGISTERS from its one coalesced read to the
 // fold: insert (LDS only) -> winners + every non-claimant's name against its claimant's (two independent random reads per
 // entry, addresses from registers and LDS: nothing in front of them) -> fold.  Larger buckets re-read their entries per phase.
+#ifndef PART_E
 #define PART_E 2
-#define JB 512                       // threads of a bucket's workgroup: PART_E * JB = 1024 entries = the most a table of 1024 slots can hold distinct
+#endif
+#ifndef JB
+#define JB 512
+#endif
+// JB threads per bucket workgroup, PART_E entries per thread in registers: PART_E * JB = 1024 = the most a table of 1024 slots holds
 template <int FN>
 __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_join_part(JoinFiles F, PartJoinArgs A, double ovlp_percent,
                                                      const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out, uint32_t cap,
@@ -894,6 +899,7 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
     // slots per bucket table: what fits 64 KB of LDS with one order key and one 16-byte payload per file (two 512-thread
     // workgroups per CU, which is what their registers allow anyway)
     uint32_t S = 1024;
+    { const char* e = getenv("GCI_JOIN_SLOTS"); if (e && atoi(e) >= 128 && atoi(e) <= 1024 && !(atoi(e) & (atoi(e) - 1))) S = (uint32_t)atoi(e); }   // (A/B)
     while (S > 128 && (size_t)S * (16 + 24 * (size_t)F.n) > 65536) S >>= 1;
     // buckets: a load of at most 0.63 in the worst case (every name distinct), 0.15 - 0.3 for two files of the same reads
     uint64_t nb = 256;
