@@ -62,6 +62,7 @@ struct gci_ctx {
     bool build_pending = false, build_text = false;
     // join scratch
     DevBuf join_table, join_last, join_hq;
+    DevBuf join_bucket;                     // partitioned join: per bucket its survivor count, first slot and output offset
     DevBuf part_a, part_b, part_hist, part_blk;   // partitioned join: entry ping-pong, histograms + segment table, scan totals
     DevBuf route_tab;                       // gci_route_*: per (part, chunk) counts and their scan
     DevBuf deflate_nruns, deflate_runs;     // gci_depth_deflate_*: per tile its constant-depth runs (k_depth_runs)

@@ -720,13 +720,13 @@ __device__ __forceinline__ bool fold_from_entry(const JoinFiles& F, const PartEn
 // JB threads per bucket workgroup, PART_E entries per thread in registers: PART_E * JB = 1024 = the most a table of 1024 slots holds
 template <int FN>
 __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_join_part(JoinFiles F, PartJoinArgs A, double ovlp_percent,
-                                                     const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ out, uint32_t cap,
-                                                     uint32_t* __restrict__ n_out, unsigned long long* __restrict__ status,
-                                                     const CountArgs cnt)
+                                                     const int32_t* __restrict__ contig_map, gci_ivl* __restrict__ sparse,
+                                                     uint32_t* __restrict__ bucket_cnt, uint32_t* __restrict__ bucket_lo,
+                                                     unsigned long long* __restrict__ status, const CountArgs cnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
     __shared__ uint32_t wtot[JB / 64];
-    __shared__ uint32_t s_base, s_used, s_bad;
+    __shared__ uint32_t s_used, s_bad;
     __shared__ int64_t s_len[COUNT_LDS], s_tf[COUNT_LDS];
     const uint32_t S = A.slots;
     const int Fn = FN ? FN : F.n;
@@ -738,8 +738,9 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t j = blockIdx.x / A.n_bins2, d = blockIdx.x % A.n_bins2;
     const uint32_t cj = A.seg[A.n_seg + 1 + j], nch = A.seg[A.n_seg + 2 + j] - cj;
-    if (nch == 0) return;                                        // empty level-1 bucket (uniform over the workgroup)
+    if (nch == 0) { if (t == 0) bucket_cnt[blockIdx.x] = 0u; return; }      // empty level-1 bucket (uniform over the workgroup)
     const uint32_t lo = A.off2[(size_t)cj * A.n_bins2 + (size_t)d * nch], hi = A.off2[(size_t)cj * A.n_bins2 + (size_t)(d + 1) * nch];
+    if (t == 0) { bucket_cnt[blockIdx.x] = 0u; bucket_lo[blockIdx.x] = lo; }
     if (lo == hi) return;
     const bool tables_in_lds = cnt.tile_cd && cnt.n_contigs <= COUNT_LDS;
     if (tables_in_lds) for (int c = t; c < cnt.n_contigs; c += JB) { s_len[c] = cnt.len[c]; s_tf[c] = cnt.tile_first[c]; }
@@ -839,8 +840,11 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int f = 0; f < file; f++) if (last[(size_t)slot * Fn + f] != 0) return false;      // an earlier file has the name
         return fold_from_entry<FN>(F, in, e, file, slot, last, pay, (meta[slot] & 1ull) != 0, ovlp_percent, contig_map, status, keep);
     };
+    // A bucket's survivors go where its entries were counted: slot lo + rank of a buffer as long as the partition -- a name
+    // survives at most once, so they fit -- and k_join_gather makes the dense output of them.  (One returning atomic per bucket
+    // on the output counter was what bounded this kernel: 32 768 same-address atomics at ~12 ns each.)
     auto emit = [&](const gci_ivl& keep, uint32_t w) {
-        if (w < cap) out[w] = keep;
+        sparse[lo + w] = keep;
         if (cnt.tile_cd) {
             const IvlSpan sp = tables_in_lds ? span_of(keep, cnt.flank, s_len, s_tf, cnt.n_contigs)
                                              : span_of(keep, cnt.flank, cnt.len, cnt.tile_first, cnt.n_contigs);
@@ -863,12 +867,12 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint32_t pre = inc - mine, all = 0;
 #pragma unroll
         for (int w = 0; w < JB / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
-        if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
-        __syncthreads();
-        uint32_t w = s_base + pre;
+        if (t == 0) bucket_cnt[blockIdx.x] = all;
+        uint32_t w = pre;
 #pragma unroll
         for (int k = 0; k < PART_E; k++) if (ok[k]) emit(keep[k], w++);
     } else {
+        uint32_t run = 0;                                        // survivors of the rounds so far (uniform)
         for (uint32_t i0 = 0; i0 < n; i0 += JB) {
             const uint32_t i = i0 + t;
             gci_ivl keep;
@@ -884,11 +888,28 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             uint32_t pre = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), all = 0;
 #pragma unroll
             for (int w = 0; w < JB / 64; w++) { if (w < wave) pre += wtot[w]; all += wtot[w]; }
-            if (t == 0) s_base = all ? atomicAdd(n_out, all) : 0u;
-            __syncthreads();
-            if (ok) emit(keep, s_base + pre);
+            if (ok) emit(keep, run + pre);
+            run += all;
+            __syncthreads();                                     // wtot is rewritten by the next round
         }
+        if (t == 0) bucket_cnt[blockIdx.x] = run;
     }
+}
+
+// The dense output of the bucket join: bucket b's bucket_cnt[b] survivors from sparse[bucket_lo[b] ...] to out[off[b] ...]
+// (off = exclusive scan of the counts, its total = the number of intervals).  One wave per bucket.
+__global__ __launch_bounds__(BLOCK) void k_join_gather(const gci_ivl* __restrict__ sparse, const uint32_t* __restrict__ bucket_cnt,
+                                                       const uint32_t* __restrict__ bucket_lo, const uint32_t* __restrict__ off,
+                                                       uint32_t n_buckets, gci_ivl* __restrict__ out, uint32_t cap, uint32_t* __restrict__ n_out)
+{
+    const uint32_t b = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = off[n_buckets];
+    if (b >= n_buckets) return;
+    const uint32_t c = bucket_cnt[b];
+    if (!c) return;
+    const gci_ivl* __restrict__ src = sparse + bucket_lo[b];
+    const uint32_t o = off[b];
+    for (uint32_t r = lane; r < c; r += 64) if (o + r < cap) out[o + r] = src[r];
 }
 
 static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t total, double ovlp_percent,
@@ -956,17 +977,29 @@ static int name_join_partitioned(gci_ctx* ctx, const JoinFiles& F, uint64_t tota
         { const char* nv = getenv("GCI_JOIN_NOVERIFY"); A.no_verify = nv && nv[0] == '1' ? 1u : 0u; }
         const size_t lds = (size_t)S * (16 + 24 * (size_t)F.n) + (size_t)S * 2;    // + the list of used slots
         const dim3 grid(B1 * B2), block(JB);
+        const uint32_t NB = B1 * B2;
+        GCI_TRY(gci_ensure(ctx, ctx->join_bucket, ((size_t)3 * NB + 2) * 4 + 64));
+        uint32_t* bcnt = (uint32_t*)ctx->join_bucket.p;
+        uint32_t* blo = bcnt + NB;
+        uint32_t* boff = blo + NB;                                                 // NB + 1 entries
+        gci_ivl* sparse = (gci_ivl*)pa;                                            // the level-1 copy of the entries is dead by now
+        static_assert(sizeof(gci_ivl) <= sizeof(PartEntry), "the sparse intervals fit the partition buffer");
         const void* kfn = F.n == 1 ? (const void*)k_join_part<1> : F.n == 2 ? (const void*)k_join_part<2> : F.n == 3 ? (const void*)k_join_part<3>
                         : F.n == 4 ? (const void*)k_join_part<4> : (const void*)k_join_part<0>;
         HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         switch (F.n) {
-        case 1: hipLaunchKernelGGL((k_join_part<1>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
-        case 2: hipLaunchKernelGGL((k_join_part<2>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
-        case 3: hipLaunchKernelGGL((k_join_part<3>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
-        case 4: hipLaunchKernelGGL((k_join_part<4>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
-        default: hipLaunchKernelGGL((k_join_part<0>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, d_out, cap, d_n_out, (unsigned long long*)d_status, cnt); break;
+        case 1: hipLaunchKernelGGL((k_join_part<1>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, sparse, bcnt, blo, (unsigned long long*)d_status, cnt); break;
+        case 2: hipLaunchKernelGGL((k_join_part<2>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, sparse, bcnt, blo, (unsigned long long*)d_status, cnt); break;
+        case 3: hipLaunchKernelGGL((k_join_part<3>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, sparse, bcnt, blo, (unsigned long long*)d_status, cnt); break;
+        case 4: hipLaunchKernelGGL((k_join_part<4>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, sparse, bcnt, blo, (unsigned long long*)d_status, cnt); break;
+        default: hipLaunchKernelGGL((k_join_part<0>), grid, block, lds, ctx->stream, F, A, ovlp_percent, d_contig_map, sparse, bcnt, blo, (unsigned long long*)d_status, cnt); break;
         }
         LAUNCHCHK("k_join_part");
+        int r2 = device_exclusive_scan<uint32_t, uint32_t>(ctx, bcnt, boff, (uint32_t*)ctx->part_blk.p, (int64_t)NB, true);
+        if (r2) return r2;
+        hipLaunchKernelGGL(k_join_gather, dim3((NB + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, ctx->stream, (const gci_ivl*)sparse,
+                           (const uint32_t*)bcnt, (const uint32_t*)blo, (const uint32_t*)boff, NB, d_out, cap, d_n_out);
+        LAUNCHCHK("k_join_gather");
     }
     *done = true;
     return GCI_OK;
