@@ -94,6 +94,7 @@ class Engine:
         self.total = 0
         self._status = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._members_host = None                 # pinned staging buffer of depth_deflate()
         m = os.environ.get("GCI_JOIN", "")
         self.join_mode = 1 if m.startswith("c") else 2 if m.startswith("p") else 0    # what gci_ctx_create read
 
@@ -282,7 +283,8 @@ class Engine:
 
     def depth_deflate(self, track: torch.Tensor) -> List[bytes]:
         """-> per contig of the layout, the bytes of the gzip members whose payload is that contig's depth lines
-        (f'{depth}\\n' per base, GCI.py:115-117; no '>' line).  gci_depth_deflate_size / _write."""
+        (f'{depth}\\n' per base, GCI.py:115-117; no '>' line), as memoryviews of a pinned buffer the engine reuses: valid until
+        the next call.  gci_depth_deflate_size / _write."""
         elem, cnt, first = [], [], [0]
         for off, length in zip(self.offsets, self.lengths):
             for g in range(0, int(length), self.MEMBER_BASES):
@@ -299,17 +301,24 @@ class Engine:
         mb, crc, isz = (torch.empty(nm, dtype=torch.int32, device=dev) for _ in range(3))
         self._chk(self.lib.gci_depth_deflate_size(self.ctx, self._p(track), self._p(d_elem), self._p(d_cnt), nm, self._p(tile_bytes),
                                                   self._p(mb), self._p(crc), self._p(isz)), "gci_depth_deflate_size")
-        sizes = mb.cpu().numpy().view(np.uint32).astype(np.uint64)
-        offs = np.zeros(nm + 1, dtype=np.uint64)
-        np.cumsum(sizes, out=offs[1:])
-        total = int(offs[nm])
+        # member offsets on the device (no round trip through the host for them); one sync for the total
+        d_off64 = torch.zeros(nm + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(mb.view(torch.int32).to(torch.int64) & 0xFFFFFFFF, 0, out=d_off64[1:])
+        total = int(d_off64[nm].item())
         out = torch.empty(total, dtype=torch.uint8, device=dev)
-        d_off = self.to_device(offs[:nm].copy())
         self._chk(self.lib.gci_depth_deflate_write(self.ctx, self._p(track), self._p(d_elem), self._p(d_cnt), nm, self._p(tile_bytes),
-                                                   self._p(crc), self._p(isz), self._p(d_off), self._p(out), total),
+                                                   self._p(crc), self._p(isz), self._p(d_off64), self._p(out), total),
                   "gci_depth_deflate_write")
-        blob = out.cpu().numpy()
-        return [blob[int(offs[first[c]]):int(offs[first[c + 1]])].tobytes() for c in range(len(self.lengths))]
+        # the members leave through a pinned staging buffer of the engine (a pageable destination halves the D2H rate and
+        # .tobytes() per contig copied everything once more): the caller gets views of it, valid until the next call
+        if self._members_host is None or int(self._members_host.shape[0]) < total:
+            self._members_host = torch.empty(max(total + (total >> 3), 1 << 20), dtype=torch.uint8).pin_memory()
+        host = self._members_host[:total]
+        host.copy_(out, non_blocking=True)
+        offs = d_off64.cpu().numpy()
+        self.sync()
+        blob = host.numpy()
+        return [memoryview(blob[int(offs[first[c]]):int(offs[first[c + 1]])]) for c in range(len(self.lengths))]
 
     def hash_bucket(self, recs: torch.Tensor, n_parts: int, part_cap: int, out: torch.Tensor,
                     next_out: Optional[torch.Tensor] = None) -> None:

@@ -776,9 +776,10 @@ def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
     """'>contig' member (host), then the contig's lines as the members the device wrote.  Contig-sharded run: every rank
     deflates the contigs it owns, rank 0 gathers the members and writes them in header order."""
     from . import hostio
-    blobs = depths.engine.depth_deflate(depths.track)
+    blobs = depths.engine.depth_deflate(depths.track)               # views of the engine's pinned staging buffer
     items = list(zip(depths.targets, depths.lengths, blobs))
     if _sharded():
+        items = [(t, L, bytes(b)) for t, L, b in items]             # (they travel pickled)
         order = {t: i for i, t in enumerate(depths.all_targets)}
         parts = SHARD.gather_to_root(items)             # to rank 0 only: the members of a genome are GBs
         if not SHARD.root:

@@ -759,7 +759,7 @@ def test_depth_text_as_gzip_members_from_the_gpu(engine):
         host[off:off + L] = d
         want.append(b"".join(b"%d\n" % int(x) for x in d.tolist()) if L < 400_000 else ("\n".join(map(str, d.tolist())) + "\n").encode())
     track.copy_(torch.from_numpy(host))
-    members = engine.depth_deflate(track)
+    members = [bytes(b) for b in engine.depth_deflate(track)]
     assert len(members) == len(lens)
     for c, blob in enumerate(members):
         assert blob[:4] == b"\x1f\x8b\x08\x00"
