@@ -1206,7 +1206,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if w.sharded else "weak",
+        # N = 1 is the first point of the curve --scaling asks for (strong by default: the same whole genome at every N)
+        "scaling": ("strong" if w.sharded else "weak") if world > 1 else (args.scaling if args.workload == "genome" else "weak"),
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",

@@ -807,8 +807,8 @@ __device__ __forceinline__ uint32_t cut_dword(uint32_t a, uint32_t b, int32_t cu
 
 // returns false when the tile needs the dense path (nothing has been written then)
 //
-// What bounds this kernel besides the HBM write rate is VALU issue (a wave64 instruction holds its SIMD16 for four
-// cycles and a CU works through ~60 tiles): everything that is uniform over a segment is kept in scalar registers
+// What bounds this kernel besides the HBM write rate is VALU issue (a wave64 instruction takes two issue cycles of its
+// SIMD-32 and a CU works through ~60 tiles): everything that is uniform over a segment is kept in scalar registers
 // (v_readlane of the owning lane), so a group of 16 text bytes costs a handful of vector instructions.
 __device__ __forceinline__ bool tile_sparse2(
     int64_t tile, uint32_t e0, uint32_t n_ev, const uint16_t* __restrict__ events, int32_t carry_in, int32_t valid,
