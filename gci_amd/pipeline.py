@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Set, Tuple
@@ -282,6 +283,70 @@ def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
     return JoinInput(torch.cat([p.recs for p in parts]), names, torch.cat(offs), 0)
 
 
+class _RunUploads:
+    """Uploads of a large BGZF file run by run of members, one run AHEAD of its consumer: two device buffers taken in turns, the
+    copies on a stream of their own from a helper thread (they come from pageable memory -- a memory-mapped file -- and block their
+    caller), so that run k + 1 crosses PCIe while the device inflates, walks and filters run k."""
+
+    def __init__(self, engine: Engine, raw, pos: np.ndarray, groups):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        self.engine, self.raw, self.pos, self.groups = engine, raw, pos, groups
+        cap = max(int(pos[hi]) - int(pos[lo]) for lo, hi in groups) + 16
+        with torch.cuda.stream(engine.stream):
+            self.bufs = [torch.empty(cap, dtype=torch.uint8, device=engine.device) for _ in range(min(2, len(groups)))]
+        self.copy = torch.cuda.Stream(device=engine.device)
+        self.copy.wait_stream(engine.stream)                 # (the buffers may recycle memory still in use on the main stream)
+        self.freed = [None] * len(self.bufs)                 # main-stream event behind the last kernel that read the buffer
+        self.pool = ThreadPoolExecutor(1)
+        self.pending = {}
+        self._start(0)
+
+    def _start(self, k: int):
+        import torch
+        if k >= len(self.groups):
+            return
+        lo, hi = self.groups[k]
+        p0, p1 = int(self.pos[lo]), int(self.pos[hi])
+        buf, freed = self.bufs[k % len(self.bufs)], self.freed[k % len(self.bufs)]
+
+        def run():
+            with torch.cuda.stream(self.copy), warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)     # a read-only memmap is only read
+                if freed is not None:
+                    self.copy.wait_event(freed)
+                n = p1 - p0
+                buf[:n].copy_(torch.from_numpy(np.asarray(self.raw[p0:p1])))
+                buf[n:n + 16].zero_()
+                ev = torch.cuda.Event()
+                ev.record(self.copy)
+            return buf[:n + 16], ev
+
+        self.pending[k] = self.pool.submit(run)
+
+    def take(self, k: int):
+        """-> run k's bytes on the device (+ 16 zero bytes), ordered before whatever the main stream does next."""
+        d_raw, ev = self.pending.pop(k).result()
+        self.engine.stream.wait_event(ev)
+        self._start(k + 1)                                   # into the other buffer: its last reader (run k - 1) is enqueued
+        return d_raw
+
+    def release(self, k: int):
+        """Everything that reads run k's buffer has been enqueued on the main stream: the run after next may overwrite it."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(self.engine.stream)
+        self.freed[k % len(self.bufs)] = ev
+
+    def close(self):
+        for f in self.pending.values():
+            try:
+                f.result()
+            except Exception:
+                pass
+        self.pool.shutdown(wait=True)
+
+
 def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int,
                         upload=None) -> Optional[JoinInput]:
     """ingest = "gpu".  A file whose inflated stream fits GCI_GPU_INFLATE_MAX stays on the device whole (the join reads
@@ -318,32 +383,39 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     groups.append((a, len(isz)))
     parts: List[JoinInput] = []
     carry, start, n_done = None, hdr.first_record, 0
-    for lo, hi in groups:
-        p0 = int(pos[lo])
-        try:
-            d_buf = engine.bgzf_inflate(raw[p0:int(pos[hi])], pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry)
-        except GciError as e:
-            if e.rec >= 0:
-                e.rec += lo
-            raise
-        if int(d_buf.shape[0]) <= start:                  # still inside the header
-            carry, start = None, start - int(d_buf.shape[0])
-            continue
-        d_off, used, ok = engine.bam_record_offsets(d_buf, start, n_ref)
-        if not ok:
-            return None
-        carry, start = (d_buf[used:].clone() if used < int(d_buf.shape[0]) else None), 0
-        if int(d_off.shape[0]) == 0:
-            continue
-        try:
-            ji = _filter_stream(engine, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
-        except GciError as e:
-            if e.rec >= 0:
-                e.rec += n_done
-            raise
-        parts.append(_keep_part(engine, ji))
-        n_done += int(d_off.shape[0])
-        del d_buf, d_off, ji
+    ahead = _RunUploads(engine, raw, pos, groups)             # the bytes of run k + 1 travel while run k is inflated and filtered
+    try:
+        for k, (lo, hi) in enumerate(groups):
+            p0 = int(pos[lo])
+            d_raw = ahead.take(k)
+            try:
+                d_buf = engine.bgzf_inflate(None, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry, d_raw=d_raw)
+            except GciError as e:
+                if e.rec >= 0:
+                    e.rec += lo
+                raise
+            ahead.release(k)
+            del d_raw
+            if int(d_buf.shape[0]) <= start:                  # still inside the header
+                carry, start = None, start - int(d_buf.shape[0])
+                continue
+            d_off, used, ok = engine.bam_record_offsets(d_buf, start, n_ref)
+            if not ok:
+                return None
+            carry, start = (d_buf[used:].clone() if used < int(d_buf.shape[0]) else None), 0
+            if int(d_off.shape[0]) == 0:
+                continue
+            try:
+                ji = _filter_stream(engine, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
+            except GciError as e:
+                if e.rec >= 0:
+                    e.rec += n_done
+                raise
+            parts.append(_keep_part(engine, ji))
+            n_done += int(d_off.shape[0])
+            del d_buf, d_off, ji
+    finally:
+        ahead.close()
     if carry is not None:
         raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % int(carry.shape[0]))
     return _concat_parts(engine, parts)

@@ -230,7 +230,14 @@ def genome_two_type(config: int = 4, scale: float = 1.0, cov_hifi: float = 40.0,
     groups = contig_groups(ctg, max(2.0e7, min(2.6e8, total / 12.0)))
     if procs is None:
         from . import hostio
-        procs = max(1, min(hostio.default_threads(), 8))       # ONT groups are GBs each: a handful of workers at a time
+        # a worker holds ~0.35 GB per Mb of its group while it makes the ONT CIGARs (chr1: ~90 GB): as many workers as a
+        # third of the free memory carries at 100 GB each, 16 at most
+        try:
+            avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")][0] / 1e6
+        except Exception:
+            avail = 64.0
+        biggest = max(sum(ctg[i][1] for i in g) for g in groups) * 0.35e-6 + 1.0
+        procs = max(1, min(hostio.default_threads(), 16, int(avail / 3.0 / biggest)))
     procs = max(1, min(int(procs), len(groups)))
     tasks = [(ctg, idx, g, (cov_hifi, cov_ont), config, config == 4) for g, idx in enumerate(groups)]
     t0 = time.time()
