@@ -113,6 +113,13 @@ EXPORTS = [
     ("gci_paf_dev_count", c_uint64, [c_void_p, c_int]),
     ("gci_paf_dev_export", c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     ("gci_paf_dev_free", c_int, [c_void_p]),
+    ("gci_paf_hits_device", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, ctypes.c_double, c_void_p,
+                                    c_void_p]),
+    ("gci_paf_hits_count", c_uint64, [c_void_p, c_int]),
+    ("gci_paf_hits_export", c_int, [c_void_p, c_int, c_void_p]),
+    ("gci_paf_hits_free", c_int, [c_void_p]),
+    ("gci_route_hits", c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p]),
+    ("gci_paf_score_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("gci_bgzf_inflate_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
     ("gci_bam_record_offsets_device", c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_int32, c_void_p, c_uint64, c_void_p]),
     ("gci_bgzf_scan", c_int, [c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),

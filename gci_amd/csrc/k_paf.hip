@@ -22,16 +22,7 @@
 
 namespace {
 
-struct PafHitD {
-    uint64_t qn_off;          // byte offset of the query name in the text
-    uint64_t qhash;
-    int64_t qlen, qs, qe, ts, te;
-    double identity;
-    uint32_t qn_len;
-    int32_t t;                // index among the selected contigs
-    uint32_t hq;
-    uint32_t slot;            // its query's slot in the table (set by k_paf_insert)
-};
+typedef gci_paf_hit PafHitD;             // include/gci_hip.h: it crosses the boundary in sharded runs
 
 struct PafTargets {
     const int32_t* slot;      // open addressing on the name hash: target index or -1
@@ -356,6 +347,13 @@ struct gci_paf_dev {
     std::vector<uint32_t> count;
 };
 
+// Stage A's result for the sharded run: per file the hits of this rank's byte range, dense and in line order (device).
+struct gci_paf_hits {
+    gci_ctx* ctx = nullptr;
+    std::vector<void*> hits;
+    std::vector<uint32_t> count;
+};
+
 static void paf_dev_release(gci_paf_dev* h)
 {
     for (void* p : h->recs) if (p) (void)hipFree(p);
@@ -363,20 +361,29 @@ static void paf_dev_release(gci_paf_dev* h)
     delete h;
 }
 
-extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const uint64_t* h_file_end, int n_files,
-                                     const char* const* targets, int n_targets, int map_qual, int mq_cutoff, double iden_percent,
-                                     gci_paf_dev** out, uint64_t* err_line)
+static void paf_hits_release(gci_paf_hits* h)
 {
-    if (!ctx || !out || n_files < 0 || (n_files && (!d_text || !h_file_end)) || (n_targets && !targets)) return GCI_E_INVALID;
-    *out = nullptr;
-    hipStream_t st = ctx->stream;
-    std::vector<void*> tmp;                                  // freed on every way out
-    auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
-    struct Cleanup { std::vector<void*>& v; ~Cleanup() { for (void* p : v) (void)hipFree(p); } } cleanup{tmp};
-#define PAF_ALLOC(var, type, count)                                       \
-    type* var = (type*)dalloc(sizeof(type) * (size_t)(count));            \
+    for (void* p : h->hits) if (p) (void)hipFree(p);
+    delete h;
+}
+
+namespace {
+
+// device scratch of one call: freed on every way out, except what `keep` takes out of it
+struct PafScratch {
+    std::vector<void*> v;
+    ~PafScratch() { for (void* p : v) (void)hipFree(p); }
+    void* alloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; v.push_back(p); return p; }
+    void keep(void* p) { for (auto& q : v) if (q == p) { q = nullptr; return; } }
+};
+#define PAF_ALLOC(var, type, count)                                         \
+    type* var = (type*)S.alloc(sizeof(type) * (size_t)(count));             \
     if (!var) return GCI_E_NOMEM
-    // ---- the selected contigs: hash table, names, sorted rank ------------------------------------------------------
+
+// the selected contigs on the device: hash table, names, rank in sorted(name) order
+int paf_targets(gci_ctx* ctx, PafScratch& S, const char* const* targets, int n_targets, PafTargets& T)
+{
+    hipStream_t st = ctx->stream;
     uint32_t tslots = 16;
     while (tslots < 2u * (uint32_t)n_targets + 2u) tslots <<= 1;
     std::vector<int32_t> h_slot(tslots, -1), h_rank(n_targets > 0 ? n_targets : 1, 0);
@@ -387,12 +394,10 @@ extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const 
         h_off[t] = names.size();
         names += nm;
         h_hash[t] = gci_name_hash((const uint8_t*)nm.data(), (uint32_t)nm.size());
-        bool dup = false;
         for (uint32_t s = (uint32_t)(h_hash[t] ^ (h_hash[t] >> 29)) & (tslots - 1);; s = (s + 1) & (tslots - 1)) {
             if (h_slot[s] < 0) { h_slot[s] = t; break; }
-            if (nm == targets[h_slot[s]]) { dup = true; break; }      // a name listed twice: the first index, as the host map does
+            if (nm == targets[h_slot[s]]) break;                         // a name listed twice: the first index, as the host map does
         }
-        (void)dup;
     }
     h_off[n_targets] = names.size();
     {
@@ -414,20 +419,31 @@ extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const 
     if (!names.empty()) HIPCHK(hipMemcpyAsync(d_tnames, names.data(), names.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_trank, h_rank.data(), h_rank.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));                        // the host vectors above may go out of scope safely
-    PafTargets T;
     T.slot = d_slot; T.hash = d_thash; T.off = d_toff; T.names = d_tnames; T.rank = d_trank; T.mask = tslots - 1;
-    PAF_ALLOC(d_status, unsigned long long, 1);
-    PAF_ALLOC(d_n, uint32_t, 4);
+    return GCI_OK;
+}
 
-    // ---- per file: lines -> hits, appended to the hits of the files before --------------------------------------------
-    std::vector<PafHitD*> file_hits(n_files, nullptr);
-    std::vector<uint32_t> hits_upto(n_files + 1, 0);
-    int pending_status = GCI_OK, n_ok = n_files;
+// Stage A -- per file: lines -> hits, dense and in line order.  A line the reference raises on ends the stage: the files in
+// front of it are complete (n_ok of them), pending_status / pending_line say what it was.
+struct PafStageA {
+    std::vector<PafHitD*> file_hits;
+    std::vector<uint32_t> hits_upto;
+    int n_ok = 0, pending_status = GCI_OK;
     uint64_t pending_line = 0;
+};
+
+int paf_stage_a(gci_ctx* ctx, PafScratch& S, const uint8_t* d_text, const uint64_t* h_file_end, int n_files, const PafTargets& T,
+                int map_qual, int mq_cutoff, double iden_percent, PafStageA& A)
+{
+    hipStream_t st = ctx->stream;
+    PAF_ALLOC(d_status, unsigned long long, 1);
+    A.file_hits.assign(n_files, nullptr);
+    A.hits_upto.assign(n_files + 1, 0);
+    A.n_ok = n_files;
     for (int f = 0; f < n_files; f++) {
         const uint64_t lo = f ? h_file_end[f - 1] : 0, hi = h_file_end[f];
         if (hi < lo) return GCI_E_INVALID;
-        hits_upto[f + 1] = hits_upto[f];
+        A.hits_upto[f + 1] = A.hits_upto[f];
         if (hi == lo) continue;
         const uint64_t n_tiles64 = (hi - lo + TILE - 1) / TILE;
         if (n_tiles64 > 0x7fffffffULL) return GCI_E_INVALID;
@@ -457,10 +473,10 @@ extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const 
         HIPCHK(hipStreamSynchronize(st));
         if (h_status != ~0ull) {
             // The reference reads and scores file after file: an error in the scoring of an EARLIER file comes first.
-            // Remember this one and score the files before it below.
-            pending_status = -(int)(h_status & 0xFF);
-            pending_line = h_status >> 8;
-            n_ok = f;
+            // Remember this one; the caller scores the files before it.
+            A.pending_status = -(int)(h_status & 0xFF);
+            A.pending_line = h_status >> 8;
+            A.n_ok = f;
             break;
         }
         PAF_ALLOC(d_pos, uint32_t, n_lines + 1);
@@ -469,91 +485,203 @@ extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const 
         uint32_t n_hits = 0;
         HIPCHK(hipMemcpyAsync(&n_hits, d_pos + n_lines, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if ((uint64_t)hits_upto[f] + n_hits > 0x7fffffffULL) return GCI_E_INVALID;
-        hits_upto[f + 1] = hits_upto[f] + n_hits;
+        if ((uint64_t)A.hits_upto[f] + n_hits > 0x7fffffffULL) return GCI_E_INVALID;
+        A.hits_upto[f + 1] = A.hits_upto[f] + n_hits;
         if (n_hits) {
             PAF_ALLOC(d_dense, PafHitD, n_hits);
             hipLaunchKernelGGL(k_paf_compact, dim3((n_lines + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hit,
                                (const uint32_t*)d_flag, (const uint32_t*)d_pos, n_lines, d_dense);
             LAUNCHCHK("k_paf_compact");
-            file_hits[f] = d_dense;
+            A.file_hits[f] = d_dense;
         }
     }
-    auto pending = [&]() { if (err_line) *err_line = pending_line; return pending_status; };
+    for (int f = A.n_ok; f < n_files; f++) A.hits_upto[f + 1] = A.hits_upto[A.n_ok];
+    return GCI_OK;
+}
+
+// Stage B -- the hits of files 0 .. n_ok - 1 in one array (file after file, every file in line order; qn_off relative to
+// d_names): queries numbered, their hits side by side, and per file the queries scored over the hits so far.
+int paf_stage_b(gci_ctx* ctx, PafScratch& S, const uint8_t* d_names, PafHitD* d_hits, const std::vector<uint32_t>& hits_upto, int n_ok,
+                const int32_t* d_trank, gci_paf_dev* H)
+{
+    hipStream_t st = ctx->stream;
     const uint32_t total = hits_upto[n_ok];
+    if (total == 0) return GCI_OK;
     if (total > (1u << 29)) return GCI_E_INVALID;
-    gci_paf_dev* H = new (std::nothrow) gci_paf_dev();
-    if (!H) return GCI_E_NOMEM;
-    H->ctx = ctx;
-    H->recs.assign(n_files, nullptr); H->name_off.assign(n_files, nullptr); H->count.assign(n_files, 0);
-    if (total == 0) {
-        if (pending_status != GCI_OK) { paf_dev_release(H); return pending(); }
-        *out = H;
-        return GCI_OK;
-    }
-    // one array of all hits, files in command-line order
-    PafHitD* d_hits = (PafHitD*)dalloc(sizeof(PafHitD) * (size_t)total);
-    if (!d_hits) { paf_dev_release(H); return GCI_E_NOMEM; }
-    for (int f = 0; f < n_ok; f++)
-        if (file_hits[f]) {
-            hipError_t e = hipMemcpyAsync(d_hits + hits_upto[f], file_hits[f], sizeof(PafHitD) * (size_t)(hits_upto[f + 1] - hits_upto[f]),
-                                          hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) { paf_dev_release(H); return gci_fail(ctx, e, "hipMemcpyAsync(hits)"); }
-        }
-    // ---- queries: table, lists ---------------------------------------------------------------------------------------
+    PAF_ALLOC(d_status, unsigned long long, 1);
+    PAF_ALLOC(d_n, uint32_t, 4);
     uint32_t n_slots = 1024;
     while (n_slots < 2ull * total) n_slots <<= 1;
-    uint32_t* d_table = (uint32_t*)dalloc(4ull * n_slots);
-    uint32_t* d_count = (uint32_t*)dalloc(4ull * (n_slots + 1));
-    uint32_t* d_start = (uint32_t*)dalloc(4ull * (n_slots + 1));
-    uint32_t* d_hq = (uint32_t*)dalloc(4ull * n_slots);
-    uint32_t* d_cursor = (uint32_t*)dalloc(4ull * n_slots);
-    uint32_t* d_order = (uint32_t*)dalloc(4ull * total);
-    uint32_t* d_blk3 = (uint32_t*)dalloc(4ull * (n_slots / TILE + 2));
-    int64_t* d_pa = (int64_t*)dalloc(8ull * total);
-    int64_t* d_pb = (int64_t*)dalloc(8ull * total);
-    if (!d_table || !d_count || !d_start || !d_hq || !d_cursor || !d_order || !d_blk3 || !d_pa || !d_pb) { paf_dev_release(H); return GCI_E_NOMEM; }
-    int rc = GCI_OK;
-    auto bail = [&](int code) { paf_dev_release(H); return code; };
-    if (hipMemsetAsync(d_table, 0xFF, 4ull * n_slots, st) != hipSuccess || hipMemsetAsync(d_count, 0, 4ull * (n_slots + 1), st) != hipSuccess ||
-        hipMemsetAsync(d_hq, 0, 4ull * n_slots, st) != hipSuccess || hipMemsetAsync(d_cursor, 0, 4ull * n_slots, st) != hipSuccess)
-        return bail(GCI_E_HIP);
-    hipLaunchKernelGGL(k_paf_insert, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_text, d_hits, 0u, total, d_table, n_slots - 1,
+    PAF_ALLOC(d_table, uint32_t, n_slots);
+    PAF_ALLOC(d_count, uint32_t, n_slots + 1);
+    PAF_ALLOC(d_start, uint32_t, n_slots + 1);
+    PAF_ALLOC(d_hq, uint32_t, n_slots);
+    PAF_ALLOC(d_cursor, uint32_t, n_slots);
+    PAF_ALLOC(d_order, uint32_t, total);
+    PAF_ALLOC(d_blk3, uint32_t, n_slots / TILE + 2);
+    PAF_ALLOC(d_pa, int64_t, total);
+    PAF_ALLOC(d_pb, int64_t, total);
+    HIPCHK(hipMemsetAsync(d_table, 0xFF, 4ull * n_slots, st));
+    HIPCHK(hipMemsetAsync(d_count, 0, 4ull * (n_slots + 1), st));
+    HIPCHK(hipMemsetAsync(d_hq, 0, 4ull * n_slots, st));
+    HIPCHK(hipMemsetAsync(d_cursor, 0, 4ull * n_slots, st));
+    hipLaunchKernelGGL(k_paf_insert, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_names, d_hits, 0u, total, d_table, n_slots - 1,
                        d_count, d_hq);
-    rc = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_count, d_start, d_blk3, (int64_t)n_slots, true);
-    if (rc) return bail(rc);
+    LAUNCHCHK("k_paf_insert");
+    int rc = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_count, d_start, d_blk3, (int64_t)n_slots, true);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_paf_scatter, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, total,
                        (const uint32_t*)d_start, d_cursor, d_order);
-    if (hipGetLastError() != hipSuccess) return bail(GCI_E_HIP);
-    // ---- per file: score the queries over the hits so far ------------------------------------------------------------
-    if (hipMemsetAsync(d_status, 0xFF, 8, st) != hipSuccess) return bail(GCI_E_HIP);
+    LAUNCHCHK("k_paf_scatter");
+    HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, st));
     bool lists_sorted = false;
     for (int f = 0; f < n_ok; f++) {
         const uint32_t limit = hits_upto[f + 1];
         if (limit == 0) continue;
         void *p_recs = nullptr, *p_off = nullptr;
-        if (hipMalloc(&p_recs, sizeof(gci_rec) * (size_t)limit) != hipSuccess) return bail(GCI_E_NOMEM);
+        if (hipMalloc(&p_recs, sizeof(gci_rec) * (size_t)limit) != hipSuccess) return GCI_E_NOMEM;
         H->recs[f] = p_recs;
-        if (hipMalloc(&p_off, 8ull * limit) != hipSuccess) return bail(GCI_E_NOMEM);
+        if (hipMalloc(&p_off, 8ull * limit) != hipSuccess) return GCI_E_NOMEM;
         H->name_off[f] = p_off;
-        if (hipMemsetAsync(d_n, 0, 4, st) != hipSuccess) return bail(GCI_E_HIP);
+        HIPCHK(hipMemsetAsync(d_n, 0, 4, st));
         hipLaunchKernelGGL(k_paf_score, dim3((n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, (const uint32_t*)d_table,
-                           n_slots, (const uint32_t*)d_start, d_order, limit, (const uint32_t*)d_hq, (const int32_t*)d_trank, d_pa, d_pb,
+                           n_slots, (const uint32_t*)d_start, d_order, limit, (const uint32_t*)d_hq, d_trank, d_pa, d_pb,
                            lists_sorted ? 0 : 1, (gci_rec*)p_recs, (uint64_t*)p_off, d_n, d_status);
-        if (hipGetLastError() != hipSuccess) return bail(GCI_E_HIP);
+        LAUNCHCHK("k_paf_score");
         lists_sorted = true;
         uint32_t n_q = 0;
         unsigned long long h_status = 0;
-        if (hipMemcpyAsync(&n_q, d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&h_status, d_status, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return bail(GCI_E_HIP);
-        if (h_status != ~0ull) { if (err_line) *err_line = 0; return bail(-(int)(h_status & 0xFF)); }
+        HIPCHK(hipMemcpyAsync(&n_q, d_n, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&h_status, d_status, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_status != ~0ull) return -(int)(h_status & 0xFF);
         H->count[f] = n_q;
     }
-    if (pending_status != GCI_OK) { paf_dev_release(H); return pending(); }
+    return GCI_OK;
+}
+
+}  // namespace
+
+extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const uint64_t* h_file_end, int n_files,
+                                     const char* const* targets, int n_targets, int map_qual, int mq_cutoff, double iden_percent,
+                                     gci_paf_dev** out, uint64_t* err_line)
+{
+    if (!ctx || !out || n_files < 0 || (n_files && (!d_text || !h_file_end)) || (n_targets && !targets)) return GCI_E_INVALID;
+    *out = nullptr;
+    if (err_line) *err_line = 0;
+    hipStream_t st = ctx->stream;
+    PafScratch S;
+    PafTargets T;
+    int rc = paf_targets(ctx, S, targets, n_targets, T);
+    if (rc) return rc;
+    PafStageA A;
+    rc = paf_stage_a(ctx, S, d_text, h_file_end, n_files, T, map_qual, mq_cutoff, iden_percent, A);
+    if (rc) return rc;
+    auto pending = [&]() { if (err_line) *err_line = A.pending_line; return A.pending_status; };
+    gci_paf_dev* H = new (std::nothrow) gci_paf_dev();
+    if (!H) return GCI_E_NOMEM;
+    H->ctx = ctx;
+    H->recs.assign(n_files, nullptr); H->name_off.assign(n_files, nullptr); H->count.assign(n_files, 0);
+    const uint32_t total = A.hits_upto[A.n_ok];
+    if (total) {
+        // one array of all hits, files in command-line order
+        PafHitD* d_hits = (PafHitD*)S.alloc(sizeof(PafHitD) * (size_t)total);
+        if (!d_hits) { paf_dev_release(H); return GCI_E_NOMEM; }
+        for (int f = 0; f < A.n_ok; f++)
+            if (A.file_hits[f]) {
+                hipError_t e = hipMemcpyAsync(d_hits + A.hits_upto[f], A.file_hits[f],
+                                              sizeof(PafHitD) * (size_t)(A.hits_upto[f + 1] - A.hits_upto[f]), hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) { paf_dev_release(H); return gci_fail(ctx, e, "hipMemcpyAsync(hits)"); }
+            }
+        rc = paf_stage_b(ctx, S, d_text, d_hits, A.hits_upto, A.n_ok, T.rank, H);
+        if (rc) { paf_dev_release(H); return rc; }                       // (a scoring error of an earlier file comes before a pending line)
+    }
+    if (A.pending_status != GCI_OK) { paf_dev_release(H); return pending(); }
     *out = H;
     return GCI_OK;
-#undef PAF_ALLOC
+}
+
+// ---- the same in two halves, for runs that shard a PAF file by byte range (gci_amd/shard.py: ShardedPaf) -------------------
+// Stage A over this rank's range of every file (the bytes of the ranges back to back in d_text): the lines that pass, as
+// 80-byte hits whose qn_off points into d_text.  A line the reference would raise on is reported as by
+// gci_paf_filter_device, but *err_line counts from the start of the RANGE: the sharded caller does not interpret it -- all
+// ranks fall back to the whole files, where the reference's exception comes out exactly.
+extern "C" int gci_paf_hits_device(gci_ctx* ctx, const uint8_t* d_text, const uint64_t* h_file_end, int n_files,
+                                   const char* const* targets, int n_targets, int map_qual, int mq_cutoff, double iden_percent,
+                                   gci_paf_hits** out, uint64_t* err_line)
+{
+    if (!ctx || !out || n_files < 0 || (n_files && (!d_text || !h_file_end)) || (n_targets && !targets)) return GCI_E_INVALID;
+    *out = nullptr;
+    if (err_line) *err_line = 0;
+    PafScratch S;
+    PafTargets T;
+    int rc = paf_targets(ctx, S, targets, n_targets, T);
+    if (rc) return rc;
+    PafStageA A;
+    rc = paf_stage_a(ctx, S, d_text, h_file_end, n_files, T, map_qual, mq_cutoff, iden_percent, A);
+    if (rc) return rc;
+    if (A.pending_status != GCI_OK) { if (err_line) *err_line = A.pending_line; return A.pending_status; }
+    gci_paf_hits* H = new (std::nothrow) gci_paf_hits();
+    if (!H) return GCI_E_NOMEM;
+    H->ctx = ctx;
+    H->hits.assign(n_files, nullptr); H->count.assign(n_files, 0);
+    for (int f = 0; f < n_files; f++) {
+        H->count[f] = A.hits_upto[f + 1] - A.hits_upto[f];
+        if (A.file_hits[f]) { H->hits[f] = A.file_hits[f]; S.keep(A.file_hits[f]); }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = H;
+    return GCI_OK;
+}
+
+extern "C" uint64_t gci_paf_hits_count(const gci_paf_hits* h, int file)
+{
+    return h && file >= 0 && (size_t)file < h->count.size() ? h->count[file] : 0;
+}
+
+// copies file `file`'s hits (gci_paf_hits_count() entries of GCI_PAF_HIT_BYTES) into the caller's device buffer
+extern "C" int gci_paf_hits_export(const gci_paf_hits* h, int file, uint8_t* d_hits)
+{
+    if (!h || !h->ctx || file < 0 || (size_t)file >= h->count.size()) return GCI_E_INVALID;
+    gci_ctx* ctx = h->ctx;
+    const size_t n = h->count[file];
+    if (n == 0) return GCI_OK;
+    if (!d_hits) return GCI_E_INVALID;
+    HIPCHK(hipMemcpyAsync(d_hits, h->hits[file], n * sizeof(PafHitD), hipMemcpyDeviceToDevice, ctx->stream));
+    return GCI_OK;
+}
+
+extern "C" int gci_paf_hits_free(gci_paf_hits* h)
+{
+    if (!h) return GCI_OK;
+    if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
+    paf_hits_release(h);
+    return GCI_OK;
+}
+
+// Stage B over hits gathered from every rank: d_hits = the hits of the queries this rank owns, file after file
+// (h_hits_upto[f] = first hit of file f, h_hits_upto[n_files] = their number), every file in line order, qn_off relative to
+// d_names.  d_hits is modified (the query slots).  -> the handle gci_paf_filter_device returns (name offsets relative to d_names).
+extern "C" int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, const uint32_t* h_hits_upto, int n_files,
+                                    const char* const* targets, int n_targets, gci_paf_dev** out)
+{
+    if (!ctx || !out || n_files < 0 || !h_hits_upto || (n_targets && !targets)) return GCI_E_INVALID;
+    *out = nullptr;
+    std::vector<uint32_t> upto(h_hits_upto, h_hits_upto + n_files + 1);
+    for (int f = 0; f < n_files; f++) if (upto[f + 1] < upto[f]) return GCI_E_INVALID;
+    if (upto[n_files] && (!d_hits || !d_names)) return GCI_E_INVALID;
+    PafScratch S;
+    PafTargets T;
+    int rc = paf_targets(ctx, S, targets, n_targets, T);
+    if (rc) return rc;
+    gci_paf_dev* H = new (std::nothrow) gci_paf_dev();
+    if (!H) return GCI_E_NOMEM;
+    H->ctx = ctx;
+    H->recs.assign(n_files, nullptr); H->name_off.assign(n_files, nullptr); H->count.assign(n_files, 0);
+    rc = paf_stage_b(ctx, S, d_names, (PafHitD*)d_hits, upto, n_files, T.rank, H);
+    if (rc) { paf_dev_release(H); return rc; }
+    *out = H;
+    return GCI_OK;
 }
 
 extern "C" uint64_t gci_paf_dev_count(const gci_paf_dev* h, int file)

@@ -25,13 +25,20 @@
 struct RouteSrc {
     const gci_rec* recs; const uint8_t* name_base; const uint64_t* name_off; uint32_t name_delta;   // records
     const gci_ivl* ivl; const uint32_t* d_n; const int32_t* owner; int32_t n_owner;                  // intervals
+    const gci_paf_hit* hits;                                                                        // PAF hits (names: name_base + qn_off)
     uint32_t n;                                                                                     // items (intervals: at most)
 };
+static_assert(sizeof(gci_paf_hit) == GCI_PAF_HIT_BYTES, "a PAF hit is 80 bytes");
+#define ROUTE_RECS 0
+#define ROUTE_IVL 1
+#define ROUTE_HITS 2
 
-template <bool IVL>
+template <int KIND>
 __device__ __forceinline__ int route_dest(const RouteSrc& S, uint32_t i, uint32_t n, uint32_t n_parts)
 {
+    constexpr bool IVL = KIND == ROUTE_IVL;
     if (i >= n) return -1;
+    if (KIND == ROUTE_HITS) return (int)((S.hits[i].qhash >> 33) % n_parts);
     if (IVL) {
         const int32_t c = S.ivl[i].contig;
         if (c < 0 || c >= S.n_owner) return -1;
@@ -43,16 +50,17 @@ __device__ __forceinline__ int route_dest(const RouteSrc& S, uint32_t i, uint32_
     return (int)((r.name_hash >> 33) % n_parts);
 }
 
-template <bool IVL>
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_route_count(const RouteSrc S, uint32_t n_parts, uint32_t n_chunks, uint32_t* __restrict__ counts)
 {
+    constexpr bool IVL = KIND == ROUTE_IVL;
     __shared__ uint32_t h[ROUTE_MAX_PARTS];
     const uint32_t t = threadIdx.x, chunk = blockIdx.x;
     if (t < ROUTE_MAX_PARTS) h[t] = 0;
     __syncthreads();
     const uint32_t n = IVL ? min(*S.d_n, S.n) : S.n;
     for (uint32_t k = 0; k < ROUTE_CHUNK / BLOCK; k++) {
-        const int d = route_dest<IVL>(S, chunk * ROUTE_CHUNK + k * BLOCK + t, n, n_parts);
+        const int d = route_dest<KIND>(S, chunk * ROUTE_CHUNK + k * BLOCK + t, n, n_parts);
         if (d >= 0) atomicAdd(&h[d], 1u);
     }
     __syncthreads();
@@ -74,17 +82,21 @@ __device__ __forceinline__ uint32_t route_name_dword(const uint8_t* p, uint32_t 
     return w;
 }
 
-template <bool IVL>
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint32_t n_parts, uint32_t n_chunks, uint32_t cap,
                                                          const uint32_t* __restrict__ off, uint8_t* __restrict__ out,
                                                          uint8_t* __restrict__ out_names, uint32_t name_slot, unsigned long long* __restrict__ status)
 {
+    constexpr bool IVL = KIND == ROUTE_IVL;
     __shared__ uint32_t run[ROUTE_MAX_PARTS], wcnt[BLOCK / 64][ROUTE_MAX_PARTS];
     const uint32_t t = threadIdx.x, chunk = blockIdx.x, lane = t & 63, wave = t >> 6;
     if (t < n_parts) run[t] = off[(size_t)t * n_chunks + chunk] - off[(size_t)t * n_chunks];     // position inside the bucket
     if (chunk == 0 && t < n_parts) {                              // headers: how many items were routed to each part
         const uint32_t total = off[(size_t)(t + 1) * n_chunks] - off[(size_t)t * n_chunks];
-        if (IVL) {
+        if (KIND == ROUTE_HITS) {
+            gci_paf_hit h; memset(&h, 0, sizeof h); h.qhash = total; h.t = -1;
+            reinterpret_cast<gci_paf_hit*>(out)[(size_t)t * (cap + 1)] = h;
+        } else if (IVL) {
             gci_ivl h; h.contig = -1; h.start = (int32_t)total; h.end = 0; h.pad = 0;
             reinterpret_cast<gci_ivl*>(out)[(size_t)t * (cap + 1)] = h;
         } else {
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint3
         for (uint32_t i = t; i < (BLOCK / 64) * ROUTE_MAX_PARTS; i += BLOCK) (&wcnt[0][0])[i] = 0;
         __syncthreads();
         const uint32_t i = chunk * ROUTE_CHUNK + k * BLOCK + t;
-        const int d = route_dest<IVL>(S, i, n, n_parts);
+        const int d = route_dest<KIND>(S, i, n, n_parts);
         // rank among the lanes of this wave that go to the same part, in lane order
         uint32_t lane_rank = 0;
         for (unsigned long long todo = __ballot(d >= 0); todo;) {
@@ -118,7 +130,15 @@ __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint3
         if (t < n_parts) { uint32_t a = 0; for (uint32_t w = 0; w < BLOCK / 64; w++) a += wcnt[w][t]; run[t] += a; }
         if (d >= 0 && pos < cap) {
             const size_t slot = (size_t)d * (cap + 1) + 1 + pos;
-            if (IVL) reinterpret_cast<gci_ivl*>(out)[slot] = S.ivl[i];
+            if (KIND == ROUTE_HITS) {
+                const gci_paf_hit h = S.hits[i];
+                reinterpret_cast<gci_paf_hit*>(out)[slot] = h;
+                uint32_t* nd = reinterpret_cast<uint32_t*>(out_names + ((size_t)d * cap + pos) * name_slot);
+                if (h.qn_len > name_slot) atomicMin(status, (unsigned long long)(unsigned)(-GCI_E_CAPACITY));
+                const uint8_t* src = S.name_base + h.qn_off;
+                const uint32_t len = h.qn_len < name_slot ? h.qn_len : name_slot;
+                for (uint32_t w = 0; w < name_slot / 4; w++) nd[w] = route_name_dword(src, len, w);
+            } else if (IVL) reinterpret_cast<gci_ivl*>(out)[slot] = S.ivl[i];
             else {
                 gci_rec r = S.recs[i];
                 r.flags |= GCI_REC_NAME16;                        // a routed name slot: 16-byte aligned, zero padded
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_route_scatter(const RouteSrc S, uint3
     }
 }
 
-static int route_impl(gci_ctx* ctx, const RouteSrc& S, bool ivl, uint32_t n_parts, uint32_t cap, uint8_t* d_out, uint8_t* d_out_names,
+static int route_impl(gci_ctx* ctx, const RouteSrc& S, int kind, uint32_t n_parts, uint32_t cap, uint8_t* d_out, uint8_t* d_out_names,
                       uint32_t name_slot, uint64_t* d_status)
 {
     if (n_parts == 0 || n_parts > ROUTE_MAX_PARTS || !d_out || !d_status) return GCI_E_INVALID;
@@ -144,14 +164,17 @@ static int route_impl(gci_ctx* ctx, const RouteSrc& S, bool ivl, uint32_t n_part
     GCI_TRY(gci_ensure(ctx, ctx->part_blk, (n_tab / TILE + 2) * 4));
     uint32_t* tab = (uint32_t*)ctx->route_tab.p;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
-    if (ivl) hipLaunchKernelGGL((k_route_count<true>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, tab);
-    else hipLaunchKernelGGL((k_route_count<false>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, tab);
+    if (kind == ROUTE_IVL) hipLaunchKernelGGL((k_route_count<ROUTE_IVL>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, tab);
+    else if (kind == ROUTE_HITS) hipLaunchKernelGGL((k_route_count<ROUTE_HITS>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, tab);
+    else hipLaunchKernelGGL((k_route_count<ROUTE_RECS>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, tab);
     LAUNCHCHK("k_route_count");
     int r = device_exclusive_scan<uint32_t, uint32_t>(ctx, tab, tab, (uint32_t*)ctx->part_blk.p, (int64_t)n_tab, true);
     if (r) return r;
-    if (ivl) hipLaunchKernelGGL((k_route_scatter<true>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, cap,
-                                (const uint32_t*)tab, d_out, d_out_names, name_slot, (unsigned long long*)d_status);
-    else hipLaunchKernelGGL((k_route_scatter<false>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, cap,
+    if (kind == ROUTE_IVL) hipLaunchKernelGGL((k_route_scatter<ROUTE_IVL>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, cap,
+                                              (const uint32_t*)tab, d_out, d_out_names, name_slot, (unsigned long long*)d_status);
+    else if (kind == ROUTE_HITS) hipLaunchKernelGGL((k_route_scatter<ROUTE_HITS>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks,
+                                                    cap, (const uint32_t*)tab, d_out, d_out_names, name_slot, (unsigned long long*)d_status);
+    else hipLaunchKernelGGL((k_route_scatter<ROUTE_RECS>), dim3(n_chunks), dim3(BLOCK), 0, ctx->stream, S, n_parts, n_chunks, cap,
                             (const uint32_t*)tab, d_out, d_out_names, name_slot, (unsigned long long*)d_status);
     LAUNCHCHK("k_route_scatter");
     return GCI_OK;
@@ -167,7 +190,7 @@ extern "C" int gci_route_records(gci_ctx* ctx, const gci_join_file* h_file, uint
     memset(&S, 0, sizeof S);
     S.recs = h_file->d_recs; S.name_base = h_file->d_name_base; S.name_off = h_file->d_name_off; S.name_delta = h_file->name_delta;
     S.n = h_file->n_recs;
-    return route_impl(ctx, S, false, n_parts, cap, (uint8_t*)d_out_recs, d_out_names, name_slot, d_status);
+    return route_impl(ctx, S, ROUTE_RECS, n_parts, cap, (uint8_t*)d_out_recs, d_out_names, name_slot, d_status);
 }
 
 extern "C" int gci_route_intervals(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n, const int32_t* d_owner,
@@ -177,7 +200,19 @@ extern "C" int gci_route_intervals(gci_ctx* ctx, const gci_ivl* d_ivl, const uin
     RouteSrc S;
     memset(&S, 0, sizeof S);
     S.ivl = d_ivl; S.d_n = d_n; S.owner = d_owner; S.n_owner = n_contigs; S.n = max_n;
-    return route_impl(ctx, S, true, n_parts, cap, (uint8_t*)d_out, nullptr, 16, d_status);
+    return route_impl(ctx, S, ROUTE_IVL, n_parts, cap, (uint8_t*)d_out, nullptr, 16, d_status);
+}
+
+// PAF hits of a byte range -> the ranks that own their query names (stable: a query's hits keep their line order).
+extern "C" int gci_route_hits(gci_ctx* ctx, const uint8_t* d_hits, uint32_t n, const uint8_t* d_name_base, uint32_t n_parts, uint32_t cap,
+                              uint8_t* d_out_hits, uint8_t* d_out_names, uint32_t name_slot, uint64_t* d_status)
+{
+    if (name_slot < 16 || name_slot > 65536 || (name_slot & 15u)) return GCI_E_INVALID;
+    if (!ctx || !d_out_names || (n && (!d_hits || !d_name_base))) return GCI_E_INVALID;
+    RouteSrc S;
+    memset(&S, 0, sizeof S);
+    S.hits = reinterpret_cast<const gci_paf_hit*>(d_hits); S.name_base = d_name_base; S.n = n;
+    return route_impl(ctx, S, ROUTE_HITS, n_parts, cap, d_out_hits, d_out_names, name_slot, d_status);
 }
 
 // ---- after the all-to-all: what arrived beyond a bucket's count is not data ---------------------------------------------

@@ -513,15 +513,72 @@ class Engine:
             raise GciError(st, "gci_paf_filter_device: %s (line %d) %s" % (self.lib.gci_strerror(st).decode(), line.value, detail),
                            rec=int(line.value))
         try:
+            return self._paf_dev_inputs(handle, len(bufs), d_text)
+        finally:
+            self.lib.gci_paf_dev_free(handle)
+
+    # ---- the PAF filter in two halves (runs that shard a PAF file by byte range: shard.paf_by_byte_range) ----
+    PAF_HIT_BYTES = 80
+
+    def _paf_dev_inputs(self, handle, n_files: int, d_names: torch.Tensor) -> List[JoinInput]:
+        out = []
+        for f in range(n_files):
+            n = int(self.lib.gci_paf_dev_count(handle, f))
+            recs = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+            off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            self._chk(self.lib.gci_paf_dev_export(handle, f, self._p(recs), self._p(off)), "gci_paf_dev_export")
+            out.append(JoinInput(recs[:n], d_names, off[:n], 0))
+        self.sync()
+        return out
+
+    def paf_hits_text(self, d_text: torch.Tensor, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
+                      iden_percent: float) -> List[torch.Tensor]:
+        """Stage A (gci_paf_hits_device) over the byte ranges in d_text (ends[i] = end of file i's range): per file the lines
+        that pass, as a uint8 tensor [n, 80] of gci_paf_hit in line order (qn_off points into d_text)."""
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        n_files = int(ends.shape[0])
+        tnames = [t.encode() for t in targets]
+        tarr = (ctypes.c_char_p * max(len(tnames), 1))(*tnames)
+        handle, line = ctypes.c_void_p(None), ctypes.c_uint64(0)
+        st = self.lib.gci_paf_hits_device(self.ctx, self._p(d_text), ends.ctypes.data_as(ctypes.c_void_p), n_files, tarr, len(tnames),
+                                          int(map_qual), int(mq_cutoff), float(iden_percent), ctypes.byref(handle), ctypes.byref(line))
+        if st != 0:
+            raise GciError(st, "gci_paf_hits_device: %s (line %d of the range)" % (self.lib.gci_strerror(st).decode(), line.value),
+                           rec=int(line.value))
+        try:
             out = []
-            for f in range(len(bufs)):
-                n = int(self.lib.gci_paf_dev_count(handle, f))
-                recs = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
-                off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
-                self._chk(self.lib.gci_paf_dev_export(handle, f, self._p(recs), self._p(off)), "gci_paf_dev_export")
-                out.append(JoinInput(recs[:n], d_text, off[:n], 0))
+            for f in range(n_files):
+                n = int(self.lib.gci_paf_hits_count(handle, f))
+                h = torch.empty((max(n, 1), self.PAF_HIT_BYTES), dtype=torch.uint8, device=self.device)
+                self._chk(self.lib.gci_paf_hits_export(handle, f, self._p(h)), "gci_paf_hits_export")
+                out.append(h[:n])
             self.sync()
             return out
+        finally:
+            self.lib.gci_paf_hits_free(handle)
+
+    def route_hits(self, hits: torch.Tensor, d_name_base: torch.Tensor, n_parts: int, cap: int, out_hits: torch.Tensor,
+                   out_names: torch.Tensor, name_slot: int, status: torch.Tensor) -> None:
+        """gci_route_hits: hits [n, 80] -> out_hits [n_parts * (cap + 1), 80] (slot 0 of a bucket: header, qhash = count), their
+        query names into out_names [n_parts * cap * name_slot]."""
+        n = int(hits.shape[0])
+        self._chk(self.lib.gci_route_hits(self.ctx, self._p(hits) if n else None, n, self._p(d_name_base), int(n_parts), int(cap),
+                                          self._p(out_hits), self._p(out_names), int(name_slot), self._p(status)), "gci_route_hits")
+
+    def paf_score_hits(self, d_names: torch.Tensor, d_hits: torch.Tensor, upto: Sequence[int], targets: Sequence[str]) -> List[JoinInput]:
+        """Stage B (gci_paf_score_device): d_hits [total, 80] = the hits of the queries this rank owns, file after file
+        (upto[f] = first hit of file f, upto[-1] = total), qn_off relative to d_names -> one JoinInput per file."""
+        n_files = len(upto) - 1
+        h_upto = np.ascontiguousarray(upto, dtype=np.uint32)
+        tnames = [t.encode() for t in targets]
+        tarr = (ctypes.c_char_p * max(len(tnames), 1))(*tnames)
+        handle = ctypes.c_void_p(None)
+        st = self.lib.gci_paf_score_device(self.ctx, self._p(d_names), self._p(d_hits) if int(h_upto[-1]) else None,
+                                           h_upto.ctypes.data_as(ctypes.c_void_p), n_files, tarr, len(tnames), ctypes.byref(handle))
+        if st != 0:
+            raise GciError(st, "gci_paf_score_device: %s" % self.lib.gci_strerror(st).decode(), rec=0)
+        try:
+            return self._paf_dev_inputs(handle, n_files, d_names)
         finally:
             self.lib.gci_paf_dev_free(handle)
 

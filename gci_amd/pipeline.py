@@ -756,7 +756,9 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
     (GCI.py:269, 296-297) -- but it is independent per NAME: every rank filters the records of ITS contigs (K1), routes them
     by name hash to the rank that owns the name (two all-to-alls per file), joins the names it owns and routes the surviving
     intervals to the owners of their contigs (shard.ShardedJoin; round 2 replicated every record on every rank).
-    PAF files are filtered whole on every rank (K2; they are a hundredth of the BAMs); a rank keeps the names it owns."""
+    PAF files are sharded by byte range (shard.paf_by_byte_range: every rank tokenises the lines of its range, the hits travel to
+    the rank that owns their query name and are scored there); GCI_PAF_SHARDING=whole keeps round 2's way (every rank filters the
+    whole files and keeps the names it owns), which is also what runs when a line raises."""
     from . import shard
     first = bamfmt.read_header(bam_files[0])
     pairs = [(r, l) for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)]
@@ -773,8 +775,15 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
     err, err_contig = None, 1 << 30
     try:
         if len(paf_files) != 0:
-            paf_inputs = [_own_names_only(engine, ji, SHARD.world, SHARD.rank)
-                          for ji in engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)]
+            # every rank tokenises 1 / world of the files' bytes; the hits are scored on the rank that owns their query name
+            # (None: a line the reference raises on -- then every rank reads the whole files, and the exception comes out exact)
+            by_range = None
+            if PAF_SHARDING == "range":
+                by_range = shard.paf_by_byte_range(engine, paf_files, targets, map_qual, mq_cutoff, iden_percent, SHARD.world, SHARD.rank,
+                                                   SHARD.all_reduce_max, engine.device, via_host=SHARD.backend != "nccl")
+            paf_inputs = by_range if by_range is not None else [
+                _own_names_only(engine, ji, SHARD.world, SHARD.rank)
+                for ji in engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)]
         for path in bam_files:
             local.append(bam_records_of_contigs(engine, path, targets, list(local_tl), filt, threads))
     except GciError as e:
@@ -827,6 +836,9 @@ def _reraise_like_reference(e: GciError):
         raise ZeroDivisionError("division by zero") from e
     raise e
 
+
+# Contig-sharded runs: "range" (default) = PAF files by byte range, "whole" = every rank the whole files.
+PAF_SHARDING = os.environ.get("GCI_PAF_SHARDING", "range")
 
 # How `{prefix}.depth.gz` is produced.  "gpu" (default): the device writes the gzip members straight from the track
 # (gci_depth_deflate_*: no text buffer, a few MB cross PCIe).  "host": the device renders the text, host threads gzip it.

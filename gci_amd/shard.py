@@ -336,13 +336,7 @@ class ShardedJoin:
         self._alloc([int(c * factor) for c in self.rec_cap], int(self.ivl_cap * factor))
 
     def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
-        if not self.via_host:
-            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
-            return
-        h = send.reshape(-1).cpu()
-        r = torch.empty_like(h)
-        dist.all_to_all_single(r, h, group=self.group)
-        recv.view(-1).copy_(r)
+        all_to_all_bytes(recv, send, self.group, self.via_host)
 
     def exchange_file(self, f: int, ji) -> "object":
         """One file's records of this rank -> the records (of every rank) whose names this rank owns, as a join input."""
@@ -379,3 +373,151 @@ class ShardedJoin:
         what += ["gci_name_join", "gci_route_intervals", "gci_route_seal_intervals"]
         for w, name in zip(self.status.cpu().numpy().view(np.uint64).tolist(), what):
             decode(w, name)
+
+
+# ---- PAF files sharded by byte range (the PAF half of filter(), /root/reference/GCI.py:211-254) ------------------------------
+
+def line_start_at_or_after(raw: np.ndarray, pos: int) -> int:
+    """The first position >= pos of the byte array `raw` at which a line starts, as Python's universal newlines cut lines (what
+    `for line in f` at GCI.py:217 sees; k_paf.hip: line_starts_at): position 0, behind '\\n', or behind a '\\r' that no '\\n'
+    follows.  len(raw) when no line starts at or behind pos."""
+    n = int(raw.shape[0])
+    if pos <= 0:
+        return 0
+    p = int(pos)
+    while p < n:
+        hi = min(n, p + (1 << 16))
+        prev = np.asarray(raw[p - 1:hi - 1])
+        cur = np.asarray(raw[p:hi])
+        hit = np.flatnonzero((prev == 10) | ((prev == 13) & (cur != 10)))
+        if hit.shape[0]:
+            return p + int(hit[0])
+        p = hi
+    return n
+
+
+def byte_range_of_rank(raw: np.ndarray, rank: int, world: int) -> Tuple[int, int]:
+    """Rank `rank`'s share of a text file: the lines that START in [size * rank / world, size * (rank + 1) / world)."""
+    n = int(raw.shape[0])
+    lo = line_start_at_or_after(raw, n * rank // world)
+    hi = n if rank + 1 == world else line_start_at_or_after(raw, n * (rank + 1) // world)
+    return lo, max(lo, hi)
+
+
+def all_to_all_bytes(recv: torch.Tensor, send: torch.Tensor, group=None, via_host: bool = False) -> None:
+    """Equal-split all-to-all of two device tensors of the same shape (via_host: staged through host memory, gloo)."""
+    if not via_host:
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+        return
+    h = send.reshape(-1).cpu()
+    r = torch.empty_like(h)
+    dist.all_to_all_single(r, h, group=group)
+    recv.view(-1).copy_(r)
+
+
+def paf_by_byte_range(ops, paths: Sequence[str], targets: Sequence[str], map_qual: int, mq_cutoff: int, iden_percent: float,
+                      world: int, rank: int, all_reduce_max, device: torch.device, group=None, via_host: bool = False,
+                      slack: float = 1.3) -> Optional[list]:
+    """The PAF files of a run, every rank parsing 1/world of their BYTES.
+
+    GCI.py:211-254 scores a query over ALL its lines (of all files so far, in file order), and a query's lines may lie
+    anywhere in a file -- so the work splits in two: (A) every rank tokenises and filters the lines that start in its byte range
+    of every file (`ops.paf_hits_text`: the expensive half -- str.strip / split / int() / the f64 identity of every line);
+    (B) the 80-byte hits travel to the rank that owns their query name ((hash >> 33) % world, the routing rule of the records:
+    one all-to-all of hits and one of name slots per file, stable, so that a query's hits arrive in line order: the ranges ascend
+    with the rank) and are scored there (`ops.paf_score_hits`).  -> one JoinInput per file holding the queries THIS rank owns,
+    i.e. what `_own_names_only(paf_filter(whole files))` gives.
+
+    None: some rank met a line (or a query) the reference raises on -- every rank returns None together and the caller runs the
+    whole files the old way, where the reference's exception comes out with its exact type and line."""
+    F = len(paths)
+    bad = 0
+    hits: List[torch.Tensor] = []
+    d_text = None
+    try:
+        parts = []
+        for p in paths:
+            raw = np.memmap(p, dtype=np.uint8, mode="r") if _file_size(p) else np.zeros(0, np.uint8)
+            lo, hi = byte_range_of_rank(raw, rank, world)
+            parts.append(np.asarray(raw[lo:hi]))
+        ends = np.cumsum([x.shape[0] for x in parts], dtype=np.uint64)
+        text = np.concatenate(parts + [np.zeros(16, np.uint8)])
+        d_text = ops.to_device(text)
+        hits = ops.paf_hits_text(d_text, ends, targets, map_qual, mq_cutoff, iden_percent)
+    except Exception as e:                                   # noqa: BLE001 -- agreed on below; the fallback raises it properly
+        if not _is_data_error(e):
+            raise
+        bad = 1
+    counts = [int(h.shape[0]) for h in hits] if not bad else [0] * F
+    longest = 0
+    if not bad:
+        for h in hits:
+            if int(h.shape[0]):
+                longest = max(longest, int(h[:, 64:68].contiguous().view(torch.int32).max().item()))
+    red = all_reduce_max([bad, longest] + counts)
+    if red[0]:
+        return None
+    name_slot = max(16, (red[1] + 15) // 16 * 16)
+    caps = [int(c * slack / world) + 256 for c in red[2:]]
+    B = ops.PAF_HIT_BYTES
+    while True:
+        status = torch.full((F,), -1, dtype=torch.int64, device=device)
+        recv_hits, recv_names = [], []
+        for f in range(F):
+            cap = caps[f]
+            send_h = torch.zeros((world * (cap + 1), B), dtype=torch.uint8, device=device)
+            send_n = torch.zeros(world * cap * name_slot, dtype=torch.uint8, device=device)
+            ops.route_hits(hits[f], d_text, world, cap, send_h, send_n, name_slot, status[f:f + 1])
+            r_h, r_n = torch.empty_like(send_h), torch.empty_like(send_n)
+            all_to_all_bytes(r_h, send_h, group, via_host)
+            all_to_all_bytes(r_n, send_n, group, via_host)
+            recv_hits.append(r_h)
+            recv_names.append(r_n)
+        # a bucket that overflowed on ANY rank (queries hash unevenly): larger buckets everywhere, again
+        over = int((status.cpu() != -1).any().item())
+        if all_reduce_max([over])[0]:
+            caps = [2 * c for c in caps]
+            continue
+        break
+    # what arrived: per file, per source rank, `count` hits behind the header slot -> one dense array in (file, rank, line) order,
+    # the names of all files in one buffer, qn_off pointing at the name slots
+    d_names = torch.cat(recv_names + [torch.zeros(16, dtype=torch.uint8, device=device)])
+    dense, upto, base = [], [0], 0
+    for f in range(F):
+        cap = caps[f]
+        bk = recv_hits[f].view(world, cap + 1, B)
+        cnt = bk[:, 0, 8:16].contiguous().view(torch.int64).reshape(-1).cpu().tolist()
+        n_f = 0
+        for d in range(world):
+            c = int(cnt[d])
+            if c:
+                part = bk[d, 1:1 + c].clone()
+                off = base + (d * cap + torch.arange(c, dtype=torch.int64, device=device)) * name_slot
+                part[:, 0:8] = off.view(torch.uint8).view(c, 8)
+                dense.append(part)
+                n_f += c
+        upto.append(upto[-1] + n_f)
+        base += world * cap * name_slot
+    d_hits = torch.cat(dense) if dense else torch.zeros((1, B), dtype=torch.uint8, device=device)
+    bad, out = 0, None
+    try:
+        out = ops.paf_score_hits(d_names, d_hits, upto, targets)
+    except Exception as e:                                   # noqa: BLE001
+        if not _is_data_error(e):
+            raise
+        bad = 1
+    if all_reduce_max([bad])[0]:
+        return None
+    return out
+
+
+def _file_size(path: str) -> int:
+    import os
+    return os.path.getsize(path)
+
+
+def _is_data_error(e: Exception) -> bool:
+    """An error the INPUT causes (a line the reference raises on): the sharded PAF path hands those to the whole-file path.
+    Anything else (HIP, memory, a bug) is raised where it happens."""
+    from ._lib import GciError, GCI_E_MALFORMED, GCI_E_ZERO_DIV
+    return isinstance(e, GciError) and e.status in (GCI_E_MALFORMED, GCI_E_ZERO_DIV)

@@ -435,6 +435,40 @@ uint64_t gci_paf_dev_count(const gci_paf_dev* r, int file);
 int gci_paf_dev_export(const gci_paf_dev* r, int file, gci_rec* d_recs, uint64_t* d_name_off);
 int gci_paf_dev_free(gci_paf_dev* r);
 
+/* The same filter in two halves, for runs that shard a PAF file over the GPUs of a node by BYTE RANGE (each rank tokenises the
+ * lines of its range; a query's lines may lie in several ranges, and GCI.py:241-254 scores a query over all of them -- in
+ * file order, over all files so far -- so the hits travel to the rank that owns the query name before they are scored):
+ *   gci_paf_hits_device   stage A: the lines of this rank's ranges (d_text: the ranges of the files back to back, cut at line
+ *                         starts) that pass GCI.py:218-239, as gci_paf_hit in line order; errors as gci_paf_filter_device,
+ *                         *err_line counted from the start of the range (sharded callers fall back to the whole files on
+ *                         any error, where the reference's exception comes out exactly)
+ *   gci_route_hits        hits -> n_parts buckets of (cap + 1) slots by (qhash >> 33) % n_parts, stable (slot 0: header,
+ *                         qhash = count), query names into slots of name_slot bytes -- as gci_route_records
+ *   gci_paf_score_device  stage B: the hits of the queries this rank owns, file after file (h_hits_upto), every file in line
+ *                         order (source rank after source rank: the ranges ascend with the rank), qn_off relative to d_names
+ *                         -> the handle of gci_paf_filter_device */
+typedef struct gci_paf_hit {
+    uint64_t qn_off;          /* where the query name lies (stage A: in d_text; stage B: in d_names) */
+    uint64_t qhash;           /* gci_name_hash of the query name */
+    int64_t qlen, qs, qe, ts, te;
+    double identity;          /* nmatch / alnlen, IEEE f64 */
+    uint32_t qn_len;
+    int32_t t;                /* target: index among the selected contigs */
+    uint32_t hq;              /* mapq >= mq_cutoff */
+    uint32_t slot;            /* scratch of stage B */
+} gci_paf_hit;
+#define GCI_PAF_HIT_BYTES 80
+typedef struct gci_paf_hits gci_paf_hits;
+int gci_paf_hits_device(gci_ctx* ctx, const uint8_t* d_text, const uint64_t* h_file_end, int n_files, const char* const* targets,
+                        int n_targets, int map_qual, int mq_cutoff, double iden_percent, gci_paf_hits** out, uint64_t* err_line);
+uint64_t gci_paf_hits_count(const gci_paf_hits* r, int file);
+int gci_paf_hits_export(const gci_paf_hits* r, int file, uint8_t* d_hits);
+int gci_paf_hits_free(gci_paf_hits* r);
+int gci_route_hits(gci_ctx* ctx, const uint8_t* d_hits, uint32_t n, const uint8_t* d_name_base, uint32_t n_parts, uint32_t cap,
+                   uint8_t* d_out_hits, uint8_t* d_out_names, uint32_t name_slot, uint64_t* d_status);
+int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, const uint32_t* h_hits_upto, int n_files,
+                         const char* const* targets, int n_targets, gci_paf_dev** out);
+
 /* ---- N1 on the GPU: BGZF inflate and the BAM record walk (k_inflate.hip; replaces pysam / htslib at GCI.py:150-151) ---------
  * gci_bgzf_inflate_device: d_raw = the bytes of a BGZF file (or of a run of its members) on the device; d_member_pos[m] =
  * offset of member m in d_raw, n_members + 1 entries (the last = end of the run; gci_bgzf_blocks makes the table on the

@@ -287,3 +287,193 @@ def test_world2_gloo_name_hash_sharded_join():
         p.join(60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+# ---- PAF files by byte range (shard.paf_by_byte_range) with plain-Python stand-ins for the three device operations ---------------
+
+HIT_DTYPE = np.dtype([("qn_off", "<u8"), ("qhash", "<u8"), ("qlen", "<i8"), ("qs", "<i8"), ("qe", "<i8"), ("ts", "<i8"), ("te", "<i8"),
+                      ("identity", "<f8"), ("qn_len", "<u4"), ("t", "<i4"), ("hq", "<u4"), ("slot", "<u4")])
+assert HIT_DTYPE.itemsize == 80
+
+
+class _PafOps:
+    """gci_paf_hits_device / gci_route_hits / gci_paf_score_device restated over numpy + tests/paf_ref's scoring rules."""
+    PAF_HIT_BYTES = 80
+
+    def __init__(self):
+        from gci_amd.device import REC_DTYPE, name_hash_np
+        self.REC_DTYPE, self.hash = REC_DTYPE, name_hash_np
+
+    def to_device(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a).copy())
+
+    def paf_hits_text(self, d_text, ends, targets, map_qual, mq_cutoff, iden_percent):
+        import re
+        text = d_text.numpy().tobytes()
+        out, lo = [], 0
+        for hi in [int(e) for e in ends]:
+            rows = []
+            for m in re.finditer(rb"[^\r\n]*(?:\r\n|\r|\n|\Z)", text[lo:hi]):
+                if m.end() == m.start():
+                    continue
+                raw = m.group(0)
+                line = raw.decode().strip()
+                col = line.split("\t")
+                if col[5] not in targets:
+                    continue
+                ident = int(col[9]) / int(col[10])
+                mapq = int(col[11])
+                if mapq >= map_qual and ident >= iden_percent:
+                    lead = len(raw) - len(raw.lstrip(b" \t\n\r\x0b\x0c"))
+                    q = col[0].encode()
+                    rows.append((lo + m.start() + lead, int(self.hash([q])[0]), int(col[1]), int(col[2]), int(col[3]), int(col[7]), int(col[8]),
+                                 ident, len(q), targets.index(col[5]), 1 if mapq >= mq_cutoff else 0, 0))
+            a = np.array(rows, dtype=HIT_DTYPE) if rows else np.zeros(0, dtype=HIT_DTYPE)
+            out.append(torch.from_numpy(a.view(np.uint8).reshape(-1, 80).copy()))
+            lo = hi
+        return out
+
+    def route_hits(self, hits, d_name_base, n_parts, cap, out_hits, out_names, name_slot, status):
+        h = hits.numpy().reshape(-1).view(HIT_DTYPE) if int(hits.shape[0]) else np.zeros(0, dtype=HIT_DTYPE)
+        base = d_name_base.numpy()
+        oh = out_hits.numpy().reshape(-1).view(HIT_DTYPE).reshape(n_parts, cap + 1)
+        on = out_names.numpy().reshape(n_parts, cap, name_slot)
+        oh[:] = 0
+        on[:] = 0
+        dest = (h["qhash"] >> np.uint64(33)) % np.uint64(n_parts)
+        for d in range(n_parts):
+            idx = np.flatnonzero(dest == d)                      # stable: line order kept
+            oh[d, 0]["qhash"] = idx.shape[0]
+            oh[d, 0]["t"] = -1
+            if idx.shape[0] > cap:
+                status[0] = 8
+                idx = idx[:cap]
+            oh[d, 1:1 + idx.shape[0]] = h[idx]
+            for k, i in enumerate(idx):
+                o, l = int(h["qn_off"][i]), int(h["qn_len"][i])
+                on[d, k, :l] = base[o:o + l]
+
+    def paf_score_hits(self, d_names, d_hits, upto, targets):
+        from gci_amd.device import JoinInput
+        from gci_amd.pipeline import _merge_span
+        names = d_names.numpy()
+        h = d_hits.numpy().reshape(-1).view(HIT_DTYPE)
+        blocks, hq, where = {}, set(), {}
+        out = []
+        for f in range(len(upto) - 1):
+            for i in range(upto[f], upto[f + 1]):
+                o, l = int(h["qn_off"][i]), int(h["qn_len"][i])
+                q = names[o:o + l].tobytes()
+                where.setdefault(q, o)
+                blocks.setdefault(q, {}).setdefault(int(h["t"][i]), []).append(
+                    (int(h["qlen"][i]), int(h["qs"][i]), int(h["qe"][i]), int(h["ts"][i]), int(h["te"][i]), float(h["identity"][i])))
+                if h["hq"][i]:
+                    hq.add(q)
+            recs = np.zeros(len(blocks), dtype=self.REC_DTYPE)
+            off = np.zeros(len(blocks), dtype=np.int64)
+            for k, (q, by_t) in enumerate(blocks.items()):
+                best_key, best = None, None
+                for t, alns in by_t.items():
+                    covered, _, _ = _merge_span([(a[1], a[2]) for a in alns])
+                    total = 0
+                    for a in alns:
+                        total = total + a[5]
+                    key = (total / len(alns) * (covered / alns[0][0]), targets[t])
+                    if best_key is None or key > best_key:
+                        _, s, e = _merge_span([(a[3], a[4]) for a in alns])
+                        best_key, best = key, (t, s, e, alns[0][0])
+                recs[k]["name_hash"] = int(self.hash([q])[0])
+                recs[k]["contig"], recs[k]["start"], recs[k]["end"], recs[k]["qlen"] = best
+                recs[k]["rec_idx"], recs[k]["name_len"] = k, len(q)
+                off[k] = where[q]
+            recs["flags"] = 1
+            out.append((JoinInput(torch.from_numpy(recs.view(np.uint8).reshape(-1, 32).copy()), d_names, torch.from_numpy(off), 0), set(hq)))
+        return out
+
+
+def _worker_paf_ranges(rank, world, port, q, paths, newline):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gci_amd import shard
+        from gci_amd.device import REC_DTYPE
+        import paf_ref
+
+        def all_reduce_max(values):
+            t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [int(x) for x in t.tolist()]
+        targets = ["chr1", "chr2", "chr3"]
+        ops = _PafOps()
+        got = shard.paf_by_byte_range(ops, paths, targets, 30, 50, 0.9, world, rank, all_reduce_max, torch.device("cpu"), via_host=True)
+        want, want_hq = paf_ref.paf_filter_py(paths, targets, 30, 50, 0.9)
+        assert got is not None and len(got) == len(paths)
+        n_mine = 0
+        for f, (ji, hq) in enumerate(got):
+            recs = ji.recs.numpy().reshape(-1).view(REC_DTYPE)
+            names = ji.name_base.numpy()
+            mine = {}
+            for r in recs:
+                o = int(ji.name_off[int(r["rec_idx"])])
+                qn = names[o:o + int(r["name_len"])].tobytes().decode()
+                assert (int(r["name_hash"]) >> 33) % world == rank            # every query on the rank that owns its name
+                mine[qn] = (targets[int(r["contig"])], int(r["start"]), int(r["end"]), int(r["qlen"]))
+            owned = {k: v for k, v in want[f].items() if (int(ops.hash([k.encode()])[0]) >> 33) % world == rank}
+            assert mine == owned, (f, len(mine), len(owned))
+            n_mine += len(mine)
+        assert n_mine > 20
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,newline", [(2, "\n"), (3, "\r\n"), (2, "\r")])
+def test_gloo_paf_files_by_byte_range(tmp_path, world, newline):
+    """shard.paf_by_byte_range over gloo: every rank parses the lines that start in its byte range of two PAF files (queries with
+    lines in both halves of a file and in both files), the hits travel to the rank that owns the query -- the union over the ranks
+    is exactly the whole-file filter's per-file dicts (tests/paf_ref.py), each query on the rank (name hash >> 33) % world."""
+    rng = np.random.default_rng(5)
+    targets = ["chr1", "chr2", "chr3", "other"]
+    paths = []
+    for f in range(2):
+        lines = []
+        for i in range(400):
+            qn = "read%d/%d" % (f * 150 + int(rng.integers(0, 300)), int(rng.integers(0, 3)))      # repeats inside and across the files
+            qlen = int(rng.integers(5000, 20000))
+            qs = int(rng.integers(0, qlen // 2)); qe = int(rng.integers(qs + 1, qlen))
+            ts = int(rng.integers(0, 100000)); te = ts + (qe - qs)
+            alen = qe - qs + int(rng.integers(0, 50)); nm = int(alen * rng.uniform(0.85, 1.0))
+            lines.append("\t".join(map(str, [qn, qlen, qs, qe, "+", targets[int(rng.integers(0, 4))], 200000, ts, te, nm, alen,
+                                              int(rng.integers(0, 61)), "tp:A:P"])))
+        p = tmp_path / ("f%d.paf" % f)
+        p.write_bytes((newline.join(lines) + (newline if f == 0 else "")).encode())
+        paths.append(str(p))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + world * 7 + len(newline)) % 2000
+    procs = [ctx.Process(target=_worker_paf_ranges, args=(r, world, port, q, paths, newline)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_line_starts_for_byte_ranges():
+    from gci_amd import shard
+    raw = np.frombuffer(b"ab\ncd\r\nef\rgh\n", dtype=np.uint8)
+    starts = [0, 3, 7, 10]
+    for pos in range(len(raw) + 1):
+        want = min([s for s in starts if s >= pos] + [len(raw)])
+        assert shard.line_start_at_or_after(raw, pos) == want, pos
+    for world in (1, 2, 3, 5, 20):
+        cuts = [shard.byte_range_of_rank(raw, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(raw)
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(lo in starts + [len(raw)] for lo, _ in cuts)

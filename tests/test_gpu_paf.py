@@ -156,3 +156,97 @@ def test_large_file_and_error_lines(engine, oracle, tmp_path):
     empty = tmp_path / "empty.paf"
     empty.write_bytes(b"")
     assert gpu_dicts(engine, [str(empty), str(bad)], ["t0"], 30, 50, 0.9) == ([{}, {}], set())
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_byte_ranges_routed_hits_scored_per_owner(engine, oracle, tmp_path, world):
+    """The two halves of the PAF filter the sharded command line uses (shard.paf_by_byte_range), with the ranks played one after
+    the other on this GPU: stage A over every rank's byte range of three files (gci_paf_hits_device), the hits routed by query
+    hash (gci_route_hits), the buckets of owner d put together as its all-to-all would deliver them, stage B per owner
+    (gci_paf_score_device) -- the union over the owners is the whole-file filter's per-file dicts, every query on its owner."""
+    import torch
+    from gci_amd import shard
+    from gci_amd.device import name_hash_np
+    rng = np.random.default_rng(21)
+    targets = ["t%d" % i for i in range(5)]
+    paths = []
+    for f in range(3):
+        rows = []
+        for _ in range(2500):
+            q = "m64/%d/ccs" % int(rng.integers(0, 900)) if rng.random() < 0.9 else "a_rather_long_query_name_%d_of_more_than_48_bytes_in_all____" % int(rng.integers(0, 50))
+            qlen = int(rng.choice([1000, 2000, 5000]))
+            qs = int(rng.integers(0, qlen // 100)) * 50
+            qe = min(qlen, qs + int(rng.integers(1, 20)) * 50)
+            ts = int(rng.integers(0, 100)) * 100
+            aln = qe - qs
+            rows.append("\t".join(map(str, (q, qlen, qs, qe, "+", str(rng.choice(targets + ["other"])), 100000, ts, ts + aln,
+                                            int(aln * rng.choice([0.85, 0.9, 0.95, 1.0])), aln, int(rng.choice([0, 29, 30, 49, 50, 60])), "tp:A:P"))))
+        p = tmp_path / ("r%d.paf" % f)
+        sep = ("\n", "\r\n", "\r")[f]
+        p.write_bytes(sep.join(rows).encode() + (b"" if f == 1 else sep.encode()))
+        paths.append(str(p))
+    args = (30, 50, 0.9)
+    want, want_hq = oracle.paf_filter(paths, targets, *args)
+    raws = [np.fromfile(p, dtype=np.uint8) for p in paths]
+    dev = engine.device
+    B = engine.PAF_HIT_BYTES
+    # stage A + routing, rank after rank
+    sent = []                                                     # [rank][file] = (buckets, names, cap)
+    slot_bytes = 64
+    for r in range(world):
+        parts = [raw[slice(*shard.byte_range_of_rank(raw, r, world))] for raw in raws]
+        ends = np.cumsum([x.shape[0] for x in parts], dtype=np.uint64)
+        d_text = engine.to_device(np.concatenate(parts + [np.zeros(16, np.uint8)]))
+        hits = engine.paf_hits_text(d_text, ends, targets, *args)
+        per_file = []
+        for f, h in enumerate(hits):
+            cap = int(h.shape[0]) + 8
+            sh = torch.zeros((world * (cap + 1), B), dtype=torch.uint8, device=dev)
+            sn = torch.zeros(world * cap * slot_bytes, dtype=torch.uint8, device=dev)
+            st = torch.full((1,), -1, dtype=torch.int64, device=dev)
+            engine.route_hits(h, d_text, world, cap, sh, sn, slot_bytes, st)
+            assert int(st.item()) == -1
+            per_file.append((sh.view(world, cap + 1, B), sn.view(world, cap, slot_bytes), cap))
+        sent.append(per_file)
+    assert sum(int(b[:, 0, 8:16].contiguous().view(torch.int64).sum().item()) for pf in sent for b, _, _ in pf) > 3000
+    # stage B per owner
+    got = [dict() for _ in paths]
+    got_hq = set()
+    for d in range(world):
+        dense, names, upto, base = [], [], [0], 0
+        for f in range(len(paths)):
+            n_f = 0
+            for r in range(world):
+                bk, nm, cap = sent[r][f]
+                c = int(bk[d, 0, 8:16].contiguous().view(torch.int64).item())
+                part = bk[d, 1:1 + c].clone()
+                off = base + torch.arange(c, dtype=torch.int64, device=dev) * slot_bytes
+                if c:
+                    part[:, 0:8] = off.view(torch.uint8).view(c, 8)
+                dense.append(part)
+                names.append(nm[d, :c].reshape(-1))
+                base += c * slot_bytes
+                n_f += c
+            upto.append(upto[-1] + n_f)
+        d_names = torch.cat(names + [torch.zeros(16, dtype=torch.uint8, device=dev)])
+        d_hits = torch.cat(dense) if upto[-1] else torch.zeros((1, B), dtype=torch.uint8, device=dev)
+        for f, ji in enumerate(engine.paf_score_hits(d_names, d_hits, upto, targets)):
+            r = ji.recs.cpu().numpy().reshape(-1).view(REC_DTYPE)
+            off = ji.name_off.cpu().numpy()
+            text = ji.name_base.cpu().numpy()
+            for i in range(r.shape[0]):
+                q = bytes(text[int(off[i]):int(off[i]) + int(r["name_len"][i])])
+                assert (int(name_hash_np([q])[0]) >> 33) % world == d and int(r["name_hash"][i]) == int(name_hash_np([q])[0])
+                assert q.decode() not in got[f]
+                got[f][q.decode()] = (targets[int(r["contig"][i])], int(r["start"][i]), int(r["end"][i]), int(r["qlen"][i]))
+                if int(r["flags"][i]) & REC_HQ:
+                    got_hq.add(q.decode())
+    assert got == want and got_hq == want_hq and len(got[2]) > len(got[0]) > 100
+    # a line the reference raises on: stage A reports it (the sharded caller then takes the whole files)
+    bad = tmp_path / "bad.paf"
+    bad.write_text("q\t100\t0\t50\t+\tt0\t1000\t0\t50\tfifty\t50\t60\n")
+    raw = np.fromfile(str(bad), dtype=np.uint8)
+    with pytest.raises(GciError) as e:
+        engine.paf_hits_text(engine.to_device(np.concatenate([raw, np.zeros(16, np.uint8)])), np.asarray([raw.shape[0]], dtype=np.uint64),
+                             targets, *args)
+    assert e.value.status == GCI_E_MALFORMED
