@@ -190,17 +190,74 @@ def diploid_contigs(scale: float = 1.0) -> Tuple[Tuple[str, int], ...]:
     return tuple(out)
 
 
+def _memory_budget_gb() -> float:
+    """What this process and its children may still allocate: the memory cgroup's limit less its current use when there is one
+    (the GPU boxes: 300 GiB in a 3 TB machine -- MemAvailable alone says 2.9 TB), else MemAvailable."""
+    avail = 64.0
+    try:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")][0] / 1e6
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = min(avail, (int(lim) - cur) / 1e9)
+    except Exception:
+        pass
+    return max(1.0, avail)
+
+
+class _MemoryGuard:
+    """Watches the resident memory of this process and its children while a pool generates a workload; past `limit_gb` it
+    terminates the pool's workers (its own children, by PID) so that the generation fails instead of the machine."""
+
+    def __init__(self, executor, limit_gb: float):
+        import threading
+        self.ex, self.limit, self.tripped, self.peak = executor, float(limit_gb), False, 0.0
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        try:
+            import psutil
+        except Exception:
+            return
+        me = psutil.Process()
+        while not self._stop.wait(0.5):
+            try:
+                rss = me.memory_info().rss + sum(c.memory_info().rss for c in me.children(recursive=True))
+            except Exception:
+                continue
+            self.peak = max(self.peak, rss / 1e9)
+            if rss / 1e9 > self.limit:
+                self.tripped = True
+                for p in list(getattr(self.ex, "_processes", {}).values()):
+                    try:
+                        p.terminate()
+                    except Exception:
+                        pass
+                return
+
+    def stop(self):
+        self._stop.set()
+
+
 def _gen_group_two(args):
     """Worker: one group of contigs -> per read type (BAM heads bytes, offsets, aligned, k1 bytes, name bytes, per-contig
     aligned, PAF text, PAF aligned, reads)."""
-    contigs, idx, g, cov, config, want_paf = args
+    contigs, idx, g, cov, config, want_paf = args[:6]
+    j, k = args[6:8] if len(args) > 6 else (0, 1)              # part j of k of the group's reads (coverage / k each: bounded memory)
     sub = tuple(contigs[i] for i in idx)
+    tag = "g%02d" % g if k == 1 else "g%02dp%02d" % (g, j)
     out = []
     for t, (kind, c) in enumerate((("hifi", cov[0]), ("ont", cov[1]))):
-        rs = synth.simulate_reads(sub, c, kind, seed=synth.seed_for(config, 2 * t) + 7 * g, long_cigar_frac=0.0005 if kind == "ont" else 0.0,
-                                  name_prefix=("m64011_g%02d/" % g) if kind == "hifi" else None)
+        rs = synth.simulate_reads(sub, c / k, kind, seed=synth.seed_for(config, 2 * t) + 7 * g + 1000003 * j,
+                                  long_cigar_frac=0.0005 if kind == "ont" else 0.0,
+                                  name_prefix=("m64011_%s/" % tag) if kind == "hifi" else None)
         if kind == "ont":                                       # names unique across groups (the generator numbers from 0)
-            rs.names = np.char.add(("g%02d-" % g).encode(), rs.names).astype("S")
+            rs.names = np.char.add(("%s-" % tag).encode(), rs.names).astype("S")
         rs.ref_id = (rs.ref_id + idx[0]).astype(np.int32)
         rs.contigs = tuple(contigs)
         mapped = (rs.flag & 4) == 0
@@ -210,14 +267,14 @@ def _gen_group_two(args):
         first = bamfmt.parse_header(s).first_record
         paf, paf_al = None, 0
         if want_paf:
-            other = synth.perturb(rs, synth.seed_for(config, 2 * t + 1) + 7 * g)
+            other = synth.perturb(rs, synth.seed_for(config, 2 * t + 1) + 7 * g + 1000003 * j)
             other.contigs = tuple(contigs)
-            paf = synth.to_paf_text(other, synth.seed_for(config, 10 + t) + g)
+            paf = synth.to_paf_text(other, synth.seed_for(config, 10 + t) + g + 1000003 * j)
             keep = ((other.flag & 0x4) == 0) & ((other.flag & 0x100) == 0)
             paf_al = int(other.ref_span()[keep].sum())
         out.append((s[first:].copy(), (o - np.uint64(first)).astype(np.uint64), int(per_contig.sum()), _k1_algorithmic_bytes(rs),
                     int(np.char.str_len(rs.names).sum()), per_contig, paf, paf_al, len(rs)))
-    return g, out
+    return (g, j), out
 
 
 def genome_two_type(config: int = 4, scale: float = 1.0, cov_hifi: float = 40.0, cov_ont: float = 40.0, procs: Optional[int] = None,
@@ -228,39 +285,50 @@ def genome_two_type(config: int = 4, scale: float = 1.0, cov_hifi: float = 40.0,
         else diploid_contigs(scale)
     total = sum(l for _, l in ctg)
     groups = contig_groups(ctg, max(2.0e7, min(2.6e8, total / 12.0)))
+    # A worker holds ~0.35 GB per Mb of reference while it makes ONT CIGARs at 40x (chr1 whole: ~90 GB; the GPU boxes run in a
+    # 300 GiB memory cgroup): a group's reads are made in k parts of coverage / k each, at most TASK_GB per task, and as many
+    # tasks at a time as half the memory this process may still take carries.
+    TASK_GB = 6.0
+    per_mb = 0.35e-3 * max(cov_ont, 1.0) / 40.0 + 0.04e-3 * max(cov_hifi, 1.0) / 40.0
+    split = [max(1, int(np.ceil(sum(ctg[i][1] for i in g) * 1e-6 * per_mb * 1e3 / TASK_GB))) for g in groups]
+    budget = _memory_budget_gb()
     if procs is None:
         from . import hostio
-        # a worker holds ~0.35 GB per Mb of its group while it makes the ONT CIGARs (chr1: ~90 GB): as many workers as a
-        # third of the free memory carries at 100 GB each, 16 at most
-        try:
-            avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")][0] / 1e6
-        except Exception:
-            avail = 64.0
-        biggest = max(sum(ctg[i][1] for i in g) for g in groups) * 0.35e-6 + 1.0
-        procs = max(1, min(hostio.default_threads(), 16, int(avail / 3.0 / biggest)))
-    procs = max(1, min(int(procs), len(groups)))
-    tasks = [(ctg, idx, g, (cov_hifi, cov_ont), config, config == 4) for g, idx in enumerate(groups)]
+        procs = max(1, min(hostio.default_threads(), 16, int(budget / 2.0 / (TASK_GB + 1.0))))
+    tasks = [(ctg, idx, g, (cov_hifi, cov_ont), config, config == 4, j, split[g]) for g, idx in enumerate(groups) for j in range(split[g])]
+    procs = max(1, min(int(procs), len(tasks)))
     t0 = time.time()
     results = {}
     if procs == 1:
         for t in tasks:
-            g, out = _gen_group_two(t)
-            results[g] = out
+            key, out = _gen_group_two(t)
+            results[key] = out
     else:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
         with ProcessPoolExecutor(procs, mp_context=mp.get_context("fork")) as ex:
-            for g, out in ex.map(_gen_group_two, sorted(tasks, key=lambda t: -sum(ctg[i][1] for i in t[1]))):
-                results[g] = out
-                if verbose:
-                    print("workload: group %d/%d done, %.0f s" % (len(results), len(groups), time.time() - t0), file=sys.stderr, flush=True)
+            guard = _MemoryGuard(ex, 0.8 * budget)
+            try:
+                for key, out in ex.map(_gen_group_two, sorted(tasks, key=lambda t: -sum(ctg[i][1] for i in t[1]) / t[7])):
+                    results[key] = out
+                    if verbose:
+                        print("workload: part %d/%d done, %.0f s" % (len(results), len(tasks), time.time() - t0), file=sys.stderr, flush=True)
+            except Exception:
+                if guard.tripped:
+                    raise MemoryError("workload generation went past %.0f GB (peak seen %.0f GB): stopped before the box did" % (
+                        0.8 * budget, guard.peak)) from None
+                raise
+            finally:
+                guard.stop()
+    # parts of a group side by side, groups in header order
+    order = [(g, j) for g in range(len(groups)) for j in range(split[g])]
     hdr = np.frombuffer(bamfmt.encode_header([n for n, _ in ctg], [l for _, l in ctg]), dtype=np.uint8)
     types = []
     for t in range(2):
         parts, offs, pafs, size = [hdr], [], [], int(hdr.shape[0])
         aligned = k1 = nb = paf_al = reads = 0
         per_contig = np.zeros(len(ctg), dtype=np.int64)
-        for g in range(len(groups)):
+        for g in order:
             s, o, a, kb, n, pc, paf, pal, nr = results[g][t]
             parts.append(s)
             offs.append(o + np.uint64(size))
