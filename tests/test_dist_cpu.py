@@ -271,15 +271,16 @@ def _worker_sharded_join(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_name_hash_sharded_join():
-    """shard.ShardedJoin over gloo, two ranks: records routed by name hash, joined where their name is owned, intervals routed
+@pytest.mark.parametrize("world", [2, 3])
+def test_world2_gloo_name_hash_sharded_join(world):
+    """shard.ShardedJoin over gloo, two and three ranks: records routed by name hash, joined where their name is owned, intervals routed
     to the owner of their contig -- every rank ends with exactly the single-process join's intervals on ITS contigs."""
     from oracle import gci_oracle
     gci_oracle.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker_sharded_join, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() + 13 * world) % 2000
+    procs = [ctx.Process(target=_worker_sharded_join, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
