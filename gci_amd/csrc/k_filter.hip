@@ -803,6 +803,9 @@ struct PagesArgs {
     uint32_t rec_idx_base; gci_rec* out; uint64_t* name_off;
 };
 
+#ifndef PG_LPR
+#define PG_LPR 4                   // lanes per record in the lean pass (a power of two)
+#endif
 #ifndef PG_WAVES
 #define PG_WAVES 5                 // 96 VGPRs, no spills: 0.260 ms against 0.290 (6: 80 VGPRs, 6 spilled) and 0.288 (4) on one box
 #endif
@@ -811,10 +814,13 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
     extern __shared__ __attribute__((aligned(16))) uint8_t page[];
     __shared__ uint8_t aux_sz[256];                                         // fixed value size per aux type, 0 = other
     __shared__ uint8_t aux_kind[256];
+    __shared__ uint16_t s_full[GCI_PAGE_MAX_BYTES / 48];                    // records pass A leaves to pass B
+    __shared__ uint32_t s_n_full;
     __shared__ int32_t s_ref_sel[PG_REF_LDS];                               // refID -> selected contig, when the table is small:
     const int t = threadIdx.x;                                              // a gather from global memory in the middle of the
     const bool ref_in_lds = A.n_ref <= PG_REF_LDS;                          // parse would be a second round trip per page
     if (ref_in_lds) for (int i = t; i < A.n_ref; i += PGK) s_ref_sel[i] = A.ref_sel[i];
+    if (t == 0) s_n_full = 0;
     if (blockIdx.x == 0 && t < 4) lq.next_counters[t] = 0u;                 // nobody reads that set during this call
     if (blockIdx.x == 0 && t == 4) *lq.next_status = ~0ull;
     const uint32_t P = A.page_bytes;
@@ -845,9 +851,145 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
         if (t == 0) report(lq.status_in, first_rec < A.n_rec ? first_rec : 0u, GCI_E_MALFORMED);
         n_recs = 0;
     }
+    // Pass A: the lean path over every record of the page, PG_LPR lanes per record.  What a wave spends per record outside the
+    // CIGAR loop (header, tag walk, name hash, decision, output) is the same number of instructions whether 16 or 32 records
+    // share the wave, and the kernel is bound by instruction issue (profiles/r03t_pmc_summary.txt): fewer lanes per record,
+    // fewer instructions per page.  A record the lean path does not finish is listed for pass B.
+    {
+        const int gl = t % PG_LPR;
+        const uint32_t lgrp = (uint32_t)t / PG_LPR;
+        for (uint32_t j0 = 0; j0 < n_recs; j0 += PGK / PG_LPR) {
+            const uint32_t j = j0 + lgrp;
+            const uint32_t rec = first_rec + j;
+            // ---- the lean path: what nearly every record needs and nothing else, straight-line.  A record with anything unusual
+            // about it -- not inline (kind != 0), the long-CIGAR placeholder, a NUL inside its name, NM behind a Z / H / B tag or of
+            // an odd type or missing, an operation of 2^24 bases, a zero denominator, a quotient within 1e-4 of a threshold -- is
+            // left to pass B's fast_path(), which knows every case (1); a record that is done returns 0.
+            auto lean_path = [&]() -> int {
+#ifdef PGX_NO_LEAN
+                return 1;
+#endif
+                uint32_t base = (uint32_t)reinterpret_cast<const uint16_t*>(page + 16)[j] << 4;
+                if (base > P - 48u) return 1;
+                const uint8_t* hd = page + base;
+                const uint4 c0 = *reinterpret_cast<const uint4*>(hd);
+                const uint4 c1 = *reinterpret_cast<const uint4*>(hd + 16);
+                const uint32_t size = c0.x, kind = c0.w >> 16, l_read_name = c0.w & 0xFFu, n_cigar = c1.x & 0xFFFFu, flag = c1.x >> 16;
+                const int32_t ref_id = (int32_t)c0.y, pos = (int32_t)c0.z, l_seq = (int32_t)c1.y;
+                const int mapq = (int)((c0.w >> 8) & 0xFFu);
+                const uint32_t aux_len = c1.z;
+                const uint32_t cig_at = (36u + l_read_name + 15u) & ~15u;
+                const uint32_t aux_at = cig_at + ((4u * n_cigar + 15u) & ~15u);
+                if (kind != 0 || l_read_name == 0 || n_cigar == 0 || (uint64_t)aux_at + aux_len > size || base + size > P) return 1;
+                gci_rec r;
+                r.name_hash = 0; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + A.rec_idx_base;
+                r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = 0;
+                if (gl == 0 && A.name_off) A.name_off[rec] = page_at + base + 36u;
+                int32_t contig = -1;
+                if (!(ref_id < 0 || ref_id >= A.n_ref || (flag & (0x4u | 0x100u | 0x800u)) || mapq < A.map_qual))      // GCI.py:152-156
+                    contig = ref_in_lds ? s_ref_sel[ref_id] : A.ref_sel[ref_id];
+                if (contig < 0) {                                    // filtered, or not on a selected contig (GCI.py:151, 260)
+                    if (gl == 0) A.out[rec] = r;
+                    return 0;
+                }
+                const uint32_t op0 = lds_u32(hd + cig_at);
+                if (pos >= 0 && (op0 & 0xFu) == 4u && (op0 >> 4) == (uint32_t)l_seq) return 1;        // htslib's long-CIGAR placeholder?
+                // CIGAR totals (see fast_path)
+                uint32_t sS = 0, sQ = 0, sA = 0, sR = 0, big = 0;
+                auto add_op = [&](uint32_t v) {
+                    const uint32_t op = v & 0xFu, len = v >> 4;
+                    sS = __umul24(len, __builtin_amdgcn_ubfe(0x010u, op, 1)) + sS;
+                    sQ = __umul24(len, __builtin_amdgcn_ubfe(0x193u, op, 1)) + sQ;
+                    sA = __umul24(len, __builtin_amdgcn_ubfe(0x187u, op, 1)) + sA;
+                    sR = __umul24(len, __builtin_amdgcn_ubfe(0x18Du, op, 1)) + sR;
+                };
+#ifndef PGX_NO_CIGAR
+                {
+                    const uint8_t* cg = hd + cig_at;
+                    for (uint32_t p = gl; 4u * p < n_cigar; p += PG_LPR) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(cg + 16u * p);
+                        big |= v.x | v.y | v.z | v.w;
+                        add_op(v.x); add_op(v.y); add_op(v.z); add_op(v.w);
+                    }
+                }
+#endif
+                // first NM among fixed-size tags
+                const uint8_t* ax = hd + aux_at;
+                uint32_t q = 0, nmk = 0;
+                for (;;) {
+                    if (q + 3 > aux_len) return 1;
+                    const uint32_t w = lds_u32(ax + q);
+                    const uint32_t k = aux_kind[(w >> 16) & 0xFFu];
+                    if ((k & 7u) == 0 || q + 3 + (k & 7u) > aux_len) return 1;
+                    if ((w & 0xFFFFu) == (uint32_t)('N' | ('M' << 8))) { nmk = k; break; }
+                    q += 3 + (k & 7u);
+                }
+                if (!(nmk & 16u)) return 1;                          // NM of a non-integer type
+                const uint32_t nv = lds_u32(ax + q + 3), nbits = 8u * (nmk & 7u);
+                const int64_t NM = nbits == 32u ? ((nmk & 8u) ? (int64_t)(int32_t)nv : (int64_t)nv)
+                                                : ((nmk & 8u) ? (int64_t)__builtin_amdgcn_sbfe((int)nv, 0, nbits) : (int64_t)__builtin_amdgcn_ubfe(nv, 0, nbits));
+                // query_name: l_read_name - 1 bytes and the NUL -- if there is no NUL before it
+                const uint8_t* name = hd + 36;
+                const uint32_t name_len = l_read_name - 1u;
+                bool odd = name[name_len] != 0;
+                uint64_t acc = 0;
+                for (uint32_t k = gl; k * 8 < name_len; k += PG_LPR) {
+                    const uint32_t b0 = k * 8;
+                    uint64_t w;
+                    __builtin_memcpy(&w, name + b0, 8);
+                    const uint32_t keep = name_len - b0;
+                    if (keep < 8) w &= (1ull << (8 * keep)) - 1ull;
+                    const uint64_t full = keep < 8 ? w | (~0ull << (8 * keep)) : w;                 // bytes past the name count as non-zero
+                    odd = odd || (((full - 0x0101010101010101ull) & ~full & 0x8080808080808080ull) != 0);
+                    acc += gci_hash_word(w, k);
+                }
+#pragma unroll
+                for (int m = 1; m < PG_LPR; m <<= 1) acc += (uint64_t)__shfl_xor((long long)acc, m, PG_LPR);
+                big |= odd ? 0xF0000000u : 0u;                       // (one exchange for both reasons to leave)
+#pragma unroll
+                for (int m = 1; m < PG_LPR; m <<= 1) big |= (uint32_t)__shfl_xor((int)big, m, PG_LPR);
+                if (big >> 28) return 1;
+#define PG_SUM32(x) do { _Pragma("unroll") for (int m = 1; m < PG_LPR; m <<= 1) x += (uint32_t)__shfl_xor((int)x, m, PG_LPR); } while (0)
+                PG_SUM32(sS); PG_SUM32(sQ); PG_SUM32(sA); PG_SUM32(sR);
+#undef PG_SUM32
+                // the decision of GCI.py:163-168 where single precision settles it (ratio_cmp): den1 = M + I + S, den2 = M + I + D
+                const int64_t num2 = (int64_t)sA - NM;
+                if (sQ == 0 || sA == 0 || (sQ >> 30) || (sA >> 30) || num2 > (1 << 30) || num2 < -(1 << 30)) return 1;
+                const float x1 = (float)sS * __builtin_amdgcn_rcpf((float)sQ), c1f = (float)A.clip_percent;
+                const float x2 = (float)(int32_t)num2 * __builtin_amdgcn_rcpf((float)sA), c2f = (float)A.iden_percent;
+                const float m1 = 1e-4f * fmaxf(1.0f, fabsf(x1)), m2 = 1e-4f * fmaxf(1.0f, fabsf(x2));
+                if (!(fabs(A.clip_percent) < 1e30) || !(fabs(A.iden_percent) < 1e30)) return 1;
+                if (!(x1 < c1f - m1 || x1 > c1f + m1)) return 1;     // too close to the clip threshold for single precision
+                r.name_hash = gci_hash_finish(acc, name_len);
+                r.name_len = (uint16_t)name_len;
+                if (x1 < c1f - m1) {                                 // clip test passed: the identity test decides
+                    if (!(x2 < c2f - m2 || x2 > c2f + m2)) return 1;
+                    if (x2 > c2f + m2) {
+                        r.contig = contig; r.start = pos;
+                        r.end = (int32_t)((int64_t)pos + (sR > 0 ? (int64_t)sR : 1));
+                        r.qlen = l_seq;
+                        r.flags = GCI_REC_PASS | (mapq >= A.mq_cutoff ? GCI_REC_HQ : 0) | GCI_REC_NAME16;
+                    }
+                }
+                if (gl == 0) A.out[rec] = r;
+                return 0;
+            };
+
+#ifdef PGX_LEAN_ONLY
+            if (j < n_recs && lean_path() != 0 && gl == 0) report(lq.status_in, rec, GCI_E_INVALID);       // (timing experiment)
+#else
+            if (j < n_recs && lean_path() != 0 && gl == 0) s_full[atomicAdd(&s_n_full, 1u)] = (uint16_t)j;
+#endif
+        }
+    }
+    __syncthreads();
+    // Pass B: the records left over (every ONT record, the odd HiFi one), four lanes each, with the path that knows every case
+    const uint32_t n_full = s_n_full;
     const int gl = t & 3, grp = t >> 2;
-    for (uint32_t j0 = 0; j0 < n_recs; j0 += PGK / 4) {
-        const uint32_t j = j0 + grp;
+    for (uint32_t q0 = 0; q0 < n_full; q0 += PGK / 4) {
+        const uint32_t qi = q0 + grp;
+        const bool on = qi < n_full;
+        const uint32_t j = on ? s_full[qi] : 0u;
         const uint32_t rec = first_rec + j;
         uint64_t slow_off = 0;
         auto fast_path = [&]() -> bool {
@@ -1054,126 +1196,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             A.out[rec] = r;
             return false;
         };
-        // ---- the lean path: what nearly every record needs and nothing else, straight-line.  A record with anything unusual
-        // about it -- not inline (kind != 0), the long-CIGAR placeholder, a NUL inside its name, NM behind a Z / H / B tag or of
-        // an odd type or missing, an operation of 2^24 bases, a zero denominator, a quotient within 1e-4 of a threshold -- is
-        // left to fast_path() above, which knows every case (1); a record that is done returns 0.
-        auto lean_path = [&]() -> int {
-#ifdef PGX_NO_LEAN
-            return 1;
-#endif
-            uint32_t base = (uint32_t)reinterpret_cast<const uint16_t*>(page + 16)[j] << 4;
-            if (base > P - 48u) return 1;
-            const uint8_t* hd = page + base;
-            const uint4 c0 = *reinterpret_cast<const uint4*>(hd);
-            const uint4 c1 = *reinterpret_cast<const uint4*>(hd + 16);
-            const uint32_t size = c0.x, kind = c0.w >> 16, l_read_name = c0.w & 0xFFu, n_cigar = c1.x & 0xFFFFu, flag = c1.x >> 16;
-            const int32_t ref_id = (int32_t)c0.y, pos = (int32_t)c0.z, l_seq = (int32_t)c1.y;
-            const int mapq = (int)((c0.w >> 8) & 0xFFu);
-            const uint32_t aux_len = c1.z;
-            const uint32_t cig_at = (36u + l_read_name + 15u) & ~15u;
-            const uint32_t aux_at = cig_at + ((4u * n_cigar + 15u) & ~15u);
-            if (kind != 0 || l_read_name == 0 || n_cigar == 0 || (uint64_t)aux_at + aux_len > size || base + size > P) return 1;
-            gci_rec r;
-            r.name_hash = 0; r.contig = -1; r.start = 0; r.end = 0; r.qlen = 0; r.rec_idx = rec + A.rec_idx_base;
-            r.mapq = (uint8_t)mapq; r.flags = 0; r.name_len = 0;
-            if (gl == 0 && A.name_off) A.name_off[rec] = page_at + base + 36u;
-            int32_t contig = -1;
-            if (!(ref_id < 0 || ref_id >= A.n_ref || (flag & (0x4u | 0x100u | 0x800u)) || mapq < A.map_qual))      // GCI.py:152-156
-                contig = ref_in_lds ? s_ref_sel[ref_id] : A.ref_sel[ref_id];
-            if (contig < 0) {                                    // filtered, or not on a selected contig (GCI.py:151, 260)
-                if (gl == 0) A.out[rec] = r;
-                return 0;
-            }
-            const uint32_t op0 = lds_u32(hd + cig_at);
-            if (pos >= 0 && (op0 & 0xFu) == 4u && (op0 >> 4) == (uint32_t)l_seq) return 1;        // htslib's long-CIGAR placeholder?
-            // CIGAR totals (see fast_path)
-            uint32_t sS = 0, sQ = 0, sA = 0, sR = 0, big = 0;
-            auto add_op = [&](uint32_t v) {
-                const uint32_t op = v & 0xFu, len = v >> 4;
-                sS = __umul24(len, __builtin_amdgcn_ubfe(0x010u, op, 1)) + sS;
-                sQ = __umul24(len, __builtin_amdgcn_ubfe(0x193u, op, 1)) + sQ;
-                sA = __umul24(len, __builtin_amdgcn_ubfe(0x187u, op, 1)) + sA;
-                sR = __umul24(len, __builtin_amdgcn_ubfe(0x18Du, op, 1)) + sR;
-            };
-#ifndef PGX_NO_CIGAR
-            {
-                const uint8_t* cg = hd + cig_at;
-                for (uint32_t p = gl; 4u * p < n_cigar; p += 4) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(cg + 16u * p);
-                    big |= v.x | v.y | v.z | v.w;
-                    add_op(v.x); add_op(v.y); add_op(v.z); add_op(v.w);
-                }
-            }
-#endif
-            // first NM among fixed-size tags
-            const uint8_t* ax = hd + aux_at;
-            uint32_t q = 0, nmk = 0;
-            for (;;) {
-                if (q + 3 > aux_len) return 1;
-                const uint32_t w = lds_u32(ax + q);
-                const uint32_t k = aux_kind[(w >> 16) & 0xFFu];
-                if ((k & 7u) == 0 || q + 3 + (k & 7u) > aux_len) return 1;
-                if ((w & 0xFFFFu) == (uint32_t)('N' | ('M' << 8))) { nmk = k; break; }
-                q += 3 + (k & 7u);
-            }
-            if (!(nmk & 16u)) return 1;                          // NM of a non-integer type
-            const uint32_t nv = lds_u32(ax + q + 3), nbits = 8u * (nmk & 7u);
-            const int64_t NM = nbits == 32u ? ((nmk & 8u) ? (int64_t)(int32_t)nv : (int64_t)nv)
-                                            : ((nmk & 8u) ? (int64_t)__builtin_amdgcn_sbfe((int)nv, 0, nbits) : (int64_t)__builtin_amdgcn_ubfe(nv, 0, nbits));
-            // query_name: l_read_name - 1 bytes and the NUL -- if there is no NUL before it
-            const uint8_t* name = hd + 36;
-            const uint32_t name_len = l_read_name - 1u;
-            bool odd = name[name_len] != 0;
-            uint64_t acc = 0;
-            for (uint32_t k = gl; k * 8 < name_len; k += 4) {
-                const uint32_t b0 = k * 8;
-                uint64_t w;
-                __builtin_memcpy(&w, name + b0, 8);
-                const uint32_t keep = name_len - b0;
-                if (keep < 8) w &= (1ull << (8 * keep)) - 1ull;
-                const uint64_t full = keep < 8 ? w | (~0ull << (8 * keep)) : w;                 // bytes past the name count as non-zero
-                odd = odd || (((full - 0x0101010101010101ull) & ~full & 0x8080808080808080ull) != 0);
-                acc += gci_hash_word(w, k);
-            }
-            acc += (uint64_t)__shfl_xor((long long)acc, 1, 4);
-            acc += (uint64_t)__shfl_xor((long long)acc, 2, 4);
-            big |= odd ? 0xF0000000u : 0u;                       // (one exchange for both reasons to leave)
-            big |= (uint32_t)__shfl_xor((int)big, 1, 4);
-            big |= (uint32_t)__shfl_xor((int)big, 2, 4);
-            if (big >> 28) return 1;
-#define PG_SUM32(x) do { x += (uint32_t)__shfl_xor((int)x, 1, 4); x += (uint32_t)__shfl_xor((int)x, 2, 4); } while (0)
-            PG_SUM32(sS); PG_SUM32(sQ); PG_SUM32(sA); PG_SUM32(sR);
-#undef PG_SUM32
-            // the decision of GCI.py:163-168 where single precision settles it (ratio_cmp): den1 = M + I + S, den2 = M + I + D
-            const int64_t num2 = (int64_t)sA - NM;
-            if (sQ == 0 || sA == 0 || (sQ >> 30) || (sA >> 30) || num2 > (1 << 30) || num2 < -(1 << 30)) return 1;
-            const float x1 = (float)sS * __builtin_amdgcn_rcpf((float)sQ), c1f = (float)A.clip_percent;
-            const float x2 = (float)(int32_t)num2 * __builtin_amdgcn_rcpf((float)sA), c2f = (float)A.iden_percent;
-            const float m1 = 1e-4f * fmaxf(1.0f, fabsf(x1)), m2 = 1e-4f * fmaxf(1.0f, fabsf(x2));
-            if (!(fabs(A.clip_percent) < 1e30) || !(fabs(A.iden_percent) < 1e30)) return 1;
-            if (!(x1 < c1f - m1 || x1 > c1f + m1)) return 1;     // too close to the clip threshold for single precision
-            r.name_hash = gci_hash_finish(acc, name_len);
-            r.name_len = (uint16_t)name_len;
-            if (x1 < c1f - m1) {                                 // clip test passed: the identity test decides
-                if (!(x2 < c2f - m2 || x2 > c2f + m2)) return 1;
-                if (x2 > c2f + m2) {
-                    r.contig = contig; r.start = pos;
-                    r.end = (int32_t)((int64_t)pos + (sR > 0 ? (int64_t)sR : 1));
-                    r.qlen = l_seq;
-                    r.flags = GCI_REC_PASS | (mapq >= A.mq_cutoff ? GCI_REC_HQ : 0) | GCI_REC_NAME16;
-                }
-            }
-            if (gl == 0) A.out[rec] = r;
-            return 0;
-        };
-#ifdef PGX_LEAN_ONLY
-        const bool is_slow = false;
-        if (j < n_recs && lean_path() != 0 && gl == 0) report(lq.status_in, rec, GCI_E_INVALID);       // (timing experiment)
-        (void)fast_path;
-#else
-        const bool is_slow = j < n_recs && lean_path() != 0 && fast_path();
-#endif
+        const bool is_slow = on && fast_path();
         // records whose bytes live in the blob (kind 2), one after the other, by the whole wave
         for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
             const int l = __builtin_ctzll(m);

@@ -134,9 +134,15 @@ struct PgArgs {
 __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t page[];
+    // which records of the page leave something in the blob (nearly none of a HiFi file): the pass over the blob below looks
+    // at those only -- measuring every record again there, one after the other by the whole workgroup, was 60 dependent trips
+    // to memory per page and most of this kernel's time
+    __shared__ uint16_t s_blob_rec[GCI_PAGE_MAX_BYTES / 48];
+    __shared__ uint32_t s_n_blob;
     const uint32_t t = threadIdx.x, k = blockIdx.x;
     const uint32_t P = A.page_bytes;
     for (uint32_t i = t; i < P / 16; i += BLOCK) reinterpret_cast<uint4*>(page)[i] = make_uint4(0, 0, 0, 0);
+    if (t == 0) s_n_blob = 0;
     const uint32_t first = A.page_first[k], cnt = A.page_first[k + 1] - first;
     const unsigned long long S0 = cnt ? A.S[first] : 0ull;
     const uint32_t rec0 = 16u + a16(2u * cnt);
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
         uint8_t* dst = page + at;
         if (gl == 0) *reinterpret_cast<uint16_t*>(page + 16 + 2 * j) = (uint16_t)(at >> 4);
         const uint64_t blob_at = r.blob ? A.blob_off + A.B[i] : 0ull;
+        if (r.blob && gl == 0) s_blob_rec[atomicAdd(&s_n_blob, 1u)] = (uint16_t)j;
         // the 36-byte core: dwords 1, 2, 4, 5 and the low half of 3 as in the stream; size, kind, aux_len, blob offset patched in
         if (gl < 9) {
             uint32_t w = r.short_core ? 0u : pg_src_dword(A.bam, A.n_bytes, off, 36, gl);
@@ -188,8 +195,9 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
     uint4* g = reinterpret_cast<uint4*>(A.out + (uint64_t)k * P);
     for (uint32_t i = t; i < P / 16; i += BLOCK) g[i] = reinterpret_cast<const uint4*>(page)[i];
     // what the page leaves in the blob: CIGAR words (kind 1) or heads-form records (kind 2), record after record, all threads
-    for (uint32_t j = 0; j < cnt; j++) {
-        const uint32_t i = first + j;
+    const uint32_t n_blob = s_n_blob;                            // (written before the barrier above)
+    for (uint32_t b = 0; b < n_blob; b++) {
+        const uint32_t i = first + s_blob_rec[b];
         const uint64_t off = A.rec_off[i];
         const PgRec r = pg_measure(A.bam, A.n_bytes, off, A.has_seq != 0);         // (uniform over the workgroup)
         if (!r.blob) continue;
