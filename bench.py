@@ -1011,7 +1011,8 @@ def ingest_number(coverage, gb):
                "deflate_ratio": inflated / raw.shape[0],
                "projected_seconds_configs2_two_40x_files": 2 * 190e9 / (inflated / dt),
                "note": "pageable host memory; runs of %d MiB inflated, each: upload -> inflate + CRC on the device -> record walk -> "
-                       "record pages -> paged filter; no overlap between the runs yet" % (pipeline.BAM_CHUNK_BYTES >> 20)}
+                       "record pages -> paged filter; the bytes of run k + 1 travel (copy stream, two device buffers) while run k "
+                       "is inflated and filtered" % (pipeline.BAM_CHUNK_BYTES >> 20)}
         del ji, eng
         return out
     finally:
