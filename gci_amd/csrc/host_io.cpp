@@ -268,7 +268,7 @@ void merge_span(std::vector<std::pair<int64_t, int64_t>>& p, int64_t& covered, i
 
 bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c; }
 
-// Python's int() on a column: optional blanks, optional sign, digits
+// Python's int() on a column: optional blanks, optional sign, digits with single underscores between them
 bool parse_int(const uint8_t* a, const uint8_t* b, int64_t& v)
 {
     while (a < b && is_space(*a)) a++;
@@ -277,8 +277,15 @@ bool parse_int(const uint8_t* a, const uint8_t* b, int64_t& v)
     if (a < b && (*a == '+' || *a == '-')) { neg = *a == '-'; a++; }
     if (a >= b) return false;
     uint64_t x = 0;
+    bool prev_digit = false;
     for (; a < b; a++) {
+        if (*a == '_') {
+            if (!prev_digit || a + 1 >= b || a[1] < '0' || a[1] > '9') return false;
+            prev_digit = false;
+            continue;
+        }
         if (*a < '0' || *a > '9') return false;
+        prev_digit = true;
         if (x > (0x7fffffffffffffffULL - (*a - '0')) / 10) return false;
         x = x * 10 + (*a - '0');
     }

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(BLOCK) void k_paf_line_starts(const uint8_t* __rest
     for (uint32_t m = mask; m; m &= m - 1) starts[w++] = p0 + (uint32_t)__builtin_ctz(m);
 }
 
-// Python's int() on a column: optional blanks, optional sign, digits; false = ValueError
+// Python's int() on a column: optional blanks, optional sign, digits with single underscores between them ('1_000' is
+// 1000; '_1', '1_', '1__0' are not numbers); false = ValueError.  (A value beyond 63 bits is reported as malformed: the
+// reference would go on with a big integer.)
 __device__ __forceinline__ bool parse_int(const uint8_t* __restrict__ text, uint64_t a, uint64_t b, int64_t& v)
 {
     while (a < b && is_space(text[a])) a++;
@@ -83,9 +85,16 @@ __device__ __forceinline__ bool parse_int(const uint8_t* __restrict__ text, uint
     if (a < b && (text[a] == '+' || text[a] == '-')) { neg = text[a] == '-'; a++; }
     if (a >= b) return false;
     uint64_t x = 0;
+    bool prev_digit = false;
     for (; a < b; a++) {
         const uint8_t c = text[a];
+        if (c == '_') {
+            if (!prev_digit || a + 1 >= b || text[a + 1] < '0' || text[a + 1] > '9') return false;
+            prev_digit = false;
+            continue;
+        }
         if (c < '0' || c > '9') return false;
+        prev_digit = true;
         if (x > (0x7fffffffffffffffULL - (uint64_t)(c - '0')) / 10) return false;
         x = x * 10 + (uint64_t)(c - '0');
     }

@@ -583,6 +583,7 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
             else:                                             # K2: tokeniser, grouping and scoring on the GPU
                 inputs += engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
         except GciError as e:
+            e.paf_replay = (paf_files, targets)               # a bad LINE: Python's own exception for it, as the reference dies
             _reraise_like_reference(e)
     for path in bam_files:
         try:
@@ -781,9 +782,13 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
             if PAF_SHARDING == "range":
                 by_range = shard.paf_by_byte_range(engine, paf_files, targets, map_qual, mq_cutoff, iden_percent, SHARD.world, SHARD.rank,
                                                    SHARD.all_reduce_max, engine.device, via_host=SHARD.backend != "nccl")
-            paf_inputs = by_range if by_range is not None else [
-                _own_names_only(engine, ji, SHARD.world, SHARD.rank)
-                for ji in engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)]
+            try:
+                paf_inputs = by_range if by_range is not None else [
+                    _own_names_only(engine, ji, SHARD.world, SHARD.rank)
+                    for ji in engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)]
+            except GciError as e:
+                e.paf_replay = (paf_files, targets)
+                raise
         for path in bam_files:
             local.append(bam_records_of_contigs(engine, path, targets, list(local_tl), filt, threads))
     except GciError as e:
@@ -828,8 +833,35 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
     return depths, targets_length
 
 
+def _paf_line_exception(paf_files: Sequence[str], targets: Sequence[str]) -> Optional[BaseException]:
+    """ERROR PATH ONLY.  The device PAF filter has reported a line the reference raises on (GCI_E_MALFORMED / GCI_E_ZERO_DIV with a
+    line number); the reference would die with Python's own exception for that line -- IndexError for a missing column,
+    ValueError with int()'s message for a bad number, ZeroDivisionError for a zero alignment length -- and which one depends on
+    the order GCI.py:217-229 touches the columns in.  This replays exactly those statements over the files in order and returns
+    the first exception they raise (None if no line raises).  It computes nothing that is used: no dict, no score."""
+    tset = set(targets)
+    for path in paf_files:
+        with open(path, "r") as f:
+            for line in f:
+                try:
+                    paf = line.strip().split("\t")
+                    if paf[5] in tset:
+                        int(paf[1]), int(paf[2]), int(paf[3]), int(paf[7]), int(paf[8])
+                        num_match_res, len_aln = int(paf[9]), int(paf[10])
+                        int(paf[11])
+                        num_match_res / len_aln
+                except (IndexError, ValueError, ZeroDivisionError) as exc:
+                    return exc
+    return None
+
+
 def _reraise_like_reference(e: GciError):
     from . import _lib
+    replay = getattr(e, "paf_replay", None)
+    if replay is not None and e.status in (_lib.GCI_E_MALFORMED, _lib.GCI_E_ZERO_DIV) and getattr(e, "rec", 0) > 0:
+        exc = _paf_line_exception(*replay)
+        if exc is not None:
+            raise exc from e
     if e.status == _lib.GCI_E_NO_NM:
         raise KeyError("tag 'NM' not present") from e
     if e.status == _lib.GCI_E_ZERO_DIV:

@@ -94,6 +94,17 @@ def test_reference_errors_surface_as_the_same_exceptions(engine, tmp_path):
         bam.write_bam(p, ["chr1"], [100000], [good, bad, good])
         with pytest.raises(exc):
             pipeline.filter([], [p], prefix="x", directory=str(tmp_path), engine=engine, write=False)
+    # a PAF line the reference dies on: Python's own exception for that line (type and message), GCI.py:217-229
+    ok = "q\t100\t0\t50\t+\tchr1\t100000\t0\t50\t50\t50\t60\n"
+    for k, (line, exc, msg) in enumerate((("q2\t100\t0\t50\t+\tchr1\t100000\t0\t50\tfifty\t50\t60\n", ValueError, "invalid literal for int\\(\\) with base 10: 'fifty'"),
+                                          ("q2\t100\t0\t50\t+\tchr1\t100000\n", IndexError, "list index out of range"),
+                                          ("q2\t100\t0\t50\t+\tchr1\t100000\t0\t50\t50\t0\t60\n", ZeroDivisionError, "division by zero"))):
+        pf = tmp_path / ("bad%d.paf" % k)
+        pf.write_text(ok + line + ok)
+        pg = str(tmp_path / "good_for_paf.bam")
+        bam.write_bam(pg, ["chr1"], [100000], [good])
+        with pytest.raises(exc, match=msg):
+            pipeline.filter([str(pf)], [pg], prefix="x", directory=str(tmp_path), engine=engine, write=False)
     # qlen == 0 on the second file of a join -> ZeroDivisionError at GCI.py:292
     a = rec_bytes(0, 10, b"q", 60, 0, [op(100, "M")], 100, b"NMC\x00")
     b = rec_bytes(0, 10, b"q", 60, 0, [op(100, "M")], 0, b"NMC\x00")

@@ -77,6 +77,8 @@ def test_randomised_files_line_ends_and_blanks(engine, oracle, tmp_path):
                 cols[11] = cols[11] + "  "                      # blanks the reference's strip() / int() swallow
             elif u < 0.7:
                 cols[1] = " +" + cols[1]
+            if len(cols[7]) >= 2 and rng.random() < 0.1:
+                cols[7] = cols[7][0] + "_" + cols[7][1:]           # int('1_200') is 1200
             row = "\t".join(cols)
             if 0.7 <= u < 0.75:
                 row = "  " + row + " \t "

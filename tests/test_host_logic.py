@@ -111,7 +111,8 @@ def test_native_paf_filter_randomised(oracle, tmp_path):
             te = ts + (qe - qs)
             aln = qe - qs
             nm = int(aln * rng.choice([0.85, 0.9, 0.95, 1.0]))
-            rows.append("\t".join(map(str, (q, qlen, qs, qe, "+-"[int(rng.integers(0, 2))], t, 100000, ts, te, nm, aln,
+            ts_s = str(ts) if len(str(ts)) < 2 or rng.random() > 0.1 else str(ts)[0] + "_" + str(ts)[1:]      # int('1_200') is 1200
+            rows.append("\t".join(map(str, (q, qlen, qs, qe, "+-"[int(rng.integers(0, 2))], t, 100000, ts_s, te, nm, aln,
                                             int(rng.choice([0, 29, 30, 49, 50, 60])), "tp:A:P", "cm:i:5"))))
         p = tmp_path / ("f%d.paf" % f)
         p.write_bytes(("\r\n" if f == 1 else "\n").join(rows).encode() + (b"" if f == 2 else b"\n"))
@@ -299,3 +300,28 @@ def test_bam_heads_stream(tmp_path, kind, seed):
         hostio.bam_heads(np.fromfile(cut, dtype=np.uint8), threads=3)
     with pytest.raises(GciError):
         hostio.bam_heads(np.zeros(0, dtype=np.uint8))                      # no header at all
+
+
+def test_paf_line_error_replay_gives_pythons_exception(tmp_path):
+    """pipeline._paf_line_exception (error path only): the exception GCI.py:217-229 dies with on the first offending line, in the
+    order the reference touches the columns -- type and message are Python's own."""
+    from gci_amd import pipeline
+    good = "q\t100\t0\t50\t+\tt0\t1000\t0\t50\t50\t50\t60\n"
+    cases = [("q\t100\t0\t50\t+\tt0\t1000\t0\t50\tfifty\t50\t60\n", ValueError, "invalid literal for int() with base 10: 'fifty'"),
+             ("q\t100\t0\n", IndexError, "list index out of range"),
+             ("q\t100\t0\t50\t+\tt0\t1000\t0\n", IndexError, "list index out of range"),
+             ("q\tx\t0\t50\t+\tt0\t1000\n", ValueError, "invalid literal for int() with base 10: 'x'"),      # int(paf[1]) before paf[7]
+             ("q\t100\t0\t50\t+\tt0\t1000\t0\t50\t50\t0\t60\n", ZeroDivisionError, "division by zero"),
+             ("\n", IndexError, "list index out of range"),
+             ("q\tx\t0\t50\t+\tother\t1000\n", None, None)]                                                  # not a selected contig: skipped unread
+    for k, (bad, typ, msg) in enumerate(cases):
+        p = tmp_path / ("e%d.paf" % k)
+        p.write_text(good + bad + good)
+        exc = pipeline._paf_line_exception([str(p)], ["t0"])
+        if typ is None:
+            assert exc is None
+        else:
+            assert type(exc) is typ and str(exc) == msg, (k, exc)
+    # files in order: the first file's bad line wins
+    exc = pipeline._paf_line_exception([str(tmp_path / "e1.paf"), str(tmp_path / "e0.paf")], ["t0"])
+    assert type(exc) is IndexError
