@@ -23,7 +23,7 @@ def test_bench_line_contract():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "Gbases/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - d["config"]["aligned_bases_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches"] == 4
