@@ -878,6 +878,46 @@ def device_pipeline_number(eng, w):
                     "made on the device inside the window (gci_bam_pages_*); PCIe Gen5 x16 bounds it (63 GB/s spec)"}
 
 
+def survey_window_step(eng, w, steps):
+    """The step inside the window SURVEY.md section 8(d) defines -- "from inflated record bytes resident to all depth tracks
+    final in device memory and issue intervals on host": filter x2 -> join -> depth build WITHOUT the decimal text (K10 is not
+    in that window; the headline keeps it as the harder output), the issue-run keys copied to the host every step."""
+    import torch
+    o = w.opts
+    keep = o.want_text
+    o.want_text = 0
+    try:
+        def one():
+            chk, lib, ctx = eng._chk, eng.lib, eng.ctx
+            w.step_records()
+            chk(lib.gci_depth_build_begin(ctx, _p(w.ivl), _p(w.count), int(w.ivl.shape[0]), ctypes.byref(o)), "gci_depth_build_begin")
+            chk(lib.gci_depth_build_finish(ctx, _p(w.track), None, 0), "gci_depth_build_finish")
+            n = int(w.nkeys.item())                               # (synchronises: the keys are on the host when the step ends)
+            return w.keys[:min(n, int(w.keys.shape[0]))].cpu()
+        one()
+        torch.cuda.synchronize()
+        eng.profile_enable(1 << _lib.PROF_DEPTH_SCAN)
+        eng.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            keys = one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ms, n = eng.profile_read(reset=True).get("k_tile_build", (0.0, 0))
+        eng.profile_enable(0)
+    finally:
+        o.want_text = keep
+    L = int(sum(w.own_lengths))
+    algo = w.step_algorithmic_bytes()
+    total = algo["k1_record_filter"] + algo["name_join"] + 28 * algo["intervals"] + 4 * L
+    build_ms = ms / max(1, n)
+    return {"ms_per_step": dt * 1e3, "gbases_per_s": w.aligned_bases / dt / 1e9, "issue_run_keys_to_host": int(keys.shape[0]),
+            "algorithmic_bytes_per_step": total, "hbm_frac": total / dt / 1e9 / HBM_PEAK_GBS,
+            "k_tile_build_avg_launch_ms": build_ms, "k_tile_build_hbm_frac": (4.0 * L / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if build_ms else None,
+            "note": "SURVEY.md 8(d)'s timed window: no decimal text (4 B per base out of the build instead of 7); the issue-run keys "
+                    "reach the host inside every step"}
+
+
 def cli_shaped_step(eng, w, steps):
     """The step as the command line runs it (GCI.py:99-143 through gci_amd/pipeline.py): no decimal text in HBM -- `.depth.gz`
     leaves the device as the gzip members the GPU writes from the track (gci_depth_deflate_*), D2H of those members included.
@@ -1264,6 +1304,7 @@ def main():
             survey = {"1_kernels_only_gbases_per_s": out["value"]}
             if not args.no_e2e and args.inflight == 1:
                 out["two_steps_in_flight"] = two_in_flight(eng, w, args, device_index)
+            out["survey_window_step"] = survey_window_step(eng, w, max(3, args.steps // 2))
             out["cli_shaped_step"] = cli_shaped_step(eng, w, max(3, args.steps // 2))
             if not args.no_e2e:
                 survey["2_device_pipeline_incl_h2d_d2h"] = device_pipeline_number(eng, w)
