@@ -883,6 +883,7 @@ def survey_window_step(eng, w, steps):
     final in device memory and issue intervals on host": filter x2 -> join -> depth build WITHOUT the decimal text (K10 is not
     in that window; the headline keeps it as the harder output), the issue-run keys copied to the host every step."""
     import torch
+    from gci_amd import _lib
     o = w.opts
     keep = o.want_text
     o.want_text = 0

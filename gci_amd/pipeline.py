@@ -421,6 +421,27 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     return _concat_parts(engine, parts)
 
 
+_DROP_QUEUE = None
+
+
+def _drop_later(*objs) -> None:
+    """Give the last reference of `objs` to a helper thread.  Unmapping a 1.5 GB file mapping whose pages were all touched takes
+    14 - 18 ms on the GPU boxes (tools/exp_cli_teardown.py) -- a tenth of the command line's time at chr19, spent by the thread that
+    should be launching kernels."""
+    global _DROP_QUEUE
+    if _DROP_QUEUE is None:
+        import queue
+        import threading
+        _DROP_QUEUE = queue.SimpleQueue()
+
+        def run(q):
+            while True:
+                q.get()                      # (taken and dropped: the last reference dies here)
+
+        threading.Thread(target=run, args=(_DROP_QUEUE,), daemon=True).start()
+    _DROP_QUEUE.put(objs)
+
+
 def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
                    threads: int = 1, chunk_bytes: Optional[int] = None, ingest: Optional[str] = None) -> JoinInput:
     """K1 over one BAM file -> the file's join input (compact records + where their names are).
@@ -471,6 +492,8 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         if int(isz.sum()) > 0:
             ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, upload)
             if ji is not None:
+                _drop_later(raw)                              # (the unmapping, off this thread)
+                del raw
                 return ji
         elif upload is not None:
             upload["pool"].shutdown()
