@@ -3,6 +3,7 @@
 // framing of the depth text.  Plain C++ threads + zlib; no GPU work here.  The reference reaches these
 // layers through pysam/htslib (GCI.py:150-151) and Python's gzip (GCI.py:111).
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -15,6 +16,27 @@
 namespace {
 
 struct Block { uint64_t pos, size, isize, out; };
+
+// one member header at pos -> its size and ISIZE; false: not a well-formed BGZF member inside [pos, n)
+bool member_at(const uint8_t* raw, uint64_t n, uint64_t pos, uint64_t& size, uint32_t& isize)
+{
+    if (n - pos < 18) return false;
+    const uint8_t* h = raw + pos;
+    if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8 || !(h[3] & 4)) return false;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    if (pos + 12 + xlen > n) return false;
+    int64_t bsize = -1;
+    for (uint32_t p = 12; p + 4 <= 12 + xlen;) {
+        const uint32_t slen = h[p + 2] | (h[p + 3] << 8);
+        if (h[p] == 66 && h[p + 1] == 67 && slen == 2 && p + 6 <= 12 + xlen) bsize = h[p + 4] | (h[p + 5] << 8);
+        p += 4 + slen;
+    }
+    if (bsize < 0) return false;
+    size = (uint64_t)bsize + 1;
+    if (size < 12 + xlen + 8 || pos + size > n) return false;
+    memcpy(&isize, h + size - 4, 4);
+    return true;
+}
 
 // walk the BSIZE chain of a BGZF byte string; returns a status
 int scan(const uint8_t* raw, uint64_t n, std::vector<Block>& blocks, uint64_t& total)
@@ -43,6 +65,83 @@ int scan(const uint8_t* raw, uint64_t n, std::vector<Block>& blocks, uint64_t& t
         pos += size;
     }
     return GCI_OK;
+}
+
+// The same table by several threads.  The chain is serial -- a member's BSIZE says where the next one starts -- and at
+// genome size it is a page fault every ~27 KB over tens of GB (0.65 s for 64.5 GB, 25 ms at chr19 with the device waiting for
+// it).  So the byte string is cut into ranges; the thread of a range looks for the first position in it at which a member
+// header stands AND from which the chain holds for four members (the 16 fixed bytes of a BGZF header plus three more such
+// headers exactly where the BSIZEs say: deflate output does not produce that by chance), walks from there to the end of its
+// range, and the ranges are stitched: a range's walk must END exactly where the next range's walk STARTED -- if it does not
+// (a header-like pattern inside member data), the serial walk goes on through that range.  Same table as scan().
+int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blocks, uint64_t& total)
+{
+    uint64_t min_range = 32ull << 20;
+    if (const char* e = getenv("GCI_BGZF_RANGE")) { const long long v = atoll(e); if (v >= 64) min_range = (uint64_t)v; }   // (tests: small files)
+    uint64_t R = n / min_range;
+    if (threads < 2 || R < 2) return scan(raw, n, blocks, total);
+    if (R > (uint64_t)threads * 4) R = (uint64_t)threads * 4;
+    struct Range { uint64_t start = ~0ull, end = 0; std::vector<Block> blocks; bool bad = false; };
+    std::vector<Range> rg(R);
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const uint64_t k = next.fetch_add(1);
+            if (k >= R) return;
+            const uint64_t lo = n * k / R, hi = n * (k + 1) / R;
+            uint64_t pos = lo;
+            if (k) {                                             // the first member that starts in [lo, hi)
+                pos = ~0ull;
+                for (uint64_t p = lo; p < hi && p + 18 <= n; p++) {
+                    const uint8_t* q = (const uint8_t*)memchr(raw + p, 0x1F, (size_t)(hi - p));
+                    if (!q) break;
+                    p = (uint64_t)(q - raw);
+                    uint64_t c = p, size;
+                    uint32_t isz;
+                    int good = 0;
+                    while (good < 4 && c < n && member_at(raw, n, c, size, isz)) { c += size; good++; }
+                    if (good == 4 || (good > 0 && c == n)) { pos = p; break; }
+                }
+                if (pos == ~0ull) { rg[k].start = ~0ull; continue; }        // no member starts in this range (one huge gap?)
+            }
+            rg[k].start = pos;
+            uint64_t size;
+            uint32_t isz;
+            while (pos < hi) {
+                if (!member_at(raw, n, pos, size, isz)) { rg[k].bad = true; break; }
+                rg[k].blocks.push_back({pos, size, isz, 0});
+                pos += size;
+            }
+            rg[k].end = pos;
+        }
+    };
+    std::vector<std::thread> pool;
+    const int T = (uint64_t)threads < R ? threads : (int)R;
+    for (int t = 1; t < T; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    // stitch
+    blocks.clear();
+    total = 0;
+    uint64_t pos = 0;
+    for (uint64_t k = 0; k < R; k++) {
+        const uint64_t hi = n * (k + 1) / R;
+        if (pos >= hi) continue;                                 // the previous range's last member reaches beyond this range
+        if (!rg[k].bad && rg[k].start == pos) {
+            for (const Block& b : rg[k].blocks) { blocks.push_back({b.pos, b.size, b.isize, total}); total += b.isize; }
+            pos = rg[k].end;
+            continue;
+        }
+        while (pos < hi) {                                       // this range started on something else: walk it serially
+            uint64_t size;
+            uint32_t isz;
+            if (!member_at(raw, n, pos, size, isz)) return GCI_E_MALFORMED;
+            blocks.push_back({pos, size, isz, total});
+            total += isz;
+            pos += size;
+        }
+    }
+    return pos == n ? GCI_OK : GCI_E_MALFORMED;
 }
 
 template <typename F>
@@ -97,6 +196,35 @@ extern "C" int gci_bgzf_blocks(const uint8_t* h_raw, uint64_t n_raw, uint64_t* h
     if (blocks.size() < cap) h_pos[blocks.size()] = n_raw;
     return GCI_OK;
 }
+
+// The member table in one pass over the byte string, by `threads` threads (scan_mt): a handle the caller reads and frees.
+struct gci_bgzf_table { std::vector<Block> blocks; uint64_t total = 0, n_raw = 0; };
+
+extern "C" int gci_bgzf_table_build(const uint8_t* h_raw, uint64_t n_raw, int threads, gci_bgzf_table** out)
+{
+    if ((!h_raw && n_raw) || !out) return GCI_E_INVALID;
+    *out = nullptr;
+    gci_bgzf_table* t = new (std::nothrow) gci_bgzf_table();
+    if (!t) return GCI_E_NOMEM;
+    t->n_raw = n_raw;
+    const int st = scan_mt(h_raw, n_raw, threads, t->blocks, t->total);
+    if (st) { delete t; return st; }
+    *out = t;
+    return GCI_OK;
+}
+
+extern "C" uint64_t gci_bgzf_table_count(const gci_bgzf_table* t) { return t ? t->blocks.size() : 0; }
+
+// h_pos: count + 1 entries (the last = the length of the byte string); h_isize: count entries
+extern "C" int gci_bgzf_table_export(const gci_bgzf_table* t, uint64_t* h_pos, uint64_t* h_isize)
+{
+    if (!t || !h_pos || (!h_isize && !t->blocks.empty())) return GCI_E_INVALID;
+    for (size_t i = 0; i < t->blocks.size(); i++) { h_pos[i] = t->blocks[i].pos; h_isize[i] = t->blocks[i].isize; }
+    h_pos[t->blocks.size()] = t->n_raw;
+    return GCI_OK;
+}
+
+extern "C" int gci_bgzf_table_free(gci_bgzf_table* t) { delete t; return GCI_OK; }
 
 // Inflate every member into h_out (capacity cap >= the size gci_bgzf_scan reported), members in parallel.
 extern "C" int gci_bgzf_inflate(const uint8_t* h_raw, uint64_t n_raw, uint8_t* h_out, uint64_t cap, int threads,

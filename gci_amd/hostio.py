@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -91,17 +91,21 @@ def gzip_members(text, threads: int = 0, chunk: int = 8 << 20, level: int = 1) -
     return out[:n.value].tobytes()
 
 
-def bgzf_blocks(raw: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Member table of a BGZF byte array: (uint64 byte offsets with one trailing entry = len(raw), uint64 ISIZEs)."""
+def bgzf_blocks(raw: np.ndarray, threads: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Member table of a BGZF byte array: (uint64 byte offsets with one trailing entry = len(raw), uint64 ISIZEs).  One pass over
+    the member headers by `threads` host threads (default: what the container may use; gci_bgzf_table_build)."""
     lib = _lib.load()
-    nb = ctypes.c_uint64(0)
     p = raw.ctypes.data_as(ctypes.c_void_p)
-    _chk(lib.gci_bgzf_scan(p, raw.shape[0], ctypes.byref(nb), None), "gci_bgzf_scan")
-    pos = np.empty(nb.value + 1, dtype=np.uint64)
-    isz = np.empty(nb.value + 1, dtype=np.uint64)
-    _chk(lib.gci_bgzf_blocks(p, raw.shape[0], pos.ctypes.data_as(ctypes.c_void_p), isz.ctypes.data_as(ctypes.c_void_p),
-                             nb.value + 1, ctypes.byref(nb)), "gci_bgzf_blocks")
-    return pos, isz[:nb.value]
+    h = ctypes.c_void_p(None)
+    _chk(lib.gci_bgzf_table_build(p, raw.shape[0], int(threads if threads else default_threads()), ctypes.byref(h)), "gci_bgzf_table_build")
+    try:
+        n = int(lib.gci_bgzf_table_count(h))
+        pos = np.empty(n + 1, dtype=np.uint64)
+        isz = np.empty(max(n, 1), dtype=np.uint64)
+        _chk(lib.gci_bgzf_table_export(h, pos.ctypes.data_as(ctypes.c_void_p), isz.ctypes.data_as(ctypes.c_void_p)), "gci_bgzf_table_export")
+    finally:
+        lib.gci_bgzf_table_free(h)
+    return pos, isz[:n]
 
 
 def bam_chunk_offsets(buf: np.ndarray, start: int = 0) -> Tuple[np.ndarray, int]:

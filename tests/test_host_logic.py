@@ -325,3 +325,41 @@ def test_paf_line_error_replay_gives_pythons_exception(tmp_path):
     # files in order: the first file's bad line wins
     exc = pipeline._paf_line_exception([str(tmp_path / "e1.paf"), str(tmp_path / "e0.paf")], ["t0"])
     assert type(exc) is IndexError
+
+
+def test_threaded_member_table_equals_the_serial_walk(tmp_path, monkeypatch):
+    """gci_bgzf_table_build: ranges walked by threads and stitched give the table of the serial BSIZE chain -- also when member DATA
+    is full of chains of well-formed BGZF members (stored blocks holding BGZF bytes: every range then starts on a false member and
+    the stitching has to notice), and a damaged header is reported as by the serial walk."""
+    import zlib
+    from gci_amd import hostio
+    from gci_amd.formats import bgzf
+    rng = np.random.default_rng(3)
+
+    def member(payload: bytes, level: int) -> bytes:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(payload) + c.flush()
+        size = 18 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (size - 1).to_bytes(2, "little") + body +
+                zlib.crc32(payload).to_bytes(4, "little") + len(payload).to_bytes(4, "little"))
+
+    plain = b"".join(member(rng.integers(0, 4, int(rng.integers(1, 60000)), dtype=np.uint8).tobytes(), 1) for _ in range(300))
+    fake = bgzf.BGZF_EOF * 2000                                   # 2000 empty members back to back: 56 000 bytes of "headers"
+    nested = b"".join(member(fake[:int(rng.integers(28, 56000))], 0) for _ in range(120))     # level 0: stored, the bytes as they are
+    for raw_b in (plain, nested, plain + nested + plain + bgzf.BGZF_EOF):
+        raw = np.frombuffer(raw_b, dtype=np.uint8)
+        monkeypatch.delenv("GCI_BGZF_RANGE", raising=False)
+        want_pos, want_isz = hostio.bgzf_blocks(raw, threads=1)
+        assert int(want_pos[-1]) == raw.shape[0] and want_isz.shape[0] == want_pos.shape[0] - 1
+        for rng_bytes, threads in ((4096, 8), (70000, 3), (1 << 20, 16)):
+            monkeypatch.setenv("GCI_BGZF_RANGE", str(rng_bytes))
+            pos, isz = hostio.bgzf_blocks(raw, threads=threads)
+            assert np.array_equal(pos, want_pos) and np.array_equal(isz, want_isz), (rng_bytes, threads)
+    # damage: a header byte in the middle -> the same refusal
+    bad = bytearray(plain)
+    k = int(hostio.bgzf_blocks(np.frombuffer(plain, dtype=np.uint8), threads=1)[0][150])
+    bad[k + 1] = 0
+    monkeypatch.setenv("GCI_BGZF_RANGE", "4096")
+    for threads in (1, 8):
+        with pytest.raises(Exception):
+            hostio.bgzf_blocks(np.frombuffer(bytes(bad), dtype=np.uint8), threads=threads)
