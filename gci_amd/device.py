@@ -406,7 +406,9 @@ class Engine:
         n_raw = int(raw.shape[0])
         cuts = sorted({min(n_raw, (n_raw * (k + 1) // parts + 15) & ~15) for k in range(parts)} | {n_raw})
         d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
-        copy_stream = torch.cuda.Stream(device=self.device)
+        if getattr(self, "_copy_stream", None) is None:          # (creating a stream costs milliseconds: one per engine)
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        copy_stream = self._copy_stream
         copy_stream.wait_stream(self.stream)                     # (the allocation may recycle memory still in use on the main stream)
         events = [torch.cuda.Event() for _ in cuts]
         queued = [threading.Event() for _ in cuts]               # (a CUDA event that was never recorded counts as complete)

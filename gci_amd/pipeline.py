@@ -295,7 +295,9 @@ class _RunUploads:
         cap = max(int(pos[hi]) - int(pos[lo]) for lo, hi in groups) + 16
         with torch.cuda.stream(engine.stream):
             self.bufs = [torch.empty(cap, dtype=torch.uint8, device=engine.device) for _ in range(min(2, len(groups)))]
-        self.copy = torch.cuda.Stream(device=engine.device)
+        if getattr(engine, "_copy_stream", None) is None:
+            engine._copy_stream = torch.cuda.Stream(device=engine.device)
+        self.copy = engine._copy_stream
         self.copy.wait_stream(engine.stream)                 # (the buffers may recycle memory still in use on the main stream)
         self.freed = [None] * len(self.bufs)                 # main-stream event behind the last kernel that read the buffer
         self.pool = ThreadPoolExecutor(1)
