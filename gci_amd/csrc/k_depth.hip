@@ -28,6 +28,12 @@
 #include "gci_ctx.hpp"
 #include <stdlib.h>
 
+#ifndef TB_TRACK_NT
+#define TB_TRACK_NT 1                // bulk stores of the track non-temporal (A/B: tools/gpu_boxab.sh)
+#endif
+#ifndef TB_TEXT_NT
+#define TB_TEXT_NT 0
+#endif
 typedef int i32x4 __attribute__((ext_vector_type(4)));          // native vector type: __builtin_nontemporal_store takes it
 
 // ---- per interval ---------------------------------------------------------------------------------
@@ -866,7 +872,13 @@ __device__ __forceinline__ bool tile_sparse2(
             // per step; with the text non-temporal as well (or instead) the kernel itself slows down by 10 - 25 us.
             const i32x4 v4 = {dr, dr, dr, dr};
 #pragma clang loop vectorize(disable) unroll(disable)
-            for (int32_t g = g0 + lane; g < g1; g += 64) __builtin_nontemporal_store(v4, reinterpret_cast<i32x4*>(dt4) + g);
+            for (int32_t g = g0 + lane; g < g1; g += 64) {
+#if TB_TRACK_NT
+                __builtin_nontemporal_store(v4, reinterpret_cast<i32x4*>(dt4) + g);
+#else
+                reinterpret_cast<i32x4*>(dt4)[g] = v4;
+#endif
+            }
         }
     }
     TT(3);
@@ -965,7 +977,14 @@ __device__ __forceinline__ bool tile_sparse2(
                 const uint32_t D = (uint32_t)(Xr >> (8u * (x0 & (wr - 1u))));
                 const uint4 v = make_uint4(D, D, D, D);
 #pragma clang loop vectorize(disable) unroll(disable)
-                for (uint32_t c = c0 + lane; c < c1; c += 64) *reinterpret_cast<uint4*>(TB + 16u * c) = v;
+                for (uint32_t c = c0 + lane; c < c1; c += 64) {
+#if TB_TEXT_NT
+                    const i32x4 vv = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<i32x4*>(TB + 16u * c));
+#else
+                    *reinterpret_cast<uint4*>(TB + 16u * c) = v;
+#endif
+                }
             } else {
                 const uint32_t D0 = (uint32_t)Xr, D1 = (uint32_t)(Xr >> 8), D2 = (uint32_t)(Xr >> 16);
                 uint32_t ph = x0 - 3u * ((x0 * 43691u) >> 17) + lane3;                          // scalar part + lane part
@@ -977,7 +996,11 @@ __device__ __forceinline__ bool tile_sparse2(
                     v.y = ph == 0u ? D1 : ph == 1u ? D2 : D0;
                     v.z = ph == 0u ? D2 : ph == 1u ? D0 : D1;
                     v.w = v.x;
+#if TB_TEXT_NT
+                    { const i32x4 vv = {(int)v.x, (int)v.y, (int)v.z, (int)v.w}; __builtin_nontemporal_store(vv, reinterpret_cast<i32x4*>(TB + 16u * c)); }
+#else
                     *reinterpret_cast<uint4*>(TB + 16u * c) = v;
+#endif
                     ph = ph == 2u ? 0u : ph + 1u;                                               // 64 groups on: 64 = 1 (mod 3)
                 }
             }
