@@ -1045,15 +1045,17 @@ def ingest_number(coverage, gb):
         finally:
             pipeline.GPU_INFLATE_MAX = keep
         got = int(ji.recs.shape[0])
+        rnd = eng.inflate_round()
         inflated = k * body_inflated + first
         out = {"seconds": dt, "member_table_seconds": t_table, "bgzf_bytes": int(raw.shape[0]), "inflated_bytes": inflated,
                "records": got, "records_expected": k * n_rec, "gb_per_s_in": raw.shape[0] / dt / 1e9, "gb_per_s_out": inflated / dt / 1e9,
                "kept_on_device_bytes": int(ji.name_base.shape[0] + ji.recs.shape[0] * 32 + ji.name_off.shape[0] * 8),
                "deflate_ratio": inflated / raw.shape[0],
                "projected_seconds_configs2_two_40x_files": 2 * 190e9 / (inflated / dt),
-               "note": "pageable host memory; runs of %d MiB inflated, each: upload -> inflate + CRC on the device -> record walk -> "
-                       "record pages -> paged filter; the bytes of run k + 1 travel (copy stream, two device buffers) while run k "
-                       "is inflated and filtered" % (pipeline.BAM_CHUNK_BYTES >> 20)}
+               "note": "pageable host memory; runs of at most %d MiB inflated and a whole number of the device's decode rounds (%d members "
+                       "at a time), each: upload -> inflate + CRC on the device -> record walk -> record pages -> paged filter; the "
+                       "bytes of run k + 1 travel (copy stream, two device buffers) while run k is inflated and filtered" % (
+                           pipeline.BAM_CHUNK_BYTES >> 20, rnd)}
         del ji, eng
         return out
     finally:

@@ -69,6 +69,9 @@ struct alignas(16) Canon { uint16_t limit[16]; int16_t off[16]; uint16_t next[16
 #ifndef INF_WAVES
 #define INF_WAVES 4
 #endif
+#ifndef INF_DIST_BITS
+#define INF_DIST_BITS 5                // 0: distances through the 15 limits only (rounds 2 - 3a); 5: -2 %; 6 and 7 cost a workgroup per CU
+#endif
 #ifndef INF_HOT_LOOP
 #define INF_HOT_LOOP 0                // the one-exit literal loop: 42 instead of 54 instructions per literal, and 4 % SLOWER (r03z)
 #endif
@@ -81,6 +84,9 @@ struct alignas(16) LaneTabs {
     uint16_t lit_sorted[288];
 #endif
     uint16_t dist_sorted[32];
+#if INF_DIST_BITS
+    uint16_t dist_tab[1 << INF_DIST_BITS];     // primary table of the distance codes (symbol | length << 9), like lit_tab
+#endif
     Canon lit_cn, dist_cn;
 };
 static_assert(sizeof(uint16_t) << LIT_BITS >= 352, "the code lengths must fit under the primary table");
@@ -115,17 +121,17 @@ __device__ bool build_code(const uint8_t* lens, int n, Canon& cn, SortedPtr sort
 }
 
 // the primary table of the codes of at most LIT_BITS bits, from the sorted symbols (the code lengths are gone by now)
-template <typename SortedPtr>
+template <int BITS, typename SortedPtr>
 __device__ void build_table(const Canon& cn, SortedPtr sorted, uint16_t* table)
 {
-    for (int i = 0; i < (1 << LIT_BITS); i++) table[i] = 0;
+    for (int i = 0; i < (1 << BITS); i++) table[i] = 0;
     uint32_t idx = 0;
-    for (int l = 1; l <= LIT_BITS; l++) {
+    for (int l = 1; l <= BITS; l++) {
         const uint32_t end = cn.next[l];
         const int off = cn.off[l];
         for (; idx < end; idx++) {
             const uint32_t e = (uint32_t)sorted[idx] | ((uint32_t)l << 9);
-            for (uint32_t k = bit_reverse((uint32_t)((int)idx - off), l); k < (1u << LIT_BITS); k += 1u << l) table[k] = (uint16_t)e;
+            for (uint32_t k = bit_reverse((uint32_t)((int)idx - off), l); k < (1u << BITS); k += 1u << l) table[k] = (uint16_t)e;
         }
     }
 }
@@ -311,7 +317,10 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
             if (ll[256] == 0) { bad = true; break; }                          // no end-of-block code
             if (!build_code(ll, hlit, T.lit_cn, lit_sorted) || !build_code(ll + hlit, hdist, T.dist_cn, T.dist_sorted)) { bad = true; break; }
         }
-        build_table(T.lit_cn, lit_sorted, T.lit_tab);
+        build_table<LIT_BITS>(T.lit_cn, lit_sorted, T.lit_tab);
+#if INF_DIST_BITS
+        build_table<INF_DIST_BITS>(T.dist_cn, T.dist_sorted, T.dist_tab);
+#endif
         // ---- symbols of the block: runs of literals (the lanes of the wave meet again at their next match) -------------------
         for (;;) {
             int sym;
@@ -355,7 +364,12 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
             const uint32_t le = lc < 8u || lc == 28u ? 0u : (lc >> 2) - 1u;
             uint32_t len = (lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << le)) + take(B, (int)le);
             need32(B);
+#if INF_DIST_BITS
+            // (distance symbol 0 with a code of l bits is the entry l << 9: never 0, so "0 = longer code" stays unambiguous)
+            const int ds = decode<INF_DIST_BITS, 15>(B, T.dist_tab, T.dist_cn, T.dist_sorted);
+#else
             const int ds = decode<0, 15>(B, nullptr, T.dist_cn, T.dist_sorted);
+#endif
             if (ds < 0 || ds > 29) { bad = true; break; }
             const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
             const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
@@ -498,6 +512,20 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
         }
     }
     return GCI_OK;
+}
+
+// How many members the device decodes AT A TIME (CUs x resident workgroups x members per workgroup).  Every member takes about
+// as long as every other (~37 ms with the CUs full, whatever the launch size), so a launch is a whole number of such rounds:
+// 65 536 members -- a run of 4 GiB -- are 2.3 rounds and take the time of 3.  A caller that cuts a file into runs makes them
+// whole multiples of this (pipeline._bam_join_input_gpu).
+extern "C" uint32_t gci_bgzf_inflate_round(gci_ctx* ctx)
+{
+    if (!ctx) return 0;
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8>, 64, 0) != hipSuccess) return 0;
+    return (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu * 8 : 0);
 }
 
 // =====================================================================================================================

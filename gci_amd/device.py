@@ -398,6 +398,10 @@ class Engine:
         self.check_status("gci_bgzf_inflate_device")
         return out[:n_pre + total]
 
+    def inflate_round(self) -> int:
+        """Members gci_bgzf_inflate_device decodes at a time on this device (0: unknown)."""
+        return int(self.lib.gci_bgzf_inflate_round(self.ctx))
+
     def start_upload(self, raw: np.ndarray, parts: int = 2):
         """Begin uploading the bytes of a BGZF file in `parts` pieces on a copy stream of its own (a helper thread: the
         copies come from pageable memory and block their caller) -> a handle for bgzf_inflate_uploaded, which starts

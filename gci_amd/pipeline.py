@@ -231,7 +231,7 @@ GPU_INFLATE_MAX = int(os.environ.get("GCI_GPU_INFLATE_MAX", str(32 << 30)))
 
 # A BAM whose inflated stream exceeds this many bytes is streamed through the GPU chunk by chunk (K1 per chunk,
 # compact records + packed names kept, SEQ/QUAL bytes dropped): real 40x whole-genome BAMs inflate to hundreds of GB.
-BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))
+BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(8 << 30)))
 
 
 # What the record filter runs over.  "pages" (default): the records are laid out as RECORD PAGES on the device first
@@ -376,9 +376,16 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
         upload["future"].result()
         upload["pool"].shutdown()
         upload = None
+    # Runs of members of at most chunk_bytes inflated -- and a whole number of the device's decode rounds each: every member takes
+    # about as long as every other, so 65 536 members (4 GiB) on a device that decodes 28 672 at a time cost three rounds for the
+    # work of 2.3 (bench.py's ingest of 64.5 GB: 4.1 s; with whole rounds per run: see DESIGN.md section 5)
+    rnd = engine.inflate_round()
+    per_run = 0
+    if rnd > 0:
+        per_run = max(1, int(chunk_bytes // max(1, total // max(1, len(isz)))) // rnd) * rnd
     groups, a, acc = [], 0, 0
     for i, sz in enumerate(isz.tolist()):
-        if acc and acc + sz > chunk_bytes:
+        if acc and (acc + sz > chunk_bytes or (per_run and i - a >= per_run)):
             groups.append((a, i))
             a, acc = i, 0
         acc += sz
