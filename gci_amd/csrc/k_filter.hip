@@ -856,8 +856,11 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
     // share the wave, and the kernel is bound by instruction issue (profiles/r03t_pmc_summary.txt): fewer lanes per record,
     // fewer instructions per page.  A record the lean path does not finish is listed for pass B.
     {
-        const int gl = t % PG_LPR;
-        const uint32_t lgrp = (uint32_t)t / PG_LPR;
+        // (with fewer than four lanes per record not every wave has records: which waves do rotates with the page, so that the
+        // pages resident on a CU keep all four SIMDs busy -- a workgroup's waves go to the SIMDs in a fixed order)
+        const int tv = PG_LPR == 4 ? t : (int)(((uint32_t)t + 64u * (blockIdx.x & 3u)) & (PGK - 1u));
+        const int gl = tv % PG_LPR;
+        const uint32_t lgrp = (uint32_t)tv / PG_LPR;
         for (uint32_t j0 = 0; j0 < n_recs; j0 += PGK / PG_LPR) {
             const uint32_t j = j0 + lgrp;
             const uint32_t rec = first_rec + j;
