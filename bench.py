@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--heads", action="store_true", help="chr19 workload: feed the heads stream instead of the whole stream")
     ap.add_argument("--k1", choices=("pages", "stream"), default="pages",
                     help="record filter input: pages = RECORD PAGES (gci_bam_pages_*: what the command line's ingestion leaves on "
-                         "the device; gci_bam_filter_pages), stream = the heads / inflated stream + offset table (gci_bam_filter[_heads])")
+                         "the device; gci_bam_filter_pages), stream = the whole inflated stream + offset table (gci_bam_filter; chr19 workload only)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend: nccl = RCCL over xGMI (one GPU per rank); gloo stages the collectives through "
                          "host memory and lets several ranks share one GPU (GCI_DIST_DEVICE): correctness runs only")
@@ -91,6 +91,10 @@ def parse_args():
                     help="A/B: the join does not do the depth build's counting pass (gci_name_join instead of gci_name_join_count)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU name check / exchange and the all-reduce even with one rank (self-test)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="one rank: run the STRONG-scaling step of N > 1 anyway -- the join sharded by name hash over a world of one "
+                         "(every all-to-all and the all-reduce execute, through RCCL with --backend nccl): the self-test of the path an "
+                         "8-GPU node takes, on one GPU")
     ap.add_argument("--force-replicated", action="store_true",
                     help="with the exchange: always take the replicated-join fallback (all-gather of records + names)")
     return ap.parse_args()
@@ -142,6 +146,9 @@ class Workload:
         self.total_rec = sum(self.n_rec)
         # record pages: made on the device from the uploaded stream, once (ingestion, outside the timed step: it is the
         # last step of the walk over the inflated file); the stream itself is dropped
+        if k1 != "pages" and heads:
+            sys.exit("bench.py --k1 stream reads the whole inflated stream (--workload chr19 without --heads); a heads stream is "
+                     "read through its record pages")
         self.k1 = k1
         self.pages = None
         if k1 == "pages":
@@ -217,7 +224,7 @@ class Workload:
         eng, lib, ctx = self.eng, self.eng.lib, self.eng.ctx
         from gci_amd._lib import JoinFile
         chk = eng._chk
-        k1 = lib.gci_bam_filter_heads if self.heads else lib.gci_bam_filter
+        k1 = lib.gci_bam_filter                          # --k1 stream: the round-1 / 2 kernel over the whole inflated stream
         F = self.n_files
         for f in range(F):
             if self.pages is not None:
@@ -492,7 +499,7 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
                                 procs=max(1, workloads_default_procs() // max(1, world)))
     nper = len(inp.contigs)
     contig_owner = None
-    if world > 1 and args.scaling == "strong":
+    if (world > 1 or args.force_sharded) and args.scaling == "strong":
         # the same genome as N = 1: contigs dealt to the ranks, every rank keeps the records of ITS contigs (what its
         # index-driven ingestion would read of each file: pipeline.bam_records_of_contigs)
         from gci_amd import shard
@@ -1121,7 +1128,7 @@ def main():
     def eng_factory():
         """HIP context, process group and library context: created AFTER the host-side generation of the inputs."""
         torch.cuda.set_device(device_index)
-        if world > 1 or exchange:
+        if world > 1 or exchange or args.force_sharded:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             # RCCL logs to stdout: keep it off the channel on which rank 0 prints its ONE JSON line
             if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "WARN"):
@@ -1276,14 +1283,21 @@ def main():
         "kernel_us_per_launch": breakdown,
     }
 
-    if world > 1 and args.verify_oracle and args.workload == "genome":
+    forced = world == 1 and (exchange or args.force_sharded)          # one rank on the multi-rank path (the RCCL self-test)
+    if (world > 1 or forced) and args.verify_oracle and args.workload == "genome":
         ok = verify_strong_against_oracle(w) if w.sharded else verify_against_oracle_multi_rank(w, args)
         if rank == 0:
             out["parity_vs_oracle_all_ranks"] = ok
             if not ok:
                 print(json.dumps(out))
                 sys.exit("PARITY FAILURE: the multi-rank result differs from the oracle over all ranks' files")
-    if rank == 0 and world == 1 and two_type:
+    if forced:
+        out["config"]["collectives"] = {"backend": args.backend, "world": 1, "executed_per_step": (
+            "all_to_all_single x %d (records + name slots per file, intervals) + all_reduce of the sum of depth" % (2 * w.n_files + 1)
+            if w.sharded else "all_to_all_single (name-check hashes) + all_reduce of the per-contig sums"
+            + (" + all_gather_into_tensor x 3 per file (replicated join)" if w.replicated_steps else ""))}
+        out["cpu_baseline"] = None
+    elif rank == 0 and world == 1 and two_type:
         names = w.inp.names
         chosen = ["chr14", "chr22", "chrM"] if args.workload == "genome4" else ["mat_chr14", "pat_chr21", "pat_chr22"]
         hit = [c for c, segs in w.inp.gaps.items() if c in names]                     # a contig with a gap, one with a -R region

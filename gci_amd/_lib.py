@@ -67,8 +67,6 @@ EXPORTS = [
     ("gci_layout_offsets", c_int, [c_void_p, c_void_p]),
     ("gci_bam_filter", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_int32, c_int, c_int,
                                c_double, c_double, c_uint32, c_void_p, c_void_p]),
-    ("gci_bam_filter_heads", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_int32, c_int, c_int,
-                                     c_double, c_double, c_uint32, c_void_p, c_void_p]),
     ("gci_bam_pages_size", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_int, c_uint32, c_void_p]),
     ("gci_bam_pages_write", c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_int, c_void_p, c_uint64]),
     ("gci_bam_filter_pages", c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p, c_int32, c_int, c_int,

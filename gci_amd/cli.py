@@ -260,7 +260,7 @@ def main(argv=None):
             entry = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "GCI.py")
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
                                    "--master-addr", "127.0.0.1", "--master-port", str(port), entry] + argv[1:])
-    if world > 1:
+    if world > 1 or (launched and os.environ.get("GCI_FORCE_SHARDED", "0") == "1"):
         from . import shard
         ctx = shard.Context()
         if not ctx.root:

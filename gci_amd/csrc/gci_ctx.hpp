@@ -67,7 +67,9 @@ struct gci_ctx {
     DevBuf route_tab;                       // gci_route_*: per (part, chunk) counts and their scan
     DevBuf inflate_sorted;                  // gci_bgzf_inflate_device built with INF_SORTED_GLOBAL: 288 uint16 per member
     DevBuf deflate_nruns, deflate_runs;     // gci_depth_deflate_*: per tile its constant-depth runs (k_depth_runs)
-    uint32_t deflate_members = 0;           // ... of the members the last size call measured
+    uint32_t deflate_members = 0;           // ... of the members the last size call measured,
+    const void* deflate_key_depth = nullptr;    // ... over this track
+    const void* deflate_key_elem = nullptr;     // ... and this member table (the write call reuses the lists only for the same three)
     DevBuf conflict_table;                  // gci_hash_conflicts' own open-addressing tables (two, used alternately)
     uint64_t conflict_slots = 0;            // slots per table
     uint32_t conflict_parity = 0;           // which one the next call inserts into (the other one is clean by then)
@@ -76,6 +78,7 @@ struct gci_ctx {
     DevBuf pg_cost, pg_scan, pg_first;      // record pages: per-record cost / blob bytes, their scans, first record of a page
     uint32_t pg_n_rec = 0, pg_page_bytes = 0, pg_n_pages = 0;
     uint64_t pg_blob_off = 0;
+    uint64_t pg_blob_bytes = 0;               // total size of the blob the size call measured (without its 16 guard bytes)
     // issue-scan windows
     DevBuf win, win_tile_first;
     int win_flank = INT32_MIN;              // flank the cached per-contig windows were built for

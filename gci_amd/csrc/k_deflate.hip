@@ -367,7 +367,7 @@ extern "C" int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, cons
     const uint64_t n_tiles = (uint64_t)n_members * MEMBER_TILES;
     GCI_TRY(gci_ensure(ctx, ctx->deflate_nruns, n_tiles * 4));
     GCI_TRY(gci_ensure(ctx, ctx->deflate_runs, n_tiles * RUN_MAX * sizeof(int2)));
-    ctx->deflate_members = n_members;
+    ctx->deflate_members = n_members; ctx->deflate_key_depth = d_depth; ctx->deflate_key_elem = d_member_elem;
     hipLaunchKernelGGL(k_depth_runs, dim3((uint32_t)((n_tiles + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, ctx->stream, d_depth,
                        d_member_elem, d_member_n, n_members, (uint32_t*)ctx->deflate_nruns.p, (int2*)ctx->deflate_runs.p);
     LAUNCHCHK("k_depth_runs");
@@ -390,7 +390,8 @@ extern "C" int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* d_depth, con
                        const_cast<uint32_t*>(d_tile_bytes), (uint32_t*)nullptr, const_cast<uint32_t*>(d_member_crc),
                        const_cast<uint32_t*>(d_member_isize), d_member_out, d_out, cap,
                        // the run lists of the size call over the same track and members (else: the lanes walk the track)
-                       ctx->deflate_members == n_members ? (const uint32_t*)ctx->deflate_nruns.p : (const uint32_t*)nullptr,
+                       ctx->deflate_members == n_members && ctx->deflate_key_depth == d_depth && ctx->deflate_key_elem == d_member_elem
+                           ? (const uint32_t*)ctx->deflate_nruns.p : (const uint32_t*)nullptr,
                        (const int2*)ctx->deflate_runs.p);
     LAUNCHCHK("k_depth_deflate<2>");
     return GCI_OK;

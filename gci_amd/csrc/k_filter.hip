@@ -399,20 +399,10 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     const int32_t* __restrict__ ref_sel, int32_t n_ref, int map_qual, int mq_cutoff, double clip_percent,
     double iden_percent, uint32_t rec_idx_base, gci_rec* __restrict__ out, unsigned long long* __restrict__ status,
     const LongQueue lq
-#ifdef GCI_K1_TRACE
-    , unsigned long long* __restrict__ trace
-#endif
     )
 {
-#ifdef GCI_K1_TRACE
-#define TR(i) do { if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
-#else
 #define TR(i) do {} while (0)
-#endif
     TR(0);
-#if defined(GCI_K1_TRACE) && defined(GCI_K1_WALL)
-    if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 14] = wall_clock64();
-#endif
     if (blockIdx.x == 0 && threadIdx.x < 4) lq.next_counters[threadIdx.x] = 0u;    // nobody reads that set during this call
     if (blockIdx.x == 0 && threadIdx.x == 4) *lq.next_status = ~0ull;
     __shared__ __attribute__((aligned(16))) uint8_t stage[KB / G][ROW];
@@ -667,9 +657,6 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(K1_WAVES, K1
     return false;
     };
     const bool is_slow = live && fast_path();
-#if defined(GCI_K1_TRACE) && defined(GCI_K1_WALL)
-    if (threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
-#endif
     // ---- slow records of this wave, one after the other, by the whole wave (rare: NM beyond the staged window, htslib's
     // CG:B,I long-CIGAR restore, names of 73 bytes and more); no second kernel launch for them
     for (unsigned long long m = __ballot(is_slow && gl == 0); m; m &= m - 1ull) {
@@ -869,9 +856,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             // an odd type or missing, an operation of 2^24 bases, a zero denominator, a quotient within 1e-4 of a threshold -- is
             // left to pass B's fast_path(), which knows every case (1); a record that is done returns 0.
             auto lean_path = [&]() -> int {
-#ifdef PGX_NO_LEAN
-                return 1;
-#endif
                 uint32_t base = (uint32_t)reinterpret_cast<const uint16_t*>(page + 16)[j] << 4;
                 if (base > P - 48u) return 1;
                 const uint8_t* hd = page + base;
@@ -906,7 +890,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                     sA = __umul24(len, __builtin_amdgcn_ubfe(0x187u, op, 1)) + sA;
                     sR = __umul24(len, __builtin_amdgcn_ubfe(0x18Du, op, 1)) + sR;
                 };
-#ifndef PGX_NO_CIGAR
                 {
                     const uint8_t* cg = hd + cig_at;
                     for (uint32_t p = gl; 4u * p < n_cigar; p += PG_LPR) {
@@ -915,7 +898,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                         add_op(v.x); add_op(v.y); add_op(v.z); add_op(v.w);
                     }
                 }
-#endif
                 // first NM among fixed-size tags
                 const uint8_t* ax = hd + aux_at;
                 uint32_t q = 0, nmk = 0;
@@ -978,11 +960,7 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 return 0;
             };
 
-#ifdef PGX_LEAN_ONLY
-            if (j < n_recs && lean_path() != 0 && gl == 0) report(lq.status_in, rec, GCI_E_INVALID);       // (timing experiment)
-#else
             if (j < n_recs && lean_path() != 0 && gl == 0) s_full[atomicAdd(&s_n_full, 1u)] = (uint16_t)j;
-#endif
         }
     }
     __syncthreads();
@@ -1046,7 +1024,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 sA = __umul24(len, __builtin_amdgcn_ubfe(0x187u, op, 1)) + sA;
                 sR = __umul24(len, __builtin_amdgcn_ubfe(0x18Du, op, 1)) + sR;
             };
-#ifndef PGX_NO_CIGAR
             if (!ext) {
                 const uint8_t* cg = hd + cig_at;
                 for (uint32_t p = gl; 4u * p < n_cigar; p += 4) {
@@ -1055,7 +1032,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                     add_op(v.x); add_op(v.y); add_op(v.z); add_op(v.w);
                 }
             }
-#endif
             // ---- aux walk (bam_aux_get semantics): first NM; first CG when the CIGAR is htslib's long-CIGAR placeholder
             const uint8_t* ax = hd + aux_at;
             const uint32_t op0 = lds_u32(hd + cig_at);
@@ -1063,9 +1039,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             bool have_nm = false, nm_bad = false;
             int64_t NM = 0;
             uint32_t cg_q = 0xFFFFFFFFu;
-#ifdef PGX_NO_AUX
-            have_nm = true; NM = (int64_t)(lds_u32(ax) & 0xFF);
-#else
             // Four lanes walk the same tags, and a wave walks as long as its slowest record: the loop that finds NM among
             // fixed-size tags (A c C s S i I f: what aligners write around it) is kept to one tag word, one table byte and a
             // handful of instructions per tag; a Z / H / B value in front of NM, or the CG search, takes the general loop below
@@ -1112,7 +1085,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
                 }
                 q += 3 + sz;
             }
-#endif
             // htslib moves a long CIGAR back from CG:B,I when op0 == <l_seq>S (rare: the sums are redone over the tag's payload)
             bool restored = false;
             if (cg_q != 0xFFFFFFFFu && ax[cg_q] == 'B' && (ax[cg_q + 1] == 'I' || ax[cg_q + 1] == 'i')) {
@@ -1126,11 +1098,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             // ---- query_name: bytes up to the first NUL, 64-bit hash of its 8-byte words -----------------------------------
             const uint8_t* name = hd + 36;
             uint32_t nul = l_read_name;
-#ifdef PGX_NO_HASH
-            const uint32_t name_len = l_read_name - 1;
-            r.name_hash = lds_u32(name) + ((uint64_t)lds_u32(name + 8) << 32);
-            (void)nul;
-#else
             for (uint32_t i = gl * 4; i < l_read_name; i += 16) {
                 if (has_zero_byte(lds_u32(name + i))) {
                     for (uint32_t b = i; b < i + 4 && b < l_read_name; b++) if (name[b] == 0) { nul = min(nul, b); break; }
@@ -1152,7 +1119,6 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             acc += (uint64_t)__shfl_xor((long long)acc, 1, 4);
             acc += (uint64_t)__shfl_xor((long long)acc, 2, 4);
             r.name_hash = gci_hash_finish(acc, name_len);
-#endif
             r.name_len = (uint16_t)name_len;
             // in a page: at 16 k + 4, NUL and zero padding up to the CIGAR's 16-byte boundary
             const uint8_t name16 = name_len + 1u == l_read_name ? GCI_REC_NAME16 : 0;
@@ -1188,13 +1154,9 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
             PG_SUM(tS); PG_SUM(tQ); PG_SUM(tA); PG_SUM(tR);
 #undef PG_SUM
             if (gl != 0) return false;
-#ifdef PGX_NO_DECIDE
-            r.start = pos; r.end = pos + (int32_t)tR; r.qlen = (int32_t)(tS + tQ + tA + NM); r.contig = contig; r.flags = have_nm && !nm_bad ? 1 : 0;
-#else
             const int st = decide4(r, (int64_t)tS, (int64_t)tQ, (int64_t)tA, (int64_t)tR, have_nm, nm_bad, NM, pos, contig, l_seq,
                                    n_cigar, mapq, A.mq_cutoff, A.clip_percent, A.iden_percent);
             if (st != GCI_OK) report(lq.status_in, rec, st);
-#endif
             if (r.flags) r.flags |= name16;
             A.out[rec] = r;
             return false;
@@ -1213,10 +1175,11 @@ __global__ __launch_bounds__(PGK) __attribute__((amdgpu_waves_per_eu(PG_WAVES, P
 // Scratch of one K1 call: [2 x (n_slow u32, pad, n_long u64)][2 x status u64][pad][slow_list u32 x n_rec (+pad)][long items]
 // [chunk queue][chunk sums].  A queued item has at least min_item_bytes of CIGAR of its own inside the long_bytes that can
 // hold such CIGARs, and a chunk covers 4 * CHUNK_DW bytes: that bounds both queues.
-static int k1_prepare(gci_ctx* ctx, uint32_t n_rec, uint64_t long_bytes, uint32_t min_item_bytes, bool has_seq, LongQueue& lq)
+static int k1_prepare(gci_ctx* ctx, uint32_t n_rec, uint64_t long_bytes, uint32_t min_item_bytes, bool has_seq, LongQueue& lq,
+                      uint64_t extra_items = 0)
 {
     const size_t list_bytes = ((size_t)n_rec * 4 + 15) & ~(size_t)15;
-    const uint64_t by_bytes = long_bytes / min_item_bytes + 1;
+    const uint64_t by_bytes = long_bytes / min_item_bytes + 1 + extra_items;
     const uint32_t cap_items = (uint32_t)(by_bytes < n_rec ? by_bytes : n_rec);
     const uint64_t cap_chunks64 = long_bytes / (4ull * CHUNK_DW) + 2ull * cap_items + 1;
     if (cap_chunks64 > 0xFFFFFFFFull) return GCI_E_INVALID;
@@ -1274,9 +1237,6 @@ static int bam_filter_impl(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes,
     hipLaunchKernelGGL(k_bam_filter, dim3((n_rec + per_block - 1) / per_block), dim3(KB), 0, ctx->stream, d_bam, n_bytes,
                        d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base,
                        d_out, (unsigned long long*)d_status, lq
-#ifdef GCI_K1_TRACE
-                       , (unsigned long long*)strtoull(getenv("GCI_K1_TRACE_PTR") ? getenv("GCI_K1_TRACE_PTR") : "0", nullptr, 0)
-#endif
                        );
     LAUNCHCHK("k_bam_filter");
     return k1_finish(ctx, d_bam, n_bytes, lq, mq_cutoff, clip_percent, iden_percent, d_out, d_status);
@@ -1293,8 +1253,14 @@ extern "C" int gci_bam_filter_pages(gci_ctx* ctx, const uint8_t* d_pages, uint64
     if (page_bytes < 8192 || page_bytes > GCI_PAGE_MAX_BYTES || (page_bytes & 4095u)) return GCI_E_INVALID;
     if ((uint64_t)n_pages * page_bytes + 16 > total_bytes && n_pages) return GCI_E_INVALID;
     LongQueue lq;
-    // every queued CIGAR lies in the blob; the shortest one that does not fit a page record has ~180 operations
-    GCI_TRY(k1_prepare(ctx, n_rec, total_bytes - (uint64_t)n_pages * page_bytes, 512u, false, lq));
+    // What is queued: every passing kind-1 / kind-2 record (its CIGAR lies in the blob, in a piece of its own of a multiple of 16
+    // bytes -- a record goes there for its TAGS as well: 60 operations and 900 bytes of MD / cs / SA is kind 1 with a 240-byte
+    // piece, so the blob bounds their NUMBER by bytes / 16, not by bytes / 512 as round 3 assumed), a kind-1 record without any
+    // operation (no piece), and an inline record with an operation of 2^24 bases or more ("wide": exact sums only in the chunk
+    // path).  The last two kinds do not occur in real files; one in 64 records + 1024 may be one before the call refuses
+    // (GCI_E_CAPACITY in the status word, never a silent loss).
+    const uint64_t blob_bytes = total_bytes - (uint64_t)n_pages * page_bytes;
+    GCI_TRY(k1_prepare(ctx, n_rec, blob_bytes, 16u, false, lq, (uint64_t)n_rec / 64 + 1024));
     if (n_rec == 0 || n_pages == 0) { HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream)); return GCI_OK; }
     ctx->k1_parity ^= 1u;
     ProfScope _ps(ctx, GCI_PROF_BAM_FILTER);
@@ -1314,16 +1280,6 @@ extern "C" int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_byt
 {
     return bam_filter_impl(ctx, d_bam, n_bytes, d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent,
                            iden_percent, rec_idx_base, d_out, d_status, true);
-}
-
-// The same filter over a heads stream (gci_bam_heads: every record without its SEQ and QUAL bytes).
-extern "C" int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes, const uint64_t* d_rec_off,
-                                    uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
-                                    double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
-                                    uint64_t* d_status)
-{
-    return bam_filter_impl(ctx, d_heads, n_bytes, d_rec_off, n_rec, d_ref_sel, n_ref, map_qual, mq_cutoff, clip_percent,
-                           iden_percent, rec_idx_base, d_out, d_status, false);
 }
 
 extern "C" int gci_decode_status(uint64_t w, uint32_t* rec_idx)

@@ -223,9 +223,6 @@ struct __attribute__((aligned(16))) PartEntry {
     uint32_t name_off16;
 };
 static_assert(sizeof(PartEntry) == 32, "partition entry is 32 bytes");
-#ifndef JOIN_NAME_PREFETCH
-#define JOIN_NAME_PREFETCH 0
-#endif
 #define PART_CHUNK 8192
 #define PART_CONTIG_BITS 26
 #define PART_KEY_MASK 0xFFFFFFFFFFFFull            // the hash bits of a key
@@ -764,19 +761,6 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (in_regs && i < n) ent[k] = load_entry(in + i);
         else { ent[k].key = 0; ent[k].idx = 0; ent[k].meta = 0; ent[k].start = ent[k].end = ent[k].qlen = 0; ent[k].name_off16 = 0; }
     }
-#if JOIN_NAME_PREFETCH
-    // every entry asks for the line that holds its own name NOW: the requests travel while the table is cleared and filled, and
-    // when settle() compares an entry's name with its claimant's, both lines were asked for a microsecond ago (the claimant is
-    // an entry of this bucket too)
-    uint32_t pf[PART_E];
-#pragma unroll
-    for (int k = 0; k < PART_E; k++) {
-        const uint32_t i = (uint32_t)t + (uint32_t)k * JB;
-        pf[k] = 0;
-        if (in_regs && i < n && !A.no_verify)
-            pf[k] = *reinterpret_cast<const uint32_t*>((uintptr_t)entry_name(F, ent[k]) & ~(uintptr_t)3);
-    }
-#endif
     auto name_word = [](const PartEntry& e) -> unsigned long long {
         return (unsigned long long)e.name_off16 | ((e.key >> 60) << 32) | (((e.key >> 48) & 0xFFFull) << 36) |
                ((unsigned long long)((e.meta >> PART_CONTIG_BITS) & 15u) << 48) | ((unsigned long long)(e.meta >> 31) << 52);
@@ -830,10 +814,6 @@ __global__ __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (uint32_t i = t; i < n; i += JB) insert(load_entry(in + i), i, exact);
         }
         __syncthreads();
-#if JOIN_NAME_PREFETCH
-#pragma unroll
-        for (int k = 0; k < PART_E; k++) asm volatile("" :: "v"(pf[k]));      // (the requests are kept, and waited for no earlier than here)
-#endif
         if (in_regs) {
 #pragma unroll
             for (int k = 0; k < PART_E; k++) {

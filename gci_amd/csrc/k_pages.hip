@@ -232,7 +232,7 @@ extern "C" int gci_bam_pages_size(gci_ctx* ctx, const uint8_t* d_stream, uint64_
     if (!ctx || !h_out || (n_rec && (!d_stream || !d_rec_off))) return GCI_E_INVALID;
     if (page_bytes < 8192 || page_bytes > GCI_PAGE_MAX_BYTES || (page_bytes & 4095u)) return GCI_E_INVALID;
     h_out[0] = h_out[1] = h_out[2] = 0;
-    ctx->pg_n_rec = n_rec; ctx->pg_page_bytes = page_bytes; ctx->pg_n_pages = 0; ctx->pg_blob_off = 0;
+    ctx->pg_n_rec = n_rec; ctx->pg_page_bytes = page_bytes; ctx->pg_n_pages = 0; ctx->pg_blob_off = 0; ctx->pg_blob_bytes = 0;
     if (n_rec == 0) { h_out[1] = 16; return GCI_OK; }
     const uint32_t Q = page_bytes - PG_MAX_REC - 48;
     GCI_TRY(gci_ensure(ctx, ctx->pg_cost, ((size_t)n_rec + 1) * 4 * 2));
@@ -261,6 +261,7 @@ extern "C" int gci_bam_pages_size(gci_ctx* ctx, const uint8_t* d_stream, uint64_
     LAUNCHCHK("k_pg_first");
     ctx->pg_n_pages = (uint32_t)n_pages;
     ctx->pg_blob_off = n_pages * page_bytes;
+    ctx->pg_blob_bytes = b_total;
     h_out[0] = n_pages;
     h_out[1] = n_pages * page_bytes + b_total + 16;
     h_out[2] = ctx->pg_blob_off;
@@ -280,10 +281,11 @@ extern "C" int gci_bam_pages_write(gci_ctx* ctx, const uint8_t* d_stream, uint64
     A.bam = d_stream; A.n_bytes = n_bytes; A.rec_off = d_rec_off; A.n_rec = n_rec; A.has_seq = has_seq;
     A.S = S; A.B = B; A.page_first = (const uint32_t*)ctx->pg_first.p; A.page_bytes = ctx->pg_page_bytes;
     A.blob_off = ctx->pg_blob_off; A.out = d_out;
-    if (cap < ctx->pg_blob_off + 16) return GCI_E_CAPACITY;
+    const uint64_t need = ctx->pg_blob_off + ctx->pg_blob_bytes + 16;        // = h_out[1] of the size call
+    if (cap < need) return GCI_E_CAPACITY;
     hipLaunchKernelGGL(k_pg_write, dim3(ctx->pg_n_pages), dim3(BLOCK), ctx->pg_page_bytes, ctx->stream, A);
     LAUNCHCHK("k_pg_write");
-    // the 16 readable bytes behind the blob (k_cigar_chunks fetches whole 16-byte pieces)
-    HIPCHK(hipMemsetAsync(d_out + cap - 16, 0, 16, ctx->stream));
+    // the 16 zero bytes directly behind the blob (k_cigar_chunks fetches whole 16-byte pieces)
+    HIPCHK(hipMemsetAsync(d_out + need - 16, 0, 16, ctx->stream));
     return GCI_OK;
 }

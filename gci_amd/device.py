@@ -164,13 +164,13 @@ class Engine:
     # ---- R1 ----------------------------------------------------------------------------------
     def bam_filter(self, d_bam: torch.Tensor, d_rec_off: torch.Tensor, d_ref_sel: torch.Tensor, map_qual: int,
                    mq_cutoff: int, clip_percent: float, iden_percent: float, out: Optional[torch.Tensor] = None,
-                   check: bool = True, rec_idx_base: int = 0, heads: bool = False) -> torch.Tensor:
-        """heads=True: d_bam is a heads stream (hostio.bam_heads), records without SEQ / QUAL."""
+                   check: bool = True, rec_idx_base: int = 0) -> torch.Tensor:
+        """K1 over the whole inflated stream (the round-1 / 2 kernel, GCI_K1=stream; the product runs bam_pages +
+        bam_filter_pages)."""
         n = int(d_rec_off.shape[0])
         if out is None:
             out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
-        fn = self.lib.gci_bam_filter_heads if heads else self.lib.gci_bam_filter
-        st = fn(self.ctx, self._p(d_bam), int(d_bam.shape[0]), self._p(d_rec_off), n, self._p(d_ref_sel),
+        st = self.lib.gci_bam_filter(self.ctx, self._p(d_bam), int(d_bam.shape[0]), self._p(d_rec_off), n, self._p(d_ref_sel),
                 int(d_ref_sel.shape[0]), int(map_qual), int(mq_cutoff), float(clip_percent), float(iden_percent),
                 int(rec_idx_base), self._p(out), self._p(self._status))
         self._chk(st, "gci_bam_filter")

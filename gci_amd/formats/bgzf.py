@@ -51,6 +51,22 @@ def compress(data: bytes, level: int = 1, threads: int = 1) -> bytes:
     return b"".join(members) + BGZF_EOF
 
 
+def member_size(raw, pos: int) -> int:
+    """Total bytes of the BGZF member that starts at `pos` (its BSIZE + 1), found by walking the extra sub-fields: BC need not be
+    the first one."""
+    n = len(raw)
+    if n - pos < 18 or raw[pos] != 0x1F or raw[pos + 1] != 0x8B or raw[pos + 2] != 8 or not (raw[pos + 3] & 4):
+        raise BGZFError("not a BGZF member at byte %d" % pos)
+    xlen = int(raw[pos + 10]) | (int(raw[pos + 11]) << 8)
+    p, end = pos + 12, min(n, pos + 12 + xlen)
+    while p + 4 <= end:
+        slen = int(raw[p + 2]) | (int(raw[p + 3]) << 8)
+        if raw[p] == 66 and raw[p + 1] == 67 and slen == 2 and p + 6 <= end:
+            return (int(raw[p + 4]) | (int(raw[p + 5]) << 8)) + 1
+        p += 4 + slen
+    raise BGZFError("gzip member without BC sub-field at byte %d" % pos)
+
+
 def scan_blocks(raw: bytes) -> List[Tuple[int, int, int]]:
     """Return [(member_offset, member_size, isize)] by walking the BSIZE chain."""
     out = []

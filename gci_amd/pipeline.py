@@ -31,6 +31,7 @@ from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
 from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
 from .formats import bam as bamfmt
+from .formats import bgzf
 from .formats import fasta
 
 _ENGINE: Optional[Engine] = None
@@ -101,7 +102,7 @@ class DepthTracks:
         """np.mean over the concatenation of all contigs (GCI.py:862-868): integers, so exact.  In a contig-sharded run
         the numerator and denominator are ONE integer all-reduce over the ranks (RCCL over xGMI)."""
         total, bases = int(self.sums().sum()), sum(self.lengths)
-        if SHARD is not None and SHARD.world > 1:
+        if _sharded():
             total, bases = SHARD.all_reduce_sum([total, bases])
         return float(total) / float(bases)
 
@@ -115,7 +116,9 @@ def _is_root() -> bool:
 
 
 def _sharded() -> bool:
-    return SHARD is not None and SHARD.world > 1
+    """A contig-sharded run: more than one rank -- or ONE rank made to take the sharded path (GCI_FORCE_SHARDED=1 under
+    torch.distributed.run --nproc-per-node 1: every collective of the multi-GPU path, RCCL included, on a single GPU)."""
+    return SHARD is not None and (SHARD.world > 1 or SHARD.forced)
 
 
 def refuse_overwrite(path: str, force) -> None:
@@ -245,22 +248,27 @@ def _filter_stream(engine: Engine, d_stream: torch.Tensor, d_off: torch.Tensor, 
                    rec_idx_base: int = 0) -> JoinInput:
     """K1 over the records of an inflated BAM stream (has_seq) or a heads stream -> join input (records + where their names are)."""
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
-    if K1_MODE == "pages":
+    if K1_MODE == "pages" or not has_seq:                 # (a heads stream is only ever read through its pages)
         pages = engine.bam_pages(d_stream, d_off, has_seq)
         recs, noff = engine.bam_filter_pages(pages, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base)
-        return JoinInput(recs, pages.buf, noff, 0)
-    recs = engine.bam_filter(d_stream, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base,
-                             heads=not has_seq)
+        ji = JoinInput(recs, pages.buf, noff, 0)
+        ji.blob_bytes = int(pages.buf.shape[0]) - pages.blob_off - 16      # CIGARs / oversize records behind the pages (ONT: GBs)
+        return ji
+    recs = engine.bam_filter(d_stream, d_off, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base)
     return JoinInput(recs, d_stream, d_off, 36)
 
 
 def _keep_part(engine: Engine, ji: JoinInput) -> JoinInput:
     """What is kept of one run of a file that goes through the device run by run: the records and their names -- the pages
     as they are (they ARE the compact form), or, of a whole stream, the names packed (gci_pack_names)."""
-    if ji.name_delta == 0:
+    if ji.name_delta == 0 and getattr(ji, "blob_bytes", 0) == 0:
         return JoinInput(ji.recs.clone(), ji.name_base, ji.name_off.clone(), 0)
+    # pages with a blob behind them (an ONT run: ~12 KB of CIGAR words per record, tens of GB per file) or a whole stream: only
+    # the names are needed from here on -- packed, the rest is released with the run
     names, noff = engine.pack_names(ji)
     recs = ji.recs.clone()
+    if ji.name_delta == 0:
+        recs[:, 29] &= 3                                  # packed names no longer lie at 16 k + 4: not GCI_REC_NAME16
     return JoinInput(recs, names.clone(), noff[:-1].clone(), 0)
 
 
@@ -460,7 +468,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
     takes the next path.
     ingest = "heads": the native host pipeline (gci_bam_heads) inflates the file group by group and keeps every record
     without its SEQ / QUAL bytes; only that heads stream (about 400 B of a 27 KB HiFi record) is uploaded and filtered
-    (gci_bam_filter_heads); names stay addressable inside it.
+    through its record pages; names stay addressable inside those.
     ingest = "full" (or an explicit chunk_bytes): the whole stream, inflated on the host, goes to the device.  Small
     files: one upload.  Large files: groups of BGZF members are inflated into a host buffer (the next group on a
     background thread while the GPU works on the current one), the partial record at the end of a group is carried
@@ -689,9 +697,12 @@ def bam_records_of_contigs(engine: Engine, path: str, targets: Sequence[str], ow
         # ends in (end >> 16), hopping BSIZE from header to header -- a rank never touches the members of the other ranks'
         # contigs (round 2 scanned the whole file on every rank: N x the file's pages through the page cache)
         c_beg, c_end = beg >> 16, end >> 16
-        if not (0 <= c_beg <= c_end and c_end + 18 <= n_raw and bytes(raw[c_end:c_end + 4]) == b"\x1f\x8b\x08\x04"):
+        if not (0 <= c_beg <= c_end and c_end + 18 <= n_raw):
             raise bamfmt.BAMError("index of %s does not match its BGZF members" % path)
-        run_end = c_end + int(raw[c_end + 16]) + (int(raw[c_end + 17]) << 8) + 1    # BSIZE of the last member
+        try:
+            run_end = c_end + bgzf.member_size(raw, c_end)                           # (the BC sub-field wherever it stands)
+        except bgzf.BGZFError as e:
+            raise bamfmt.BAMError("index of %s does not match its BGZF members" % path) from e
         try:
             pos, isz = hostio.bgzf_blocks(np.asarray(raw[c_beg:min(run_end, n_raw)]))
         except Exception as e:                                                    # noqa: BLE001
@@ -830,26 +841,43 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
     longest = max([int(ji.recs[:, 30:32].contiguous().view(torch.int16).max().item()) if int(ji.recs.shape[0]) else 0 for ji in local] + [1])
     slot = (SHARD.all_reduce_max([longest])[0] + 15) // 16 * 16
     sj = shard.ShardedJoin(engine, [int(ji.recs.shape[0]) for ji in local], SHARD.owner, engine.device,
-                           via_host=SHARD.backend != "nccl", name_slot=max(16, slot))
-    while True:
-        inputs = paf_inputs + [sj.exchange_file(f, ji) for f, ji in enumerate(local)]
-        ivl, n_slots = sj.join(inputs, ovlp_percent)
-        err = None
-        try:
-            def decode(w, what):
-                rec = ctypes.c_uint32(0)
-                st = engine.lib.gci_decode_status(w, ctypes.byref(rec))
-                if st != 0:
-                    raise GciError(st, "%s: %s" % (what, engine.lib.gci_strerror(st).decode()), rec=int(rec.value))
-            sj.check(decode)
-        except GciError as e:
-            err = e
-        grow = SHARD.all_reduce_max([1 if (err is not None and err.status == _lib.GCI_E_CAPACITY) else 0])[0]
-        if grow:                                    # a bucket overflowed somewhere (names hash unevenly): larger buckets, again
-            sj.grow()
-            continue
-        _agree_on_error(err)
-        break
+                           via_host=SHARD.backend != "nccl", name_slot=max(16, slot),
+                           extra_records=sum(int(ji.recs.shape[0]) for ji in paf_inputs))
+    classic = False
+    try:
+        while True:
+            inputs = paf_inputs + [sj.exchange_file(f, ji) for f, ji in enumerate(local)]
+            ivl, n_slots = sj.join(inputs, ovlp_percent)
+            err = None
+            try:
+                def decode(w, what):
+                    rec = ctypes.c_uint32(0)
+                    st = engine.lib.gci_decode_status(w, ctypes.byref(rec))
+                    if st != 0:
+                        e = GciError(st, "%s: %s" % (what, engine.lib.gci_strerror(st).decode()), rec=int(rec.value))
+                        e.what = what
+                        raise e
+                sj.check(decode)
+            except GciError as e:
+                err = e
+            cap = err is not None and err.status == _lib.GCI_E_CAPACITY
+            # GCI_E_CAPACITY has two senders.  The partitioned JOIN refuses what its 32-byte entries / LDS tables cannot hold
+            # (adversarial names): every rank then joins on the classic table, once -- larger buckets would change nothing.
+            # A ROUTE / SEAL step reports a bucket that overflowed (names hash unevenly): larger buckets, again.
+            from_join = cap and getattr(err, "what", "") == "gci_name_join"
+            refuse, grow = SHARD.all_reduce_max([1 if from_join else 0, 1 if (cap and not from_join) else 0])
+            if grow:
+                sj.grow()
+                continue
+            if refuse and not classic:
+                classic = True
+                engine._chk(engine.lib.gci_join_mode(engine.ctx, 1), "gci_join_mode")
+                continue
+            _agree_on_error(err)
+            break
+    finally:
+        if classic:
+            engine._chk(engine.lib.gci_join_mode(engine.ctx, engine.join_mode), "gci_join_mode")
     track = engine.new_track()
     fused = engine.depth_build_fused(ivl, None, flank_len, track, want_text=False, want_sums=True, issue=issue_hint, counted=False)
     depths = DepthTracks(engine, local_tl, track)

@@ -38,6 +38,8 @@ class Context:
         self.backend = os.environ.get("GCI_DIST_BACKEND", "nccl")
         # the GPU of this rank: LOCAL_RANK, or GCI_DIST_DEVICE (all ranks on one device: tests)
         self.device_index = int(os.environ.get("GCI_DIST_DEVICE", str(self.local_rank)))
+        # one rank made to take the sharded path (every collective runs, over a world of one: the RCCL self-test on one GPU)
+        self.forced = os.environ.get("GCI_FORCE_SHARDED", "0") == "1"
         self.owner: List[int] = []
 
     @property
@@ -291,11 +293,13 @@ class ShardedJoin:
     name_join (an `Engine`; the CPU tests pass numpy stand-ins)."""
 
     def __init__(self, ops, n_local: Sequence[int], owner: Sequence[int], device: torch.device, group=None,
-                 via_host: bool = False, slack: float = 1.3, name_slot: int = 48):
+                 via_host: bool = False, slack: float = 1.3, name_slot: int = 48, extra_records: int = 0):
         """name_slot: bytes of a routed name slot, a multiple of 16 and at least the longest query name of the run (the same on
-        every rank)."""
+        every rank).  extra_records: rows of the join inputs that do NOT come through exchange_file (PAF records already on the
+        rank that owns their name): the join can emit an interval for each of them (GCI.py:279-280, 298-299)."""
         self.ops, self.group, self.via_host, self.device = ops, group, via_host, device
         self.ROUTE_NAME = int(name_slot)
+        self.extra_records = int(extra_records)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n_files = len(n_local)
@@ -325,8 +329,10 @@ class ShardedJoin:
             i = torch.arange(W * (c + 1), dtype=torch.int64, device=dev)
             d, k = i // (c + 1), i % (c + 1) - 1
             self.name_off.append(((d * c + k.clamp(min=0)) * self.ROUTE_NAME).contiguous())
-        total = sum(W * (c + 1) for c in self.rec_cap)
-        self.ivl = z(max(total, 1), 4, dt=torch.int32)                      # what the local join emits (global contig indices)
+        # what the local join emits (global contig indices): at most one interval per distinct name, i.e. <= every record that can
+        # arrive (the routed BAM buckets) + every PAF record the caller passes to join() beside them (`extra_records`)
+        total = sum(W * (c + 1) for c in self.rec_cap) + self.extra_records
+        self.ivl = z(max(total, 1), 4, dt=torch.int32)
         self.count = z(1, dt=torch.int32)
         self.send_ivl = z(W * (self.ivl_cap + 1), 4, dt=torch.int32)
         self.recv_ivl = z(W * (self.ivl_cap + 1), 4, dt=torch.int32)
@@ -353,6 +359,9 @@ class ShardedJoin:
         sit on the rank that owns their name is passed as it is).  -> (intervals int32 [W * (cap + 1), 4] on the contigs of THIS
         rank, contig = index in its track layout or -1 for an empty slot; their number of slots)."""
         F, W = self.n_files, self.world
+        rows = sum(int(i.recs.shape[0]) for i in inputs)
+        if rows > int(self.ivl.shape[0]):                 # (inputs the constructor was not told about: never emit past the array)
+            self.ivl = torch.zeros((rows, 4), dtype=torch.int32, device=self.device)
         self.ops.name_join(inputs, ovlp_percent, None, self.ivl, self.count, False, None, status=self.status[2 * F:2 * F + 1])
         self.ops.route_intervals(self.ivl, self.count, self.owner, W, self.ivl_cap, self.send_ivl, self.status[2 * F + 1:2 * F + 2])
         self._all_to_all(self.recv_ivl, self.send_ivl)
@@ -373,6 +382,10 @@ class ShardedJoin:
         what += ["gci_name_join", "gci_route_intervals", "gci_route_seal_intervals"]
         for w, name in zip(self.status.cpu().numpy().view(np.uint64).tolist(), what):
             decode(w, name)
+        n = int(self.count.cpu().reshape(-1)[0])          # the join counts what it could not store as well: never a silent loss
+        if n > int(self.ivl.shape[0]):
+            raise RuntimeError("ShardedJoin: the join emitted %d intervals into %d rows" % (n, int(self.ivl.shape[0])))
+
 
 
 # ---- PAF files sharded by byte range (the PAF half of filter(), /root/reference/GCI.py:211-254) ------------------------------

@@ -157,13 +157,6 @@ int gci_bam_filter(gci_ctx* ctx, const uint8_t* d_bam, uint64_t n_bytes, const u
                    uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
                    double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
                    uint64_t* d_status);
-/* The same filter over a HEADS STREAM (gci_bam_heads below): the BAM header followed by every record without its
- * SEQ and QUAL bytes (block_size shortened accordingly, l_seq unchanged) -- the bytes read_sam never looks at
- * (GCI.py:146-169), 98 % of a HiFi record.  Same outputs, same status word. */
-int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes, const uint64_t* d_rec_off,
-                         uint32_t n_rec, const int32_t* d_ref_sel, int32_t n_ref, int map_qual, int mq_cutoff,
-                         double clip_percent, double iden_percent, uint32_t rec_idx_base, gci_rec* d_out,
-                         uint64_t* d_status);
 /* ---- R1 over RECORD PAGES (round 3): the layout the record filter is fastest on --------------------------------
  * read_sam (GCI.py:146-169) looks at ~400 of a HiFi record's 27 000 bytes.  gci_bam_pages_size / _write copy exactly
  * those bytes -- once, on the device, as the last step of the ingestion that walks the inflated stream anyway -- into
@@ -180,7 +173,9 @@ int gci_bam_filter_heads(gci_ctx* ctx, const uint8_t* d_heads, uint64_t n_bytes,
  *            long-CIGAR records, kilobytes of tags); kind 4: a record the stream filter reports GCI_E_MALFORMED for.
  *   Record i goes to page floor(S_i / (page_bytes - GCI_PAGE_MAX_REC - 48)), S = exclusive scan of (size + 2).
  *
- * gci_bam_pages_size: d_stream / d_rec_off as for gci_bam_filter (has_seq != 0) or gci_bam_filter_heads (has_seq == 0);
+ * gci_bam_pages_size: d_stream / d_rec_off as for gci_bam_filter (has_seq != 0), or a HEADS STREAM (has_seq == 0: gci_bam_heads
+ *   below -- the BAM header followed by every record without its SEQ and QUAL bytes, block_size shortened accordingly, l_seq
+ *   unchanged: the bytes read_sam never looks at, GCI.py:146-169, are 98 % of a HiFi record);
  *   h_out[0] = n_pages, h_out[1] = bytes of the buffer to allocate, h_out[2] = offset of the blob.  Synchronises.
  * gci_bam_pages_write: fills d_out (cap >= h_out[1]) for the input the size call measured.
  * gci_bam_filter_pages: the filter over such a buffer -- same records, same status word as gci_bam_filter over the
@@ -371,7 +366,7 @@ int gci_fasta_n_scan(gci_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, cons
  *                            member table, and the record offsets of one chunk with the partial tail reported
  *   gci_bam_heads            BGZF file bytes -> heads stream + record offsets in one pipelined pass (replaces
  *                            pysam's AlignmentFile + fetch, GCI.py:150-151, for a host that feeds
- *                            gci_bam_filter_heads): groups of `group_bytes` (0 = 16 MiB) of inflated members rotate
+ *                            gci_bam_pages_* with has_seq = 0): groups of `group_bytes` (0 = 16 MiB) of inflated members rotate
  *                            through three buffers -- worker threads inflate group g while the caller's thread walks
  *                            the block_size chain of group g-1 and the workers copy the heads of group g-2 -- so the
  *                            inflated stream (27 KB per HiFi record) never exists as a whole and only ~400 B per

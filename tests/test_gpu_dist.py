@@ -113,3 +113,55 @@ def test_bench_two_ranks_against_the_oracle(scaling, shared, tmp_path):
         assert "sharded by name hash" in out["config"]["join"]
     else:
         assert ("replicated" in out["config"]["join"]) == (shared > 0)
+
+
+# ---- RCCL itself: the branch an 8-GPU node takes, executed on ONE GPU over a world of one ------------------
+# Two ranks cannot share a device under RCCL, so everything above stages its collectives through host memory (gloo).  These
+# run the nccl branch for real: device tensors straight into all_to_all_single / all_reduce / all_gather_into_tensor on an RCCL
+# communicator of world size 1 -- dtype, contiguity, divisibility and stream ordering against the library's kernels are those
+# of N = 8.
+
+def _run_one_rank_rccl(script_argv, port, extra_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **(extra_env or {}))
+    env.pop("GCI_DIST_DEVICE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_argv
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("mode", ["sharded", "exchange", "replicated"])
+def test_bench_step_over_rccl_world_of_one(mode):
+    """bench.py's multi-GPU step with --backend nccl: the name-hash-sharded join (2 F + 1 all-to-alls + the all-reduce), the
+    round-2 name check (hash all-to-all + all-reduce) and the replicated join (all-gathers) -- each checked against the oracle."""
+    import json
+    flag = {"sharded": ["--force-sharded"], "exchange": ["--force-exchange"], "replicated": ["--force-exchange", "--force-replicated"]}[mode]
+    r = _run_one_rank_rccl([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scale", "0.01",
+                            "--backend", "nccl", "--verify-oracle"] + flag + (["--scaling", "weak"] if mode != "sharded" else []),
+                           29770 + len(mode))
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["parity_vs_oracle_all_ranks"] is True
+    assert out["config"]["collectives"]["backend"] == "nccl"
+    if mode == "sharded":
+        assert "sharded by name hash" in out["config"]["join"]
+    if mode == "replicated":
+        assert "replicated" in out["config"]["join"]
+
+
+@pytest.mark.parametrize("k,case", list(enumerate(["c3_two_bam", "c5_two_type"])))
+def test_command_line_over_rccl_world_of_one(k, case, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1 GCI.py ...` with GCI_FORCE_SHARDED=1 and the default backend (nccl =
+    RCCL): the contig-sharded command line -- index-driven ingestion, PAF by byte range, ShardedJoin, the gathers to rank 0, the
+    all-reduces -- writes the reference's files and transcript."""
+    out = str(tmp_path / "out")
+    argv = cli_args(case, out)
+    r = _run_one_rank_rccl([os.path.join(ROOT, "GCI.py")] + argv[1:], 29780 + k, {"GCI_FORCE_SHARDED": "1", "GCI_DIST_BACKEND": "nccl"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    got, want = read_outputs(out), expected(case)
+    assert sorted(got) == sorted(want)
+    for fn in want:
+        assert got[fn] == want[fn], fn
+    first, _, rest = r.stdout.partition("\n")
+    assert first.startswith("Used arguments:{")
+    inp = os.path.join(GOLDEN, case, "inputs")
+    assert rest.replace(out, "{OUT}").replace(inp, "{IN}") == manifest(case)["stdout"]

@@ -35,9 +35,12 @@ def test_genome_dual_bam_full_path_matches_oracle(engine, oracle, genome, join_m
     ref_sel = engine.to_device(np.arange(len(names), dtype=np.int32))
     ins = []
     for f in inp.files:
+        # what the command line and bench.py run: record pages made on the device from the heads stream, the paged filter
         d_s, d_o = engine.to_device(f.stream), engine.to_device(f.offsets)
-        recs = engine.bam_filter(d_s, d_o, ref_sel, *FILTER, heads=True)
-        ins.append(JoinInput(recs, d_s, d_o, 36))
+        pages = engine.bam_pages(d_s, d_o, False)
+        del d_s, d_o
+        recs, noff = engine.bam_filter_pages(pages, ref_sel, *FILTER)
+        ins.append(JoinInput(recs, pages.buf, noff, 0))
     ivl, cnt = engine.name_join(ins, OVLP, count_flank=FLANK)
     track = engine.new_track()
     fused = engine.depth_build_fused(ivl, cnt, FLANK, track, want_text=True, want_sums=True, issue=(-1.0, 0.0, FLANK),

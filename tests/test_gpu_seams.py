@@ -31,10 +31,7 @@ def _filter_case(engine, oracle, rs, targets=None, mq=30, cut=50, cp=0.1, ip=0.9
     # the same records without their SEQ / QUAL bytes (what the command line uploads): the same 32 bytes per record
     from gci_amd.formats import bam
     h_bytes, h_offs = heads_expected(stream, offs, bam.parse_header(stream).first_record)
-    via_heads = engine.bam_filter(engine.to_device(np.frombuffer(h_bytes, dtype=np.uint8)), engine.to_device(h_offs),
-                                  engine.to_device(ref_sel), mq, cut, cp, ip, heads=True)
-    assert torch.equal(via_heads, full)
-    # ... and as record pages (gci_bam_pages_*, gci_bam_filter_pages), made from either stream
+    # ... as record pages (gci_bam_pages_*, gci_bam_filter_pages), made from either stream
     _via_pages(engine, d_bam, d_off, True, ref_sel, mq, cut, cp, ip, full, stream)
     h_np = np.frombuffer(h_bytes, dtype=np.uint8)
     _via_pages(engine, engine.to_device(h_np), engine.to_device(h_offs), False, ref_sel, mq, cut, cp, ip, full, h_np, page_bytes=8192)
@@ -660,20 +657,17 @@ def test_bam_filter_randomised_records(engine, oracle, seed):
                 assert g.value.status == e.status, (e.status, g.value.status)
                 # the GPU reports the FIRST failing record in file order, like the oracle's loop
                 assert g.value.rec == e.rec
-                with pytest.raises(GciErr) as gh:                       # the same through the heads stream
-                    engine.bam_filter(d_heads, engine.to_device(h_offs[keep]), engine.to_device(ref_sel), 30, 50, cp, ip,
-                                      heads=True)
+                with pytest.raises(GciErr) as gh:                       # the same through the pages of the heads stream
+                    engine.bam_filter_pages(engine.bam_pages(d_heads, engine.to_device(h_offs[keep]), False), engine.to_device(ref_sel),
+                                            30, 50, cp, ip)
                 assert (gh.value.status, gh.value.rec) == (e.status, e.rec)
-                with pytest.raises(GciErr) as gp:                       # ... and through record pages
+                with pytest.raises(GciErr) as gp:                       # ... and through those of the whole stream
                     engine.bam_filter_pages(engine.bam_pages(d_bam, engine.to_device(o_sub), True), engine.to_device(ref_sel), 30, 50, cp, ip)
                 assert (gp.value.status, gp.value.rec) == (e.status, e.rec)
                 keep[np.flatnonzero(keep)[e.rec]] = False
                 n_checked += 1
         full = engine.bam_filter(d_bam, engine.to_device(o_sub), engine.to_device(ref_sel), 30, 50, cp, ip).clone()
         got = _recs_np(full)
-        via_heads = engine.bam_filter(d_heads, engine.to_device(h_offs[keep]), engine.to_device(ref_sel), 30, 50, cp, ip,
-                                      heads=True)
-        assert torch.equal(via_heads, full)                              # records without SEQ / QUAL: same 32 bytes out
         h_np = np.frombuffer(h_bytes, dtype=np.uint8)
         for pb in (8192, 16384, 32768):                                   # record pages of every size, from either stream
             _via_pages(engine, d_bam, engine.to_device(o_sub), True, ref_sel, 30, 50, cp, ip, full, stream, page_bytes=pb)
@@ -895,3 +889,42 @@ def test_depth_gz_skips_zero_length_contigs(engine, tmp_path):
     pipeline.write_depth(str(tmp_path), "z", tr, 1)
     text = gzip.open(str(tmp_path / "z.depth.gz"), "rb").read()
     assert text == b">a\n" + b"0\n" * 5000 + b">b\n" + b"0\n" * 4100
+
+
+def test_paged_filter_of_tag_heavy_records(engine, oracle):
+    """A file in which EVERY record carries ~800 bytes of tags behind a CIGAR of some 60 operations (HiFi with MD / cs / SA): none
+    fits a page record, so each one keeps its CIGAR in the blob in a piece of 240 bytes and every passing one goes through the
+    chunk queue -- whose capacity round 3 derived from blob bytes / 512 and refused such a file (GCI_E_CAPACITY)."""
+    from gci_amd.formats import bam
+    rng = np.random.default_rng(77)
+    refs = [("t0", 4_000_000), ("t1", 1_000_000)]
+    recs = []
+    for i in range(6000):
+        ops = []
+        for k in range(int(rng.integers(40, 100))):
+            ops.append((7, int(rng.integers(100, 400))) if k % 2 == 0 else (int(rng.choice([1, 2, 8])), int(rng.integers(1, 3))))
+        if rng.random() < 0.1:
+            ops.insert(0, (4, int(rng.integers(10, 4000))))
+        qlen = sum(l for o, l in ops if (bam.QUERY_CONSUMING >> o) & 1)
+        nm = sum(l for o, l in ops if o in (1, 2, 8))
+        tags = [("NM", "i", nm), ("MD", "Z", "A7" * int(rng.integers(150, 250))), ("cs", "Z", ":9*ag" * int(rng.integers(60, 90))),
+                ("SA", "Z", "t1,100,+,50S900M,60,3;")]
+        if i % 50 == 0:
+            tags = tags[1:] + tags[:1]                 # NM behind the long tags
+        recs.append(bam.encode_record(int(rng.integers(0, 2)), int(rng.integers(0, 900_000)), "tagged/%d/ccs" % i,
+                                      int(rng.choice([60, 60, 60, 20])), int(rng.choice([0, 16, 0x800])), ops, qlen, bam.encode_aux(tags)))
+    hdr = bam.encode_header([r for r, _ in refs], [l for _, l in refs])
+    stream = np.frombuffer(hdr + b"".join(recs), dtype=np.uint8).copy()
+    offs = bam.record_offsets(stream, bam.parse_header(stream).first_record)
+    ref_sel = np.array([0, 1], np.int32)
+    want = oracle.bam_filter_arrays(stream, offs, ref_sel, 30, 50, 0.1, 0.9)
+    d_bam, d_off = engine.to_device(stream), engine.to_device(offs)
+    full = engine.bam_filter(d_bam, d_off, engine.to_device(ref_sel), 30, 50, 0.1, 0.9).clone()
+    pages = _via_pages(engine, d_bam, d_off, True, ref_sel, 30, 50, 0.1, 0.9, full, stream)
+    blob = int(pages.buf.shape[0]) - pages.blob_off - 16
+    assert 0 < blob < 6000 * 512                       # the bound of round 3 (blob / 512 items) would have been < the records queued
+    got = _recs_np(full)
+    p = want["passed"].astype(bool)
+    assert np.array_equal((got["flags"] & 1).astype(bool), p) and p.sum() > 3000
+    for f in ("contig", "start", "end", "qlen"):
+        assert np.array_equal(got[f][p], want[f][p]), f
