@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip numbers (2) and (3) of SURVEY.md 8(d): the device pipeline incl. H2D / D2H and the "
                          "command-line wall time on a chr19 BAM with realistic SEQ / QUAL entropy")
+    ap.add_argument("--no-cli-genome", action="store_true",
+                    help="genome workload: skip survey_8d.3_command_line_genome (the command line as a process of its own on the two "
+                         "genome-size BGZF files: ~130 GB written to tmpfs first, minutes of host-side deflate)")
     ap.add_argument("--ingest-gb", type=float, default=64.0,
                     help="survey_8d.3b: GB of realistic-entropy BGZF streamed from host RAM through the command line's ingestion "
                          "(0: skip)")
@@ -662,6 +665,7 @@ def parity_genome(w, chosen=("chr14", "chr22", "chrM")):
     a = np.clip(iv[:, 1] + FLANK, 0, Ls)
     b = np.clip(iv[:, 2] - FLANK + 1, 0, Ls)
     ok = ok and int(np.maximum(b - a, 0).sum()) == int(sums.sum())
+    w.oracle_on_chosen = {"depths": depths, "bed": bed, "lengths": tl}      # (cli_genome_number holds the command line's files against it)
     return bool(ok), chosen
 
 
@@ -1106,6 +1110,103 @@ def cli_number(coverage):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def cli_genome_number(inp, oracle_on_chosen, verbose=True):
+    """(3) at the size the metric is quoted on: `python GCI.py -r chm13.fa --hifi a.bam b.bam` as a process of its own on the
+    two 40x whole-genome BGZF BAM files of the resident workload (the same records as the timed step, written back as the files
+    they came from: every record with SEQ / QUAL bytes of realistic entropy, deflated at level 1 in htslib's block geometry --
+    workloads.write_bgzf_from_heads) and the 3.1 GB assembly, all on tmpfs (a warm page cache).  Wall time of the process, the
+    per-phase split it logs (GCI_PHASES), and the files it wrote -- .depth.gz, .bed, .gci -- against the oracle on the contigs of
+    `oracle_on_chosen` (parity_genome's)."""
+    import gzip
+    import shutil
+    import subprocess
+    import tempfile
+    from gci_amd import hostio, synth, workloads
+    from oracle import gci_oracle as O
+    need = 0
+    for f in inp.files:
+        o = f.offsets.astype(np.int64)
+        l_seq = f.stream[(o[:, None] + np.arange(20, 24)[None, :])].copy().view("<i4").reshape(-1).astype(np.int64)
+        need += int((int(f.stream.shape[0]) + int(((l_seq + 1) // 2 + l_seq).sum())) / 2.2)
+    need += int(sum(inp.lengths) * 1.02) + (2 << 30)
+    base = None
+    for d in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if shutil.disk_usage(d).free > need * 1.1:
+                base = d
+                break
+        except OSError:
+            pass
+    mem = workloads._memory_budget_gb() * 1e9
+    if base is None or (base == "/dev/shm" and mem < need * 1.25 + 40e9):
+        return {"skipped": "needs %.0f GB of file space (tmpfs counts as memory: %.0f GB may still be taken)" % (need / 1e9, mem / 1e9)}
+    tmp = tempfile.mkdtemp(prefix="gci_cli_genome_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        bams, made = [], []
+        for k, f in enumerate(inp.files):
+            p = os.path.join(tmp, "hifi_aligner%d.bam" % (k + 1))
+            made.append(workloads.write_bgzf_from_heads(p, f.stream, f.offsets, seed=20250919 + k, verbose=verbose))
+            bams.append(p)
+        fa = os.path.join(tmp, "chm13.fa")
+        synth.write_reference_fasta(fa, inp.contigs)
+        t_gen = time.perf_counter() - t0
+        od, ph = os.path.join(tmp, "out"), os.path.join(tmp, "phases.json")
+        env = dict(os.environ, GCI_PHASES=ph, PYTHONPATH=ROOT)
+        cmd = [sys.executable, os.path.join(ROOT, "GCI.py"), "-r", fa, "--hifi"] + bams + ["-d", od, "-t", str(hostio.default_threads())]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "GCI.py exited with %d: %s" % (r.returncode, r.stderr[-1500:])}
+        rep = json.load(open(ph))
+        # ---- the files against the oracle, on whole contigs
+        chosen = list(oracle_on_chosen["depths"])
+        layout = [v for k, v in rep["notes"].items() if k.startswith("depth_gz_layout:")][0]
+        ok = sorted(layout) == sorted(n for n, l in inp.contigs if l > 0)
+        with open(os.path.join(od, "GCI.depth.gz"), "rb") as f:
+            for c in chosen:
+                a, b = layout[c]
+                f.seek(a)
+                got = gzip.decompress(f.read(b - a))
+                ok = ok and got == (">%s\n" % c).encode() + O.depth_text_contig(oracle_on_chosen["depths"][c])
+                del got
+        bed_lines = {}
+        for line in open(os.path.join(od, "GCI.0.depth.bed")):
+            bed_lines.setdefault(line.split("\t", 1)[0], []).append(line)
+        for c in chosen:
+            ok = ok and "".join(bed_lines.get(c, [])) == O.bed_text({c: oracle_on_chosen["bed"][c]})
+        tl = oracle_on_chosen["lengths"]
+        want_rows = {}
+        for c in chosen:                                       # a contig's row of the .gci depends on that contig alone
+            text = O.compute_index_text({c: tl[c]}, [{c: oracle_on_chosen["bed"][c]}], ["HiFi"], FLANK, 0.005)[0]
+            want_rows[c] = [l for l in text.split("\n") if l.startswith(c + "\t")]
+        got_rows = {}
+        for line in open(os.path.join(od, "GCI.gci")).read().split("\n"):
+            got_rows.setdefault(line.split("\t", 1)[0], []).append(line)
+        for c in chosen:
+            ok = ok and got_rows.get(c) == want_rows[c] and len(want_rows[c]) == 1
+        outputs = {fn: os.path.getsize(os.path.join(od, fn)) for fn in sorted(os.listdir(od))}
+        aligned = inp.aligned_bases
+        serial = ("per file: the member table (host threads, then nothing of the file is on the device before it is done); per run of "
+                  "members: the wait for its upload when the link is behind; after the last byte of the last file: join -> depth "
+                  "build -> .depth.gz members -> D2H -> file writes; the FASTA is read and scanned before the first BAM byte moves")
+        return {"seconds": wall, "gbases_per_s": aligned / wall / 1e9, "process": "python GCI.py (a process of its own: interpreter, "
+                "import torch, HIP context and library load are inside the wall time)",
+                "startup_seconds_outside_the_phase_log": wall - rep["total_s"],
+                "phases_wall_s": {k: round(v, 4) for k, v in rep["wall_s"].items()},
+                "phases_device_s": {k: round(v, 4) for k, v in rep["gpu_s"].items()},
+                "bgzf_bytes": rep["notes"].get("bgzf_bytes"), "inflated_bytes": rep["notes"].get("inflated_bytes"),
+                "bgzf_members": rep["notes"].get("bgzf_members"),
+                "deflate_ratio": rep["notes"].get("inflated_bytes", 0) / max(1, rep["notes"].get("bgzf_bytes", 1)),
+                "files": "two 40x HiFi BGZF BAMs (%s bytes) + %d-byte FASTA on %s (warm page cache)" % (
+                    " + ".join(str(m["bytes"]) for m in made), os.path.getsize(fa), base),
+                "outputs_bytes": outputs, "parity_vs_oracle_on_contigs": chosen, "parity": bool(ok),
+                "input_generation_seconds": t_gen, "serial_in_it": serial, "host_threads": hostio.default_threads()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     import torch
@@ -1340,7 +1441,15 @@ def main():
                     "port_over_reference": ratio}
             else:
                 out["cpu_baseline"] = None
-            w.inp = None
+            if not args.no_e2e and not args.no_cli_genome and args.reads == "hifi":
+                inp, orc = w.inp, w.oracle_on_chosen
+                survey["3_command_line_genome"] = cli_genome_number(inp, orc)
+                if survey["3_command_line_genome"].get("parity") is False:
+                    out["survey_8d"] = survey
+                    print(json.dumps(out))
+                    sys.exit("PARITY FAILURE: the command line's files differ from the oracle at genome size")
+                del inp, orc
+            w.inp = w.oracle_on_chosen = None
             if not args.no_e2e:
                 survey["3_command_line_chr19_realistic_bam"] = cli_number(args.coverage)
                 if args.ingest_gb > 0:

@@ -18,7 +18,7 @@ import sys
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
-from . import pipeline
+from . import phases, pipeline
 from .plot import plot_depth
 from .formats import bam as bamfmt
 from .formats import fasta
@@ -161,15 +161,18 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         _usable_directory(f"{directory}/images")
         image_type = image_type.lower()
 
-    ref_ids = fasta.record_ids_indexed(reference)
+    with phases.wall("fasta_read_and_title_index"):
+        ref_ids = fasta.record_ids_indexed(reference)
     _check_names(ref_ids, chrs_list, regions_bed)
     kinds = [ReadType("HiFi", "HiFi", "_hifi", "hifi", hifi), ReadType("ONT", "Nano", "_nano", "ont", nano)]
-    for kind in kinds:
-        if kind.given:
-            kind.read_headers(ref_ids)
+    with phases.wall("bam_headers"):
+        for kind in kinds:
+            if kind.given:
+                kind.read_headers(ref_ids)
 
     print("Finding gaps ...")
-    Ns_bed, Ns_bed_file = pipeline.get_Ns_ref(reference, prefix, directory, force)
+    with phases.wall("fasta_n_scan_upload_and_kernel"):
+        Ns_bed, Ns_bed_file = pipeline.get_Ns_ref(reference, prefix, directory, force)
     if Ns_bed_file is not None:
         print(f"Finding gaps done!!! The gaps are in {Ns_bed_file}\n\n")
     else:
@@ -194,10 +197,12 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
     targets_length = None
     for kind in given:                                               # filter + gap mask per read type (GCI.py:991-1016)
         pfx = prefix + kind.suffix if both else prefix
-        depths, targets_length = pipeline.filter(kind.pafs, kind.bams, pfx, map_qual, mq_cutoff, iden_percent, clip_percent,
-                                                 ovlp_percent, flank_len, directory, force, kind.log_name, chrs_list, threads,
-                                                 issue_hint=hint)
-        tracks.append(pipeline.merge_gaps_depths(depths, Ns_bed))
+        with phases.wall("filter[%s]" % kind.log_name):
+            depths, targets_length = pipeline.filter(kind.pafs, kind.bams, pfx, map_qual, mq_cutoff, iden_percent, clip_percent,
+                                                     ovlp_percent, flank_len, directory, force, kind.log_name, chrs_list, threads,
+                                                     issue_hint=hint)
+        with phases.wall("merge_gaps_depths"):
+            tracks.append(pipeline.merge_gaps_depths(depths, Ns_bed))
         prefixes.append(pfx)
         logs.append(kind.log_name)
         labels.append(kind.index_name)
@@ -208,9 +213,11 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         prefixes.append(prefix + "_two_type")
         logs.append("two_types")
         labels.append("HiFi + Nano")
-    beds = [pipeline.merge_depth(t, p, threshold, flank_len, directory, force, log) for t, p, log in zip(tracks, prefixes, logs)]
-    pipeline.compute_index(targets_length, prefix, directory, force, beds, labels, flank_len, dist_percent, regions_bed, tracks,
-                           threshold, chrs_list)
+    with phases.wall("merge_depth_bed"):
+        beds = [pipeline.merge_depth(t, p, threshold, flank_len, directory, force, log) for t, p, log in zip(tracks, prefixes, logs)]
+    with phases.wall("compute_index_gci"):
+        pipeline.compute_index(targets_length, prefix, directory, force, beds, labels, flank_len, dist_percent, regions_bed, tracks,
+                               threshold, chrs_list)
     if plot:
         plot_depth(plotted, depth_min, depth_max, window_size, image_type, directory, prefix, force, targets_length,
                    dist_percent, regions_bed, threshold)
@@ -296,6 +303,16 @@ def _main_single(argv, ctx):
               f'({args["mq_cutoff"]}), which means that wouldn\'t filter any reads\n' + HELP_HINT,
               file=sys.stderr if ctx is None or ctx.root else open(os.devnull, "w"))
     print(f"Used arguments:{args}")
+    phase_file = phases.env_start()                   # GCI_PHASES=<file.json>: where the run spends its time (nothing is printed)
+    try:
+        _run(args, ctx)
+    finally:
+        if phase_file and (ctx is None or ctx.root):
+            phases.report(phase_file)
+            phases.stop()
+
+
+def _run(args, ctx):
     if ctx is not None:
         import torch.distributed as dist
         ctx.init()

@@ -72,9 +72,6 @@ struct alignas(16) Canon { uint16_t limit[16]; int16_t off[16]; uint16_t next[16
 #ifndef INF_DIST_BITS
 #define INF_DIST_BITS 5                // 0: distances through the 15 limits only (rounds 2 - 3a); 5: -2 %; 6 and 7 cost a workgroup per CU
 #endif
-#ifndef INF_HOT_LOOP
-#define INF_HOT_LOOP 0                // the one-exit literal loop: 42 instead of 54 instructions per literal, and 4 % SLOWER (r03z)
-#endif
 struct alignas(16) LaneTabs {
     union {
         uint16_t lit_tab[1 << LIT_BITS];
@@ -209,11 +206,20 @@ __device__ __forceinline__ int decode(Bits& B, const uint16_t* table, const Cano
 }  // namespace
 
 // One lane = one member; INF_LANES members per workgroup (one wave; its other lanes leave at once).
-template <int INF_LANES>
+//
+// TOKENS (round 4: the two-phase inflate).  With the copies in it, the lanes of a wave spend their time apart: one walks a
+// literal run while its neighbours wait for the store -> load round trips of their matches (~0.4 us each), so more than 8
+// members per wave only added waiting.  With TOKENS the kernel DECODES only: a match leaves a 3-byte token at the place of its
+// first three bytes -- length - 3, distance - 1 (15 bits): a match is at least three bytes long, so the token always fits --
+// and one bit in `bitmap` (one bit per output byte, a member's words start at word (o0 >> 6) + m), and nothing is read back.
+// k_bgzf_copy then resolves the matches: one lane per member again, but no tables, no LDS, every lane of every wave busy and
+// ten thousand waves in flight to cover the round trips.
+template <int INF_LANES, bool TOKENS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF_WAVES, INF_WAVES)))
 void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
                     const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
-                    uint64_t out_cap, unsigned long long* __restrict__ status, uint16_t* __restrict__ sorted_scratch)
+                    uint64_t out_cap, unsigned long long* __restrict__ status, uint16_t* __restrict__ sorted_scratch,
+                    unsigned long long* __restrict__ bitmap)
 {
     __shared__ LaneTabs tabs[INF_LANES];
     const int lane = threadIdx.x;
@@ -271,6 +277,14 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
         oc++; op++;
         if (oc == 8) { st8(dst + op - 8, ob); ob = 0; oc = 0; }
     };
+    // TOKENS: the bits of the 64 output positions [64 bw, 64 bw + 64) gather in `bm`; a word is stored when the output moves past it
+    unsigned long long bm = 0;
+    uint32_t bw = 0;
+    unsigned long long* const bmw = TOKENS ? bitmap + (o0 >> 6) + m : nullptr;
+    auto mark = [&](uint32_t at) __attribute__((always_inline)) {          // a match starts at output position `at` (>= 64 bw)
+        while ((at >> 6) != bw) { bmw[bw] = bm; bm = 0; bw++; }
+        bm |= 1ull << (at & 63u);
+    };
     for (bool last = false; !last && !bad;) {
         // every block header must lie inside the payload (a damaged stream of empty non-final blocks would never end otherwise:
         // everything else in a block is bounded by the member's output length)
@@ -324,30 +338,6 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
         // ---- symbols of the block: runs of literals (the lanes of the wave meet again at their next match) -------------------
         for (;;) {
             int sym;
-#if INF_HOT_LOOP
-            // An experiment that stays in the source, off: a loop with ONE way out for the literals whose code the primary table
-            // holds (the compiler's bookkeeping for several exits is half of the 54 instructions a literal costs in the loop
-            // below; this one has 42) -- measured 77.6 ms against 74.5: the lanes that leave for a long code now wait for the
-            // others' literal runs twice.
-            for (;;) {
-                uint32_t e;
-                bool go;
-                do {
-                    need32(B);
-                    e = T.lit_tab[(uint32_t)B.bb & ((1u << LIT_BITS) - 1u)];       // symbol | length << 9; 0: a longer code
-                    go = (e != 0u) & ((e & 0x100u) == 0u) & (op < isize);        // a literal the table knows, and room for it
-                    const int l = go ? (int)(e >> 9) : 0;
-                    B.bb >>= l; B.bn -= l;
-                    if (go) emit(e & 0xFFu);
-                } while (go);
-                asm volatile("" : "+v"(e));                                       // (the reason for leaving is read off e below, not kept in masks)
-                if (e != 0u && !(e & 0x100u)) { sym = -1; break; }                // a literal with the output full
-                sym = decode<LIT_BITS, 15>(B, T.lit_tab, T.lit_cn, lit_sorted);   // (32 bits are valid: nothing was taken since need32)
-                if (sym < 0 || sym >= 256) break;
-                if (op >= isize) { sym = -1; break; }
-                emit((uint32_t)sym);
-            }
-#else
             for (;;) {
                 need32(B);
                 sym = decode<LIT_BITS, 15>(B, T.lit_tab, T.lit_cn, lit_sorted);
@@ -355,7 +345,6 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
                 if (op >= isize) { sym = -1; break; }
                 emit((uint32_t)sym);
             }
-#endif
             if (sym < 0 || sym > 285) { bad = true; break; }
             if (sym == 256) break;
             // length and distance codes (RFC 1951 3.2.5) by arithmetic: a table in constant memory is a vector-memory load
@@ -374,6 +363,15 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
             const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
             const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
             if (dist > op || op + len > isize) { bad = true; break; }
+            if (TOKENS) {
+                // the token takes the place of the match's first three bytes and travels with the literals
+                mark(op);
+                const uint32_t d1 = dist - 1u;
+                emit(len - 3u); emit(d1 & 0xFFu); emit(d1 >> 8);
+                flush();
+                op += len - 3u;
+                continue;
+            }
             // the copy reads this member's own output back from memory (a lane's stores and loads stay in order)
             flush();
             const uint8_t* src = dst + op - dist;
@@ -419,12 +417,88 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
         }
     }
     flush();
+    if (TOKENS && !bad) {                                                       // the rest of the member's bitmap words
+        const uint32_t nw = (isize + 63u) >> 6;
+        while (bw < nw) { bmw[bw] = bm; bm = 0; bw++; }
+    }
     if (!bad && op != isize) bad = true;
     if (!bad) {                                                                // the stream may not run past the payload
         const long long bits = 32ll * B.taken - 8ll * head - B.bn;
         if (bits > 8ll * pay_len) bad = true;
     }
     if (bad) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
+}
+
+// Phase 2 of the two-phase inflate: the matches k_bgzf_inflate<., true> left as tokens, resolved in order by one lane per
+// member.  The output buffer is the window: a lane's stores and loads stay in order, so a match reads what the matches before
+// it wrote.  No tables, no LDS, 64 members per wave: what hides the two round trips per match is the number of waves in flight.
+// Every token is checked against the member's bounds (a member the decoder gave up on leaves arbitrary words behind).
+__global__ __launch_bounds__(256) void k_bgzf_copy(const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
+                                                   const unsigned long long* __restrict__ bitmap)
+{
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= n_members) return;
+    const uint64_t o0 = out_off[m];
+    const uint32_t isize = (uint32_t)(out_off[m + 1] - o0);
+    if (isize > 65536u) return;
+    uint8_t* const dst = out + o0;
+    const unsigned long long* const bmw = bitmap + (o0 >> 6) + m;
+    const uint32_t nw = (isize + 63u) >> 6;
+    // exactly n (1 .. 8) bytes: what lies behind a match is final already (the literals and tokens of phase 1)
+    auto store_n = [](uint8_t* t, unsigned long long v, uint32_t n) __attribute__((always_inline)) {
+        if (n >= 8u) { st8(t, v); return; }
+        if (n & 4u) { const uint32_t x = (uint32_t)v; __builtin_memcpy(t, &x, 4); t += 4; v >>= 32; }
+        if (n & 2u) { const uint16_t x = (uint16_t)v; __builtin_memcpy(t, &x, 2); t += 2; v >>= 16; }
+        if (n & 1u) *t = (uint8_t)v;
+    };
+    unsigned long long w_next = nw ? bmw[0] : 0ull;
+    for (uint32_t wi = 0; wi < nw; wi++) {
+        unsigned long long w = w_next;
+        w_next = wi + 1 < nw ? bmw[wi + 1] : 0ull;
+        while (w) {
+            const uint32_t pos = wi * 64u + (uint32_t)__builtin_ctzll(w);
+            w &= w - 1ull;
+            if (pos + 3u > isize) break;
+            uint8_t* to = dst + pos;
+            const uint32_t t0 = to[0], t1 = to[1], t2 = to[2];
+            uint32_t len = t0 + 3u;
+            const uint32_t dist = (t1 | (t2 << 8)) + 1u;
+            if (dist > pos || pos + len > isize) continue;
+            const uint8_t* src = to - dist;
+            if (dist >= 8) {
+                // up to four 8-byte pieces per round trip: as many as lie wholly in front of what the round itself writes
+                while (len) {
+                    const uint32_t nb = min(min(4u, dist >> 3), (len + 7u) >> 3);
+                    unsigned long long v[4];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) v[i] = i < nb ? ld8(src + 8 * i) : 0ull;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++)
+                        if (i < nb) store_n(to + 8 * i, v[i], min(8u, len - 8u * i));
+                    const uint32_t adv = min(len, 8u * nb);
+                    src += adv; to += adv; len -= adv;
+                }
+            } else {
+                // a short period: its bytes once, made periodic over eight bytes, stored in steps of whole periods
+                unsigned long long pat = 0;
+                if (pos >= 8) pat = ld8(to - 8) >> (8 * (8 - dist));
+                else {
+#pragma unroll
+                    for (int i = 0; i < 7; i++) pat |= (unsigned long long)((uint32_t)i < dist ? src[i] : (uint8_t)0) << (8 * i);
+                }
+                pat &= ~0ull >> (8 * (8 - dist));
+                if (dist < 8) pat |= pat << (8 * dist);
+                if (dist < 4) pat |= pat << (16 * dist);
+                if (dist < 2) pat |= pat << 32;
+                const uint32_t step = dist * (8u / dist);
+                while (len) {
+                    const uint32_t adv = min(len, step);
+                    store_n(to, pat, adv);
+                    to += adv; len -= adv;
+                }
+            }
+        }
+    }
 }
 
 // CRC-32 of every member's output against its trailer: one wave per member.
@@ -490,21 +564,39 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
     if (n_members) {
         // members per wave: fewer = more waves per SIMD to overlap the memory round trips, more = fewer instructions issued
-        static const int lanes = [] { const char* e = getenv("GCI_INFLATE_LANES"); return e ? atoi(e) : 8; }();
+        static const int lanes = [] { const char* e = getenv("GCI_INFLATE_LANES"); return e ? atoi(e) : 0; }();   // 0: the mode's default
         uint16_t* sorted_scratch = nullptr;
 #if INF_SORTED_GLOBAL
         GCI_TRY(gci_ensure(ctx, ctx->inflate_sorted, (size_t)n_members * 288 * 2));
         sorted_scratch = (uint16_t*)ctx->inflate_sorted.p;
 #endif
+        // GCI_INFLATE_PHASES=1: the round-2 / 3 kernel (decode and copy in one); 2 (default): decode to tokens, then k_bgzf_copy
+        static const int phases = [] { const char* e = getenv("GCI_INFLATE_PHASES"); return e ? atoi(e) : 2; }();
+        unsigned long long* bitmap = nullptr;
+        if (phases == 2) {
+            GCI_TRY(gci_ensure(ctx, ctx->inflate_bitmap, ((size_t)(out_cap >> 6) + n_members + 2) * 8));
+            bitmap = (unsigned long long*)ctx->inflate_bitmap.p;
+        }
         auto launch = [&](auto kern, int per) {
             hipLaunchKernelGGL(kern, dim3((n_members + per - 1) / per), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, n_members,
-                               d_out, out_cap, (unsigned long long*)d_status, sorted_scratch);
+                               d_out, out_cap, (unsigned long long*)d_status, sorted_scratch, bitmap);
         };
-        if (lanes == 4) launch(k_bgzf_inflate<4>, 4);
-        else if (lanes == 16) launch(k_bgzf_inflate<16>, 16);
-        else if (lanes == 32) launch(k_bgzf_inflate<32>, 32);
-        else launch(k_bgzf_inflate<8>, 8);
-        LAUNCHCHK("k_bgzf_inflate");
+        if (phases == 2) {
+            if (lanes == 8) launch(k_bgzf_inflate<8, true>, 8);
+            else if (lanes == 32) launch(k_bgzf_inflate<32, true>, 32);
+            else if (lanes == 64) launch(k_bgzf_inflate<64, true>, 64);
+            else launch(k_bgzf_inflate<16, true>, 16);
+            LAUNCHCHK("k_bgzf_inflate<tokens>");
+            hipLaunchKernelGGL(k_bgzf_copy, dim3((n_members + 255) / 256), dim3(256), 0, ctx->stream, d_out_off, n_members, d_out,
+                               (const unsigned long long*)bitmap);
+            LAUNCHCHK("k_bgzf_copy");
+        } else {
+            if (lanes == 4) launch(k_bgzf_inflate<4, false>, 4);
+            else if (lanes == 16) launch(k_bgzf_inflate<16, false>, 16);
+            else if (lanes == 32) launch(k_bgzf_inflate<32, false>, 32);
+            else launch(k_bgzf_inflate<8, false>, 8);
+            LAUNCHCHK("k_bgzf_inflate");
+        }
         if (check_crc) {
             hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, ctx->stream, d_raw, d_member_pos,
                                d_out_off, n_members, (const uint8_t*)d_out, (unsigned long long*)d_status);
@@ -524,8 +616,26 @@ extern "C" uint32_t gci_bgzf_inflate_round(gci_ctx* ctx)
     int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8>, 64, 0) != hipSuccess) return 0;
-    return (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu * 8 : 0);
+    const char* e = getenv("GCI_INFLATE_PHASES");
+    const char* l = getenv("GCI_INFLATE_LANES");
+    const int two = !e || atoi(e) == 2, lanes = l ? atoi(l) : 0;
+    hipError_t r;
+    int per = 8;
+    if (two) {
+        per = lanes == 8 ? 8 : lanes == 32 ? 32 : lanes == 64 ? 64 : 16;
+        r = per == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8, true>, 64, 0)
+          : per == 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<32, true>, 64, 0)
+          : per == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<64, true>, 64, 0)
+          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<16, true>, 64, 0);
+    } else {
+        per = lanes == 4 ? 4 : lanes == 16 ? 16 : lanes == 32 ? 32 : 8;
+        r = per == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<4, false>, 64, 0)
+          : per == 16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<16, false>, 64, 0)
+          : per == 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<32, false>, 64, 0)
+          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8, false>, 64, 0);
+    }
+    if (r != hipSuccess) return 0;
+    return (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu * per : 0);
 }
 
 // =====================================================================================================================

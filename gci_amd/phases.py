@@ -1,0 +1,100 @@
+"""Where a run of the command line spends its time (number 3): wall-clock phases of the host and, inside the
+ingestion, device time per stage from HIP events on the engine's stream (recorded without synchronising: the uploads, the
+inflate and the record filter of consecutive runs overlap, and a `torch.cuda.synchronize()` per stage would undo exactly that).
+
+Off by default -- the command line prints and writes what the reference does and nothing else.  `GCI_PHASES=<file.json>` (or
+`phases.start()` from a harness such as bench.py) switches it on; `phases.report()` returns / writes the split."""
+from __future__ import annotations
+
+import contextlib
+import json
+import os
+import time
+from typing import Dict, List, Optional, Tuple
+
+_ON = False
+_WALL: List[Tuple[str, float]] = []
+_GPU: List[Tuple[str, object, object]] = []
+_NOTES: Dict[str, object] = {}
+_T0 = 0.0
+
+
+def start() -> None:
+    global _ON, _T0
+    _ON = True
+    _WALL.clear()
+    _GPU.clear()
+    _NOTES.clear()
+    _T0 = time.perf_counter()
+
+
+def stop() -> None:
+    global _ON
+    _ON = False
+
+
+def on() -> bool:
+    return _ON
+
+
+def env_start() -> Optional[str]:
+    """Called by the command line: GCI_PHASES=<path> switches the log on; -> the path."""
+    p = os.environ.get("GCI_PHASES")
+    if p:
+        start()
+    return p or None
+
+
+@contextlib.contextmanager
+def wall(name: str):
+    """A host wall-clock phase (nested phases are listed with their own names; they do not subtract from the outer one)."""
+    if not _ON:
+        yield
+        return
+    t = time.perf_counter()
+    try:
+        yield
+    finally:
+        _WALL.append((name, time.perf_counter() - t))
+
+
+@contextlib.contextmanager
+def gpu(name: str, stream=None):
+    """Device time of what is enqueued inside, between two events on the current (= the engine's) stream."""
+    if not _ON:
+        yield
+        return
+    import torch
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    try:
+        yield
+    finally:
+        b.record(stream)
+        _GPU.append((name, a, b))
+
+
+def note(key: str, value) -> None:
+    if _ON:
+        _NOTES[key] = value
+
+
+def add(key: str, value) -> None:
+    if _ON:
+        _NOTES[key] = _NOTES.get(key, 0) + value
+
+
+def report(path: Optional[str] = None) -> dict:
+    """{"wall_s": {phase: seconds (summed over its occurrences)}, "gpu_s": {stage: seconds}, "notes": {...}, "total_s"}."""
+    out = {"total_s": time.perf_counter() - _T0, "wall_s": {}, "gpu_s": {}, "notes": dict(_NOTES)}
+    for name, s in _WALL:
+        out["wall_s"][name] = out["wall_s"].get(name, 0.0) + s
+    if _GPU:
+        import torch
+        torch.cuda.synchronize()
+        for name, a, b in _GPU:
+            out["gpu_s"][name] = out["gpu_s"].get(name, 0.0) + a.elapsed_time(b) * 1e-3
+    if path:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    return out

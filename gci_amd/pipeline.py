@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Set, Tuple
 import numpy as np
 import torch
 
-from . import score
+from . import phases, score
 from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
 from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
@@ -249,8 +249,10 @@ def _filter_stream(engine: Engine, d_stream: torch.Tensor, d_off: torch.Tensor, 
     """K1 over the records of an inflated BAM stream (has_seq) or a heads stream -> join input (records + where their names are)."""
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
     if K1_MODE == "pages" or not has_seq:                 # (a heads stream is only ever read through its pages)
-        pages = engine.bam_pages(d_stream, d_off, has_seq)
-        recs, noff = engine.bam_filter_pages(pages, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base)
+        with phases.gpu("record pages"):
+            pages = engine.bam_pages(d_stream, d_off, has_seq)
+        with phases.gpu("record filter (K1)"):
+            recs, noff = engine.bam_filter_pages(pages, ref_sel, map_qual, mq_cutoff, clip_percent, iden_percent, rec_idx_base=rec_idx_base)
         ji = JoinInput(recs, pages.buf, noff, 0)
         ji.blob_bytes = int(pages.buf.shape[0]) - pages.blob_off - 16      # CIGARs / oversize records behind the pages (ONT: GBs)
         return ji
@@ -369,12 +371,14 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     n_ref = len(hdr.references)
     total = int(isz.sum())
     if total <= GPU_INFLATE_MAX:
-        if upload is not None:
-            d_bam = engine.bgzf_inflate_uploaded(upload, pos, isz, check_crc=BGZF_CRC)
-            upload = None
-        else:
-            d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC)
-        d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, n_ref)
+        with phases.gpu("bgzf_inflate + crc"):
+            if upload is not None:
+                d_bam = engine.bgzf_inflate_uploaded(upload, pos, isz, check_crc=BGZF_CRC)
+                upload = None
+            else:
+                d_bam = engine.bgzf_inflate(raw, pos, isz, check_crc=BGZF_CRC)
+        with phases.gpu("record walk"):
+            d_off, used, ok = engine.bam_record_offsets(d_bam, hdr.first_record, n_ref)
         if not ok:
             return None
         if used != total:
@@ -404,9 +408,11 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     try:
         for k, (lo, hi) in enumerate(groups):
             p0 = int(pos[lo])
-            d_raw = ahead.take(k)
+            with phases.wall("  wait for the upload of a run (host blocked)"):
+                d_raw = ahead.take(k)
             try:
-                d_buf = engine.bgzf_inflate(None, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry, d_raw=d_raw)
+                with phases.gpu("bgzf_inflate + crc"):
+                    d_buf = engine.bgzf_inflate(None, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry, d_raw=d_raw)
             except GciError as e:
                 if e.rec >= 0:
                     e.rec += lo
@@ -416,7 +422,8 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
             if int(d_buf.shape[0]) <= start:                  # still inside the header
                 carry, start = None, start - int(d_buf.shape[0])
                 continue
-            d_off, used, ok = engine.bam_record_offsets(d_buf, start, n_ref)
+            with phases.gpu("record walk"):
+                d_off, used, ok = engine.bam_record_offsets(d_buf, start, n_ref)
             if not ok:
                 return None
             carry, start = (d_buf[used:].clone() if used < int(d_buf.shape[0]) else None), 0
@@ -501,13 +508,20 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         if 0 < raw.shape[0] <= GPU_INFLATE_MAX // 8:
             upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1)
         try:
-            pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+            with phases.wall("bgzf_member_table"):
+                pos, isz = hostio.bgzf_blocks(np.asarray(raw))
         except BaseException:
             if upload is not None:
                 upload["pool"].shutdown()
             raise
+        phases.add("bgzf_bytes", int(raw.shape[0]))
+        phases.add("bgzf_members", int(isz.shape[0]))
+        phases.add("inflated_bytes", int(isz.sum()))
         if int(isz.sum()) > 0:
-            ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, upload)
+            with phases.wall("bam_ingest (upload | inflate + crc | record walk | pages | filter, overlapped)"):
+                ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, upload)
+                if phases.on():
+                    torch.cuda.synchronize()
             if ji is not None:
                 _drop_later(raw)                              # (the unmapping, off this thread)
                 del raw
@@ -631,13 +645,15 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
         except GciError as e:
             _reraise_like_reference(e)
     try:
-        ivl, count = engine.name_join(inputs, ovlp_percent, count_flank=flank_len)     # + the build's counting pass
+        with phases.wall("name_join"), phases.gpu("name join"):
+            ivl, count = engine.name_join(inputs, ovlp_percent, count_flank=flank_len)     # + the build's counting pass
     except GciError as e:
         _reraise_like_reference(e)
     track = engine.new_track()
     text_on_device = bool(write) and DEPTH_GZ != "gpu"
-    fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=text_on_device, want_sums=True,
-                                     issue=issue_hint, counted=True)
+    with phases.wall("depth_build"), phases.gpu("depth build"):
+        fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=text_on_device, want_sums=True,
+                                         issue=issue_hint, counted=True)
     depths = DepthTracks(engine, targets_length, track)
     depths._fresh_sums = fused["sums"]
     if issue_hint is not None:
@@ -646,10 +662,11 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     print(f"Filtering {log_reads_type} alignment files done!!!")
     if write:
         print(f'Writing depths into "{directory}/{prefix}.depth.gz" ...')
-        if text_on_device:
-            _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
-        else:
-            _write_depth_members(directory, prefix, depths)
+        with phases.wall("write_depth_gz (deflate on the device, D2H, file)"):
+            if text_on_device:
+                _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
+            else:
+                _write_depth_members(directory, prefix, depths)
         print("Writing depths done!!!\n\n")
     return depths, targets_length
 
@@ -964,12 +981,16 @@ def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
     path = f"{directory}/{prefix}.depth.gz"
     if os.path.exists(path):
         os.remove(path)
+    layout = {}
     with open(path, "wb") as f:
         for t, L, blob in items:
             if L == 0:
                 continue              # the reference's chunk loop never runs for an empty contig: not even the '>' line
+            at = f.tell()
             f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
             f.write(blob)
+            layout[t] = (at, f.tell())
+    phases.note("depth_gz_layout:" + path, layout)    # (a harness that checks single contigs of a genome-size file reads this)
 
 
 def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, threads) -> None:

@@ -355,3 +355,143 @@ def genome_two_type(config: int = 4, scale: float = 1.0, cov_hifi: float = 40.0,
         print("workload: %d contigs, %d bp, reads hifi %d ont %d, %.0f s on %d processes" % (
             len(ctg), total, types[0].n_reads, types[1].n_reads, time.time() - t0, procs), file=sys.stderr, flush=True)
     return TwoTypeInput(ctg, types[0], types[1], gaps, regions)
+
+
+# ---- a heads stream back as the BGZF file it came from (bench.py: the command line at genome size, SURVEY.md 8d number 3) ----
+
+_BG = {}          # what the forked workers of write_bgzf_from_heads read: heads stream, offsets, shared member sizes
+
+
+def _bgzf_member(payload, level: int = 1) -> bytes:
+    import struct
+    import zlib
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = comp.compress(payload) + comp.flush()
+    if 12 + 6 + len(body) + 8 - 1 > 0xFFFF:                  # would not fit BSIZE: stored
+        comp = zlib.compressobj(0, zlib.DEFLATED, -15)
+        body = comp.compress(payload) + comp.flush()
+    head = struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, 12 + 6 + len(body) + 8 - 1)
+    return head + body + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload))
+
+
+def _bgzf_part(k: int):
+    """Worker: records [lo, hi) of the heads stream -> the records with their SEQ / QUAL bytes (random bases, HiFi-like
+    qualities: synth.to_bam_stream(seq_qual='random')) -> BGZF members cut the way htslib's writer cuts them (a record that
+    still fits the 0xFF00-byte block goes into it whole, bgzf_flush_try; only a record larger than a block is split) ->
+    written at this part's place in the file, which is known once every earlier part's size is (shared array)."""
+    import os
+    g = _BG
+    heads, offs, n_stream = g["heads"], g["offs"], g["n_stream"]
+    lo, hi = g["parts"][k]
+    qlut = synth._hifi_qual_lut()
+    rng = np.random.Generator(np.random.PCG64(g["seed"] + 7919 * k))
+    a = offs[lo:hi].astype(np.int64)
+    e = np.concatenate([a[1:], [int(offs[hi]) if hi < offs.shape[0] else n_stream]]).astype(np.int64)
+    size = e - a                                                # bytes of the record in the heads stream (block_size word included)
+    lrn = heads[a + 12].astype(np.int64)
+    ncig = heads[a + 16].astype(np.int64) | (heads[a + 17].astype(np.int64) << 8)
+    l_seq = (heads[a + 20].astype(np.int64) | (heads[a + 21].astype(np.int64) << 8) | (heads[a + 22].astype(np.int64) << 16)
+             | (heads[a + 23].astype(np.int64) << 24))
+    head_len = 36 + lrn + 4 * ncig                              # everything in front of SEQ
+    aux_len = size - head_len
+    nseq = (l_seq + 1) // 2
+    out_size = size + nseq + l_seq
+    out_off = np.zeros(hi - lo + 1, dtype=np.int64)
+    np.cumsum(out_size, out=out_off[1:])
+    total = int(out_off[-1])
+    out = qlut[rng.integers(0, 256, total, dtype=np.uint8)]     # quality-like bytes everywhere; heads, SEQ and aux are laid over them
+    seq_all = synth._SEQ_LUT[rng.integers(0, 16, int(nseq.sum()), dtype=np.uint8)]
+    sp = 0
+    for r in range(hi - lo):
+        o, s, h, q = int(out_off[r]), int(a[r]), int(head_len[r]), int(nseq[r])
+        out[o:o + h] = heads[s:s + h]
+        out[o + h:o + h + q] = seq_all[sp:sp + q]
+        sp += q
+        x = int(aux_len[r])
+        t = o + h + q + int(l_seq[r])
+        out[t:t + x] = heads[s + h:s + h + x]
+    out[(out_off[:-1, None] + np.arange(4)[None, :]).ravel()] = (out_size - 4).astype("<i4").view(np.uint8).reshape(-1, 4).ravel()
+    # member cuts
+    BLOCK = 0xFF00
+    cuts, fill = [0], 0
+    for r in range(hi - lo):
+        sz = int(out_size[r])
+        if fill and fill + sz > BLOCK:
+            cuts.append(int(out_off[r]))
+            fill = 0
+        while sz > BLOCK - fill:                                # a record larger than what is left of an empty block: split
+            take = BLOCK - fill
+            cuts.append(cuts[-1] + take if fill == 0 and cuts[-1] >= int(out_off[r]) else int(out_off[r]) + take)
+            sz -= take
+            fill = 0
+        fill += sz
+    if cuts[-1] != total:
+        cuts.append(total)
+    mv = memoryview(out)
+    pieces = []
+    if k == 0:                                                  # the BAM header: members of its own in front
+        hdr = bytes(heads[:g["first"]])
+        pieces += [_bgzf_member(hdr[i:i + BLOCK]) for i in range(0, len(hdr), BLOCK)]
+    pieces += [_bgzf_member(mv[c0:c1]) for c0, c1 in zip(cuts[:-1], cuts[1:]) if c1 > c0]
+    data = b"".join(pieces)
+    sizes = g["sizes"]
+    sizes[k] = len(data)
+    import time as _t
+    while True:                                                 # every earlier part is running or done (the pool hands parts out in order)
+        prev = sizes[:k]
+        if all(v >= 0 for v in prev):
+            break
+        _t.sleep(0.005)
+    fd = os.open(g["path"], os.O_WRONLY)
+    try:
+        os.pwrite(fd, data, int(sum(prev)))
+    finally:
+        os.close(fd)
+    return k, len(data), len(pieces), total
+
+
+def write_bgzf_from_heads(path: str, heads: np.ndarray, offsets: np.ndarray, seed: int = 7, procs: Optional[int] = None,
+                          part_records: int = 24576, verbose: bool = False) -> dict:
+    """The BGZF BAM file whose heads stream (gci_bam_heads) is `heads` / `offsets`: every record gets SEQ / QUAL bytes of realistic
+    entropy back (they are what costs inflate time; nothing on the path reads them), the stream is deflated at level 1 by
+    `procs` forked workers, part by part of `part_records` records, each part written at its place in the file as soon as the
+    sizes of all earlier parts are known.  -> {"bytes", "inflated_bytes", "members", "seconds"}."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from .formats import bgzf
+    R = int(offsets.shape[0])
+    first = bamfmt.parse_header(heads).first_record
+    parts = [(lo, min(R, lo + part_records)) for lo in range(0, R, part_records)] or [(0, 0)]
+    if procs is None:
+        from . import hostio
+        procs = hostio.default_threads()
+    procs = max(1, min(int(procs), len(parts)))
+    sizes = mp.get_context("fork").Array("q", [-1] * len(parts), lock=False)
+    _BG.clear()
+    _BG.update(heads=heads, offs=offsets, n_stream=int(heads.shape[0]), parts=parts, seed=int(seed), first=int(first), sizes=sizes,
+               path=path)
+    with open(path, "wb"):
+        pass
+    t0 = time.time()
+    done, members, inflated, nbytes = 0, 0, int(first), 0
+    try:
+        if procs == 1:
+            res = map(_bgzf_part, range(len(parts)))
+        else:
+            ex = ProcessPoolExecutor(procs, mp_context=mp.get_context("fork"))
+            res = ex.map(_bgzf_part, range(len(parts)))
+        for k, n, m, t in res:
+            done += 1
+            members += m
+            inflated += t
+            nbytes += n
+            if verbose and done % 32 == 0:
+                print("bgzf: part %d/%d of %s, %.0f s" % (done, len(parts), path, time.time() - t0), file=sys.stderr, flush=True)
+        if procs != 1:
+            ex.shutdown()
+    finally:
+        _BG.clear()
+    with open(path, "r+b") as f:
+        f.seek(nbytes)
+        f.write(bgzf.BGZF_EOF)
+    return {"bytes": nbytes + len(bgzf.BGZF_EOF), "inflated_bytes": inflated, "members": members, "seconds": time.time() - t0}

@@ -37,6 +37,9 @@ def test_bench_line_contract():
     s8 = d["survey_8d"]
     assert s8["1_kernels_only_gbases_per_s"] == d["value"]
     assert s8["2_device_pipeline_incl_h2d_d2h"]["seconds"] > 0 and s8["3_command_line_chr19_realistic_bam"]["seconds"] > 0
+    g = s8["3_command_line_genome"]              # the command line as a process of its own on the two BGZF files of the workload
+    assert g["parity"] is True and len(g["parity_vs_oracle_on_contigs"]) >= 3 and g["seconds"] > 0
+    assert g["phases_device_s"]["bgzf_inflate + crc"] > 0 and "GCI.depth.gz" in g["outputs_bytes"] and g["deflate_ratio"] > 1.5
     sw = d["survey_window_step"]                  # the window SURVEY 8(d) defines: no text, keys on the host every step
     assert 0 < sw["ms_per_step"] and sw["gbases_per_s"] > 0 and sw["k_tile_build_avg_launch_ms"] > 0 and 0 < sw["hbm_frac"] < 1
     two = d["two_steps_in_flight"]
