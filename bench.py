@@ -385,7 +385,9 @@ class TwoTypeWorkload:
         self.gaps = None
         if inp.gaps:
             g = [(names.index(c), a, b, 0) for c, segs in inp.gaps.items() for a, b in segs]
-            self.gaps = eng.to_device(np.asarray(g, dtype=np.int32))
+            self.gaps = np.asarray(g, dtype=np.int32)           # (host rows: gci_two_type_tail takes the N runs from the host)
+        self.tail_keys = torch.empty((3, 1 << 16), dtype=torch.int64, device=dev)
+        self.tail_n = torch.zeros(3, dtype=torch.int32, device=dev)
         offs = eng.offsets
         self.windows = [(offs[names.index(c)] + a, offs[names.index(c)] + b) for c, a, b in inp.regions]
         self.aligned_bases = inp.aligned_bases
@@ -407,14 +409,15 @@ class TwoTypeWorkload:
             inputs.append(JoinInput(recs, d["pages"].buf, noff, 0))
             ivl, cnt = eng.name_join(inputs, OVLP, out=d["ivl"], count=d["count"], check=False, count_flank=FLANK)
             d["jstatus"] = eng._status.clone()
-            d["fused"] = eng.depth_build_fused(ivl, cnt, FLANK, d["track"], want_text=False, want_sums=True,
-                                               issue=None if self.gaps is not None else (-1.0, 0.0, FLANK), counted=True)
-            if self.gaps is not None:
-                eng.gap_mask(d["track"], self.gaps)
-        eng.max2(self.types[0]["track"], self.types[1]["track"], out=self.two)
-        for d in self.types:
-            runs.append(d["fused"]["runs"] if self.gaps is None else eng.issue_scan(d["track"], -1.0, 0.0, FLANK))
-        runs.append(eng.issue_scan(self.two, -1.0, 0.0, FLANK))
+            d["fused"] = eng.depth_build_fused(ivl, cnt, FLANK, d["track"], want_text=False, want_sums=True, issue=None, counted=True)
+        # the tail in one pass (gci_two_type_tail): N-run masks of both tracks, their maximum, the issue runs of all three
+        eng.two_type_tail(self.types[0]["track"], self.types[1]["track"], self.gaps, -1.0, 0.0, FLANK, out=self.two,
+                          keys=self.tail_keys, n_keys=self.tail_n, read=False)
+        n = self.tail_n.cpu().numpy()                           # (the one read of the tail: three counters, then the few keys)
+        if int(n.max()) > int(self.tail_keys.shape[1]):
+            raise RuntimeError("bench: issue-run key buffer too small")
+        hk = self.tail_keys.cpu().numpy().view(np.uint64)
+        runs = [eng._keys_to_runs(hk[x, :int(n[x])], len(names)) for x in range(3)]
         reg = [eng.issue_scan_windows(t, self.windows, -1.0, 0.0) for t in (self.types[0]["track"], self.types[1]["track"], self.two)] \
             if self.windows else None
         self.last = dict(runs=runs, regions=reg)
@@ -438,7 +441,7 @@ class TwoTypeWorkload:
         paf = sum(int(d["paf"].shape[0]) for d in self.types if d["paf"] is not None)
         join = sum(48 * d["n_rec"] + 16 * k for d, k in zip(self.types, K))
         build = sum(28 * k + 4 * L for k in K)
-        rest = 12 * L + 4 * L + (2 * 4 * L if self.gaps is not None else 0)     # max2; scan of the merged track; scans of masked tracks
+        rest = 12 * L                                            # the tail in one pass: two tracks read, their maximum written
         return {"k1_record_filter": k1, "paf_text": paf, "name_join": join, "depth_build": build, "max_and_scans": rest,
                 "total": k1 + paf + join + build + rest, "intervals": K, "bases": L, "text_bytes": 0}
 

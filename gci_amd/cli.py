@@ -202,13 +202,13 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
                                                      ovlp_percent, flank_len, directory, force, kind.log_name, chrs_list, threads,
                                                      issue_hint=hint)
         with phases.wall("merge_gaps_depths"):
-            tracks.append(pipeline.merge_gaps_depths(depths, Ns_bed))
+            tracks.append(pipeline.merge_gaps_depths(depths, Ns_bed, lazy=both))     # (both: masked in the pass that merges them)
         prefixes.append(pfx)
         logs.append(kind.log_name)
         labels.append(kind.index_name)
     plotted = list(tracks)
     if both:                                                         # per-base maximum of the two masked tracks
-        two = pipeline.merge_two_type_depth(tracks[0], tracks[1], prefix + "_two_type", directory, force, threads)
+        two = pipeline.merge_two_type_depth(tracks[0], tracks[1], prefix + "_two_type", directory, force, threads, issue_hint=hint)
         tracks.append(pipeline.merge_gaps_depths(two, Ns_bed))
         prefixes.append(prefix + "_two_type")
         logs.append("two_types")

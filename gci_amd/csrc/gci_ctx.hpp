@@ -80,6 +80,8 @@ struct gci_ctx {
     uint32_t pg_n_rec = 0, pg_page_bytes = 0, pg_n_pages = 0;
     uint64_t pg_blob_off = 0;
     uint64_t pg_blob_bytes = 0;               // total size of the blob the size call measured (without its 16 guard bytes)
+    DevBuf tail_gaps;                       // gci_two_type_tail: the N runs as absolute sorted [begin, end) element ranges
+    std::vector<int64_t> tail_gaps_host;    // ... what was uploaded last
     // issue-scan windows
     DevBuf win, win_tile_first;
     int win_flank = INT32_MIN;              // flank the cached per-contig windows were built for

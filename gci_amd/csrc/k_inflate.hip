@@ -335,6 +335,45 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
 #if INF_DIST_BITS
         build_table<INF_DIST_BITS>(T.dist_cn, T.dist_sorted, T.dist_tab);
 #endif
+        if (TOKENS) {
+            // ---- symbols of the block, ONE per lane and iteration, whatever it is: literal and match are two sides of an `if`
+            // inside the body, so the lanes stay together symbol by symbol -- and zlib closes a block after a fixed number of
+            // symbols (lit_bufsize), so they also reach the ends of their blocks together.  (The loop below, which walks a
+            // whole run of literals before it looks at a match, lets a lane in a quality stretch -- a match every other symbol --
+            // wait for its neighbour's fifty literals of sequence: at 8 lanes per wave it issued 26 wave-instructions per
+            // symbol where a literal takes ~50 for all of them.)
+            for (;;) {
+                need32(B);
+                const int sym = decode<LIT_BITS, 15>(B, T.lit_tab, T.lit_cn, lit_sorted);
+                if (sym < 0 || sym > 285) { bad = true; break; }
+                if (sym == 256) break;
+                if (sym < 256) {
+                    if (op >= isize) { bad = true; break; }
+                    emit((uint32_t)sym);
+                } else {
+                    const uint32_t lc = (uint32_t)sym - 257u;
+                    const uint32_t le = lc < 8u || lc == 28u ? 0u : (lc >> 2) - 1u;
+                    const uint32_t len = (lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << le)) + take(B, (int)le);
+                    need32(B);
+#if INF_DIST_BITS
+                    const int ds = decode<INF_DIST_BITS, 15>(B, T.dist_tab, T.dist_cn, T.dist_sorted);
+#else
+                    const int ds = decode<0, 15>(B, nullptr, T.dist_cn, T.dist_sorted);
+#endif
+                    if (ds < 0 || ds > 29) { bad = true; break; }
+                    const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+                    const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
+                    if (dist > op || op + len > isize) { bad = true; break; }
+                    // the token takes the place of the match's first three bytes and travels with the literals
+                    mark(op);
+                    const uint32_t d1 = dist - 1u;
+                    emit(len - 3u); emit(d1 & 0xFFu); emit(d1 >> 8);
+                    flush();
+                    op += len - 3u;
+                }
+            }
+            continue;
+        }
         // ---- symbols of the block: runs of literals (the lanes of the wave meet again at their next match) -------------------
         for (;;) {
             int sym;
@@ -363,15 +402,6 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
             const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
             const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
             if (dist > op || op + len > isize) { bad = true; break; }
-            if (TOKENS) {
-                // the token takes the place of the match's first three bytes and travels with the literals
-                mark(op);
-                const uint32_t d1 = dist - 1u;
-                emit(len - 3u); emit(d1 & 0xFFu); emit(d1 >> 8);
-                flush();
-                op += len - 3u;
-                continue;
-            }
             // the copy reads this member's own output back from memory (a lane's stores and loads stay in order)
             flush();
             const uint8_t* src = dst + op - dist;
@@ -451,51 +481,63 @@ __global__ __launch_bounds__(256) void k_bgzf_copy(const uint64_t* __restrict__ 
         if (n & 2u) { const uint16_t x = (uint16_t)v; __builtin_memcpy(t, &x, 2); t += 2; v >>= 16; }
         if (n & 1u) *t = (uint8_t)v;
     };
-    unsigned long long w_next = nw ? bmw[0] : 0ull;
-    for (uint32_t wi = 0; wi < nw; wi++) {
-        unsigned long long w = w_next;
-        w_next = wi + 1 < nw ? bmw[wi + 1] : 0ull;
-        while (w) {
-            const uint32_t pos = wi * 64u + (uint32_t)__builtin_ctzll(w);
-            w &= w - 1ull;
-            if (pos + 3u > isize) break;
-            uint8_t* to = dst + pos;
-            const uint32_t t0 = to[0], t1 = to[1], t2 = to[2];
-            uint32_t len = t0 + 3u;
-            const uint32_t dist = (t1 | (t2 << 8)) + 1u;
-            if (dist > pos || pos + len > isize) continue;
-            const uint8_t* src = to - dist;
-            if (dist >= 8) {
-                // up to four 8-byte pieces per round trip: as many as lie wholly in front of what the round itself writes
-                while (len) {
-                    const uint32_t nb = min(min(4u, dist >> 3), (len + 7u) >> 3);
-                    unsigned long long v[4];
+    // The bitmap words one ahead, the token of the NEXT match loaded before the current one is copied: a match then costs one
+    // round trip (its source must be read behind the stores of the match before it), not three dependent ones.
+    uint32_t wi = 0;
+    unsigned long long w = nw ? bmw[0] : 0ull, w_next = nw > 1 ? bmw[1] : 0ull;
+    auto next_token = [&](uint32_t& pos) __attribute__((always_inline)) -> bool {
+        while (!w) {
+            wi++;
+            if (wi >= nw) return false;
+            w = w_next;
+            w_next = wi + 1 < nw ? bmw[wi + 1] : 0ull;
+        }
+        pos = wi * 64u + (uint32_t)__builtin_ctzll(w);
+        w &= w - 1ull;
+        return pos + 3u <= isize;
+    };
+    uint32_t npos = 0, n0 = 0, n1 = 0, n2 = 0;
+    bool have = next_token(npos);
+    if (have) { n0 = dst[npos]; n1 = dst[npos + 1]; n2 = dst[npos + 2]; }
+    while (have) {
+        const uint32_t pos = npos;
+        uint32_t len = n0 + 3u;
+        const uint32_t dist = (n1 | (n2 << 8)) + 1u;
+        have = next_token(npos);
+        if (have) { n0 = dst[npos]; n1 = dst[npos + 1]; n2 = dst[npos + 2]; }       // (it lies behind what this match writes)
+        if (dist > pos || pos + len > isize) continue;
+        uint8_t* to = dst + pos;
+        const uint8_t* src = to - dist;
+        if (dist >= 8) {
+            // up to four 8-byte pieces per round trip: as many as lie wholly in front of what the round itself writes
+            while (len) {
+                const uint32_t nb = min(min(4u, dist >> 3), (len + 7u) >> 3);
+                unsigned long long v[4];
 #pragma unroll
-                    for (uint32_t i = 0; i < 4; i++) v[i] = i < nb ? ld8(src + 8 * i) : 0ull;
+                for (uint32_t i = 0; i < 4; i++) v[i] = i < nb ? ld8(src + 8 * i) : 0ull;
 #pragma unroll
-                    for (uint32_t i = 0; i < 4; i++)
-                        if (i < nb) store_n(to + 8 * i, v[i], min(8u, len - 8u * i));
-                    const uint32_t adv = min(len, 8u * nb);
-                    src += adv; to += adv; len -= adv;
-                }
-            } else {
-                // a short period: its bytes once, made periodic over eight bytes, stored in steps of whole periods
-                unsigned long long pat = 0;
-                if (pos >= 8) pat = ld8(to - 8) >> (8 * (8 - dist));
-                else {
+                for (uint32_t i = 0; i < 4; i++)
+                    if (i < nb) store_n(to + 8 * i, v[i], min(8u, len - 8u * i));
+                const uint32_t adv = min(len, 8u * nb);
+                src += adv; to += adv; len -= adv;
+            }
+        } else {
+            // a short period: its bytes once, made periodic over eight bytes, stored in steps of whole periods
+            unsigned long long pat = 0;
+            if (pos >= 8) pat = ld8(to - 8) >> (8 * (8 - dist));
+            else {
 #pragma unroll
-                    for (int i = 0; i < 7; i++) pat |= (unsigned long long)((uint32_t)i < dist ? src[i] : (uint8_t)0) << (8 * i);
-                }
-                pat &= ~0ull >> (8 * (8 - dist));
-                if (dist < 8) pat |= pat << (8 * dist);
-                if (dist < 4) pat |= pat << (16 * dist);
-                if (dist < 2) pat |= pat << 32;
-                const uint32_t step = dist * (8u / dist);
-                while (len) {
-                    const uint32_t adv = min(len, step);
-                    store_n(to, pat, adv);
-                    to += adv; len -= adv;
-                }
+                for (int i = 0; i < 7; i++) pat |= (unsigned long long)((uint32_t)i < dist ? src[i] : (uint8_t)0) << (8 * i);
+            }
+            pat &= ~0ull >> (8 * (8 - dist));
+            if (dist < 8) pat |= pat << (8 * dist);
+            if (dist < 4) pat |= pat << (16 * dist);
+            if (dist < 2) pat |= pat << 32;
+            const uint32_t step = dist * (8u / dist);
+            while (len) {
+                const uint32_t adv = min(len, step);
+                store_n(to, pat, adv);
+                to += adv; len -= adv;
             }
         }
     }

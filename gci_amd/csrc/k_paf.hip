@@ -36,48 +36,75 @@ struct PafTargets {
 __device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c; }
 
 // a line starts at p: the first byte of the file, or behind '\n', or behind a '\r' that is not followed by '\n'
-__device__ __forceinline__ bool line_starts_at(const uint8_t* __restrict__ text, uint64_t lo, uint64_t p)
-{
-    if (p == lo) return true;
-    const uint8_t prev = text[p - 1];
-    return prev == '\n' || (prev == '\r' && text[p] != '\n');
-}
-
-__global__ __launch_bounds__(BLOCK) void k_paf_count_lines(const uint8_t* __restrict__ text, uint64_t lo, uint64_t hi,
-                                                           uint32_t* __restrict__ tile_count)
-{
-    __shared__ uint32_t wtot[BLOCK / 64];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint64_t p0 = lo + (uint64_t)blockIdx.x * TILE + (uint64_t)t * 16;
-    uint32_t n = 0;
-    for (int i = 0; i < 16; i++) if (p0 + i < hi && line_starts_at(text, lo, p0 + i)) n++;
-    n = wave_sum<uint32_t>(n);
-    if (lane == 0) wtot[wave] = n;
-    __syncthreads();
-    if (t == 0) tile_count[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_paf_line_starts(const uint8_t* __restrict__ text, uint64_t lo, uint64_t hi,
-                                                           const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ starts)
+//
+// k_paf_lines<false> counts the line starts of every 4096-byte tile, k_paf_lines<true> writes them at the scanned offsets.
+// (Round 3 tested text[p - 1] and text[p] with byte loads, sixteen positions per lane: 0.5 TB/s for ONE sequential read.)  A lane
+// takes sixteen bytes with one aligned 16-byte load -- tiles are laid over the text from the 16-byte boundary at or below the
+// file's first byte --, the byte in front of them comes from the lane before it (the first lane of a wave reads it), and the
+// sixteen tests run on registers.
+template <bool WRITE>
+__global__ __launch_bounds__(BLOCK) void k_paf_lines(const uint8_t* __restrict__ text, uint64_t lo, uint64_t hi,
+                                                     uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_off,
+                                                     uint64_t* __restrict__ starts)
 {
     __shared__ uint32_t wtot[BLOCK / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint64_t p0 = lo + (uint64_t)blockIdx.x * TILE + (uint64_t)t * 16;
+    const uint32_t delta = (uint32_t)((uintptr_t)(text + lo) & 15u);
+    const int64_t w0 = (int64_t)lo - (int64_t)delta + (int64_t)blockIdx.x * TILE + (int64_t)t * 16;     // first byte of this lane's window
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    if (w0 >= 0 && (uint64_t)w0 + 16 <= hi) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + w0);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else {
+        for (int i = 0; i < 16; i++) {
+            const int64_t p = w0 + i;
+            if (p >= (int64_t)lo && (uint64_t)p < hi) d[i >> 2] |= (uint32_t)text[p] << (8 * (i & 3));
+        }
+    }
+    uint32_t prev = (uint32_t)__shfl_up((int)(d[3] >> 24), 1, 64);
+    if (lane == 0) prev = w0 - 1 >= (int64_t)lo && (uint64_t)(w0 - 1) < hi ? text[w0 - 1] : 0u;
     uint32_t mask = 0;
-    for (int i = 0; i < 16; i++) if (p0 + i < hi && line_starts_at(text, lo, p0 + i)) mask |= 1u << i;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t cur = (d[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const int64_t p = w0 + i;
+        const bool in = p >= (int64_t)lo && (uint64_t)p < hi;
+        const bool start = p == (int64_t)lo || prev == '\n' || (prev == '\r' && cur != '\n');
+        if (in && start) mask |= 1u << i;
+        prev = cur;
+    }
     const uint32_t n = (uint32_t)__builtin_popcount(mask);
-    const uint32_t inc = wave_inclusive<uint32_t>(n, lane);
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t w = tile_off[blockIdx.x] + inc - n;
-    for (int k = 0; k < wave; k++) w += wtot[k];
-    for (uint32_t m = mask; m; m &= m - 1) starts[w++] = p0 + (uint32_t)__builtin_ctz(m);
+    if (!WRITE) {
+        const uint32_t tot = wave_sum<uint32_t>(n);
+        if (lane == 0) wtot[wave] = tot;
+        __syncthreads();
+        if (t == 0) tile_count[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    } else {
+        const uint32_t inc = wave_inclusive<uint32_t>(n, lane);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t w = tile_off[blockIdx.x] + inc - n;
+        for (int k = 0; k < wave; k++) w += wtot[k];
+        for (uint32_t m = mask; m; m &= m - 1) starts[w++] = (uint64_t)(w0 + (int64_t)__builtin_ctz(m));
+    }
 }
+
+// Where the bytes of the text are read from: the text itself, or the copy of a stretch of it a workgroup holds in LDS
+// (`origin` = the position of the copy's first byte).
+struct GlobalSrc {
+    const uint8_t* __restrict__ p;
+    __device__ __forceinline__ uint8_t operator[](uint64_t i) const { return p[i]; }
+};
+struct LdsSrc {
+    const uint8_t* l; uint64_t origin;
+    __device__ __forceinline__ uint8_t operator[](uint64_t i) const { return l[(uint32_t)(i - origin)]; }
+};
 
 // Python's int() on a column: optional blanks, optional sign, digits with single underscores between them ('1_000' is
 // 1000; '_1', '1_', '1__0' are not numbers); false = ValueError.  (A value beyond 63 bits is reported as malformed: the
 // reference would go on with a big integer.)
-__device__ __forceinline__ bool parse_int(const uint8_t* __restrict__ text, uint64_t a, uint64_t b, int64_t& v)
+template <typename Src>
+__device__ __forceinline__ bool parse_int(const Src text, uint64_t a, uint64_t b, int64_t& v)
 {
     while (a < b && is_space(text[a])) a++;
     while (b > a && is_space(text[b - 1])) b--;
@@ -102,12 +129,13 @@ __device__ __forceinline__ bool parse_int(const uint8_t* __restrict__ text, uint
     return true;
 }
 
-__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* __restrict__ p, uint32_t len)      // == gci_name_hash
+template <typename Src>
+__device__ __forceinline__ uint64_t hash_src(const Src text, uint64_t at, uint32_t len)      // == gci_name_hash
 {
     uint64_t acc = 0;
     for (uint32_t k = 0; k * 8 < len; k++) {
         uint64_t w = 0;
-        for (int b = 0; b < 8; b++) if (k * 8 + b < len) w |= (uint64_t)p[k * 8 + b] << (8 * b);
+        for (int b = 0; b < 8; b++) if (k * 8 + b < len) w |= (uint64_t)text[at + k * 8 + b] << (8 * b);
         acc += gci_hash_word(w, k);
     }
     return gci_hash_finish(acc, len);
@@ -119,18 +147,14 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t* __restrict__ a, const
     return true;
 }
 
-// One lane per line.  flag[i]: 1 = the line passed the filter (hit[i] is valid), 0 = skipped.  An offending line
-// reports (line number << 8 | -status) into *status with atomicMin: the FIRST such line of the file is what the reference
-// raises on (its lines are read in order).
-__global__ __launch_bounds__(BLOCK) void k_paf_tokenise(const uint8_t* __restrict__ text, uint64_t hi, const uint64_t* __restrict__ starts,
-                                                        uint32_t n_lines, uint64_t line_base, PafTargets T, int map_qual, int mq_cutoff,
-                                                        double iden_percent, PafHitD* __restrict__ hit, uint32_t* __restrict__ flag,
-                                                        unsigned long long* __restrict__ status)
+// One line: str.strip() + split('\t'), the twelve columns, the target, the eight int()s, the filter (GCI.py:218-239).
+// flag: 1 = the line passed the filter (h is valid), 0 = skipped.  An offending line reports (line number << 8 | -status) into
+// *status with atomicMin: the FIRST such line of the file is what the reference raises on (its lines are read in order).
+template <typename Src>
+__device__ __forceinline__ uint32_t paf_line(const Src text, uint64_t a, uint64_t hi, unsigned long long line_no, const PafTargets& T,
+                                             int map_qual, int mq_cutoff, double iden_percent, PafHitD& h,
+                                             unsigned long long* __restrict__ status)
 {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_lines) return;
-    flag[i] = 0;
-    uint64_t a = starts[i];
     // the end of the line is only looked for when fewer than thirteen columns turn up before it
     while (a < hi && text[a] != '\n' && text[a] != '\r' && is_space(text[a])) a++;               // lstrip
     uint64_t col[12], cend[12];
@@ -139,8 +163,10 @@ __global__ __launch_bounds__(BLOCK) void k_paf_tokenise(const uint8_t* __restric
     uint64_t q = a;
     bool eol = false;
     for (;;) {
-        if (q >= hi || text[q] == '\n' || text[q] == '\r') { eol = true; break; }
-        if (text[q] == '\t') {
+        if (q >= hi) { eol = true; break; }
+        const uint8_t c = text[q];
+        if (c == '\n' || c == '\r') { eol = true; break; }
+        if (c == '\t') {
             cend[nc] = q;
             if (nc == 11) break;                      // column 11 ends at a tab: nothing behind it matters
             col[++nc] = q + 1;
@@ -155,20 +181,23 @@ __global__ __launch_bounds__(BLOCK) void k_paf_tokenise(const uint8_t* __restric
         cend[nc] = b;
         if (b == a) nc = 0;                           // ''.split('\t') == ['']: one empty column
     }
-    const unsigned long long line_no = line_base + i + 1;                                        // 1-based, over the file
     auto fail = [&](int code) { atomicMin(status, (line_no << 8) | (unsigned long long)(uint8_t)(-code)); };
-    if (nc < 5) { fail(GCI_E_MALFORMED); return; }                                              // col[5]: IndexError
+    if (nc < 5) { fail(GCI_E_MALFORMED); return 0; }                                            // col[5]: IndexError
     // target among the selected contigs (GCI.py:220)
     const uint32_t tlen = (uint32_t)(cend[5] - col[5]);
-    const uint64_t th = hash_bytes(text + col[5], tlen);
+    const uint64_t th = hash_src(text, col[5], tlen);
     int32_t t = -1;
     for (uint32_t s = (uint32_t)(th ^ (th >> 29)) & T.mask;; s = (s + 1) & T.mask) {
         const int32_t c = T.slot[s];
         if (c < 0) break;
-        if (T.hash[c] == th && T.off[c + 1] - T.off[c] == tlen && bytes_equal(T.names + T.off[c], text + col[5], tlen)) { t = c; break; }
+        if (T.hash[c] == th && T.off[c + 1] - T.off[c] == tlen) {
+            bool same = true;
+            for (uint32_t i = 0; i < tlen; i++) same = same && T.names[T.off[c] + i] == text[col[5] + i];
+            if (same) { t = c; break; }
+        }
     }
-    if (t < 0) return;
-    if (nc < 11) { fail(GCI_E_MALFORMED); return; }                                             // IndexError further right
+    if (t < 0) return 0;
+    if (nc < 11) { fail(GCI_E_MALFORMED); return 0; }                                           // IndexError further right
     int64_t qlen, qs, qe, ts, te, nmatch, alnlen, mapq;
     bool ok = parse_int(text, col[1], cend[1], qlen);
     ok = ok && parse_int(text, col[2], cend[2], qs);
@@ -178,17 +207,57 @@ __global__ __launch_bounds__(BLOCK) void k_paf_tokenise(const uint8_t* __restric
     ok = ok && parse_int(text, col[9], cend[9], nmatch);
     ok = ok && parse_int(text, col[10], cend[10], alnlen);
     ok = ok && parse_int(text, col[11], cend[11], mapq);
-    if (!ok) { fail(GCI_E_MALFORMED); return; }                                                 // ValueError
-    if (alnlen == 0) { fail(GCI_E_ZERO_DIV); return; }                                          // nmatch / alnlen
+    if (!ok) { fail(GCI_E_MALFORMED); return 0; }                                               // ValueError
+    if (alnlen == 0) { fail(GCI_E_ZERO_DIV); return 0; }                                        // nmatch / alnlen
     const double identity = (double)nmatch / (double)alnlen;
-    if (!(mapq >= map_qual && identity >= iden_percent)) return;
-    PafHitD h;
+    if (!(mapq >= map_qual && identity >= iden_percent)) return 0;
     h.qn_off = col[0]; h.qn_len = (uint32_t)(cend[0] - col[0]);
-    h.qhash = hash_bytes(text + col[0], h.qn_len);
+    h.qhash = hash_src(text, col[0], h.qn_len);
     h.qlen = qlen; h.qs = qs; h.qe = qe; h.ts = ts; h.te = te; h.identity = identity;
     h.t = t; h.hq = mapq >= mq_cutoff ? 1u : 0u; h.slot = 0;
-    hit[i] = h;
-    flag[i] = 1;
+    return 1;
+}
+
+// One lane per line, one workgroup per BLOCK consecutive lines.  Their bytes are one stretch of the text, [start of the first,
+// start of the line behind the last): the workgroup copies it into LDS with aligned 16-byte loads -- ONE coalesced trip to memory
+// -- and the lanes walk their lines there (round 3 walked ~150 bytes of global memory byte by byte per lane: 165 GB/s).  A
+// stretch that does not fit (lines of kilobytes: cg:Z: tags) is walked in global memory as before.
+#define PAF_LDS_BYTES 49152
+__global__ __launch_bounds__(BLOCK) void k_paf_tokenise(const uint8_t* __restrict__ text, uint64_t hi, const uint64_t* __restrict__ starts,
+                                                        uint32_t n_lines, uint64_t line_base, PafTargets T, int map_qual, int mq_cutoff,
+                                                        double iden_percent, PafHitD* __restrict__ hit, uint32_t* __restrict__ flag,
+                                                        unsigned long long* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_text[];
+    const uint32_t i0 = blockIdx.x * BLOCK, i = i0 + threadIdx.x;
+    const uint64_t s0 = starts[i0];
+    const uint64_t s1 = i0 + BLOCK < n_lines ? starts[i0 + BLOCK] : hi;
+    const uint32_t al = (uint32_t)((uintptr_t)(text + s0) & 15u);
+    const uint64_t origin = s0 - al;                                   // (may lie in front of the text by < 16 bytes: never read)
+    const bool in_lds = s1 - s0 + al <= PAF_LDS_BYTES;
+    if (in_lds) {
+        const uint32_t nv = (uint32_t)((s1 - s0 + al + 15) >> 4);
+        for (uint32_t v = threadIdx.x; v < nv; v += BLOCK) {
+            const uint64_t p = origin + 16ull * v;
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if ((v > 0 || al == 0) && p + 16 <= s1) x = *reinterpret_cast<const uint4*>(text + p);
+            else {
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (int k = 0; k < 16; k++) if (p + k >= s0 && p + k < s1) w[k >> 2] |= (uint32_t)text[p + k] << (8 * (k & 3));
+                x = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(s_text + 16u * v) = x;
+        }
+        __syncthreads();
+    }
+    if (i >= n_lines) return;
+    PafHitD h;
+    uint32_t f;
+    // (a line ends in front of the next one's start: inside the stretch, so `s1` bounds the walk exactly as `hi` does)
+    if (in_lds) f = paf_line(LdsSrc{s_text, origin}, starts[i], s1, line_base + i + 1, T, map_qual, mq_cutoff, iden_percent, h, status);
+    else f = paf_line(GlobalSrc{text}, starts[i], hi, line_base + i + 1, T, map_qual, mq_cutoff, iden_percent, h, status);
+    flag[i] = f;
+    if (f) hit[i] = h;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_paf_compact(const PafHitD* __restrict__ hit, const uint32_t* __restrict__ flag,
@@ -454,13 +523,14 @@ int paf_stage_a(gci_ctx* ctx, PafScratch& S, const uint8_t* d_text, const uint64
         if (hi < lo) return GCI_E_INVALID;
         A.hits_upto[f + 1] = A.hits_upto[f];
         if (hi == lo) continue;
-        const uint64_t n_tiles64 = (hi - lo + TILE - 1) / TILE;
+        const uint64_t n_tiles64 = (hi - lo + 15 + TILE - 1) / TILE;          // (tiles start at the 16-byte boundary at or below `lo`)
         if (n_tiles64 > 0x7fffffffULL) return GCI_E_INVALID;
         const uint32_t n_tiles = (uint32_t)n_tiles64;
         PAF_ALLOC(d_tile, uint32_t, n_tiles + 1);
         PAF_ALLOC(d_blk, uint32_t, n_tiles / TILE + 2);
-        hipLaunchKernelGGL(k_paf_count_lines, dim3(n_tiles), dim3(BLOCK), 0, st, d_text, lo, hi, d_tile);
-        LAUNCHCHK("k_paf_count_lines");
+        hipLaunchKernelGGL(k_paf_lines<false>, dim3(n_tiles), dim3(BLOCK), 0, st, d_text, lo, hi, d_tile, (const uint32_t*)nullptr,
+                           (uint64_t*)nullptr);
+        LAUNCHCHK("k_paf_lines<count>");
         int r = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_tile, d_tile, d_blk, (int64_t)n_tiles, true);
         if (r) return r;
         uint32_t n_lines = 0;
@@ -468,13 +538,14 @@ int paf_stage_a(gci_ctx* ctx, PafScratch& S, const uint8_t* d_text, const uint64
         HIPCHK(hipStreamSynchronize(st));
         if (n_lines == 0) continue;
         PAF_ALLOC(d_starts, uint64_t, n_lines);
-        hipLaunchKernelGGL(k_paf_line_starts, dim3(n_tiles), dim3(BLOCK), 0, st, d_text, lo, hi, (const uint32_t*)d_tile, d_starts);
-        LAUNCHCHK("k_paf_line_starts");
+        hipLaunchKernelGGL(k_paf_lines<true>, dim3(n_tiles), dim3(BLOCK), 0, st, d_text, lo, hi, (uint32_t*)nullptr, (const uint32_t*)d_tile,
+                           d_starts);
+        LAUNCHCHK("k_paf_lines<write>");
         PAF_ALLOC(d_hit, PafHitD, n_lines);
         PAF_ALLOC(d_flag, uint32_t, n_lines + 1);
         PAF_ALLOC(d_blk2, uint32_t, n_lines / TILE + 2);
         HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, st));
-        hipLaunchKernelGGL(k_paf_tokenise, dim3((n_lines + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_text, hi, (const uint64_t*)d_starts,
+        hipLaunchKernelGGL(k_paf_tokenise, dim3((n_lines + BLOCK - 1) / BLOCK), dim3(BLOCK), PAF_LDS_BYTES + 16, st, d_text, hi, (const uint64_t*)d_starts,
                            n_lines, (uint64_t)0, T, map_qual, mq_cutoff, iden_percent, d_hit, d_flag, d_status);
         LAUNCHCHK("k_paf_tokenise");
         unsigned long long h_status = 0;

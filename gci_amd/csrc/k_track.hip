@@ -3,6 +3,8 @@
 // (masked, merged or uploaded tracks); a fresh build gets the same results fused into
 // k_tile_build (k_depth.hip) without re-reading the track.
 #include "gci_ctx.hpp"
+#include <algorithm>
+#include <utility>
 
 // ============================================================================================
 // K6: gap mask (GCI.py:324-328), K7: two-type max (GCI.py:350)
@@ -216,6 +218,161 @@ extern "C" int gci_issue_scan(gci_ctx* ctx, const int32_t* d_depth, double lo, d
         ctx->win_flank = flank;
     }
     return issue_scan_launch(ctx, d_depth, ctx->win_n, ctx->win_tiles, lo, hi, d_keys, cap, d_n_keys);
+}
+
+// ============================================================================================
+// The tail of a two-read-type run in ONE pass (GCI.py:1014-1024): gap masks of both tracks (GCI.py:324-328), their per-base
+// maximum (GCI.py:350) and the issue-run boundaries of all three tracks (GCI.py:369-390).
+// ============================================================================================
+//
+// Done seam by seam -- gci_gap_mask x 2, gci_max2, gci_issue_scan x 3 -- the two tracks are read twice and the merged one once
+// more: 24 bytes per base.  Here a workgroup takes one 4096-base tile of both tracks, zeroes the bases inside N runs in
+// registers (and writes a tile back only if a run touched it), writes the maximum and tests every base of the three tracks
+// against `lo < d <= hi` inside the contig's window [flank, L - flank): 12 bytes per base.  The N runs arrive as absolute,
+// sorted, disjoint [begin, end) element ranges of the track (made on the host from the reference's contig coordinates with
+// Python's slice rules); a tile finds its first run by binary search, and nearly every tile has none.
+struct TailArgs {
+    int32_t* a; int32_t* b; int32_t* out;
+    const int64_t* gaps; uint32_t n_gaps;                    // [begin, end) pairs, sorted, disjoint
+    const int64_t* len; const int64_t* off; const int64_t* tile_first; int32_t n_contigs;
+    int32_t lo, hi, flank;
+    unsigned long long* keys; uint32_t cap; uint32_t* n_keys;     // three key arrays of `cap` entries, three counters
+};
+
+__device__ __forceinline__ bool tail_in_gap(const int64_t* __restrict__ gaps, uint32_t g0, uint32_t g1, int64_t p)
+{
+    for (uint32_t g = g0; g < g1; g++) if (p >= gaps[2 * g] && p < gaps[2 * g + 1]) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_two_type_tail(TailArgs A)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    const int32_t c = contig_of_tile(A.tile_first, A.n_contigs, blockIdx.x);
+    const int64_t L = A.len[c], o = A.off[c];
+    int64_t wa = gci_slice_bound(A.flank, L), wb = gci_slice_bound(L - A.flank, L);
+    if (wb < wa) wb = wa;
+    const int64_t Wb = o + wa, We = o + wb;                  // the window of this contig, in track elements
+    const int64_t p0 = (int64_t)blockIdx.x * TILE;
+    // the N runs that touch this tile: [g0, g1)
+    uint32_t g0 = 0, g1 = 0;
+    if (A.n_gaps) {
+        uint32_t lo_i = 0, hi_i = A.n_gaps;                  // first run with end > p0
+        while (lo_i < hi_i) { const uint32_t mid = (lo_i + hi_i) >> 1; if (A.gaps[2 * mid + 1] > p0) hi_i = mid; else lo_i = mid + 1; }
+        g0 = lo_i;
+        g1 = g0;
+        while (g1 < A.n_gaps && A.gaps[2 * g1] < p0 + TILE) g1++;
+    }
+    const bool gapped = g1 > g0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int64_t p = p0 + (int64_t)(j * BLOCK + t) * 4;
+        int4 va = *reinterpret_cast<const int4*>(A.a + p), vb = *reinterpret_cast<const int4*>(A.b + p);
+        int32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+        if (gapped) {
+            bool touched = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (tail_in_gap(A.gaps, g0, g1, p + k)) { da[k] = 0; db[k] = 0; touched = true; }
+            if (touched) {
+                *reinterpret_cast<int4*>(A.a + p) = make_int4(da[0], da[1], da[2], da[3]);
+                *reinterpret_cast<int4*>(A.b + p) = make_int4(db[0], db[1], db[2], db[3]);
+            }
+        }
+        int32_t dm[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dm[k] = max(da[k], db[k]);
+        *reinterpret_cast<int4*>(A.out + p) = make_int4(dm[0], dm[1], dm[2], dm[3]);
+        // run boundaries of the three tracks (k_issue_scan's rule, the window being the contig's)
+        uint32_t g[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool in = (p + k >= Wb) && (p + k < We);
+            g[0][k] = in && da[k] >= A.lo && da[k] <= A.hi;
+            g[1][k] = in && db[k] >= A.lo && db[k] <= A.hi;
+            g[2][k] = in && dm[k] >= A.lo && dm[k] <= A.hi;
+        }
+        int gp[3];
+#pragma unroll
+        for (int x = 0; x < 3; x++) gp[x] = __shfl_up((int)g[x][3], 1, 64);
+        if (lane == 0) {
+            gp[0] = gp[1] = gp[2] = 0;
+            if (p - 1 >= Wb && p - 1 < We) {                 // (p - 1 lies in the same contig: the window starts inside it)
+                int32_t xa = A.a[p - 1], xb = A.b[p - 1];
+                if (A.n_gaps) {                               // (the base before may lie in a run of the tile in front)
+                    uint32_t lo_i = 0, hi_i = A.n_gaps;       // first run with end > p - 1
+                    while (lo_i < hi_i) { const uint32_t mid = (lo_i + hi_i) >> 1; if (A.gaps[2 * mid + 1] > p - 1) hi_i = mid; else lo_i = mid + 1; }
+                    if (lo_i < A.n_gaps && A.gaps[2 * lo_i] <= p - 1) xa = xb = 0;
+                }
+                const int32_t xm = max(xa, xb);
+                gp[0] = xa >= A.lo && xa <= A.hi; gp[1] = xb >= A.lo && xb <= A.hi; gp[2] = xm >= A.lo && xm <= A.hi;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            if (!(g[x][0] | g[x][1] | g[x][2] | g[x][3] | (uint32_t)gp[x])) continue;
+            unsigned long long* keys = A.keys + (size_t)x * A.cap;
+            bool prev = (bool)gp[x];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t q = p + k;
+                const bool gk = (bool)g[x][k];
+                if (gk != prev && q >= Wb && (gk || q < We)) {
+                    const uint32_t s = atomicAdd(A.n_keys + x, 1u);
+                    if (s < A.cap) keys[s] = issue_key((uint32_t)c, q - Wb, !gk);
+                }
+                if (gk && q == We - 1) {
+                    const uint32_t s = atomicAdd(A.n_keys + x, 1u);
+                    if (s < A.cap) keys[s] = issue_key((uint32_t)c, We - Wb, true);
+                }
+                prev = gk;
+            }
+        }
+    }
+}
+
+// h_gaps: the N runs in the reference's coordinates (contig = index in the layout, [start, end) with Python's slice rules, as
+// gci_gap_mask takes them on the device); d_a / d_b are masked IN PLACE, d_out receives their maximum; d_keys: 3 x cap keys
+// (track a, track b, the maximum; the keys gci_issue_scan(track, lo, hi, flank) gives), d_n_keys: 3 counters.
+extern "C" int gci_two_type_tail(gci_ctx* ctx, int32_t* d_a, int32_t* d_b, int32_t* d_out, const gci_ivl* h_gaps, uint32_t n_gaps,
+                                 double lo, double hi, int flank, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys)
+{
+    if (!ctx || !d_a || !d_b || !d_out || !d_n_keys || (cap && !d_keys) || (n_gaps && !h_gaps)) return GCI_E_INVALID;
+    if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
+    HIPCHK(hipMemsetAsync(d_n_keys, 0, 12, ctx->stream));
+    if (ctx->n_tiles == 0) return GCI_OK;
+    // absolute, sorted, merged element ranges of the N runs (uploaded again only when they change)
+    std::vector<std::pair<int64_t, int64_t>> g;
+    g.reserve(n_gaps);
+    for (uint32_t i = 0; i < n_gaps; i++) {
+        const gci_ivl v = h_gaps[i];
+        if (v.contig < 0 || v.contig >= ctx->n_contigs) continue;
+        const int64_t L = ctx->len[v.contig];
+        const int64_t a = gci_slice_bound(v.start, L), b = gci_slice_bound(v.end, L);
+        if (b > a) g.emplace_back(ctx->off[v.contig] + a, ctx->off[v.contig] + b);
+    }
+    std::sort(g.begin(), g.end());
+    std::vector<int64_t> flat;
+    for (const auto& r : g) {
+        if (!flat.empty() && r.first <= flat.back()) { if (r.second > flat.back()) flat.back() = r.second; }
+        else { flat.push_back(r.first); flat.push_back(r.second); }
+    }
+    if (flat != ctx->tail_gaps_host) {
+        GCI_TRY(gci_ensure(ctx, ctx->tail_gaps, flat.size() * 8 + 16));
+        if (!flat.empty()) GCI_TRY(gci_upload_small(ctx, ctx->tail_gaps.p, flat.data(), flat.size() * 8));
+        ctx->tail_gaps_host = flat;
+    }
+    const IntRange rg = gci_int_range(lo, hi);
+    TailArgs A;
+    A.a = d_a; A.b = d_b; A.out = d_out;
+    A.gaps = (const int64_t*)ctx->tail_gaps.p; A.n_gaps = (uint32_t)(flat.size() / 2);
+    A.len = (const int64_t*)ctx->d_len.p; A.off = (const int64_t*)ctx->d_off.p; A.tile_first = (const int64_t*)ctx->d_tile_first.p;
+    A.n_contigs = ctx->n_contigs; A.lo = rg.lo; A.hi = rg.hi; A.flank = flank;
+    A.keys = (unsigned long long*)d_keys; A.cap = cap; A.n_keys = d_n_keys;
+    ProfScope _ps(ctx, GCI_PROF_MAX2);
+    hipLaunchKernelGGL(k_two_type_tail, dim3((uint32_t)ctx->n_tiles), dim3(BLOCK), 0, ctx->stream, A);
+    LAUNCHCHK("k_two_type_tail");
+    return GCI_OK;
 }
 
 // ============================================================================================

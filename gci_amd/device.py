@@ -662,6 +662,33 @@ class Engine:
         self._chk(self.lib.gci_max2(self.ctx, self._p(a), self._p(b), self._p(out)), "gci_max2")
         return out
 
+    def two_type_tail(self, a: torch.Tensor, b: torch.Tensor, gaps: Optional[np.ndarray], lo: float, hi: float, flank: int,
+                      out: Optional[torch.Tensor] = None, keys: Optional[torch.Tensor] = None, n_keys: Optional[torch.Tensor] = None,
+                      read: bool = True):
+        """gci_two_type_tail: N-run masks of both tracks (in place; gaps = int32 [n, 4] rows (contig, start, end, 0) on the HOST, or
+        None), their maximum and the issue runs of all three in one pass.  -> (maximum track, [runs of a, of b, of the maximum]);
+        read=False: (maximum track, keys int64 [3, cap] on the device, n_keys int32 [3]) with nothing copied to the host."""
+        if out is None:
+            out = self.new_track()
+        g = np.ascontiguousarray(gaps, dtype=np.int32).reshape(-1, 4) if gaps is not None and len(gaps) else None
+        cap = int(keys.shape[1]) if keys is not None else 1 << 16
+        while True:
+            if keys is None:
+                keys = torch.empty((3, cap), dtype=torch.int64, device=self.device)
+            if n_keys is None:
+                n_keys = torch.zeros(3, dtype=torch.int32, device=self.device)
+            self._chk(self.lib.gci_two_type_tail(self.ctx, self._p(a), self._p(b), self._p(out),
+                                                 ctypes.c_void_p(g.ctypes.data) if g is not None else None, 0 if g is None else int(g.shape[0]),
+                                                 float(lo), float(hi), int(flank), self._p(keys), cap, self._p(n_keys)), "gci_two_type_tail")
+            if not read:
+                return out, keys, n_keys
+            n = n_keys.cpu().numpy()
+            if int(n.max()) <= cap:
+                break
+            cap, keys = int(n.max()), None                  # (masking again changes nothing; the maximum is recomputed)
+        hk = keys.cpu().numpy().view(np.uint64)
+        return out, [self._keys_to_runs(hk[x, :int(n[x])], len(self.lengths)) for x in range(3)]
+
     def depth_sum(self, track: torch.Tensor) -> np.ndarray:
         sums = torch.zeros(max(len(self.lengths), 1), dtype=torch.int64, device=self.device)
         self._chk(self.lib.gci_depth_sum(self.ctx, self._p(track), self._p(sums)), "gci_depth_sum")

@@ -64,14 +64,26 @@ class DepthTracks:
         # by-products of the fused build, valid until the track is modified (gap mask)
         self._fresh_runs = None        # ((lo, hi, flank), per-contig raw runs)
         self._fresh_sums = None
+        # N runs whose mask is still to be applied (merge_gaps_depths(lazy=True): a two-read-type run masks both tracks in the one
+        # pass that also merges them, merge_two_type_depth) -- applied by whatever looks at the track first
+        self._pending_gaps: Optional[np.ndarray] = None
+        self._masked_with: Optional[bytes] = None      # the rows of the mask this track already carries
 
     def invalidate(self) -> None:
         self._fresh_runs = None
         self._fresh_sums = None
 
-    def _bind(self) -> None:
+    def _bind_layout(self) -> None:
         if self.engine.lengths != self.lengths:
             self.engine.set_layout(self.lengths)
+
+    def _bind(self) -> None:
+        self._bind_layout()
+        if self._pending_gaps is not None:
+            rows, self._pending_gaps = self._pending_gaps, None
+            self.engine.gap_mask(self.track, self.engine.to_device(rows))
+            self._masked_with = rows.tobytes()
+            self.invalidate()
 
     def keys(self):
         return self.targets_length.keys()
@@ -145,13 +157,22 @@ def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
     return None, None
 
 
-def merge_gaps_depths(depths: DepthTracks = None, Ns_bed=None) -> DepthTracks:
+def merge_gaps_depths(depths: DepthTracks = None, Ns_bed=None, lazy: bool = False) -> DepthTracks:
+    """lazy: the mask is noted and applied by whatever reads the track first -- in a two-read-type run that is the one pass of
+    merge_two_type_depth, which masks both tracks, merges them and finds the issue runs of all three."""
     if Ns_bed is not None:
         rows = [(depths.targets.index(t), a, b, 0) for t, segs in Ns_bed.items() if t in depths for a, b in segs]
         if rows:
+            arr = np.asarray(rows, dtype=np.int32).reshape(-1, 4)
+            if depths._pending_gaps is None and depths._masked_with == arr.tobytes():
+                return depths                         # masked with exactly these runs already (the merged track of two masked ones)
             depths._bind()
-            gaps = depths.engine.to_device(np.asarray(rows, dtype=np.int32).reshape(-1, 4))
-            depths.engine.gap_mask(depths.track, gaps)
+            if lazy:
+                depths._pending_gaps = arr
+                depths.invalidate()
+                return depths
+            depths.engine.gap_mask(depths.track, depths.engine.to_device(arr))
+            depths._masked_with = arr.tobytes()
             depths.invalidate()
     return depths
 
@@ -1011,16 +1032,34 @@ def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, thread
 
 
 def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTracks = None, prefix="GCI_two_type",
-                         directory=".", force=False, threads=1, write=True) -> DepthTracks:
+                         directory=".", force=False, threads=1, write=True, issue_hint=None) -> DepthTracks:
+    """issue_hint = (leftmost, rightmost, flank_len) of the collapse_depth_range() calls that follow (as for filter()): the merge
+    is then ONE pass over the two tracks that also applies their pending N-run masks (merge_gaps_depths(lazy=True)) and finds the
+    issue runs of the HiFi, the ONT and the merged track (gci_two_type_tail) -- 12 bytes per base instead of 24."""
     print("Merging HiFi and ONT depth file ...")
     if write:
         refuse_overwrite(f"{directory}/{prefix}.depth.gz", force)
-    hifi_depths._bind()
     if nano_depths.targets != hifi_depths.targets or nano_depths.lengths != hifi_depths.lengths:
         # the reference indexes nano by the HiFi dict's keys; GCI() has already checked both headers agree
         raise KeyError("HiFi and ONT depth tracks cover different contigs")
-    merged = DepthTracks(hifi_depths.engine, hifi_depths.targets_length,
-                         hifi_depths.engine.max2(hifi_depths.track, nano_depths.track))
+    engine = hifi_depths.engine
+    pend = [d._pending_gaps for d in (hifi_depths, nano_depths)]
+    same_pending = (pend[0] is None and pend[1] is None) or (pend[0] is not None and pend[1] is not None and
+                                                             pend[0].tobytes() == pend[1].tobytes())
+    if issue_hint is not None and nano_depths.engine is engine and same_pending:
+        hifi_depths._bind_layout()
+        lo, hi, fl = float(issue_hint[0]), float(issue_hint[1]), int(issue_hint[2])
+        two, runs = engine.two_type_tail(hifi_depths.track, nano_depths.track, pend[0], lo, hi, fl)
+        merged = DepthTracks(engine, hifi_depths.targets_length, two)
+        for d, r in zip((hifi_depths, nano_depths, merged), runs):
+            if pend[0] is not None:
+                d._pending_gaps, d._masked_with = None, pend[0].tobytes()
+                d._fresh_sums = None
+            d._fresh_runs = ((lo, hi, fl), r)
+    else:
+        hifi_depths._bind()
+        nano_depths._bind()
+        merged = DepthTracks(engine, hifi_depths.targets_length, engine.max2(hifi_depths.track, nano_depths.track))
     merged.all_targets = hifi_depths.all_targets
     if write:
         write_depth(directory, prefix, merged, threads)

@@ -928,3 +928,42 @@ def test_paged_filter_of_tag_heavy_records(engine, oracle):
     assert np.array_equal((got["flags"] & 1).astype(bool), p) and p.sum() > 2000
     for f in ("contig", "start", "end", "qlen"):
         assert np.array_equal(got[f][p], want[f][p]), f
+
+
+@pytest.mark.parametrize("flank,threshold,with_gaps", [(15, 0, True), (15, 0, False), (0, 1, True), (40, 2, True)])
+def test_two_type_tail_in_one_pass_equals_the_seams(engine, oracle, flank, threshold, with_gaps):
+    """gci_two_type_tail -- N-run masks of both tracks, their per-base maximum and the issue runs of all three in ONE pass over
+    the two tracks -- against the oracle's merge_gaps_depths / max2 / collapse_depth_range, through the pipeline's lazy masks
+    (merge_gaps_depths(lazy=True) + merge_two_type_depth(issue_hint=...)): runs that start or end on tile borders, at the window
+    edges, inside and at the borders of N runs, N runs that span tiles and contigs that are shorter than a tile or than 2 flanks."""
+    rng = np.random.default_rng(100 + flank)
+    shapes = {"a": 200_001, "b": 4096, "c": 8193, "tiny": 20, "one": 2 * flank + 1, "d": 12_345}
+    h = {k: _random_depth(rng, L) for k, L in shapes.items()}
+    n = {k: _random_depth(rng, L) for k, L in shapes.items()}
+    for t in (h, n):                                  # low-depth runs right at tile borders and across them
+        t["a"][4090:4100] = 0; t["a"][8192:8200] = 0; t["a"][12280:12288] = 0
+    h["a"][100_000:100_050] = 0; n["a"][100_020:100_090] = 0      # a run of the maximum that is a run of neither alone in full
+    gaps = {"a": [(4000, 4097), (8190, 12_300), (150_000, 150_001), (199_990, 250_000), (-30, -10)], "c": [(0, 5), (8192, 8193)],
+            "tiny": [(3, 9)], "nope": [(1, 2)]} if with_gaps else None
+    th, tn = _upload_depths(engine, h), _upload_depths(engine, n)
+    pipeline.merge_gaps_depths(th, gaps, lazy=True)
+    pipeline.merge_gaps_depths(tn, gaps, lazy=True)
+    assert (th._pending_gaps is not None) == with_gaps
+    two = pipeline.merge_two_type_depth(th, tn, write=False, issue_hint=(-1, threshold, flank))
+    assert th._pending_gaps is None and tn._pending_gaps is None and two._fresh_runs is not None
+    pipeline.merge_gaps_depths(two, gaps)             # the reference masks the merged track as well (GCI.py:1019): nothing left to do
+    assert two._fresh_runs is not None
+    oracle.merge_gaps_depths(h, gaps)
+    oracle.merge_gaps_depths(n, gaps)
+    m = oracle.max2(h, n)
+    oracle.merge_gaps_depths(m, gaps)
+    for tr, want in ((th, h), (tn, n), (two, m)):
+        for k in shapes:
+            assert np.array_equal(tr[k], want[k]), k
+        assert pipeline.collapse_depth_range(tr, -1, threshold, flank, 0) == oracle.collapse_depth_range(want, -1, threshold, flank, 0)
+        fresh = tr._fresh_runs
+        tr.invalidate()                                # ... and the same from a scan of the finished track
+        assert pipeline.collapse_depth_range(tr, -1, threshold, flank, 0) == oracle.collapse_depth_range(want, -1, threshold, flank, 0)
+        assert fresh is not None
+    assert sum(len(v) for v in oracle.collapse_depth_range(m, -1, threshold, flank, 0).values()) > 5
+    assert two.mean() == oracle.mean_depth(m)
