@@ -480,6 +480,52 @@ def parity_two_type(w, chosen):
     return bool(ok), chosen
 
 
+def plot_front_end_number(w, window_size=50000, dmax=4.0):
+    """N3 at the size of configs[4] ("`-p` windowed depth"): what plot_depth() computes before it draws (GCI.py:837-868, 660-705)
+    -- per read type the global mean depth of the masked track (one read of it, gci_depth_sum) and the zero-delimited sliding-
+    window means of EVERY contig (the zero runs: one gci_issue_scan_windows over all contigs; the window sums: one gci_range_sums)
+    -- timed on the tracks the last step left, and held against the oracle's base-by-base loop on 2 Mb stretches (one of them
+    behind 2^31 elements of the track)."""
+    import torch
+    from gci_amd import pipeline
+    from oracle import gci_oracle as O
+    inp, eng = w.inp, w.eng
+    names, tl = inp.names, dict(inp.contigs)
+    tracks = [pipeline.DepthTracks(eng, tl, d["track"]) for d in w.types]
+    items = [(t, 0, None) for t in names]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    means, series = [], []
+    for tr in tracks:
+        means.append(tr.mean())
+        series.append(pipeline.sliding_window_average_depth_many(tr, items, window_size, means[-1] * dmax))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    offs = eng.offsets
+    far = max(range(len(names)), key=lambda c: offs[c])
+    picks = [(names[far], 1_000_000, 3_000_000), (names[0], 0, 2_000_000), (names[len(names) // 2], inp.lengths[len(names) // 2] - 2_000_000, None)]
+    for c, segs in list(inp.gaps.items())[:1]:                       # a stretch with an N run in it
+        a = max(0, segs[0][0] - 1_000_000)
+        picks.append((c, a, a + 2_000_000))
+    ok = True
+    for k, tr in enumerate(tracks):
+        got = pipeline.sliding_window_average_depth_many(tr, picks, window_size, means[k] * dmax)
+        for (c, a, b), (pos, val, _) in zip(picks, got):
+            host = tr[c]
+            b2 = len(host) if b is None else b
+            want_pos, want_val = O.sliding_window_average_depth(host[a:b2], window_size, means[k] * dmax, a)
+            ok = ok and pos == want_pos and np.array_equal(val, want_val)
+            del host
+        ok = ok and means[k] == float(sum(int(tr.sums()[i]) for i in range(len(names)))) / float(sum(inp.lengths))
+    n_vals = sum(len(p) for s in series for p, _, _ in s)
+    L = sum(inp.lengths)
+    return {"seconds": dt, "tracks": len(tracks), "contigs": len(names), "window_size": window_size, "values": n_vals,
+            "algorithmic_bytes": 3 * 4 * L * len(tracks), "hbm_frac": 3 * 4 * L * len(tracks) / dt / 1e9 / HBM_PEAK_GBS,
+            "parity_vs_oracle": bool(ok), "parity_stretches": ["%s:%d-%s" % (c, a, b if b is not None else "end") for c, a, b in picks],
+            "note": "per read type: mean depth (gci_depth_sum), zero runs of all contigs (one gci_issue_scan_windows), window sums (one "
+                    "gci_range_sums); three reads of each track"}
+
+
 def make_two_type_workload(eng_factory, rank, world, args, exchange, replicated):
     from gci_amd import workloads
     if world > 1:
@@ -1411,6 +1457,11 @@ def main():
         out["parity_contigs"] = chosen
         out["roofline"]["kernel"] = "k_tile_build (depth write; no text in this workload)"
         out["cpu_baseline"] = None
+        if ok and args.workload == "diploid":
+            out["plot_front_end_n3"] = plot_front_end_number(w)
+            if not out["plot_front_end_n3"]["parity_vs_oracle"]:
+                print(json.dumps(out))
+                sys.exit("PARITY FAILURE: the -p front end differs from the oracle at full size")
         if not ok:
             print(json.dumps(out))
             sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")

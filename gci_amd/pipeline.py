@@ -1144,66 +1144,95 @@ def merge_depth(depths: DepthTracks = None, prefix="GCI", threshold=0, flank_len
 # N3: the `-p` numeric front-end
 # ==============================================================================================
 
-def sliding_window_average_depth(depths: DepthTracks, target: str, window_size=50000, max_depth=None, start=0, end=None):
-    """sliding_window_average_depth(depths[target][start:end], window_size, max_depth, start, target) of the
-    reference (GCI.py:660-705) for a track in HBM: -> (positions in Mb: list of float, values: float64 array).
+def sliding_window_average_depth_many(depths: DepthTracks, items: Sequence[Tuple[str, int, Optional[int]]], window_size=50000,
+                                      max_depth=None):
+    """sliding_window_average_depth(depths[target][start:end], window_size, max_depth, start, target) of the reference
+    (GCI.py:660-705) for every (target, start, end) of `items` over a track in HBM, in TWO device calls for all of them:
+    -> [(positions in Mb: list of float, values: float64 array, the reference's warning line or None)].
 
-    The reference walks the bases one by one and restarts its window at every zero-depth base.  Which bases emit a
-    value follows from the zero runs and the window size alone, so the device finds the zero runs
-    (gci_issue_scan_windows) and sums the windows (gci_range_sums); the few thousand windows are assembled here."""
+    The reference walks the bases one by one and restarts its window at every zero-depth base.  Which bases emit a value follows
+    from the zero runs and the window size alone, so the device finds the zero runs of all items (ONE gci_issue_scan_windows)
+    and sums all their windows (ONE gci_range_sums); the few thousand windows per contig are assembled here."""
     depths._bind()
-    c = depths.targets.index(target)
-    L = depths.lengths[c]
-    a = _slice_bound(start, L)
-    b = max(a, _slice_bound(L if end is None else end, L))
-    n = b - a
-    if n < window_size:
-        print(f'Warning!!! The length ({n}) of plotting region ({target}:{start}-{start + n}) is less than the window size '
-              f'({window_size}), and therefore the window size will be 1 bp', file=sys.stderr)
-        window_size = 1
-    if n == 0:
-        return [], np.array([], dtype=np.float64)
-    o = depths.engine.offsets[c] + a
-    zero = depths.engine.issue_scan_windows(depths.track, [(o, o + n)], -1, 0)[0].reshape(-1, 2)     # runs of depth 0
-    # the non-zero runs in between
-    edges = np.concatenate([[0], zero.reshape(-1), [n]]).astype(np.int64)
-    p, q = edges[0::2], edges[1::2]
-    keep = q > p
-    p, q = p[keep], q[keep]
-    full = (q - p) // window_size                           # whole windows per run, then one partial flush
-    rem = (q - p) - full * window_size
-    # window k of run r: [p + k w, p + (k + 1) w); emitted at its last base
-    run_of = np.repeat(np.arange(p.shape[0]), full)
-    k = np.arange(int(full.sum()), dtype=np.int64) - np.repeat(np.cumsum(full) - full, full)
-    wb = p[run_of] + k * window_size
-    we = wb + window_size
-    has_rem = rem > 0
-    rb, re_ = (q - rem)[has_rem], q[has_rem]
-    begins = np.concatenate([wb, rb])
-    ends = np.concatenate([we, re_])
-    sums = depths.engine.range_sums(depths.track, np.stack([begins + o, ends + o], axis=1))
-    means = sums.astype(np.float64) / (ends - begins).astype(np.float64)    # int / int, both < 2^53: as Python's true division
-    means = np.where(means > max_depth, np.float64(max_depth), means)
-    zlen = zero[:, 1] - zero[:, 0]
-    zidx = np.repeat(zero[:, 0] - (np.cumsum(zlen) - zlen), zlen) + np.arange(int(zlen.sum()), dtype=np.int64)
-    idx = np.concatenate([ends - 1, zidx])
-    val = np.concatenate([means, np.zeros(zidx.shape[0], dtype=np.float64)])
-    order = np.argsort(idx, kind="stable")
-    idx, val = idx[order], val[order]
-    return ((idx + start) / 1e6).tolist(), val
+    geo = []
+    for target, start, end in items:
+        c = depths.targets.index(target)
+        L = depths.lengths[c]
+        a = _slice_bound(start, L)
+        b = max(a, _slice_bound(L if end is None else end, L))
+        n = b - a
+        w, warn = window_size, None
+        if n < window_size:
+            warn = (f'Warning!!! The length ({n}) of plotting region ({target}:{start}-{start + n}) is less than the window size '
+                    f'({window_size}), and therefore the window size will be 1 bp')
+            w = 1
+        geo.append((depths.engine.offsets[c] + a, n, w, warn, start))
+    live = [k for k, g in enumerate(geo) if g[1] > 0]
+    zeros = depths.engine.issue_scan_windows(depths.track, [(geo[k][0], geo[k][0] + geo[k][1]) for k in live], -1, 0) if live else []
+    plans, ranges = {}, []
+    for k, z in zip(live, zeros):
+        o, n, w, _, _ = geo[k]
+        zero = z.reshape(-1, 2)                                  # runs of depth 0, relative to the item's first base
+        edges = np.concatenate([[0], zero.reshape(-1), [n]]).astype(np.int64)       # the non-zero runs in between
+        p, q = edges[0::2], edges[1::2]
+        keep = q > p
+        p, q = p[keep], q[keep]
+        full = (q - p) // w                                      # whole windows per run, then one partial flush
+        rem = (q - p) - full * w
+        # window k of run r: [p + k w, p + (k + 1) w); emitted at its last base
+        run_of = np.repeat(np.arange(p.shape[0]), full)
+        kk = np.arange(int(full.sum()), dtype=np.int64) - np.repeat(np.cumsum(full) - full, full)
+        wb = p[run_of] + kk * w
+        has_rem = rem > 0
+        begins = np.concatenate([wb, (q - rem)[has_rem]])
+        ends = np.concatenate([wb + w, q[has_rem]])
+        plans[k] = (zero, begins, ends, len(ranges), begins.shape[0])
+        ranges.append(np.stack([begins + o, ends + o], axis=1))
+    sums = depths.engine.range_sums(depths.track, np.concatenate(ranges)) if ranges else np.zeros(0, dtype=np.int64)
+    at = np.concatenate([[0], np.cumsum([r.shape[0] for r in ranges])]).astype(np.int64) if ranges else np.zeros(1, np.int64)
+    out = []
+    for k, (o, n, w, warn, start) in enumerate(geo):
+        if n == 0:
+            out.append(([], np.array([], dtype=np.float64), warn))
+            continue
+        zero, begins, ends, slot, cnt = plans[k]
+        s = sums[int(at[slot]):int(at[slot]) + cnt]
+        means = s.astype(np.float64) / (ends - begins).astype(np.float64)   # int / int, both < 2^53: as Python's true division
+        means = np.where(means > max_depth, np.float64(max_depth), means)
+        zlen = zero[:, 1] - zero[:, 0]
+        zidx = np.repeat(zero[:, 0] - (np.cumsum(zlen) - zlen), zlen) + np.arange(int(zlen.sum()), dtype=np.int64)
+        idx = np.concatenate([ends - 1, zidx])
+        val = np.concatenate([means, np.zeros(zidx.shape[0], dtype=np.float64)])
+        order = np.argsort(idx, kind="stable")
+        idx, val = idx[order], val[order]
+        out.append((((idx + start) / 1e6).tolist(), val, warn))
+    return out
+
+
+def sliding_window_average_depth(depths: DepthTracks, target: str, window_size=50000, max_depth=None, start=0, end=None):
+    """One (target, start, end): -> (positions in Mb: list of float, values: float64 array); the reference's warning for a region
+    shorter than the window goes to stderr (GCI.py:675-677)."""
+    pos, val, warn = sliding_window_average_depth_many(depths, [(target, start, end)], window_size, max_depth)[0]
+    if warn:
+        print(warn, file=sys.stderr)
+    return pos, val
 
 
 def pre_plot_base(depths_list: Sequence[DepthTracks], max_depths: Sequence[float], window_size=50000, start=0,
                   region: Optional[Tuple[str, int, int]] = None):
     """pre_plot_base of the reference (GCI.py:708-739).  region = (target, start, end) is the reference's
-    `{target: depths[start:end]}` input of the regions loop (GCI.py:887-892); None = every contig, whole."""
+    `{target: depths[start:end]}` input of the regions loop (GCI.py:887-892); None = every contig, whole.  Per track all its
+    contigs go through the device together (two calls); the warnings come out in the reference's order (target by target)."""
+    targets = [region[0]] if region else depths_list[0].targets
+    items = [(t, region[1] if region else start, region[2] if region else None) for t in targets]
+    per_track = [sliding_window_average_depth_many(tr, items, window_size, max_depths[i]) for i, tr in enumerate(depths_list)]
     averaged = [{} for _ in depths_list]
     maxima = [[] for _ in depths_list]
-    targets = [region[0]] if region else depths_list[0].targets
-    for target in targets:
-        for i, tr in enumerate(depths_list):
-            pos, val = sliding_window_average_depth(tr, target, window_size, max_depths[i], region[1] if region else start,
-                                                    region[2] if region else None)
+    for k, target in enumerate(targets):
+        for i in range(len(depths_list)):
+            pos, val, warn = per_track[i][k]
+            if warn:
+                print(warn, file=sys.stderr)
             averaged[i][target] = (pos, val)
             maxima[i].append(max(val))
     if _sharded() and region is None:            # the axis limits span every contig: the few maxima of all ranks
