@@ -48,7 +48,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("genome", "chr19", "genome4", "diploid"), default="genome",
+    ap.add_argument("--paf-gb", type=float, default=20.0,
+                    help="--workload paf: size of the PAF text (the reference's CHM13 run reads a 48 GB ONT PAF and a 3.6 GB HiFi PAF)")
+    ap.add_argument("--workload", choices=("genome", "chr19", "genome4", "diploid", "paf"), default="genome",
                     help="genome: BASELINE configs[2] (default); chr19: configs[1], one contig and one BAM per rank; genome4: configs[3] "
                          "on ONE GPU (CHM13, --hifi + --nano, per read type one BAM + one PAF: two filters, max, three issue scans, three "
                          "tracks); diploid: configs[4] on ONE GPU (mat + pat, 46 contigs, 6.2 Gb, HiFi 100x + ONT, 20 N gaps, -R regions)")
@@ -1256,8 +1258,106 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def paf_number(args):
+    """K2 at the size of the reference's published run (README.md:321: a 48 GB ONT PAF + a 3.6 GB HiFi PAF): `--paf-gb` GB of PAF text
+    through gci_paf_filter_device (the PAF path of filter(), GCI.py:211-254), text resident in HBM.  The text is a chunk of ~1 M
+    lines -- the PAF view of simulated HiFi reads over CHM13, 2 % of them split into 2 - 3 blocks (synth.to_paf_text) -- repeated
+    with the chunk number written into every query name, so every chunk has its own queries; a query's lines all lie in its chunk
+    and the filter treats every query independently, so the oracle over chunk 0 alone is the exact expectation for chunk 0's
+    queries (and, with the chunk number replaced, for every other chunk's)."""
+    import tempfile
+    import torch
+    from gci_amd import synth
+    from gci_amd.device import Engine, REC_DTYPE
+    from oracle import gci_oracle as O
+    contigs = synth.CHM13
+    names = [n for n, _ in contigs]
+    t0 = time.perf_counter()
+    rs = synth.simulate_reads(contigs, 6.0, "hifi", seed=synth.seed_for(4, 1), name_prefix="c0000/m64011_190830/")
+    other = synth.perturb(rs, synth.seed_for(4, 3))
+    other.contigs = tuple(contigs)
+    chunk = synth.to_paf_text(other, synth.seed_for(4, 11))
+    keep = ((other.flag & 0x4) == 0) & ((other.flag & 0x100) == 0)
+    aligned_chunk = int(other.ref_span()[keep].sum())
+    del rs, other
+    nl = np.flatnonzero(chunk == 10)
+    starts = np.concatenate([[0], nl[:-1] + 1]).astype(np.int64)
+    assert bytes(chunk[:5]) == b"c0000"
+    K = max(1, int(round(args.paf_gb * 1e9 / chunk.shape[0])))
+    if K > 9999:
+        sys.exit("bench.py --workload paf: at most 9999 chunks")
+    text = np.empty(K * chunk.shape[0] + 16, dtype=np.uint8)
+    text[-16:] = 0
+    for k in range(K):
+        seg = text[k * chunk.shape[0]:(k + 1) * chunk.shape[0]]
+        seg[:] = chunk
+        digits = np.frombuffer(b"%04d" % k, dtype=np.uint8)
+        for j in range(4):
+            seg[starts + 1 + j] = digits[j]
+    n_bytes = K * int(chunk.shape[0])
+    t_gen = time.perf_counter() - t0
+    eng = Engine(0)
+    t0 = time.perf_counter()
+    d_text = eng.to_device(text)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter() - t0
+    ends = np.asarray([n_bytes], dtype=np.uint64)
+    for _ in range(max(1, args.warmup)):
+        out = eng.paf_filter_text(d_text, ends, names, FILTER[0], FILTER[1], FILTER[3])
+        del out
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.paf_filter_text(d_text, ends, names, FILTER[0], FILTER[1], FILTER[3])
+        if _ + 1 < args.steps:
+            del out
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # ---- parity: chunk 0 (and the last chunk) against the oracle over the chunk's own text
+    with tempfile.TemporaryDirectory() as tmp:
+        p = os.path.join(tmp, "chunk0.paf")
+        chunk.tofile(p)
+        want, want_hq = O.paf_filter([p], names, FILTER[0], FILTER[1], FILTER[3])
+    want = want[0]
+    recs = out[0].recs.cpu().numpy().reshape(-1).view(REC_DTYPE)
+    noff = out[0].name_off.cpu().numpy()
+    ok = True
+    for k in sorted({0, K - 1}):
+        lo, hi = k * chunk.shape[0], (k + 1) * chunk.shape[0]
+        sel = np.flatnonzero((noff >= lo) & (noff < hi))
+        got = {}
+        for i in sel.tolist():
+            nm = bytes(text[int(noff[i]):int(noff[i]) + int(recs["name_len"][i])]).decode()
+            got["c0000" + nm[5:]] = (names[int(recs["contig"][i])], int(recs["start"][i]), int(recs["end"][i]), int(recs["qlen"][i]),
+                                     bool(recs["flags"][i] & 2))
+            ok = ok and nm[:5] == "c%04d" % k
+        exp = {q: (s[0], s[1], s[2], s[3], q in want_hq) for q, s in want.items()}
+        ok = ok and got == exp
+    n_lines = K * int(nl.shape[0])
+    return {"seconds_per_pass": dt, "paf_bytes": n_bytes, "lines": n_lines, "queries_out": int(recs.shape[0]), "chunks": K,
+            "ms_per_gb_of_text": dt * 1e3 / (n_bytes / 1e9), "text_gb_per_s": n_bytes / dt / 1e9, "lines_per_s": n_lines / dt,
+            "aligned_bases": K * aligned_chunk, "parity_vs_oracle_chunks": sorted({0, K - 1}), "parity": bool(ok),
+            "h2d_seconds_outside_the_pass": t_h2d, "generation_seconds": t_gen}
+
+
 def main():
     args = parse_args()
+    if args.workload == "paf":
+        r = paf_number(args)
+        out = {"metric": "aligned Gbases/s through filter+depth pipeline (CHM13, 40x HiFi)", "value": r["aligned_bases"] / r["seconds_per_pass"] / 1e9,
+               "unit": "Gbases/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["seconds_per_pass"] * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64 / f64", "data": "synthetic",
+               "config": {"workload": "the PAF half of filter() alone (K2, GCI.py:211-254): %.1f GB of PAF text resident in HBM, one pass = "
+                                      "line starts -> tokenise + filter -> query table -> per-query scoring" % (r["paf_bytes"] / 1e9),
+                          "baseline_config": "the PAF inputs of configs[3] at the size of the reference's published run"},
+               "roofline": {"bound": "hbm", "kernel": "K2 as a whole (seven k_paf_* kernels + scans)", "achieved": r["text_gb_per_s"],
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["text_gb_per_s"] / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_launch": r["paf_bytes"]},
+               "cpu_baseline": None, "paf": r}
+        print(json.dumps(out), flush=True)
+        if not r["parity"]:
+            sys.exit("PARITY FAILURE: the PAF filter differs from the oracle")
+        return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -65,8 +65,6 @@ struct gci_ctx {
     DevBuf join_bucket;                     // partitioned join: per bucket its survivor count, first slot and output offset
     DevBuf part_a, part_b, part_hist, part_blk;   // partitioned join: entry ping-pong, histograms + segment table, scan totals
     DevBuf route_tab;                       // gci_route_*: per (part, chunk) counts and their scan
-    DevBuf inflate_sorted;                  // gci_bgzf_inflate_device built with INF_SORTED_GLOBAL: 288 uint16 per member
-    DevBuf inflate_bitmap;                  // two-phase inflate: one bit per output byte, set where a match token lies
     DevBuf deflate_nruns, deflate_runs;     // gci_depth_deflate_*: per tile its constant-depth runs (k_depth_runs)
     uint32_t deflate_members = 0;           // ... of the members the last size call measured,
     const void* deflate_key_depth = nullptr;    // ... over this track

@@ -60,30 +60,16 @@ struct alignas(16) Canon { uint16_t limit[16]; int16_t off[16]; uint16_t next[16
 
 // What one member's decoder keeps in LDS: 1.3 KB, which is what bounds the members a CU decodes at a time.  The code
 // lengths of a block are only needed until its codes are built and share the primary table's space.
-// INF_SORTED_GLOBAL: the literal / length symbols sorted by code (576 of the 1344 bytes) live in a scratch buffer in global
-// memory instead -- they are read when a code is longer than LIT_BITS and while the tables are built, and 768 bytes per member
-// let a CU decode 208 members at a time instead of 119 (if the registers allow as many waves: INF_WAVES).
-#ifndef INF_SORTED_GLOBAL
-#define INF_SORTED_GLOBAL 0
-#endif
-#ifndef INF_WAVES
 #define INF_WAVES 4
-#endif
-#ifndef INF_DIST_BITS
-#define INF_DIST_BITS 5                // 0: distances through the 15 limits only (rounds 2 - 3a); 5: -2 %; 6 and 7 cost a workgroup per CU
-#endif
+#define INF_DIST_BITS 5                // primary table of the distance codes: 5 bits (-2 % against none; 6 and 7 cost a workgroup per CU)
 struct alignas(16) LaneTabs {
     union {
         uint16_t lit_tab[1 << LIT_BITS];
         uint8_t lens[352];          // [0, 19): the code-length code; [32, 32 + 286 + 30): both alphabets
     };
-#if !INF_SORTED_GLOBAL
     uint16_t lit_sorted[288];
-#endif
     uint16_t dist_sorted[32];
-#if INF_DIST_BITS
     uint16_t dist_tab[1 << INF_DIST_BITS];     // primary table of the distance codes (symbol | length << 9), like lit_tab
-#endif
     Canon lit_cn, dist_cn;
 };
 static_assert(sizeof(uint16_t) << LIT_BITS >= 352, "the code lengths must fit under the primary table");
@@ -206,20 +192,11 @@ __device__ __forceinline__ int decode(Bits& B, const uint16_t* table, const Cano
 }  // namespace
 
 // One lane = one member; INF_LANES members per workgroup (one wave; its other lanes leave at once).
-//
-// TOKENS (round 4: the two-phase inflate).  With the copies in it, the lanes of a wave spend their time apart: one walks a
-// literal run while its neighbours wait for the store -> load round trips of their matches (~0.4 us each), so more than 8
-// members per wave only added waiting.  With TOKENS the kernel DECODES only: a match leaves a 3-byte token at the place of its
-// first three bytes -- length - 3, distance - 1 (15 bits): a match is at least three bytes long, so the token always fits --
-// and one bit in `bitmap` (one bit per output byte, a member's words start at word (o0 >> 6) + m), and nothing is read back.
-// k_bgzf_copy then resolves the matches: one lane per member again, but no tables, no LDS, every lane of every wave busy and
-// ten thousand waves in flight to cover the round trips.
-template <int INF_LANES, bool TOKENS>
+template <int INF_LANES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF_WAVES, INF_WAVES)))
 void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
                     const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
-                    uint64_t out_cap, unsigned long long* __restrict__ status, uint16_t* __restrict__ sorted_scratch,
-                    unsigned long long* __restrict__ bitmap)
+                    uint64_t out_cap, unsigned long long* __restrict__ status)
 {
     __shared__ LaneTabs tabs[INF_LANES];
     const int lane = threadIdx.x;
@@ -227,13 +204,7 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
     const uint32_t m = blockIdx.x * INF_LANES + lane;
     if (m >= n_members) return;
     LaneTabs& T = tabs[lane];
-#if INF_SORTED_GLOBAL
-    typedef __attribute__((address_space(1))) uint16_t gu16;
-    gu16* const lit_sorted = (gu16*)(sorted_scratch + (size_t)m * 288);
-#else
     uint16_t* const lit_sorted = T.lit_sorted;
-    (void)sorted_scratch;
-#endif
     const uint64_t pos = member_pos[m], pos_next = member_pos[m + 1];
     const uint64_t o0 = out_off[m];
     const uint32_t isize = (uint32_t)(out_off[m + 1] - o0);
@@ -276,14 +247,6 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
         ob |= (unsigned long long)byte << (8 * oc);
         oc++; op++;
         if (oc == 8) { st8(dst + op - 8, ob); ob = 0; oc = 0; }
-    };
-    // TOKENS: the bits of the 64 output positions [64 bw, 64 bw + 64) gather in `bm`; a word is stored when the output moves past it
-    unsigned long long bm = 0;
-    uint32_t bw = 0;
-    unsigned long long* const bmw = TOKENS ? bitmap + (o0 >> 6) + m : nullptr;
-    auto mark = [&](uint32_t at) __attribute__((always_inline)) {          // a match starts at output position `at` (>= 64 bw)
-        while ((at >> 6) != bw) { bmw[bw] = bm; bm = 0; bw++; }
-        bm |= 1ull << (at & 63u);
     };
     for (bool last = false; !last && !bad;) {
         // every block header must lie inside the payload (a damaged stream of empty non-final blocks would never end otherwise:
@@ -332,48 +295,7 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
             if (!build_code(ll, hlit, T.lit_cn, lit_sorted) || !build_code(ll + hlit, hdist, T.dist_cn, T.dist_sorted)) { bad = true; break; }
         }
         build_table<LIT_BITS>(T.lit_cn, lit_sorted, T.lit_tab);
-#if INF_DIST_BITS
         build_table<INF_DIST_BITS>(T.dist_cn, T.dist_sorted, T.dist_tab);
-#endif
-        if (TOKENS) {
-            // ---- symbols of the block, ONE per lane and iteration, whatever it is: literal and match are two sides of an `if`
-            // inside the body, so the lanes stay together symbol by symbol -- and zlib closes a block after a fixed number of
-            // symbols (lit_bufsize), so they also reach the ends of their blocks together.  (The loop below, which walks a
-            // whole run of literals before it looks at a match, lets a lane in a quality stretch -- a match every other symbol --
-            // wait for its neighbour's fifty literals of sequence: at 8 lanes per wave it issued 26 wave-instructions per
-            // symbol where a literal takes ~50 for all of them.)
-            for (;;) {
-                need32(B);
-                const int sym = decode<LIT_BITS, 15>(B, T.lit_tab, T.lit_cn, lit_sorted);
-                if (sym < 0 || sym > 285) { bad = true; break; }
-                if (sym == 256) break;
-                if (sym < 256) {
-                    if (op >= isize) { bad = true; break; }
-                    emit((uint32_t)sym);
-                } else {
-                    const uint32_t lc = (uint32_t)sym - 257u;
-                    const uint32_t le = lc < 8u || lc == 28u ? 0u : (lc >> 2) - 1u;
-                    const uint32_t len = (lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << le)) + take(B, (int)le);
-                    need32(B);
-#if INF_DIST_BITS
-                    const int ds = decode<INF_DIST_BITS, 15>(B, T.dist_tab, T.dist_cn, T.dist_sorted);
-#else
-                    const int ds = decode<0, 15>(B, nullptr, T.dist_cn, T.dist_sorted);
-#endif
-                    if (ds < 0 || ds > 29) { bad = true; break; }
-                    const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
-                    const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
-                    if (dist > op || op + len > isize) { bad = true; break; }
-                    // the token takes the place of the match's first three bytes and travels with the literals
-                    mark(op);
-                    const uint32_t d1 = dist - 1u;
-                    emit(len - 3u); emit(d1 & 0xFFu); emit(d1 >> 8);
-                    flush();
-                    op += len - 3u;
-                }
-            }
-            continue;
-        }
         // ---- symbols of the block: runs of literals (the lanes of the wave meet again at their next match) -------------------
         for (;;) {
             int sym;
@@ -392,12 +314,8 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
             const uint32_t le = lc < 8u || lc == 28u ? 0u : (lc >> 2) - 1u;
             uint32_t len = (lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << le)) + take(B, (int)le);
             need32(B);
-#if INF_DIST_BITS
             // (distance symbol 0 with a code of l bits is the entry l << 9: never 0, so "0 = longer code" stays unambiguous)
             const int ds = decode<INF_DIST_BITS, 15>(B, T.dist_tab, T.dist_cn, T.dist_sorted);
-#else
-            const int ds = decode<0, 15>(B, nullptr, T.dist_cn, T.dist_sorted);
-#endif
             if (ds < 0 || ds > 29) { bad = true; break; }
             const uint32_t de = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
             const uint32_t dist = (ds < 4 ? (uint32_t)ds + 1u : 1u + ((2u + ((uint32_t)ds & 1u)) << de)) + take(B, (int)de);
@@ -447,100 +365,12 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
         }
     }
     flush();
-    if (TOKENS && !bad) {                                                       // the rest of the member's bitmap words
-        const uint32_t nw = (isize + 63u) >> 6;
-        while (bw < nw) { bmw[bw] = bm; bm = 0; bw++; }
-    }
     if (!bad && op != isize) bad = true;
     if (!bad) {                                                                // the stream may not run past the payload
         const long long bits = 32ll * B.taken - 8ll * head - B.bn;
         if (bits > 8ll * pay_len) bad = true;
     }
     if (bad) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
-}
-
-// Phase 2 of the two-phase inflate: the matches k_bgzf_inflate<., true> left as tokens, resolved in order by one lane per
-// member.  The output buffer is the window: a lane's stores and loads stay in order, so a match reads what the matches before
-// it wrote.  No tables, no LDS, 64 members per wave: what hides the two round trips per match is the number of waves in flight.
-// Every token is checked against the member's bounds (a member the decoder gave up on leaves arbitrary words behind).
-__global__ __launch_bounds__(256) void k_bgzf_copy(const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
-                                                   const unsigned long long* __restrict__ bitmap)
-{
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= n_members) return;
-    const uint64_t o0 = out_off[m];
-    const uint32_t isize = (uint32_t)(out_off[m + 1] - o0);
-    if (isize > 65536u) return;
-    uint8_t* const dst = out + o0;
-    const unsigned long long* const bmw = bitmap + (o0 >> 6) + m;
-    const uint32_t nw = (isize + 63u) >> 6;
-    // exactly n (1 .. 8) bytes: what lies behind a match is final already (the literals and tokens of phase 1)
-    auto store_n = [](uint8_t* t, unsigned long long v, uint32_t n) __attribute__((always_inline)) {
-        if (n >= 8u) { st8(t, v); return; }
-        if (n & 4u) { const uint32_t x = (uint32_t)v; __builtin_memcpy(t, &x, 4); t += 4; v >>= 32; }
-        if (n & 2u) { const uint16_t x = (uint16_t)v; __builtin_memcpy(t, &x, 2); t += 2; v >>= 16; }
-        if (n & 1u) *t = (uint8_t)v;
-    };
-    // The bitmap words one ahead, the token of the NEXT match loaded before the current one is copied: a match then costs one
-    // round trip (its source must be read behind the stores of the match before it), not three dependent ones.
-    uint32_t wi = 0;
-    unsigned long long w = nw ? bmw[0] : 0ull, w_next = nw > 1 ? bmw[1] : 0ull;
-    auto next_token = [&](uint32_t& pos) __attribute__((always_inline)) -> bool {
-        while (!w) {
-            wi++;
-            if (wi >= nw) return false;
-            w = w_next;
-            w_next = wi + 1 < nw ? bmw[wi + 1] : 0ull;
-        }
-        pos = wi * 64u + (uint32_t)__builtin_ctzll(w);
-        w &= w - 1ull;
-        return pos + 3u <= isize;
-    };
-    uint32_t npos = 0, n0 = 0, n1 = 0, n2 = 0;
-    bool have = next_token(npos);
-    if (have) { n0 = dst[npos]; n1 = dst[npos + 1]; n2 = dst[npos + 2]; }
-    while (have) {
-        const uint32_t pos = npos;
-        uint32_t len = n0 + 3u;
-        const uint32_t dist = (n1 | (n2 << 8)) + 1u;
-        have = next_token(npos);
-        if (have) { n0 = dst[npos]; n1 = dst[npos + 1]; n2 = dst[npos + 2]; }       // (it lies behind what this match writes)
-        if (dist > pos || pos + len > isize) continue;
-        uint8_t* to = dst + pos;
-        const uint8_t* src = to - dist;
-        if (dist >= 8) {
-            // up to four 8-byte pieces per round trip: as many as lie wholly in front of what the round itself writes
-            while (len) {
-                const uint32_t nb = min(min(4u, dist >> 3), (len + 7u) >> 3);
-                unsigned long long v[4];
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) v[i] = i < nb ? ld8(src + 8 * i) : 0ull;
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++)
-                    if (i < nb) store_n(to + 8 * i, v[i], min(8u, len - 8u * i));
-                const uint32_t adv = min(len, 8u * nb);
-                src += adv; to += adv; len -= adv;
-            }
-        } else {
-            // a short period: its bytes once, made periodic over eight bytes, stored in steps of whole periods
-            unsigned long long pat = 0;
-            if (pos >= 8) pat = ld8(to - 8) >> (8 * (8 - dist));
-            else {
-#pragma unroll
-                for (int i = 0; i < 7; i++) pat |= (unsigned long long)((uint32_t)i < dist ? src[i] : (uint8_t)0) << (8 * i);
-            }
-            pat &= ~0ull >> (8 * (8 - dist));
-            if (dist < 8) pat |= pat << (8 * dist);
-            if (dist < 4) pat |= pat << (16 * dist);
-            if (dist < 2) pat |= pat << 32;
-            const uint32_t step = dist * (8u / dist);
-            while (len) {
-                const uint32_t adv = min(len, step);
-                store_n(to, pat, adv);
-                to += adv; len -= adv;
-            }
-        }
-    }
 }
 
 // CRC-32 of every member's output against its trailer: one wave per member.
@@ -606,39 +436,16 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
     if (n_members) {
         // members per wave: fewer = more waves per SIMD to overlap the memory round trips, more = fewer instructions issued
-        static const int lanes = [] { const char* e = getenv("GCI_INFLATE_LANES"); return e ? atoi(e) : 0; }();   // 0: the mode's default
-        uint16_t* sorted_scratch = nullptr;
-#if INF_SORTED_GLOBAL
-        GCI_TRY(gci_ensure(ctx, ctx->inflate_sorted, (size_t)n_members * 288 * 2));
-        sorted_scratch = (uint16_t*)ctx->inflate_sorted.p;
-#endif
-        // GCI_INFLATE_PHASES=1: the round-2 / 3 kernel (decode and copy in one); 2 (default): decode to tokens, then k_bgzf_copy
-        static const int phases = [] { const char* e = getenv("GCI_INFLATE_PHASES"); return e ? atoi(e) : 2; }();
-        unsigned long long* bitmap = nullptr;
-        if (phases == 2) {
-            GCI_TRY(gci_ensure(ctx, ctx->inflate_bitmap, ((size_t)(out_cap >> 6) + n_members + 2) * 8));
-            bitmap = (unsigned long long*)ctx->inflate_bitmap.p;
-        }
+        static const int lanes = [] { const char* e = getenv("GCI_INFLATE_LANES"); return e ? atoi(e) : 8; }();
         auto launch = [&](auto kern, int per) {
             hipLaunchKernelGGL(kern, dim3((n_members + per - 1) / per), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, n_members,
-                               d_out, out_cap, (unsigned long long*)d_status, sorted_scratch, bitmap);
+                               d_out, out_cap, (unsigned long long*)d_status);
         };
-        if (phases == 2) {
-            if (lanes == 8) launch(k_bgzf_inflate<8, true>, 8);
-            else if (lanes == 32) launch(k_bgzf_inflate<32, true>, 32);
-            else if (lanes == 64) launch(k_bgzf_inflate<64, true>, 64);
-            else launch(k_bgzf_inflate<16, true>, 16);
-            LAUNCHCHK("k_bgzf_inflate<tokens>");
-            hipLaunchKernelGGL(k_bgzf_copy, dim3((n_members + 255) / 256), dim3(256), 0, ctx->stream, d_out_off, n_members, d_out,
-                               (const unsigned long long*)bitmap);
-            LAUNCHCHK("k_bgzf_copy");
-        } else {
-            if (lanes == 4) launch(k_bgzf_inflate<4, false>, 4);
-            else if (lanes == 16) launch(k_bgzf_inflate<16, false>, 16);
-            else if (lanes == 32) launch(k_bgzf_inflate<32, false>, 32);
-            else launch(k_bgzf_inflate<8, false>, 8);
-            LAUNCHCHK("k_bgzf_inflate");
-        }
+        if (lanes == 4) launch(k_bgzf_inflate<4>, 4);
+        else if (lanes == 16) launch(k_bgzf_inflate<16>, 16);
+        else if (lanes == 32) launch(k_bgzf_inflate<32>, 32);
+        else launch(k_bgzf_inflate<8>, 8);
+        LAUNCHCHK("k_bgzf_inflate");
         if (check_crc) {
             hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, ctx->stream, d_raw, d_member_pos,
                                d_out_off, n_members, (const uint8_t*)d_out, (unsigned long long*)d_status);
@@ -658,26 +465,8 @@ extern "C" uint32_t gci_bgzf_inflate_round(gci_ctx* ctx)
     int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    const char* e = getenv("GCI_INFLATE_PHASES");
-    const char* l = getenv("GCI_INFLATE_LANES");
-    const int two = !e || atoi(e) == 2, lanes = l ? atoi(l) : 0;
-    hipError_t r;
-    int per = 8;
-    if (two) {
-        per = lanes == 8 ? 8 : lanes == 32 ? 32 : lanes == 64 ? 64 : 16;
-        r = per == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8, true>, 64, 0)
-          : per == 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<32, true>, 64, 0)
-          : per == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<64, true>, 64, 0)
-          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<16, true>, 64, 0);
-    } else {
-        per = lanes == 4 ? 4 : lanes == 16 ? 16 : lanes == 32 ? 32 : 8;
-        r = per == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<4, false>, 64, 0)
-          : per == 16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<16, false>, 64, 0)
-          : per == 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<32, false>, 64, 0)
-          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8, false>, 64, 0);
-    }
-    if (r != hipSuccess) return 0;
-    return (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu * per : 0);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bgzf_inflate<8>, 64, 0) != hipSuccess) return 0;
+    return (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu * 8 : 0);
 }
 
 // =====================================================================================================================

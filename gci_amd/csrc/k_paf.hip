@@ -92,12 +92,21 @@ __global__ __launch_bounds__(BLOCK) void k_paf_lines(const uint8_t* __restrict__
 // Where the bytes of the text are read from: the text itself, or the copy of a stretch of it a workgroup holds in LDS
 // (`origin` = the position of the copy's first byte).
 struct GlobalSrc {
+    static constexpr bool WIDE = false;
     const uint8_t* __restrict__ p;
     __device__ __forceinline__ uint8_t operator[](uint64_t i) const { return p[i]; }
+    __device__ __forceinline__ unsigned long long load8(uint64_t) const { return 0; }
 };
 struct LdsSrc {
+    static constexpr bool WIDE = true;                     // eight bytes at any address in one read (the copy has 16 bytes of slack)
     const uint8_t* l; uint64_t origin;
     __device__ __forceinline__ uint8_t operator[](uint64_t i) const { return l[(uint32_t)(i - origin)]; }
+    __device__ __forceinline__ unsigned long long load8(uint64_t i) const
+    {
+        unsigned long long v;
+        __builtin_memcpy(&v, l + (uint32_t)(i - origin), 8);
+        return v;
+    }
 };
 
 // Python's int() on a column: optional blanks, optional sign, digits with single underscores between them ('1_000' is
@@ -162,16 +171,41 @@ __device__ __forceinline__ uint32_t paf_line(const Src text, uint64_t a, uint64_
     col[0] = a;
     uint64_t q = a;
     bool eol = false;
-    for (;;) {
-        if (q >= hi) { eol = true; break; }
-        const uint8_t c = text[q];
-        if (c == '\n' || c == '\r') { eol = true; break; }
-        if (c == '\t') {
-            cend[nc] = q;
-            if (nc == 11) break;                      // column 11 ends at a tab: nothing behind it matters
-            col[++nc] = q + 1;
+    if (Src::WIDE) {
+        // eight bytes per step: the tabs and line ends among them by exact byte-wise zero detection (no false positives: the
+        // per-byte add cannot carry into its neighbour)
+        for (bool done = false; !done;) {
+            if (q >= hi) { eol = true; break; }
+            const unsigned long long x = text.load8(q);
+            const uint32_t lim = hi - q < 8 ? (uint32_t)(hi - q) : 8u;
+            auto zeros = [](unsigned long long v) __attribute__((always_inline)) {
+                const unsigned long long k = 0x7f7f7f7f7f7f7f7fULL;
+                return ~(((v & k) + k) | v | k);                         // 0x80 in every byte of v that is zero
+            };
+            unsigned long long m = zeros(x ^ 0x0909090909090909ULL) | zeros(x ^ 0x0a0a0a0a0a0a0a0aULL) | zeros(x ^ 0x0d0d0d0d0d0d0d0dULL);
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m) >> 3;
+                m &= m - 1ull;
+                if (b >= lim) break;
+                if (((x >> (8 * b)) & 0xFFu) != '\t') { q += b; eol = true; done = true; break; }
+                cend[nc] = q + b;
+                if (nc == 11) { q += b; done = true; break; }            // column 11 ends at a tab: nothing behind it matters
+                col[++nc] = q + b + 1;
+            }
+            if (!done) q += lim;
         }
-        q++;
+    } else {
+        for (;;) {
+            if (q >= hi) { eol = true; break; }
+            const uint8_t c = text[q];
+            if (c == '\n' || c == '\r') { eol = true; break; }
+            if (c == '\t') {
+                cend[nc] = q;
+                if (nc == 11) break;                      // column 11 ends at a tab: nothing behind it matters
+                col[++nc] = q + 1;
+            }
+            q++;
+        }
     }
     if (eol) {
         // str.strip(): blanks (tabs too) at the end of the line go before it is split

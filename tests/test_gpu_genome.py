@@ -104,6 +104,9 @@ def test_two_read_types_bam_and_paf_match_oracle(engine, oracle, config):
     assert ok and len(used) >= 3
     # every long ONT CIGAR went through the blob and the chunk queue: ONT records pass the filter at all
     assert int(w.types[1]["count"].item()) > 0.3 * inp.nano.n_reads
+    if config == 5:                                      # configs[4] names "-p windowed depth": the numeric front end on all contigs
+        n3 = bench.plot_front_end_number(w)
+        assert n3["parity_vs_oracle"] and n3["values"] > 46 and n3["contigs"] == 46
     del w
     import torch
     torch.cuda.empty_cache()

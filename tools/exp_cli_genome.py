@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""The command line as a process of its own on two whole-genome BGZF BAM files at a chosen scale (bench.py's
+survey_8d.3_command_line_genome leg alone): files written to tmpfs from the heads streams of workloads.genome_dual, `python GCI.py`
+timed with its phase log, outputs held against the oracle on three contigs.  Usage: exp_cli_genome.py [scale] [--keep DIR]
+With GCI_EXP_PROFILE=1 the run is repeated under rocprofv3 --kernel-trace --stats (kernel table printed)."""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from gci_amd import workloads, synth
+from oracle import gci_oracle as O
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+inp = workloads.genome_dual(scale, 40.0, contigs=synth.CHM13, verbose=True)
+O.build()
+names = inp.names
+chosen = ["chr14", "chr22", "chrM"]
+file1 = O.file1_on_contigs([(f.stream, f.offsets, names) for f in inp.files], names, chosen, *bench.FILTER, bench.OVLP, heads=True)
+tl = {c: inp.lengths[names.index(c)] for c in chosen}
+depths = O.depth_build(file1, tl, bench.FLANK)
+orc = {"depths": depths, "bed": O.collapse_depth_range(depths, -1, 0, bench.FLANK, 0), "lengths": tl}
+if os.environ.get("GCI_EXP_PROFILE"):
+    # keep the files: run the command line once more under the profiler
+    import tempfile, shutil
+    from gci_amd import hostio
+    tmp = tempfile.mkdtemp(prefix="gci_cli_prof_", dir="/dev/shm")
+    try:
+        bams = []
+        for k, f in enumerate(inp.files):
+            p = os.path.join(tmp, "a%d.bam" % k)
+            workloads.write_bgzf_from_heads(p, f.stream, f.offsets, seed=20250919 + k)
+            bams.append(p)
+        fa = os.path.join(tmp, "ref.fa")
+        synth.write_reference_fasta(fa, inp.contigs)
+        env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")
+        out = os.path.join(ROOT, "gpurun_out", "cli_prof")
+        shutil.rmtree(out, ignore_errors=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "cli", "--",
+               sys.executable, os.path.join(ROOT, "GCI.py"), "-r", fa, "--hifi"] + bams + ["-d", os.path.join(tmp, "out"), "-t", str(hostio.default_threads())]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd="/tmp")
+        print("profiled run: rc %d, %.2f s" % (r.returncode, time.perf_counter() - t0), r.stderr[-500:] if r.returncode else "")
+        ph = json.load(open(os.path.join(tmp, "ph.json")))
+        ph["notes"] = {k: v for k, v in ph["notes"].items() if not k.startswith("depth_gz_layout")}
+        print(json.dumps(ph, indent=1))
+        if os.environ.get("GCI_EXP_CPROFILE"):
+            # once more in this process under cProfile: where the HOST spends the time the kernels do not account for
+            import cProfile, pstats, io, contextlib
+            from gci_amd import cli
+            pr = cProfile.Profile()
+            with contextlib.redirect_stdout(io.StringIO()):
+                pr.enable()
+                cli.main(["GCI.py", "-r", fa, "--hifi"] + bams + ["-d", os.path.join(tmp, "out2"), "-t", str(hostio.default_threads())])
+                pr.disable()
+            st = io.StringIO()
+            pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+            print(st.getvalue()[:9000])
+        import csv, glob
+        for fcsv in glob.glob(out + "/**/*kernel_stats.csv", recursive=True):
+            rows = sorted(csv.DictReader(open(fcsv)), key=lambda r: -float(r["TotalDurationNs"]))
+            for r in rows[:25]:
+                print("%-70s %6s calls %10.3f ms total %8.3f ms avg" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e6))
+        for fcsv in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
+            os.remove(fcsv)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+else:
+    print(json.dumps(bench.cli_genome_number(inp, orc), indent=1))
