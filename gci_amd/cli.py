@@ -161,6 +161,8 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         _usable_directory(f"{directory}/images")
         image_type = image_type.lower()
 
+    # (the member tables of the BAM files are started on now, on helper threads: nothing below waits for them before filter())
+    pipeline.prefetch_member_tables([p for files in (hifi, nano) if files for p in files if p.endswith(".bam") and os.path.isfile(p)])
     with phases.wall("fasta_read_and_title_index"):
         ref_ids = fasta.record_ids_indexed(reference)
     _check_names(ref_ids, chrs_list, regions_bed)

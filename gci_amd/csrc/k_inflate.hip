@@ -180,9 +180,14 @@ __device__ __forceinline__ int decode(Bits& B, const uint16_t* table, const Cano
     if (PRIMARY + 1 < 8) { const uint4 v = *reinterpret_cast<const uint4*>(&cn.limit[0]); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
     if (MAXL >= 8) { const uint4 v = *reinterpret_cast<const uint4*>(&cn.limit[8]); w[4] = v.x; w[5] = v.y; w[6] = v.z; w[7] = v.w; }
     const uint32_t c = __brev((uint32_t)B.bb) >> 17;
-    int l = PRIMARY + 1;
+    // the length = the number of limits <= c among limit[0 .. 15] (limit[0] = 0 is the "1 +"; the limits of the lengths the primary
+    // table covers are <= c for a code that is not in it, and a word that was not loaded is 0: counted as it should be).  Two limits
+    // per word: with c < 2^15 and limit <= 2^15, (c + 2^15) - limit has bit 15 set iff c >= limit and never borrows from the half
+    // above it -- one subtraction, one AND and one population count per pair instead of two compares and their bookkeeping.
+    const uint32_t c2 = (c | (c << 16)) + 0x80008000u;
+    int l = 0;
 #pragma unroll
-    for (int k = PRIMARY + 1; k <= MAXL; k++) l += c >= ((w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) ? 1 : 0;
+    for (int k = 0; k < (MAXL >= 8 ? 8 : 4); k++) l += __builtin_popcount((c2 - w[k]) & 0x80008000u);
     if (l > MAXL) return -1;
     const int at = (int)cn.off[l] + (int)(c >> (15 - l));
     B.bb >>= l; B.bn -= l;

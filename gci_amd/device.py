@@ -402,10 +402,11 @@ class Engine:
         """Members gci_bgzf_inflate_device decodes at a time on this device (0: unknown)."""
         return int(self.lib.gci_bgzf_inflate_round(self.ctx))
 
-    def start_upload(self, raw: np.ndarray, parts: int = 2):
+    def start_upload(self, raw: np.ndarray, parts: int = 2, forget=None):
         """Begin uploading the bytes of a BGZF file in `parts` pieces on a copy stream of its own (a helper thread: the
         copies come from pageable memory and block their caller) -> a handle for bgzf_inflate_uploaded, which starts
-        inflating the members of a piece as soon as that piece has arrived."""
+        inflating the members of a piece as soon as that piece has arrived.  forget(raw, lo, hi): called behind every piece (a
+        memory-mapped file: pipeline._forget_pages)."""
         from concurrent.futures import ThreadPoolExecutor
         n_raw = int(raw.shape[0])
         cuts = sorted({min(n_raw, (n_raw * (k + 1) // parts + 15) & ~15) for k in range(parts)} | {n_raw})
@@ -425,6 +426,8 @@ class Engine:
                 for k, hi in enumerate(cuts):
                     if hi > lo:
                         d_raw[lo:hi].copy_(torch.from_numpy(np.asarray(raw[lo:hi])))
+                        if forget is not None:
+                            forget(raw, lo, hi)
                     events[k].record(copy_stream)
                     queued[k].set()
                     lo = hi

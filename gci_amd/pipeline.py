@@ -314,6 +314,24 @@ def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
     return JoinInput(torch.cat([p.recs for p in parts]), names, torch.cat(offs), 0)
 
 
+def _forget_pages(raw, lo: int, hi: int) -> None:
+    """The pages [lo, hi) of a memory-mapped input file have been read for the last time: drop their entries from this process's
+    page table (madvise DONTNEED; the page cache keeps the data).  What this is for: unmapping a file ALL of whose pages were
+    touched tears down one entry per 4 KB -- ~1 s for a 77 GB BAM -- under the address-space lock, and whatever else the process
+    does with its address space meanwhile waits for it: the next file's mapping, and every hipMalloc (the join's scratch was
+    measured at 3 s of wall time for 1.5 ms of kernels behind the second whole-genome file).  Forgotten run by run, behind the
+    upload that read them, the teardown is spread under the device's inflate time and the final unmap finds nothing to do."""
+    import mmap as _mmap
+    mm = getattr(raw, "_mmap", None)
+    if mm is None or hi <= lo or not hasattr(mm, "madvise"):
+        return
+    a = lo // _mmap.PAGESIZE * _mmap.PAGESIZE
+    try:
+        mm.madvise(_mmap.MADV_DONTNEED, a, hi - a)
+    except (OSError, ValueError, AttributeError):
+        pass
+
+
 class _RunUploads:
     """Uploads of a large BGZF file run by run of members, one run AHEAD of its consumer: two device buffers taken in turns, the
     copies on a stream of their own from a helper thread (they come from pageable memory -- a memory-mapped file -- and block their
@@ -351,6 +369,7 @@ class _RunUploads:
                 n = p1 - p0
                 buf[:n].copy_(torch.from_numpy(np.asarray(self.raw[p0:p1])))
                 buf[n:n + 16].zero_()
+                _forget_pages(self.raw, p0, p1)                  # (the copy from pageable memory has read them by now)
                 ev = torch.cuda.Event()
                 ev.record(self.copy)
             return buf[:n + 16], ev
@@ -487,6 +506,37 @@ def _drop_later(*objs) -> None:
     _DROP_QUEUE.put(objs)
 
 
+_TABLES: Dict[str, object] = {}        # path -> (memory map of the file, future of its BGZF member table): prefetch_member_tables
+
+
+def prefetch_member_tables(paths: Sequence[str]) -> None:
+    """Start on the BGZF member tables of the BAM files of a run (host threads, file after file) before anything needs them: the
+    command line calls this as soon as it knows its inputs, so the first file's table is made while the assembly is read and
+    scanned for N runs, and every later file's while the file before it is inflated on the device -- at genome size half a second
+    per file that used to sit in front of the file's first byte on the device.  bam_join_input() picks the results up; an
+    unreadable or damaged file raises there, where it did before."""
+    from . import hostio
+    if os.environ.get("GCI_BAM_INGEST", "gpu") != "gpu" or not paths or _sharded():
+        return                                            # (a contig-sharded run reads only its contigs' members, through the index)
+    pool = ThreadPoolExecutor(1)
+
+    def table(raw):
+        with phases.wall("bgzf_member_table (ahead, on a helper thread)"):
+            return hostio.bgzf_blocks(np.asarray(raw))
+
+    for path in paths:
+        if path in _TABLES:
+            continue
+        try:
+            if not os.path.getsize(path):
+                continue
+            raw = np.memmap(path, dtype=np.uint8, mode="r")
+        except OSError:
+            continue                                      # (bam_join_input meets the same error itself)
+        _TABLES[path] = (raw, pool.submit(table, raw))
+    pool.shutdown(wait=False)
+
+
 def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
                    threads: int = 1, chunk_bytes: Optional[int] = None, ingest: Optional[str] = None) -> JoinInput:
     """K1 over one BAM file -> the file's join input (compact records + where their names are).
@@ -508,7 +558,8 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         raise ValueError("ingest must be 'heads', 'full' or 'gpu'")
     chunk_bytes = int(chunk_bytes or BAM_CHUNK_BYTES)
     nthreads = hostio.pick_threads(threads)
-    raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+    ahead = _TABLES.pop(path, None) if ingest == "gpu" else None
+    raw = ahead[0] if ahead is not None else (np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8))
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
 
     def ref_sel_for(hdr):
@@ -527,10 +578,12 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         # fit -- BGZF deflates BAM 2.4 - 4 : 1 -- is uploaded run by run instead)
         upload = None
         if 0 < raw.shape[0] <= GPU_INFLATE_MAX // 8:
-            upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1)
+            upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1, forget=_forget_pages)
         try:
             with phases.wall("bgzf_member_table"):
-                pos, isz = hostio.bgzf_blocks(np.asarray(raw))
+                pos, isz = ahead[1].result() if ahead is not None else hostio.bgzf_blocks(np.asarray(raw))
+            if upload is None:
+                _forget_pages(raw, 0, int(raw.shape[0]))      # (the table touched a page per member; a whole-file upload still reads them)
         except BaseException:
             if upload is not None:
                 upload["pool"].shutdown()
