@@ -381,6 +381,7 @@ class TwoTypeWorkload:
                      paf=eng.to_device(t.paf) if t.paf is not None else None,
                      paf_end=np.asarray([t.paf.shape[0]], dtype=np.uint64) if t.paf is not None else None,
                      track=eng.new_track(), ivl=torch.empty((2 * max(n, 1) + 16, 4), dtype=torch.int32, device=dev),
+                     sums=torch.zeros(len(names), dtype=torch.int64, device=dev),
                      count=torch.zeros(1, dtype=torch.int32, device=dev), k1_bytes=t.bam.k1_bytes)
             self.types.append(d)
         self.two = eng.new_track()
@@ -411,7 +412,7 @@ class TwoTypeWorkload:
             inputs.append(JoinInput(recs, d["pages"].buf, noff, 0))
             ivl, cnt = eng.name_join(inputs, OVLP, out=d["ivl"], count=d["count"], check=False, count_flank=FLANK)
             d["jstatus"] = eng._status.clone()
-            d["fused"] = eng.depth_build_fused(ivl, cnt, FLANK, d["track"], want_text=False, want_sums=True, issue=None, counted=True)
+            d["fused"] = eng.depth_build_fused(ivl, cnt, FLANK, d["track"], want_text=False, want_sums=d["sums"], issue=None, counted=True)
         # the tail in one pass (gci_two_type_tail): N-run masks of both tracks, their maximum, the issue runs of all three
         eng.two_type_tail(self.types[0]["track"], self.types[1]["track"], self.gaps, -1.0, 0.0, FLANK, out=self.two,
                           keys=self.tail_keys, n_keys=self.tail_n, read=False)

@@ -617,7 +617,10 @@ class Engine:
         o.counted = 1 if counted else 0
         o.want_text = 1 if want_text else 0
         text_off = torch.zeros(nc + 1, dtype=torch.int64, device=self.device) if want_text else None
-        sums = torch.zeros(max(nc, 1), dtype=torch.int64, device=self.device) if want_sums else None
+        # want_sums: True = per-contig sums returned as a host array; a device tensor (int64 [n_contigs]) = written there, nothing copied
+        sums_dev = want_sums if isinstance(want_sums, torch.Tensor) else None
+        want_sums = bool(sums_dev is not None or want_sums is True)
+        sums = sums_dev if sums_dev is not None else (torch.zeros(max(nc, 1), dtype=torch.int64, device=self.device) if want_sums else None)
         o.d_contig_text_off = text_off.data_ptr() if want_text else None
         o.d_sums = sums.data_ptr() if want_sums else None
         cap = int(key_cap)                                 # grown (and the first pass repeated) when more run boundaries turn up
@@ -648,7 +651,7 @@ class Engine:
         if want_text:
             out["text"] = text[:int(out["text_off"][nc])]
         if want_sums:
-            out["sums"] = sums.cpu().numpy()[:nc]
+            out["sums"] = sums if sums_dev is not None else sums.cpu().numpy()[:nc]
         if issue is not None:
             out["runs"] = self._keys_to_runs(keys[:nk].cpu().numpy().view(np.uint64), nc)
         return out

@@ -315,15 +315,17 @@ def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
 
 
 def _forget_pages(raw, lo: int, hi: int) -> None:
-    """The pages [lo, hi) of a memory-mapped input file have been read for the last time: drop their entries from this process's
-    page table (madvise DONTNEED; the page cache keeps the data).  What this is for: unmapping a file ALL of whose pages were
-    touched tears down one entry per 4 KB -- ~1 s for a 77 GB BAM -- under the address-space lock, and whatever else the process
-    does with its address space meanwhile waits for it: the next file's mapping, and every hipMalloc (the join's scratch was
-    measured at 3 s of wall time for 1.5 ms of kernels behind the second whole-genome file).  Forgotten run by run, behind the
-    upload that read them, the teardown is spread under the device's inflate time and the final unmap finds nothing to do."""
+    """The pages [lo, hi) of a memory-mapped input file have been read for the last time BY THE CPU: drop their entries from this
+    process's page table (madvise DONTNEED; the page cache keeps the data), so that the final unmap of a 77 GB file does not
+    tear down 19 M entries at once under the address-space lock (every hipMalloc and every new mapping of the process waits
+    for that: the join's scratch behind the second whole-genome file was measured at 3 s of wall time for 1.5 ms of kernels).
+    ONLY for ranges the GPU driver never saw: a pageable host-to-device copy registers the user pages with the driver, and a
+    madvise / munmap over registered pages goes through its MMU notifier, which evicts the process's GPU queues while it
+    invalidates -- measured: every kernel of the run 1.4 - 8 x slower, the command line at 1/4 genome 9.2 s instead of 5.2 s
+    (profiles/r04j_forget_pages_ab.txt).  _RunUploads therefore stages the file's bytes through pinned memory itself."""
     import mmap as _mmap
     mm = getattr(raw, "_mmap", None)
-    if mm is None or hi <= lo or not hasattr(mm, "madvise"):
+    if mm is None or hi <= lo or not hasattr(mm, "madvise") or os.environ.get("GCI_FORGET_PAGES", "1") == "0":
         return
     a = lo // _mmap.PAGESIZE * _mmap.PAGESIZE
     try:
@@ -332,10 +334,47 @@ def _forget_pages(raw, lo: int, hi: int) -> None:
         pass
 
 
+class _Staging:
+    """A ring of pinned host buffers through which the bytes of a memory-mapped file travel to the device: host threads copy a
+    piece of the mapping into a slot (parallel memcpy out of the page cache: the page faults are theirs, not the copy engine's),
+    the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
+    SLOT = 192 << 20
+    SLOTS = 6
+    THREADS = 6
+
+    def __init__(self, engine: Engine):
+        self.slots = [torch.empty(self.SLOT, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self.views = [s.numpy() for s in self.slots]
+        self.free_at = [None] * self.SLOTS
+        self.next = 0
+        self.pool = ThreadPoolExecutor(self.THREADS)
+
+    def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream) -> None:
+        """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued."""
+        for a in range(p0, p1, self.SLOT):
+            b = min(p1, a + self.SLOT)
+            k = self.next
+            self.next = (k + 1) % self.SLOTS
+            if self.free_at[k] is not None:
+                self.free_at[k].synchronize()                  # (the helper thread waits; the device and the main thread do not)
+            view = self.views[k]
+            step = -(-(b - a) // self.THREADS)
+            step = (step + 4095) // 4096 * 4096
+            jobs = [self.pool.submit(np.copyto, view[x - a:min(b, x + step) - a], raw[x:min(b, x + step)]) for x in range(a, b, step)]
+            for j in jobs:
+                j.result()
+            _forget_pages(raw, a, b)
+            with torch.cuda.stream(stream):
+                dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            self.free_at[k] = ev
+
+
 class _RunUploads:
     """Uploads of a large BGZF file run by run of members, one run AHEAD of its consumer: two device buffers taken in turns, the
-    copies on a stream of their own from a helper thread (they come from pageable memory -- a memory-mapped file -- and block their
-    caller), so that run k + 1 crosses PCIe while the device inflates, walks and filters run k."""
+    bytes staged through pinned memory by host threads (`_Staging`) and copied on a stream of their own from a helper thread, so
+    that run k + 1 crosses PCIe while the device inflates, walks and filters run k."""
 
     def __init__(self, engine: Engine, raw, pos: np.ndarray, groups):
         import torch
@@ -349,6 +388,9 @@ class _RunUploads:
         self.copy = engine._copy_stream
         self.copy.wait_stream(engine.stream)                 # (the buffers may recycle memory still in use on the main stream)
         self.freed = [None] * len(self.bufs)                 # main-stream event behind the last kernel that read the buffer
+        self.staged = isinstance(raw, np.memmap) and os.environ.get("GCI_UPLOAD", "staged") == "staged"
+        if self.staged and getattr(engine, "_staging", None) is None:
+            engine._staging = _Staging(engine)
         self.pool = ThreadPoolExecutor(1)
         self.pending = {}
         self._start(0)
@@ -367,9 +409,11 @@ class _RunUploads:
                 if freed is not None:
                     self.copy.wait_event(freed)
                 n = p1 - p0
-                buf[:n].copy_(torch.from_numpy(np.asarray(self.raw[p0:p1])))
+                if self.staged:
+                    self.engine._staging.send(self.raw, p0, p1, buf, self.copy)
+                else:
+                    buf[:n].copy_(torch.from_numpy(np.asarray(self.raw[p0:p1])))
                 buf[n:n + 16].zero_()
-                _forget_pages(self.raw, p0, p1)                  # (the copy from pageable memory has read them by now)
                 ev = torch.cuda.Event()
                 ev.record(self.copy)
             return buf[:n + 16], ev
@@ -578,12 +622,10 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         # fit -- BGZF deflates BAM 2.4 - 4 : 1 -- is uploaded run by run instead)
         upload = None
         if 0 < raw.shape[0] <= GPU_INFLATE_MAX // 8:
-            upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1, forget=_forget_pages)
+            upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1)
         try:
             with phases.wall("bgzf_member_table"):
                 pos, isz = ahead[1].result() if ahead is not None else hostio.bgzf_blocks(np.asarray(raw))
-            if upload is None:
-                _forget_pages(raw, 0, int(raw.shape[0]))      # (the table touched a page per member; a whole-file upload still reads them)
         except BaseException:
             if upload is not None:
                 upload["pool"].shutdown()

@@ -33,6 +33,20 @@ if os.environ.get("GCI_EXP_PROFILE"):
             bams.append(p)
         fa = os.path.join(tmp, "ref.fa")
         synth.write_reference_fasta(fa, inp.contigs)
+        # A/B of host-side switches on the same files and the same box, unprofiled: wall time and the phase log
+        for label, extra in (("product (staged upload)", {}), ("GCI_UPLOAD=pageable", {"GCI_UPLOAD": "pageable"}), ("staged, pages kept", {"GCI_FORGET_PAGES": "0"}),
+                             ("product again", {})):
+            env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, **extra)
+            od = os.path.join(tmp, "out_ab")
+            shutil.rmtree(od, ignore_errors=True)
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "GCI.py"), "-r", fa, "--hifi"] + bams + ["-d", od, "-t", str(hostio.default_threads())],
+                               env=env, capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            ph = json.load(open(os.path.join(tmp, "ph_ab.json")))
+            keep = ("bam_ingest", "name_join", "filter[", "fasta", "bgzf_member")
+            print("%-26s rc %d wall %.2f s | " % (label, r.returncode, wall) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
+                  + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0), flush=True)
         env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")
         out = os.path.join(ROOT, "gpurun_out", "cli_prof")
         shutil.rmtree(out, ignore_errors=True)
