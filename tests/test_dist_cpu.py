@@ -263,6 +263,14 @@ def _worker_sharded_join(rank, world, port, q):
         got = sorted((mine_c[c], s, e) for c, s, e, _ in ivl.numpy().tolist() if c >= 0)
         want = sorted((targets.index(t), s, e) for t, s, e in O.name_join(dicts, hq, 0.9).values() if owner[targets.index(t)] == rank)
         assert got == want and len(want) > 50, (len(got), len(want))
+        # capacity of what the join may emit: the routed buckets + the rows a caller passes beside them (PAF records), and never
+        # fewer rows than its inputs have (intervals past the array were dropped without a word)
+        more = shard.ShardedJoin(ops, [int(ji.recs.shape[0]) for ji in local], owner, torch.device("cpu"), extra_records=12345)
+        assert more.ivl.shape[0] == sj.ivl.shape[0] + 12345
+        sj.ivl = sj.ivl[:1].clone()
+        ivl2, _ = sj.join(inputs, 0.9)
+        sj.check(lambda w, what: None if w == (1 << 64) - 1 else (_ for _ in ()).throw(AssertionError((what, w))))
+        assert sorted((mine_c[c], s, e) for c, s, e, _ in ivl2.numpy().tolist() if c >= 0) == want
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
