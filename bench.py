@@ -65,6 +65,10 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip numbers (2) and (3) of SURVEY.md 8(d): the device pipeline incl. H2D / D2H and the "
                          "command-line wall time on a chr19 BAM with realistic SEQ / QUAL entropy")
+    ap.add_argument("--only-step", action="store_true",
+                    help="genome workload: the timed step, its roofline and the full-size parity check only -- no window / command-line-"
+                         "shaped / in-flight legs (their k_tile_build launches write no text and would blur a profiler's per-kernel "
+                         "averages), no end-to-end numbers, no CPU baseline: what tools/round_profile.sh wraps in rocprofv3")
     ap.add_argument("--no-cli-genome", action="store_true",
                     help="genome workload: skip survey_8d.3_command_line_genome (the command line as a process of its own on the two "
                          "genome-size BGZF files: ~130 GB written to tmpfs first, minutes of host-side deflate)")
@@ -1273,6 +1277,7 @@ def paf_number(args):
     from oracle import gci_oracle as O
     contigs = synth.CHM13
     names = [n for n, _ in contigs]
+    os.environ.setdefault("GCI_PAF_POOL_KEEP_GB", "256")          # the passes reuse K2's scratch (a command line makes one pass)
     t0 = time.perf_counter()
     rs = synth.simulate_reads(contigs, 6.0, "hifi", seed=synth.seed_for(4, 1), name_prefix="c0000/m64011_190830/")
     other = synth.perturb(rs, synth.seed_for(4, 3))
@@ -1308,8 +1313,12 @@ def paf_number(args):
         del out
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    passes = []
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         out = eng.paf_filter_text(d_text, ends, names, FILTER[0], FILTER[1], FILTER[3])
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t1)
         if _ + 1 < args.steps:
             del out
     torch.cuda.synchronize()
@@ -1335,7 +1344,7 @@ def paf_number(args):
         exp = {q: (s[0], s[1], s[2], s[3], q in want_hq) for q, s in want.items()}
         ok = ok and got == exp
     n_lines = K * int(nl.shape[0])
-    return {"seconds_per_pass": dt, "paf_bytes": n_bytes, "lines": n_lines, "queries_out": int(recs.shape[0]), "chunks": K,
+    return {"seconds_per_pass": dt, "pass_seconds": [round(x, 4) for x in passes], "paf_bytes": n_bytes, "lines": n_lines, "queries_out": int(recs.shape[0]), "chunks": K,
             "ms_per_gb_of_text": dt * 1e3 / (n_bytes / 1e9), "text_gb_per_s": n_bytes / dt / 1e9, "lines_per_s": n_lines / dt,
             "aligned_bases": K * aligned_chunk, "parity_vs_oracle_chunks": sorted({0, K - 1}), "parity": bool(ok),
             "h2d_seconds_outside_the_pass": t_h2d, "generation_seconds": t_gen}
@@ -1343,6 +1352,8 @@ def paf_number(args):
 
 def main():
     args = parse_args()
+    if args.only_step:
+        args.no_e2e = args.no_cpu_baseline = args.no_cli_genome = True
     if args.workload == "paf":
         r = paf_number(args)
         out = {"metric": "aligned Gbases/s through filter+depth pipeline (CHM13, 40x HiFi)", "value": r["aligned_bases"] / r["seconds_per_pass"] / 1e9,
@@ -1577,8 +1588,9 @@ def main():
             survey = {"1_kernels_only_gbases_per_s": out["value"]}
             if not args.no_e2e and args.inflight == 1:
                 out["two_steps_in_flight"] = two_in_flight(eng, w, args, device_index)
-            out["survey_window_step"] = survey_window_step(eng, w, max(3, args.steps // 2))
-            out["cli_shaped_step"] = cli_shaped_step(eng, w, max(3, args.steps // 2))
+            if not args.only_step:
+                out["survey_window_step"] = survey_window_step(eng, w, max(3, args.steps // 2))
+                out["cli_shaped_step"] = cli_shaped_step(eng, w, max(3, args.steps // 2))
             if not args.no_e2e:
                 survey["2_device_pipeline_incl_h2d_d2h"] = device_pipeline_number(eng, w)
             if not args.no_cpu_baseline:

@@ -79,6 +79,7 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->part_a, &ctx->part_b, &ctx->part_hist, &ctx->part_blk, &ctx->conflict_table, &ctx->win,
                       &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items, &ctx->pg_cost, &ctx->pg_scan, &ctx->pg_first, &ctx->route_tab, &ctx->deflate_nruns, &ctx->deflate_runs, &ctx->join_bucket, &ctx->tail_gaps};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (DevBuf& b : ctx->paf_pool) if (b.p) (void)hipFree(b.p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto* v : {&ctx->prof_live, &ctx->prof_free}) for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -78,6 +78,7 @@ struct gci_ctx {
     uint32_t pg_n_rec = 0, pg_page_bytes = 0, pg_n_pages = 0;
     uint64_t pg_blob_off = 0;
     uint64_t pg_blob_bytes = 0;               // total size of the blob the size call measured (without its 16 guard bytes)
+    std::vector<DevBuf> paf_pool;           // K2's scratch, in the order a call asks for it (k_paf.hip: PafScratch)
     DevBuf tail_gaps;                       // gci_two_type_tail: the N runs as absolute sorted [begin, end) element ranges
     std::vector<int64_t> tail_gaps_host;    // ... what was uploaded last
     // issue-scan windows

@@ -381,7 +381,24 @@ __global__ __launch_bounds__(BLOCK) void k_paf_score(const PafHitD* __restrict__
         }
         uint32_t m = a0;
         while (m < a1 && order[m] < limit) m++;                          // the query's hits in files 0 .. i
-        if (m > a0) {
+        if (m == a0 + 1) {
+            // ONE line of this query so far -- nine queries in ten: its target, its target block, nothing to merge and nothing to
+            // compare (the score only orders targets); the division by qlen of GCI.py:249 still raises on 0.  One read of the hit
+            // instead of the dependent trips through the scratch lists below.
+            const PafHitD x = hits[order[a0]];
+            if (x.qlen == 0) atomicMin(status, ((unsigned long long)order[a0] << 8) | (unsigned)(-GCI_E_ZERO_DIV));
+            else if ((x.te - x.ts > -1 && (x.ts > 0x7fffffffLL || x.ts < -0x80000000LL || x.te > 0x7fffffffLL || x.te < -0x80000000LL)) ||
+                     x.qlen > 0x7fffffffLL || x.qlen < -0x80000000LL || x.qn_len > 0xFFFF)
+                atomicMin(status, ((unsigned long long)table[s] << 8) | (unsigned)(-GCI_E_INVALID));
+            else {
+                const bool block = x.te - x.ts > -1;                  // (merge_span's "longest block" starts from length -1)
+                r.name_hash = x.qhash; r.contig = x.t; r.start = block ? (int32_t)x.ts : 0; r.end = block ? (int32_t)x.te : 0;
+                r.qlen = (int32_t)x.qlen; r.rec_idx = s; r.mapq = 0;
+                r.flags = (uint8_t)(GCI_REC_PASS | (hq[s] ? GCI_REC_HQ : 0)); r.name_len = (uint16_t)x.qn_len;
+                name_off = x.qn_off;
+                emit = true;
+            }
+        } else if (m > a0) {
             bool have = false;
             double best_rank = 0;
             int32_t best_t = -1;
@@ -481,12 +498,34 @@ static void paf_hits_release(gci_paf_hits* h)
 
 namespace {
 
-// device scratch of one call: freed on every way out, except what `keep` takes out of it
+// Device scratch of one call.  The buffers belong to the context and are handed out in the order they are asked for -- the same
+// order in every call with as many files -- so a second call of the same size allocates nothing: a step of configs[3] makes two
+// such calls, and twenty hipMalloc + hipFree each (every hipFree a device-wide synchronisation) were part of every one.  A call
+// whose scratch is beyond PAF_POOL_KEEP (a PAF of tens of GB) gives it back when it ends, as before.
+#define PAF_POOL_KEEP (16ull << 30)
 struct PafScratch {
-    std::vector<void*> v;
-    ~PafScratch() { for (void* p : v) (void)hipFree(p); }
-    void* alloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; v.push_back(p); return p; }
-    void keep(void* p) { for (auto& q : v) if (q == p) { q = nullptr; return; } }
+    gci_ctx* ctx;
+    size_t next = 0;
+    explicit PafScratch(gci_ctx* c) : ctx(c) {}
+    ~PafScratch()
+    {
+        size_t held = 0;
+        for (const DevBuf& b : ctx->paf_pool) held += b.cap;
+        // (GCI_PAF_POOL_KEEP_GB: a harness that repeats a pass over tens of GB keeps the scratch instead -- giving ~70 GB back to the
+        // driver and asking for it again made single passes of bench.py --workload paf take 2 - 3 s instead of 0.22 s)
+        static const size_t keep = [] { const char* e = getenv("GCI_PAF_POOL_KEEP_GB"); return e ? (size_t)atoll(e) << 30 : (size_t)PAF_POOL_KEEP; }();
+        if (held <= keep) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        for (DevBuf& b : ctx->paf_pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    }
+    void* alloc(size_t bytes)
+    {
+        if (next >= ctx->paf_pool.size()) ctx->paf_pool.emplace_back();
+        DevBuf& b = ctx->paf_pool[next++];
+        return gci_ensure(ctx, b, bytes ? bytes : 16) == GCI_OK ? b.p : nullptr;
+    }
+    // p leaves the pool: the caller owns it from here on (hipFree)
+    void keep(void* p) { for (DevBuf& b : ctx->paf_pool) if (b.p == p) { b.p = nullptr; b.cap = 0; return; } }
 };
 #define PAF_ALLOC(var, type, count)                                         \
     type* var = (type*)S.alloc(sizeof(type) * (size_t)(count));             \
@@ -684,7 +723,7 @@ extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const 
     *out = nullptr;
     if (err_line) *err_line = 0;
     hipStream_t st = ctx->stream;
-    PafScratch S;
+    PafScratch S(ctx);
     PafTargets T;
     int rc = paf_targets(ctx, S, targets, n_targets, T);
     if (rc) return rc;
@@ -727,7 +766,7 @@ extern "C" int gci_paf_hits_device(gci_ctx* ctx, const uint8_t* d_text, const ui
     if (!ctx || !out || n_files < 0 || (n_files && (!d_text || !h_file_end)) || (n_targets && !targets)) return GCI_E_INVALID;
     *out = nullptr;
     if (err_line) *err_line = 0;
-    PafScratch S;
+    PafScratch S(ctx);
     PafTargets T;
     int rc = paf_targets(ctx, S, targets, n_targets, T);
     if (rc) return rc;
@@ -784,7 +823,7 @@ extern "C" int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_
     std::vector<uint32_t> upto(h_hits_upto, h_hits_upto + n_files + 1);
     for (int f = 0; f < n_files; f++) if (upto[f + 1] < upto[f]) return GCI_E_INVALID;
     if (upto[n_files] && (!d_hits || !d_names)) return GCI_E_INVALID;
-    PafScratch S;
+    PafScratch S(ctx);
     PafTargets T;
     int rc = paf_targets(ctx, S, targets, n_targets, T);
     if (rc) return rc;

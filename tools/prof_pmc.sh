@@ -4,7 +4,7 @@
 set -u
 tag=${1:-r01}
 export TMPDIR=/tmp
-cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e"
+cmd="python bench.py --steps 3 --warmup 1 --only-step"
 run() { # name, counters...
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}/${name} -o pmc -- $cmd > gpurun_out/pmc_${tag}_${name}.json 2> gpurun_out/pmc_${tag}_${name}.err
