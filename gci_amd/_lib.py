@@ -94,7 +94,7 @@ EXPORTS = [
     ("gci_gap_mask", c_int, [c_void_p, c_void_p, c_void_p, c_uint32]),
     ("gci_max2", c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     ("gci_two_type_tail", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_double, c_double, c_int, c_void_p,
-                                  c_uint32, c_void_p]),
+                                  c_uint32, c_void_p, c_void_p]),
     ("gci_issue_scan", c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_uint32, c_void_p]),
     ("gci_issue_scan_windows", c_int, [c_void_p, c_void_p, POINTER(Window), c_uint32, c_double, c_double, c_void_p,
                                        c_uint32, c_void_p]),

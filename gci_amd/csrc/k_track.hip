@@ -237,6 +237,7 @@ struct TailArgs {
     const int64_t* len; const int64_t* off; const int64_t* tile_first; int32_t n_contigs;
     int32_t lo, hi, flank;
     unsigned long long* keys; uint32_t cap; uint32_t* n_keys;     // three key arrays of `cap` entries, three counters
+    long long* tile_sums; int64_t n_tiles;                        // nullable: 3 x n_tiles sums of depth (a, b, the maximum)
 };
 
 __device__ __forceinline__ bool tail_in_gap(const int64_t* __restrict__ gaps, uint32_t g0, uint32_t g1, int64_t p)
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(BLOCK) void k_two_type_tail(TailArgs A)
         while (g1 < A.n_gaps && A.gaps[2 * g1] < p0 + TILE) g1++;
     }
     const bool gapped = g1 > g0;
+    long long sum[3] = {0, 0, 0};                            // (the padding behind a contig's last base is kept at zero)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int64_t p = p0 + (int64_t)(j * BLOCK + t) * 4;
@@ -283,6 +285,8 @@ __global__ __launch_bounds__(BLOCK) void k_two_type_tail(TailArgs A)
 #pragma unroll
         for (int k = 0; k < 4; k++) dm[k] = max(da[k], db[k]);
         *reinterpret_cast<int4*>(A.out + p) = make_int4(dm[0], dm[1], dm[2], dm[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sum[0] += da[k]; sum[1] += db[k]; sum[2] += dm[k]; }
         // run boundaries of the three tracks (k_issue_scan's rule, the window being the contig's)
         uint32_t g[3][4];
 #pragma unroll
@@ -329,18 +333,28 @@ __global__ __launch_bounds__(BLOCK) void k_two_type_tail(TailArgs A)
             }
         }
     }
+    if (A.tile_sums) {
+        __shared__ long long part[3][BLOCK / 64];
+        const int wave = t >> 6;
+#pragma unroll
+        for (int x = 0; x < 3; x++) { const long long v = wave_sum<long long>(sum[x]); if (lane == 0) part[x][wave] = v; }
+        __syncthreads();
+        if (t < 3) A.tile_sums[(int64_t)t * A.n_tiles + blockIdx.x] = part[t][0] + part[t][1] + part[t][2] + part[t][3];
+    }
 }
 
 // h_gaps: the N runs in the reference's coordinates (contig = index in the layout, [start, end) with Python's slice rules, as
 // gci_gap_mask takes them on the device); d_a / d_b are masked IN PLACE, d_out receives their maximum; d_keys: 3 x cap keys
 // (track a, track b, the maximum; the keys gci_issue_scan(track, lo, hi, flank) gives), d_n_keys: 3 counters.
 extern "C" int gci_two_type_tail(gci_ctx* ctx, int32_t* d_a, int32_t* d_b, int32_t* d_out, const gci_ivl* h_gaps, uint32_t n_gaps,
-                                 double lo, double hi, int flank, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys)
+                                 double lo, double hi, int flank, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys, int64_t* d_sums)
 {
     if (!ctx || !d_a || !d_b || !d_out || !d_n_keys || (cap && !d_keys) || (n_gaps && !h_gaps)) return GCI_E_INVALID;
     if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
     HIPCHK(hipMemsetAsync(d_n_keys, 0, 12, ctx->stream));
+    if (d_sums) HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)3 * ctx->n_contigs * 8, ctx->stream));
     if (ctx->n_tiles == 0) return GCI_OK;
+    if (d_sums) GCI_TRY(gci_ensure(ctx, ctx->tail_sums, (size_t)3 * ctx->n_tiles * 8));
     // absolute, sorted, merged element ranges of the N runs (uploaded again only when they change)
     std::vector<std::pair<int64_t, int64_t>> g;
     g.reserve(n_gaps);
@@ -369,9 +383,17 @@ extern "C" int gci_two_type_tail(gci_ctx* ctx, int32_t* d_a, int32_t* d_b, int32
     A.len = (const int64_t*)ctx->d_len.p; A.off = (const int64_t*)ctx->d_off.p; A.tile_first = (const int64_t*)ctx->d_tile_first.p;
     A.n_contigs = ctx->n_contigs; A.lo = rg.lo; A.hi = rg.hi; A.flank = flank;
     A.keys = (unsigned long long*)d_keys; A.cap = cap; A.n_keys = d_n_keys;
+    A.tile_sums = d_sums ? (long long*)ctx->tail_sums.p : nullptr; A.n_tiles = ctx->n_tiles;
     ProfScope _ps(ctx, GCI_PROF_MAX2);
     hipLaunchKernelGGL(k_two_type_tail, dim3((uint32_t)ctx->n_tiles), dim3(BLOCK), 0, ctx->stream, A);
     LAUNCHCHK("k_two_type_tail");
+    if (d_sums)
+        for (int x = 0; x < 3; x++) {
+            hipLaunchKernelGGL(k_reduce_tiles, dim3(ctx->n_contigs, REDUCE_SPLIT), dim3(BLOCK), 0, ctx->stream,
+                               (const long long*)ctx->tail_sums.p + (size_t)x * ctx->n_tiles, (const int64_t*)ctx->d_tile_first.p,
+                               (unsigned long long*)d_sums + (size_t)x * ctx->n_contigs);
+            LAUNCHCHK("k_reduce_tiles");
+        }
     return GCI_OK;
 }
 

@@ -54,6 +54,64 @@ def name_hash_np(names: Sequence[bytes]) -> np.ndarray:
         return mix(acc ^ (lens.astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)))
 
 
+def _forget_pages(raw, lo: int, hi: int) -> None:
+    """The pages [lo, hi) of a memory-mapped input file have been read for the last time BY THE CPU: drop their entries from this
+    process's page table (madvise DONTNEED; the page cache keeps the data), so that the final unmap of a 77 GB file does not
+    tear down 19 M entries at once under the address-space lock (every hipMalloc and every new mapping of the process waits
+    for that: the join's scratch behind the second whole-genome file was measured at 3 s of wall time for 1.5 ms of kernels).
+    ONLY for ranges the GPU driver never saw: a pageable host-to-device copy registers the user pages with the driver, and a
+    madvise / munmap over registered pages goes through its MMU notifier, which evicts the process's GPU queues while it
+    invalidates -- measured: every kernel of the run 1.4 - 8 x slower, the command line at 1/4 genome 9.2 s instead of 5.2 s
+    (profiles/r04j_forget_pages_ab.txt).  pipeline._RunUploads therefore stages the file's bytes through pinned memory itself."""
+    import mmap as _mmap
+    mm = getattr(raw, "_mmap", None)
+    if mm is None or hi <= lo or not hasattr(mm, "madvise") or os.environ.get("GCI_FORGET_PAGES", "1") == "0":
+        return
+    a = lo // _mmap.PAGESIZE * _mmap.PAGESIZE
+    try:
+        mm.madvise(_mmap.MADV_DONTNEED, a, hi - a)
+    except (OSError, ValueError, AttributeError):
+        pass
+
+
+class _Staging:
+    """A ring of pinned host buffers through which the bytes of a memory-mapped file travel to the device: host threads copy a
+    piece of the mapping into a slot (parallel memcpy out of the page cache: the page faults are theirs, not the copy engine's),
+    the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
+    SLOT = 192 << 20
+    SLOTS = 6
+    THREADS = 8
+
+    def __init__(self, engine=None):
+        self.slots = [torch.empty(self.SLOT, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self.views = [s.numpy() for s in self.slots]
+        self.free_at = [None] * self.SLOTS
+        self.next = 0
+        self.pool = ThreadPoolExecutor(self.THREADS)
+
+    def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream) -> None:
+        """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued."""
+        for a in range(p0, p1, self.SLOT):
+            b = min(p1, a + self.SLOT)
+            k = self.next
+            self.next = (k + 1) % self.SLOTS
+            if self.free_at[k] is not None:
+                self.free_at[k].synchronize()                  # (the helper thread waits; the device and the main thread do not)
+            view = self.views[k]
+            step = -(-(b - a) // self.THREADS)
+            step = (step + 4095) // 4096 * 4096
+            jobs = [self.pool.submit(np.copyto, view[x - a:min(b, x + step) - a], raw[x:min(b, x + step)]) for x in range(a, b, step)]
+            for j in jobs:
+                j.result()
+            _forget_pages(raw, a, b)
+            with torch.cuda.stream(stream):
+                dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            self.free_at[k] = ev
+
+
+
 @dataclass
 class JoinInput:
     """One file of the join: compact records on the device + where its name bytes are."""
@@ -131,6 +189,22 @@ class Engine:
         elif a.dtype == np.uint32:
             a = a.view(np.int32)
         return torch.from_numpy(a).to(self.device)
+
+    def upload_staged(self, a: np.ndarray) -> torch.Tensor:
+        """A large host array (the 3 GB assembly) to the device through the ring of pinned buffers (`_Staging`) instead of one
+        pageable copy: host threads fill a slot while the one before it crosses PCIe.  Ordered before what this engine's stream
+        does next."""
+        a = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+        n = int(a.shape[0])
+        if getattr(self, "_staging", None) is None:
+            self._staging = _Staging(self)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        dst = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+        self._copy_stream.wait_stream(self.stream)
+        self._staging.send(a, 0, n, dst, self._copy_stream)
+        self.stream.wait_stream(self._copy_stream)
+        return dst[:n]
 
     # ---- per-kernel HIP-event timing (library side, on the ctx stream) -------------------------
     def profile_enable(self, mask: int) -> None:
@@ -670,10 +744,11 @@ class Engine:
 
     def two_type_tail(self, a: torch.Tensor, b: torch.Tensor, gaps: Optional[np.ndarray], lo: float, hi: float, flank: int,
                       out: Optional[torch.Tensor] = None, keys: Optional[torch.Tensor] = None, n_keys: Optional[torch.Tensor] = None,
-                      read: bool = True):
+                      read: bool = True, sums: Optional[torch.Tensor] = None):
         """gci_two_type_tail: N-run masks of both tracks (in place; gaps = int32 [n, 4] rows (contig, start, end, 0) on the HOST, or
         None), their maximum and the issue runs of all three in one pass.  -> (maximum track, [runs of a, of b, of the maximum]);
-        read=False: (maximum track, keys int64 [3, cap] on the device, n_keys int32 [3]) with nothing copied to the host."""
+        read=False: (maximum track, keys int64 [3, cap] on the device, n_keys int32 [3]) with nothing copied to the host.
+        sums: int64 [3, n_contigs] on the device, filled with the per-contig sums of depth of the three tracks."""
         if out is None:
             out = self.new_track()
         g = np.ascontiguousarray(gaps, dtype=np.int32).reshape(-1, 4) if gaps is not None and len(gaps) else None
@@ -685,7 +760,8 @@ class Engine:
                 n_keys = torch.zeros(3, dtype=torch.int32, device=self.device)
             self._chk(self.lib.gci_two_type_tail(self.ctx, self._p(a), self._p(b), self._p(out),
                                                  ctypes.c_void_p(g.ctypes.data) if g is not None else None, 0 if g is None else int(g.shape[0]),
-                                                 float(lo), float(hi), int(flank), self._p(keys), cap, self._p(n_keys)), "gci_two_type_tail")
+                                                 float(lo), float(hi), int(flank), self._p(keys), cap, self._p(n_keys), self._p(sums)),
+                      "gci_two_type_tail")
             if not read:
                 return out, keys, n_keys
             n = n_keys.cpu().numpy()
@@ -704,7 +780,7 @@ class Engine:
         """gci_fasta_n_scan over the bytes of a FASTA file: bodies = int64 [n_records, 2] byte ranges of the record
         bodies -> (uint32 kept-byte count per 4096-byte tile, sorted uint64 keys (offset << 1 | is_end))."""
         n = int(text.shape[0])
-        d_text = self.to_device(text)
+        d_text = self.upload_staged(text) if n >= (256 << 20) else self.to_device(text)
         d_body = self.to_device(np.ascontiguousarray(bodies, dtype=np.int64).reshape(-1, 2))
         tiles = (n + 4095) // 4096
         kept = torch.zeros(max(tiles, 1), dtype=torch.int32, device=self.device)

@@ -42,7 +42,32 @@ def _records(buf: np.ndarray) -> Iterator[Tuple[str, np.ndarray]]:
 
 
 def load(path: str) -> np.ndarray:
-    return np.fromfile(path, dtype=np.uint8)
+    """The file's bytes.  A large file (a 3 GB assembly) is read by eight threads, each its share straight into the array
+    (np.fromfile alone: 0.55 s of the command line at genome size)."""
+    import os
+    n = os.path.getsize(path)
+    if n < (64 << 20):
+        return np.fromfile(path, dtype=np.uint8)
+    from concurrent.futures import ThreadPoolExecutor
+    buf = np.empty(n, dtype=np.uint8)
+    parts = 8
+    step = -(-n // parts)
+
+    def read(k):
+        a, b = k * step, min(n, (k + 1) * step)
+        with open(path, "rb", buffering=0) as f:
+            f.seek(a)
+            mv = memoryview(buf)[a:b]
+            got = 0
+            while got < b - a:
+                r = f.readinto(mv[got:])
+                if not r:
+                    raise IOError("short read of %s" % path)
+                got += r
+
+    with ThreadPoolExecutor(parts) as ex:
+        list(ex.map(read, range(parts)))
+    return buf
 
 
 def record_ids(path: str) -> List[str]:

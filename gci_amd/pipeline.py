@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import phases, score
-from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
+from .device import Engine, JoinInput, REC_DTYPE, name_hash_np, _Staging, _forget_pages
 from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
 from .formats import bam as bamfmt
@@ -312,63 +312,6 @@ def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
         names[at:at + int(p.name_base.shape[0])] = p.name_base
         at += (int(p.name_base.shape[0]) + 15) // 16 * 16
     return JoinInput(torch.cat([p.recs for p in parts]), names, torch.cat(offs), 0)
-
-
-def _forget_pages(raw, lo: int, hi: int) -> None:
-    """The pages [lo, hi) of a memory-mapped input file have been read for the last time BY THE CPU: drop their entries from this
-    process's page table (madvise DONTNEED; the page cache keeps the data), so that the final unmap of a 77 GB file does not
-    tear down 19 M entries at once under the address-space lock (every hipMalloc and every new mapping of the process waits
-    for that: the join's scratch behind the second whole-genome file was measured at 3 s of wall time for 1.5 ms of kernels).
-    ONLY for ranges the GPU driver never saw: a pageable host-to-device copy registers the user pages with the driver, and a
-    madvise / munmap over registered pages goes through its MMU notifier, which evicts the process's GPU queues while it
-    invalidates -- measured: every kernel of the run 1.4 - 8 x slower, the command line at 1/4 genome 9.2 s instead of 5.2 s
-    (profiles/r04j_forget_pages_ab.txt).  _RunUploads therefore stages the file's bytes through pinned memory itself."""
-    import mmap as _mmap
-    mm = getattr(raw, "_mmap", None)
-    if mm is None or hi <= lo or not hasattr(mm, "madvise") or os.environ.get("GCI_FORGET_PAGES", "1") == "0":
-        return
-    a = lo // _mmap.PAGESIZE * _mmap.PAGESIZE
-    try:
-        mm.madvise(_mmap.MADV_DONTNEED, a, hi - a)
-    except (OSError, ValueError, AttributeError):
-        pass
-
-
-class _Staging:
-    """A ring of pinned host buffers through which the bytes of a memory-mapped file travel to the device: host threads copy a
-    piece of the mapping into a slot (parallel memcpy out of the page cache: the page faults are theirs, not the copy engine's),
-    the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
-    SLOT = 192 << 20
-    SLOTS = 6
-    THREADS = 6
-
-    def __init__(self, engine: Engine):
-        self.slots = [torch.empty(self.SLOT, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
-        self.views = [s.numpy() for s in self.slots]
-        self.free_at = [None] * self.SLOTS
-        self.next = 0
-        self.pool = ThreadPoolExecutor(self.THREADS)
-
-    def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream) -> None:
-        """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued."""
-        for a in range(p0, p1, self.SLOT):
-            b = min(p1, a + self.SLOT)
-            k = self.next
-            self.next = (k + 1) % self.SLOTS
-            if self.free_at[k] is not None:
-                self.free_at[k].synchronize()                  # (the helper thread waits; the device and the main thread do not)
-            view = self.views[k]
-            step = -(-(b - a) // self.THREADS)
-            step = (step + 4095) // 4096 * 4096
-            jobs = [self.pool.submit(np.copyto, view[x - a:min(b, x + step) - a], raw[x:min(b, x + step)]) for x in range(a, b, step)]
-            for j in jobs:
-                j.result()
-            _forget_pages(raw, a, b)
-            with torch.cuda.stream(stream):
-                dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-            self.free_at[k] = ev
 
 
 class _RunUploads:
@@ -1144,12 +1087,14 @@ def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTrac
     if issue_hint is not None and nano_depths.engine is engine and same_pending:
         hifi_depths._bind_layout()
         lo, hi, fl = float(issue_hint[0]), float(issue_hint[1]), int(issue_hint[2])
-        two, runs = engine.two_type_tail(hifi_depths.track, nano_depths.track, pend[0], lo, hi, fl)
+        d_sums = torch.zeros((3, max(len(hifi_depths.targets), 1)), dtype=torch.int64, device=engine.device)
+        two, runs = engine.two_type_tail(hifi_depths.track, nano_depths.track, pend[0], lo, hi, fl, sums=d_sums)
         merged = DepthTracks(engine, hifi_depths.targets_length, two)
-        for d, r in zip((hifi_depths, nano_depths, merged), runs):
+        h_sums = d_sums.cpu().numpy()[:, :len(hifi_depths.targets)]
+        for k, (d, r) in enumerate(zip((hifi_depths, nano_depths, merged), runs)):
             if pend[0] is not None:
                 d._pending_gaps, d._masked_with = None, pend[0].tobytes()
-                d._fresh_sums = None
+            d._fresh_sums = h_sums[k].copy()                     # (the numerator of the mean depth of a `-p` run: no pass of its own)
             d._fresh_runs = ((lo, hi, fl), r)
     else:
         hifi_depths._bind()

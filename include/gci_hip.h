@@ -301,10 +301,11 @@ int gci_max2(gci_ctx* ctx, const int32_t* d_a, const int32_t* d_b, int32_t* d_ou
 /* The tail of a two-read-type run in one pass over the two tracks (GCI.py:1014-1024): N-run masks of both (GCI.py:324-328; h_gaps
  * in contig coordinates with Python's slice rules, HOST memory), their per-base maximum (GCI.py:350) into d_out, and the
  * issue-run boundary keys of all three tracks (GCI.py:369-390): d_keys = 3 x cap keys, d_n_keys = 3 counters -- per track the
- * keys gci_issue_scan(track, lo, hi, flank) gives.  d_a / d_b are masked in place.  12 bytes per base instead of the 24 of
- * gci_gap_mask x 2 + gci_max2 + gci_issue_scan x 3. */
+ * keys gci_issue_scan(track, lo, hi, flank) gives.  d_a / d_b are masked in place.  d_sums (nullable): 3 x n_contigs sums of depth
+ * (the masked a, the masked b, the maximum: what gci_depth_sum gives for each -- the numerator of np.mean, GCI.py:862-868).
+ * 12 bytes per base instead of the 24 of gci_gap_mask x 2 + gci_max2 + gci_issue_scan x 3 (+ 12 for three gci_depth_sum). */
 int gci_two_type_tail(gci_ctx* ctx, int32_t* d_a, int32_t* d_b, int32_t* d_out, const gci_ivl* h_gaps, uint32_t n_gaps,
-                      double lo, double hi, int flank, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys);
+                      double lo, double hi, int flank, uint64_t* d_keys, uint32_t cap, uint32_t* d_n_keys, int64_t* d_sums);
 
 /* ---- R10: issue scan ------------------------------------------------------------------------
  * Finds every maximal run of `lo < depth <= hi` inside each window.  Emits unordered 64-bit

@@ -967,3 +967,12 @@ def test_two_type_tail_in_one_pass_equals_the_seams(engine, oracle, flank, thres
         assert fresh is not None
     assert sum(len(v) for v in oracle.collapse_depth_range(m, -1, threshold, flank, 0).values()) > 5
     assert two.mean() == oracle.mean_depth(m)
+    # the per-contig sums came out of the same pass (the mean depth of a `-p` run): equal to a pass of their own
+    th2, tn2 = _upload_depths(engine, h), _upload_depths(engine, n)
+    pipeline.merge_gaps_depths(th2, gaps, lazy=True)
+    pipeline.merge_gaps_depths(tn2, gaps, lazy=True)
+    two2 = pipeline.merge_two_type_depth(th2, tn2, write=False, issue_hint=(-1, threshold, flank))
+    for tr, want in ((th2, h), (tn2, n), (two2, m)):
+        assert tr._fresh_sums is not None and [int(x) for x in tr.sums()] == [int(want[k].sum()) for k in shapes]
+        assert tr.mean() == oracle.mean_depth(want)
+        assert [int(x) for x in engine.depth_sum(tr.track)] == [int(want[k].sum()) for k in shapes]
