@@ -79,8 +79,8 @@ class _Staging:
     """A ring of pinned host buffers through which the bytes of a memory-mapped file travel to the device: host threads copy a
     piece of the mapping into a slot (parallel memcpy out of the page cache: the page faults are theirs, not the copy engine's),
     the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
-    SLOT = 192 << 20
-    SLOTS = 6
+    SLOT = 64 << 20              # (page-locking costs ~0.3 s per GB on these hosts: a ring of 256 MB, not of 1.2 GB)
+    SLOTS = 4
     THREADS = 8
 
     def __init__(self, engine=None):
