@@ -473,40 +473,6 @@ class Engine:
         self.check_status("gci_bgzf_inflate_device")
         return out[:n_pre + total]
 
-    def bgzf_inflate_into(self, d_raw: torch.Tensor, pos: np.ndarray, isize: np.ndarray, out: torch.Tensor, at: int,
-                          status: torch.Tensor, check_crc: bool = True) -> int:
-        """bgzf_inflate without its wait: the members of d_raw (pos / isize as for bgzf_inflate) are inflated into out[at : at + total]
-        on THIS engine's stream, the status word goes to `status` (int64 [1]; the caller reads it when it gets to the run:
-        decode_status).  -> total.  (What lets the next run's inflate start while the host is still busy with this run's records.)"""
-        n = int(isize.shape[0])
-        off = np.zeros(n + 1, dtype=np.uint64)
-        np.cumsum(isize, out=off[1:])
-        total = int(off[n])
-        if int(out.shape[0]) < at + total:
-            raise ValueError("bgzf_inflate_into: output buffer too small")
-        with torch.cuda.stream(self.stream):
-            d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
-            self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(d_raw), self._p(d_pos), self._p(d_off), n,
-                                                       ctypes.c_void_p(out.data_ptr() + at), total, int(check_crc), self._p(status)),
-                      "gci_bgzf_inflate_device")
-            self._inflate_tables = (d_pos, d_off)          # (alive until the next call: the kernel reads them)
-        return total
-
-    def decode_status(self, status: torch.Tensor, what: str) -> None:
-        """Raises what a status word written by a call made with check=False / a status tensor of its own reports (waits for it)."""
-        w = int(status.reshape(-1)[0].item()) & _M64
-        rec = ctypes.c_uint32(0)
-        st = self.lib.gci_decode_status(w, ctypes.byref(rec))
-        if st != 0:
-            raise GciError(st, "%s: %s (record %d)" % (what, self.lib.gci_strerror(st).decode(), rec.value), rec=int(rec.value))
-
-    def side_engine(self) -> "Engine":
-        """A second context on a stream of its own on the same device (made once): work that must not wait behind this engine's
-        host round trips -- the inflate of the next run of a large file."""
-        if getattr(self, "_side", None) is None:
-            self._side = Engine(self.device.index, stream=torch.cuda.Stream(device=self.device))
-        return self._side
-
     def inflate_round(self) -> int:
         """Members gci_bgzf_inflate_device decodes at a time on this device (0: unknown)."""
         return int(self.lib.gci_bgzf_inflate_round(self.ctx))

@@ -363,18 +363,18 @@ class _RunUploads:
 
         self.pending[k] = self.pool.submit(run)
 
-    def take(self, k: int, stream=None):
-        """-> run k's bytes on the device (+ 16 zero bytes), ordered before whatever `stream` (the main stream) does next."""
+    def take(self, k: int):
+        """-> run k's bytes on the device (+ 16 zero bytes), ordered before whatever the main stream does next."""
         d_raw, ev = self.pending.pop(k).result()
-        (stream or self.engine.stream).wait_event(ev)
+        self.engine.stream.wait_event(ev)
         self._start(k + 1)                                   # into the other buffer: its last reader (run k - 1) is enqueued
         return d_raw
 
-    def release(self, k: int, stream=None):
-        """Everything that reads run k's buffer has been enqueued on `stream` (the main stream): the run after next may overwrite it."""
+    def release(self, k: int):
+        """Everything that reads run k's buffer has been enqueued on the main stream: the run after next may overwrite it."""
         import torch
         ev = torch.cuda.Event()
-        ev.record(stream or self.engine.stream)
+        ev.record(self.engine.stream)
         self.freed[k % len(self.bufs)] = ev
 
     def close(self):
@@ -432,53 +432,20 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     parts: List[JoinInput] = []
     carry, start, n_done = None, hdr.first_record, 0
     ahead = _RunUploads(engine, raw, pos, groups)             # the bytes of run k + 1 travel while run k is inflated and filtered
-    # The inflate of run k + 1 is enqueued -- on a stream and a library context of its own -- BEFORE the host turns to the records
-    # of run k (the walk, the pages and the filter read counts back half a dozen times per run, and on one stream the device
-    # idled through every one of those round trips: 1.5 s of a 9.4 s ingestion at genome size).  The partial record a run ends in
-    # is only known after that run's walk, so a run is inflated behind HEAD bytes of headroom and its predecessor's tail is copied
-    # in front of it afterwards.
-    HEAD = 64 << 20
-    side = engine.side_engine()
-
-    def launch(k):
-        lo, hi = groups[k]
-        p0 = int(pos[lo])
-        with phases.wall("  wait for the upload of a run (host blocked)"):
-            d_raw = ahead.take(k, side.stream)
-        total_k = int(isz[lo:hi].sum())
-        out = torch.empty(HEAD + total_k, dtype=torch.uint8, device=engine.device)
-        out.record_stream(side.stream)
-        status = torch.full((1,), -1, dtype=torch.int64, device=engine.device)
-        status.record_stream(side.stream)
-        side.stream.wait_stream(engine.stream)               # (the buffer may recycle memory the main stream still reads)
-        with phases.gpu("bgzf_inflate + crc", side.stream):
-            side.bgzf_inflate_into(d_raw, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], out, HEAD, status, check_crc=BGZF_CRC)
-        ev = torch.cuda.Event()
-        ev.record(side.stream)
-        ahead.release(k, side.stream)
-        return out, total_k, ev, status
-
-    overlap = os.environ.get("GCI_INGEST_OVERLAP", "1") != "0"
     try:
-        nxt = None
         for k, (lo, hi) in enumerate(groups):
-            out, total_k, ev, status = nxt if nxt is not None else launch(k)
-            nxt = launch(k + 1) if (overlap and k + 1 < len(groups)) else None
-            engine.stream.wait_event(ev)
+            p0 = int(pos[lo])
+            with phases.wall("  wait for the upload of a run (host blocked)"):
+                d_raw = ahead.take(k)
             try:
-                engine.decode_status(status, "gci_bgzf_inflate_device")
+                with phases.gpu("bgzf_inflate + crc"):
+                    d_buf = engine.bgzf_inflate(None, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry, d_raw=d_raw)
             except GciError as e:
                 if e.rec >= 0:
                     e.rec += lo
                 raise
-            n_pre = int(carry.shape[0]) if carry is not None else 0
-            if n_pre <= HEAD:
-                if n_pre:
-                    out[HEAD - n_pre:HEAD].copy_(carry)
-                d_buf = out[HEAD - n_pre:HEAD + total_k]
-            else:                                             # (a partial record beyond the headroom: its own buffer)
-                d_buf = torch.cat([carry, out[HEAD:HEAD + total_k]])
-            del out
+            ahead.release(k)
+            del d_raw
             if int(d_buf.shape[0]) <= start:                  # still inside the header
                 carry, start = None, start - int(d_buf.shape[0])
                 continue

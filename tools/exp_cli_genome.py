@@ -36,8 +36,6 @@ if os.environ.get("GCI_EXP_PROFILE"):
         # A/B of host-side switches on the same files and the same box, unprofiled: wall time and the phase log
         variants = (("product (staged upload)", {}), ("GCI_UPLOAD=pageable", {"GCI_UPLOAD": "pageable"}), ("staged, pages kept", {"GCI_FORGET_PAGES": "0"}),
                     ("product again", {}))
-        if os.environ.get("GCI_EXP_VARIANTS") == "overlap":
-            variants = (("product", {}), ("GCI_INGEST_OVERLAP=0", {"GCI_INGEST_OVERLAP": "0"}), ("product again", {}), ("GCI_INGEST_OVERLAP=0 again", {"GCI_INGEST_OVERLAP": "0"}))
         for label, extra in variants:
             env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, **extra)
             od = os.path.join(tmp, "out_ab")
