@@ -507,11 +507,14 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
         return                                            # (a contig-sharded run reads only its contigs' members, through the index)
     pool = ThreadPoolExecutor(1)
 
-    def table(raw):
+    def table(raw, threads):
         with phases.wall("bgzf_member_table (ahead, on a helper thread)"):
-            return hostio.bgzf_blocks(np.asarray(raw))
+            return hostio.bgzf_blocks(np.asarray(raw), threads=threads)
 
-    for path in paths:
+    # (the first file's table is wanted as soon as the assembly has been scanned; the later ones have the seconds the file before
+    # them takes on the device, and their threads would compete with the ones that stage that file's bytes: a quarter as many)
+    many = hostio.default_threads()
+    for k, path in enumerate(paths):
         if path in _TABLES:
             continue
         try:
@@ -520,7 +523,7 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
             raw = np.memmap(path, dtype=np.uint8, mode="r")
         except OSError:
             continue                                      # (bam_join_input meets the same error itself)
-        _TABLES[path] = (raw, pool.submit(table, raw))
+        _TABLES[path] = (raw, pool.submit(table, raw, max(2, many // 2) if k == 0 else max(2, many // 4)))
     pool.shutdown(wait=False)
 
 
