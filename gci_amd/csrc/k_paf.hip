@@ -452,19 +452,27 @@ __global__ __launch_bounds__(BLOCK) void k_paf_score(const PafHitD* __restrict__
             }
         }
     }
-    // one returning atomic per wave that emits anything
+    // ONE returning atomic per workgroup on the output counter: a returning atomic on one address costs ~6 - 12 ns whoever asks, and
+    // one per wave -- nearly every wave emits something -- was the kernel: 131 k of them in 0.77 ms for a 438 MB file, 8.4 M of
+    // them in the 96 ms of a 20 GB one
+    __shared__ uint32_t s_cnt[BLOCK / 64];
+    __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long bal = __ballot(emit);
-    if (bal) {
-        const int lane = threadIdx.x & 63, first = __builtin_ctzll(bal);
-        uint32_t base = 0;
-        if (lane == first) base = atomicAdd(n_out, (uint32_t)__builtin_popcountll(bal));
-        base = (uint32_t)__shfl((int)base, first, 64);
-        if (emit) {
-            const uint32_t w = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-            r.rec_idx = w;
-            out[w] = r;
-            out_name_off[w] = name_off;
-        }
+    if (lane == 0) s_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < BLOCK / 64; k++) tot += s_cnt[k];
+        s_base = tot ? atomicAdd(n_out, tot) : 0u;
+    }
+    __syncthreads();
+    if (emit) {
+        uint32_t w = s_base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; k++) w += s_cnt[k];
+        r.rec_idx = w;
+        out[w] = r;
+        out_name_off[w] = name_off;
     }
 }
 
