@@ -1106,7 +1106,7 @@ def ingest_number(coverage, gb):
         pipeline.GPU_INFLATE_MAX = 0                             # run by run, as for a file of this size
         try:
             t0 = time.perf_counter()
-            ji = pipeline._bam_join_input_gpu(eng, hp, raw, pos, isz, ref_sel_for, FILTER, pipeline.BAM_CHUNK_BYTES)
+            ji = pipeline._bam_join_input_gpu(eng, hp, raw, pipeline._Members(eng, pipeline.BAM_CHUNK_BYTES, pos, isz), ref_sel_for, FILTER)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         finally:

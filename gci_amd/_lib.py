@@ -126,6 +126,8 @@ EXPORTS = [
     ("gci_bgzf_scan", c_int, [c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
     ("gci_bgzf_blocks", c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
     ("gci_bgzf_table_build", c_int, [c_void_p, c_uint64, c_int, POINTER(c_void_p)]),
+    ("gci_bgzf_table_build_prefix", c_int, [c_void_p, c_uint64, c_uint64, c_int, POINTER(c_void_p)]),
+    ("gci_bgzf_table_build_fd", c_int, [c_int, c_uint64, c_int, POINTER(c_void_p)]),
     ("gci_bgzf_table_count", c_uint64, [c_void_p]),
     ("gci_bgzf_table_export", c_int, [c_void_p, c_void_p, c_void_p]),
     ("gci_bgzf_table_free", c_int, [c_void_p]),

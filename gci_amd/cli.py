@@ -150,6 +150,14 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
         clip_percent=0.1, flank_len=15, threshold=0, plot=False, depth_min=0.1, depth_max=4.0, window_size=50000,
         image_type="png", force=False, dist_percent=0.005, reference=None, regions=None, chrs=None, threads=1):
     """Same signature, checks (in the same order) and outputs as the reference's GCI() (GCI.py:897-1028)."""
+    try:
+        _gci(**locals())
+    finally:
+        pipeline.quiesce_ahead()          # (whatever was started ahead and not taken -- a run that died early -- is waited for and dropped)
+
+
+def _gci(hifi, nano, directory, prefix, map_qual, mq_cutoff, iden_percent, ovlp_percent, clip_percent, flank_len, threshold, plot,
+         depth_min, depth_max, window_size, image_type, force, dist_percent, reference, regions, chrs, threads):
     chrs_list = chrs.strip().split(",") if chrs is not None else []
     regions_bed = _load_regions(regions)
     if directory.endswith("/"):
@@ -172,6 +180,11 @@ def GCI(hifi=[], nano=[], directory=".", prefix="GCI", map_qual=30, mq_cutoff=50
             if kind.given:
                 kind.read_headers(ref_ids)
 
+    # (the first BAM file's ingestion starts now, on a helper thread: the device inflates while the assembly is scanned)
+    for kind in kinds:
+        if kind.given and kind.bams:
+            pipeline.start_ingest_ahead(kind.bams, chrs_list, (map_qual, mq_cutoff, clip_percent, iden_percent), threads)
+            break
     print("Finding gaps ...")
     with phases.wall("fasta_n_scan_upload_and_kernel"):
         Ns_bed, Ns_bed_file = pipeline.get_Ns_ref(reference, prefix, directory, force)

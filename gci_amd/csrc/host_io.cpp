@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -16,27 +17,6 @@
 namespace {
 
 struct Block { uint64_t pos, size, isize, out; };
-
-// one member header at pos -> its size and ISIZE; false: not a well-formed BGZF member inside [pos, n)
-bool member_at(const uint8_t* raw, uint64_t n, uint64_t pos, uint64_t& size, uint32_t& isize)
-{
-    if (n - pos < 18) return false;
-    const uint8_t* h = raw + pos;
-    if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8 || !(h[3] & 4)) return false;
-    const uint32_t xlen = h[10] | (h[11] << 8);
-    if (pos + 12 + xlen > n) return false;
-    int64_t bsize = -1;
-    for (uint32_t p = 12; p + 4 <= 12 + xlen;) {
-        const uint32_t slen = h[p + 2] | (h[p + 3] << 8);
-        if (h[p] == 66 && h[p + 1] == 67 && slen == 2 && p + 6 <= 12 + xlen) bsize = h[p + 4] | (h[p + 5] << 8);
-        p += 4 + slen;
-    }
-    if (bsize < 0) return false;
-    size = (uint64_t)bsize + 1;
-    if (size < 12 + xlen + 8 || pos + size > n) return false;
-    memcpy(&isize, h + size - 4, 4);
-    return true;
-}
 
 // walk the BSIZE chain of a BGZF byte string; returns a status
 int scan(const uint8_t* raw, uint64_t n, std::vector<Block>& blocks, uint64_t& total)
@@ -67,6 +47,94 @@ int scan(const uint8_t* raw, uint64_t n, std::vector<Block>& blocks, uint64_t& t
     return GCI_OK;
 }
 
+// Where the walk reads the file from.  MemSrc: the byte string itself.  FdSrc: pread() on a descriptor -- a header every
+// ~22 KB of a memory-mapped 77 GB file is one page fault per member (3.4 M of them per whole-genome BAM, 1.4 s on 16 threads that
+// contend for the one address space, while the threads that stage the file's bytes fault on it too); a pread of 32 bytes costs
+// a system call and no page-table entry.  A thread's FdSrc keeps the 32 bytes it read last: the ISIZE of a member (its last
+// four bytes) and the header of the next one arrive in one call.
+struct MemSrc {
+    const uint8_t* raw; uint64_t n;
+    bool fetch(uint64_t pos, uint32_t len, uint8_t* dst) { if (pos > n || n - pos < len) return false; memcpy(dst, raw + pos, len); return true; }
+    // the first 0x1F in [lo, hi) or ~0
+    uint64_t find_magic(uint64_t lo, uint64_t hi)
+    {
+        const uint8_t* q = (const uint8_t*)memchr(raw + lo, 0x1F, (size_t)(hi - lo));
+        return q ? (uint64_t)(q - raw) : ~0ull;
+    }
+};
+struct FdSrc {
+    int fd; uint64_t n;
+    uint64_t cpos = ~0ull; uint32_t clen = 0; uint8_t cache[32];
+    std::vector<uint8_t> win;
+    bool fetch(uint64_t pos, uint32_t len, uint8_t* dst)
+    {
+        if (pos > n || n - pos < len) return false;
+        if (cpos != ~0ull && pos >= cpos && pos + len <= cpos + clen) { memcpy(dst, cache + (pos - cpos), len); return true; }
+        if (len <= sizeof(cache)) {
+            const uint32_t want = (uint32_t)(n - pos < sizeof(cache) ? n - pos : sizeof(cache));
+            if (!read_all(pos, want, cache)) return false;
+            cpos = pos; clen = want;
+            memcpy(dst, cache, len);
+            return true;
+        }
+        return read_all(pos, len, dst);
+    }
+    bool read_all(uint64_t pos, uint32_t len, uint8_t* dst)
+    {
+        uint32_t got = 0;
+        while (got < len) {
+            const ssize_t r = pread(fd, dst + got, len - got, (off_t)(pos + got));
+            if (r <= 0) return false;
+            got += (uint32_t)r;
+        }
+        return true;
+    }
+    uint64_t find_magic(uint64_t lo, uint64_t hi)
+    {
+        const uint32_t W = 1u << 18;
+        win.resize(W);
+        for (uint64_t a = lo; a < hi; a += W) {
+            const uint32_t len = (uint32_t)(hi - a < W ? hi - a : W);
+            if (!read_all(a, len, win.data())) return ~0ull;
+            const uint8_t* q = (const uint8_t*)memchr(win.data(), 0x1F, len);
+            if (q) return a + (uint64_t)(q - win.data());
+        }
+        return ~0ull;
+    }
+};
+
+// member_at() through a source
+template <typename Src>
+bool member_via(Src& src, uint64_t pos, uint64_t& size, uint32_t& isize)
+{
+    const uint64_t n = src.n;
+    if (pos > n || n - pos < 18) return false;
+    uint8_t h[18];
+    if (!src.fetch(pos, 18, h)) return false;
+    if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8 || !(h[3] & 4)) return false;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    if (pos + 12 + xlen > n) return false;
+    int64_t bsize = -1;
+    if (xlen == 6) {                                             // what every BGZF writer makes: the one BC subfield
+        if (h[12] == 66 && h[13] == 67 && (h[14] | (h[15] << 8)) == 2) bsize = h[16] | (h[17] << 8);
+    } else {
+        std::vector<uint8_t> x(12 + (size_t)xlen);
+        if (!src.fetch(pos, 12 + xlen, x.data())) return false;
+        for (uint32_t p = 12; p + 4 <= 12 + xlen;) {
+            const uint32_t slen = x[p + 2] | (x[p + 3] << 8);
+            if (x[p] == 66 && x[p + 1] == 67 && slen == 2 && p + 6 <= 12 + xlen) bsize = x[p + 4] | (x[p + 5] << 8);
+            p += 4 + slen;
+        }
+    }
+    if (bsize < 0) return false;
+    size = (uint64_t)bsize + 1;
+    if (size < 12 + xlen + 8 || pos + size > n) return false;
+    uint8_t t[4];
+    if (!src.fetch(pos + size - 4, 4, t)) return false;
+    memcpy(&isize, t, 4);
+    return true;
+}
+
 // The same table by several threads.  The chain is serial -- a member's BSIZE says where the next one starts -- and at
 // genome size it is a page fault every ~27 KB over tens of GB (0.65 s for 64.5 GB, 25 ms at chr19 with the device waiting for
 // it).  So the byte string is cut into ranges; the thread of a range looks for the first position in it at which a member
@@ -74,17 +142,23 @@ int scan(const uint8_t* raw, uint64_t n, std::vector<Block>& blocks, uint64_t& t
 // headers exactly where the BSIZEs say: deflate output does not produce that by chance), walks from there to the end of its
 // range, and the ranges are stitched: a range's walk must END exactly where the next range's walk STARTED -- if it does not
 // (a header-like pattern inside member data), the serial walk goes on through that range.  Same table as scan().
-int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blocks, uint64_t& total)
+// limit < n: only the members that START in front of `limit` (the table of the beginning of a file, wanted before the rest).
+template <typename Src>
+int scan_mt_via(const Src& proto, int threads, std::vector<Block>& blocks, uint64_t& total, uint64_t limit = ~0ull)
 {
+    const uint64_t n_all = proto.n;
+    const uint64_t n = limit < n_all ? limit : n_all;            // the ranges cut [0, n); members are read up to n_all
     uint64_t min_range = 32ull << 20;
     if (const char* e = getenv("GCI_BGZF_RANGE")) { const long long v = atoll(e); if (v >= 64) min_range = (uint64_t)v; }   // (tests: small files)
     uint64_t R = n / min_range;
-    if (threads < 2 || R < 2) return scan(raw, n, blocks, total);
+    if (threads < 1) threads = 1;
+    if (R < 1) R = 1;
     if (R > (uint64_t)threads * 4) R = (uint64_t)threads * 4;
     struct Range { uint64_t start = ~0ull, end = 0; std::vector<Block> blocks; bool bad = false; };
     std::vector<Range> rg(R);
     std::atomic<uint64_t> next{0};
     auto work = [&]() {
+        Src src = proto;                                         // (a thread's own read cache)
         for (;;) {
             const uint64_t k = next.fetch_add(1);
             if (k >= R) return;
@@ -92,15 +166,14 @@ int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blo
             uint64_t pos = lo;
             if (k) {                                             // the first member that starts in [lo, hi)
                 pos = ~0ull;
-                for (uint64_t p = lo; p < hi && p + 18 <= n; p++) {
-                    const uint8_t* q = (const uint8_t*)memchr(raw + p, 0x1F, (size_t)(hi - p));
-                    if (!q) break;
-                    p = (uint64_t)(q - raw);
+                for (uint64_t p = lo; p < hi && p + 18 <= n_all; p++) {
+                    p = src.find_magic(p, hi);
+                    if (p == ~0ull) break;
                     uint64_t c = p, size;
                     uint32_t isz;
                     int good = 0;
-                    while (good < 4 && c < n && member_at(raw, n, c, size, isz)) { c += size; good++; }
-                    if (good == 4 || (good > 0 && c == n)) { pos = p; break; }
+                    while (good < 4 && c < n_all && member_via(src, c, size, isz)) { c += size; good++; }
+                    if (good == 4 || (good > 0 && c == n_all)) { pos = p; break; }
                 }
                 if (pos == ~0ull) { rg[k].start = ~0ull; continue; }        // no member starts in this range (one huge gap?)
             }
@@ -108,7 +181,7 @@ int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blo
             uint64_t size;
             uint32_t isz;
             while (pos < hi) {
-                if (!member_at(raw, n, pos, size, isz)) { rg[k].bad = true; break; }
+                if (!member_via(src, pos, size, isz)) { rg[k].bad = true; break; }
                 rg[k].blocks.push_back({pos, size, isz, 0});
                 pos += size;
             }
@@ -121,6 +194,7 @@ int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blo
     work();
     for (auto& th : pool) th.join();
     // stitch
+    Src src = proto;
     blocks.clear();
     total = 0;
     uint64_t pos = 0;
@@ -135,13 +209,21 @@ int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blo
         while (pos < hi) {                                       // this range started on something else: walk it serially
             uint64_t size;
             uint32_t isz;
-            if (!member_at(raw, n, pos, size, isz)) return GCI_E_MALFORMED;
+            if (!member_via(src, pos, size, isz)) return GCI_E_MALFORMED;
             blocks.push_back({pos, size, isz, total});
             total += isz;
             pos += size;
         }
     }
-    return pos == n ? GCI_OK : GCI_E_MALFORMED;
+    return (n < n_all ? pos >= n : pos == n) ? GCI_OK : GCI_E_MALFORMED;
+}
+
+int scan_mt(const uint8_t* raw, uint64_t n, int threads, std::vector<Block>& blocks, uint64_t& total)
+{
+    uint64_t min_range = 32ull << 20;
+    if (const char* e = getenv("GCI_BGZF_RANGE")) { const long long v = atoll(e); if (v >= 64) min_range = (uint64_t)v; }
+    if (threads < 2 || n / min_range < 2) return scan(raw, n, blocks, total);
+    return scan_mt_via(MemSrc{raw, n}, threads, blocks, total);
 }
 
 template <typename F>
@@ -208,6 +290,37 @@ extern "C" int gci_bgzf_table_build(const uint8_t* h_raw, uint64_t n_raw, int th
     if (!t) return GCI_E_NOMEM;
     t->n_raw = n_raw;
     const int st = scan_mt(h_raw, n_raw, threads, t->blocks, t->total);
+    if (st) { delete t; return st; }
+    *out = t;
+    return GCI_OK;
+}
+
+// The table of the members that start in front of byte `limit` of the string (t's byte length = where the last of them ends): what
+// a host needs to put the first run of a large file on the device while the rest of the table is still being made.
+extern "C" int gci_bgzf_table_build_prefix(const uint8_t* h_raw, uint64_t n_raw, uint64_t limit, int threads, gci_bgzf_table** out)
+{
+    if ((!h_raw && n_raw) || !out) return GCI_E_INVALID;
+    *out = nullptr;
+    gci_bgzf_table* t = new (std::nothrow) gci_bgzf_table();
+    if (!t) return GCI_E_NOMEM;
+    const int st = scan_mt_via(MemSrc{h_raw, n_raw}, threads, t->blocks, t->total, limit);
+    if (st) { delete t; return st; }
+    t->n_raw = t->blocks.empty() ? 0 : t->blocks.back().pos + t->blocks.back().size;
+    *out = t;
+    return GCI_OK;
+}
+
+// The same table read through a file descriptor (pread) instead of a mapping of the file: see FdSrc.
+extern "C" int gci_bgzf_table_build_fd(int fd, uint64_t n_raw, int threads, gci_bgzf_table** out)
+{
+    if (fd < 0 || !out) return GCI_E_INVALID;
+    *out = nullptr;
+    gci_bgzf_table* t = new (std::nothrow) gci_bgzf_table();
+    if (!t) return GCI_E_NOMEM;
+    t->n_raw = n_raw;
+    FdSrc src;
+    src.fd = fd; src.n = n_raw;
+    const int st = scan_mt_via(src, threads, t->blocks, t->total);
     if (st) { delete t; return st; }
     *out = t;
     return GCI_OK;

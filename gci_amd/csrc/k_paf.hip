@@ -109,29 +109,48 @@ struct LdsSrc {
     }
 };
 
+// Bytes of a source through an eight-byte window held in registers: a column of digits or a name costs one read of LDS per
+// eight bytes instead of one per byte (the reads of a lane depend on each other, ~100 cycles apiece).  A narrow source reads
+// through.
+template <typename Src>
+struct Window {
+    const Src t;
+    uint64_t base; unsigned long long w;
+    __device__ __forceinline__ Window(const Src s, uint64_t at) : t(s), base(at), w(Src::WIDE ? s.load8(at) : 0ull) {}
+    __device__ __forceinline__ uint8_t operator[](uint64_t i)
+    {
+        if (!Src::WIDE) return t[i];
+        if (i - base >= 8) { base = i; w = t.load8(i); }                   // also when i < base (unsigned)
+        return (uint8_t)(w >> (8 * (uint32_t)(i - base)));
+    }
+};
+
 // Python's int() on a column: optional blanks, optional sign, digits with single underscores between them ('1_000' is
 // 1000; '_1', '1_', '1__0' are not numbers); false = ValueError.  (A value beyond 63 bits is reported as malformed: the
 // reference would go on with a big integer.)
 template <typename Src>
-__device__ __forceinline__ bool parse_int(const Src text, uint64_t a, uint64_t b, int64_t& v)
+__device__ __forceinline__ bool parse_int(const Src src, uint64_t a, uint64_t b, int64_t& v)
 {
+    Window<Src> text(src, a);
     while (a < b && is_space(text[a])) a++;
-    while (b > a && is_space(text[b - 1])) b--;
+    if (Src::WIDE) { if (b > a && is_space(src[b - 1])) { do b--; while (b > a && is_space(src[b - 1])); } }
+    else while (b > a && is_space(text[b - 1])) b--;
     bool neg = false;
     if (a < b && (text[a] == '+' || text[a] == '-')) { neg = text[a] == '-'; a++; }
     if (a >= b) return false;
     uint64_t x = 0;
     bool prev_digit = false;
+    uint32_t nd = 0;                                   // eighteen digits cannot overflow: the test is for the ones behind them
     for (; a < b; a++) {
         const uint8_t c = text[a];
         if (c == '_') {
-            if (!prev_digit || a + 1 >= b || text[a + 1] < '0' || text[a + 1] > '9') return false;
+            if (!prev_digit || a + 1 >= b || src[a + 1] < '0' || src[a + 1] > '9') return false;
             prev_digit = false;
             continue;
         }
         if (c < '0' || c > '9') return false;
         prev_digit = true;
-        if (x > (0x7fffffffffffffffULL - (uint64_t)(c - '0')) / 10) return false;
+        if (++nd > 18 && x > (0x7fffffffffffffffULL - (uint64_t)(c - '0')) / 10) return false;
         x = x * 10 + (uint64_t)(c - '0');
     }
     v = neg ? -(int64_t)x : (int64_t)x;
@@ -144,7 +163,13 @@ __device__ __forceinline__ uint64_t hash_src(const Src text, uint64_t at, uint32
     uint64_t acc = 0;
     for (uint32_t k = 0; k * 8 < len; k++) {
         uint64_t w = 0;
-        for (int b = 0; b < 8; b++) if (k * 8 + b < len) w |= (uint64_t)text[at + k * 8 + b] << (8 * b);
+        if (Src::WIDE) {
+            w = text.load8(at + k * 8);
+            const uint32_t left = len - k * 8;
+            if (left < 8) w &= (1ull << (8 * left)) - 1ull;
+        } else {
+            for (int b = 0; b < 8; b++) if (k * 8 + b < len) w |= (uint64_t)text[at + k * 8 + b] << (8 * b);
+        }
         acc += gci_hash_word(w, k);
     }
     return gci_hash_finish(acc, len);
@@ -226,7 +251,8 @@ __device__ __forceinline__ uint32_t paf_line(const Src text, uint64_t a, uint64_
         if (c < 0) break;
         if (T.hash[c] == th && T.off[c + 1] - T.off[c] == tlen) {
             bool same = true;
-            for (uint32_t i = 0; i < tlen; i++) same = same && T.names[T.off[c] + i] == text[col[5] + i];
+            Window<Src> name(text, col[5]);
+            for (uint32_t i = 0; i < tlen; i++) same = same && T.names[T.off[c] + i] == name[col[5] + i];
             if (same) { t = c; break; }
         }
     }

@@ -79,37 +79,46 @@ class _Staging:
     """A ring of pinned host buffers through which the bytes of a memory-mapped file travel to the device: host threads copy a
     piece of the mapping into a slot (parallel memcpy out of the page cache: the page faults are theirs, not the copy engine's),
     the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
-    SLOT = 64 << 20              # (page-locking costs ~0.3 s per GB on these hosts: a ring of 256 MB, not of 1.2 GB)
-    SLOTS = 4
-    THREADS = 8
+    SLOT = int(os.environ.get("GCI_STAGING_SLOT_MB", "64")) << 20    # (page-locking costs ~0.3 s per GB on these hosts: a ring of 256 MB, not of 1.2 GB)
+    SLOTS = int(os.environ.get("GCI_STAGING_SLOTS", "4"))
+    THREADS = int(os.environ.get("GCI_STAGING_THREADS", "8"))
 
     def __init__(self, engine=None):
-        self.slots = [torch.empty(self.SLOT, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
-        self.views = [s.numpy() for s in self.slots]
+        self.slots = [None] * self.SLOTS
+        self.views = [None] * self.SLOTS
         self.free_at = [None] * self.SLOTS
         self.next = 0
         self.pool = ThreadPoolExecutor(self.THREADS)
+        self.lock = threading.Lock()            # (two senders -- the assembly and the first run of a BAM file -- take slots in turns)
+
+        def pin(k):                             # page-locking 64 MB takes ~20 ms: the slots side by side, the first piece waits for one
+            self.slots[k] = torch.empty(self.SLOT, dtype=torch.uint8).pin_memory()
+            self.views[k] = self.slots[k].numpy()
+
+        self.pinned = [self.pool.submit(pin, k) for k in range(self.SLOTS)]
 
     def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream) -> None:
         """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued."""
         for a in range(p0, p1, self.SLOT):
             b = min(p1, a + self.SLOT)
-            k = self.next
-            self.next = (k + 1) % self.SLOTS
-            if self.free_at[k] is not None:
-                self.free_at[k].synchronize()                  # (the helper thread waits; the device and the main thread do not)
-            view = self.views[k]
-            step = -(-(b - a) // self.THREADS)
-            step = (step + 4095) // 4096 * 4096
-            jobs = [self.pool.submit(np.copyto, view[x - a:min(b, x + step) - a], raw[x:min(b, x + step)]) for x in range(a, b, step)]
-            for j in jobs:
-                j.result()
-            _forget_pages(raw, a, b)
-            with torch.cuda.stream(stream):
-                dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-            self.free_at[k] = ev
+            with self.lock:
+                k = self.next
+                self.next = (k + 1) % self.SLOTS
+                if self.free_at[k] is not None:
+                    self.free_at[k].synchronize()              # (the helper thread waits; the device and the main thread do not)
+                self.pinned[k].result()
+                view = self.views[k]
+                step = -(-(b - a) // self.THREADS)
+                step = (step + 4095) // 4096 * 4096
+                jobs = [self.pool.submit(np.copyto, view[x - a:min(b, x + step) - a], raw[x:min(b, x + step)]) for x in range(a, b, step)]
+                for j in jobs:
+                    j.result()
+                _forget_pages(raw, a, b)
+                with torch.cuda.stream(stream):
+                    dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                self.free_at[k] = ev
 
 
 
@@ -154,6 +163,9 @@ class Engine:
         self._status = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._members_host = None                 # pinned staging buffer of depth_deflate()
+        self._staging = None
+        self._copy_stream = None
+        self._lock = threading.Lock()
         m = os.environ.get("GCI_JOIN", "")
         self.join_mode = 1 if m.startswith("c") else 2 if m.startswith("p") else 0    # what gci_ctx_create read
 
@@ -197,15 +209,25 @@ class Engine:
         does next."""
         a = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
         n = int(a.shape[0])
-        if getattr(self, "_staging", None) is None:
-            self._staging = _Staging(self)
-        if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=self.device)
+        staging, copy = self.staging(), self.copy_stream()
         dst = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
-        self._copy_stream.wait_stream(self.stream)
-        self._staging.send(a, 0, n, dst, self._copy_stream)
-        self.stream.wait_stream(self._copy_stream)
+        copy.wait_stream(self.stream)
+        staging.send(a, 0, n, dst, copy)
+        self.stream.wait_stream(copy)
         return dst[:n]
+
+    def staging(self) -> "_Staging":
+        """The engine's ring of pinned buffers (made on first use; a helper thread may be the first)."""
+        with self._lock:
+            if self._staging is None:
+                self._staging = _Staging(self)
+            return self._staging
+
+    def copy_stream(self) -> "torch.cuda.Stream":
+        with self._lock:
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            return self._copy_stream
 
     # ---- per-kernel HIP-event timing (library side, on the ctx stream) -------------------------
     def profile_enable(self, mask: int) -> None:
@@ -485,9 +507,7 @@ class Engine:
         n_raw = int(raw.shape[0])
         cuts = sorted({min(n_raw, (n_raw * (k + 1) // parts + 15) & ~15) for k in range(parts)} | {n_raw})
         d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
-        if getattr(self, "_copy_stream", None) is None:          # (creating a stream costs milliseconds: one per engine)
-            self._copy_stream = torch.cuda.Stream(device=self.device)
-        copy_stream = self._copy_stream
+        copy_stream = self.copy_stream()                         # (creating a stream costs milliseconds: one per engine)
         copy_stream.wait_stream(self.stream)                     # (the allocation may recycle memory still in use on the main stream)
         events = [torch.cuda.Event() for _ in cuts]
         queued = [threading.Event() for _ in cuts]               # (a CUDA event that was never recorded counts as complete)

@@ -125,7 +125,13 @@ def indexed(path: str):
     key = (os.path.realpath(path), st.st_size, st.st_mtime_ns)
     if _INDEXED is not None and _INDEXED[0] == key:
         return _INDEXED[1], _INDEXED[2]
-    buf = load(path)
+    # a large assembly is looked at through a mapping of the file (the title lines are found by threads that fault the page
+    # cache's pages in sixteen at a time; the bytes go to the device through the pinned ring straight from it) instead of being
+    # read into 3 GB of fresh memory first (0.34 - 0.55 s of the command line at genome size); GCI_FASTA_LOAD=read: as before
+    if st.st_size >= (64 << 20) and os.environ.get("GCI_FASTA_LOAD", "mmap") == "mmap":
+        buf = np.memmap(path, dtype=np.uint8, mode="r")
+    else:
+        buf = load(path)
     n = int(buf.shape[0])
     starts = [int(p) for p in hostio.fasta_titles(buf)]
     spans = []

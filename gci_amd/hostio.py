@@ -91,13 +91,41 @@ def gzip_members(text, threads: int = 0, chunk: int = 8 << 20, level: int = 1) -
     return out[:n.value].tobytes()
 
 
-def bgzf_blocks(raw: np.ndarray, threads: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+def bgzf_blocks(raw: np.ndarray, threads: Optional[int] = None, limit: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
     """Member table of a BGZF byte array: (uint64 byte offsets with one trailing entry = len(raw), uint64 ISIZEs).  One pass over
-    the member headers by `threads` host threads (default: what the container may use; gci_bgzf_table_build)."""
+    the member headers by `threads` host threads (default: what the container may use; gci_bgzf_table_build).
+    limit: only the members that start in front of that byte (the trailing offset = where the last of them ends;
+    gci_bgzf_table_build_prefix)."""
     lib = _lib.load()
     p = raw.ctypes.data_as(ctypes.c_void_p)
     h = ctypes.c_void_p(None)
-    _chk(lib.gci_bgzf_table_build(p, raw.shape[0], int(threads if threads else default_threads()), ctypes.byref(h)), "gci_bgzf_table_build")
+    th = int(threads if threads else default_threads())
+    if limit is not None and limit < raw.shape[0]:
+        _chk(lib.gci_bgzf_table_build_prefix(p, raw.shape[0], int(limit), th, ctypes.byref(h)), "gci_bgzf_table_build_prefix")
+    else:
+        _chk(lib.gci_bgzf_table_build(p, raw.shape[0], th, ctypes.byref(h)), "gci_bgzf_table_build")
+    try:
+        n = int(lib.gci_bgzf_table_count(h))
+        pos = np.empty(n + 1, dtype=np.uint64)
+        isz = np.empty(max(n, 1), dtype=np.uint64)
+        _chk(lib.gci_bgzf_table_export(h, pos.ctypes.data_as(ctypes.c_void_p), isz.ctypes.data_as(ctypes.c_void_p)), "gci_bgzf_table_export")
+    finally:
+        lib.gci_bgzf_table_free(h)
+    return pos, isz[:n]
+
+
+def bgzf_blocks_file(path: str, threads: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """bgzf_blocks() of a file, read with pread() through a descriptor instead of a mapping (gci_bgzf_table_build_fd): no page
+    fault per member, nothing of the file enters the address space."""
+    import os
+    lib = _lib.load()
+    h = ctypes.c_void_p(None)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        size = os.fstat(fd).st_size
+        _chk(lib.gci_bgzf_table_build_fd(fd, size, int(threads if threads else default_threads()), ctypes.byref(h)), "gci_bgzf_table_build_fd")
+    finally:
+        os.close(fd)
     try:
         n = int(lib.gci_bgzf_table_count(h))
         pos = np.empty(n + 1, dtype=np.uint64)

@@ -17,6 +17,8 @@ _WALL: List[Tuple[str, float]] = []
 _GPU: List[Tuple[str, object, object]] = []
 _NOTES: Dict[str, object] = {}
 _T0 = 0.0
+_TRACE = os.environ.get("GCI_PHASES_TRACE", "0") == "1"
+_BASE = None
 
 
 def start() -> None:
@@ -25,6 +27,8 @@ def start() -> None:
     _WALL.clear()
     _GPU.clear()
     _NOTES.clear()
+    global _BASE
+    _BASE = None
     _T0 = time.perf_counter()
 
 
@@ -65,6 +69,13 @@ def gpu(name: str, stream=None):
         yield
         return
     import torch
+    global _BASE
+    if _TRACE and _BASE is None:                          # a common clock: an event right behind a synchronisation + the host's time then
+        torch.cuda.synchronize()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        e.synchronize()
+        _BASE = (e, now())
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(stream)
     try:
@@ -72,6 +83,17 @@ def gpu(name: str, stream=None):
     finally:
         b.record(stream)
         _GPU.append((name, a, b))
+
+
+def now() -> float:
+    """Seconds since the log was started (0.0 when it is off)."""
+    return time.perf_counter() - _T0 if _ON else 0.0
+
+
+def trace(kind: str, *values) -> None:
+    """One line of the per-run trace of the ingestion (GCI_PHASES_TRACE=1): kept in the notes as "trace"."""
+    if _ON and _TRACE:
+        _NOTES.setdefault("trace", []).append([kind] + [round(v, 4) if isinstance(v, float) else v for v in values])
 
 
 def note(key: str, value) -> None:
@@ -94,6 +116,9 @@ def report(path: Optional[str] = None) -> dict:
         torch.cuda.synchronize()
         for name, a, b in _GPU:
             out["gpu_s"][name] = out["gpu_s"].get(name, 0.0) + a.elapsed_time(b) * 1e-3
+        if _TRACE and _BASE is not None:                  # every stage on the host's clock: [name, begin, end]
+            e0, t0 = _BASE
+            out["gpu_trace"] = [[name, round(t0 + e0.elapsed_time(a) * 1e-3, 4), round(t0 + e0.elapsed_time(b) * 1e-3, 4)] for name, a, b in _GPU]
     if path:
         with open(path, "w") as f:
             json.dump(out, f, indent=1)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 import warnings
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -38,11 +39,15 @@ _ENGINE: Optional[Engine] = None
 SHARD = None              # gci_amd.shard.Context of a multi-GPU run (set by cli.main), None for a single process
 
 
+_ENGINE_LOCK = threading.Lock()
+
+
 def default_engine() -> Engine:
     global _ENGINE
-    if _ENGINE is None:
-        _ENGINE = Engine(SHARD.device_index if SHARD is not None else 0)
-    return _ENGINE
+    with _ENGINE_LOCK:                                    # (the helper thread of prefetch_member_tables may be the first to ask)
+        if _ENGINE is None:
+            _ENGINE = Engine(SHARD.device_index if SHARD is not None else 0)
+        return _ENGINE
 
 
 def _slice_bound(v: int, L: int) -> int:
@@ -144,7 +149,12 @@ def refuse_overwrite(path: str, force) -> None:
 
 
 def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
-    _, ns_bed = fasta.n_runs_device(default_engine(), reference)          # N4: the scan itself runs on the GPU
+    if _INGEST_AHEAD:                                                     # (a helper thread owns the default context just now)
+        side = _side_engine()
+        with torch.cuda.stream(side.stream):
+            _, ns_bed = fasta.n_runs_device(side, reference)
+    else:
+        _, ns_bed = fasta.n_runs_device(default_engine(), reference)      # N4: the scan itself runs on the GPU
     if len(ns_bed) > 0:
         path = f"{directory}/{prefix}.gaps.bed"
         refuse_overwrite(path, force)
@@ -314,80 +324,171 @@ def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
     return JoinInput(torch.cat([p.recs for p in parts]), names, torch.cat(offs), 0)
 
 
+def _runs_of_members(engine: Engine, isz: np.ndarray, chunk_bytes: int) -> List[Tuple[int, int]]:
+    """Runs of members of at most chunk_bytes inflated -- and a whole number of the device's decode rounds each: every member takes
+    about as long as every other, so 65 536 members (4 GiB) on a device that decodes 28 672 at a time cost three rounds for the
+    work of 2.3 (bench.py's ingest of 64.5 GB: 4.1 s; with whole rounds per run: see DESIGN.md section 5).  Greedy, cut by cut
+    on the running sum (a loop over the 3.4 M members of a whole-genome file is a quarter of a second of interpreter)."""
+    n = int(isz.shape[0])
+    cs = np.concatenate([np.zeros(1, dtype=np.int64), np.cumsum(isz.astype(np.int64))])
+    total = int(cs[-1])
+    rnd = engine.inflate_round()
+    per_run = 0
+    if rnd > 0:
+        per_run = max(1, int(chunk_bytes // max(1, total // max(1, n))) // rnd) * rnd
+    groups, a = [], 0
+    while a < n:
+        i = int(np.searchsorted(cs, cs[a] + chunk_bytes, side="right")) - 1      # the most members that stay within chunk_bytes
+        if per_run:
+            i = min(i, a + per_run)
+        i = min(n, max(i, a + 1))
+        groups.append((a, i))
+        a = i
+    return groups or [(0, 0)]
+
+
+class _Members:
+    """The member table of a BGZF file as far as it is known -- the whole of it, or the table of the BEGINNING of the file with more
+    still being made (`rest`: a future of (offsets, ISIZEs, the future behind that or None)) -- and the runs of members the
+    ingestion goes through (`group(k)`).  Runs are cut from what is known (all but the last, possibly partial, one while more is
+    to come), so that the first run can be on the device before the walk through the 3.4 M member headers of a whole-genome file
+    (0.7 s of page faults) is over; asking for a run behind the known ones waits for the next piece."""
+
+    def __init__(self, engine: Engine, chunk_bytes: int, pos: np.ndarray, isz: np.ndarray, rest=None):
+        self.engine, self.chunk_bytes = engine, int(chunk_bytes)
+        self.pos, self.isz, self._rest = pos, isz, None
+        self.lock = threading.Lock()
+        self.groups: List[Tuple[int, int]] = []
+        self._extend(pos, isz, rest)
+
+    def _extend(self, pos, isz, rest) -> None:
+        done = self.groups[-1][1] if self.groups else 0
+        if done < int(isz.shape[0]):
+            more = [(a + done, b + done) for a, b in _runs_of_members(self.engine, isz[done:], self.chunk_bytes)]
+            self.groups += more[:-1] if rest is not None else more
+        self.pos, self.isz, self._rest = pos, isz, rest
+
+    def group(self, k: int) -> Optional[Tuple[int, int]]:
+        """Run k as (first member, one past its last), None behind the last run; self.pos / self.isz cover it afterwards."""
+        with self.lock:
+            while k >= len(self.groups) and self._rest is not None:
+                self._extend(*self._rest.result())
+            return self.groups[k] if k < len(self.groups) else None
+
+    def is_last(self, k: int) -> bool:
+        """Run k is known to be the last one (False while more of the table is to come)."""
+        with self.lock:
+            return self._rest is None and k + 1 >= len(self.groups)
+
+    def run_bytes(self) -> List[int]:
+        """File bytes of every run known so far."""
+        with self.lock:
+            return [int(self.pos[hi]) - int(self.pos[lo]) for lo, hi in self.groups]
+
+    def whole(self) -> Tuple[np.ndarray, np.ndarray]:
+        with self.lock:
+            while self._rest is not None:
+                self._extend(*self._rest.result())
+            return self.pos, self.isz
+
+    def lazy(self) -> bool:
+        return self._rest is not None
+
+
 class _RunUploads:
     """Uploads of a large BGZF file run by run of members, one run AHEAD of its consumer: two device buffers taken in turns, the
     bytes staged through pinned memory by host threads (`_Staging`) and copied on a stream of their own from a helper thread, so
     that run k + 1 crosses PCIe while the device inflates, walks and filters run k."""
 
-    def __init__(self, engine: Engine, raw, pos: np.ndarray, groups):
-        import torch
+    def __init__(self, engine: Engine, raw, members: _Members):
         from concurrent.futures import ThreadPoolExecutor
-        self.engine, self.raw, self.pos, self.groups = engine, raw, pos, groups
-        cap = max(int(pos[hi]) - int(pos[lo]) for lo, hi in groups) + 16
-        with torch.cuda.stream(engine.stream):
-            self.bufs = [torch.empty(cap, dtype=torch.uint8, device=engine.device) for _ in range(min(2, len(groups)))]
-        if getattr(engine, "_copy_stream", None) is None:
-            engine._copy_stream = torch.cuda.Stream(device=engine.device)
-        self.copy = engine._copy_stream
-        self.copy.wait_stream(engine.stream)                 # (the buffers may recycle memory still in use on the main stream)
-        self.freed = [None] * len(self.bufs)                 # main-stream event behind the last kernel that read the buffer
+        self.engine, self.raw, self.m = engine, raw, members
+        self.bufs = [None, None]
+        self.copy = engine.copy_stream()
+        self.freed = [None, None]                            # main-stream event behind the last kernel that read the buffer
         self.staged = isinstance(raw, np.memmap) and os.environ.get("GCI_UPLOAD", "staged") == "staged"
-        if self.staged and getattr(engine, "_staging", None) is None:
-            engine._staging = _Staging(engine)
+        self.staging = engine.staging() if self.staged else None
+        self.last_sent = threading.Event()                   # the last run's bytes are all enqueued: the ring is the next file's
         self.pool = ThreadPoolExecutor(1)
         self.pending = {}
         self._start(0)
 
+    def _buffer(self, k: int, need: int):
+        """The device buffer of run k (>= need bytes): one of two, made -- or made larger -- when a run asks for more than is there
+        (all the runs known by then are looked at, so that a file is served by two allocations, three when its first run was cut
+        from the beginning of the table)."""
+        i = k & 1
+        if self.bufs[i] is None or int(self.bufs[i].shape[0]) < need:
+            want = max([need] + [n + 16 for n in self.m.run_bytes()])
+            self.bufs[i] = None
+            # from the COPY stream's pool: a block recycled there was last used in that stream's order, so the upload need not wait
+            # for whatever the main stream is busy with (the file in front is still being inflated when the next file's first
+            # run leaves); the main stream's use of it is told to the allocator instead
+            with torch.cuda.stream(self.copy):
+                self.bufs[i] = torch.empty(want, dtype=torch.uint8, device=self.engine.device)
+            self.bufs[i].record_stream(self.engine.stream)
+        return self.bufs[i]
+
     def _start(self, k: int):
-        import torch
-        if k >= len(self.groups):
-            return
-        lo, hi = self.groups[k]
-        p0, p1 = int(self.pos[lo]), int(self.pos[hi])
-        buf, freed = self.bufs[k % len(self.bufs)], self.freed[k % len(self.bufs)]
+        freed = self.freed[k & 1]
 
         def run():
+            g = self.m.group(k)                              # (a run behind the first may wait here for the rest of the table)
+            if g is None:
+                self.last_sent.set()
+                return None
+            lo, hi = g
+            p0, p1 = int(self.m.pos[lo]), int(self.m.pos[hi])
+            n = p1 - p0
+            buf = self._buffer(k, n + 16)
+            t_send = phases.now()
             with torch.cuda.stream(self.copy), warnings.catch_warnings():
                 warnings.simplefilter("ignore", UserWarning)     # a read-only memmap is only read
                 if freed is not None:
                     self.copy.wait_event(freed)
-                n = p1 - p0
                 if self.staged:
-                    self.engine._staging.send(self.raw, p0, p1, buf, self.copy)
+                    self.staging.send(self.raw, p0, p1, buf, self.copy)
                 else:
                     buf[:n].copy_(torch.from_numpy(np.asarray(self.raw[p0:p1])))
                 buf[n:n + 16].zero_()
                 ev = torch.cuda.Event()
                 ev.record(self.copy)
+            phases.trace("upload", k, t_send, phases.now(), n)
+            if self.m.is_last(k):
+                self.last_sent.set()
             return buf[:n + 16], ev
 
         self.pending[k] = self.pool.submit(run)
 
     def take(self, k: int):
-        """-> run k's bytes on the device (+ 16 zero bytes), ordered before whatever the main stream does next."""
-        d_raw, ev = self.pending.pop(k).result()
+        """-> run k's bytes on the device (+ 16 zero bytes), ordered before whatever the main stream does next; None: no run k."""
+        got = self.pending.pop(k).result()
+        if got is None:
+            return None
+        d_raw, ev = got
         self.engine.stream.wait_event(ev)
         self._start(k + 1)                                   # into the other buffer: its last reader (run k - 1) is enqueued
         return d_raw
 
     def release(self, k: int):
         """Everything that reads run k's buffer has been enqueued on the main stream: the run after next may overwrite it."""
-        import torch
         ev = torch.cuda.Event()
         ev.record(self.engine.stream)
-        self.freed[k % len(self.bufs)] = ev
+        self.freed[k & 1] = ev
 
     def close(self):
-        for f in self.pending.values():
+        for f in list(self.pending.values()):
             try:
                 f.result()
-            except Exception:
+            except Exception:                             # noqa: BLE001
                 pass
+        self.pending.clear()
         self.pool.shutdown(wait=True)
+        self.last_sent.set()
 
 
-def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np.ndarray, ref_sel_for, filt, chunk_bytes: int,
-                        upload=None) -> Optional[JoinInput]:
+def _bam_join_input_gpu(engine: Engine, path: str, raw, members: _Members, ref_sel_for, filt, upload=None,
+                        uploads: Optional[_RunUploads] = None) -> Optional[JoinInput]:
     """ingest = "gpu".  A file whose inflated stream fits GCI_GPU_INFLATE_MAX stays on the device whole (the join reads
     the names inside it); a larger one goes through run by run of members (at most chunk_bytes inflated each): inflate,
     record walk, K1, and only the 32-byte records and the packed names are kept -- the partial record a run ends in is
@@ -396,8 +497,12 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
     hdr = bamfmt.read_header(path)
     ref_sel = ref_sel_for(hdr)
     n_ref = len(hdr.references)
-    total = int(isz.sum())
-    if total <= GPU_INFLATE_MAX:
+    if not members.lazy() and int(members.isz.sum()) <= GPU_INFLATE_MAX:
+        pos, isz = members.pos, members.isz
+        total = int(isz.sum())
+        if uploads is not None:
+            uploads.close()
+            uploads = None
         with phases.gpu("bgzf_inflate + crc"):
             if upload is not None:
                 d_bam = engine.bgzf_inflate_uploaded(upload, pos, isz, check_crc=BGZF_CRC)
@@ -415,28 +520,24 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
         upload["future"].result()
         upload["pool"].shutdown()
         upload = None
-    # Runs of members of at most chunk_bytes inflated -- and a whole number of the device's decode rounds each: every member takes
-    # about as long as every other, so 65 536 members (4 GiB) on a device that decodes 28 672 at a time cost three rounds for the
-    # work of 2.3 (bench.py's ingest of 64.5 GB: 4.1 s; with whole rounds per run: see DESIGN.md section 5)
-    rnd = engine.inflate_round()
-    per_run = 0
-    if rnd > 0:
-        per_run = max(1, int(chunk_bytes // max(1, total // max(1, len(isz)))) // rnd) * rnd
-    groups, a, acc = [], 0, 0
-    for i, sz in enumerate(isz.tolist()):
-        if acc and (acc + sz > chunk_bytes or (per_run and i - a >= per_run)):
-            groups.append((a, i))
-            a, acc = i, 0
-        acc += sz
-    groups.append((a, len(isz)))
+    # the bytes of run k + 1 travel while run k is inflated and filtered (the first run may be on its way already:
+    # prefetch_member_tables)
+    ahead = uploads if uploads is not None else _RunUploads(engine, raw, members)
     parts: List[JoinInput] = []
     carry, start, n_done = None, hdr.first_record, 0
-    ahead = _RunUploads(engine, raw, pos, groups)             # the bytes of run k + 1 travel while run k is inflated and filtered
     try:
-        for k, (lo, hi) in enumerate(groups):
-            p0 = int(pos[lo])
+        k = -1
+        while True:
+            k += 1
+            t_take = phases.now()
             with phases.wall("  wait for the upload of a run (host blocked)"):
                 d_raw = ahead.take(k)
+            if d_raw is None:
+                break
+            t_got = phases.now()
+            lo, hi = members.group(k)
+            pos, isz = members.pos, members.isz
+            p0 = int(pos[lo])
             try:
                 with phases.gpu("bgzf_inflate + crc"):
                     d_buf = engine.bgzf_inflate(None, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry, d_raw=d_raw)
@@ -446,6 +547,7 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
                 raise
             ahead.release(k)
             del d_raw
+            phases.trace("run", k, t_take, t_got, phases.now())
             if int(d_buf.shape[0]) <= start:                  # still inside the header
                 carry, start = None, start - int(d_buf.shape[0])
                 continue
@@ -465,6 +567,7 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, pos: np.ndarray, isz: np
             parts.append(_keep_part(engine, ji))
             n_done += int(d_off.shape[0])
             del d_buf, d_off, ji
+            phases.trace("run_done", k, phases.now())
     finally:
         ahead.close()
     if carry is not None:
@@ -493,28 +596,25 @@ def _drop_later(*objs) -> None:
     _DROP_QUEUE.put(objs)
 
 
-_TABLES: Dict[str, object] = {}        # path -> (memory map of the file, future of its BGZF member table): prefetch_member_tables
+_TABLES: Dict[str, object] = {}        # path -> (memory map of the file, future of (member offsets, ISIZEs, first-run uploader or
+                                       # None)): prefetch_member_tables
 
 
 def prefetch_member_tables(paths: Sequence[str]) -> None:
-    """Start on the BGZF member tables of the BAM files of a run (host threads, file after file) before anything needs them: the
-    command line calls this as soon as it knows its inputs, so the first file's table is made while the assembly is read and
-    scanned for N runs, and every later file's while the file before it is inflated on the device -- at genome size half a second
-    per file that used to sit in front of the file's first byte on the device.  bam_join_input() picks the results up; an
-    unreadable or damaged file raises there, where it did before."""
+    """Start on the BAM files of a run before anything needs them, on a helper thread, file after file: the BGZF member table
+    (host threads over the mapping of the file; GCI_BGZF_TABLE=pread reads the headers through a descriptor instead -- no page
+    fault per member, but slower on the boxes measured) and, for a file that will go through the device run by run, the upload of its FIRST run -- as soon as the table is there and
+    the file before it has put its last run on the copy stream.  The command line calls this as soon as it knows its inputs: the
+    first file's table and first run are made while the assembly is read and scanned for N runs, every later file's while the
+    file before it is inflated on the device -- what used to sit in front of the file's first byte on the device (half a second
+    of table, a third of a second of upload, per file at genome size).  bam_join_input() picks the results up; an unreadable or
+    damaged file raises there, where it did before."""
+    from concurrent.futures import Future
     from . import hostio
     if os.environ.get("GCI_BAM_INGEST", "gpu") != "gpu" or not paths or _sharded():
         return                                            # (a contig-sharded run reads only its contigs' members, through the index)
-    pool = ThreadPoolExecutor(1)
-
-    def table(raw, threads):
-        with phases.wall("bgzf_member_table (ahead, on a helper thread)"):
-            return hostio.bgzf_blocks(np.asarray(raw), threads=threads)
-
-    # (the first file's table is wanted as soon as the assembly has been scanned; the later ones have the seconds the file before
-    # them takes on the device, and their threads would compete with the ones that stage that file's bytes: a quarter as many)
-    many = hostio.default_threads()
-    for k, path in enumerate(paths):
+    todo = []
+    for path in paths:
         if path in _TABLES:
             continue
         try:
@@ -523,8 +623,144 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
             raw = np.memmap(path, dtype=np.uint8, mode="r")
         except OSError:
             continue                                      # (bam_join_input meets the same error itself)
-        _TABLES[path] = (raw, pool.submit(table, raw, max(2, many // 2) if k == 0 else max(2, many // 4)))
-    pool.shutdown(wait=False)
+        fut = Future()
+        _TABLES[path] = (raw, fut)
+        todo.append((path, raw, fut))
+    # (the first file's table is wanted as soon as the assembly has been scanned; the later ones have the seconds the file before
+    # them takes on the device, and their threads would compete with the ones that stage that file's bytes: a quarter as many)
+    many = hostio.default_threads()
+    by_fd = os.environ.get("GCI_BGZF_TABLE", "mmap") == "pread"     # (measured at genome size on tmpfs: pread 1.7 - 2.2 s, the mapping 1.2 - 1.4 s)
+    first_run = os.environ.get("GCI_FIRST_RUN_AHEAD", "1") != "0" and os.environ.get("GCI_UPLOAD", "staged") == "staged"
+
+    def table(path, raw, threads, limit=None, known=None):
+        """The member table up to byte `limit` (None: all of the file); known = the table of a beginning of the file: only what lies
+        behind it is walked."""
+        with phases.wall("bgzf_member_table (ahead, on a helper thread)"):
+            if by_fd and limit is None and known is None:
+                return hostio.bgzf_blocks_file(path, threads=threads)
+            begin = int(known[0][-1]) if known is not None else 0
+            if begin >= int(raw.shape[0]):
+                return known
+            pos, isz = hostio.bgzf_blocks(np.asarray(raw[begin:]), threads=threads, limit=None if limit is None else limit - begin)
+            if known is None:
+                return pos, isz
+            return np.concatenate([known[0][:-1], pos + np.uint64(begin)]), np.concatenate([known[1], isz])
+
+    def chain():
+        from concurrent.futures import Future
+        before = None                                     # the uploader of the file in front
+        for k, (path, raw, fut) in enumerate(todo):
+            try:
+                threads = max(2, many // 2) if k == 0 else max(2, many // 4)
+                n_raw = int(raw.shape[0])
+                if k == 0 and first_run and n_raw > GPU_INFLATE_MAX + (GPU_INFLATE_MAX >> 6):
+                    # (more bytes than a whole-file ingestion may inflate to: run by run for certain.)  The table of the beginning of
+                    # the file, the first run on its way, and only then the walk through the rest of the file's members
+                    engine = default_engine()
+                    # (5/8 of a run's inflated size in file bytes holds a whole first run at the usual 2.4 - 4 : 1; four times a
+                    # run's size holds eight more: a second of inflate, which covers the walk through the rest)
+                    limits = [x for x in (BAM_CHUNK_BYTES * 5 // 8, BAM_CHUNK_BYTES * 4) if x < n_raw]
+                    rests = [Future() for _ in limits]
+                    first = table(path, raw, threads, limit=limits[0]) if limits else table(path, raw, threads)
+                    members = _Members(engine, BAM_CHUNK_BYTES, first[0], first[1], rests[0] if rests else None)
+                    before = _RunUploads(engine, raw, members)
+                    fut.set_result((members, before))
+                    nxt = first
+                    for j, rest in enumerate(rests):
+                        try:
+                            nxt = table(path, raw, threads, limit=limits[j + 1] if j + 1 < len(limits) else None, known=nxt)
+                            rest.set_result((nxt[0], nxt[1], rests[j + 1] if j + 1 < len(rests) else None))
+                        except BaseException as e:        # noqa: BLE001  (raised where the run behind the known ones is asked for)
+                            for r in rests[j:]:
+                                r.set_exception(e)
+                            break
+                    continue
+                pos, isz = table(path, raw, threads)
+                if first_run and n_raw > GPU_INFLATE_MAX // 8 and int(isz.sum()) > GPU_INFLATE_MAX:
+                    engine = default_engine()
+                    members = _Members(engine, BAM_CHUNK_BYTES, pos, isz)
+                    if before is not None:
+                        before.last_sent.wait()           # (the ring of pinned buffers is the file's in front until then)
+                    before = _RunUploads(engine, raw, members)
+                    fut.set_result((members, before))
+                else:
+                    fut.set_result(((pos, isz), None))
+            except BaseException as e:                    # noqa: BLE001  (handed to the thread that asks for the table)
+                if not fut.done():
+                    fut.set_exception(e)
+
+    threading.Thread(target=chain, daemon=True).start()
+
+
+_INGEST_AHEAD: Dict[str, tuple] = {}   # path -> (key, future of its JoinInput): start_ingest_ahead
+_SIDE_ENGINE = None
+
+
+def _targets_of(first, chrs_list) -> Dict[str, int]:
+    return {r: l for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)}
+
+
+def start_ingest_ahead(bam_files: Sequence[str], chrs_list, filt: Tuple[int, int, float, float], threads: int) -> None:
+    """The ingestion of the run's FIRST BAM file -- upload, inflate, record walk, pages, K1: bam_join_input() as filter() will
+    call it -- started on a helper thread before the command line turns to the assembly's N runs: at genome size the device
+    inflates for four seconds per file and used to idle through the 0.6 s the assembly takes to cross PCIe and be scanned.
+    The helper is the ONLY user of the default engine's context until filter() has taken its result (filter() asks for it
+    before it touches the context; the N scan meanwhile runs on a context and stream of its own: get_Ns_ref).  Whatever the
+    ingestion raises is raised by filter() where bam_join_input() would have raised it."""
+    from concurrent.futures import Future
+    if (os.environ.get("GCI_INGEST_AHEAD", "1") == "0" or os.environ.get("GCI_BAM_INGEST", "gpu") != "gpu" or _sharded()
+            or not bam_files or bam_files[0] in _INGEST_AHEAD or not torch.cuda.is_available()):
+        return
+    path = bam_files[0]
+    try:
+        targets = list(_targets_of(bamfmt.read_header(path), chrs_list).keys())
+    except Exception:                                     # noqa: BLE001  (filter() meets the same error itself)
+        return
+    fut = Future()
+    engine = default_engine()
+    key = (id(engine), tuple(targets), tuple(filt), threads)
+
+    def run():
+        try:
+            fut.set_result(bam_join_input(engine, path, targets, filt, threads))
+        except BaseException as e:                        # noqa: BLE001
+            fut.set_exception(e)
+
+    _INGEST_AHEAD[path] = (key, fut)
+    threading.Thread(target=run, daemon=True).start()
+
+
+def quiesce_ahead() -> None:
+    """Nothing started ahead is left running or waiting: ingestions not taken by a filter() are waited for (their helper threads
+    own the default context until they are done), tables and first-run uploads nobody asked for are dropped."""
+    for path in list(_INGEST_AHEAD):
+        _, fut = _INGEST_AHEAD.pop(path)
+        fut.exception()                                   # (waits; the outcome is nobody's any more)
+    for path in list(_TABLES):
+        _drop_ahead(_TABLES.pop(path))
+
+
+def _side_engine() -> Engine:
+    """A second context on a stream of its own (sharing the default engine's ring of pinned buffers): what the main thread works
+    with while a helper thread owns the default one (start_ingest_ahead)."""
+    global _SIDE_ENGINE
+    if _SIDE_ENGINE is None:
+        main = default_engine()
+        _SIDE_ENGINE = Engine(main.device.index, stream=torch.cuda.Stream(device=main.device))
+        _SIDE_ENGINE._staging = main.staging()
+    return _SIDE_ENGINE
+
+
+def _drop_ahead(ahead) -> None:
+    """A prefetched table nobody will use: its uploader (if one was started) is closed once it exists."""
+    def done(fut):
+        try:
+            up = fut.result()[1]
+            if up is not None:
+                up.close()
+        except BaseException:                             # noqa: BLE001
+            pass
+    ahead[1].add_done_callback(done)
 
 
 def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tuple[int, int, float, float],
@@ -548,7 +784,10 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         raise ValueError("ingest must be 'heads', 'full' or 'gpu'")
     chunk_bytes = int(chunk_bytes or BAM_CHUNK_BYTES)
     nthreads = hostio.pick_threads(threads)
-    ahead = _TABLES.pop(path, None) if ingest == "gpu" else None
+    ahead = _TABLES.pop(path, None)
+    if ahead is not None and ingest != "gpu":
+        _drop_ahead(ahead)
+        ahead = None
     raw = ahead[0] if ahead is not None else (np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8))
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
 
@@ -569,21 +808,37 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
         upload = None
         if 0 < raw.shape[0] <= GPU_INFLATE_MAX // 8:
             upload = engine.start_upload(raw, parts=2 if raw.shape[0] >= (256 << 20) else 1)
+        members = uploads = None
         try:
             with phases.wall("bgzf_member_table"):
-                pos, isz = ahead[1].result() if ahead is not None else hostio.bgzf_blocks(np.asarray(raw))
+                if ahead is not None:
+                    members, uploads = ahead[1].result()
+                else:
+                    members = hostio.bgzf_blocks(np.asarray(raw))
         except BaseException:
             if upload is not None:
                 upload["pool"].shutdown()
             raise
-        phases.add("bgzf_bytes", int(raw.shape[0]))
-        phases.add("bgzf_members", int(isz.shape[0]))
-        phases.add("inflated_bytes", int(isz.sum()))
-        if int(isz.sum()) > 0:
+        if isinstance(members, _Members) and (members.engine is not engine or members.chunk_bytes != chunk_bytes):
+            if uploads is not None:
+                uploads.close()                               # (made for another engine or other runs: not this call's)
+            members, uploads = members.whole(), None
+        if not isinstance(members, _Members):
+            members = _Members(engine, chunk_bytes, members[0], members[1])
+        if members.lazy() or int(members.isz.sum()) > 0:
             with phases.wall("bam_ingest (upload | inflate + crc | record walk | pages | filter, overlapped)"):
-                ji = _bam_join_input_gpu(engine, path, raw, pos, isz, ref_sel_for, filt, chunk_bytes, upload)
+                try:
+                    ji = _bam_join_input_gpu(engine, path, raw, members, ref_sel_for, filt, upload, uploads)
+                finally:
+                    if uploads is not None:
+                        uploads.close()                       # (idempotent: a failure in front of the run loop leaves it open)
                 if phases.on():
                     torch.cuda.synchronize()
+            if phases.on():
+                pos, isz = members.whole()
+                phases.add("bgzf_bytes", int(raw.shape[0]))
+                phases.add("bgzf_members", int(isz.shape[0]))
+                phases.add("inflated_bytes", int(isz.sum()))
             if ji is not None:
                 _drop_later(raw)                              # (the unmapping, off this thread)
                 del raw
@@ -682,10 +937,20 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
                                flank_len, directory, log_reads_type, chrs_list, threads, engine, write, issue_hint)
 
     first = bamfmt.read_header(bam_files[0])
-    pairs = [(r, l) for r, l in zip(first.references, first.lengths) if (len(chrs_list) == 0 or r in chrs_list)]
-    targets_length = {r: l for r, l in pairs}
+    targets_length = _targets_of(first, chrs_list)
     targets = list(targets_length.keys())
     tindex = {t: i for i, t in enumerate(targets)}
+    filt = (map_qual, mq_cutoff, clip_percent, iden_percent)
+    # the first file may have been started on already (start_ingest_ahead): its helper thread owns this context until it is done
+    first_ahead = None
+    for path in [p for p in _INGEST_AHEAD if p != bam_files[0]] + ([bam_files[0]] if bam_files[0] in _INGEST_AHEAD else []):
+        key, fut = _INGEST_AHEAD.pop(path)
+        try:
+            res = ("ok", fut.result())
+        except BaseException as e:                        # noqa: BLE001  (raised below, where bam_join_input() would have)
+            res = ("err", e)
+        if path == bam_files[0] and key == (id(engine), tuple(targets), filt, threads):
+            first_ahead = res
     engine.set_layout([targets_length[t] for t in targets])
 
     inputs: List[JoinInput] = []
@@ -701,9 +966,15 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
         except GciError as e:
             e.paf_replay = (paf_files, targets)               # a bad LINE: Python's own exception for it, as the reference dies
             _reraise_like_reference(e)
-    for path in bam_files:
+    for k, path in enumerate(bam_files):
         try:
-            inputs.append(bam_join_input(engine, path, targets, (map_qual, mq_cutoff, clip_percent, iden_percent), threads))
+            if k == 0 and first_ahead is not None:
+                if first_ahead[0] == "err":
+                    raise first_ahead[1]
+                inputs.append(first_ahead[1])
+                first_ahead = None
+            else:
+                inputs.append(bam_join_input(engine, path, targets, filt, threads))
         except GciError as e:
             _reraise_like_reference(e)
     try:

@@ -403,6 +403,13 @@ int gci_bgzf_blocks(const uint8_t* h_raw, uint64_t n_raw, uint64_t* h_pos, uint6
  * (the last = n_raw) and count ISIZEs. */
 typedef struct gci_bgzf_table gci_bgzf_table;
 int gci_bgzf_table_build(const uint8_t* h_raw, uint64_t n_raw, int threads, gci_bgzf_table** out);
+/* Only the members that start in front of byte `limit` (the table's byte length = the end of the last of them): the first run of
+ * a large file can be on its way to the device while the table of the rest is made. */
+int gci_bgzf_table_build_prefix(const uint8_t* h_raw, uint64_t n_raw, uint64_t limit, int threads, gci_bgzf_table** out);
+/* The same table read with pread() through a descriptor of the file (n_raw = its size) instead of a mapping of it: one system
+ * call per member and no page-table entry -- on a freshly mapped 77 GB file the page faults of the walk are 1.4 s on 16 threads,
+ * in the address space the threads that stage the file's bytes fault in as well. */
+int gci_bgzf_table_build_fd(int fd, uint64_t n_raw, int threads, gci_bgzf_table** out);
 uint64_t gci_bgzf_table_count(const gci_bgzf_table* t);
 int gci_bgzf_table_export(const gci_bgzf_table* t, uint64_t* h_pos, uint64_t* h_isize);
 int gci_bgzf_table_free(gci_bgzf_table* t);

@@ -178,6 +178,51 @@ def test_empty_and_ragged_inputs(engine, oracle, tmp_path):
     assert gzip.open(str(tmp_path / "e.depth.gz"), "rb").read() == oracle.depth_text(host)
 
 
+def test_tables_and_first_runs_made_ahead_give_the_same_join_input(engine, oracle, tmp_path, monkeypatch):
+    """prefetch_member_tables(): the member tables of the files of a run (read with pread) and the upload of every file's first
+    run are started on a helper thread, file after file; bam_join_input() takes them over.  Same records as without, the
+    uploaders are the helper's, and nothing is left behind."""
+    import threading
+    from gci_amd.formats import bam
+    contigs = (("a", 400_000), ("b", 150_000))
+    targets, filt = ["a", "b"], (30, 50, 0.1, 0.9)
+    paths, want = [], []
+    for k, seed in enumerate((5, 6)):
+        rs = synth.simulate_reads(contigs, 8, "hifi", seed=seed).sorted()
+        stream, offs = synth.to_bam_stream(rs)
+        p = str(tmp_path / ("f%d.bam" % k))
+        bam.write_bam_stream(p, stream, level=1, threads=4)
+        paths.append(p)
+        want.append(oracle.bam_file_dict(stream, offs, targets, targets, *filt)[0])
+    monkeypatch.setattr(pipeline, "GPU_INFLATE_MAX", 0)
+    monkeypatch.setattr(pipeline, "BAM_CHUNK_BYTES", 400_000)
+    monkeypatch.setattr(pipeline, "_ENGINE", engine)
+    made = []
+    init = pipeline._RunUploads.__init__
+
+    def spy(self, *a, **kw):
+        made.append(threading.current_thread() is threading.main_thread())
+        init(self, *a, **kw)
+
+    monkeypatch.setattr(pipeline._RunUploads, "__init__", spy)
+    engine.set_layout([dict(contigs)[t] for t in targets])
+    plain = [pipeline.bam_join_input(engine, p, targets, filt, threads=4) for p in paths]
+    assert made == [True, True]
+    del made[:]
+    pipeline.prefetch_member_tables(paths)
+    assert sorted(pipeline._TABLES) == sorted(paths)
+    ahead = [pipeline.bam_join_input(engine, p, targets, filt, threads=4) for p in paths]
+    assert made == [False, False] and not pipeline._TABLES
+    for a, b, w in zip(plain, ahead, want):
+        ra, rb = a.recs.cpu().numpy(), b.recs.cpu().numpy()
+        assert ra.shape[0] == rb.shape[0] and np.array_equal(ra, rb)
+        assert int((ra.reshape(-1).view(pipeline.REC_DTYPE)["flags"] & 1).sum()) >= len(w) > 0
+    # a table nobody asks for with the device path: dropped, its uploader closed
+    pipeline.prefetch_member_tables(paths[:1])
+    ji = pipeline.bam_join_input(engine, paths[0], targets, filt, threads=4, ingest="heads")
+    assert ji.recs.shape[0] == plain[0].recs.shape[0] and not pipeline._TABLES
+
+
 @pytest.mark.parametrize("k1", ["pages", "stream"])
 def test_streamed_bam_ingestion_equals_one_shot(engine, oracle, tmp_path, monkeypatch, k1):
     """A BAM larger than the chunk budget is streamed: groups of BGZF members, partial records carried over, K1 per

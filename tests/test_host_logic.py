@@ -355,11 +355,41 @@ def test_threaded_member_table_equals_the_serial_walk(tmp_path, monkeypatch):
             monkeypatch.setenv("GCI_BGZF_RANGE", str(rng_bytes))
             pos, isz = hostio.bgzf_blocks(raw, threads=threads)
             assert np.array_equal(pos, want_pos) and np.array_equal(isz, want_isz), (rng_bytes, threads)
+            # the table of the beginning of the string: the members that start in front of `limit`, whatever the ranges cut
+            for limit in (1, raw.shape[0] // 3, raw.shape[0] - 1):
+                ppos, pisz = hostio.bgzf_blocks(raw, threads=threads, limit=limit)
+                k = int(np.searchsorted(want_pos[:-1], limit, side="left"))
+                assert np.array_equal(ppos, want_pos[:k + 1]) and np.array_equal(pisz, want_isz[:k]), ("prefix", rng_bytes, threads, limit)
+            # the same table read through a descriptor (gci_bgzf_table_build_fd: pread instead of the mapping)
+            (tmp_path / "t.bgzf").write_bytes(raw_b)
+            pos, isz = hostio.bgzf_blocks_file(str(tmp_path / "t.bgzf"), threads=threads)
+            assert np.array_equal(pos, want_pos) and np.array_equal(isz, want_isz), ("fd", rng_bytes, threads)
+    # a member whose extra field holds another subfield in front of BC (RFC 1952 allows it; htslib never writes it)
+    def member_x(payload: bytes) -> bytes:
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = c.compress(payload) + c.flush()
+        size = 12 + 10 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x0a\x00XY\x00\x00BC\x02\x00" + (size - 1).to_bytes(2, "little") + body +
+                zlib.crc32(payload).to_bytes(4, "little") + len(payload).to_bytes(4, "little"))
+    odd = b"".join(member_x(b"ACGT" * int(rng.integers(1, 9000))) for _ in range(40)) + bgzf.BGZF_EOF
+    (tmp_path / "odd.bgzf").write_bytes(odd)
+    monkeypatch.setenv("GCI_BGZF_RANGE", "4096")
+    want = hostio.bgzf_blocks(np.frombuffer(odd, dtype=np.uint8), threads=1)
+    assert want[1].shape[0] == 41
+    for threads in (1, 4):
+        got = hostio.bgzf_blocks_file(str(tmp_path / "odd.bgzf"), threads=threads)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     # damage: a header byte in the middle -> the same refusal
     bad = bytearray(plain)
     k = int(hostio.bgzf_blocks(np.frombuffer(plain, dtype=np.uint8), threads=1)[0][150])
     bad[k + 1] = 0
     monkeypatch.setenv("GCI_BGZF_RANGE", "4096")
+    (tmp_path / "bad.bgzf").write_bytes(bytes(bad))
+    (tmp_path / "cut.bgzf").write_bytes(plain[:-5])
     for threads in (1, 8):
         with pytest.raises(Exception):
             hostio.bgzf_blocks(np.frombuffer(bytes(bad), dtype=np.uint8), threads=threads)
+        with pytest.raises(Exception):
+            hostio.bgzf_blocks_file(str(tmp_path / "bad.bgzf"), threads=threads)
+        with pytest.raises(Exception):
+            hostio.bgzf_blocks_file(str(tmp_path / "cut.bgzf"), threads=threads)

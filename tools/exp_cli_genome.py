@@ -47,7 +47,11 @@ if os.environ.get("GCI_EXP_PROFILE"):
                                env=env, capture_output=True, text=True)
             wall = time.perf_counter() - t0
             ph = json.load(open(os.path.join(tmp, "ph_ab.json")))
-            keep = ("bam_ingest", "name_join", "filter[", "fasta", "bgzf_member")
+            if os.environ.get("GCI_EXP_SAVE"):               # the whole phase log (with its per-run trace under GCI_PHASES_TRACE=1)
+                os.makedirs(os.environ["GCI_EXP_SAVE"], exist_ok=True)
+                ph2 = dict(ph, notes={k: v for k, v in ph["notes"].items() if not k.startswith("depth_gz_layout")})
+                json.dump(ph2, open(os.path.join(os.environ["GCI_EXP_SAVE"], "phases_%s.json" % label.replace(" ", "_")), "w"))
+            keep = ("bam_ingest", "name_join", "filter[", "fasta", "bgzf_member", "wait")
             print("%-26s rc %d wall %.2f s | " % (label, r.returncode, wall) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
                   + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0), flush=True)
         env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")

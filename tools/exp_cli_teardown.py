@@ -20,7 +20,7 @@ for it in range(3):
     raw = np.memmap(p, dtype=np.uint8, mode="r"); mark("memmap")
     upload = eng.start_upload(raw, parts=2); mark("start_upload")
     pos, isz = hostio.bgzf_blocks(np.asarray(raw)); mark("bgzf_blocks")
-    ji = pipeline._bam_join_input_gpu(eng, p, raw, pos, isz, lambda hdr: eng.to_device(np.zeros(1, np.int32)), filt, pipeline.BAM_CHUNK_BYTES, upload)
+    ji = pipeline._bam_join_input_gpu(eng, p, raw, pipeline._Members(eng, pipeline.BAM_CHUNK_BYTES, pos, isz), lambda hdr: eng.to_device(np.zeros(1, np.int32)), filt, upload)
     mark("_bam_join_input_gpu")
     torch.cuda.synchronize(); mark("sync")
     up_keys = list(upload.keys())
