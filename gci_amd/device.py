@@ -90,6 +90,7 @@ class _Staging:
         self.next = 0
         self.pool = ThreadPoolExecutor(self.THREADS)
         self.lock = threading.Lock()            # (two senders -- the assembly and the first run of a BAM file -- take slots in turns)
+        self.urgent = 0
 
         def pin(k):                             # page-locking 64 MB takes ~20 ms: the slots side by side, the first piece waits for one
             self.slots[k] = torch.empty(self.SLOT, dtype=torch.uint8).pin_memory()
@@ -97,10 +98,26 @@ class _Staging:
 
         self.pinned = [self.pool.submit(pin, k) for k in range(self.SLOTS)]
 
-    def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream) -> None:
-        """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued."""
+    def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream, urgent: bool = True) -> None:
+        """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued.  A sender that is not
+        urgent (the assembly, whose N runs nobody waits for) lets the urgent ones (the runs of a BAM file: the device inflates them
+        as they arrive) go first, piece by piece."""
+        if urgent:
+            with self.lock:
+                self.urgent += 1
+        try:
+            self._send(raw, p0, p1, dst, stream, urgent)
+        finally:
+            if urgent:
+                with self.lock:
+                    self.urgent -= 1
+
+    def _send(self, raw, p0, p1, dst, stream, urgent) -> None:
+        import time
         for a in range(p0, p1, self.SLOT):
             b = min(p1, a + self.SLOT)
+            while not urgent and self.urgent > 0:
+                time.sleep(0.0005)
             with self.lock:
                 k = self.next
                 self.next = (k + 1) % self.SLOTS
@@ -212,7 +229,7 @@ class Engine:
         staging, copy = self.staging(), self.copy_stream()
         dst = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
         copy.wait_stream(self.stream)
-        staging.send(a, 0, n, dst, copy)
+        staging.send(a, 0, n, dst, copy, urgent=os.environ.get("GCI_FASTA_URGENT", "0") == "1")
         self.stream.wait_stream(copy)
         return dst[:n]
 
