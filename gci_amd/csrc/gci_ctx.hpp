@@ -79,6 +79,7 @@ struct gci_ctx {
     uint64_t pg_blob_off = 0;
     uint64_t pg_blob_bytes = 0;               // total size of the blob the size call measured (without its 16 guard bytes)
     std::vector<DevBuf> paf_pool;           // K2's scratch, in the order a call asks for it (k_paf.hip: PafScratch)
+    DevBuf crc_tabs;                        // k_bgzf_crc: the 32 look-up tables (k_crc_tables), made on first use
     DevBuf tail_sums;                       // gci_two_type_tail: per-tile sums of the three tracks
     DevBuf tail_gaps;                       // gci_two_type_tail: the N runs as absolute sorted [begin, end) element ranges
     std::vector<int64_t> tail_gaps_host;    // ... what was uploaded last

@@ -37,6 +37,26 @@ __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 
 constexpr uint32_t CRC_POLY = 0xEDB88320u;      // reflected: bit 31 holds x^0
 
+constexpr uint32_t gf_mul_c(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 32; i++) {
+        r ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+    }
+    return r;
+}
+struct XPow8 { uint32_t v[32]; };
+constexpr XPow8 make_xpow8()                       // v[k] = x^(8 * 2^k) mod P, reflected (x^8 = 0x00800000)
+{
+    XPow8 t{};
+    uint32_t p = 0x00800000u;
+    for (int k = 0; k < 32; k++) { t.v[k] = p; p = gf_mul_c(p, p); }
+    return t;
+}
+__constant__ XPow8 c_xpow8 = make_xpow8();
+
 __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)   // a * b mod P over GF(2), reflected representation
 {
     uint32_t r = 0;
@@ -378,58 +398,83 @@ void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict_
     if (bad) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
 }
 
-// CRC-32 of every member's output against its trailer: one wave per member.
+// CRC-32 of every member's output against its trailer: one wave per member, CRC_PER_WAVE members one after the other.
+//
+// The wave reads the member as rows of 1 KB -- lane l the 16 bytes at 16 l of every row: coalesced, where a contiguous share per lane
+// made every load touch 64 cache lines for 16 bytes each (1 TB/s) -- and CRC's linearity puts the pieces together: lane l's register
+// runs over ITS pieces as if the 1008 bytes between two of them were zeros, i.e. absorbing a piece and skipping to the next one is
+//   reg' = sum over the 16 bytes b_j of W[15 - j][b_j]     (the first four bytes xor-ed with reg, as in slicing-by-16),
+//   W[k][b] = T[k][b] * x^(8 * 1008),  T[k][b] = the register after byte b and k zero bytes;
+// the lane's last piece is absorbed with T (nothing is skipped behind it), the register then multiplied by x^(8 * bytes behind
+// the piece) from the powers x^(8 * 2^k), and the 64 products xor-ed.  The register starts at all ones where the member starts;
+// the fewer than 16 bytes behind the last whole piece are one lane's, byte by byte, with no bytes behind them.  The 32 tables are
+// made once per context (k_crc_tables) and copied into LDS by every workgroup.
+#define CRC_ROW 1024u
+#define CRC_PER_WAVE 8
+
+__global__ __launch_bounds__(256) void k_crc_tables(uint32_t* __restrict__ tabs)          // tabs[0..16): T, [16..32): W
+{
+    __shared__ uint32_t t0[256];
+    const int i = threadIdx.x;
+    uint32_t c = (uint32_t)i;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+    t0[i] = c;
+    __syncthreads();
+    uint32_t skip = 0x80000000u;                                               // x^(8 * (CRC_ROW - 16))
+    for (uint32_t e = CRC_ROW - 16u, k = 0; e; e >>= 1, k++) if (e & 1u) skip = gf_mul(skip, c_xpow8.v[k]);
+    for (int k = 0; k < 16; k++) {
+        tabs[k * 256 + i] = c;
+        tabs[(16 + k) * 256 + i] = gf_mul(c, skip);
+        c = (c >> 8) ^ t0[c & 0xFFu];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_bgzf_crc(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
                                                     const uint64_t* __restrict__ out_off, uint32_t n_members, const uint8_t* __restrict__ out,
-                                                    unsigned long long* __restrict__ status)
+                                                    const uint32_t* __restrict__ tabs, unsigned long long* __restrict__ status)
 {
-    __shared__ uint32_t crc_tab[256];
-    for (int i = threadIdx.x; i < 256; i += BLOCK) {
-        uint32_t c = (uint32_t)i;
-        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
-        crc_tab[i] = c;
-    }
+    __shared__ __attribute__((aligned(16))) uint32_t T[32][256];
+    for (int i = threadIdx.x; i < 32 * 256 / 4; i += BLOCK)
+        reinterpret_cast<uint4*>(&T[0][0])[i] = reinterpret_cast<const uint4*>(tabs)[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint32_t m = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (m >= n_members) return;
-    const uint64_t o0 = out_off[m];
-    const uint32_t n = (uint32_t)(out_off[m + 1] - o0);
-    // lane l: the CRC register (started at 0: the pure polynomial remainder) of its share of the output; the shares are cut
-    // at 16-byte addresses and read as whole uint4 (the first lane takes the bytes in front of the first boundary as well)
-    const uint8_t* p0 = out + o0;
-    const uint8_t* pe = p0 + n;
-    const uint8_t* pa = reinterpret_cast<const uint8_t*>(((uintptr_t)p0 + 15) & ~(uintptr_t)15);
-    if (pa > pe) pa = pe;
-    const uint32_t per = (((uint32_t)(pe - pa) + 63) / 64 + 15) & ~15u;
-    const uint8_t* a = lane ? pa + min((uint32_t)(pe - pa), (uint32_t)lane * per) : p0;
-    const uint8_t* b = pa + min((uint32_t)(pe - pa), (uint32_t)(lane + 1) * per);
-    const uint32_t share = (uint32_t)(b - a);
-    uint32_t c = 0;
-    for (; a < b && ((uintptr_t)a & 15u); a++) c = crc_tab[(c ^ *a) & 0xFFu] ^ (c >> 8);
-    for (; a + 16 <= b; a += 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(a);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            c ^= w[k];
-#pragma unroll
-            for (int j = 0; j < 4; j++) c = crc_tab[c & 0xFFu] ^ (c >> 8);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    for (uint32_t m = wave * CRC_PER_WAVE; m < min(n_members, (wave + 1) * CRC_PER_WAVE); m++) {
+        const uint64_t o0 = out_off[m];
+        const uint32_t n = (uint32_t)(out_off[m + 1] - o0);
+        const uint8_t* p0 = out + o0;
+        const uint32_t full = n >> 4;                                         // whole 16-byte pieces; piece j is lane j % 64's
+        const uint32_t count = full > lane ? (full - lane + 63u) >> 6 : 0u;
+        uint32_t c = (lane == 0 && full) ? 0xFFFFFFFFu : 0u;
+        const uint8_t* q = p0 + 16u * lane;
+        for (uint32_t i = 0; i < count; i++, q += CRC_ROW) {
+            uint4 v;
+            __builtin_memcpy(&v, q, 16);                                      // (any address: the member starts where the one before it ended)
+            const uint32_t x = v.x ^ c;
+            const uint32_t (*S)[256] = i + 1 < count ? &T[16] : &T[0];        // W but for the lane's last piece
+            c = S[15][x & 0xFFu] ^ S[14][(x >> 8) & 0xFFu] ^ S[13][(x >> 16) & 0xFFu] ^ S[12][x >> 24]
+              ^ S[11][v.y & 0xFFu] ^ S[10][(v.y >> 8) & 0xFFu] ^ S[9][(v.y >> 16) & 0xFFu] ^ S[8][v.y >> 24]
+              ^ S[7][v.z & 0xFFu] ^ S[6][(v.z >> 8) & 0xFFu] ^ S[5][(v.z >> 16) & 0xFFu] ^ S[4][v.z >> 24]
+              ^ S[3][v.w & 0xFFu] ^ S[2][(v.w >> 8) & 0xFFu] ^ S[1][(v.w >> 16) & 0xFFu] ^ S[0][v.w >> 24];
         }
-    }
-    for (; a < b; a++) c = crc_tab[(c ^ *a) & 0xFFu] ^ (c >> 8);
-    uint32_t xp = 0x80000000u, base = 0x00800000u;                            // x^0, x^8 (reflected); xp = x^(8 (b - a))
-    for (uint32_t e = share; e; e >>= 1) { if (e & 1u) xp = gf_mul(xp, base); base = gf_mul(base, base); }
-    for (int d = 1; d < 64; d <<= 1) {                                        // ordered product: (c, x) . (c', x') = (c x' + c', x x')
-        const uint32_t oc = (uint32_t)__shfl_down((int)c, d, 64), ox = (uint32_t)__shfl_down((int)xp, d, 64);
-        if ((lane & (2 * d - 1)) == 0) { c = gf_mul(c, ox) ^ oc; xp = gf_mul(xp, ox); }
-    }
-    if (lane == 0) {
-        // crc32(M) = reg_ff(M) ^ ~0 with reg_ff(M) = reg_0(M) ^ (0xFFFFFFFF * x^(8 n)): the all-ones start value is a term of its own
-        const uint32_t got = c ^ gf_mul(0xFFFFFFFFu, xp) ^ 0xFFFFFFFFu;
-        const uint64_t tp = member_pos[m + 1] - 8;
-        const uint32_t want = (uint32_t)raw[tp] | ((uint32_t)raw[tp + 1] << 8) | ((uint32_t)raw[tp + 2] << 16) | ((uint32_t)raw[tp + 3] << 24);
-        if (got != want) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
+        // the bytes behind the lane's last piece
+        const uint32_t behind = count ? n - 16u * ((count - 1u) * 64u + lane + 1u) : 0u;
+        uint32_t xp = 0x80000000u;                                            // x^0, reflected
+        for (uint32_t e = behind, k = 0; e; e >>= 1, k++) if (e & 1u) xp = gf_mul(xp, c_xpow8.v[k]);
+        c = gf_mul(c, xp);
+        if (lane == 0 && (n & 15u)) {                                         // the last n % 16 bytes: nothing behind them
+            uint32_t r = full ? 0u : 0xFFFFFFFFu;
+            for (uint32_t k = 16u * full; k < n; k++) r = T[0][(r ^ p0[k]) & 0xFFu] ^ (r >> 8);
+            c ^= r;
+        }
+        if (lane == 0 && n == 0) c = 0xFFFFFFFFu;
+        for (int d = 1; d < 64; d <<= 1) c ^= (uint32_t)__shfl_xor((int)c, d, 64);
+        if (lane == 0) {
+            const uint32_t got = c ^ 0xFFFFFFFFu;
+            const uint64_t tp = member_pos[m + 1] - 8;
+            const uint32_t want = (uint32_t)raw[tp] | ((uint32_t)raw[tp + 1] << 8) | ((uint32_t)raw[tp + 2] << 16) | ((uint32_t)raw[tp + 3] << 24);
+            if (got != want) atomicMin(status, ((unsigned long long)m << 8) | (unsigned long long)(uint8_t)(-GCI_E_MALFORMED));
+        }
     }
 }
 
@@ -452,8 +497,15 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
         else launch(k_bgzf_inflate<8>, 8);
         LAUNCHCHK("k_bgzf_inflate");
         if (check_crc) {
-            hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, ctx->stream, d_raw, d_member_pos,
-                               d_out_off, n_members, (const uint8_t*)d_out, (unsigned long long*)d_status);
+            if (!ctx->crc_tabs.p) {
+                const int st = gci_ensure(ctx, ctx->crc_tabs, 32 * 256 * sizeof(uint32_t));
+                if (st) return st;
+                hipLaunchKernelGGL(k_crc_tables, dim3(1), dim3(256), 0, ctx->stream, (uint32_t*)ctx->crc_tabs.p);
+                LAUNCHCHK("k_crc_tables");
+            }
+            const uint32_t per_block = (BLOCK / 64) * CRC_PER_WAVE;
+            hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + per_block - 1) / per_block), dim3(BLOCK), 0, ctx->stream, d_raw, d_member_pos,
+                               d_out_off, n_members, (const uint8_t*)d_out, (const uint32_t*)ctx->crc_tabs.p, (unsigned long long*)d_status);
             LAUNCHCHK("k_bgzf_crc");
         }
     }
