@@ -328,10 +328,14 @@ __global__ __launch_bounds__(BLOCK) void k_paf_compact(const PafHitD* __restrict
 }
 
 #define QEMPTY 0xFFFFFFFFu
-// query table: slot = index of the hit that claimed it; per slot the number of hits and the high-quality bit
-__global__ __launch_bounds__(BLOCK) void k_paf_insert(const uint8_t* __restrict__ text, PafHitD* __restrict__ hits, uint32_t first,
+// query table: slot = index of the hit that claimed it; per slot ONE 64-bit word -- the number of its hits (low half) and of its
+// high-quality hits (high half) -- bumped by one returning atomic whose old value is the hit's place among the slot's hits: the
+// scatter behind the scan needs no atomic of its own, and reads the slots and places as two dense arrays instead of one word out
+// of every 88-byte hit.
+__global__ __launch_bounds__(BLOCK) void k_paf_insert(const uint8_t* __restrict__ text, const PafHitD* __restrict__ hits, uint32_t first,
                                                       uint32_t n, uint32_t* __restrict__ table, uint32_t mask,
-                                                      uint32_t* __restrict__ count, uint32_t* __restrict__ hq)
+                                                      unsigned long long* __restrict__ count, uint32_t* __restrict__ slot_of,
+                                                      uint32_t* __restrict__ place_of)
 {
     const uint32_t i = first + blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -347,18 +351,16 @@ __global__ __launch_bounds__(BLOCK) void k_paf_insert(const uint8_t* __restrict_
         if (o.qhash == h.qhash && o.qn_len == h.qn_len && bytes_equal(text + o.qn_off, text + h.qn_off, h.qn_len)) break;
         s = (s + 1) & mask;
     }
-    hits[i].slot = s;
-    atomicAdd(count + s, 1u);
-    if (h.hq) atomicOr(hq + s, 1u);
+    slot_of[i] = s;
+    place_of[i] = (uint32_t)atomicAdd(count + s, 1ull | ((unsigned long long)(h.hq ? 1u : 0u) << 32));
 }
 
-__global__ __launch_bounds__(BLOCK) void k_paf_scatter(const PafHitD* __restrict__ hits, uint32_t n, const uint32_t* __restrict__ start,
-                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ order)
+__global__ __launch_bounds__(BLOCK) void k_paf_scatter(const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ place_of, uint32_t n,
+                                                       const uint32_t* __restrict__ start, uint32_t* __restrict__ order)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint32_t s = hits[i].slot;
-    order[start[s] + atomicAdd(cursor + s, 1u)] = i;
+    order[start[slot_of[i]] + place_of[i]] = i;
 }
 
 // union of closed-touching blocks [a, b), sorted in place: covered length and the longest merged block (leftmost on ties)
@@ -386,7 +388,7 @@ __device__ __forceinline__ void merge_span(int64_t* __restrict__ pa, int64_t* __
 // One lane per query (table slot) over its hits below `limit` (= the hits of files 0 .. i): GCI.py:241-254.
 __global__ __launch_bounds__(BLOCK) void k_paf_score(const PafHitD* __restrict__ hits, const uint32_t* __restrict__ table, uint32_t n_slots,
                                                      const uint32_t* __restrict__ start, uint32_t* __restrict__ order, uint32_t limit,
-                                                     const uint32_t* __restrict__ hq, const int32_t* __restrict__ trank,
+                                                     const unsigned long long* __restrict__ hq, const int32_t* __restrict__ trank,
                                                      int64_t* __restrict__ pa, int64_t* __restrict__ pb, int sort_lists,
                                                      gci_rec* __restrict__ out, uint64_t* __restrict__ out_name_off,
                                                      uint32_t* __restrict__ n_out, unsigned long long* __restrict__ status)
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_paf_score(const PafHitD* __restrict__
                 const bool block = x.te - x.ts > -1;                  // (merge_span's "longest block" starts from length -1)
                 r.name_hash = x.qhash; r.contig = x.t; r.start = block ? (int32_t)x.ts : 0; r.end = block ? (int32_t)x.te : 0;
                 r.qlen = (int32_t)x.qlen; r.rec_idx = s; r.mapq = 0;
-                r.flags = (uint8_t)(GCI_REC_PASS | (hq[s] ? GCI_REC_HQ : 0)); r.name_len = (uint16_t)x.qn_len;
+                r.flags = (uint8_t)(GCI_REC_PASS | ((hq[s] >> 32) ? GCI_REC_HQ : 0)); r.name_len = (uint16_t)x.qn_len;
                 name_off = x.qn_off;
                 emit = true;
             }
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void k_paf_score(const PafHitD* __restrict__
                 } else {
                     r.name_hash = q0.qhash; r.contig = best_t; r.start = (int32_t)best_s; r.end = (int32_t)best_e;
                     r.qlen = (int32_t)best_qlen; r.rec_idx = s; r.mapq = 0;
-                    r.flags = (uint8_t)(GCI_REC_PASS | (hq[s] ? GCI_REC_HQ : 0)); r.name_len = (uint16_t)q0.qn_len;
+                    r.flags = (uint8_t)(GCI_REC_PASS | ((hq[s] >> 32) ? GCI_REC_HQ : 0)); r.name_len = (uint16_t)q0.qn_len;
                     name_off = q0.qn_off;
                     emit = true;
                 }
@@ -674,7 +676,8 @@ int paf_stage_a(gci_ctx* ctx, PafScratch& S, const uint8_t* d_text, const uint64
         HIPCHK(hipStreamSynchronize(st));
         if ((uint64_t)A.hits_upto[f] + n_hits > 0x7fffffffULL) return GCI_E_INVALID;
         A.hits_upto[f + 1] = A.hits_upto[f] + n_hits;
-        if (n_hits) {
+        if (n_hits == n_lines) A.file_hits[f] = d_hit;                    // every line passed: nothing to squeeze out
+        else if (n_hits) {
             PAF_ALLOC(d_dense, PafHitD, n_hits);
             hipLaunchKernelGGL(k_paf_compact, dim3((n_lines + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hit,
                                (const uint32_t*)d_flag, (const uint32_t*)d_pos, n_lines, d_dense);
@@ -700,25 +703,24 @@ int paf_stage_b(gci_ctx* ctx, PafScratch& S, const uint8_t* d_names, PafHitD* d_
     uint32_t n_slots = 1024;
     while (n_slots < 2ull * total) n_slots <<= 1;
     PAF_ALLOC(d_table, uint32_t, n_slots);
-    PAF_ALLOC(d_count, uint32_t, n_slots + 1);
+    PAF_ALLOC(d_count, unsigned long long, n_slots + 1);
     PAF_ALLOC(d_start, uint32_t, n_slots + 1);
-    PAF_ALLOC(d_hq, uint32_t, n_slots);
-    PAF_ALLOC(d_cursor, uint32_t, n_slots);
+    PAF_ALLOC(d_slot_of, uint32_t, total);
+    PAF_ALLOC(d_place_of, uint32_t, total);
     PAF_ALLOC(d_order, uint32_t, total);
     PAF_ALLOC(d_blk3, uint32_t, n_slots / TILE + 2);
     PAF_ALLOC(d_pa, int64_t, total);
     PAF_ALLOC(d_pb, int64_t, total);
     HIPCHK(hipMemsetAsync(d_table, 0xFF, 4ull * n_slots, st));
-    HIPCHK(hipMemsetAsync(d_count, 0, 4ull * (n_slots + 1), st));
-    HIPCHK(hipMemsetAsync(d_hq, 0, 4ull * n_slots, st));
-    HIPCHK(hipMemsetAsync(d_cursor, 0, 4ull * n_slots, st));
-    hipLaunchKernelGGL(k_paf_insert, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_names, d_hits, 0u, total, d_table, n_slots - 1,
-                       d_count, d_hq);
+    HIPCHK(hipMemsetAsync(d_count, 0, 8ull * (n_slots + 1), st));
+    hipLaunchKernelGGL(k_paf_insert, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_names, (const PafHitD*)d_hits, 0u, total, d_table,
+                       n_slots - 1, d_count, d_slot_of, d_place_of);
     LAUNCHCHK("k_paf_insert");
-    int rc = device_exclusive_scan<uint32_t, uint32_t>(ctx, d_count, d_start, d_blk3, (int64_t)n_slots, true);
+    // (the scan reads the low half of every counter: the number of hits)
+    int rc = device_exclusive_scan<unsigned long long, uint32_t>(ctx, d_count, d_start, d_blk3, (int64_t)n_slots, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_paf_scatter, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, total,
-                       (const uint32_t*)d_start, d_cursor, d_order);
+    hipLaunchKernelGGL(k_paf_scatter, dim3((total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const uint32_t*)d_slot_of,
+                       (const uint32_t*)d_place_of, total, (const uint32_t*)d_start, d_order);
     LAUNCHCHK("k_paf_scatter");
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, st));
     bool lists_sorted = false;
@@ -732,7 +734,7 @@ int paf_stage_b(gci_ctx* ctx, PafScratch& S, const uint8_t* d_names, PafHitD* d_
         H->name_off[f] = p_off;
         HIPCHK(hipMemsetAsync(d_n, 0, 4, st));
         hipLaunchKernelGGL(k_paf_score, dim3((n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, (const uint32_t*)d_table,
-                           n_slots, (const uint32_t*)d_start, d_order, limit, (const uint32_t*)d_hq, d_trank, d_pa, d_pb,
+                           n_slots, (const uint32_t*)d_start, d_order, limit, (const unsigned long long*)d_count, d_trank, d_pa, d_pb,
                            lists_sorted ? 0 : 1, (gci_rec*)p_recs, (uint64_t*)p_off, d_n, d_status);
         LAUNCHCHK("k_paf_score");
         lists_sorted = true;
@@ -771,10 +773,12 @@ extern "C" int gci_paf_filter_device(gci_ctx* ctx, const uint8_t* d_text, const 
     H->recs.assign(n_files, nullptr); H->name_off.assign(n_files, nullptr); H->count.assign(n_files, 0);
     const uint32_t total = A.hits_upto[A.n_ok];
     if (total) {
-        // one array of all hits, files in command-line order
-        PafHitD* d_hits = (PafHitD*)S.alloc(sizeof(PafHitD) * (size_t)total);
+        // one array of all hits, files in command-line order (the hits of the only file with any are that array)
+        int with_hits = 0, only = -1;
+        for (int f = 0; f < A.n_ok; f++) if (A.file_hits[f]) { with_hits++; only = f; }
+        PafHitD* d_hits = with_hits == 1 ? A.file_hits[only] : (PafHitD*)S.alloc(sizeof(PafHitD) * (size_t)total);
         if (!d_hits) { paf_dev_release(H); return GCI_E_NOMEM; }
-        for (int f = 0; f < A.n_ok; f++)
+        for (int f = 0; f < A.n_ok && with_hits != 1; f++)
             if (A.file_hits[f]) {
                 hipError_t e = hipMemcpyAsync(d_hits + A.hits_upto[f], A.file_hits[f],
                                               sizeof(PafHitD) * (size_t)(A.hits_upto[f + 1] - A.hits_upto[f]), hipMemcpyDeviceToDevice, st);
@@ -877,6 +881,18 @@ extern "C" uint64_t gci_paf_dev_count(const gci_paf_dev* h, int file)
 }
 
 // copies file `file`'s records and name offsets into the caller's device buffers (gci_paf_dev_count() entries each)
+namespace {
+// (a device-to-device hipMemcpyAsync of 7 GB goes at 180 GB/s here -- the copy engines --, a kernel at the memory's rate)
+__global__ __launch_bounds__(BLOCK) void k_copy8(const uint2* __restrict__ src, uint2* __restrict__ dst, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) dst[i] = src[i];
+}
+__global__ __launch_bounds__(BLOCK) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" int gci_paf_dev_export(const gci_paf_dev* h, int file, gci_rec* d_recs, uint64_t* d_name_off)
 {
     if (!h || !h->ctx || file < 0 || (size_t)file >= h->count.size()) return GCI_E_INVALID;
@@ -884,8 +900,17 @@ extern "C" int gci_paf_dev_export(const gci_paf_dev* h, int file, gci_rec* d_rec
     const size_t n = h->count[file];
     if (n == 0) return GCI_OK;
     if (!d_recs || !d_name_off) return GCI_E_INVALID;
-    HIPCHK(hipMemcpyAsync(d_recs, h->recs[file], n * sizeof(gci_rec), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_name_off, h->name_off[file], n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    static_assert(sizeof(gci_rec) == 32, "two 16-byte pieces per record");
+    if (((uintptr_t)d_recs & 15u) || ((uintptr_t)d_name_off & 7u)) {
+        HIPCHK(hipMemcpyAsync(d_recs, h->recs[file], n * sizeof(gci_rec), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_name_off, h->name_off[file], n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return GCI_OK;
+    }
+    const uint32_t g16 = (uint32_t)std::min<uint64_t>((2 * n + BLOCK - 1) / BLOCK, 65536), g8 = (uint32_t)std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 65536);
+    hipLaunchKernelGGL(k_copy16, dim3(g16), dim3(BLOCK), 0, ctx->stream, (const uint4*)h->recs[file], (uint4*)d_recs, (uint64_t)(2 * n));
+    LAUNCHCHK("k_copy16");
+    hipLaunchKernelGGL(k_copy8, dim3(g8), dim3(BLOCK), 0, ctx->stream, (const uint2*)h->name_off[file], (uint2*)d_name_off, (uint64_t)n);
+    LAUNCHCHK("k_copy8");
     return GCI_OK;
 }
 
