@@ -52,6 +52,9 @@ if os.environ.get("GCI_EXP_PROFILE"):
                 ph2 = dict(ph, notes={k: v for k, v in ph["notes"].items() if not k.startswith("depth_gz_layout")})
                 json.dump(ph2, open(os.path.join(os.environ["GCI_EXP_SAVE"], "phases_%s.json" % label.replace(" ", "_")), "w"))
             keep = ("bam_ingest", "name_join", "filter[", "fasta", "bgzf_member", "wait")
+            if os.environ.get("GCI_EXP_MEMINFO"):            # what the page cache looks like behind the run (huge pages of tmpfs?)
+                mi = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/meminfo")}
+                print("   meminfo: " + ", ".join("%s %s" % (k, mi.get(k)) for k in ("Shmem", "ShmemHugePages", "ShmemPmdMapped", "Active(file)", "Inactive(file)", "Active(anon)", "Inactive(anon)", "Mapped")), flush=True)
             print("%-26s rc %d wall %.2f s | " % (label, r.returncode, wall) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
                   + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0), flush=True)
         env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")
