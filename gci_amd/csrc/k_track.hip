@@ -3,6 +3,7 @@
 // (masked, merged or uploaded tracks); a fresh build gets the same results fused into
 // k_tile_build (k_depth.hip) without re-reading the track.
 #include "gci_ctx.hpp"
+#include <stdlib.h>
 #include <algorithm>
 #include <utility>
 
@@ -266,7 +267,9 @@ __global__ __launch_bounds__(BLOCK) void k_two_type_tail(TailArgs A)
     }
     const bool gapped = g1 > g0;
     long long sum[3] = {0, 0, 0};                            // (the padding behind a contig's last base is kept at zero)
-#pragma unroll
+    // (not unrolled: four groups in flight are 110 VGPRs and four waves per SIMD with the sums, 19.0 ms for the 6.1 Gb diploid; one
+    // group is 58 VGPRs and eight waves, 14.4 ms -- the kernel streams, it wants the waves more than the groups)
+#pragma unroll 1
     for (int j = 0; j < 4; j++) {
         const int64_t p = p0 + (int64_t)(j * BLOCK + t) * 4;
         int4 va = *reinterpret_cast<const int4*>(A.a + p), vb = *reinterpret_cast<const int4*>(A.b + p);
