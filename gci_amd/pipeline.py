@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import phases, score
-from .device import Engine, JoinInput, REC_DTYPE, name_hash_np, _Staging, _forget_pages
+from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
 from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
 from .formats import bam as bamfmt
@@ -603,12 +603,13 @@ _TABLES: Dict[str, object] = {}        # path -> (memory map of the file, future
 def prefetch_member_tables(paths: Sequence[str]) -> None:
     """Start on the BAM files of a run before anything needs them, on a helper thread, file after file: the BGZF member table
     (host threads over the mapping of the file; GCI_BGZF_TABLE=pread reads the headers through a descriptor instead -- no page
-    fault per member, but slower on the boxes measured) and, for a file that will go through the device run by run, the upload of its FIRST run -- as soon as the table is there and
-    the file before it has put its last run on the copy stream.  The command line calls this as soon as it knows its inputs: the
-    first file's table and first run are made while the assembly is read and scanned for N runs, every later file's while the
-    file before it is inflated on the device -- what used to sit in front of the file's first byte on the device (half a second
-    of table, a third of a second of upload, per file at genome size).  bam_join_input() picks the results up; an unreadable or
-    damaged file raises there, where it did before."""
+    fault per member, but slower on the boxes measured) and, for a file that will go through the device run by run, the upload
+    of its FIRST run.  The first file's table is made in pieces (_Members): its first run leaves as soon as the table of the
+    file's beginning is there; a later file's as soon as the file in front of it has put its last run on the copy stream.  The
+    command line calls this as soon as it knows its inputs, so what used to sit in front of a file's first byte on the device --
+    0.7 s of table and a third of a second of upload per file at genome size -- happens beside the assembly's N scan and beside
+    the inflate of the file in front.  bam_join_input() picks the results up; an unreadable or damaged file raises there (a
+    damaged member behind the table's first piece: where the run that holds it is asked for)."""
     from concurrent.futures import Future
     from . import hostio
     if os.environ.get("GCI_BAM_INGEST", "gpu") != "gpu" or not paths or _sharded():
