@@ -78,17 +78,46 @@ __device__ __forceinline__ CrcPair crc_line(const Line& l)
     return {c ^ 0xFFFFFFFFu, x};
 }
 
-// n >= 1 copies of a string
-__device__ __forceinline__ CrcPair crc_repeat(CrcPair base, uint32_t n)
+// n >= 1 copies of a line of w bytes behind a string.  With X = x^(8 w) the pair of n copies is (c * G_n, X^n), G_n = 1 + X + ... +
+// X^(n - 1) -- which depends on w and n only: G_(a + b) = G_a * X^b + G_b, so G_n and X^n are put together from the entries
+// for the set bits of n of a table of (X^(2^k), G_(2^k)) per line width, made when the translation unit is compiled.  Two products
+// per set bit and three to apply the result, where squaring (c, X) bit by bit took four per bit of n: the size pass of the members
+// was bound by exactly this arithmetic.
+constexpr uint32_t gf_mul_c(uint32_t a, uint32_t b)
 {
-    CrcPair r{0u, GF_ONE};                                                      // the empty string
-    for (;;) {
-        if (n & 1u) r = crc_cat(r, base);
-        n >>= 1;
-        if (!n) break;
-        base = crc_cat(base, base);
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
     }
-    return r;
+    return p;
+}
+constexpr int REP_W = 12, REP_K = 13;                                           // line widths 0 .. 11, runs of up to 2^13 - 1 lines (a tile: 4096)
+struct RepTab { uint32_t x[REP_W][REP_K], g[REP_W][REP_K]; };
+constexpr RepTab make_rep_tab()
+{
+    RepTab t{};
+    uint32_t xw = GF_ONE;                                                       // x^(8 w)
+    for (int w = 0; w < REP_W; w++) {
+        uint32_t x = xw, g = GF_ONE;
+        for (int k = 0; k < REP_K; k++) {
+            t.x[w][k] = x; t.g[w][k] = g;
+            g = gf_mul_c(g, x) ^ g;                                             // G_(2 m) = G_m * X^m + G_m
+            x = gf_mul_c(x, x);
+        }
+        xw = gf_mul_c(xw, 0x00800000u);                                         // * x^8
+    }
+    return t;
+}
+__constant__ RepTab c_rep = make_rep_tab();
+static_assert(TILE < (1 << REP_K), "a run is at most a tile of lines");
+
+__device__ __forceinline__ CrcPair crc_append_lines(CrcPair front, uint32_t line_crc, uint32_t w, uint32_t n)
+{
+    uint32_t g = 0u, xn = GF_ONE;                                               // (G_0, X^0)
+    for (uint32_t k = 0; n; n >>= 1, k++)
+        if (n & 1u) { const uint32_t xk = c_rep.x[w][k]; g = gf_mul(g, xk) ^ c_rep.g[w][k]; xn = gf_mul(xn, xk); }
+    return {gf_mul(front.c, xn) ^ gf_mul(line_crc, g), gf_mul(front.x, xn)};
 }
 
 // ---- bit writer: DEFLATE packs bits LSB first; Huffman codes go in most-significant bit first, i.e. bit-reversed --------
@@ -320,7 +349,7 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
                 const uint32_t rn = run_n[r][lane];
                 const Line l = make_line((uint32_t)run_v[r][lane]);
                 if (PASS == 1) {
-                    tile = crc_cat(tile, crc_repeat(crc_line(l), rn));
+                    tile = crc_append_lines(tile, crc_line(l).c, l.w, rn);
                     text_len += rn * l.w;
                 }
                 put_run(o, l, rn);
