@@ -46,6 +46,37 @@ def test_cli_reproduces_reference_files(engine, case, tmp_path, capsys):
     assert read_outputs(out) == got
 
 
+def test_first_bam_is_ingested_on_a_helper_thread_beside_the_n_scan(engine, tmp_path, monkeypatch, capsys):
+    """The command line starts the ingestion of its first BAM file on a helper thread before it scans the assembly for N runs
+    (pipeline.start_ingest_ahead; the N scan then runs on a context of its own) and filter() takes the result over: same files
+    as with GCI_INGEST_AHEAD=0, the first file's bam_join_input() off the main thread, nothing left behind."""
+    import threading
+    from gci_amd import cli
+    case = "c3_two_bam" if "c3_two_bam" in CASES else CASES[0]
+    pipeline._ENGINE = engine
+    seen = []
+    real = pipeline.bam_join_input
+
+    def spy(eng, path, *a, **kw):
+        seen.append((os.path.basename(path), threading.current_thread() is threading.main_thread(), eng is engine))
+        return real(eng, path, *a, **kw)
+
+    monkeypatch.setattr(pipeline, "bam_join_input", spy)
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("GCI_INGEST_AHEAD", knob)
+        del seen[:]
+        out = str(tmp_path / ("out" + knob))
+        cli.main(cli_args(case, out))
+        outs[knob] = read_outputs(out)
+        assert not pipeline._INGEST_AHEAD and not pipeline._TABLES
+        assert all(on_engine for _, _, on_engine in seen)
+        first_on_main = seen[0][1]
+        assert first_on_main == (knob == "0") and all(on_main for _, on_main, _ in seen[1:])
+    capsys.readouterr()
+    assert outs["1"] == outs["0"] == {k: v for k, v in expected(case).items()}
+
+
 def test_mh63_example_through_gpu(engine, oracle):
     """example/MH63.depth.gz -> MH63.0.depth.bed + MH63.gci, byte for byte, with the scan and the
     text on the GPU (396 Mb, 12 contigs)."""
