@@ -1,0 +1,210 @@
+// inflate_wave_host_check.cpp -- the kernel of tools/hwtests/inflate_wave.hip played lane by lane on the host, with the very helpers
+// the kernel uses (inflate_wave_core.hpp compiled for the host), every member of a BGZF file held against zlib.
+//   g++ -O2 -std=c++17 -o /tmp/iw_check tools/hwtests/inflate_wave_host_check.cpp -lz && /tmp/iw_check file.bam [max members]
+// The phases are the kernel's (same variables, a loop over the 64 lanes where the kernel has the wave); what it cannot show is what
+// only hardware shows: the ordering of the wave's stores and loads in the copies, and speed.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <vector>
+
+static inline uint32_t brev32(uint32_t v)
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+#define IW_DEV
+#define IW_INLINE static inline
+#define IW_CONST static const
+#define IW_BREV(x) brev32(x)
+#include "inflate_wave_core.hpp"
+
+struct Match { uint32_t o, len, d; };
+
+// -> status (ST_*); out: isize bytes
+static uint32_t member(const uint8_t* base, uint32_t nbits, uint32_t isize, std::vector<uint8_t>& dst, uint64_t stats[8])
+{
+    static Tabs T;
+    static uint32_t note[64][WINDOW / 32];
+    dst.assign(isize + 8, 0);
+    std::vector<Match> mlist;
+    uint32_t bpos = 0, out_pos = 0;
+    for (bool last = false; !last;) {
+        uint32_t p0 = bpos;
+        const int type = block_header(base, p0, nbits, T, last);
+        const uint32_t body0 = p0;
+        memset(note, 0, sizeof note);
+        if (type == 3) return ST_HEADER;
+        if (type == 0) {
+            const uint32_t byte = (body0 + 7u) >> 3;
+            if (8u * (byte + 4u) > nbits) return ST_HEADER;
+            const uint32_t len = (uint32_t)base[byte] | ((uint32_t)base[byte + 1] << 8), nlen = (uint32_t)base[byte + 2] | ((uint32_t)base[byte + 3] << 8);
+            if ((len ^ 0xFFFFu) != nlen || out_pos + len > isize || 8u * (byte + 4u + len) > nbits) return ST_HEADER;
+            memcpy(dst.data() + out_pos, base + byte + 4, len);
+            out_pos += len;
+            bpos = 8u * (byte + 4u + len);
+            continue;
+        }
+        uint32_t piece = (nbits - body0 + 63u) / 64u;
+        if (piece < MIN_PIECE) piece = MIN_PIECE;
+        uint32_t start[64], e_k[64], ob[64], om[64], eob_at[64], eob_end[64], eob_ob[64], eob_om[64], eob2_at[64], eob2_end[64], eob2_ob[64], eob2_om[64], meet[64], xb[64], xm[64], x_eob_end[64], from[64];
+        bool active[64], x_eob[64], x_fail[64];
+        for (int lane = 0; lane < 64; lane++) {                                       // 2.
+            start[lane] = body0 + (uint32_t)lane * piece;
+            active[lane] = start[lane] < nbits;
+            const uint32_t bound = start[lane] + piece;
+            uint32_t p = start[lane];
+            ob[lane] = om[lane] = 0; eob_at[lane] = eob2_at[lane] = NONE; eob_end[lane] = eob2_end[lane] = eob_ob[lane] = eob_om[lane] = eob2_ob[lane] = eob2_om[lane] = 0;
+            if (active[lane]) {
+                while (p < bound && p < nbits) {
+                    const uint32_t rel = p - start[lane];
+                    if (rel < WINDOW) note[lane][rel >> 5] |= 1u << (rel & 31u);
+                    const Sym s = step(base, p, nbits, T);
+                    if (s.kind == 2u) {
+                        if (eob_at[lane] == NONE) { eob_at[lane] = p; eob_end[lane] = p + s.used; eob_ob[lane] = ob[lane]; eob_om[lane] = om[lane]; }
+                        else if (eob2_at[lane] == NONE) { eob2_at[lane] = p; eob2_end[lane] = p + s.used; eob2_ob[lane] = ob[lane]; eob2_om[lane] = om[lane]; }
+                    }
+                    p += s.used;
+                    if (s.kind == 0u) ob[lane] += 1u; else if (s.kind == 1u) { ob[lane] += s.a; om[lane] += 1u; }
+                }
+            }
+            e_k[lane] = p;
+        }
+        for (int lane = 0; lane < 64; lane++) {                                       // 3.
+            meet[lane] = NONE; xb[lane] = xm[lane] = 0; x_eob_end[lane] = 0; x_eob[lane] = x_fail[lane] = false;
+            const uint32_t bound = start[lane] + piece;
+            const bool has_next = lane < 63 && active[lane] && start[lane] + piece < nbits;
+            if (has_next) {
+                uint32_t q = e_k[lane];
+                for (;;) {
+                    const uint32_t rel = q - bound;
+                    if (rel >= WINDOW) { x_fail[lane] = true; break; }
+                    if ((note[lane + 1][rel >> 5] >> (rel & 31u)) & 1u) { meet[lane] = q; break; }
+                    const Sym s = step(base, q, nbits, T);
+                    if (s.kind == 3u) { x_fail[lane] = true; break; }
+                    if (s.kind == 2u) { x_eob[lane] = true; x_eob_end[lane] = q + s.used; break; }
+                    q += s.used;
+                    if (s.kind == 0u) xb[lane] += 1u; else { xb[lane] += s.a; xm[lane] += 1u; }
+                }
+                stats[2] += e_k[lane] >= bound ? (meet[lane] != NONE ? meet[lane] - bound : 0) : 0;
+                stats[3]++;
+            }
+        }
+        int E = -1;
+        bool own_eob[64];
+        for (int lane = 0; lane < 64; lane++) {
+            from[lane] = lane ? meet[lane - 1] : body0;
+            if (eob_at[lane] != NONE && from[lane] != NONE && eob_at[lane] < from[lane]) {
+                eob_at[lane] = eob2_at[lane]; eob_end[lane] = eob2_end[lane]; eob_ob[lane] = eob2_ob[lane]; eob_om[lane] = eob2_om[lane];
+            }
+            own_eob[lane] = active[lane] && eob_at[lane] != NONE && from[lane] != NONE && eob_at[lane] >= from[lane];
+            if (E < 0 && (own_eob[lane] || x_eob[lane])) E = lane;
+        }
+        if (E < 0) return ST_LANES;
+        for (int lane = 0; lane <= E; lane++) {
+            if (from[lane] == NONE) return ST_NO_MEETING;
+            if (eob_at[lane] != NONE && eob_at[lane] < from[lane]) return ST_FALSE_EOB;
+            if (lane < E && (x_fail[lane] || meet[lane] == NONE)) return ST_NO_MEETING;
+        }
+        uint32_t sb[64] = {0}, sm[64] = {0};
+        for (int lane = 1; lane <= E; lane++) {
+            uint32_t q = start[lane];
+            while (q < from[lane]) {
+                const Sym s = step(base, q, nbits, T);
+                q += s.used;
+                if (s.kind == 0u) sb[lane] += 1u; else if (s.kind == 1u) { sb[lane] += s.a; sm[lane] += 1u; }
+            }
+            if (q != from[lane]) return ST_UNDECODABLE;
+        }
+        uint32_t cb[64] = {0}, cm[64] = {0}, stop[64] = {0}, off_b[64], off_m[64], tot_b = 0, tot_m = 0;
+        for (int lane = 0; lane <= E; lane++) {
+            if (lane == E && own_eob[lane]) { cb[lane] = eob_ob[lane] - sb[lane]; cm[lane] = eob_om[lane] - sm[lane]; }
+            else { cb[lane] = ob[lane] - sb[lane] + xb[lane]; cm[lane] = om[lane] - sm[lane] + xm[lane]; }
+            stop[lane] = lane < E ? meet[lane] : (own_eob[lane] ? eob_at[lane] : x_eob_end[lane]);
+        }
+        for (int lane = 0; lane < 64; lane++) { off_b[lane] = tot_b; off_m[lane] = tot_m; tot_b += cb[lane]; tot_m += cm[lane]; }
+        if (out_pos + tot_b > isize) return ST_LENGTH;
+        if (mlist.size() + tot_m > MATCH_CAP) return ST_CAPACITY;
+        const uint32_t n_match = (uint32_t)mlist.size();
+        mlist.resize(n_match + tot_m);
+        for (int lane = 0; lane <= E; lane++) {                                       // 5.
+            uint32_t q = from[lane], o = out_pos + off_b[lane], mi = n_match + off_m[lane];
+            for (;;) {
+                if (lane < E && q == stop[lane]) break;
+                const Sym s = step(base, q, nbits, T);
+                if (s.kind == 2u) break;
+                if (s.kind == 3u) return ST_UNDECODABLE;
+                q += s.used;
+                if (s.kind == 0u) dst[o++] = (uint8_t)s.a;
+                else { mlist[mi++] = {o, s.a, s.b}; o += s.a; }
+                if (lane < E && q > stop[lane]) return ST_UNDECODABLE;
+            }
+            if (o != out_pos + off_b[lane] + cb[lane] || mi != n_match + off_m[lane] + cm[lane]) return ST_UNDECODABLE;
+        }
+        out_pos += tot_b;
+        bpos = own_eob[E] ? eob_end[E] : x_eob_end[E];
+        stats[4] += (uint64_t)(E + 1);
+        stats[5]++;
+    }
+    if (out_pos != isize) return ST_LENGTH;
+    for (const Match& mm : mlist) {                                                   // 6.
+        if (mm.d == 0 || mm.d > mm.o) return ST_UNDECODABLE;
+        for (uint32_t x = 0; x < mm.len; x++) dst[mm.o + x] = dst[mm.o - mm.d + x];
+    }
+    stats[6] += mlist.size();
+    return ST_OK;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s file.bgzf [max members]\n", argv[0]); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> raw((size_t)n + 64, 0);
+    if (fread(raw.data(), 1, (size_t)n, f) != (size_t)n) return 2;
+    fclose(f);
+    const long max_members = argc > 2 ? atol(argv[2]) : 1L << 40;
+    uint64_t stats[8] = {0};
+    long members = 0, same = 0, by_status[8] = {0};
+    std::vector<uint8_t> got, want;
+    for (uint64_t pos = 0; pos + 26 <= (uint64_t)n && members < max_members; members++) {
+        const uint8_t* h = raw.data() + pos;
+        if (h[0] != 0x1F || h[1] != 0x8B) { fprintf(stderr, "not a gzip member at %llu\n", (unsigned long long)pos); return 1; }
+        const uint32_t xlen = h[10] | (h[11] << 8), bsize = (h[16] | (h[17] << 8)) + 1u;
+        const uint8_t* base = h + 12 + xlen;
+        const uint32_t pay = bsize - 12 - xlen - 8;
+        uint32_t isize;
+        memcpy(&isize, h + bsize - 4, 4);
+        want.assign(isize + 8, 0);
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        inflateInit2(&z, -15);
+        z.next_in = (Bytef*)base; z.avail_in = pay; z.next_out = want.data(); z.avail_out = isize + 8;
+        const int zr = inflate(&z, Z_FINISH);
+        inflateEnd(&z);
+        if (zr != Z_STREAM_END || z.total_out != isize) { fprintf(stderr, "zlib refuses member %ld\n", members); return 1; }
+        const uint32_t st = member(base, 8u * pay, isize, got, stats);
+        by_status[st < 8 ? st : 7]++;
+        if (st == ST_OK) {
+            if (memcmp(got.data(), want.data(), isize) == 0) same++;
+            else { fprintf(stderr, "member %ld DIFFERS from zlib\n", members); return 1; }
+        }
+        pos += bsize;
+    }
+    printf("%ld members: %ld decoded by the wave scheme and equal to zlib byte for byte; by status: ok %ld, header %ld, no meeting point %ld, false end of block %ld, "
+           "undecodable %ld, capacity %ld, length %ld, lanes %ld (anything but ok goes to the lane-per-member kernel)\n",
+           members, same, by_status[0], by_status[1], by_status[2], by_status[3], by_status[4], by_status[5], by_status[6], by_status[7]);
+    printf("stitches %llu, mean overrun into the neighbour's piece %.0f bits; lanes in use per block: mean %.1f; matches %llu\n",
+           (unsigned long long)stats[3], stats[3] ? (double)stats[2] / (double)stats[3] : 0.0, stats[5] ? (double)stats[4] / (double)stats[5] : 0.0,
+           (unsigned long long)stats[6]);
+    return 0;
+}
