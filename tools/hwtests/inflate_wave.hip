@@ -16,9 +16,9 @@
 //   4. the lane whose true range holds the end-of-block code ends the block; the lanes behind it are void;
 //   5. prefix sums over the lanes give every lane its place in the output and in the member's match list; a second pass over the
 //      same bits writes the literals and lists the matches {destination, length, distance};
-//   6. the copies.  v0 (this file): the wave takes the matches in order, one at a time, the lanes copy its bytes side by side
-//      (byte by byte by one lane when source and destination overlap).  The plan is a window in LDS and batches of 64 matches
-//      (model_inflate_wave.py: 5.9 passes per batch); v0 is there to prove the decode.
+//   6. the copies: 64 matches at a time, one per lane; a lane copies when the earlier lanes of the batch whose destination meets its
+//      source are done (5.96 passes per batch on the host).  v1 (this file): the bytes in global memory, a round trip per pass; the
+//      member's window in LDS is the next step.
 // A member that does not stitch (no meeting point within WINDOW bits, an end-of-block code on a wrong path, an undecodable spot on
 // the true path, a capacity) is reported in status[] and left to the lane-per-member kernel.
 #include <hip/hip_runtime.h>
@@ -197,24 +197,45 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
             bpos = (uint32_t)__shfl((int)(own_eob ? eob_end : x_eob_end), E, 64);
         }
         if (st == ST_OK && out_pos != isize) st = ST_LENGTH;
-        // ---- 6. the copies (v0: in order, one match at a time, its bytes side by side) ----------------------------------------------
+        // ---- 6. the copies: 64 matches at a time, one per lane, in output order ------------------------------------------------------
+        // What lies in front of a batch is final (earlier batches, literals).  Lane i depends on the earlier lanes of the batch whose
+        // destination meets its source: a contiguous range of lanes, as the destinations ascend (two binary searches over the batch's
+        // destinations in LDS).  A pass copies every lane whose range is done -- decided on the state in front of the pass, the lanes of
+        // a pass copy side by side --; 5.96 passes per batch on the host (inflate_wave_host_check.cpp).  v1: the bytes in global memory
+        // (a round trip per pass); the window of the member in LDS is the next step.
         if (st == ST_OK) {
+            __shared__ uint32_t s_o[64], s_end[64];
             __threadfence_block();
-            for (uint32_t i = 0; i < n_match; i++) {
-                const uint2 mm = mlist[i];
+            bool c_bad = false;
+            for (uint32_t b0 = 0; b0 < n_match; b0 += 64) {
+                const uint32_t nb = n_match - b0 < 64u ? n_match - b0 : 64u;
+                const bool have = (uint32_t)lane < nb;
+                const uint2 mm = have ? mlist[b0 + lane] : make_uint2(0u, 1u);
                 const uint32_t o = mm.x & 0x1FFFFu, len = mm.x >> 17, d = mm.y;
-                if (d == 0u || d > o) { st = ST_UNDECODABLE; break; }
-                if (d >= len) {
-                    uint8_t v[5];
-#pragma unroll
-                    for (int r = 0; r < 5; r++) { const uint32_t x = (uint32_t)lane + 64u * r; if (x < len) v[r] = dst[o - d + x]; }
-#pragma unroll
-                    for (int r = 0; r < 5; r++) { const uint32_t x = (uint32_t)lane + 64u * r; if (x < len) dst[o + x] = v[r]; }
-                } else if (lane == 0) {
-                    for (uint32_t x = 0; x < len; x++) dst[o + x] = dst[o - d + x];
+                if (have && (d == 0u || d > o)) c_bad = true;
+                s_o[lane] = have ? o : 0xFFFFFFFFu; s_end[lane] = have ? o + len : 0xFFFFFFFFu;
+                __syncthreads();
+                const uint32_t s0 = o - d, s1 = s0 + len;
+                uint32_t lo = 0, hi = nb;                                  // first lane whose end > s0; first lane whose start >= s1
+                for (uint32_t a = 0, b = nb; a < b;) { const uint32_t mid = (a + b) >> 1; if (s_end[mid] > s0) b = mid; else a = mid + 1; lo = a < b ? b : a; }
+                for (uint32_t a = 0, b = nb; a < b;) { const uint32_t mid = (a + b) >> 1; if (s_o[mid] >= s1) b = mid; else a = mid + 1; hi = a < b ? b : a; }
+                if (hi > (uint32_t)lane) hi = (uint32_t)lane;
+                const unsigned long long dep = hi > lo ? (((1ull << hi) - 1ull) & ~((1ull << lo) - 1ull)) : 0ull;
+                const unsigned long long all = nb == 64u ? ~0ull : ((1ull << nb) - 1ull);
+                unsigned long long done = 0ull;
+                if (__ballot(c_bad)) break;
+                while (done != all) {
+                    const bool ready = have && !((done >> lane) & 1ull) && (dep & ~done) == 0ull;
+                    const unsigned long long rmask = __ballot(ready);
+                    if (rmask == 0ull) { c_bad = true; break; }
+                    if (ready) for (uint32_t x = 0; x < len; x++) dst[o + x] = dst[s0 + x];       // (its own bytes when d < len: in order)
+                    __threadfence_block();
+                    done |= rmask;
                 }
-                __threadfence_block();
+                if (__ballot(c_bad)) break;
+                __syncthreads();
             }
+            if (__ballot(c_bad)) st = ST_UNDECODABLE;
         }
         if (lane == 0) status[m] = st;
         __syncthreads();

@@ -153,9 +153,45 @@ static uint32_t member(const uint8_t* base, uint32_t nbits, uint32_t isize, std:
         stats[5]++;
     }
     if (out_pos != isize) return ST_LENGTH;
-    for (const Match& mm : mlist) {                                                   // 6.
-        if (mm.d == 0 || mm.d > mm.o) return ST_UNDECODABLE;
-        for (uint32_t x = 0; x < mm.len; x++) dst[mm.o + x] = dst[mm.o - mm.d + x];
+    // 6. the copies, as the NEXT version of the kernel is to make them: 64 matches at a time, one per lane, in output order.  What lies
+    // in front of the batch is final (earlier batches, literals).  Lane i depends on the earlier lanes of the batch whose destination
+    // meets its source -- a contiguous range of lanes, as destinations ascend --; a pass copies every lane whose range is done (decided
+    // on the state in front of the pass: the lanes of a pass copy side by side), until the batch is done.
+    for (size_t b0 = 0; b0 < mlist.size(); b0 += 64) {
+        const int nb = (int)(mlist.size() - b0 < 64 ? mlist.size() - b0 : 64);
+        uint64_t dep[64], done = 0, all = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+        for (int i = 0; i < nb; i++) {
+            const Match& mi = mlist[b0 + i];
+            if (mi.d == 0 || mi.d > mi.o) return ST_UNDECODABLE;
+            const uint32_t s0 = mi.o - mi.d, s1 = s0 + mi.len;              // (the part of the source inside the match itself is the lane's own)
+            dep[i] = 0;
+            for (int j = 0; j < i; j++) {
+                const Match& mj = mlist[b0 + j];
+                if (mj.o < s1 && mj.o + mj.len > s0) dep[i] |= 1ull << j;
+            }
+            // the same as a range of lanes, by two binary searches over the batch's ascending destinations (the kernel's way)
+            int lo = 0, hi = nb;
+            for (int a = 0, b = nb; a < b;) { const int mid = (a + b) >> 1; if (mlist[b0 + mid].o + mlist[b0 + mid].len > s0) b = mid; else a = mid + 1; lo = b; if (a >= b) lo = a; }
+            for (int a = 0, b = nb; a < b;) { const int mid = (a + b) >> 1; if (mlist[b0 + mid].o >= s1) b = mid; else a = mid + 1; hi = b; if (a >= b) hi = a; }
+            if (hi > i) hi = i;
+            const uint64_t range = hi > lo ? (((hi == 64 ? 0ull : (1ull << hi)) - 1ull) & ~((1ull << lo) - 1ull)) : 0ull;
+            if (range != dep[i]) { fprintf(stderr, "dependency range differs from the pairwise test\n"); return ST_UNDECODABLE; }
+        }
+        uint32_t passes = 0;
+        while (done != all) {
+            uint64_t ready = 0;
+            for (int i = 0; i < nb; i++) if (!((done >> i) & 1ull) && (dep[i] & ~done) == 0) ready |= 1ull << i;
+            if (!ready) return ST_UNDECODABLE;
+            for (int i = 0; i < nb; i++)
+                if ((ready >> i) & 1ull) {
+                    const Match& mm = mlist[b0 + i];
+                    for (uint32_t x = 0; x < mm.len; x++) dst[mm.o + x] = dst[mm.o - mm.d + x];
+                }
+            done |= ready;
+            passes++;
+        }
+        stats[7] += passes;
+        stats[1]++;
     }
     stats[6] += mlist.size();
     return ST_OK;
@@ -203,8 +239,9 @@ int main(int argc, char** argv)
     printf("%ld members: %ld decoded by the wave scheme and equal to zlib byte for byte; by status: ok %ld, header %ld, no meeting point %ld, false end of block %ld, "
            "undecodable %ld, capacity %ld, length %ld, lanes %ld (anything but ok goes to the lane-per-member kernel)\n",
            members, same, by_status[0], by_status[1], by_status[2], by_status[3], by_status[4], by_status[5], by_status[6], by_status[7]);
-    printf("stitches %llu, mean overrun into the neighbour's piece %.0f bits; lanes in use per block: mean %.1f; matches %llu\n",
+    printf("stitches %llu, mean overrun into the neighbour's piece %.0f bits; lanes in use per block: mean %.1f; matches %llu in %llu batches of 64, "
+           "%.2f passes per batch\n",
            (unsigned long long)stats[3], stats[3] ? (double)stats[2] / (double)stats[3] : 0.0, stats[5] ? (double)stats[4] / (double)stats[5] : 0.0,
-           (unsigned long long)stats[6]);
+           (unsigned long long)stats[6], (unsigned long long)stats[1], stats[1] ? (double)stats[7] / (double)stats[1] : 0.0);
     return 0;
 }
