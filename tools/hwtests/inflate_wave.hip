@@ -19,6 +19,12 @@
 //   6. the copies: 64 matches at a time, one per lane; a lane copies when the earlier lanes of the batch whose destination meets its
 //      source are done (5.96 passes per batch on the host).  v1 (this file): the bytes in global memory, a round trip per pass; the
 //      member's window in LDS is the next step.
+// Known costs of this first version, for whoever runs it first: (a) the block header and the three code tables are lane 0's work
+// alone -- ~320 code lengths, three passes over them, 288 table entries: about as many wave-instructions as the two decode passes
+// of a piece, so they want the other 63 lanes (code lengths by all lanes is not possible -- it is a bit stream --, the counting,
+// the sorting by code and the primary tables are); (b) every symbol costs an unaligned 8-byte load from global memory (a piece is
+// ~220 bytes: the lanes of a wave read 14 KB side by side, L1 should hold it; the payload in LDS would take 27 KB per wave);
+// (c) the copies make a round trip to memory per pass, ~6 passes per 64 matches, ~190 batches per member.
 // A member that does not stitch (no meeting point within WINDOW bits, an end-of-block code on a wrong path, an undecodable spot on
 // the true path, a capacity) is reported in status[] and left to the lane-per-member kernel.
 #include <hip/hip_runtime.h>
