@@ -11,7 +11,13 @@
 #endif
 
 constexpr int LIT_BITS = 8, DIST_BITS = 5;
-constexpr uint32_t WINDOW = 1024, MIN_PIECE = 2048, NONE = 0xFFFFFFFFu;
+#ifndef IW_WINDOW
+#define IW_WINDOW 1024
+#endif
+#ifndef IW_MIN_PIECE
+#define IW_MIN_PIECE 2048
+#endif
+constexpr uint32_t WINDOW = IW_WINDOW, MIN_PIECE = IW_MIN_PIECE, NONE = 0xFFFFFFFFu;    // (-DIW_WINDOW=..: inflate_wave_host_check sweeps them)
 constexpr uint32_t MATCH_CAP = 22016;                    // a member's matches: at most 65536 / 3
 
 IW_CONST uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
