@@ -19,10 +19,10 @@
 //   6. the copies: 64 matches at a time, one per lane; a lane copies when the earlier lanes of the batch whose destination meets its
 //      source are done (5.96 passes per batch on the host).  v1 (this file): the bytes in global memory, a round trip per pass; the
 //      member's window in LDS is the next step.
-// Known costs of this first version, for whoever runs it first: (a) the block header and the three code tables are lane 0's work
-// alone -- ~320 code lengths, three passes over them, 288 table entries: about as many wave-instructions as the two decode passes
-// of a piece, so they want the other 63 lanes (code lengths by all lanes is not possible -- it is a bit stream --, the counting,
-// the sorting by code and the primary tables are); (b) every symbol costs an unaligned 8-byte load from global memory (a piece is
+// Known costs of this first version, for whoever runs it first: (a) the block header and the sorting of the symbols by code are lane
+// 0's work alone -- ~320 code lengths, three passes over them: about as many wave-instructions as a decode pass of a piece; the
+// primary tables are filled by all lanes (table_entry), the counting and the sorting by code could be (the code lengths themselves are
+// a bit stream); (b) every symbol costs an unaligned 8-byte load from global memory (a piece is
 // ~220 bytes: the lanes of a wave read 14 KB side by side, L1 should hold it; the payload in LDS would take 27 KB per wave);
 // (c) the copies make a round trip to memory per pass, ~6 passes per 64 matches, ~190 batches per member.
 // A member that does not stitch (no meeting point within WINDOW bits, an end-of-block code on a wrong path, an undecodable spot on
@@ -79,6 +79,11 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
             const uint32_t type = s_hdr[0], body0 = s_hdr[1];
             last = s_hdr[2] != 0u;
             if (type == 3u) { st = ST_HEADER; break; }
+            if (type != 0u) {                                             // the primary tables: every lane its entries
+                for (uint32_t k = lane; k < (1u << LIT_BITS); k += 64) T.lit_tab[k] = table_entry(k, LIT_BITS, T.lit_cn, T.lit_sorted);
+                if (lane < (1 << DIST_BITS)) T.dist_tab[lane] = table_entry((uint32_t)lane, DIST_BITS, T.dist_cn, T.dist_sorted);
+                __syncthreads();
+            }
             if (type == 0u) {                                             // stored
                 const uint32_t byte = (body0 + 7u) >> 3;
                 if (8u * (byte + 4u) > nbits) { st = ST_HEADER; break; }

@@ -81,6 +81,19 @@ IW_DEV void build_table(int bits, const Canon& cn, const uint16_t* sorted, uint1
     }
 }
 
+// Entry k of a primary table of `bits` bits WITHOUT the other entries: the canonical search on the index itself (k = the next bits of the
+// stream, first bit lowest).  A code of at most `bits` bits is met iff c < limit[bits] -- exact on the padded value, as that limit has
+// its low 15 - bits bits clear --, its length is the number of limits[0 .. bits) <= c.  So the 64 lanes of a wave fill a table side by
+// side (four entries each for the literals), where build_table() is one lane's loop.  Same entries as build_table().
+IW_INLINE uint16_t table_entry(uint32_t k, int bits, const Canon& cn, const uint16_t* sorted)
+{
+    const uint32_t c = IW_BREV(k) >> 17;                                   // the index as the top bits of a 15-bit code, zeros behind
+    if (c >= cn.limit[bits]) return 0;
+    int l = 0;
+    for (int j = 0; j < bits; j++) l += cn.limit[j] <= c ? 1 : 0;
+    return (uint16_t)((uint32_t)sorted[(int)cn.off[l] + (int)(c >> (15 - l))] | ((uint32_t)l << 9));
+}
+
 // one code: the primary table (primary_bits > 0), else the canonical search; -1: no such code.  len = bits of the code.
 IW_INLINE int code_at(unsigned long long bits, const uint16_t* table, int primary_bits, const Canon& cn,
                                        const uint16_t* sorted, int& len)
@@ -168,8 +181,7 @@ IW_DEV int block_header(const uint8_t* base, uint32_t& pos, uint32_t nbits, Tabs
         if (ll[256] == 0) return 3;
     }
     if (!build_code(ll, hlit, T.lit_cn, T.lit_sorted) || !build_code(ll + hlit, hdist, T.dist_cn, T.dist_sorted)) return 3;
-    build_table(LIT_BITS, T.lit_cn, T.lit_sorted, T.lit_tab);
-    build_table(DIST_BITS, T.dist_cn, T.dist_sorted, T.dist_tab);
+    // (the two primary tables are filled by the caller: entry by entry, table_entry(), by all the lanes of the wave)
     return (int)type;
 }
 

@@ -41,6 +41,14 @@ static uint32_t member(const uint8_t* base, uint32_t nbits, uint32_t isize, std:
         const uint32_t body0 = p0;
         memset(note, 0, sizeof note);
         if (type == 3) return ST_HEADER;
+        if (type != 0) {                                                           // the tables entry by entry (the kernel: every lane its entries) ...
+            for (uint32_t k = 0; k < (1u << LIT_BITS); k++) T.lit_tab[k] = table_entry(k, LIT_BITS, T.lit_cn, T.lit_sorted);
+            for (uint32_t k = 0; k < (1u << DIST_BITS); k++) T.dist_tab[k] = table_entry(k, DIST_BITS, T.dist_cn, T.dist_sorted);
+            uint16_t lt[1 << LIT_BITS], dt[1 << DIST_BITS];                        // ... == one lane's loop over the codes
+            build_table(LIT_BITS, T.lit_cn, T.lit_sorted, lt);
+            build_table(DIST_BITS, T.dist_cn, T.dist_sorted, dt);
+            if (memcmp(lt, T.lit_tab, sizeof lt) || memcmp(dt, T.dist_tab, sizeof dt)) { fprintf(stderr, "a primary table differs from build_table()\n"); return ST_HEADER; }
+        }
         if (type == 0) {
             const uint32_t byte = (body0 + 7u) >> 3;
             if (8u * (byte + 4u) > nbits) return ST_HEADER;
