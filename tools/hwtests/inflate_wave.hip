@@ -6,7 +6,8 @@
 // runs it on a BAM with SEQ / QUAL of realistic entropy and compares every member with zlib.
 //
 // Per DEFLATE block of a member:
-//   1. lane 0 reads the block header and builds the code tables in LDS (one set per wave: 1.4 KB, not 1.3 KB per member-lane);
+//   1. lane 0 reads the block header's code lengths; the wave sorts the symbols by code (ballots) and fills the primary tables (every
+//      lane its entries) -- one set of tables per wave in LDS: 1.4 KB, not 1.3 KB per member-lane;
 //   2. the rest of the payload is cut into 64 pieces of equal bit length (>= MIN_PIECE); lane k decodes from the START of piece k as
 //      if a literal / length symbol began there, counts output bytes and matches, and notes the symbol starts it visits in the
 //      first WINDOW bits of its piece as a bitmap in LDS;
@@ -19,10 +20,8 @@
 //   6. the copies: 64 matches at a time, one per lane; a lane copies when the earlier lanes of the batch whose destination meets its
 //      source are done (5.96 passes per batch on the host).  v1 (this file): the bytes in global memory, a round trip per pass; the
 //      member's window in LDS is the next step.
-// Known costs of this first version, for whoever runs it first: (a) the block header and the sorting of the symbols by code are lane
-// 0's work alone -- ~320 code lengths, three passes over them: about as many wave-instructions as a decode pass of a piece; the
-// primary tables are filled by all lanes (table_entry), the counting and the sorting by code could be (the code lengths themselves are
-// a bit stream); (b) every symbol costs an unaligned 8-byte load from global memory (a piece is
+// Known costs of this first version, for whoever runs it first: (a) the ~320 code lengths of a block header are lane 0's work alone
+// (they are a bit stream); the sorting by code and the primary tables are the wave's; (b) every symbol costs an unaligned 8-byte load from global memory (a piece is
 // ~220 bytes: the lanes of a wave read 14 KB side by side, L1 should hold it; the payload in LDS would take 27 KB per wave);
 // (c) the copies make a round trip to memory per pass, ~6 passes per 64 matches, ~190 batches per member.
 // A member that does not stitch (no meeting point within WINDOW bits, an end-of-block code on a wrong path, an undecodable spot on
@@ -33,6 +32,54 @@
 #include "inflate_wave_core.hpp"
 
 namespace {
+
+// build_code() by the whole wave (one workgroup = one wave): the counts per code length and the place of every symbol among the symbols
+// of its length by ballots -- lane s + 64 c holds symbol s of chunk c, a ballot per (length, chunk) --, the fifteen-step prefix over the
+// lengths by lane 0.  Same Canon and same `sorted` as build_code() (the host check plays it lane by lane and compares).
+__device__ bool build_code_wave(const uint8_t* lens, int n, Canon& cn, uint16_t* sorted, int lane, uint32_t* s_ok)
+{
+    uint32_t my[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) { const int s = lane + 64 * c; my[c] = s < n ? lens[s] : 0u; }
+    uint32_t cnt = 0;
+    for (uint32_t L = 1; L < 16; L++) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) t += (uint32_t)__builtin_popcountll(__ballot(my[c] == L));
+        if ((uint32_t)lane == L) cnt = t;
+    }
+    if (lane < 16) cn.next[lane] = (uint16_t)(lane ? cnt : 0u);
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t code = 0, idx = 0, left = 1u << 15, prev = 0;
+        bool ok = true;
+        cn.limit[0] = 0; cn.off[0] = 0;
+        for (int l = 1; l < 16; l++) {
+            const uint32_t k = cn.next[l];
+            code = (code + prev) << 1;
+            cn.limit[l] = (uint16_t)((code + k) << (15 - l));
+            cn.off[l] = (int16_t)((int)idx - (int)code);
+            cn.next[l] = (uint16_t)idx;
+            idx += k; prev = k;
+            const uint32_t need = k << (15 - l);
+            if (need > left) ok = false; else left -= need;
+        }
+        *s_ok = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    for (uint32_t L = 1; L < 16; L++) {
+        uint32_t at = cn.next[L];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const unsigned long long mask = __ballot(my[c] == L);
+            if (my[c] == L) sorted[at + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(lane + 64 * c);
+            at += (uint32_t)__builtin_popcountll(mask);
+        }
+        if (lane == 0) cn.next[L] = (uint16_t)at;                        // one past the last symbol of length L, as build_code() leaves it
+    }
+    __syncthreads();
+    return *s_ok != 0u;
+}
 
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, int lane, uint32_t& total)
 {
@@ -53,7 +100,7 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
 {
     __shared__ Tabs T;
     __shared__ uint32_t note[64][WINDOW / 32];
-    __shared__ uint32_t s_hdr[4];                                         // type, body start, last, -
+    __shared__ uint32_t s_hdr[8];                                         // type, body start, last, hlit | hdist << 16, flag of build_code_wave
     const int lane = threadIdx.x;
     uint2* const mlist = matches + (size_t)blockIdx.x * MATCH_CAP;
     for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
@@ -71,15 +118,20 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
             if (lane == 0) {
                 uint32_t p = bpos;
                 bool l = false;
-                const int type = block_header(base, p, nbits, T, l);
-                s_hdr[0] = (uint32_t)type; s_hdr[1] = p; s_hdr[2] = l ? 1u : 0u;
+                int hlit = 0, hdist = 0;
+                const int type = block_header(base, p, nbits, T, l, hlit, hdist, false);
+                s_hdr[0] = (uint32_t)type; s_hdr[1] = p; s_hdr[2] = l ? 1u : 0u; s_hdr[3] = (uint32_t)hlit | ((uint32_t)hdist << 16);
             }
             for (uint32_t i = lane; i < 64u * (WINDOW / 32); i += 64) (&note[0][0])[i] = 0u;
             __syncthreads();
             const uint32_t type = s_hdr[0], body0 = s_hdr[1];
             last = s_hdr[2] != 0u;
             if (type == 3u) { st = ST_HEADER; break; }
-            if (type != 0u) {                                             // the primary tables: every lane its entries
+            if (type != 0u) {                                             // the two codes, then the primary tables: every lane its share
+                const int hlit = (int)(s_hdr[3] & 0xFFFFu), hdist = (int)(s_hdr[3] >> 16);
+                const bool ok_l = build_code_wave(T.lens + 32, hlit, T.lit_cn, T.lit_sorted, lane, &s_hdr[4]);
+                const bool ok_d = build_code_wave(T.lens + 32 + hlit, hdist, T.dist_cn, T.dist_sorted, lane, &s_hdr[4]);
+                if (!ok_l || !ok_d) { st = ST_HEADER; break; }
                 for (uint32_t k = lane; k < (1u << LIT_BITS); k += 64) T.lit_tab[k] = table_entry(k, LIT_BITS, T.lit_cn, T.lit_sorted);
                 if (lane < (1 << DIST_BITS)) T.dist_tab[lane] = table_entry((uint32_t)lane, DIST_BITS, T.dist_cn, T.dist_sorted);
                 __syncthreads();

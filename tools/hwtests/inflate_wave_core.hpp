@@ -139,7 +139,9 @@ IW_INLINE Sym step(const uint8_t* base, uint32_t pos, uint32_t nbits, const Tabs
 }
 
 // lane 0: the header of the block at bit `pos`; -> type (0 stored, 1 fixed, 2 dynamic; 3 = damaged), pos behind the header
-IW_DEV int block_header(const uint8_t* base, uint32_t& pos, uint32_t nbits, Tabs& T, bool& last)
+// codes = false: the code lengths only (T.lens + 32: hlit literal / length lengths, then hdist distance lengths); the caller builds the
+// two codes (the kernel with all lanes: build_code_wave)
+IW_DEV int block_header(const uint8_t* base, uint32_t& pos, uint32_t nbits, Tabs& T, bool& last, int& hlit, int& hdist, bool codes)
 {
     if (pos + 3 > nbits) return 3;
     unsigned long long bits = peek(base, pos);
@@ -149,7 +151,7 @@ IW_DEV int block_header(const uint8_t* base, uint32_t& pos, uint32_t nbits, Tabs
     if (type == 0) return 0;
     if (type == 3) return 3;
     uint8_t* ll = T.lens + 32;
-    int hlit = 288, hdist = 30;
+    hlit = 288; hdist = 30;
     if (type == 1) {
         for (int i = 0; i < 288; i++) ll[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
         for (int i = 0; i < 30; i++) ll[288 + i] = 5;
@@ -180,7 +182,7 @@ IW_DEV int block_header(const uint8_t* base, uint32_t& pos, uint32_t nbits, Tabs
         }
         if (ll[256] == 0) return 3;
     }
-    if (!build_code(ll, hlit, T.lit_cn, T.lit_sorted) || !build_code(ll + hlit, hdist, T.dist_cn, T.dist_sorted)) return 3;
+    if (codes && (!build_code(ll, hlit, T.lit_cn, T.lit_sorted) || !build_code(ll + hlit, hdist, T.dist_cn, T.dist_sorted))) return 3;
     // (the two primary tables are filled by the caller: entry by entry, table_entry(), by all the lanes of the wave)
     return (int)type;
 }

@@ -37,7 +37,42 @@ static uint32_t member(const uint8_t* base, uint32_t nbits, uint32_t isize, std:
     uint32_t bpos = 0, out_pos = 0;
     for (bool last = false; !last;) {
         uint32_t p0 = bpos;
-        const int type = block_header(base, p0, nbits, T, last);
+        int hlit = 0, hdist = 0;
+        const int type = block_header(base, p0, nbits, T, last, hlit, hdist, true);
+        if (type == 1 || type == 2) {                                              // build_code_wave(), lane by lane == build_code()
+            for (int which = 0; which < 2; which++) {
+                const uint8_t* lens = T.lens + 32 + (which ? hlit : 0);
+                const int n = which ? hdist : hlit;
+                const Canon& want = which ? T.dist_cn : T.lit_cn;
+                const uint16_t* want_sorted = which ? T.dist_sorted : T.lit_sorted;
+                Canon cn;
+                uint16_t sorted[320] = {0};
+                uint32_t cnt[16] = {0};
+                for (int c = 0; c < 5; c++) for (int lane = 0; lane < 64; lane++) { const int sy = lane + 64 * c; if (sy < n) cnt[lens[sy]]++; }
+                cnt[0] = 0;
+                uint32_t code = 0, idx = 0, prev = 0;
+                cn.limit[0] = 0; cn.off[0] = 0; cn.next[0] = 0;
+                for (int l = 1; l < 16; l++) {
+                    code = (code + prev) << 1;
+                    cn.limit[l] = (uint16_t)((code + cnt[l]) << (15 - l)); cn.off[l] = (int16_t)((int)idx - (int)code); cn.next[l] = (uint16_t)idx;
+                    idx += cnt[l]; prev = cnt[l];
+                }
+                int used = 0;
+                for (uint32_t L = 1; L < 16; L++) {
+                    uint32_t at = cn.next[L];
+                    for (int c = 0; c < 5; c++) {
+                        uint64_t mask = 0;
+                        for (int lane = 0; lane < 64; lane++) { const int sy = lane + 64 * c; if (sy < n && lens[sy] == L) mask |= 1ull << lane; }
+                        for (int lane = 0; lane < 64; lane++)
+                            if ((mask >> lane) & 1ull) { sorted[at + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(lane + 64 * c); used++; }
+                        at += (uint32_t)__builtin_popcountll(mask);
+                    }
+                    cn.next[L] = (uint16_t)at;
+                }
+                if (memcmp(cn.limit, want.limit, sizeof cn.limit) || memcmp(cn.off, want.off, sizeof cn.off) || memcmp(cn.next, want.next, sizeof cn.next) ||
+                    memcmp(sorted, want_sorted, sizeof(uint16_t) * (size_t)used)) { fprintf(stderr, "the wave's code differs from build_code()\n"); return ST_HEADER; }
+            }
+        }
         const uint32_t body0 = p0;
         memset(note, 0, sizeof note);
         if (type == 3) return ST_HEADER;
