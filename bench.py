@@ -18,7 +18,7 @@ without SEQ / QUAL: what `gci_bam_heads` makes of a BGZF file and what the comma
 At N>1 (weak scaling) every rank owns one CHM13-sized haplotype of an N-haplotype assembly and the records of its
 contigs from both files.
 
-Launch:  python bench.py --gpus 1 --steps K --warmup W
+Launch:  python bench.py --gpus N --steps K --warmup W      (N > 1: re-launches itself under torch.distributed.run, one process per GPU)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line.
 """
@@ -549,13 +549,49 @@ def make_two_type_workload(eng_factory, rank, world, args, exchange, replicated)
     return eng, w
 
 
+def genome_dual_once(args, rank, world, base):
+    """The genome workload of this run.  At N > 1 every rank needs the same two files: rank 0 generates them ONCE on all of the host's
+    cores and leaves them as .npy files in the directory the launcher made (GCI_BENCH_SHARED, tmpfs); the other ranks map them.
+    Without such a directory (a launch by hand under torch.distributed.run) every rank generates with its share of the cores."""
+    from gci_amd import workloads
+    shared = os.environ.get("GCI_BENCH_SHARED")
+    if world == 1 or not shared or not os.path.isdir(shared):
+        return workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0), kind=args.reads,
+                                     procs=max(1, workloads_default_procs() // max(1, world)))
+    done = os.path.join(shared, "genome_dual.done")
+    if rank == 0:
+        inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=True, kind=args.reads, procs=workloads_default_procs())
+        meta = {"contigs": [[n, int(l)] for n, l in inp.contigs], "files": []}
+        for i, f in enumerate(inp.files):
+            np.save(os.path.join(shared, "f%d_stream.npy" % i), f.stream)
+            np.save(os.path.join(shared, "f%d_offsets.npy" % i), f.offsets)
+            np.save(os.path.join(shared, "f%d_per_contig.npy" % i), f.aligned_per_contig)
+            meta["files"].append({"aligned_bases": int(f.aligned_bases), "k1_bytes": int(f.k1_bytes), "name_bytes": int(f.name_bytes)})
+        with open(done + ".tmp", "w") as fh:
+            json.dump(meta, fh)
+        os.rename(done + ".tmp", done)
+        return inp
+    t0 = time.time()
+    while not os.path.exists(done):
+        if time.time() - t0 > 3600:
+            sys.exit("bench: rank %d waited an hour for rank 0's workload in %s" % (rank, shared))
+        time.sleep(0.2)
+    meta = json.load(open(done))
+    files = []
+    for i, m in enumerate(meta["files"]):
+        files.append(workloads.AlignmentFile(np.load(os.path.join(shared, "f%d_stream.npy" % i), mmap_mode="r"),
+                                             np.load(os.path.join(shared, "f%d_offsets.npy" % i), mmap_mode="r"),
+                                             m["aligned_bases"], m["k1_bytes"], m["name_bytes"],
+                                             np.load(os.path.join(shared, "f%d_per_contig.npy" % i))))
+    return workloads.GenomeInput(tuple((n, int(l)) for n, l in meta["contigs"]), files)
+
+
 def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
     """configs[2]; at N>1 haplotype `rank` of an N-haplotype assembly (contig names h<r>_chrN, read names unique to the
     rank).  The host arrays are generated BEFORE the HIP context exists (worker processes are forked)."""
     from gci_amd import synth, workloads
     base = synth.CHM13
-    inp = workloads.genome_dual(args.scale, args.coverage, contigs=base, verbose=(rank == 0), kind=args.reads,
-                                procs=max(1, workloads_default_procs() // max(1, world)))
+    inp = genome_dual_once(args, rank, world, base)
     nper = len(inp.contigs)
     contig_owner = None
     if (world > 1 or args.force_sharded) and args.scaling == "strong":
@@ -593,7 +629,7 @@ def make_genome_workload(eng_factory, rank, world, args, exchange, replicated):
         hdr = np.frombuffer(bamfmt.encode_header([n for n, _ in all_contigs], [l for _, l in all_contigs]), dtype=np.uint8)
         for fobj in inp.files:
             first = bamfmt.parse_header(fobj.stream).first_record
-            body = fobj.stream[first:]
+            body = fobj.stream[first:] if fobj.stream.flags.writeable else np.array(fobj.stream[first:])   # (a mapped file of rank 0's: copy)
             offs = fobj.offsets - np.uint64(first)
             ref = body[(offs[:, None] + np.arange(4, 8, dtype=np.uint64)[None, :]).astype(np.int64)].copy().view("<i4").reshape(-1)
             ref = np.where(ref >= 0, ref + rank * nper, ref).astype("<i4")
@@ -1385,8 +1421,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    launched = all(k in os.environ for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR"))
+    if args.gpus > 1 and not launched:
+        # `python bench.py --gpus N` on its own: become the launcher (one process per GPU over RCCL), as GCI.py --gpus N does
+        # (gci_amd/cli.py).  The strong-scaling workload is generated ONCE, by rank 0, into a directory every rank maps.
+        import tempfile
+        port = int(os.environ.get("MASTER_PORT", str(29700 + os.getpid() % 2000)))
+        shared = tempfile.mkdtemp(prefix="gci_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        env = dict(os.environ, GCI_BENCH_SHARED=shared)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import subprocess
+        rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env)
+        import shutil
+        shutil.rmtree(shared, ignore_errors=True)
+        sys.exit(rc)
+    if not launched:
+        rank, local_rank, world = 0, 0, 1
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE %d" % (args.gpus, world))
     import torch.distributed as dist
     exchange = args.force_exchange or args.force_replicated
 
@@ -1543,6 +1596,7 @@ def main():
                                 + ("heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream") + (")" if w.pages else ""),
                    "input_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "steps_in_flight": len(lanes),
+                   "workload_generated": "once, by rank 0" if (world > 1 and os.environ.get("GCI_BENCH_SHARED")) else "by every rank" if world > 1 else "in this process",
                    "join": ("sharded by name hash: per file one all-to-all of 32-byte records and one of 48-byte name slots, then one of "
                             "16-byte intervals to the owners of their contigs; %d bytes leave this rank per step" % w.sj.bytes_per_step()
                             if w.sharded else "local" if not w.exchange else

@@ -30,6 +30,9 @@
 #include <stdint.h>
 
 #include "inflate_wave_core.hpp"
+#ifndef IW_STAGE
+#define IW_STAGE 4
+#endif
 
 namespace {
 
@@ -146,6 +149,9 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
                 bpos = 8u * (byte + 4u + len);
                 continue;
             }
+#if IW_STAGE < 1
+            if (__ballot(T.lit_tab[lane] == 0xFFFFu) == ~0ull) { st = ST_LANES; } else { st = ST_LANES + 1; } break;
+#endif
             // ---- 2. every lane over its own piece ---------------------------------------------------------------------------------
             uint32_t piece = (nbits - body0 + 63u) / 64u;
             if (piece < MIN_PIECE) piece = MIN_PIECE;
@@ -171,6 +177,9 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
             }
             const uint32_t e_k = p;                                       // the lane stands here (behind its piece, or on its end-of-block code)
             __syncthreads();
+#if IW_STAGE < 2
+            if (__ballot(ob == 0xFFFFFFFFu)) { st = ST_LANES; } else { st = ST_LANES + 1; } break;
+#endif
             // ---- 3. stitch: on into the neighbour's piece until a position it noted ------------------------------------------------
             uint32_t meet = NONE, xb = 0, xm = 0, x_eob_end = 0;         // meeting point, bytes / matches of the overrun
             bool x_eob = false, x_fail = false;
@@ -228,6 +237,9 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
                 if (q != from) undec = true;                             // the lane did not pass through `from` after all
             }
             if (__ballot(undec)) { st = ST_UNDECODABLE; break; }
+#if IW_STAGE < 3
+            if (__ballot(sb == 0xFFFFFFFFu)) { st = ST_LANES; } else { st = ST_LANES + 1; } break;
+#endif
             // ---- 4. / 5. every lane's share, its place, the second pass --------------------------------------------------------------
             uint32_t cb = 0, cm = 0, stop = 0;                           // bytes, matches, and where the lane's share ends
             if (lane <= E) {
@@ -266,7 +278,7 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_wave(const uint8_t* _
         // destinations in LDS).  A pass copies every lane whose range is done -- decided on the state in front of the pass, the lanes of
         // a pass copy side by side --; 5.96 passes per batch on the host (inflate_wave_host_check.cpp).  v1: the bytes in global memory
         // (a round trip per pass); the window of the member in LDS is the next step.
-        if (st == ST_OK) {
+        if (st == ST_OK && IW_STAGE >= 4) {
             __shared__ uint32_t s_o[64], s_end[64];
             __threadfence_block();
             bool c_bad = false;

@@ -15,8 +15,9 @@ from gci_amd.formats import bam as bamfmt
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
 grid = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-so = os.path.join(HERE, "libinflate_wave.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so,
+stage = os.environ.get("IW_STAGE", "4")
+so = os.path.join(HERE, "libinflate_wave_s%s.so" % stage)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DIW_STAGE=" + stage, "-o", so,
                        os.path.join(HERE, "inflate_wave.hip")])
 lib = ctypes.CDLL(so)
 lib.inflate_wave_launch.restype = ctypes.c_int
@@ -49,9 +50,10 @@ for _ in range(3):
     ms.append(a.elapsed_time(b))
 status = d_status.cpu().numpy()
 out = d_out.cpu().numpy()
-names = ["ok", "header", "no meeting point", "false end of block", "undecodable", "capacity", "length", "lanes"]
+names = ["ok", "header", "no meeting point", "false end of block", "undecodable", "capacity", "length", "lanes", "cut"]
+print("IW_STAGE", stage)
 print("%d members, %.1f MB -> %.1f MB; launches %s ms (v0 copies: one match at a time)" % (n, raw.shape[0] / 1e6, stream.shape[0] / 1e6, ["%.1f" % x for x in ms]))
-print("by status:", {names[k]: int((status == k).sum()) for k in range(8) if (status == k).any()})
+print("by status:", {names[k]: int((status == k).sum()) for k in range(9) if (status == k).any()})
 bad = 0
 for m in np.flatnonzero(status == 0).tolist():
     a, b = int(off[m]), int(off[m + 1])
