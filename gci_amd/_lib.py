@@ -121,6 +121,7 @@ EXPORTS = [
     ("gci_route_hits", c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p]),
     ("gci_paf_score_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("gci_bgzf_inflate_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
+    ("gci_bgzf_inflate_last_stats", c_int, [c_void_p, c_void_p]),
     ("gci_bgzf_inflate_round", c_uint32, [c_void_p]),
     ("gci_bam_record_offsets_device", c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_int32, c_void_p, c_uint64, c_void_p]),
     ("gci_bgzf_scan", c_int, [c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),

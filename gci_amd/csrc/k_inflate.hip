@@ -221,13 +221,14 @@ template <int INF_LANES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF_WAVES, INF_WAVES)))
 void k_bgzf_inflate(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
                     const uint64_t* __restrict__ out_off, uint32_t n_members, uint8_t* __restrict__ out,
-                    uint64_t out_cap, unsigned long long* __restrict__ status)
+                    uint64_t out_cap, unsigned long long* __restrict__ status, const uint32_t* __restrict__ done_by_wave)
 {
     __shared__ LaneTabs tabs[INF_LANES];
     const int lane = threadIdx.x;
     if (lane >= INF_LANES) return;
     const uint32_t m = blockIdx.x * INF_LANES + lane;
     if (m >= n_members) return;
+    if (done_by_wave && done_by_wave[m] == 0u) return;                        // k_inflate_wave.hip decoded this one
     LaneTabs& T = tabs[lane];
     uint16_t* const lit_sorted = T.lit_sorted;
     const uint64_t pos = member_pos[m], pos_next = member_pos[m + 1];
@@ -478,6 +479,9 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_crc(const uint8_t* __restrict__ 
     }
 }
 
+int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off, uint32_t n_members,
+                         uint8_t* d_out, uint64_t out_cap, uint32_t* d_wstatus);          // k_inflate_wave.hip
+
 // d_raw must be readable up to 8 bytes past its last member (the decoder loads whole aligned dwords).
 extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off,
                                        uint32_t n_members, uint8_t* d_out, uint64_t out_cap, int check_crc, uint64_t* d_status)
@@ -485,11 +489,25 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
     if (!ctx || !d_status || (n_members && (!d_raw || !d_member_pos || !d_out_off || !d_out))) return GCI_E_INVALID;
     HIPCHK(hipMemsetAsync(d_status, 0xFF, 8, ctx->stream));
     if (n_members) {
+        // GCI_INFLATE=lane: every member by the lane-per-member kernel (round 2 - 4); default: a wave per member (k_inflate_wave.hip),
+        // the members it hands back -- its status word != 0 -- by the lane-per-member kernel behind it
+        static const bool wave = [] { const char* e = getenv("GCI_INFLATE"); return !(e && !strcmp(e, "lane")); }();
+        const uint32_t* d_done = nullptr;
+        ctx->inflate_last_n = 0;
+        if (wave) {
+            int st = gci_ensure(ctx, ctx->inflate_wstatus, (size_t)n_members * sizeof(uint32_t));
+            if (st) return st;
+            HIPCHK(hipMemsetAsync(ctx->inflate_wstatus.p, 0xFF, (size_t)n_members * sizeof(uint32_t), ctx->stream));
+            st = gci_inflate_wave_run(ctx, d_raw, d_member_pos, d_out_off, n_members, d_out, out_cap, (uint32_t*)ctx->inflate_wstatus.p);
+            if (st) return st;
+            d_done = (const uint32_t*)ctx->inflate_wstatus.p;
+            ctx->inflate_last_n = n_members;
+        }
         // members per wave: fewer = more waves per SIMD to overlap the memory round trips, more = fewer instructions issued
         static const int lanes = [] { const char* e = getenv("GCI_INFLATE_LANES"); return e ? atoi(e) : 8; }();
         auto launch = [&](auto kern, int per) {
             hipLaunchKernelGGL(kern, dim3((n_members + per - 1) / per), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, n_members,
-                               d_out, out_cap, (unsigned long long*)d_status);
+                               d_out, out_cap, (unsigned long long*)d_status, d_done);
         };
         if (lanes == 4) launch(k_bgzf_inflate<4>, 4);
         else if (lanes == 16) launch(k_bgzf_inflate<16>, 16);
@@ -497,11 +515,12 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
         else launch(k_bgzf_inflate<8>, 8);
         LAUNCHCHK("k_bgzf_inflate");
         if (check_crc) {
-            if (!ctx->crc_tabs.p) {
+            if (!ctx->crc_tabs_ready) {                                      // (ready only once the launch went through)
                 const int st = gci_ensure(ctx, ctx->crc_tabs, 32 * 256 * sizeof(uint32_t));
                 if (st) return st;
                 hipLaunchKernelGGL(k_crc_tables, dim3(1), dim3(256), 0, ctx->stream, (uint32_t*)ctx->crc_tabs.p);
                 LAUNCHCHK("k_crc_tables");
+                ctx->crc_tabs_ready = true;
             }
             const uint32_t per_block = (BLOCK / 64) * CRC_PER_WAVE;
             hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + per_block - 1) / per_block), dim3(BLOCK), 0, ctx->stream, d_raw, d_member_pos,

@@ -512,6 +512,13 @@ class Engine:
         self.check_status("gci_bgzf_inflate_device")
         return out[:n_pre + total]
 
+    def inflate_stats(self) -> dict:
+        """How the members of the last bgzf_inflate fared with the wave decoder (gci_bgzf_inflate_last_stats; synchronises)."""
+        c = (ctypes.c_uint32 * 8)()
+        self._chk(self.lib.gci_bgzf_inflate_last_stats(self.ctx, c), "gci_bgzf_inflate_last_stats")
+        names = ("decoded", "header", "no meeting point", "false end of block", "undecodable", "length", "lanes", "not tried")
+        return {k: int(v) for k, v in zip(names, c)}
+
     def inflate_round(self) -> int:
         """Members gci_bgzf_inflate_device decodes at a time on this device (0: unknown)."""
         return int(self.lib.gci_bgzf_inflate_round(self.ctx))

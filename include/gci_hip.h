@@ -492,10 +492,16 @@ int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, 
  * gci_bgzf_inflate_device: d_raw = the bytes of a BGZF file (or of a run of its members) on the device; d_member_pos[m] =
  * offset of member m in d_raw, n_members + 1 entries (the last = end of the run; gci_bgzf_blocks makes the table on the
  * host); d_out_off[m] = where member m's output goes in d_out (exclusive scan of the members' ISIZE, n_members + 1 entries).
- * One lane per member (decode tables in LDS, the output buffer is the window); every member's length and -- check_crc != 0,
- * by a second kernel, one wave per member -- CRC-32 are verified.  d_raw must be readable for 8 bytes past its last member
- * (the decoder fetches whole aligned dwords).
+ * A WAVE per member (k_inflate_wave.hip: the block's body cut into 64 pieces decoded side by side from guessed bit offsets and
+ * stitched where neighbouring decoders fall into step, the symbols as a stream in scratch memory of the context, the copies
+ * resolved by pointer jumping over the member's output in LDS); the members that do not stitch -- a few in a thousand -- and,
+ * with GCI_INFLATE=lane in the environment, all of them by one LANE per member (k_inflate.hip: decode tables in LDS, the output
+ * buffer is the window).  Every member's length and -- check_crc != 0, by a further kernel, one wave per member -- CRC-32 are
+ * verified.  d_raw must be readable for 8 bytes past its last member (the decoders fetch whole aligned words).
  * *d_status: min over failing members of (member << 8 | -status), UINT64_MAX if none (decode with gci_decode_status).
+ * gci_bgzf_inflate_last_stats (synchronises): how the members of the context's LAST gci_bgzf_inflate_device call fared with the
+ * wave decoder -- h_counts[0] decoded, [1] header not taken, [2] no meeting point, [3] end-of-block codes on wrong paths,
+ * [4] undecodable / copies, [5] length, [6] lanes, [7] not tried (GCI_INFLATE=lane); [1 .. 6] went to the lane decoder.
  *
  * gci_bam_record_offsets_device: the byte offset of every record of an inflated BAM stream on the device, without the serial
  * block_size chain: candidate record starts by a strict format test on every byte position, successor lookup, reachability
@@ -505,6 +511,7 @@ int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, 
  * The call synchronises. */
 int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off,
                             uint32_t n_members, uint8_t* d_out, uint64_t out_cap, int check_crc, uint64_t* d_status);
+int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[8]);
 /* Members the device decodes at a time (a launch takes a whole number of such rounds: size runs of a large file accordingly); 0 = unknown. */
 uint32_t gci_bgzf_inflate_round(gci_ctx* ctx);
 int gci_bam_record_offsets_device(gci_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, uint64_t first_record, int32_t n_ref,
