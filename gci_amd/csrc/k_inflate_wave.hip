@@ -11,13 +11,13 @@
 //                 whole wave (ballots per code length; every lane its table entries);
 //     per chunk   64 pieces of the payload staged in LDS TRANSPOSED (8-byte unit u of piece k at [u][k]: whatever unit a lane
 //                 stands on, lane k reads bank pair k -- no conflicts although the lanes advance at their own pace);
-//       pass 1    lane k decodes from the start of piece k as if a symbol began there, counts symbols and output bytes and
-//                 notes the symbol starts it visits in the first WINDOW bits as a bitmap;
-//       stitch    lane k runs on into piece k + 1 until it stands on a position lane k + 1 noted: from there lane k + 1's
-//                 sequence is the true one.  Lane k + 1 re-reads its first symbols up to there to know what to leave out.
+//       pass 1    lane k decodes from the start of piece k as if a symbol began there and LISTS its symbols (32-bit entries: literal
+//                 byte, or length and distance) in scratch memory, entry i of lane k at [i][k]; behind every 64-bit boundary of its
+//                 piece it notes where it stood first and how many symbols it had listed by then (a checkpoint);
+//       stitch    lane k runs on into piece k + 1 until, behind a boundary, it stands where lane k + 1 stood: from there lane
+//                 k + 1's sequence is the true one, and its checkpoint says which of its listed symbols to leave out.
 //                 (Same position + same tables = same sequence: a stitched result is exact, not probable.)
-//       pass 2    prefix sums over the lanes give every lane its place; it decodes its true range again and writes one
-//                 32-bit entry per symbol -- literal byte, or (length, distance) -- to the member's SYMBOL STREAM in HBM.
+//       gather    prefix sums over the lanes give every lane's share of its list its place in the member's SYMBOL STREAM in HBM.
 //     A lane's piece does not stop at an end-of-block code (on a wrong path it is a false one); the first lane whose TRUE range
 //     holds one ends the block, the lanes behind it are void, the next block starts a new chunk behind it.
 //   k_inflate_copy (kernel B; one workgroup of 16 waves per member, the member's output as 65 536 16-bit cells in LDS):
@@ -33,13 +33,14 @@
 // A member that does not stitch (no meeting point within WINDOW bits, end-of-block codes on wrong paths, a header the quick
 // parser rejects) is marked in its status word and left to k_bgzf_inflate (0.2 % of the members of a HiFi BAM).
 #include "gci_ctx.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 
 #ifndef IW_PIECE_LOG2
-#define IW_PIECE_LOG2 10                 // bits per lane and chunk: 1024 (8 KB of payload per wave in LDS)
+#define IW_PIECE_LOG2 9                  // bits per lane and chunk: 512 (4 KB of payload per wave in LDS)
 #endif
-#ifndef IW_WINDOW
-#define IW_WINDOW 1024                   // bits of a piece whose symbol starts are noted (a lane that finds no meeting point there takes the piece over)
+#ifndef IW_GRAIN_LOG2
+#define IW_GRAIN_LOG2 6                  // a lane notes where it stands first behind every 64-bit boundary of its piece
 #endif
 #ifndef IW_LIT_BITS
 #define IW_LIT_BITS 9
@@ -52,14 +53,16 @@ namespace iw {
 
 constexpr uint32_t PIECE = 1u << IW_PIECE_LOG2;                 // bits
 constexpr uint32_t PU_LOG2 = IW_PIECE_LOG2 - 6, PU = 1u << PU_LOG2;   // 8-byte units per piece
-constexpr uint32_t CHUNK_U = 64u * PU, TAIL_U = 4;              // units per chunk; units kept behind it (a symbol that begins in the chunk ends there)
-constexpr uint32_t WINDOW = IW_WINDOW, NW = WINDOW / 32;
-static_assert(WINDOW <= PIECE, "a window is part of its piece");
+constexpr uint32_t CHUNK_U = 64u * PU, TAIL_U = PU;             // units per chunk; units kept behind it (a symbol that begins in the chunk ends there)
+constexpr uint32_t GRAIN_LOG2 = IW_GRAIN_LOG2, NCK = PIECE >> GRAIN_LOG2;   // checkpoints per piece (a symbol is shorter than a grain: no grain is skipped)
+static_assert((1u << GRAIN_LOG2) >= 48u, "a symbol with its extra bits must be shorter than a grain");
 constexpr int LIT_BITS = IW_LIT_BITS, DIST_BITS = IW_DIST_BITS;
 // codes longer than the primary table's index: their 15-bit values (first bit highest) lie at the top of the code space, from
-// limit[BITS] on -- a direct table over that range.  A HiFi BAM's blocks need ~300 / ~130 entries; beyond the table: the search.
-constexpr uint32_t LIT_TAIL = 1024, DIST_TAIL = 256;
+// limit[BITS] on -- a direct table over that range.  A HiFi BAM's blocks need ~300 / ~130 entries; in a block that needs more
+// than the tables hold (Codes::search_*, uniform) the lanes that stand on such a code search the limits.
+constexpr uint32_t LIT_TAIL = 512, DIST_TAIL = 256;
 constexpr uint32_t HDR_U = CHUNK_U < 128u ? CHUNK_U : 128u;    // units staged for a block's header (8192 bits; the longest header has 4498)
+constexpr uint32_t MAXS = PIECE < 512u ? 256u : PIECE / 2u;      // symbols a lane may list per chunk (its piece and what it runs on into)
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t SYM_STRIDE = 65536;                          // entries of symbol stream per member (one per output byte at most)
 
@@ -72,7 +75,7 @@ struct alignas(16) Canon { uint16_t limit[16]; int16_t off[16]; uint16_t next[16
 
 struct alignas(16) Lds {
     unsigned long long pay[CHUNK_U + TAIL_U];      // the chunk, transposed: unit u of piece k at [(u << 6) | k]; the tail linear behind it
-    uint32_t note[64 * NW];                        // word w of lane k's bitmap at [(w << 6) | k]
+    uint32_t ckpt[64 * NCK];                       // lane k, grain c at [(c << 6) | k]: (where it stood first in the grain) << 16 | symbols listed by then
     uint16_t lit_tab[1 << LIT_BITS];               // symbol | length << 9; 0 = a longer code
     uint16_t lit_tail[LIT_TAIL];                   // ... of the 15-bit code value c: [c - limit[LIT_BITS]]; 0 = no such code
     uint16_t dist_tab[1 << DIST_BITS];
@@ -85,7 +88,7 @@ struct alignas(16) Lds {
     uint32_t hdr[8];
 };
 
-__device__ __forceinline__ uint32_t pay_index(uint32_t U) { return U < CHUNK_U ? ((U & (PU - 1u)) << 6) | (U >> PU_LOG2) : (U < CHUNK_U + TAIL_U ? U : CHUNK_U + TAIL_U - 1u); }
+__device__ __forceinline__ uint32_t pay_index(uint32_t U) { return U < CHUNK_U ? ((U & (PU - 1u)) << 6) | (U >> PU_LOG2) : U; }
 
 // 64 bits from bit p of the chunk
 __device__ __forceinline__ unsigned long long peek(const Lds& S, uint32_t p)
@@ -96,7 +99,7 @@ __device__ __forceinline__ unsigned long long peek(const Lds& S, uint32_t p)
 }
 
 // A lane's place in the chunk: the unit it stands in and the two behind it in registers -- the bits of a symbol come out of
-// them without a look into LDS, and the unit fetched when the lane moves on is needed a whole unit later.
+// them without a look into LDS; the unit after those is fetched at the top of every step and taken up when the lane moves on.
 struct Reader {
     uint32_t p, U;
     unsigned long long cur, nxt, nx2;
@@ -110,10 +113,13 @@ struct Reader {
         const uint32_t s = p & 63u;
         return s ? (cur >> s) | (nxt << (64u - s)) : cur;
     }
-    __device__ __forceinline__ void advance(const Lds& S, uint32_t used)      // used < 64
+    __device__ __forceinline__ unsigned long long ahead(const Lds& S) const { return S.pay[pay_index(U + 3u)]; }
+    __device__ __forceinline__ void advance(uint32_t used, unsigned long long n3)      // used < 64; n3 = ahead()
     {
         p += used;
-        if ((p >> 6) != U) { U++; cur = nxt; nxt = nx2; nx2 = S.pay[pay_index(U + 2u)]; }
+        const bool cross = (p >> 6) != U;
+        cur = cross ? nxt : cur; nxt = cross ? nx2 : nxt; nx2 = cross ? n3 : nx2;
+        U += cross ? 1u : 0u;
     }
 };
 
@@ -133,17 +139,19 @@ __device__ __forceinline__ int code_search(uint32_t bits, const Canon& cn, const
 }
 
 // what the wave keeps in registers of a block's two codes (uniform)
-struct Codes { uint32_t lit_lim, dist_lim; };
+struct Codes { uint32_t lit_lim, dist_lim; bool search_l, search_d; };
 
-// entry (symbol | length << 9, 0 = none) of the code the bits begin with: primary table, tail table, search
+// entry (symbol | length << 9, 0 = none) of the code the bits begin with: the primary table and the tail table, both looked up at
+// once -- no branch, one wait
 template <int BITS, uint32_t TAIL>
-__device__ __forceinline__ uint32_t code_entry(uint32_t b, const uint16_t* tab, const uint16_t* tail, uint32_t lim, const Canon& cn, const uint16_t* sorted)
+__device__ __forceinline__ uint32_t code_entry(uint32_t b, const uint16_t* tab, const uint16_t* tail, uint32_t lim, bool search, const Canon& cn,
+                                               const uint16_t* sorted)
 {
-    uint32_t e = tab[b & ((1u << BITS) - 1u)];
-    if (e == 0u) {
-        const uint32_t t = (__brev(b) >> 17) - lim;                           // (lim <= the code value of anything the primary table does not hold)
-        if (t < TAIL) e = tail[t];
-        else {
+    const uint32_t t = (__brev(b) >> 17) - lim;                               // (wraps to a huge value for a code in front of the tail)
+    const uint32_t e_p = tab[b & ((1u << BITS) - 1u)], e_t = tail[t < TAIL ? t : TAIL - 1u];
+    uint32_t e = e_p ? e_p : t < TAIL ? e_t : 0u;
+    if (search) {                                                             // (uniform, and false for the blocks of a BAM)
+        if (e_p == 0u && t >= TAIL && t < 0x8000u) {
             int l = 0;
             const int s = code_search(b, cn, sorted, l);
             e = s < 0 ? 0u : (uint32_t)s | ((uint32_t)l << 9);
@@ -152,33 +160,33 @@ __device__ __forceinline__ uint32_t code_entry(uint32_t b, const uint16_t* tab, 
     return e;
 }
 
-// kind: 0 literal (a = byte), 1 match (a = length, b = distance), 2 end of block, 3 nothing decodable (used = 1: a wrong path moves on)
-struct Sym { uint32_t kind, a, b, used; };
+// kind: 0 literal, 1 match (entry = what the symbol stream holds for them), 2 end of block, 3 nothing decodable (used = 1: a wrong path moves on)
+struct Sym { uint32_t kind, used, entry; };
 
 // the literal / length symbol the reader stands on with everything that belongs to it (48 bits at most); nb = end of the stream
 __device__ __forceinline__ Sym step(const Lds& S, const Codes& C, const Reader& R, uint32_t nb)
 {
     const unsigned long long bits = R.bits();
     const uint32_t b = (uint32_t)bits;
-    const uint32_t e = code_entry<LIT_BITS, LIT_TAIL>(b, S.lit_tab, S.lit_tail, C.lit_lim, S.lit_cn, S.lit_sorted);
+    const uint32_t e = code_entry<LIT_BITS, LIT_TAIL>(b, S.lit_tab, S.lit_tail, C.lit_lim, C.search_l, S.lit_cn, S.lit_sorted);
     const uint32_t l = e >> 9, s = e & 0x1FFu;
     // the length code's base and extra bits by arithmetic (RFC 1951 3.2.5); for a literal the values are not used
     const uint32_t lc = s - 257u;
     const uint32_t le = lc < 8u || lc >= 28u ? 0u : (lc >> 2) - 1u;
-    const uint32_t len = (lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << le)) + ((b >> l) & ((1u << le) - 1u));
+    const uint32_t len3 = (lc < 8u ? lc : lc == 28u ? 255u : ((4u + (lc & 3u)) << le)) + ((b >> l) & ((1u << le) - 1u));
     const uint32_t used1 = l + le;
     const uint32_t b2 = (uint32_t)(bits >> used1);
-    const uint32_t e2 = code_entry<DIST_BITS, DIST_TAIL>(b2, S.dist_tab, S.dist_tail, C.dist_lim, S.dist_cn, S.dist_sorted);
+    const uint32_t e2 = code_entry<DIST_BITS, DIST_TAIL>(b2, S.dist_tab, S.dist_tail, C.dist_lim, C.search_d, S.dist_cn, S.dist_sorted);
     const uint32_t dl = e2 >> 9, ds = e2 & 0x1FFu;
-    const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
-    const uint32_t dist = (ds < 4u ? ds + 1u : 1u + ((2u + (ds & 1u)) << de)) + ((b2 >> dl) & ((1u << de) - 1u));
-    Sym r;
+    const uint32_t de = ds < 4u ? 0u : ((ds >> 1) - 1u) & 15u;
+    const uint32_t dist1 = (ds < 4u ? ds : ((2u + (ds & 1u)) << de)) + ((b2 >> dl) & ((1u << de) - 1u));
     const bool is_match = s > 256u;
-    r.used = is_match ? used1 + dl + de : l;
-    r.kind = is_match ? 1u : s == 256u ? 2u : 0u;
-    r.a = is_match ? len : s;
-    r.b = dist;
-    if (e == 0u || s > 285u || (is_match && (e2 == 0u || ds > 29u)) || R.p + r.used > nb) { r.kind = 3u; r.used = 1u; }
+    const uint32_t used = is_match ? used1 + dl + de : l;
+    const bool bad = e == 0u || s > 285u || (is_match && (e2 == 0u || ds > 29u)) || R.p + used > nb;
+    Sym r;
+    r.used = bad ? 1u : used;
+    r.kind = bad ? 3u : is_match ? 1u : s == 256u ? 2u : 0u;
+    r.entry = is_match ? (len3 << 15) | dist1 : 0x80000000u | s;
     return r;
 }
 
@@ -273,12 +281,13 @@ __device__ __forceinline__ uint16_t table_entry(uint32_t k, int bits, const Cano
 }
 
 // the primary and the tail table of one code, every lane its entries
-__device__ __forceinline__ void fill_tables(uint16_t* tab, int bits, uint16_t* tail, uint32_t n_tail, const Canon& cn, const uint16_t* sorted, int lane)
+__device__ __forceinline__ bool fill_tables(uint16_t* tab, int bits, uint16_t* tail, uint32_t n_tail, const Canon& cn, const uint16_t* sorted, int lane)
 {
     for (uint32_t k = lane; k < (1u << bits); k += 64) tab[k] = table_entry(k, bits, cn, sorted);
-    const uint32_t lim = cn.limit[bits];
-    const uint32_t n = 32768u - lim < n_tail ? 32768u - lim : n_tail;
-    for (uint32_t t = lane; t < n; t += 64) tail[t] = entry_of_value(lim + t, cn, sorted);
+    const uint32_t lim = cn.limit[bits], top = cn.limit[15];                   // codes exist below `top` only
+    const uint32_t want = top > lim ? top - lim : 0u;
+    for (uint32_t t = lane; t < n_tail; t += 64) tail[t] = t < want ? entry_of_value(lim + t, cn, sorted) : (uint16_t)0;
+    return want <= n_tail;                                                     // false: codes the tables do not hold
 }
 
 // lane 0: the code lengths of a dynamic block behind its 14 + 3 hclen bits, through the 7-bit table of the code-length code
@@ -334,23 +343,34 @@ __device__ __forceinline__ void stage(Lds& S, const unsigned long long* __restri
 using namespace iw;
 
 // ---- kernel A ------------------------------------------------------------------------------------------------------------
-// members [m0, m0 + n_batch) of the run; sym: n_batch x SYM_STRIDE entries; n_sym, wstatus: one word per member of the RUN
+// members [m0, m0 + n_batch) of the run; sym: n_batch x SYM_STRIDE entries; n_sym, wstatus: one word per member of the RUN;
+// lists: per workgroup 64 x MAXS entries, entry i of lane k at [i * 64 + k] (a step's stores are one 256-byte row)
 // entry: bit 31 set = literal (low 8 bits); else (length - 3) << 15 | (distance - 1)
-extern "C" __global__ __launch_bounds__(64) void k_inflate_symbols(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
+extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
                                                                    const uint64_t* __restrict__ out_off, uint64_t out_cap, uint32_t m0, uint32_t n_batch,
                                                                    uint32_t* __restrict__ sym, uint32_t* __restrict__ n_sym,
-                                                                   uint32_t* __restrict__ wstatus, uint32_t cut)
+                                                                   uint32_t* __restrict__ wstatus, uint32_t* __restrict__ lists, uint32_t* __restrict__ next,
+                                                                   uint32_t cut, unsigned long long* __restrict__ prof)
 {
-    // (cut: measurements only -- 1 leaves a block behind its tables, 2 behind pass 1, 3 behind the stitch and the recount; 0 = the kernel)
+    // (prof: measurements only -- cycles per phase, summed over the waves: GCI_IW_PROF=1, tools/hwtests/inflate_product.py)
+    unsigned long long t_hdr = 0, t_stage = 0, t_p1 = 0, t_st = 0, t_ch = 0, t_ga = 0, n_chunks = 0, t_all0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define IW_T(acc, t0) do { if (prof) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); acc += _n - t0; t0 = _n; } } while (0)
+    // (cut: measurements only -- 1 leaves a block behind its tables, 2 behind pass 1, 3 behind the stitch; 0 = the kernel)
     __shared__ Lds S;
     const int lane = threadIdx.x;
-    for (uint32_t mb = blockIdx.x; mb < n_batch; mb += gridDim.x) {
+    uint32_t* const list = lists + (size_t)blockIdx.x * (64u * MAXS) + (uint32_t)lane;     // entry i at list[64 i]
+    // the members of the batch are handed out one at a time (`next`: a counter the host zeroes): a member takes as long as it takes
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) S.hdr[7] = atomicAdd(next, 1u);
+        __syncthreads();
+        const uint32_t mb = S.hdr[7];
+        if (mb >= n_batch) break;
         const uint32_t m = m0 + mb;
         const uint64_t pos0 = member_pos[m], pos1 = member_pos[m + 1];
         const uint32_t isize = (uint32_t)(out_off[m + 1] - out_off[m]);
         uint32_t* const msym = sym + (size_t)mb * SYM_STRIDE;
         uint32_t st = ST_OK;
-        __syncthreads();
         if (pos1 < pos0 + 26 || isize > 65536u || out_off[m + 1] > out_cap || raw[pos0] != 0x1f || raw[pos0 + 1] != 0x8b || raw[pos0 + 2] != 8) {
             if (lane == 0) { wstatus[m] = ST_HEADER; n_sym[m] = 0; }
             continue;
@@ -362,9 +382,10 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_symbols(const uint8_t
         const uint32_t bias = 8u * (uint32_t)(a0 & 7u);
         const uint32_t nbits = bias + 8u * (uint32_t)(pos1 - 8 - (pos0 + 12 + xlen));          // end of the DEFLATE stream (bits from g8)
         const uint32_t U_end = (nbits + 63u) >> 6;
-        uint32_t tpos = bias, out_pos = 0, ns = 0;                          // (uniform over the wave)
+        uint32_t tpos = bias, ns = 0;                                       // (uniform over the wave)
         for (bool last = false; !last && st == ST_OK;) {
             // ---- the block's header: 3 + 14 + 57 bits and the code lengths -- 128 units hold any header this kernel takes -----------
+            unsigned long long tt = prof ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t cbU = tpos >> 6;
             __syncthreads();
             stage(S, g8, cbU, U_end, HDR_U, lane);
@@ -412,15 +433,15 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_symbols(const uint8_t
                 }
                 body0 = p + 64u * cbU;
             }
-            if (type == 3u) { st = ST_HEADER; break; }
+            if (type == 3u) { st = 15u; break; }
             if (type == 0u) {                                             // stored: its bytes as literals
                 const uint8_t* const gb = (const uint8_t*)g8;
                 const uint32_t byte = (body0 + 7u) >> 3;
                 if (8u * (byte + 4u) > nbits) { st = ST_HEADER; break; }
                 const uint32_t len = (uint32_t)gb[byte] | ((uint32_t)gb[byte + 1] << 8), nlen = (uint32_t)gb[byte + 2] | ((uint32_t)gb[byte + 3] << 8);
-                if ((len ^ 0xFFFFu) != nlen || out_pos + len > isize || 8u * (byte + 4u + len) > nbits) { st = ST_HEADER; break; }
+                if ((len ^ 0xFFFFu) != nlen || ns + len > isize || 8u * (byte + 4u + len) > nbits) { st = ST_HEADER; break; }
                 for (uint32_t i = lane; i < len; i += 64) msym[ns + i] = 0x80000000u | (uint32_t)gb[byte + 4u + i];
-                out_pos += len; ns += len;
+                ns += len;
                 tpos = 8u * (byte + 4u + len);
                 continue;
             }
@@ -429,185 +450,206 @@ extern "C" __global__ __launch_bounds__(64) void k_inflate_symbols(const uint8_t
                 __syncthreads();
                 const bool ok_l = build_code_wave(S.lens + 32, hlit, S.lit_cn, S.lit_sorted, lane, &S.hdr[4]);
                 const bool ok_d = build_code_wave(S.lens + 32 + hlit, hdist, S.dist_cn, S.dist_sorted, lane, &S.hdr[4]);
-                if (!ok_l || !ok_d) { st = ST_HEADER; break; }
-                fill_tables(S.lit_tab, LIT_BITS, S.lit_tail, LIT_TAIL, S.lit_cn, S.lit_sorted, lane);
-                fill_tables(S.dist_tab, DIST_BITS, S.dist_tail, DIST_TAIL, S.dist_cn, S.dist_sorted, lane);
+                if (!ok_l || !ok_d) { st = 12u; break; }
+                const bool fits_l = fill_tables(S.lit_tab, LIT_BITS, S.lit_tail, LIT_TAIL, S.lit_cn, S.lit_sorted, lane);
+                const bool fits_d = fill_tables(S.dist_tab, DIST_BITS, S.dist_tail, DIST_TAIL, S.dist_cn, S.dist_sorted, lane);
+                C.search_l = !fits_l; C.search_d = !fits_d;               // (long codes beyond the tail tables: searched)
                 C.lit_lim = S.lit_cn.limit[LIT_BITS]; C.dist_lim = S.dist_cn.limit[DIST_BITS];
             }
             if (cut == 1u) { st = ST_LANES; break; }
+            IW_T(t_hdr, tt);
             // ---- the block's body, chunk by chunk ----------------------------------------------------------------------------
             uint32_t cpos = body0;                                        // a symbol begins here
             for (bool block_done = false; !block_done && st == ST_OK;) {
                 cbU = cpos >> 6;
                 __syncthreads();
                 stage(S, g8, cbU, U_end, CHUNK_U + TAIL_U, lane);
-                for (uint32_t i = lane; i < 64u * NW; i += 64) S.note[i] = 0u;
+                for (uint32_t i = lane; i < 64u * NCK; i += 64) S.ckpt[i] = NONE;
                 __syncthreads();
                 const uint32_t nb = nbits - 64u * cbU;                    // end of the stream, in bits of the chunk
-                // ---- pass 1: every lane over its own piece -----------------------------------------------------------------
+                if (cut == 4u) { st = ST_LANES; break; }
+                IW_T(t_stage, tt); n_chunks++;
+                // ---- pass 1: every lane over its own piece, its symbols into its list -------------------------------------------
                 const uint32_t start = lane == 0 ? cpos - 64u * cbU : (uint32_t)lane * PIECE;
                 const uint32_t bound = ((uint32_t)lane + 1u) * PIECE;
                 const bool active = start < nb;
-                uint32_t ob = 0, os = 0;
-                // end-of-block codes the lane passes: on a wrong path they are false ones (a fixed code has one in 128 symbols), so a
-                // lane does not stop at them.  Those in the window (where the lane's true path may begin) as a list of positions, the
-                // first one behind the window -- on the true path if the lane is on it at all -- with the counts in front of it.
-                uint32_t ew0 = NONE, ew1 = NONE, ew2 = NONE, ew3 = NONE, n_ew = 0;
-                uint32_t eob_at = NONE, eob_end = 0, eob_ob = 0, eob_os = 0;
+                uint32_t os = 0;                                          // entries in the list
+                // End-of-block codes the lane passes: on a wrong path they mean nothing (a fixed code has one in 128 symbols), so the lane
+                // goes on; the first four with the symbols listed in front of them (position << 16 | count).
+                uint32_t eb0 = NONE, eb1 = NONE, eb2 = NONE, eb3 = NONE, n_eb = 0;
                 Reader R;
                 R.seek(S, active ? start : 0u);
                 if (active) {
                     const uint32_t pend = bound < nb ? bound : nb;
+                    uint32_t grain = NONE;                                // the grain the lane stood in last
                     while (R.p < pend) {
-                        const uint32_t rel = R.p - (uint32_t)lane * PIECE;
-                        if (rel < WINDOW) atomicOr(&S.note[((rel >> 5) << 6) | (uint32_t)lane], 1u << (rel & 31u));
+                        const unsigned long long n3 = R.ahead(S);
+                        const uint32_t rel = R.p - (uint32_t)lane * PIECE, g = rel >> GRAIN_LOG2;
+                        if (g != grain) { S.ckpt[(g << 6) | (uint32_t)lane] = (rel << 16) | os; grain = g; }
                         const Sym s = step(S, C, R, nb);
-                        if (s.kind == 2u) {
-                            if (rel < WINDOW) {
-                                if (n_ew == 0u) ew0 = R.p; else if (n_ew == 1u) ew1 = R.p; else if (n_ew == 2u) ew2 = R.p; else if (n_ew == 3u) ew3 = R.p;
-                                n_ew++;
-                            } else if (eob_at == NONE) { eob_at = R.p; eob_end = R.p + s.used; eob_ob = ob; eob_os = os; }
+                        if (__ballot(s.kind == 2u)) {                      // (rare: the whole wave skips this)
+                            if (s.kind == 2u) {
+                                const uint32_t v = (rel << 16) | os;
+                                if (n_eb == 0u) eb0 = v; else if (n_eb == 1u) eb1 = v; else if (n_eb == 2u) eb2 = v; else if (n_eb == 3u) eb3 = v;
+                                n_eb++;
+                            }
                         }
-                        R.advance(S, s.used);
-                        ob += s.kind == 0u ? 1u : s.kind == 1u ? s.a : 0u;
-                        os += s.kind < 2u ? 1u : 0u;
+                        if (s.kind < 2u) {
+                            if (os < MAXS && cut != 6u) list[64u * os] = s.entry;      // (a share that reaches beyond the list is caught below)
+                            os++;
+                        }
+                        R.advance(s.used, n3);
                     }
                 }
                 __syncthreads();
-                if (cut == 2u) { st = __ballot(ob == NONE) ? ST_LANES : ST_LENGTH; break; }
-                // ---- stitch: on behind the piece until a position the lane of THAT piece noted ---------------------------------
-                // (normally within a few symbols in the neighbour's window; a lane that finds none there takes the neighbour's piece
-                // over -- decodes it to its end -- and looks in the window of the piece after it: the neighbour is void then)
-                uint32_t meet = NONE, meet_lane = 64u, xb = 0, xs = 0, x_eob_at = 0, x_eob_end = 0, x_end = 0;
+                IW_T(t_p1, tt);
+                if (cut == 2u || cut == 6u) { st = __ballot(os == NONE) ? ST_LANES : ST_LENGTH; break; }
+                // ---- stitch: on behind the piece until, first behind a boundary, the lane stands where the lane of THAT piece stood ------
+                // (normally within a few symbols; a lane that never falls into step with its neighbour inside the neighbour's piece
+                // has decoded that piece itself by then -- the neighbour is void -- and goes on into the piece after it)
+                uint32_t meet = NONE, meet_lane = 64u, meet_cnt = 0, xs = 0, x_eob_end = 0, x_end = 0;
                 bool x_eob = false, x_fail = false;
                 if (active) {
+                    uint32_t grain = NONE;
                     for (;;) {
                         const uint32_t q = R.p;
                         if (q >= 64u * PIECE) { x_end = q; break; }                        // the end of the chunk: the block goes on behind it
                         if (q >= nb) { x_fail = true; break; }                              // the stream ends without an end-of-block code
-                        const uint32_t j = q >> IW_PIECE_LOG2, rel = q & (PIECE - 1u);
-                        if (rel < WINDOW && ((S.note[((rel >> 5) << 6) | j] >> (rel & 31u)) & 1u)) { meet = q; meet_lane = j; break; }
+                        const uint32_t g = q >> GRAIN_LOG2;                                 // (grains of the chunk: piece j's are j NCK ...)
+                        if (g != grain) {
+                            grain = g;
+                            const uint32_t j = q >> IW_PIECE_LOG2, rel = q & (PIECE - 1u);
+                            const uint32_t c = S.ckpt[((rel >> GRAIN_LOG2) << 6) | j];
+                            if (c != NONE && (c >> 16) == rel) { meet = q; meet_lane = j; meet_cnt = c & 0xFFFFu; break; }
+                        }
+                        const unsigned long long n3 = R.ahead(S);
                         const Sym s = step(S, C, R, nb);
                         if (s.kind == 3u) { x_fail = true; break; }
-                        if (s.kind == 2u) { x_eob = true; x_eob_at = q; x_eob_end = q + s.used; break; }
-                        R.advance(S, s.used);
-                        xs += 1u;
-                        xb += s.kind == 0u ? 1u : s.a;
+                        if (s.kind == 2u) { x_eob = true; x_eob_end = q + s.used; break; }
+                        if (os + xs < MAXS) list[64u * (os + xs)] = s.entry;
+                        xs++;
+                        R.advance(s.used, n3);
                     }
                 }
-                // ---- the chain of lanes on the true path: lane 0, the lane it met, ... (uniform; a step per live lane) ------------
-                uint32_t from = NONE;
+                IW_T(t_st, tt);
+                // ---- the lanes on the true path: lane 0, the lane it met, the lane THAT one met, ... up to the first one that ends the block
+                // or runs out of the chunk.  Nearly always every lane met its neighbour: then each lane's beginning is what the lane in
+                // front of it found, and all of it is decided side by side; a lane that took a piece over (or has more end-of-block codes
+                // than it lists) sends the wave down the chain one lane at a time.
+                uint32_t ss = 0, cs = 0;                                                     // the lane's share of its list: [ss, ss + cs)
                 bool live = false, own_eob = false, block_ends = false, chain_bad = false;
-                uint32_t own_at = NONE;                                                      // the lane's own end-of-block code, if it ends the block
+                uint32_t own_end = 0;                                                        // behind the lane's own end-of-block code, if it ends the block
                 int E = 0;
+                const uint32_t base = (uint32_t)lane * PIECE;
+                // the lane's first end-of-block code at or behind a position of its piece (both relative to the piece); NONE - 1: look again
+                auto own_code = [&](uint32_t from_rel) -> uint32_t {
+                    uint32_t own = NONE;
+                    if (eb3 != NONE && (eb3 >> 16) >= from_rel) own = eb3;
+                    if (eb2 != NONE && (eb2 >> 16) >= from_rel) own = eb2;
+                    if (eb1 != NONE && (eb1 >> 16) >= from_rel) own = eb1;
+                    if (eb0 != NONE && (eb0 >> 16) >= from_rel) own = eb0;
+                    return own == NONE && n_eb > 4u ? NONE - 1u : own;
+                };
+                bool fast = false;
                 {
-                    uint32_t cur = 0, from_cur = cpos - 64u * cbU;
+                    // (the shuffles by every lane: a lane switched off for them would hand its neighbour a zero)
+                    const uint32_t up_meet = (uint32_t)__shfl_up((int)meet, 1, 64), up_cnt = (uint32_t)__shfl_up((int)meet_cnt, 1, 64);
+                    const uint32_t from_f = lane == 0 ? cpos - 64u * cbU : up_meet;
+                    const uint32_t ss_f = lane == 0 ? 0u : up_cnt;
+                    // (for a lane whose neighbour in front found nothing these are NONE / garbage: such a lane lies behind E or the fast way is left)
+                    const uint32_t own = active && from_f != NONE && from_f >= base ? own_code(from_f - base) : NONE;
+                    const bool ends = own != NONE || x_eob || (active && !x_eob && !x_fail && meet_lane >= 64u) || !active;   // ... the chain, one way or the other
+                    const unsigned long long ends_mask = __ballot(ends);
+                    const int e = ends_mask ? __ffsll((long long)ends_mask) - 1 : 63;
+                    const unsigned long long upto = e >= 63 ? ~0ull : ((1ull << (e + 1)) - 1ull), below = upto >> 1;
+                    const bool odd = (lane < e && (meet_lane != (uint32_t)lane + 1u || x_fail)) || (lane <= e && (!active || own == NONE - 1u));
+                    if (cut != 7u && ends_mask && (__ballot(odd) & upto) == 0ull && !(bool)__shfl((int)(x_fail && own == NONE), e, 64)) {
+                        fast = true; E = e; (void)below;
+                        live = lane <= e; ss = ss_f;
+                        if (live) {
+                            if (lane == e && own != NONE) {
+                                own_eob = true; cs = (own & 0xFFFFu) - ss;
+                                R.seek(S, base + (own >> 16));
+                                const Sym y = step(S, C, R, nb);
+                                own_end = base + (own >> 16) + y.used;
+                            } else cs = os + xs - ss;
+                        }
+                        block_ends = (bool)__shfl((int)(own != NONE || x_eob), e, 64);
+                    }
+                }
+                if (!fast) {
+                    uint32_t cur = 0, from_cur = cpos - 64u * cbU, ss_cur = 0;
                     for (;;) {
                         if ((uint32_t)lane == cur) {
-                            live = true; from = from_cur;
-                            // its first end-of-block code at or behind `from`
-                            uint32_t c = NONE;
-                            if (ew0 != NONE && ew0 >= from) c = ew0; else if (ew1 != NONE && ew1 >= from) c = ew1;
-                            else if (ew2 != NONE && ew2 >= from) c = ew2; else if (ew3 != NONE && ew3 >= from) c = ew3;
-                            else if (n_ew > 4u) c = NONE - 1u;                               // (more of them than the list holds: not ours)
-                            else c = eob_at;
-                            own_at = c;
+                            live = true; ss = ss_cur;
+                            uint32_t own = own_code(from_cur - base);
+                            if (own == NONE - 1u) {
+                                // more of them than the list holds and none of the listed ones behind `from`: the lane's piece once
+                                // more from there, alone (one lane in thousands of chunks)
+                                own = NONE;
+                                R.seek(S, from_cur);
+                                const uint32_t pend = bound < nb ? bound : nb;
+                                uint32_t cnt = ss_cur;
+                                while (R.p < pend) {
+                                    const unsigned long long n3 = R.ahead(S);
+                                    const Sym y = step(S, C, R, nb);
+                                    if (y.kind == 2u) { own = ((R.p - base) << 16) | cnt; break; }
+                                    cnt += y.kind < 2u ? 1u : 0u;
+                                    R.advance(y.used, n3);
+                                }
+                            }
+                            if (own != NONE) {
+                                own_eob = true; cs = (own & 0xFFFFu) - ss;
+                                R.seek(S, base + (own >> 16));
+                                const Sym y = step(S, C, R, nb);
+                                own_end = base + (own >> 16) + y.used;
+                            } else cs = os + xs - ss;
                         }
-                        const uint32_t c_u = (uint32_t)__shfl((int)own_at, (int)cur, 64);
-                        if (c_u == NONE - 1u || !(bool)__shfl((int)active, (int)cur, 64)) { chain_bad = true; break; }
-                        if (c_u != NONE) { E = (int)cur; block_ends = true; if ((uint32_t)lane == cur) own_eob = true; break; }
-                        if ((bool)__shfl((int)x_fail, (int)cur, 64)) { chain_bad = true; break; }
+                        if (!(bool)__shfl((int)active, (int)cur, 64)) { chain_bad = true; st = 10u; break; }
+                        if ((bool)__shfl((int)own_eob, (int)cur, 64)) { E = (int)cur; block_ends = true; break; }
+                        if ((bool)__shfl((int)x_fail, (int)cur, 64)) { chain_bad = true; st = 11u; break; }
                         if ((bool)__shfl((int)x_eob, (int)cur, 64)) { E = (int)cur; block_ends = true; break; }
                         const uint32_t nl = (uint32_t)__shfl((int)meet_lane, (int)cur, 64);
                         if (nl >= 64u) { E = (int)cur; break; }                              // ran to the end of the chunk
                         from_cur = (uint32_t)__shfl((int)meet, (int)cur, 64);
+                        ss_cur = (uint32_t)__shfl((int)meet_cnt, (int)cur, 64);
                         cur = nl;
                     }
                 }
-                if (chain_bad) { st = ST_NO_MEETING; break; }
-                // what a live lane decoded in front of `from` does not count: the same symbols again, counted; a lane that ends the block
-                // inside its window counts on to its end-of-block code
-                uint32_t sb = 0, ss = 0, tb = 0, ts = 0;
-                bool undec = false;
-                const bool eob_in_window = own_eob && own_at != eob_at;
-                if (live && (lane >= 1 || eob_in_window)) {
-                    R.seek(S, start);
-                    while (R.p < from) {
-                        const Sym s = step(S, C, R, nb);
-                        R.advance(S, s.used);
-                        sb += s.kind == 0u ? 1u : s.kind == 1u ? s.a : 0u;
-                        ss += s.kind < 2u ? 1u : 0u;
-                    }
-                    if (R.p != from) undec = true;
-                    if (eob_in_window) {
-                        while (R.p < own_at) {
-                            const Sym s = step(S, C, R, nb);
-                            R.advance(S, s.used);
-                            if (s.kind >= 2u) undec = true;
-                            tb += s.kind == 0u ? 1u : s.a;
-                            ts += 1u;
-                        }
-                        if (R.p != own_at) undec = true;
-                        const Sym s = step(S, C, R, nb);
-                        if (s.kind != 2u) undec = true;
-                        eob_end = R.p + s.used;
-                    }
-                }
-                if (__ballot(undec)) { st = ST_UNDECODABLE; break; }
-                if (cut == 3u) { st = __ballot(sb == NONE) ? ST_LANES : ST_LENGTH; break; }
-                // ---- every live lane's share and its place -------------------------------------------------------------------------
-                uint32_t cb = 0, cs = 0, stop = 0;
+                if (chain_bad) break;
+                if (cut == 3u) { st = __ballot(ss == NONE - 3u) ? ST_LANES : ST_LENGTH; break; }
+                if (__ballot(live && (ss + cs > MAXS || ss + cs < ss))) { st = 9u; break; }   // (a share the list did not hold)
+                IW_T(t_ch, tt);
+                uint32_t tot_s = 0;
+                const uint32_t off_s = wave_excl_sum(cs, lane, tot_s);
+                if (ns + tot_s > isize) { st = ST_LENGTH; break; }                            // (a symbol is at least a byte)
+                // ---- the shares into the member's symbol stream, four entries per store ------------------------------------------------
                 if (live) {
-                    if (own_eob) {
-                        if (eob_in_window) { cb = tb; cs = ts; } else { cb = eob_ob - sb; cs = eob_os - ss; }
-                        stop = own_at;
-                    } else {
-                        cb = ob - sb + xb; cs = os - ss + xs;
-                        stop = x_eob ? x_eob_at : meet != NONE ? meet : x_end;
-                    }
-                }
-                uint32_t tot_b = 0, tot_s = 0;
-                const uint32_t off_b = wave_excl_sum(cb, lane, tot_b), off_s = wave_excl_sum(cs, lane, tot_s);
-                if (out_pos + tot_b > isize) { st = ST_LENGTH; break; }
-                // ---- pass 2: the true range again, one entry per symbol; four entries leave as one 16-byte store ------------------------
-                bool w_bad = false;
-                if (live) {
-                    R.seek(S, from);
-                    uint32_t o = out_pos + off_b, i = 0;
                     uint32_t* const w = msym + ns + off_s;
-                    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                    while (i < cs) {
-                        const Sym s = step(S, C, R, nb);
-                        if (s.kind >= 2u) { w_bad = true; break; }
-                        R.advance(S, s.used);
-                        if (s.kind == 1u && s.b > o) { w_bad = true; break; }
-                        const uint32_t e = s.kind == 0u ? 0x80000000u | s.a : ((s.a - 3u) << 15) | (s.b - 1u);
-                        o += s.kind == 0u ? 1u : s.a;
-                        const uint32_t k = i & 3u;                          // (i is the same in every lane that is still at work)
-                        if (k == 0u) e0 = e; else if (k == 1u) e1 = e; else if (k == 2u) e2 = e; else e3 = e;
-                        i++;
-                        if (k == 3u) { const uint4 v = make_uint4(e0, e1, e2, e3); __builtin_memcpy(w + i - 4u, &v, 16); }
+                    const uint32_t* const r = list + 64u * ss;
+                    uint32_t i = 0;
+                    for (; i + 4u <= cs; i += 4u) {
+                        const uint4 v = make_uint4(r[64u * i], r[64u * (i + 1u)], r[64u * (i + 2u)], r[64u * (i + 3u)]);
+                        __builtin_memcpy(w + i, &v, 16);
                     }
-                    if (!w_bad) {
-                        const uint32_t k = i & 3u, at = i - k;
-                        if (k > 0u) w[at] = e0;
-                        if (k > 1u) w[at + 1u] = e1;
-                        if (k > 2u) w[at + 2u] = e2;
-                    }
-                    if (R.p != stop || o != out_pos + off_b + cb) w_bad = true;
+                    for (; i < cs; i++) w[i] = r[64u * i];
                 }
-                if (__ballot(w_bad)) { st = ST_UNDECODABLE; break; }
-                out_pos += tot_b; ns += tot_s;
+                ns += tot_s;
+                IW_T(t_ga, tt);
                 if (block_ends) {
-                    tpos = 64u * cbU + (uint32_t)__shfl((int)(own_eob ? eob_end : x_eob_end), E, 64);
+                    tpos = 64u * cbU + (uint32_t)__shfl((int)(own_eob ? own_end : x_eob_end), E, 64);
                     block_done = true;
                 } else cpos = 64u * cbU + (uint32_t)__shfl((int)x_end, E, 64);
             }
         }
-        if (st == ST_OK && out_pos != isize) st = ST_LENGTH;
         if (st == ST_OK && tpos > nbits) st = ST_LENGTH;
         if (lane == 0) { wstatus[m] = st; n_sym[m] = st == ST_OK ? ns : 0u; }
     }
+    if (prof && lane == 0) {
+        atomicAdd(&prof[0], t_hdr); atomicAdd(&prof[1], t_stage); atomicAdd(&prof[2], t_p1); atomicAdd(&prof[3], t_st); atomicAdd(&prof[4], t_ch);
+        atomicAdd(&prof[5], t_ga); atomicAdd(&prof[6], __builtin_amdgcn_s_memtime() - t_all0); atomicAdd(&prof[7], n_chunks);
+    }
+#undef IW_T
 }
 
 // ---- kernel B ------------------------------------------------------------------------------------------------------------
@@ -616,8 +658,10 @@ constexpr uint32_t CP_UNIT = 256;                               // cells a wave 
 
 extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
                                                                         uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off,
-                                                                        uint32_t m0, uint8_t* __restrict__ out, uint32_t cut)
+                                                                        uint32_t m0, uint8_t* __restrict__ out, uint32_t cut,
+                                                                        unsigned long long* __restrict__ prof)
 {
+    unsigned long long tb = prof ? __builtin_amdgcn_s_memtime() : 0, t_place = 0, t_res = 0, n_ur = 0, n_rounds = 0;
     __shared__ uint16_t W[65536];
     __shared__ uint32_t wsum[2][CP_WAVES];
     __shared__ uint32_t s_bad;
@@ -695,8 +739,9 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
     }
     if (bad) atomicOr(&s_bad, 1u);
     __syncthreads();
-    if (s_bad || run != isize) { if (tid == 0) wstatus[m] = ST_UNDECODABLE; return; }
+    if (s_bad || run != isize) { if (tid == 0) wstatus[m] = s_bad ? 17u : run < isize ? 16u : 18u; return; }
     if (cut == 1u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
+    if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_place = n - tb; tb = n; }
     // ---- resolve: pointer jumping; unit u (256 cells) is wave u % 16's, four cells per lane in flight -----------------------------------
     volatile uint16_t* const Wv = W;
     const uint32_t n_units = (isize + CP_UNIT - 1u) / CP_UNIT;
@@ -704,7 +749,9 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
     for (uint32_t j = 0; j < 16u; j++) if ((uint32_t)wave + 16u * j < n_units) pending |= 1u << j;
     while (pending) {
         uint32_t next = 0;
+        n_rounds++;
         for (uint32_t rest = pending; rest; rest &= rest - 1u) {
+            n_ur++;
             const uint32_t j = (uint32_t)__ffs((int)rest) - 1u;
             const uint32_t i0 = ((uint32_t)wave + 16u * j) * CP_UNIT + (uint32_t)lane;
             uint32_t v[4], u[4];
@@ -729,6 +776,7 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
         pending = next;
     }
     if (cut == 2u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
+    if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_res = n - tb; tb = n; }
     // ---- write: the wave's units, 16 bytes per lane and step (a unit = 16 lanes' worth: four units per step) -----------------------------
     uint8_t* const dst = out + o0;
     for (uint32_t j = 0; j < 16u; j += 4u) {
@@ -747,6 +795,10 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
             for (uint32_t x = 0; x < 16u && i + x < isize; x++) dst[i + x] = (uint8_t)(x < 8u ? lo >> (8u * x) : hi >> (8u * (x - 8u)));
         }
     }
+    if (prof && lane == 0) {
+        atomicAdd(&prof[8], t_place); atomicAdd(&prof[9], t_res); atomicAdd(&prof[10], __builtin_amdgcn_s_memtime() - tb); atomicAdd(&prof[11], n_ur);
+        atomicAdd(&prof[12], n_rounds); atomicMax(&prof[13], n_rounds); atomicAdd(&prof[14], 1ull);
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -759,6 +811,14 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     static const int waves_per_cu = [] { const char* e = getenv("GCI_INFLATE_WAVES"); return e ? atoi(e) : 0; }();
     static const uint32_t cut_a = [] { const char* e = getenv("GCI_IW_CUT_A"); return (uint32_t)(e ? atoi(e) : 0); }();   // (measurements)
     static const uint32_t cut_b = [] { const char* e = getenv("GCI_IW_CUT_B"); return (uint32_t)(e ? atoi(e) : 0); }();
+    static const bool want_prof = [] { const char* e = getenv("GCI_IW_PROF"); return e && atoi(e) != 0; }();
+    unsigned long long* d_prof = nullptr;
+    if (want_prof) {
+        const int stp = gci_ensure(ctx, ctx->inflate_prof, 16 * sizeof(unsigned long long));
+        if (stp) return stp;
+        d_prof = (unsigned long long*)ctx->inflate_prof.p;
+        HIPCHK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    }
     const uint32_t batch = n_members < batch_max ? n_members : batch_max;
     int st = gci_ensure(ctx, ctx->inflate_sym, (size_t)batch * SYM_STRIDE * sizeof(uint32_t));
     if (st) return st;
@@ -769,27 +829,43 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_symbols, 64, 0));
     if (waves_per_cu > 0 && waves_per_cu < per_cu) per_cu = waves_per_cu;
     const uint32_t resident = (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu : 1024);
+    st = gci_ensure(ctx, ctx->inflate_lists, (size_t)resident * 64u * MAXS * sizeof(uint32_t));
+    if (st) return st;
+    const uint32_t n_batches = (n_members + batch - 1u) / batch;
+    st = gci_ensure(ctx, ctx->inflate_next, (size_t)n_batches * sizeof(uint32_t));
+    if (st) return st;
+    HIPCHK(hipMemsetAsync(ctx->inflate_next.p, 0, (size_t)n_batches * sizeof(uint32_t), ctx->stream));
     for (uint32_t m0 = 0; m0 < n_members; m0 += batch) {
         const uint32_t nb = n_members - m0 < batch ? n_members - m0 : batch;
         hipLaunchKernelGGL(k_inflate_symbols, dim3(nb < resident ? nb : resident), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, out_cap, m0, nb,
-                           (uint32_t*)ctx->inflate_sym.p, (uint32_t*)ctx->inflate_nsym.p, d_wstatus, cut_a);
+                           (uint32_t*)ctx->inflate_sym.p, (uint32_t*)ctx->inflate_nsym.p, d_wstatus, (uint32_t*)ctx->inflate_lists.p, (uint32_t*)ctx->inflate_next.p + m0 / batch, cut_a, d_prof);
         LAUNCHCHK("k_inflate_symbols");
         hipLaunchKernelGGL(k_inflate_copy, dim3(nb), dim3(CP_THREADS), 0, ctx->stream, (const uint32_t*)ctx->inflate_sym.p,
-                           (const uint32_t*)ctx->inflate_nsym.p, d_wstatus, d_out_off, m0, d_out, cut_b);
+                           (const uint32_t*)ctx->inflate_nsym.p, d_wstatus, d_out_off, m0, d_out, cut_b, d_prof);
         LAUNCHCHK("k_inflate_copy");
+    }
+    if (want_prof) {
+        unsigned long long h[16];
+        HIPCHK(hipMemcpyAsync(h, d_prof, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const double a = (double)h[6] > 0 ? 100.0 / (double)h[6] : 0.0, b = (double)(h[8] + h[9] + h[10]) > 0 ? 100.0 / (double)(h[8] + h[9] + h[10]) : 0.0;
+        fprintf(stderr, "iw prof: A %% of wave time: header %.1f stage %.1f pass1 %.1f stitch %.1f chain %.1f gather %.1f; chunks %llu (%.0f cycles each); "
+                        "B %%: place %.1f resolve %.1f write %.1f; unit-rounds per member %.1f, rounds per wave %.2f (max %llu)\n",
+                a * h[0], a * h[1], a * h[2], a * h[3], a * h[4], a * h[5], h[7], h[7] ? (double)h[6] / (double)h[7] : 0.0, b * h[8], b * h[9], b * h[10],
+                h[14] ? (double)h[11] / ((double)h[14] / 16.0) : 0.0, h[14] ? (double)h[12] / (double)h[14] : 0.0, h[13]);
     }
     return GCI_OK;
 }
 
-extern "C" int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[8])
+extern "C" int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[32])
 {
     if (!ctx || !h_counts) return GCI_E_INVALID;
-    for (int k = 0; k < 8; k++) h_counts[k] = 0;
+    for (int k = 0; k < 32; k++) h_counts[k] = 0;
     const uint32_t n = ctx->inflate_last_n;
     if (!n) return GCI_OK;
     std::vector<uint32_t> h(n);
     HIPCHK(hipMemcpyAsync(h.data(), ctx->inflate_wstatus.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (uint32_t v : h) h_counts[v < 7u ? v : 7u]++;
+    for (uint32_t v : h) h_counts[v < 31u ? v : 31u]++;
     return GCI_OK;
 }

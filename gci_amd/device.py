@@ -514,10 +514,10 @@ class Engine:
 
     def inflate_stats(self) -> dict:
         """How the members of the last bgzf_inflate fared with the wave decoder (gci_bgzf_inflate_last_stats; synchronises)."""
-        c = (ctypes.c_uint32 * 8)()
+        c = (ctypes.c_uint32 * 32)()
         self._chk(self.lib.gci_bgzf_inflate_last_stats(self.ctx, c), "gci_bgzf_inflate_last_stats")
-        names = ("decoded", "header", "no meeting point", "false end of block", "undecodable", "length", "lanes", "not tried")
-        return {k: int(v) for k, v in zip(names, c)}
+        names = ("decoded", "header", "no meeting point", "false end of block", "undecodable", "length", "lanes") + tuple("cause %d" % k for k in range(7, 31)) + ("not tried",)
+        return {k: int(v) for k, v in zip(names, c) if v or k in ("decoded", "not tried")}
 
     def inflate_round(self) -> int:
         """Members gci_bgzf_inflate_device decodes at a time on this device (0: unknown)."""

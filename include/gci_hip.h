@@ -511,7 +511,7 @@ int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, 
  * The call synchronises. */
 int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off,
                             uint32_t n_members, uint8_t* d_out, uint64_t out_cap, int check_crc, uint64_t* d_status);
-int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[8]);
+int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[32]);
 /* Members the device decodes at a time (a launch takes a whole number of such rounds: size runs of a large file accordingly); 0 = unknown. */
 uint32_t gci_bgzf_inflate_round(gci_ctx* ctx);
 int gci_bam_record_offsets_device(gci_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, uint64_t first_record, int32_t n_ref,

@@ -10,6 +10,8 @@ one() {  # name, env...
 {
 one full CHECK_CRC=0
 one a1 GCI_IW_CUT_A=1 CHECK_CRC=0
+one a4 GCI_IW_CUT_A=4 CHECK_CRC=0
+one a6 GCI_IW_CUT_A=6 CHECK_CRC=0
 one a2 GCI_IW_CUT_A=2 CHECK_CRC=0
 one a3 GCI_IW_CUT_A=3 CHECK_CRC=0
 one b1 GCI_IW_CUT_B=1 CHECK_CRC=0
