@@ -377,9 +377,11 @@ extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint
         }
         const uint32_t xlen = (uint32_t)raw[pos0 + 10] | ((uint32_t)raw[pos0 + 11] << 8);
         if (pos0 + 12 + xlen + 8 > pos1) { if (lane == 0) { wstatus[m] = ST_HEADER; n_sym[m] = 0; } continue; }
-        const uintptr_t a0 = (uintptr_t)(raw + pos0 + 12 + xlen);
-        const unsigned long long* const g8 = (const unsigned long long*)(a0 & ~(uintptr_t)7);
-        const uint32_t bias = 8u * (uint32_t)(a0 & 7u);
+        // the payload as 8-byte units of global memory from the aligned address in front of it (derived from `raw`, so that the loads
+        // stay global ones: a pointer made out of an integer would be a flat one)
+        const uint32_t mis = (uint32_t)(((uintptr_t)raw + pos0 + 12 + xlen) & 7u);
+        const unsigned long long* const g8 = (const unsigned long long*)(raw + (pos0 + 12 + xlen - mis));
+        const uint32_t bias = 8u * mis;
         const uint32_t nbits = bias + 8u * (uint32_t)(pos1 - 8 - (pos0 + 12 + xlen));          // end of the DEFLATE stream (bits from g8)
         const uint32_t U_end = (nbits + 63u) >> 6;
         uint32_t tpos = bias, ns = 0;                                       // (uniform over the wave)
@@ -730,9 +732,9 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
             dst += len[k];
         }
         for (unsigned long long todo = __ballot(long_len != 0u); todo; todo &= todo - 1ull) {
-            const int src = __ffsll((long long)todo) - 1;
-            const uint32_t d0 = (uint32_t)__shfl((int)long_dst, src, 64), n = (uint32_t)__shfl((int)long_len, src, 64);
-            const uint16_t v = (uint16_t)(0x8000u | ((uint32_t)__shfl((int)long_dist, src, 64) - 1u));
+            const int src = __ffsll((long long)todo) - 1;                     // (uniform: the three values come over the scalar path)
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)long_dst, src), n = (uint32_t)__builtin_amdgcn_readlane((int)long_len, src);
+            const uint16_t v = (uint16_t)(0x8000u | ((uint32_t)__builtin_amdgcn_readlane((int)long_dist, src) - 1u));
             for (uint32_t x = (uint32_t)lane; x < n; x += 64) W[d0 + x] = v;
         }
         run += total;
@@ -743,7 +745,7 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
     if (cut == 1u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
     if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_place = n - tb; tb = n; }
     // ---- resolve: pointer jumping; unit u (256 cells) is wave u % 16's, four cells per lane in flight -----------------------------------
-    volatile uint16_t* const Wv = W;
+    // (plain LDS accesses; the compiler may keep nothing of W in registers from one look at a unit to the next: the barrier below)
     const uint32_t n_units = (isize + CP_UNIT - 1u) / CP_UNIT;
     uint32_t pending = 0;                                               // bit j: unit wave + 16 j
     for (uint32_t j = 0; j < 16u; j++) if ((uint32_t)wave + 16u * j < n_units) pending |= 1u << j;
@@ -754,27 +756,31 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
             n_ur++;
             const uint32_t j = (uint32_t)__ffs((int)rest) - 1u;
             const uint32_t i0 = ((uint32_t)wave + 16u * j) * CP_UNIT + (uint32_t)lane;
+            __asm__ volatile("" ::: "memory");
             uint32_t v[4], u[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; v[k] = i < isize ? (uint32_t)Wv[i] : 0u; }
+            for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; v[k] = i < isize ? (uint32_t)W[i] : 0u; }
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; u[k] = (v[k] & 0x8000u) ? (uint32_t)Wv[i - (v[k] & 0x7FFFu) - 1u] : 0u; }
+            for (int k = 0; k < 4; k++) {                                // (a cell that holds a byte reads itself: no branch around the look-up)
+                const uint32_t i = i0 + 64u * (uint32_t)k;
+                const uint32_t src = (v[k] & 0x8000u) ? i - (v[k] & 0x7FFFu) - 1u : (i < isize ? i : 0u);
+                u[k] = (uint32_t)W[src];
+            }
             bool open = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!(v[k] & 0x8000u)) continue;
                 const uint32_t i = i0 + 64u * (uint32_t)k;
-                if (!(u[k] & 0x8000u)) Wv[i] = (uint16_t)u[k];
-                else {
-                    open = true;
-                    const uint32_t d2 = (v[k] & 0x7FFFu) + (u[k] & 0x7FFFu) + 2u;
-                    if (d2 <= 0x8000u) Wv[i] = (uint16_t)(0x8000u | (d2 - 1u));
-                }
+                const bool ptr = (v[k] & 0x8000u) != 0u, to_ptr = (u[k] & 0x8000u) != 0u;
+                const uint32_t d2 = (v[k] & 0x7FFFu) + (u[k] & 0x7FFFu) + 2u;
+                const uint32_t nv = !to_ptr ? u[k] : d2 <= 0x8000u ? 0x8000u | (d2 - 1u) : v[k];
+                if (ptr && nv != v[k]) W[i] = (uint16_t)nv;
+                open = open || (ptr && to_ptr);
             }
             if (__ballot(open)) next |= 1u << j;
         }
         pending = next;
     }
+    __asm__ volatile("" ::: "memory");
     if (cut == 2u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
     if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_res = n - tb; tb = n; }
     // ---- write: the wave's units, 16 bytes per lane and step (a unit = 16 lanes' worth: four units per step) -----------------------------
@@ -807,7 +813,7 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
 int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off, uint32_t n_members,
                          uint8_t* d_out, uint64_t out_cap, uint32_t* d_wstatus)
 {
-    static const uint32_t batch_max = [] { const char* e = getenv("GCI_INFLATE_BATCH"); const int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
+    static const uint32_t batch_max = [] { const char* e = getenv("GCI_INFLATE_BATCH"); const int v = e ? atoi(e) : 16384; return (uint32_t)(v < 64 ? 64 : v); }();
     static const int waves_per_cu = [] { const char* e = getenv("GCI_INFLATE_WAVES"); return e ? atoi(e) : 0; }();
     static const uint32_t cut_a = [] { const char* e = getenv("GCI_IW_CUT_A"); return (uint32_t)(e ? atoi(e) : 0); }();   // (measurements)
     static const uint32_t cut_b = [] { const char* e = getenv("GCI_IW_CUT_B"); return (uint32_t)(e ? atoi(e) : 0); }();

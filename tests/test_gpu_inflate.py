@@ -56,6 +56,28 @@ def test_members_of_every_flavour(engine):
     assert len(members) > 50
 
 
+def test_the_wave_decoder_takes_the_members_and_hands_back_what_it_cannot_list(engine):
+    """Who decoded what (gci_bgzf_inflate_last_stats): members of a BAM-like mix -- stored, fixed, dynamic, several blocks, long
+    codes -- are the wave decoder's (k_inflate_wave.hip); a member whose symbols are one or two bits long (more symbols per piece
+    than a lane lists) goes to the lane decoder -- and both give zlib's bytes."""
+    rng = np.random.default_rng(43)
+    qual = synth._hifi_qual_lut()[rng.integers(0, 256, 60000, dtype=np.uint8)].tobytes()
+    seq = synth._SEQ_LUT[rng.integers(0, 16, 30000, dtype=np.uint8)].tobytes()
+    skew = bytes(rng.choice(np.arange(256, dtype=np.uint8), size=64000, p=np.r_[0.5, 0.25, np.full(254, 0.25 / 254)]))
+    usual = [member(qual, level=1), member(seq + qual[:30000], level=6), member(skew, level=6), member(qual[:20000], level=0),
+             member(qual[:30000], level=6, strategy=zlib.Z_FIXED), member(seq + qual[:30000], level=9, mem_level=1)]
+    want = [qual, seq + qual[:30000], skew, qual[:20000], qual[:30000], seq + qual[:30000]]
+    raw = b"".join(usual) + bgzf.BGZF_EOF
+    assert inflate_gpu(engine, raw) == b"".join(want)
+    st = engine.inflate_stats()
+    assert st["decoded"] == len(usual) + 1 and st["not tried"] == 0, st
+    two_symbols = bytes(rng.choice(np.array([65, 66], dtype=np.uint8), size=60000))         # Huffman only: one bit per symbol
+    raw = member(two_symbols, level=6, strategy=zlib.Z_HUFFMAN_ONLY) + member(qual, level=1) + bgzf.BGZF_EOF
+    assert inflate_gpu(engine, raw) == two_symbols + qual
+    st = engine.inflate_stats()
+    assert st["decoded"] == 2 and sum(v for k, v in st.items() if k not in ("decoded", "not tried")) == 1, st
+
+
 def test_match_shapes(engine):
     """Every way a match is copied: periods 1 .. 7 and distances 8 .. 40 against lengths 3 .. 258, at the start of a
     member, in its middle and ending exactly at its end (where the 8-byte stores must not run over into the next member)."""
