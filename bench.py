@@ -549,6 +549,47 @@ def make_two_type_workload(eng_factory, rank, world, args, exchange, replicated)
     return eng, w
 
 
+def smi_sample():
+    """What the box says about itself (rocm-smi; none of it is in this program's hands): shader / memory clocks, power, temperatures
+    of GPU 0.  Taken before and after the timed steps so that a slow box can be told from a slow kernel."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        c = d.get("card0") or next(iter(d.values()))
+        keep = {}
+        for k, v in c.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "temperature")) and "level" not in kl.replace("clock level", ""):
+                keep[k] = v
+            elif "clock level" in kl and any(t in kl for t in ("sclk", "mclk")):
+                keep[k] = v
+        return keep or None
+    except Exception:
+        return None
+
+
+def fill_ceiling_gbs(eng, nbytes, reps=6):
+    """The rate this box, in this process, writes a buffer of the size of the dominant kernel's output with a plain fill (torch's
+    zero_(): a stream of 16-byte stores, nothing read) -- the ceiling that kernel can be held against when two boxes differ."""
+    import torch
+    nbytes = int(min(nbytes, 24e9))
+    with torch.cuda.stream(eng.stream):
+        x = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+        for _ in range(2):
+            x.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(eng.stream)
+        for _ in range(reps):
+            x.zero_()
+        b.record(eng.stream)
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    del x
+    torch.cuda.empty_cache()
+    return nbytes / (ms * 1e-3) / 1e9
+
+
 def genome_dual_once(args, rank, world, base):
     """The genome workload of this run.  At N > 1 every rank needs the same two files: rank 0 generates them ONCE on all of the host's
     cores and leaves them as .npy files in the directory the launcher made (GCI_BENCH_SHARED, tmpfs); the other ranks map them.
@@ -833,6 +874,49 @@ def cpu_baseline_genome(inp, target_cpu_s=20.0):
     return {"seconds": dt, "cores": cores, "os_cpu_count": os.cpu_count(), "sample_contigs": [names[c] for c in sample],
             "sample_bases": int(sum(inp.lengths[c] for c in sample)), "sample_aligned_bases": aligned,
             "issue_runs": int(sum(len(x[1]) for x in out))}
+
+
+def cpu_baseline_libgci_cpu(inp, gpu_track=None):
+    """The same step on the WHOLE workload through libgci_cpu.so -- include/gci_hip.h compiled a second time, by g++, for host
+    memory and host threads (gci_amd/csrc/cpu/gci_cpu.cpp) -- on every core of the host: record filter per
+    file (heads streams), the join, the depth build, the issue scan, the depth text, the sums.  What it writes is held against the
+    GPU's track, base for base."""
+    from gci_amd import cpu
+    cpu.build()
+    e = cpu.CpuEngine(threads=os.cpu_count() or 1)
+    e.set_layout(inp.lengths)
+    e.heads(True)
+    sel = np.arange(len(inp.names), dtype=np.int32)
+    t0 = time.perf_counter()
+    stages = {}
+
+    def lap(name, t=[t0]):
+        now = time.perf_counter()
+        stages[name] = round(now - t[0], 3)
+        t[0] = now
+
+    files = []
+    for f in inp.files:
+        stream = np.ascontiguousarray(f.stream)
+        files.append((e.bam_filter(stream, f.offsets, sel, *FILTER), stream, f.offsets, 36))
+    lap("record filter x%d" % len(files))
+    ivl = e.name_join(files, OVLP)
+    lap("join")
+    track = e.depth_build(ivl, FLANK)
+    lap("depth build")
+    keys = e.issue_keys(track, -1, 0, FLANK)
+    lap("issue scan")
+    text, toff = e.depth_text(track)
+    lap("depth text")
+    sums = e.depth_sum(track)
+    lap("sums")
+    dt = time.perf_counter() - t0
+    out = {"seconds": dt, "cores": e.threads, "os_cpu_count": os.cpu_count(), "stages_s": stages, "intervals": int(ivl.shape[0]),
+           "issue_run_keys": int(keys.shape[0]), "text_bytes": int(text.shape[0]), "sum_of_depth": int(sums.sum())}
+    del text
+    if gpu_track is not None:
+        out["equal_to_the_gpu_track"] = bool(np.array_equal(track, gpu_track))
+    return out
 
 
 def cpu_baseline_chr19(w):
@@ -1522,11 +1606,13 @@ def main():
     for e_k, _, _ in lanes:
         e_k.profile_enable(1 << _lib.PROF_DEPTH_SCAN)      # HIP events around the dominant kernel only
         e_k.profile_read(reset=True)
+    smi_before = smi_sample() if rank == 0 else None
     fence()
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    smi_after = smi_sample() if rank == 0 else None
     prof = {}
     for e_k, _, _ in lanes:
         for name, (ms, n) in e_k.profile_read(reset=True).items():
@@ -1562,9 +1648,16 @@ def main():
         tag = "genome" if args.workload == "genome" else "chr19"
         tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_%s_traffic.json" % tag))
         if tj and args.scale == 1.0 and args.coverage == 40.0 and (args.workload == "genome" or args.contig_len == CHR19_LEN):
-            traffic = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))["hbm_bytes_per_launch"]
-            traffic_source = "profiles/%s (stored: the PMC passes of an earlier run of this workload -- rocprofv3 wraps the command, this " \
-                             "process cannot collect them)" % tj[-1]
+            tf = json.load(open(os.path.join(ROOT, "profiles", tj[-1])))
+            # the file must be about THIS kernel on THIS workload: its name, and HBM bytes within 10 % of the algorithmic ones
+            # (a kernel that changed, or a workload of another size, makes the stored counters stale: then no traffic is reported)
+            if tf.get("kernel") == "k_tile_build" and 0.9 * algo_bytes <= tf["hbm_bytes_per_launch"] <= 1.5 * algo_bytes:
+                traffic = tf["hbm_bytes_per_launch"]
+                traffic_source = "profiles/%s (stored: the PMC passes of an earlier run of this workload -- rocprofv3 wraps the command, this " \
+                                 "process cannot collect them)" % tj[-1]
+            else:
+                traffic_source = "profiles/%s REFUSED: it is about kernel %r with %.3g HBM bytes per launch, this run's k_tile_build has %.3g " \
+                                 "algorithmic bytes" % (tj[-1], tf.get("kernel"), tf.get("hbm_bytes_per_launch", 0.0), algo_bytes)
     except Exception:
         traffic = None
 
@@ -1573,6 +1666,12 @@ def main():
         w.step()
     breakdown = {k: round(ms / n * 1e3, 2) for k, (ms, n) in eng.profile_read(reset=True).items()}   # us / launch
     eng.profile_enable(0)
+    fill_gbs = None
+    if world == 1 and rank == 0 and algo_bytes > 0:
+        try:
+            fill_gbs = fill_ceiling_gbs(eng, algo_bytes)
+        except Exception:
+            fill_gbs = None
 
     out = {
         "metric": "aligned Gbases/s through filter+depth pipeline (CHM13, 40x HiFi)",
@@ -1596,6 +1695,7 @@ def main():
                                 + ("heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream") + (")" if w.pages else ""),
                    "input_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "steps_in_flight": len(lanes),
+                   "value_is": "SURVEY 8(d) number (1): kernels only, record pages already resident in HBM; numbers (2) and (3) in survey_8d",
                    "workload_generated": "once, by rank 0" if (world > 1 and os.environ.get("GCI_BENCH_SHARED")) else "by every rank" if world > 1 else "in this process",
                    "join": ("sharded by name hash: per file one all-to-all of 32-byte records and one of 48-byte name slots, then one of "
                             "16-byte intervals to the owners of their contigs; %d bytes leave this rank per step" % w.sj.bytes_per_step()
@@ -1604,7 +1704,10 @@ def main():
                             "replicated (all-gather of records + names)")},
         "roofline": {"bound": "hbm", "kernel": "k_tile_build (depth + text write)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
+                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n,
+                     # what a plain fill of as many bytes reaches on this box in this process, and the kernel against THAT
+                     "fill_ceiling_gbs": fill_gbs, "frac_of_fill_ceiling": (achieved / fill_gbs) if fill_gbs else None,
+                     "box": {"rocm_smi_before_steps": smi_before, "rocm_smi_after_steps": smi_after}},
         "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": algo},
         "kernel_us_per_launch": breakdown,
@@ -1659,18 +1762,30 @@ def main():
             if not args.no_e2e:
                 survey["2_device_pipeline_incl_h2d_d2h"] = device_pipeline_number(eng, w)
             if not args.no_cpu_baseline:
-                c = cpu_baseline_genome(w.inp)
-                frac = c["sample_bases"] / float(sum(w.inp.lengths))
-                sample_aligned = c["sample_aligned_bases"]
-                ratio = port_over_reference()
+                # the whole workload through libgci_cpu.so on every core; the oracle's port on a sample stays beside it (the ratio
+                # port / reference measured in the build container translates THAT one to the reference's Python)
+                gpu_track = w.track.cpu().numpy()
+                c = cpu_baseline_libgci_cpu(w.inp, gpu_track)
+                del gpu_track
+                if c.get("equal_to_the_gpu_track") is False:
+                    out["cpu_baseline"] = c
+                    print(json.dumps(out))
+                    sys.exit("PARITY FAILURE: libgci_cpu.so and the GPU disagree on the depth track")
+                o = cpu_baseline_genome(w.inp, target_cpu_s=8.0)
+                frac = o["sample_bases"] / float(sum(w.inp.lengths))
                 out["cpu_baseline"] = {
-                    "value": sample_aligned / c["seconds"] / 1e9, "unit": "Gbases/s", "cores": c["cores"], "kind": "port",
-                    "sample": "contigs %s (%d bp = %.1f %% of the workload, both files) through oracle/gci_oracle.{c,py} with the "
-                              "reference's structure (process pool over contigs for the filter, serial join, pool for depth / "
-                              "scan / text), %.1f s wall on %d processes (os.cpu_count() = %s)" % (
-                                  ",".join(c["sample_contigs"]), c["sample_bases"], 100.0 * frac, c["seconds"], c["cores"],
-                                  c["os_cpu_count"]),
-                    "port_over_reference": ratio}
+                    "value": aligned_total / c["seconds"] / 1e9, "unit": "Gbases/s", "cores": c["cores"], "kind": "port", "port": "libgci_cpu",
+                    "sample": "100 %%: the whole workload (both files, all %d contigs) through libgci_cpu.so -- include/gci_hip.h compiled by g++ "
+                              "for host memory and host threads -- on %d threads (os.cpu_count() = %s), %.2f s wall: %s; its depth track equals "
+                              "the GPU's base for base" % (len(w.inp.names), c["cores"], c["os_cpu_count"], c["seconds"],
+                                                           ", ".join("%s %.2f" % kv for kv in c["stages_s"].items())),
+                    "equal_to_the_gpu_track": c.get("equal_to_the_gpu_track"),
+                    "oracle_port_on_a_sample": {
+                        "value": o["sample_aligned_bases"] / o["seconds"] / 1e9, "cores": o["cores"],
+                        "sample": "contigs %s (%.1f %% of the workload) through oracle/gci_oracle.{c,py} with the reference's structure (process "
+                                  "pools over contigs, serial join), %.1f s on %d processes" % (",".join(o["sample_contigs"]), 100.0 * frac,
+                                                                                               o["seconds"], o["cores"]),
+                        "port_over_reference": port_over_reference()}}
             else:
                 out["cpu_baseline"] = None
             if not args.no_e2e and not args.no_cli_genome and args.reads == "hifi":
@@ -1688,6 +1803,16 @@ def main():
                     torch.cuda.empty_cache()
                     survey["3b_ingest_genome"] = ingest_number(args.coverage, args.ingest_gb)
             out["survey_8d"] = survey
+            # the three numbers of SURVEY 8(d) where the driver's record keeps them (it stores `config` whole)
+            g3 = survey.get("3_command_line_genome") or {}
+            p2 = survey.get("2_device_pipeline_incl_h2d_d2h") or {}
+            out["config"]["survey_8d"] = {
+                "1_kernels_only_gbases_per_s": out["value"],
+                "2_device_pipeline_gbases_per_s": p2.get("gbases_per_s"), "2_device_pipeline_s": p2.get("seconds"),
+                "3_command_line_genome_s": g3.get("seconds"), "3_first_pass_s": g3.get("seconds_first_pass_over_freshly_written_files"),
+                "3_command_line_genome_gbases_per_s": g3.get("gbases_per_s"),
+                "3_inflate_crc_device_s": (g3.get("phases_device_s") or {}).get("bgzf_inflate + crc"),
+                "3_parity": g3.get("parity")}
         elif not args.no_cpu_baseline:
             cdt, depths, bed, text, mean = cpu_baseline_chr19(w)
             out["cpu_baseline"] = {"value": w.aligned_bases / cdt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",

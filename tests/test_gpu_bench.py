@@ -32,7 +32,9 @@ def test_bench_line_contract():
     assert rf["avg_launch_ms"] < d["ms_per_step"]
     assert 0 < d["step_roofline"]["frac"] < 1
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Gbases/s" and cb["sample"]
+    assert cb["kind"] == "port" and cb["port"] == "libgci_cpu" and cb["cores"] == os.cpu_count() and cb["value"] > 0
+    assert cb["unit"] == "Gbases/s" and cb["sample"].startswith("100 %") and cb["equal_to_the_gpu_track"] is True
+    assert cb["oracle_port_on_a_sample"]["value"] > 0
     assert d["parity_vs_oracle_full_size"] is True
     s8 = d["survey_8d"]
     assert s8["1_kernels_only_gbases_per_s"] == d["value"]
