@@ -23,6 +23,11 @@ def _wake_the_gpu():
         pass
 
 
+if __name__ == "__main__" and os.environ.get("GCI_STUCK_TRACE"):
+    # measurements: every N seconds the stacks of all threads on stderr (a process that sits somewhere says where)
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["GCI_STUCK_TRACE"]), repeat=True)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and os.environ.get("GCI_EARLY_HIP", "1") != "0":
     import threading
     threading.Thread(target=_wake_the_gpu, daemon=True).start()

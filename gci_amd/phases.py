@@ -21,6 +21,16 @@ _TRACE = os.environ.get("GCI_PHASES_TRACE", "0") == "1"
 _BASE = None
 
 
+def process_age() -> float:
+    """Seconds since this process was started (exec), from /proc: what of a run's wall time lies in front of / behind the phase log."""
+    try:
+        ticks = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[19])
+        up = float(open("/proc/uptime").read().split()[0])
+        return up - ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:                                      # noqa: BLE001
+        return -1.0
+
+
 def start() -> None:
     global _ON, _T0
     _ON = True
@@ -30,6 +40,7 @@ def start() -> None:
     global _BASE
     _BASE = None
     _T0 = time.perf_counter()
+    _NOTES["process_age_s_when_the_phase_clock_started"] = round(process_age(), 3)
 
 
 def stop() -> None:
@@ -109,6 +120,7 @@ def add(key: str, value) -> None:
 def report(path: Optional[str] = None) -> dict:
     """{"wall_s": {phase: seconds (summed over its occurrences)}, "gpu_s": {stage: seconds}, "notes": {...}, "total_s"}."""
     out = {"total_s": time.perf_counter() - _T0, "wall_s": {}, "gpu_s": {}, "notes": dict(_NOTES)}
+    out["notes"]["process_age_s_at_the_report"] = round(process_age(), 3)
     for name, s in _WALL:
         out["wall_s"][name] = out["wall_s"].get(name, 0.0) + s
     if _GPU:

@@ -39,7 +39,7 @@ if os.environ.get("GCI_EXP_PROFILE"):
         if os.environ.get("GCI_EXP_AB"):                   # e.g. '[["16 GiB runs", {"GCI_BAM_CHUNK_BYTES": "17179869184"}]]'
             variants = [("product", {})] + [(a, b) for a, b in json.loads(os.environ["GCI_EXP_AB"])] + [("product again", {})]
         for label, extra in variants:
-            env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, **extra)
+            env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, GCI_STUCK_TRACE="15", **extra)
             od = os.path.join(tmp, "out_ab")
             shutil.rmtree(od, ignore_errors=True)
             t0 = time.perf_counter()
@@ -47,6 +47,8 @@ if os.environ.get("GCI_EXP_PROFILE"):
                                env=env, capture_output=True, text=True)
             wall = time.perf_counter() - t0
             ph = json.load(open(os.path.join(tmp, "ph_ab.json")))
+            if wall - ph.get("total_s", 0.0) > 10.0:         # a process that sat somewhere outside its phases: what it said
+                print("   stderr tail: " + r.stderr[-3000:], flush=True)
             if os.environ.get("GCI_EXP_SAVE"):               # the whole phase log (with its per-run trace under GCI_PHASES_TRACE=1)
                 os.makedirs(os.environ["GCI_EXP_SAVE"], exist_ok=True)
                 ph2 = dict(ph, notes={k: v for k, v in ph["notes"].items() if not k.startswith("depth_gz_layout")})
@@ -55,7 +57,9 @@ if os.environ.get("GCI_EXP_PROFILE"):
             if os.environ.get("GCI_EXP_MEMINFO"):            # what the page cache looks like behind the run (huge pages of tmpfs?)
                 mi = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/meminfo")}
                 print("   meminfo: " + ", ".join("%s %s" % (k, mi.get(k)) for k in ("Shmem", "ShmemHugePages", "ShmemPmdMapped", "Active(file)", "Inactive(file)", "Active(anon)", "Inactive(anon)", "Mapped")), flush=True)
-            print("%-26s rc %d wall %.2f s | " % (label, r.returncode, wall) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
+            print("%-26s rc %d wall %.2f s (in front of the phase log %.2f, behind its report %.2f) | " % (
+                  label, r.returncode, wall, ph["notes"].get("process_age_s_when_the_phase_clock_started", -1),
+                  wall - ph["notes"].get("process_age_s_at_the_report", wall)) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
                   + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0), flush=True)
         env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")
         out = os.path.join(ROOT, "gpurun_out", "cli_prof")
