@@ -120,6 +120,9 @@ EXPORTS = [
     ("gci_paf_hits_free", c_int, [c_void_p]),
     ("gci_route_hits", c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p]),
     ("gci_paf_score_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    ("gci_stage_create", c_int, [c_void_p, c_uint64, c_int, c_int, POINTER(c_void_p)]),
+    ("gci_stage_send", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_int]),
+    ("gci_stage_free", c_int, [c_void_p]),
     ("gci_bgzf_inflate_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
     ("gci_bgzf_inflate_last_stats", c_int, [c_void_p, c_void_p]),
     ("gci_bgzf_inflate_round", c_uint32, [c_void_p]),

@@ -81,9 +81,17 @@ class _Staging:
     the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
     SLOT = int(os.environ.get("GCI_STAGING_SLOT_MB", "64")) << 20    # (page-locking costs ~0.3 s per GB on these hosts: a ring of 256 MB, not of 1.2 GB)
     SLOTS = int(os.environ.get("GCI_STAGING_SLOTS", "4"))
-    THREADS = int(os.environ.get("GCI_STAGING_THREADS", "8"))
+    THREADS = int(os.environ.get("GCI_STAGING_THREADS", "12"))
 
     def __init__(self, engine=None):
+        # the loop over the slots is the library's (staging.cpp: gci_stage_send) -- the Python one below stays behind GCI_STAGING=python
+        self.native = None
+        self.engine = engine
+        if engine is not None and os.environ.get("GCI_STAGING", "native") != "python":
+            h = ctypes.c_void_p()
+            engine._chk(engine.lib.gci_stage_create(engine.ctx, self.SLOT, self.SLOTS, self.THREADS, ctypes.byref(h)), "gci_stage_create")
+            self.native = h
+            return
         self.slots = [None] * self.SLOTS
         self.views = [None] * self.SLOTS
         self.free_at = [None] * self.SLOTS
@@ -98,10 +106,23 @@ class _Staging:
 
         self.pinned = [self.pool.submit(pin, k) for k in range(self.SLOTS)]
 
+    def close(self):
+        if self.native is not None:
+            self.engine.lib.gci_stage_free(self.native)
+            self.native = None
+
     def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream, urgent: bool = True) -> None:
         """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued.  A sender that is not
         urgent (the assembly, whose N runs nobody waits for) lets the urgent ones (the runs of a BAM file: the device inflates them
         as they arrive) go first, piece by piece."""
+        if self.native is not None:
+            if p1 <= p0:
+                return
+            src = raw.ctypes.data + p0                      # (a numpy array / memmap of uint8: its bytes as they lie)
+            forget = 1 if (getattr(raw, "_mmap", None) is not None and os.environ.get("GCI_FORGET_PAGES", "1") != "0") else 0
+            self.engine._chk(self.engine.lib.gci_stage_send(self.engine.ctx, self.native, ctypes.c_void_p(src), p1 - p0, ctypes.c_void_p(dst.data_ptr()),
+                                                            ctypes.c_void_p(stream.cuda_stream), forget, 1 if urgent else 0), "gci_stage_send")
+            return
         if urgent:
             with self.lock:
                 self.urgent += 1

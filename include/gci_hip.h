@@ -488,6 +488,17 @@ int gci_route_hits(gci_ctx* ctx, const uint8_t* d_hits, uint32_t n, const uint8_
 int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, const uint32_t* h_hits_upto, int n_files,
                          const char* const* targets, int n_targets, gci_paf_dev** out);
 
+/* ---- the way of a memory-mapped input file to the device (staging.cpp) ---------------------------------------------------------
+ * A ring of n_slots pinned host buffers of slot_bytes each, filled by `threads` host threads (parallel memcpy out of the page
+ * cache) and emptied by DMA on the caller's stream.  gci_stage_send: h_src[0, n) -> d_dst[0, n) on `stream` (a hipStream_t);
+ * returns when the last piece is enqueued -- its bytes are in a pinned slot by then, the caller may unmap the file.  forget != 0
+ * drops the pages of h_src from the process's page table as they are read (madvise DONTNEED; the page cache keeps the data);
+ * urgent == 0 lets urgent calls of other threads go first, piece by piece.  Calls from several threads take slots in turns. */
+typedef struct gci_stage gci_stage;
+int gci_stage_create(gci_ctx* ctx, uint64_t slot_bytes, int n_slots, int threads, gci_stage** out);
+int gci_stage_send(gci_ctx* ctx, gci_stage* stage, const uint8_t* h_src, uint64_t n, uint8_t* d_dst, void* stream, int forget, int urgent);
+int gci_stage_free(gci_stage* stage);
+
 /* ---- N1 on the GPU: BGZF inflate and the BAM record walk (k_inflate.hip; replaces pysam / htslib at GCI.py:150-151) ---------
  * gci_bgzf_inflate_device: d_raw = the bytes of a BGZF file (or of a run of its members) on the device; d_member_pos[m] =
  * offset of member m in d_raw, n_members + 1 entries (the last = end of the run; gci_bgzf_blocks makes the table on the

@@ -16,10 +16,12 @@ inp = workloads.genome_dual(scale, 40.0, contigs=synth.CHM13, verbose=True)
 O.build()
 names = inp.names
 chosen = ["chr14", "chr22", "chrM"]
-file1 = O.file1_on_contigs([(f.stream, f.offsets, names) for f in inp.files], names, chosen, *bench.FILTER, bench.OVLP, heads=True)
-tl = {c: inp.lengths[names.index(c)] for c in chosen}
-depths = O.depth_build(file1, tl, bench.FLANK)
-orc = {"depths": depths, "bed": O.collapse_depth_range(depths, -1, 0, bench.FLANK, 0), "lengths": tl}
+orc = None
+if not os.environ.get("GCI_EXP_PROFILE"):                  # (the A/B mode times host-side switches: no oracle needed)
+    file1 = O.file1_on_contigs([(f.stream, f.offsets, names) for f in inp.files], names, chosen, *bench.FILTER, bench.OVLP, heads=True)
+    tl = {c: inp.lengths[names.index(c)] for c in chosen}
+    depths = O.depth_build(file1, tl, bench.FLANK)
+    orc = {"depths": depths, "bed": O.collapse_depth_range(depths, -1, 0, bench.FLANK, 0), "lengths": tl}
 if os.environ.get("GCI_EXP_PROFILE"):
     # keep the files: run the command line once more under the profiler
     import tempfile, shutil
@@ -61,6 +63,8 @@ if os.environ.get("GCI_EXP_PROFILE"):
                   label, r.returncode, wall, ph["notes"].get("process_age_s_when_the_phase_clock_started", -1),
                   wall - ph["notes"].get("process_age_s_at_the_report", wall)) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
                   + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0), flush=True)
+        if os.environ.get("GCI_EXP_NO_ROCPROF"):
+            raise SystemExit(0)
         env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")
         out = os.path.join(ROOT, "gpurun_out", "cli_prof")
         shutil.rmtree(out, ignore_errors=True)
