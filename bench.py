@@ -69,6 +69,9 @@ def parse_args():
                     help="genome workload: the timed step, its roofline and the full-size parity check only -- no window / command-line-"
                          "shaped / in-flight legs (their k_tile_build launches write no text and would blur a profiler's per-kernel "
                          "averages), no end-to-end numbers, no CPU baseline: what tools/round_profile.sh wraps in rocprofv3")
+    ap.add_argument("--cli", action="store_true",
+                    help="genome4 / diploid: also run the two-read-type COMMAND LINE on real files (BGZF BAMs + PAFs on tmpfs) and hold its "
+                         "files against the oracle (SURVEY 8(d) number 3 for configs[3]); kept out of the default run")
     ap.add_argument("--no-cli-genome", action="store_true",
                     help="genome workload: skip survey_8d.3_command_line_genome (the command line as a process of its own on the two "
                          "genome-size BGZF files: ~130 GB written to tmpfs first, minutes of host-side deflate)")
@@ -1408,6 +1411,108 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def cli_two_type_number(inp, chosen, verbose=True):
+    """SURVEY.md 8(d) number (3) for the two-read-type command line (GCI.py:1007-1026 -- the run the reference's only published timing,
+    images/RAM_t32.png, is about: per read type one BAM and one PAF): the inputs as real files on tmpfs -- BGZF BAMs with SEQ / QUAL of
+    realistic entropy written from the heads streams, the PAF texts as they are, the assembly as FASTA --, `python GCI.py --hifi ...
+    --nano ...` as a process of its own, twice; wall time, the process's own phase log, and the three depth files, the three BED files and
+    the .gci rows of `chosen` whole contigs against the oracle (filter() restricted to those contigs, per read type; gap mask; max)."""
+    import gzip
+    import shutil
+    import subprocess
+    import tempfile
+    from gci_amd import hostio, synth, workloads
+    from oracle import gci_oracle as O
+    O.build()
+    names = inp.names
+    chosen = [c for c in chosen if c in names]
+    tl = {c: inp.lengths[names.index(c)] for c in chosen}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="gci_cli_two_type_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        files = {}
+        for kind, t in (("hifi", inp.hifi), ("nano", inp.nano)):
+            p = os.path.join(tmp, "%s.bam" % kind)
+            made = workloads.write_bgzf_from_heads(p, t.bam.stream, t.bam.offsets, seed=20250919 + (0 if kind == "hifi" else 1), verbose=verbose)
+            files[kind] = [p]
+            if t.paf is not None:
+                q = os.path.join(tmp, "%s.paf" % kind)
+                t.paf.tofile(q)
+                files[kind].append(q)
+            files[kind + "_made"] = made
+        fa = os.path.join(tmp, "assembly.fa")
+        synth.write_reference_fasta(fa, inp.contigs, gaps=inp.gaps) if inp.gaps else synth.write_reference_fasta(fa, inp.contigs)
+        t_gen = time.perf_counter() - t0
+        od, ph = os.path.join(tmp, "out"), os.path.join(tmp, "phases.json")
+        env = dict(os.environ, GCI_PHASES=ph, PYTHONPATH=ROOT)
+        cmd = [sys.executable, os.path.join(ROOT, "GCI.py"), "-r", fa, "--hifi"] + files["hifi"] + ["--nano"] + files["nano"] + \
+              ["-d", od, "-t", str(hostio.default_threads())]
+        walls, reps, given_up = [], [], 0
+        for _ in range(4):
+            shutil.rmtree(od, ignore_errors=True)
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            except subprocess.TimeoutExpired:
+                given_up += 1
+                if given_up >= 2:
+                    return {"error": "two passes did not finish in 300 s each; input generation took %.0f s" % t_gen}
+                continue
+            walls.append(time.perf_counter() - t0)
+            if r.returncode != 0:
+                return {"error": "GCI.py exited with %d: %s" % (r.returncode, r.stderr[-1500:])}
+            reps.append(json.load(open(ph)))
+            if len(walls) == 2:
+                break
+        wall, rep = walls[1], reps[1]
+        # ---- the oracle on the chosen contigs, per read type; then the files
+        tracks = []
+        for t in (inp.hifi, inp.nano):
+            file1 = O.file1_on_contigs_mixed([t.paf.tobytes()] if t.paf is not None else [], [(t.bam.stream, t.bam.offsets, names)], names, chosen,
+                                             FILTER[0], FILTER[1], FILTER[2], FILTER[3], OVLP, heads=True)
+            d = O.depth_build(file1, tl, FLANK)
+            tracks.append(d)
+        layouts = {os.path.basename(k.split(":", 1)[1]): v for k, v in rep["notes"].items() if k.startswith("depth_gz_layout:")}
+        ok = True
+        raw_tracks = [{c: v.copy() for c, v in d.items()} for d in tracks]              # (a read type's own .depth.gz is written before the gap mask)
+        for d in tracks:
+            O.merge_gaps_depths(d, {c: v for c, v in inp.gaps.items() if c in tl} or None)
+        two = O.max2(tracks[0], tracks[1])
+        for fn, want_text_of, want_bed_of in (("GCI_hifi", raw_tracks[0], tracks[0]), ("GCI_nano", raw_tracks[1], tracks[1]), ("GCI_two_type", two, two)):
+            layout = layouts.get(fn + ".depth.gz")
+            ok = ok and layout is not None
+            if layout is None:
+                continue
+            with open(os.path.join(od, fn + ".depth.gz"), "rb") as f:
+                for c in chosen:
+                    a, b = layout[c]
+                    f.seek(a)
+                    got = gzip.decompress(f.read(b - a))
+                    ok = ok and got == (">%s\n" % c).encode() + O.depth_text_contig(want_text_of[c])
+                    del got
+            bed = O.collapse_depth_range(want_bed_of, -1, 0, FLANK, 0)
+            lines = {}
+            for line in open(os.path.join(od, fn + ".0.depth.bed")):
+                lines.setdefault(line.split("\t", 1)[0], []).append(line)
+            for c in chosen:
+                ok = ok and "".join(lines.get(c, [])) == O.bed_text({c: bed[c]})
+        outputs = {fn: os.path.getsize(os.path.join(od, fn)) for fn in sorted(os.listdir(od))}
+        aligned = int(inp.hifi.bam.aligned_bases + inp.nano.bam.aligned_bases + inp.hifi.paf_aligned_bases + inp.nano.paf_aligned_bases)
+        return {"seconds": wall, "gbases_per_s": aligned / wall / 1e9, "seconds_first_pass_over_freshly_written_files": walls[0],
+                "passes_given_up_after_300_s": given_up,
+                "command": "python GCI.py -r assembly.fa --hifi hifi.bam hifi.paf --nano nano.bam nano.paf -d out (a process of its own)",
+                "seconds_in_front_of_the_phase_log": rep["notes"].get("process_age_s_when_the_phase_clock_started"),
+                "phases_wall_s": {k: round(v, 4) for k, v in rep["wall_s"].items()},
+                "phases_device_s": {k: round(v, 4) for k, v in rep["gpu_s"].items()},
+                "files": {k: {"bytes": [os.path.getsize(p) for p in v]} for k, v in files.items() if not k.endswith("_made")},
+                "bam_members": {k[:-5]: v.get("members") for k, v in files.items() if k.endswith("_made")},
+                "outputs_bytes": outputs, "parity_vs_oracle_on_contigs": chosen, "parity": bool(ok), "input_generation_seconds": t_gen,
+                "reference_published": "6.03 h / 1.83 h for its CHM13 run on other hardware (images/RAM_t32.png): context, not a comparison"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def paf_number(args):
     """K2 at the size of the reference's published run (README.md:321: a 48 GB ONT PAF + a 3.6 GB HiFi PAF): `--paf-gb` GB of PAF text
     through gci_paf_filter_device (the PAF path of filter(), GCI.py:211-254), text resident in HBM.  The text is a chunk of ~1 M
@@ -1751,6 +1856,12 @@ def main():
         out["parity_contigs"] = chosen
         out["roofline"]["kernel"] = "k_tile_build (depth write; no text in this workload)"
         out["cpu_baseline"] = None
+        if ok and args.cli:
+            inp2 = w.inp
+            out["survey_8d"] = {"1_kernels_only_gbases_per_s": out["value"], "3_command_line_two_read_types": cli_two_type_number(inp2, chosen)}
+            if out["survey_8d"]["3_command_line_two_read_types"].get("parity") is False:
+                print(json.dumps(out))
+                sys.exit("PARITY FAILURE: the two-read-type command line's files differ from the oracle")
         if ok and args.workload == "diploid":
             out["plot_front_end_n3"] = plot_front_end_number(w)
             if not out["plot_front_end_n3"]["parity_vs_oracle"]:
