@@ -28,11 +28,32 @@ if __name__ == "__main__" and os.environ.get("GCI_STUCK_TRACE"):
     import faulthandler
     faulthandler.dump_traceback_later(float(os.environ["GCI_STUCK_TRACE"]), repeat=True)
 
-if __name__ == "__main__" and len(sys.argv) > 1 and os.environ.get("GCI_EARLY_HIP", "1") != "0":
+def _a_run_of_this_process(argv) -> bool:
+    """True for a command line that will do its work HERE: not --help / --version / no arguments (they end in argparse), not the
+    launcher of a multi-GPU run (it execs torch.distributed.run right away: a runtime that is starting on another thread would be
+    torn down under it)."""
+    if len(argv) < 2 or any(a in ("-h", "--help", "-v", "--version") for a in argv[1:]):
+        return False
+    launched = all(k in os.environ for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR"))
+    for k, a in enumerate(argv[1:], 1):
+        if a == "--gpus" or a.startswith("--gpus="):
+            n = a.split("=", 1)[1] if "=" in a else (argv[k + 1] if k + 1 < len(argv) else "1")
+            if n.isdigit() and int(n) > 1 and not launched:
+                return False
+    return True
+
+
+_WAKER = None
+if __name__ == "__main__" and _a_run_of_this_process(sys.argv) and os.environ.get("GCI_EARLY_HIP", "1") != "0":
     import threading
-    threading.Thread(target=_wake_the_gpu, daemon=True).start()
+    _WAKER = threading.Thread(target=_wake_the_gpu, daemon=True)
+    _WAKER.start()
 
 from gci_amd.cli import main  # noqa: E402
 
 if __name__ == "__main__":
-    main(sys.argv)
+    try:
+        main(sys.argv)
+    finally:
+        if _WAKER is not None:
+            _WAKER.join(timeout=10.0)                 # (an early exit -- a refused argument -- does not leave while the runtime is starting)

@@ -119,6 +119,7 @@ EXPORTS = [
     ("gci_paf_hits_export", c_int, [c_void_p, c_int, c_void_p]),
     ("gci_paf_hits_free", c_int, [c_void_p]),
     ("gci_route_hits", c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p]),
+    ("gci_paf_pool_release", c_int, [c_void_p]),
     ("gci_paf_score_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("gci_stage_create", c_int, [c_void_p, c_uint64, c_int, c_int, POINTER(c_void_p)]),
     ("gci_stage_send", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_int]),

@@ -563,6 +563,24 @@ struct PafScratch {
     // p leaves the pool: the caller owns it from here on (hipFree)
     void keep(void* p) { for (DevBuf& b : ctx->paf_pool) if (b.p == p) { b.p = nullptr; b.cap = 0; return; } }
 };
+}  // namespace
+
+// The pooled scratch of the PAF filter given back to the driver (the pipeline calls this when the PAF stage of filter() is over: the
+// BAM ingestion, the join and the depth build behind it allocate through the host's allocator, and up to 16 GB held here outside of
+// it would be theirs to miss).  The next PAF call allocates again.
+extern "C" int gci_paf_pool_release(gci_ctx* ctx)
+{
+    if (!ctx) return GCI_E_INVALID;
+    bool any = false;
+    for (const DevBuf& b : ctx->paf_pool) any = any || b.p;
+    if (!any) return GCI_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (DevBuf& b : ctx->paf_pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    return GCI_OK;
+}
+
+namespace {
+
 #define PAF_ALLOC(var, type, count)                                         \
     type* var = (type*)S.alloc(sizeof(type) * (size_t)(count));             \
     if (!var) return GCI_E_NOMEM

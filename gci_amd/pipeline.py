@@ -651,6 +651,10 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
         from concurrent.futures import Future
         before = None                                     # the uploader of the file in front
         for k, (path, raw, fut) in enumerate(todo):
+            if _QUIESCE.is_set():                         # (the run is over: nobody will ask for this file's table)
+                if not fut.done():
+                    fut.set_exception(RuntimeError("the run ended before %s was reached" % path))
+                continue
             try:
                 threads = max(2, many // 2) if k == 0 else max(2, many // 4)
                 n_raw = int(raw.shape[0])
@@ -681,7 +685,9 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
                     engine = default_engine()
                     members = _Members(engine, BAM_CHUNK_BYTES, pos, isz)
                     if before is not None:
-                        before.last_sent.wait()           # (the ring of pinned buffers is the file's in front until then)
+                        while not before.last_sent.wait(0.05):            # (the ring of pinned buffers is the file's in front until then)
+                            if _QUIESCE.is_set():
+                                break
                     before = _RunUploads(engine, raw, members)
                     fut.set_result((members, before))
                 else:
@@ -690,9 +696,13 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
                 if not fut.done():
                     fut.set_exception(e)
 
-    threading.Thread(target=chain, daemon=True).start()
+    th = threading.Thread(target=chain, daemon=True)
+    _CHAINS.append(th)
+    th.start()
 
 
+_CHAINS: List[threading.Thread] = []    # the helper threads of prefetch_member_tables (quiesce_ahead joins them)
+_QUIESCE = threading.Event()             # set: a chain stops in front of its next file
 _INGEST_AHEAD: Dict[str, tuple] = {}   # path -> (key, future of its JoinInput): start_ingest_ahead
 _SIDE_ENGINE = None
 
@@ -737,8 +747,17 @@ def quiesce_ahead() -> None:
     for path in list(_INGEST_AHEAD):
         _, fut = _INGEST_AHEAD.pop(path)
         fut.exception()                                   # (waits; the outcome is nobody's any more)
+    # the threads that make tables and first uploads ahead: told to stop in front of their next file, their uploaders (a later
+    # file's waits for the ring until the one in front has sent its last run) closed, and waited for -- so that the interpreter never
+    # finalises under a thread that is inside HIP or torch (an early sys.exit would otherwise race it)
+    _QUIESCE.set()
     for path in list(_TABLES):
         _drop_ahead(_TABLES.pop(path))
+    for th in list(_CHAINS):
+        if th is not threading.current_thread():
+            th.join(timeout=30.0)
+    del _CHAINS[:]
+    _QUIESCE.clear()
 
 
 def _side_engine() -> Engine:
@@ -964,6 +983,10 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
                 inputs += [JoinInput(engine.to_device(r), engine.to_device(nm), engine.to_device(off), 0) for r, nm, off in native]
             else:                                             # K2: tokeniser, grouping and scoring on the GPU
                 inputs += engine.paf_filter(paf_files, targets, map_qual, mq_cutoff, iden_percent)
+                if bam_files and os.environ.get("GCI_PAF_POOL_KEEP_GB") is None:
+                    # the PAF stage is over: its pooled scratch (raw device memory, outside torch's allocator) back to the driver before
+                    # the BAM ingestion, the join and the depth build ask for theirs (a harness that repeats the stage says KEEP)
+                    engine.lib.gci_paf_pool_release(engine.ctx)
         except GciError as e:
             e.paf_replay = (paf_files, targets)               # a bad LINE: Python's own exception for it, as the reference dies
             _reraise_like_reference(e)

@@ -487,6 +487,9 @@ int gci_route_hits(gci_ctx* ctx, const uint8_t* d_hits, uint32_t n, const uint8_
                    uint8_t* d_out_hits, uint8_t* d_out_names, uint32_t name_slot, uint64_t* d_status);
 int gci_paf_score_device(gci_ctx* ctx, const uint8_t* d_names, uint8_t* d_hits, const uint32_t* h_hits_upto, int n_files,
                          const char* const* targets, int n_targets, gci_paf_dev** out);
+/* The PAF filter's pooled scratch (kept in the context between calls, up to 16 GB) given back to the driver: for a host whose other
+ * stages allocate through an allocator of their own.  Synchronises when there is something to free. */
+int gci_paf_pool_release(gci_ctx* ctx);
 
 /* ---- the way of a memory-mapped input file to the device (staging.cpp) ---------------------------------------------------------
  * A ring of n_slots pinned host buffers of slot_bytes each, filled by `threads` host threads (parallel memcpy out of the page

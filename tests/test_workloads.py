@@ -107,6 +107,10 @@ def test_phase_log_is_off_unless_asked_for(tmp_path):
     phases.add("n", 3)
     rep = phases.report(str(tmp_path / "p.json"))
     phases.stop()
-    assert set(rep["wall_s"]) == {"a", "b"} and rep["notes"] == {"n": 5} and rep["gpu_s"] == {} and rep["total_s"] >= rep["wall_s"]["a"]
+    ages = {k: v for k, v in rep["notes"].items() if k.startswith("process_age_s_")}       # (how old the process was: two notes of the log's own)
+    assert set(ages) == {"process_age_s_when_the_phase_clock_started", "process_age_s_at_the_report"}
+    assert 0 <= ages["process_age_s_when_the_phase_clock_started"] <= ages["process_age_s_at_the_report"]
+    assert {k: v for k, v in rep["notes"].items() if k not in ages} == {"n": 5}
+    assert set(rep["wall_s"]) == {"a", "b"} and rep["gpu_s"] == {} and rep["total_s"] >= rep["wall_s"]["a"]
     import json
-    assert json.load(open(tmp_path / "p.json"))["notes"] == {"n": 5}
+    assert json.load(open(tmp_path / "p.json"))["notes"] == rep["notes"]
