@@ -1329,12 +1329,20 @@ def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
     blobs = depths.engine.depth_deflate(depths.track)               # views of the engine's pinned staging buffer
     items = list(zip(depths.targets, depths.lengths, blobs))
     if _sharded():
-        items = [(t, L, bytes(b)) for t, L, b in items]             # (they travel pickled)
+        # to rank 0 only (the members of a genome are GBs), as bytes: a sized gather of one uint8 tensor per rank -- which contigs a
+        # rank owns every rank knows (SHARD.owner), so names and lengths need not travel
         order = {t: i for i, t in enumerate(depths.all_targets)}
-        parts = SHARD.gather_to_root(items)             # to rank 0 only: the members of a genome are GBs
+        parts = SHARD.gather_bytes_to_root([np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b for _, _, b in items])
         if not SHARD.root:
             return
-        items = sorted((x for part in parts for x in part), key=lambda x: order[x[0]])
+        all_t = depths.all_targets
+        items = []
+        for r, blobs_r in enumerate(parts):
+            owned = [c for c, o in enumerate(SHARD.owner) if o == r]
+            assert len(owned) == len(blobs_r), (r, len(owned), len(blobs_r))
+            # (a contig of length 0 has no members: its empty blob stands for "L == 0" below)
+            items += [(all_t[c], int(b.shape[0]), b.tobytes()) for c, b in zip(owned, blobs_r)]
+        items.sort(key=lambda x: order[x[0]])
     path = f"{directory}/{prefix}.depth.gz"
     if os.path.exists(path):
         os.remove(path)

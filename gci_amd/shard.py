@@ -92,6 +92,40 @@ class Context:
         dist.gather_object(obj, out, dst=0)
         return out
 
+    def gather_bytes_to_root(self, blobs: Sequence) -> Optional[List[List[np.ndarray]]]:
+        """Per rank a list of byte strings (the .depth.gz members of the contigs it owns) -> on rank 0, in rank order, every rank's
+        list as uint8 arrays; None elsewhere.  Nothing is pickled: the counts and the sizes travel as int64 tensors (all-gathers of
+        fixed shape), the bytes as ONE gather of a uint8 tensor padded to the largest rank's total."""
+        dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
+        arrs = [np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b.reshape(-1).view(np.uint8) for b in blobs]
+        count = torch.tensor([len(arrs)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(counts, count)
+        counts = [int(c.item()) for c in counts]
+        width = max(counts + [1])
+        mine = torch.zeros(width, dtype=torch.int64, device=dev)
+        if arrs:
+            mine[:len(arrs)] = torch.tensor([int(a.shape[0]) for a in arrs], dtype=torch.int64)
+        sizes = [torch.zeros(width, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(sizes, mine)
+        sizes = [s.cpu().numpy()[:c] for s, c in zip(sizes, counts)]
+        total = max([int(s.sum()) for s in sizes] + [1])
+        buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        at = 0
+        for a in arrs:
+            buf[at:at + a.shape[0]] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            at += int(a.shape[0])
+        got = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(self.world)] if self.root else None
+        dist.gather(buf, got, dst=0)
+        if not self.root:
+            return None
+        out = []
+        for g, sz in zip(got, sizes):
+            h = g.cpu().numpy()
+            cuts = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
+            out.append([h[cuts[k]:cuts[k + 1]] for k in range(len(sz))])
+        return out
+
     def all_reduce_max(self, values: Sequence[int]) -> List[int]:
         dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)

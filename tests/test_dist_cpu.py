@@ -486,3 +486,45 @@ def test_line_starts_for_byte_ranges():
         cuts = [shard.byte_range_of_rank(raw, r, world) for r in range(world)]
         assert cuts[0][0] == 0 and cuts[-1][1] == len(raw)
         assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(lo in starts + [len(raw)] for lo, _ in cuts)
+
+
+def _bytes_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gci_amd import shard
+        ctx = shard.Context.__new__(shard.Context)           # (the collectives only: no device, no second init)
+        ctx.rank, ctx.world, ctx.backend, ctx.device_index = rank, world, "gloo", 0            # (root is a property: rank == 0)
+        rng = np.random.default_rng(rank)
+        # rank r sends r + (r % 2) blobs of sizes 0 .. 70 000 (an empty list, empty blobs, one larger than the others' totals)
+        mine = [rng.integers(0, 256, int(s), dtype=np.uint8) for s in ([0, 70_000, 5][:rank + (rank % 2)] if rank else [])]
+        got = ctx.gather_bytes_to_root([m.tobytes() if k % 2 else m for k, m in enumerate(mine)])
+        if rank == 0:
+            ok = len(got) == world
+            for r in range(world):
+                want = [np.random.default_rng(r).integers(0, 256, int(s), dtype=np.uint8) for s in ([0, 70_000, 5][:r + (r % 2)] if r else [])]
+                rg = np.random.default_rng(r)
+                want = [rg.integers(0, 256, int(s), dtype=np.uint8) for s in ([0, 70_000, 5][:r + (r % 2)] if r else [])]
+                ok = ok and len(got[r]) == len(want) and all(np.array_equal(a, b) for a, b in zip(got[r], want))
+            q.put(bool(ok))
+        else:
+            q.put(got is None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_members_travel_as_one_sized_gather_of_bytes():
+    """shard.Context.gather_bytes_to_root (how the .depth.gz members of a contig-sharded run reach rank 0): ragged lists of blobs,
+    an empty list, empty blobs -- rank 0 gets every rank's list byte for byte, the others None; nothing pickled."""
+    world, port = 3, 29877
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_bytes_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(res), res
