@@ -123,6 +123,7 @@ EXPORTS = [
     ("gci_paf_score_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("gci_stage_create", c_int, [c_void_p, c_uint64, c_int, c_int, POINTER(c_void_p)]),
     ("gci_stage_send", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_int]),
+    ("gci_stage_send_fd", c_int, [c_void_p, c_void_p, c_int, c_uint64, c_uint64, c_void_p, c_void_p, c_int]),
     ("gci_stage_free", c_int, [c_void_p]),
     ("gci_bgzf_inflate_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
     ("gci_bgzf_inflate_last_stats", c_int, [c_void_p, c_void_p]),

@@ -29,9 +29,12 @@ struct gci_stage {
     std::vector<std::thread> workers;
     std::mutex m;
     std::condition_variable go, done;
-    const uint8_t* src = nullptr;
+    const uint8_t* src = nullptr;          // a mapping ... or
+    int fd = -1;                            // ... a descriptor read with pread (no page faults on a mapping: the kernel copies out of the page cache itself)
+    uint64_t fd_off = 0;
     uint8_t* dst = nullptr;
     size_t n = 0, step = 0;
+    std::atomic<int> io_error{0};
     std::atomic<size_t> part{0};
     int busy = 0;
     uint64_t gen = 0;
@@ -53,7 +56,15 @@ void worker(gci_stage* s)
         for (;;) {
             const size_t at = s->part.fetch_add(1) * s->step;
             if (at >= s->n) break;
-            memcpy(s->dst + at, s->src + at, std::min(s->step, s->n - at));
+            const size_t len = std::min(s->step, s->n - at);
+            if (s->fd < 0) memcpy(s->dst + at, s->src + at, len);
+            else {
+                for (size_t got = 0; got < len;) {
+                    const ssize_t r = pread(s->fd, s->dst + at + got, len - got, (off_t)(s->fd_off + at + got));
+                    if (r <= 0) { s->io_error = 1; break; }
+                    got += (size_t)r;
+                }
+            }
         }
         std::lock_guard<std::mutex> lk(s->m);
         if (--s->busy == 0) s->done.notify_one();
@@ -61,14 +72,14 @@ void worker(gci_stage* s)
 }
 
 // src[0, n) -> dst by all the threads; returns when the last byte is there
-void copy_parallel(gci_stage* s, uint8_t* dst, const uint8_t* src, size_t n)
+void copy_parallel(gci_stage* s, uint8_t* dst, const uint8_t* src, int fd, uint64_t fd_off, size_t n)
 {
     const size_t T = (size_t)s->threads;
     size_t step = (n + T - 1) / T;
     step = (step + 4095) / 4096 * 4096;
     {
         std::lock_guard<std::mutex> lk(s->m);
-        s->src = src; s->dst = dst; s->n = n; s->step = step;
+        s->src = src; s->fd = fd; s->fd_off = fd_off; s->dst = dst; s->n = n; s->step = step;
         s->part = 0;
         s->busy = (int)s->workers.size();
         s->gen++;
@@ -102,9 +113,9 @@ extern "C" int gci_stage_create(gci_ctx* ctx, uint64_t slot_bytes, int n_slots, 
 // pinned slot by then: the caller may unmap the file).  forget != 0: the pages of h_src are dropped from the process's page table
 // as they have been read (madvise DONTNEED: the page cache keeps the data; see device.py _forget_pages for why).  urgent == 0: the
 // call lets urgent ones go first, piece by piece (the assembly, whose N runs nobody waits for, next to the runs of a BAM file).
-extern "C" int gci_stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, uint64_t n, uint8_t* d_dst, void* stream, int forget, int urgent)
+static int stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, int fd, uint64_t fd_off, uint64_t n, uint8_t* d_dst, void* stream, int forget,
+                      int urgent)
 {
-    if (!ctx || !s || (n && (!h_src || !d_dst))) return GCI_E_INVALID;
     if (urgent) s->urgent++;
     int rc = GCI_OK;
     const long page = sysconf(_SC_PAGESIZE);
@@ -118,8 +129,9 @@ extern "C" int gci_stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, 
             if (hipHostMalloc(&s->slot[(size_t)k], s->slot_bytes, hipHostMallocDefault) != hipSuccess) { rc = gci_fail(ctx, hipGetLastError(), "hipHostMalloc (staging slot)"); break; }
         }
         if (s->used[(size_t)k] && hipEventSynchronize(s->ev[(size_t)k]) != hipSuccess) { rc = gci_fail(ctx, hipGetLastError(), "hipEventSynchronize (staging slot)"); break; }
-        copy_parallel(s, (uint8_t*)s->slot[(size_t)k], h_src + a, len);
-        if (forget) {
+        copy_parallel(s, (uint8_t*)s->slot[(size_t)k], h_src ? h_src + a : nullptr, fd, fd_off + a, len);
+        if (fd >= 0 && s->io_error.load()) { rc = GCI_E_INVALID; break; }
+        if (forget && h_src) {
             const uintptr_t lo = ((uintptr_t)(h_src + a) + (uintptr_t)page - 1) / (uintptr_t)page * (uintptr_t)page, hi = (uintptr_t)(h_src + a + len) / (uintptr_t)page * (uintptr_t)page;
             if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
         }
@@ -129,6 +141,24 @@ extern "C" int gci_stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, 
     }
     if (urgent) s->urgent--;
     return rc;
+}
+
+// h_src[0, n) -> d_dst[0, n), enqueued on `stream` (a hipStream_t); returns when the last piece is ENQUEUED (its bytes are in a
+// pinned slot by then: the caller may unmap the file).  forget != 0: the pages of h_src are dropped from the process's page table
+// as they have been read (madvise DONTNEED: the page cache keeps the data; see device.py _forget_pages for why).  urgent == 0: the
+// call lets urgent ones go first, piece by piece (the assembly, whose N runs nobody waits for, next to the runs of a BAM file).
+extern "C" int gci_stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, uint64_t n, uint8_t* d_dst, void* stream, int forget, int urgent)
+{
+    if (!ctx || !s || (n && (!h_src || !d_dst))) return GCI_E_INVALID;
+    return stage_send(ctx, s, h_src, -1, 0, n, d_dst, stream, forget, urgent);
+}
+
+// the same from a file descriptor: bytes [offset, offset + n) of `fd` by pread() into the slots -- no mapping, no page faults
+extern "C" int gci_stage_send_fd(gci_ctx* ctx, gci_stage* s, int fd, uint64_t offset, uint64_t n, uint8_t* d_dst, void* stream, int urgent)
+{
+    if (!ctx || !s || fd < 0 || (n && !d_dst)) return GCI_E_INVALID;
+    s->io_error = 0;
+    return stage_send(ctx, s, nullptr, fd, offset, n, d_dst, stream, 0, urgent);
 }
 
 extern "C" int gci_stage_free(gci_stage* s)

@@ -87,6 +87,7 @@ class _Staging:
         # the loop over the slots is the library's (staging.cpp: gci_stage_send) -- the Python one below stays behind GCI_STAGING=python
         self.native = None
         self.engine = engine
+        self._fds = {}
         if engine is not None and os.environ.get("GCI_STAGING", "native") != "python":
             h = ctypes.c_void_p()
             engine._chk(engine.lib.gci_stage_create(engine.ctx, self.SLOT, self.SLOTS, self.THREADS, ctypes.byref(h)), "gci_stage_create")
@@ -117,6 +118,16 @@ class _Staging:
         as they arrive) go first, piece by piece."""
         if self.native is not None:
             if p1 <= p0:
+                return
+            path = getattr(raw, "filename", None)
+            if path is not None and os.environ.get("GCI_STAGING_READ", "mmap") == "pread":
+                # the file's bytes by pread() into the slots (one descriptor per file, kept): no page faults on the mapping
+                fd = self._fds.get(path)
+                if fd is None:
+                    fd = self._fds[path] = os.open(path, os.O_RDONLY)
+                base = int(getattr(raw, "offset", 0))
+                self.engine._chk(self.engine.lib.gci_stage_send_fd(self.engine.ctx, self.native, fd, base + p0, p1 - p0, ctypes.c_void_p(dst.data_ptr()),
+                                                                   ctypes.c_void_p(stream.cuda_stream), 1 if urgent else 0), "gci_stage_send_fd")
                 return
             src = raw.ctypes.data + p0                      # (a numpy array / memmap of uint8: its bytes as they lie)
             forget = 1 if (getattr(raw, "_mmap", None) is not None and os.environ.get("GCI_FORGET_PAGES", "1") != "0") else 0

@@ -500,6 +500,8 @@ int gci_paf_pool_release(gci_ctx* ctx);
 typedef struct gci_stage gci_stage;
 int gci_stage_create(gci_ctx* ctx, uint64_t slot_bytes, int n_slots, int threads, gci_stage** out);
 int gci_stage_send(gci_ctx* ctx, gci_stage* stage, const uint8_t* h_src, uint64_t n, uint8_t* d_dst, void* stream, int forget, int urgent);
+/* ... from a file descriptor: bytes [offset, offset + n) by pread() straight into the pinned slots (no mapping, no page faults) */
+int gci_stage_send_fd(gci_ctx* ctx, gci_stage* stage, int fd, uint64_t offset, uint64_t n, uint8_t* d_dst, void* stream, int urgent);
 int gci_stage_free(gci_stage* stage);
 
 /* ---- N1 on the GPU: BGZF inflate and the BAM record walk (k_inflate.hip; replaces pysam / htslib at GCI.py:150-151) ---------
