@@ -77,11 +77,14 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
     DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_cd, &ctx->tile_carry, &ctx->dense_flag, &ctx->dense_list, &ctx->evp_items, &ctx->evp_hist, &ctx->evp_blk, &ctx->d_tile_valid,
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->part_a, &ctx->part_b, &ctx->part_hist, &ctx->part_blk, &ctx->conflict_table, &ctx->win,
-                      &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items, &ctx->pg_cost, &ctx->pg_scan, &ctx->pg_first, &ctx->route_tab, &ctx->deflate_nruns, &ctx->deflate_runs, &ctx->join_bucket, &ctx->tail_gaps, &ctx->tail_sums, &ctx->crc_tabs, &ctx->inflate_sym, &ctx->inflate_nsym, &ctx->inflate_wstatus, &ctx->inflate_lists, &ctx->inflate_prof, &ctx->inflate_next};
+                      &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items, &ctx->pg_cost, &ctx->pg_scan, &ctx->pg_first, &ctx->route_tab, &ctx->deflate_nruns, &ctx->deflate_runs, &ctx->join_bucket, &ctx->tail_gaps, &ctx->tail_sums, &ctx->crc_tabs, &ctx->inflate_sym, &ctx->inflate_nsym, &ctx->inflate_wstatus, &ctx->inflate_lists, &ctx->inflate_prof, &ctx->inflate_next, &ctx->inflate_sym2, &ctx->inflate_lists2};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : ctx->paf_pool) if (b.p) (void)hipFree(b.p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto* v : {&ctx->prof_live, &ctx->prof_free}) for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (ctx->inflate_stream2) { (void)hipStreamSynchronize(ctx->inflate_stream2); (void)hipStreamDestroy(ctx->inflate_stream2); }
+    if (ctx->inflate_ev_in) (void)hipEventDestroy(ctx->inflate_ev_in);
+    if (ctx->inflate_ev_out) (void)hipEventDestroy(ctx->inflate_ev_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GCI_OK;

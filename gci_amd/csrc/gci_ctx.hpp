@@ -82,7 +82,10 @@ struct gci_ctx {
     DevBuf crc_tabs;                        // k_bgzf_crc: the 32 look-up tables (k_crc_tables), made on first use
     bool crc_tabs_ready = false;            // ... set once k_crc_tables has been launched without an error
     uint32_t inflate_last_n = 0;            // members of the last gci_bgzf_inflate_device call (0: the wave decoder was not used)
-    DevBuf inflate_sym, inflate_nsym, inflate_wstatus, inflate_lists, inflate_prof, inflate_next;   // k_inflate_wave.hip: a batch's symbol streams, per member its symbols and how it fared
+    DevBuf inflate_sym, inflate_nsym, inflate_wstatus, inflate_lists, inflate_prof, inflate_next;
+    DevBuf inflate_sym2, inflate_lists2;    // ... of the batches that run on the second stream
+    hipStream_t inflate_stream2 = nullptr;  // k_inflate_wave.hip: every other batch of members on a stream of its own (made on first use)
+    hipEvent_t inflate_ev_in = nullptr, inflate_ev_out = nullptr;   // k_inflate_wave.hip: a batch's symbol streams, per member its symbols and how it fared
     DevBuf tail_sums;                       // gci_two_type_tail: per-tile sums of the three tracks
     DevBuf tail_gaps;                       // gci_two_type_tail: the N runs as absolute sorted [begin, end) element ranges
     std::vector<int64_t> tail_gaps_host;    // ... what was uploaded last

@@ -655,19 +655,23 @@ extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint
 }
 
 // ---- kernel B ------------------------------------------------------------------------------------------------------------
-constexpr int CP_THREADS = 1024, CP_WAVES = CP_THREADS / 64;
-constexpr uint32_t CP_UNIT = 256;                               // cells a wave handles at a time (four per lane); unit u is wave u % 16's
+#ifndef IW_CP_THREADS
+#define IW_CP_THREADS 1024
+#endif
+constexpr int CP_THREADS = IW_CP_THREADS, CP_WAVES = CP_THREADS / 64;
+constexpr uint32_t CP_UNIT = 256;                               // cells a wave handles at a time (four per lane); unit u is wave u % CP_WAVES's
+constexpr uint32_t CP_UPW = 256u / (uint32_t)CP_WAVES;          // units per wave (65 536 cells = 256 units)
+static_assert(CP_UPW <= 32u && CP_UPW % 4u == 0u, "a wave's units are a 32-bit mask, written four at a time");
 
-extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
-                                                                        uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off,
-                                                                        uint32_t m0, uint8_t* __restrict__ out, uint32_t cut,
-                                                                        unsigned long long* __restrict__ prof)
+// one member (member mb of the batch) by the whole workgroup
+__device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t (*wsum)[CP_WAVES], uint32_t& s_bad, uint32_t mb,
+                                            const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
+                                            uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off,
+                                            uint32_t m0, uint8_t* __restrict__ out, uint32_t cut,
+                                            unsigned long long* __restrict__ prof)
 {
     unsigned long long tb = prof ? __builtin_amdgcn_s_memtime() : 0, t_place = 0, t_res = 0, n_ur = 0, n_rounds = 0;
-    __shared__ uint16_t W[65536];
-    __shared__ uint32_t wsum[2][CP_WAVES];
-    __shared__ uint32_t s_bad;
-    const uint32_t mb = blockIdx.x, m = m0 + mb;
+    const uint32_t m = m0 + mb;
     if (wstatus[m] != ST_OK) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ns = n_sym[m];
@@ -748,14 +752,14 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
     // (plain LDS accesses; the compiler may keep nothing of W in registers from one look at a unit to the next: the barrier below)
     const uint32_t n_units = (isize + CP_UNIT - 1u) / CP_UNIT;
     uint32_t pending = 0;                                               // bit j: unit wave + 16 j
-    for (uint32_t j = 0; j < 16u; j++) if ((uint32_t)wave + 16u * j < n_units) pending |= 1u << j;
+    for (uint32_t j = 0; j < CP_UPW; j++) if ((uint32_t)wave + (uint32_t)CP_WAVES * j < n_units) pending |= 1u << j;
     while (pending) {
         uint32_t next = 0;
         n_rounds++;
         for (uint32_t rest = pending; rest; rest &= rest - 1u) {
             n_ur++;
             const uint32_t j = (uint32_t)__ffs((int)rest) - 1u;
-            const uint32_t i0 = ((uint32_t)wave + 16u * j) * CP_UNIT + (uint32_t)lane;
+            const uint32_t i0 = ((uint32_t)wave + (uint32_t)CP_WAVES * j) * CP_UNIT + (uint32_t)lane;
             __asm__ volatile("" ::: "memory");
             uint32_t v[4], u[4];
 #pragma unroll
@@ -785,8 +789,8 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
     if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_res = n - tb; tb = n; }
     // ---- write: the wave's units, 16 bytes per lane and step (a unit = 16 lanes' worth: four units per step) -----------------------------
     uint8_t* const dst = out + o0;
-    for (uint32_t j = 0; j < 16u; j += 4u) {
-        const uint32_t unit = (uint32_t)wave + 16u * (j + ((uint32_t)lane >> 4));
+    for (uint32_t j = 0; j < CP_UPW; j += 4u) {
+        const uint32_t unit = (uint32_t)wave + (uint32_t)CP_WAVES * (j + ((uint32_t)lane >> 4));
         const uint32_t i = unit * CP_UNIT + 16u * ((uint32_t)lane & 15u);
         if (i >= isize) continue;
         const uint4 a = *reinterpret_cast<const uint4*>(&W[i]), b = *reinterpret_cast<const uint4*>(&W[i + 8]);
@@ -807,13 +811,29 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
     }
 }
 
+// One workgroup per CU for the whole batch (the member's cells take the CU's LDS anyway): the members in strides of the grid, so that
+// no CU waits for a workgroup to be dispatched between two members.
+extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
+                                                                        uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off,
+                                                                        uint32_t m0, uint32_t n_batch, uint8_t* __restrict__ out, uint32_t cut,
+                                                                        unsigned long long* __restrict__ prof)
+{
+    __shared__ uint16_t W[65536];
+    __shared__ uint32_t wsum[2][CP_WAVES];
+    __shared__ uint32_t s_bad;
+    for (uint32_t mb = blockIdx.x; mb < n_batch; mb += gridDim.x) {
+        copy_member(W, wsum, s_bad, mb, sym, n_sym, wstatus, out_off, m0, out, cut, prof);
+        __syncthreads();                                                  // (every wave has written its bytes: the cells are the next member's)
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 // The members of a run in batches of `batch` members (the symbol stream of a batch: batch x 256 KB of scratch): A over the batch,
 // B over the batch.  d_wstatus / d_nsym: one word per member of the run (scratch of the context).
 int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off, uint32_t n_members,
                          uint8_t* d_out, uint64_t out_cap, uint32_t* d_wstatus)
 {
-    static const uint32_t batch_max = [] { const char* e = getenv("GCI_INFLATE_BATCH"); const int v = e ? atoi(e) : 16384; return (uint32_t)(v < 64 ? 64 : v); }();
+    static const uint32_t batch_max = [] { const char* e = getenv("GCI_INFLATE_BATCH"); const int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
     static const int waves_per_cu = [] { const char* e = getenv("GCI_INFLATE_WAVES"); return e ? atoi(e) : 0; }();
     static const uint32_t cut_a = [] { const char* e = getenv("GCI_IW_CUT_A"); return (uint32_t)(e ? atoi(e) : 0); }();   // (measurements)
     static const uint32_t cut_b = [] { const char* e = getenv("GCI_IW_CUT_B"); return (uint32_t)(e ? atoi(e) : 0); }();
@@ -825,7 +845,14 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
         d_prof = (unsigned long long*)ctx->inflate_prof.p;
         HIPCHK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
     }
+    // The members in batches (the symbol streams of a batch: batch x 256 KB of scratch), every other batch on a second stream with
+    // scratch of its own: a wave takes a millisecond per member, so the last members of a batch leave most of the chip idle -- the
+    // other stream's kernels move in as CUs fall free (and the copy kernel of one batch runs beside the decode of the next).
+    static const bool copy_persistent = [] { const char* e = getenv("GCI_INFLATE_COPY_GRID"); return !(e && !strcmp(e, "members")); }();   // (A/B)
+    static const int n_streams = [] { const char* e = getenv("GCI_INFLATE_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 2 ? 2 : v; }();
     const uint32_t batch = n_members < batch_max ? n_members : batch_max;
+    const uint32_t n_batches = (n_members + batch - 1u) / batch;
+    const bool two = n_streams == 2 && n_batches > 1u && !want_prof;
     int st = gci_ensure(ctx, ctx->inflate_sym, (size_t)batch * SYM_STRIDE * sizeof(uint32_t));
     if (st) return st;
     st = gci_ensure(ctx, ctx->inflate_nsym, (size_t)n_members * sizeof(uint32_t));
@@ -837,18 +864,40 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     const uint32_t resident = (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu : 1024);
     st = gci_ensure(ctx, ctx->inflate_lists, (size_t)resident * 64u * MAXS * sizeof(uint32_t));
     if (st) return st;
-    const uint32_t n_batches = (n_members + batch - 1u) / batch;
     st = gci_ensure(ctx, ctx->inflate_next, (size_t)n_batches * sizeof(uint32_t));
     if (st) return st;
     HIPCHK(hipMemsetAsync(ctx->inflate_next.p, 0, (size_t)n_batches * sizeof(uint32_t), ctx->stream));
-    for (uint32_t m0 = 0; m0 < n_members; m0 += batch) {
+    if (two) {
+        st = gci_ensure(ctx, ctx->inflate_sym2, (size_t)batch * SYM_STRIDE * sizeof(uint32_t));
+        if (st) return st;
+        st = gci_ensure(ctx, ctx->inflate_lists2, (size_t)resident * 64u * MAXS * sizeof(uint32_t));
+        if (st) return st;
+        if (!ctx->inflate_stream2) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->inflate_stream2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->inflate_ev_in, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->inflate_ev_out, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ctx->inflate_ev_in, ctx->stream));              // (the inputs, the status words, the counters: ready)
+        HIPCHK(hipStreamWaitEvent(ctx->inflate_stream2, ctx->inflate_ev_in, 0));
+    }
+    uint32_t k = 0;
+    for (uint32_t m0 = 0; m0 < n_members; m0 += batch, k++) {
         const uint32_t nb = n_members - m0 < batch ? n_members - m0 : batch;
-        hipLaunchKernelGGL(k_inflate_symbols, dim3(nb < resident ? nb : resident), dim3(64), 0, ctx->stream, d_raw, d_member_pos, d_out_off, out_cap, m0, nb,
-                           (uint32_t*)ctx->inflate_sym.p, (uint32_t*)ctx->inflate_nsym.p, d_wstatus, (uint32_t*)ctx->inflate_lists.p, (uint32_t*)ctx->inflate_next.p + m0 / batch, cut_a, d_prof);
+        const bool second = two && (k & 1u);
+        hipStream_t sm = second ? ctx->inflate_stream2 : ctx->stream;
+        uint32_t* const symk = (uint32_t*)(second ? ctx->inflate_sym2.p : ctx->inflate_sym.p);
+        uint32_t* const listk = (uint32_t*)(second ? ctx->inflate_lists2.p : ctx->inflate_lists.p);
+        hipLaunchKernelGGL(k_inflate_symbols, dim3(nb < resident ? nb : resident), dim3(64), 0, sm, d_raw, d_member_pos, d_out_off, out_cap, m0, nb,
+                           symk, (uint32_t*)ctx->inflate_nsym.p, d_wstatus, listk, (uint32_t*)ctx->inflate_next.p + k, cut_a, d_prof);
         LAUNCHCHK("k_inflate_symbols");
-        hipLaunchKernelGGL(k_inflate_copy, dim3(nb), dim3(CP_THREADS), 0, ctx->stream, (const uint32_t*)ctx->inflate_sym.p,
-                           (const uint32_t*)ctx->inflate_nsym.p, d_wstatus, d_out_off, m0, d_out, cut_b, d_prof);
+        const uint32_t copy_grid = copy_persistent && cus > 0 ? (nb < (uint32_t)cus ? nb : (uint32_t)cus) : nb;
+        hipLaunchKernelGGL(k_inflate_copy, dim3(copy_grid), dim3(CP_THREADS), 0, sm, (const uint32_t*)symk,
+                           (const uint32_t*)ctx->inflate_nsym.p, d_wstatus, d_out_off, m0, nb, d_out, cut_b, d_prof);
         LAUNCHCHK("k_inflate_copy");
+    }
+    if (two) {
+        HIPCHK(hipEventRecord(ctx->inflate_ev_out, ctx->inflate_stream2));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->inflate_ev_out, 0));       // (the lane decoder and the CRC check behind this: after both)
     }
     if (want_prof) {
         unsigned long long h[16];
