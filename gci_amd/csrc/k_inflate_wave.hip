@@ -75,7 +75,7 @@ struct alignas(16) Canon { uint16_t limit[16]; int16_t off[16]; uint16_t next[16
 
 struct alignas(16) Lds {
     unsigned long long pay[CHUNK_U + TAIL_U];      // the chunk, transposed: unit u of piece k at [(u << 6) | k]; the tail linear behind it
-    uint32_t ckpt[64 * NCK];                       // lane k, grain c at [(c << 6) | k]: (where it stood first in the grain) << 16 | symbols listed by then
+    uint32_t ckpt[64 * (NCK + 1)];                 // lane k, grain c at [(c << 6) | k]: (where it stood first in the grain) << 16 | symbols listed by then; row NCK: writes that are none
     uint16_t lit_tab[1 << LIT_BITS];               // symbol | length << 9; 0 = a longer code
     uint16_t lit_tail[LIT_TAIL];                   // ... of the 15-bit code value c: [c - limit[LIT_BITS]]; 0 = no such code
     uint16_t dist_tab[1 << DIST_BITS];
@@ -358,7 +358,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint
     // (cut: measurements only -- 1 leaves a block behind its tables, 2 behind pass 1, 3 behind the stitch; 0 = the kernel)
     __shared__ Lds S;
     const int lane = threadIdx.x;
-    uint32_t* const list = lists + (size_t)blockIdx.x * (64u * MAXS) + (uint32_t)lane;     // entry i at list[64 i]
+    uint32_t* const list = lists + (size_t)blockIdx.x * (64u * (MAXS + 1u)) + (uint32_t)lane;     // entry i at list[64 i]; row MAXS: writes that are none
     // the members of the batch are handed out one at a time (`next`: a counter the host zeroes): a member takes as long as it takes
     for (;;) {
         __syncthreads();
@@ -455,8 +455,11 @@ extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint
                 if (!ok_l || !ok_d) { st = 12u; break; }
                 const bool fits_l = fill_tables(S.lit_tab, LIT_BITS, S.lit_tail, LIT_TAIL, S.lit_cn, S.lit_sorted, lane);
                 const bool fits_d = fill_tables(S.dist_tab, DIST_BITS, S.dist_tail, DIST_TAIL, S.dist_cn, S.dist_sorted, lane);
-                C.search_l = !fits_l; C.search_d = !fits_d;               // (long codes beyond the tail tables: searched)
-                C.lit_lim = S.lit_cn.limit[LIT_BITS]; C.dist_lim = S.dist_cn.limit[DIST_BITS];
+                // (the same in every lane: said so, and the four live in scalar registers -- a branch on them costs no exec-mask work)
+                C.search_l = __builtin_amdgcn_readfirstlane(fits_l ? 0 : 1) != 0;             // long codes beyond the tail tables: searched
+                C.search_d = __builtin_amdgcn_readfirstlane(fits_d ? 0 : 1) != 0;
+                C.lit_lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lit_cn.limit[LIT_BITS]);
+                C.dist_lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.dist_cn.limit[DIST_BITS]);
             }
             if (cut == 1u) { st = ST_LANES; break; }
             IW_T(t_hdr, tt);
@@ -487,7 +490,8 @@ extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint
                     while (R.p < pend) {
                         const unsigned long long n3 = R.ahead(S);
                         const uint32_t rel = R.p - (uint32_t)lane * PIECE, g = rel >> GRAIN_LOG2;
-                        if (g != grain) { S.ckpt[(g << 6) | (uint32_t)lane] = (rel << 16) | os; grain = g; }
+                        S.ckpt[((g != grain ? g : NCK) << 6) | (uint32_t)lane] = (rel << 16) | os;     // (no branch: a step in a grain it has noted writes the spare row)
+                        grain = g;
                         const Sym s = step(S, C, R, nb);
                         if (__ballot(s.kind == 2u)) {                      // (rare: the whole wave skips this)
                             if (s.kind == 2u) {
@@ -496,10 +500,10 @@ extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint
                                 n_eb++;
                             }
                         }
-                        if (s.kind < 2u) {
-                            if (os < MAXS && cut != 6u) list[64u * os] = s.entry;      // (a share that reaches beyond the list is caught below)
-                            os++;
-                        }
+                        // (no branch: what is no symbol, or lies beyond the list, goes to the spare row; a share that reaches beyond the list
+                        // is caught below)
+                        list[64u * (s.kind < 2u && os < MAXS ? os : MAXS)] = s.entry;
+                        os += s.kind < 2u ? 1u : 0u;
                         R.advance(s.used, n3);
                     }
                 }
@@ -711,6 +715,7 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t (
         if (run + total > isize) { bad = true; break; }                   // (uniform)
         uint32_t dst = run + woff + inc - tl;
         // literals and the first cells of a match by its own lane; what lies behind the eighth cell by the whole wave, match by match
+        // (eight stores without a branch and a hand-over per symbol were tried: 2 % slower -- short matches pay for stores they do not need)
         uint32_t long_dst = 0, long_len = 0, long_dist = 0;               // (at most one of a thread's four is taken over: the others stay inline)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -833,7 +838,7 @@ extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const ui
 int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off, uint32_t n_members,
                          uint8_t* d_out, uint64_t out_cap, uint32_t* d_wstatus)
 {
-    static const uint32_t batch_max = [] { const char* e = getenv("GCI_INFLATE_BATCH"); const int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
+    static const uint32_t batch_max = [] { const char* e = getenv("GCI_INFLATE_BATCH"); const int v = e ? atoi(e) : 16384; return (uint32_t)(v < 64 ? 64 : v); }();
     static const int waves_per_cu = [] { const char* e = getenv("GCI_INFLATE_WAVES"); return e ? atoi(e) : 0; }();
     static const uint32_t cut_a = [] { const char* e = getenv("GCI_IW_CUT_A"); return (uint32_t)(e ? atoi(e) : 0); }();   // (measurements)
     static const uint32_t cut_b = [] { const char* e = getenv("GCI_IW_CUT_B"); return (uint32_t)(e ? atoi(e) : 0); }();
@@ -862,7 +867,7 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_symbols, 64, 0));
     if (waves_per_cu > 0 && waves_per_cu < per_cu) per_cu = waves_per_cu;
     const uint32_t resident = (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu : 1024);
-    st = gci_ensure(ctx, ctx->inflate_lists, (size_t)resident * 64u * MAXS * sizeof(uint32_t));
+    st = gci_ensure(ctx, ctx->inflate_lists, (size_t)resident * 64u * (MAXS + 1u) * sizeof(uint32_t));
     if (st) return st;
     st = gci_ensure(ctx, ctx->inflate_next, (size_t)n_batches * sizeof(uint32_t));
     if (st) return st;
@@ -870,7 +875,7 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     if (two) {
         st = gci_ensure(ctx, ctx->inflate_sym2, (size_t)batch * SYM_STRIDE * sizeof(uint32_t));
         if (st) return st;
-        st = gci_ensure(ctx, ctx->inflate_lists2, (size_t)resident * 64u * MAXS * sizeof(uint32_t));
+        st = gci_ensure(ctx, ctx->inflate_lists2, (size_t)resident * 64u * (MAXS + 1u) * sizeof(uint32_t));
         if (st) return st;
         if (!ctx->inflate_stream2) {
             HIPCHK(hipStreamCreateWithFlags(&ctx->inflate_stream2, hipStreamNonBlocking));
