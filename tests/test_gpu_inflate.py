@@ -78,6 +78,51 @@ def test_the_wave_decoder_takes_the_members_and_hands_back_what_it_cannot_list(e
     assert st["decoded"] == 2 and sum(v for k, v in st.items() if k not in ("decoded", "not tried")) == 1, st
 
 
+def test_many_small_batches_on_two_streams(tmp_path):
+    """The host side of the wave inflate with its knobs turned down: batches of 64 members alternating between two streams (scratch of
+    their own), the copy kernel's workgroups looping over a batch, members handed out by a counter per batch -- 1 500 members of every
+    flavour and size in a process of its own (the knobs are read once per process), equal to zlib's bytes; and the same with one stream
+    and the lane decoder alone."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, zlib, struct, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_gpu_inflate import member\n"
+        "from gci_amd import hostio, synth\n"
+        "from gci_amd.device import Engine\n"
+        "from gci_amd.formats import bgzf\n"
+        "rng = np.random.default_rng(7)\n"
+        "lut = synth._hifi_qual_lut()\n"
+        "members, want = [], []\n"
+        "for i in range(1500):\n"
+        "    n = int(rng.choice([0, 1, 17, 300, 5000, 30000, 65000]))\n"
+        "    kind = i %% 4\n"
+        "    p = (lut[rng.integers(0, 256, n, dtype=np.uint8)].tobytes() if kind == 0 else rng.integers(0, 256, n, dtype=np.uint8).tobytes() if kind == 1\n"
+        "         else (b'chr7\\t1234\\tACGT' * (n // 14 + 1))[:n] if kind == 2 else bytes(n))\n"
+        "    kw = [dict(level=1), dict(level=6), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED), dict(level=9, mem_level=1)][i %% 5]\n"
+        "    try:\n"
+        "        members.append(member(p, **kw)); want.append(p)\n"
+        "    except AssertionError:\n"
+        "        pass\n"
+        "raw = np.frombuffer(b''.join(members) + bgzf.BGZF_EOF, dtype=np.uint8)\n"
+        "pos, isz = hostio.bgzf_blocks(raw)\n"
+        "e = Engine(0)\n"
+        "got = e.bgzf_inflate(raw, pos, isz).cpu().numpy().tobytes()\n"
+        "assert got == b''.join(want), 'inflate differs'\n"
+        "print('members', len(members), e.inflate_stats())\n" % (root, os.path.join(root, "tests")))
+    for env in (dict(GCI_INFLATE_BATCH="64", GCI_INFLATE_STREAMS="2"), dict(GCI_INFLATE_BATCH="200", GCI_INFLATE_STREAMS="1", GCI_INFLATE_COPY_GRID="members"),
+                dict(GCI_INFLATE="lane")):
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        assert "members" in r.stdout
+        if "GCI_INFLATE" not in env:
+            assert "'decoded': 0" not in r.stdout and "'not tried': 0" in r.stdout, r.stdout
+
+
 def test_match_shapes(engine):
     """Every way a match is copied: periods 1 .. 7 and distances 8 .. 40 against lengths 3 .. 258, at the start of a
     member, in its middle and ending exactly at its end (where the 8-byte stores must not run over into the next member)."""
