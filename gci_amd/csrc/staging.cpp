@@ -22,23 +22,26 @@ struct gci_stage {
     std::vector<void*> slot;
     std::vector<hipEvent_t> ev;
     std::vector<char> used;
-    int next = 0;
-    std::mutex piece;                       // a piece (one slot's worth) at a time: two senders take slots in turns
+    std::mutex ring;                        // a send (or a stretch of a non-urgent one) has the ring to itself
     std::atomic<int> urgent{0};
-    // the copying threads
+    // the copying threads and the send they work for: tasks = (piece, part), taken from a counter -- a thread that is done with its
+    // part of one piece goes on to the next piece (into the next slot) without waiting for the others
     std::vector<std::thread> workers;
     std::mutex m;
-    std::condition_variable go, done;
+    std::condition_variable go, filled, room;
     const uint8_t* src = nullptr;          // a mapping ... or
     int fd = -1;                            // ... a descriptor read with pread (no page faults on a mapping: the kernel copies out of the page cache itself)
-    uint64_t fd_off = 0;
-    uint8_t* dst = nullptr;
-    size_t n = 0, step = 0;
-    std::atomic<int> io_error{0};
-    std::atomic<size_t> part{0};
+    uint64_t fd_off = 0, n = 0;
+    size_t part_bytes = 0;
+    uint64_t n_pieces = 0, parts_per_piece = 1;
+    std::atomic<uint64_t> next_task{0};
+    uint64_t n_tasks = 0;
+    std::vector<int> remaining;             // per piece: parts not yet copied (under m)
+    uint64_t fill_allowed = 0;              // pieces [0, fill_allowed) may be written into their slots (under m)
     int busy = 0;
     uint64_t gen = 0;
     bool stop = false;
+    std::atomic<int> io_error{0};
 };
 
 namespace {
@@ -54,39 +57,32 @@ void worker(gci_stage* s)
             seen = s->gen;
         }
         for (;;) {
-            const size_t at = s->part.fetch_add(1) * s->step;
-            if (at >= s->n) break;
-            const size_t len = std::min(s->step, s->n - at);
-            if (s->fd < 0) memcpy(s->dst + at, s->src + at, len);
-            else {
-                for (size_t got = 0; got < len;) {
-                    const ssize_t r = pread(s->fd, s->dst + at + got, len - got, (off_t)(s->fd_off + at + got));
-                    if (r <= 0) { s->io_error = 1; break; }
-                    got += (size_t)r;
+            const uint64_t task = s->next_task.fetch_add(1);
+            if (task >= s->n_tasks) break;
+            const uint64_t piece = task / s->parts_per_piece, part = task % s->parts_per_piece;
+            {
+                std::unique_lock<std::mutex> lk(s->m);                     // its slot must be free (the copy of the piece that had it: over)
+                s->room.wait(lk, [&] { return piece < s->fill_allowed; });
+            }
+            const uint64_t p0 = piece * (uint64_t)s->slot_bytes, p1 = std::min<uint64_t>(s->n, p0 + s->slot_bytes);
+            const uint64_t a = p0 + part * (uint64_t)s->part_bytes, b = std::min<uint64_t>(p1, a + s->part_bytes);
+            if (a < b) {
+                uint8_t* dst = (uint8_t*)s->slot[(size_t)(piece % (uint64_t)s->n_slots)] + (a - p0);
+                if (s->fd < 0) memcpy(dst, s->src + a, (size_t)(b - a));
+                else {
+                    for (uint64_t got = 0; got < b - a;) {
+                        const ssize_t r = pread(s->fd, dst + got, (size_t)(b - a - got), (off_t)(s->fd_off + a + got));
+                        if (r <= 0) { s->io_error = 1; break; }
+                        got += (uint64_t)r;
+                    }
                 }
             }
+            std::lock_guard<std::mutex> lk(s->m);
+            if (--s->remaining[(size_t)piece] == 0) s->filled.notify_all();
         }
         std::lock_guard<std::mutex> lk(s->m);
-        if (--s->busy == 0) s->done.notify_one();
+        if (--s->busy == 0) s->filled.notify_all();
     }
-}
-
-// src[0, n) -> dst by all the threads; returns when the last byte is there
-void copy_parallel(gci_stage* s, uint8_t* dst, const uint8_t* src, int fd, uint64_t fd_off, size_t n)
-{
-    const size_t T = (size_t)s->threads;
-    size_t step = (n + T - 1) / T;
-    step = (step + 4095) / 4096 * 4096;
-    {
-        std::lock_guard<std::mutex> lk(s->m);
-        s->src = src; s->fd = fd; s->fd_off = fd_off; s->dst = dst; s->n = n; s->step = step;
-        s->part = 0;
-        s->busy = (int)s->workers.size();
-        s->gen++;
-    }
-    s->go.notify_all();
-    std::unique_lock<std::mutex> lk(s->m);
-    s->done.wait(lk, [&] { return s->busy == 0; });
 }
 
 }  // namespace
@@ -109,35 +105,86 @@ extern "C" int gci_stage_create(gci_ctx* ctx, uint64_t slot_bytes, int n_slots, 
     return GCI_OK;
 }
 
-// h_src[0, n) -> d_dst[0, n), enqueued on `stream` (a hipStream_t); returns when the last piece is ENQUEUED (its bytes are in a
-// pinned slot by then: the caller may unmap the file).  forget != 0: the pages of h_src are dropped from the process's page table
-// as they have been read (madvise DONTNEED: the page cache keeps the data; see device.py _forget_pages for why).  urgent == 0: the
-// call lets urgent ones go first, piece by piece (the assembly, whose N runs nobody waits for, next to the runs of a BAM file).
+static int stage_stretch(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, int fd, uint64_t fd_off, uint64_t n, uint8_t* d_dst, hipStream_t stream, int forget)
+{
+    const uint64_t S = (uint64_t)s->n_slots;
+    for (int k = 0; k < s->n_slots; k++) {
+        if (!s->slot[(size_t)k] && hipHostMalloc(&s->slot[(size_t)k], s->slot_bytes, hipHostMallocDefault) != hipSuccess)
+            return gci_fail(ctx, hipGetLastError(), "hipHostMalloc (staging slot)");
+        if (s->used[(size_t)k]) {                                            // (a slot an earlier send left on the bus)
+            if (hipEventSynchronize(s->ev[(size_t)k]) != hipSuccess) return gci_fail(ctx, hipGetLastError(), "hipEventSynchronize (staging slot)");
+            s->used[(size_t)k] = 0;
+        }
+    }
+    const long page = sysconf(_SC_PAGESIZE);
+    const uint64_t pieces = (n + s->slot_bytes - 1) / s->slot_bytes;
+    size_t part = (s->slot_bytes + 7) / 8;                                   // eight parts per piece (8 MB of a 64 MB slot)
+    part = (part + 4095) / 4096 * 4096;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        s->src = h_src; s->fd = fd; s->fd_off = fd_off; s->n = n; s->part_bytes = part;
+        s->n_pieces = pieces; s->parts_per_piece = (s->slot_bytes + part - 1) / part;
+        s->n_tasks = pieces * s->parts_per_piece;
+        s->remaining.assign((size_t)pieces, (int)s->parts_per_piece);
+        s->fill_allowed = std::min<uint64_t>(pieces, S);
+        s->next_task = 0;
+        s->busy = (int)s->workers.size();
+        s->io_error = 0;
+        s->gen++;
+    }
+    s->go.notify_all();
+    int rc = GCI_OK;
+    for (uint64_t p = 0; p < pieces; p++) {
+        {
+            std::unique_lock<std::mutex> lk(s->m);
+            s->filled.wait(lk, [&] { return s->remaining[(size_t)p] == 0; });
+        }
+        const uint64_t a = p * (uint64_t)s->slot_bytes;
+        const size_t len = (size_t)std::min<uint64_t>(s->slot_bytes, n - a);
+        const size_t k = (size_t)(p % S);
+        if (rc == GCI_OK && fd >= 0 && s->io_error.load()) rc = GCI_E_INVALID;
+        if (rc == GCI_OK && forget && h_src) {
+            const uintptr_t lo = ((uintptr_t)(h_src + a) + (uintptr_t)page - 1) / (uintptr_t)page * (uintptr_t)page, hi = (uintptr_t)(h_src + a + len) / (uintptr_t)page * (uintptr_t)page;
+            if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+        }
+        if (rc == GCI_OK && (hipMemcpyAsync(d_dst + a, s->slot[k], len, hipMemcpyHostToDevice, stream) != hipSuccess || hipEventRecord(s->ev[k], stream) != hipSuccess))
+            rc = gci_fail(ctx, hipGetLastError(), "hipMemcpyAsync (staging slot)");
+        if (rc == GCI_OK) s->used[k] = 1;
+        // the slot of piece p - (S - 2) is wanted by piece p + 2: wait for the copy that reads it (two copies stay in flight behind it)
+        if (p + 2 >= S && p + 2 < pieces + 0 + 0 && p + 2 - S < pieces) {
+            const uint64_t q = p + 2 - S;
+            if (rc == GCI_OK && s->used[(size_t)(q % S)] && hipEventSynchronize(s->ev[(size_t)(q % S)]) != hipSuccess)
+                rc = gci_fail(ctx, hipGetLastError(), "hipEventSynchronize (staging slot)");
+            std::lock_guard<std::mutex> lk(s->m);
+            s->fill_allowed = std::max<uint64_t>(s->fill_allowed, std::min<uint64_t>(pieces, q + S + 1));
+            s->room.notify_all();
+        } else if (rc != GCI_OK) {
+            std::lock_guard<std::mutex> lk(s->m);                            // (an error: let the threads run out)
+            s->fill_allowed = pieces;
+            s->room.notify_all();
+        }
+    }
+    {
+        std::unique_lock<std::mutex> lk(s->m);
+        s->fill_allowed = pieces;
+        s->room.notify_all();
+        s->filled.wait(lk, [&] { return s->busy == 0; });
+    }
+    return rc;
+}
+
 static int stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, int fd, uint64_t fd_off, uint64_t n, uint8_t* d_dst, void* stream, int forget,
                       int urgent)
 {
     if (urgent) s->urgent++;
     int rc = GCI_OK;
-    const long page = sysconf(_SC_PAGESIZE);
-    for (uint64_t a = 0; a < n && rc == GCI_OK; a += s->slot_bytes) {
-        const size_t len = (size_t)std::min<uint64_t>(s->slot_bytes, n - a);
+    // an urgent send takes the ring for all of its bytes; one that is not goes in stretches of four slots and lets urgent ones in between
+    const uint64_t stretch = urgent ? n : 4ull * (uint64_t)s->slot_bytes;
+    for (uint64_t a = 0; a < n && rc == GCI_OK; a += stretch) {
         while (!urgent && s->urgent.load() > 0) usleep(300);
-        std::lock_guard<std::mutex> lk(s->piece);
-        const int k = s->next;
-        s->next = (k + 1) % s->n_slots;
-        if (!s->slot[(size_t)k]) {
-            if (hipHostMalloc(&s->slot[(size_t)k], s->slot_bytes, hipHostMallocDefault) != hipSuccess) { rc = gci_fail(ctx, hipGetLastError(), "hipHostMalloc (staging slot)"); break; }
-        }
-        if (s->used[(size_t)k] && hipEventSynchronize(s->ev[(size_t)k]) != hipSuccess) { rc = gci_fail(ctx, hipGetLastError(), "hipEventSynchronize (staging slot)"); break; }
-        copy_parallel(s, (uint8_t*)s->slot[(size_t)k], h_src ? h_src + a : nullptr, fd, fd_off + a, len);
-        if (fd >= 0 && s->io_error.load()) { rc = GCI_E_INVALID; break; }
-        if (forget && h_src) {
-            const uintptr_t lo = ((uintptr_t)(h_src + a) + (uintptr_t)page - 1) / (uintptr_t)page * (uintptr_t)page, hi = (uintptr_t)(h_src + a + len) / (uintptr_t)page * (uintptr_t)page;
-            if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
-        }
-        if (hipMemcpyAsync(d_dst + a, s->slot[(size_t)k], len, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
-            hipEventRecord(s->ev[(size_t)k], (hipStream_t)stream) != hipSuccess) { rc = gci_fail(ctx, hipGetLastError(), "hipMemcpyAsync (staging slot)"); break; }
-        s->used[(size_t)k] = 1;
+        std::lock_guard<std::mutex> lk(s->ring);
+        const uint64_t len = std::min<uint64_t>(stretch, n - a);
+        rc = stage_stretch(ctx, s, h_src ? h_src + a : nullptr, fd, fd_off + a, len, d_dst + a, (hipStream_t)stream, forget);
     }
     if (urgent) s->urgent--;
     return rc;
@@ -157,7 +204,6 @@ extern "C" int gci_stage_send(gci_ctx* ctx, gci_stage* s, const uint8_t* h_src, 
 extern "C" int gci_stage_send_fd(gci_ctx* ctx, gci_stage* s, int fd, uint64_t offset, uint64_t n, uint8_t* d_dst, void* stream, int urgent)
 {
     if (!ctx || !s || fd < 0 || (n && !d_dst)) return GCI_E_INVALID;
-    s->io_error = 0;
     return stage_send(ctx, s, nullptr, fd, offset, n, d_dst, stream, 0, urgent);
 }
 
