@@ -495,7 +495,7 @@ extern "C" int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const
         const uint32_t* d_done = nullptr;
         ctx->inflate_last_n = 0;
         if (wave) {
-            int st = gci_ensure(ctx, ctx->inflate_wstatus, (size_t)n_members * sizeof(uint32_t));
+            int st = gci_ensure(ctx, ctx->inflate_wstatus, (size_t)(n_members > 2048u && n_members < 262144u ? 262144u : n_members) * sizeof(uint32_t));
             if (st) return st;
             HIPCHK(hipMemsetAsync(ctx->inflate_wstatus.p, 0xFF, (size_t)n_members * sizeof(uint32_t), ctx->stream));
             st = gci_inflate_wave_run(ctx, d_raw, d_member_pos, d_out_off, n_members, d_out, out_cap, (uint32_t*)ctx->inflate_wstatus.p);
