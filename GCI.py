@@ -4,6 +4,8 @@ the work is done by the gfx950 HIP path in gci_amd/ -- see gci_amd/cli.py."""
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (gci_amd/__init__.py says why; here as well: the runtime is woken below, before that import)
+
 
 def _wake_the_gpu():
     """The HIP runtime's own start (driver, device, primary context: a few tenths of a second without the interpreter) on a

@@ -854,7 +854,14 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     // scratch of its own: a wave takes a millisecond per member, so the last members of a batch leave most of the chip idle -- the
     // other stream's kernels move in as CUs fall free (and the copy kernel of one batch runs beside the decode of the next).
     static const bool copy_persistent = [] { const char* e = getenv("GCI_INFLATE_COPY_GRID"); return !(e && !strcmp(e, "members")); }();   // (A/B)
-    static const int n_streams = [] { const char* e = getenv("GCI_INFLATE_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 2 ? 2 : v; }();
+    // (two streams only in a process whose runtime has hardware queues to spare -- GPU_MAX_HW_QUEUES >= 8, which gci_amd sets --: with the
+    // default four, the second stream came to share a queue with the host's copy stream and every upload waited for an inflate)
+    static const int n_streams = [] {
+        const char* e = getenv("GCI_INFLATE_STREAMS");
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int v = e ? atoi(e) : (q && atoi(q) >= 8 ? 2 : 1);
+        return v < 1 ? 1 : v > 2 ? 2 : v;
+    }();
     const uint32_t batch = n_members < batch_max ? n_members : batch_max;
     const uint32_t n_batches = (n_members + batch - 1u) / batch;
     const bool two = n_streams == 2 && n_batches > 1u && !want_prof;

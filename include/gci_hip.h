@@ -515,6 +515,9 @@ int gci_stage_free(gci_stage* stage);
  * buffer is the window).  Every member's length and -- check_crc != 0, by a further kernel, one wave per member -- CRC-32 are
  * verified.  d_raw must be readable for 8 bytes past its last member (the decoders fetch whole aligned words).
  * *d_status: min over failing members of (member << 8 | -status), UINT64_MAX if none (decode with gci_decode_status).
+ * Every other batch of members runs on a second stream of the context's own when the process's HIP runtime has hardware queues to
+ * spare (GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the runtime starts; the default four are shared by all streams of a process,
+ * and a copy stream that shares one with the inflate waits for it); GCI_INFLATE_STREAMS=1|2 overrides.
  * gci_bgzf_inflate_last_stats (synchronises): how the members of the context's LAST gci_bgzf_inflate_device call fared with the
  * wave decoder -- h_counts[0] decoded, [1] header not taken, [2] no meeting point, [3] end-of-block codes on wrong paths,
  * [4] undecodable / copies, [5] length, [6] lanes, [7] not tried (GCI_INFLATE=lane); [1 .. 6] went to the lane decoder.

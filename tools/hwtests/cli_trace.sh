@@ -1,19 +1,21 @@
-# the per-run timeline of the ingestion (GCI_PHASES_TRACE=1) of the command line on two 0.3-genome BAMs: uploads against device stages
+# the per-run timeline of the ingestion (GCI_PHASES_TRACE=1) of the command line on two BAMs at a scale of the genome, under variants of
+# the environment (GCI_TRACE_AB: JSON list of [label, {env}]): per variant the median rate of the uploads behind the first of a file
 mkdir -p /root/repo/gpurun_out/$1
 cd /root/repo
-GCI_EXP_PROFILE=1 GCI_EXP_NO_ROCPROF=1 GCI_PHASES_TRACE=1 GCI_EXP_SAVE=/tmp/ph GCI_EXP_AB='[["traced", {}]]' timeout 500 python tools/exp_cli_genome.py ${2:-0.3} 2>&1 | grep -E "rc [0-9]+ wall" | cut -c1-300
+AB=${GCI_TRACE_AB:-'[["traced", {}]]'}
+GCI_EXP_PROFILE=1 GCI_EXP_NO_ROCPROF=1 GCI_PHASES_TRACE=1 GCI_EXP_SAVE=/tmp/ph GCI_EXP_AB="$AB" timeout 560 python tools/exp_cli_genome.py ${2:-0.3} 2>&1 | grep -E "rc [0-9]+ wall" | cut -c1-330
 python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("/tmp/ph/phases_traced.json")):
+import json,glob,statistics
+for f in sorted(glob.glob("/tmp/ph/phases_*.json")):
     d=json.load(open(f))
     tr=d["notes"].get("trace",[])
     ups=[t for t in tr if t[0]=="upload"]
     gt=d.get("gpu_trace",[])
     inf=[g for g in gt if g[0].startswith("bgzf_inflate")]
-    print("run: upload begin end GB/s | inflate begin end")
-    for k,u in enumerate(ups):
-        i=inf[k] if k < len(inf) else ["",0,0]
-        print("%2d  %.3f %.3f %5.1f | %.3f %.3f" % (u[1], u[2], u[3], u[4]/1e9/max(1e-9,u[3]-u[2]), i[1], i[2]))
-    others=[t for t in tr if t[0]!="upload"][:12]
-    print("other trace kinds:", sorted({t[0] for t in tr}))
+    rates=[u[4]/1e9/max(1e-9,u[3]-u[2]) for u in ups if u[1] not in (0,) and u[4] > 2e9]
+    durs=[u[3]-u[2] for u in ups if u[1] not in (0,) and u[4] > 2e9]
+    idur=[g[2]-g[1] for g in inf if g[2]-g[1] > 0.03]
+    print("%-40s uploads behind the first: median %.1f GB/s (%.3f s per run of %.2f GB); inflate per run median %.3f s; first runs %s GB/s" % (
+        f.split("phases_")[1][:-5], statistics.median(rates) if rates else 0, statistics.median(durs) if durs else 0, ups[1][4]/1e9 if len(ups)>1 else 0,
+        statistics.median(idur) if idur else 0, ["%.0f" % (u[4]/1e9/max(1e-9,u[3]-u[2])) for u in ups if u[1]==0]))
 PY

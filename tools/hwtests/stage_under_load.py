@@ -7,7 +7,7 @@ import numpy as np, torch
 from gci_amd import synth, hostio
 from gci_amd.device import Engine
 from gci_amd.formats import bam as bamfmt
-rs = synth.simulate_reads((("chr19", int(61_707_364 * 0.25)),), 40, "hifi", seed=synth.seed_for(2, 0))
+rs = synth.simulate_reads((("chr19", int(61_707_364 * float(sys.argv[1]) if len(sys.argv) > 1 else 15_426_841)),), 40, "hifi", seed=synth.seed_for(2, 0))
 stream, _ = synth.to_bam_stream(rs, seq_qual="random", seed=7)
 pb = os.path.join(tempfile.mkdtemp(), "x.bam"); bamfmt.write_bam_stream(pb, stream, level=1, threads=hostio.default_threads())
 raw = np.fromfile(pb, dtype=np.uint8); pos, isz = hostio.bgzf_blocks(raw)
