@@ -1117,12 +1117,13 @@ def survey_window_step(eng, w, steps):
 
 def cli_shaped_step(eng, w, steps):
     """The step as the command line runs it (GCI.py:99-143 through gci_amd/pipeline.py): no decimal text in HBM -- `.depth.gz`
-    leaves the device as the gzip members the GPU writes from the track (gci_depth_deflate_*), D2H of those members included.
+    leaves the device as the gzip members the GPU writes from the build's run lists (gci_depth_deflate_*), D2H of those members included.
     The headline step keeps the text (the harder output)."""
     import torch
     o = w.opts
     keep = o.want_text
     o.want_text = 0
+    o.want_runs = 1                      # as pipeline.filter asks when the members come from the device
     try:
         def one():
             chk, lib, ctx = eng._chk, eng.lib, eng.ctx
@@ -1139,14 +1140,15 @@ def cli_shaped_step(eng, w, steps):
         dt = (time.perf_counter() - t0) / steps
     finally:
         o.want_text = keep
+        o.want_runs = 0
     L = int(sum(w.own_lengths))
     members = int(sum(len(b) for b in blobs))
     algo = w.step_algorithmic_bytes()
-    total = algo["k1_record_filter"] + algo["name_join"] + 28 * algo["intervals"] + 4 * L + 2 * 4 * L + members
+    total = algo["k1_record_filter"] + algo["name_join"] + 28 * algo["intervals"] + 4 * L + 8 * 24 * (L // 4096) + members
     return {"ms_per_step": dt * 1e3, "gbases_per_s": w.aligned_bases / dt / 1e9, "depth_gz_member_bytes": members,
             "algorithmic_bytes_per_step": total, "hbm_frac": total / dt / 1e9 / HBM_PEAK_GBS,
-            "note": "filter x2 -> join -> depth build without text -> .depth.gz members written by the GPU from the track (two reads "
-                    "of it) and copied to the host"}
+            "note": "filter x2 -> join -> depth build without text -> .depth.gz members written by the GPU from the run lists the "
+                    "build keeps (gci_build_opts.want_runs: the track is written once and not read) and copied to the host"}
 
 
 def two_in_flight(eng, w, args, device_index):

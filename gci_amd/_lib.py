@@ -43,7 +43,7 @@ class Window(ctypes.Structure):
 class BuildOpts(ctypes.Structure):
     _fields_ = [("flank", c_int), ("want_text", c_int), ("d_contig_text_off", c_void_p), ("d_sums", c_void_p),
                 ("d_n_keys", c_void_p), ("d_keys", c_void_p), ("key_cap", c_uint32), ("issue_flank", c_int),
-                ("lo", c_double), ("hi", c_double), ("counted", c_int)]
+                ("lo", c_double), ("hi", c_double), ("counted", c_int), ("want_runs", c_int)]
 
 
 # every symbol include/gci_hip.h declares: (name, restype, argtypes)

@@ -77,7 +77,7 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
     DevBuf* bufs[] = {&ctx->d_len, &ctx->d_off, &ctx->d_tile_first, &ctx->tile_cd, &ctx->tile_carry, &ctx->dense_flag, &ctx->dense_list, &ctx->evp_items, &ctx->evp_hist, &ctx->evp_blk, &ctx->d_tile_valid,
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->part_a, &ctx->part_b, &ctx->part_hist, &ctx->part_blk, &ctx->conflict_table, &ctx->win,
-                      &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items, &ctx->pg_cost, &ctx->pg_scan, &ctx->pg_first, &ctx->route_tab, &ctx->deflate_nruns, &ctx->deflate_runs, &ctx->join_bucket, &ctx->tail_gaps, &ctx->tail_sums, &ctx->crc_tabs, &ctx->inflate_sym, &ctx->inflate_nsym, &ctx->inflate_wstatus, &ctx->inflate_lists, &ctx->inflate_prof, &ctx->inflate_next, &ctx->inflate_sym2, &ctx->inflate_lists2};
+                      &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items, &ctx->pg_cost, &ctx->pg_scan, &ctx->pg_first, &ctx->route_tab, &ctx->deflate_nruns, &ctx->deflate_runs, &ctx->deflate_tab, &ctx->build_nruns, &ctx->build_runs, &ctx->join_bucket, &ctx->tail_gaps, &ctx->tail_sums, &ctx->crc_tabs, &ctx->inflate_sym, &ctx->inflate_nsym, &ctx->inflate_wstatus, &ctx->inflate_lists, &ctx->inflate_prof, &ctx->inflate_next, &ctx->inflate_sym2, &ctx->inflate_lists2};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (DevBuf& b : ctx->paf_pool) if (b.p) (void)hipFree(b.p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -235,6 +235,7 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(tiles + 1) * 8, ctx->stream));
     ctx->cd_state = 0;
     ctx->build_pending = false;
+    ctx->build_runs_track = nullptr;
     return GCI_OK;
 }
 

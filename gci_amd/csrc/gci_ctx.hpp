@@ -21,6 +21,9 @@
 #define BLOCK 256
 static_assert(TILE == BLOCK * 16, "a tile is 16 elements per thread");
 
+constexpr int GCI_RUN_MAX = 64;                  // run lists of a tile (k_tile_build / k_depth_runs -> k_depth_deflate): entries per tile
+constexpr uint32_t GCI_RUNS_WALK = 0xFFFFFFFFu;  // ... "not listed: walk the track"
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -60,12 +63,18 @@ struct gci_ctx {
     uint32_t build_max_n = 0;               // capacity the pending begin() was issued with
     int build_flank = 0;
     bool build_pending = false, build_text = false;
+    bool build_runs_wanted = false;         // gci_build_opts.want_runs of the pending build
+    DevBuf build_nruns, build_runs;         // ... per tile of the layout its constant-depth runs, as k_tile_build saw them
+    const void* build_runs_track = nullptr; // ... and the track they describe (nullptr: none; cleared by whatever writes a track)
     // join scratch
     DevBuf join_table, join_last, join_hq;
     DevBuf join_bucket;                     // partitioned join: per bucket its survivor count, first slot and output offset
     DevBuf part_a, part_b, part_hist, part_blk;   // partitioned join: entry ping-pong, histograms + segment table, scan totals
     DevBuf route_tab;                       // gci_route_*: per (part, chunk) counts and their scan
     DevBuf deflate_nruns, deflate_runs;     // gci_depth_deflate_*: per tile its constant-depth runs (k_depth_runs)
+    DevBuf deflate_tab;                     // ... the CRC tables of the size pass (k_deflate.hip: host_crc_tab)
+    bool deflate_tab_ready = false;
+    bool deflate_from_build = false;        // ... the last size call took the lists of the build (build_runs) instead
     uint32_t deflate_members = 0;           // ... of the members the last size call measured,
     const void* deflate_key_depth = nullptr;    // ... over this track
     const void* deflate_key_elem = nullptr;     // ... and this member table (the write call reuses the lists only for the same three)

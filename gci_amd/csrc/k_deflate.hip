@@ -78,11 +78,14 @@ __device__ __forceinline__ CrcPair crc_line(const Line& l)
     return {c ^ 0xFFFFFFFFu, x};
 }
 
-// n >= 1 copies of a line of w bytes behind a string.  With X = x^(8 w) the pair of n copies is (c * G_n, X^n), G_n = 1 + X + ... +
-// X^(n - 1) -- which depends on w and n only: G_(a + b) = G_a * X^b + G_b, so G_n and X^n are put together from the entries
-// for the set bits of n of a table of (X^(2^k), G_(2^k)) per line width, made when the translation unit is compiled.  Two products
-// per set bit and three to apply the result, where squaring (c, X) bit by bit took four per bit of n: the size pass of the members
-// was bound by exactly this arithmetic.
+// n >= 1 copies of a line of w bytes behind a string.  With X = x^(8 w) the CRC of n copies behind a string of CRC c is
+// c * X^n + line_crc * G_n, G_n = 1 + X + ... + X^(n - 1) -- X^n and G_n depend on w and n only, and G_(a + b) = G_a * X^b + G_b.
+// Round 3 put them together from a table of (X^(2^k), G_(2^k)) per line width: two products per set bit of n, three to apply
+// them and one more for the string's own x^(8 len) -- ~16 products of 32 shift-and-add steps per run, and the size pass of
+// the members (5.3 ms at genome scale, `profiles/r03t_bench_kernel_stats.csv`) was bound by exactly this arithmetic.  Round 5:
+// n <= 4096 is two digits to the base 64, the table (made by the host when a context first deflates: 12.5 KB) holds
+// (X^(j 64^k), G_(j 64^k)) for j <= 64, so X^n and G_n are ONE product each; the CRC of a line below 1024 is a table entry
+// too; and the tile's x^(8 len) is made once, from the bits of its text length, behind the last run: four products per run.
 constexpr uint32_t gf_mul_c(uint32_t a, uint32_t b)
 {
     uint32_t p = 0;
@@ -92,32 +95,35 @@ constexpr uint32_t gf_mul_c(uint32_t a, uint32_t b)
     }
     return p;
 }
-constexpr int REP_W = 12, REP_K = 13;                                           // line widths 0 .. 11, runs of up to 2^13 - 1 lines (a tile: 4096)
-struct RepTab { uint32_t x[REP_W][REP_K], g[REP_W][REP_K]; };
-constexpr RepTab make_rep_tab()
-{
-    RepTab t{};
-    uint32_t xw = GF_ONE;                                                       // x^(8 w)
-    for (int w = 0; w < REP_W; w++) {
-        uint32_t x = xw, g = GF_ONE;
-        for (int k = 0; k < REP_K; k++) {
-            t.x[w][k] = x; t.g[w][k] = g;
-            g = gf_mul_c(g, x) ^ g;                                             // G_(2 m) = G_m * X^m + G_m
-            x = gf_mul_c(x, x);
-        }
-        xw = gf_mul_c(xw, 0x00800000u);                                         // * x^8
-    }
-    return t;
-}
-__constant__ RepTab c_rep = make_rep_tab();
-static_assert(TILE < (1 << REP_K), "a run is at most a tile of lines");
+constexpr int REP_W = 12;                                                       // line widths 0 .. 11
+constexpr int REP_J = 65;                                                       // digits 0 .. 64 (n = 4096 = 64 * 64)
+constexpr int LINE_TAB = 1024;                                                  // CRCs of the lines "0\n" .. "1023\n"
+constexpr int POW_K = 17;                                                       // x^(8 2^k): a tile's text is < 2^17 bytes
+static_assert(TILE <= 64 * 64, "a run is at most two digits to the base 64");
+static_assert((uint64_t)TILE * (REP_W - 1) < (1ull << POW_K), "the text of a tile");
+// layout of the table (uint32): [REP_W][2][REP_J] pairs (x, g) | LINE_TAB line CRCs | POW_K powers
+constexpr size_t TAB_REP = 0, TAB_LINE = (size_t)REP_W * 2 * REP_J * 2, TAB_POW = TAB_LINE + LINE_TAB, TAB_WORDS = TAB_POW + POW_K;
 
-__device__ __forceinline__ CrcPair crc_append_lines(CrcPair front, uint32_t line_crc, uint32_t w, uint32_t n)
+struct CrcTab {
+    const uint2* __restrict__ rep;
+    const uint32_t* __restrict__ line;
+    const uint32_t* __restrict__ pow8;
+};
+
+__device__ __forceinline__ uint32_t crc_append_lines(uint32_t front_c, uint32_t line_crc, uint32_t w, uint32_t n, const CrcTab& t)
 {
-    uint32_t g = 0u, xn = GF_ONE;                                               // (G_0, X^0)
-    for (uint32_t k = 0; n; n >>= 1, k++)
-        if (n & 1u) { const uint32_t xk = c_rep.x[w][k]; g = gf_mul(g, xk) ^ c_rep.g[w][k]; xn = gf_mul(xn, xk); }
-    return {gf_mul(front.c, xn) ^ gf_mul(line_crc, g), gf_mul(front.x, xn)};
+    const uint2 lo = t.rep[(w * 2u + 0u) * REP_J + (n & 63u)], hi = t.rep[(w * 2u + 1u) * REP_J + (n >> 6)];
+    const uint32_t xn = gf_mul(hi.x, lo.x);                                     // X^(64 a + b)
+    const uint32_t gn = gf_mul(hi.y, lo.x) ^ lo.y;                              // G_(64 a) * X^b + G_b
+    return gf_mul(front_c, xn) ^ gf_mul(line_crc, gn);
+}
+
+__device__ __forceinline__ uint32_t pow_x8(uint32_t len, const CrcTab& t)       // x^(8 len)
+{
+    uint32_t x = GF_ONE;
+    for (uint32_t k = 0; len; len >>= 1, k++)
+        if (len & 1u) x = gf_mul(x, t.pow8[k]);
+    return x;
 }
 
 // ---- bit writer: DEFLATE packs bits LSB first; Huffman codes go in most-significant bit first, i.e. bit-reversed --------
@@ -190,12 +196,26 @@ __device__ __forceinline__ void put_run(BitOut& o, const Line& l, uint32_t n)
 // element through DPP), the starts are ranked with a wave scan and land in LDS, and the tile's runs -- {depth, length},
 // ~20 of them in long-read data -- go to a list the encode passes read instead of the track.  A tile with more than
 // RUN_MAX runs (short reads, pile-ups) keeps the lane's own walk.
-constexpr int RUN_MAX = 64;
-constexpr uint32_t RUNS_WALK = 0xFFFFFFFFu;      // tile_nruns: not in the list, walk the track
+constexpr int RUN_MAX = GCI_RUN_MAX;
+constexpr uint32_t RUNS_WALK = GCI_RUNS_WALK;    // tile_nruns: not in the list, walk the track
+
+// Where a tile's list lies.  by_track = false: entry 64 m + t (the lists k_depth_runs made for exactly these members).  by_track = true:
+// the lists are those of a depth build (gci_build_opts.want_runs: k_tile_build wrote down the segments it had in registers), one
+// per 4096-base tile of the LAYOUT -- a member that starts on a tile boundary finds its tile t at element / 4096 + t; one that
+// does not has no lists (NO_LIST: its lanes walk the track).
+constexpr uint64_t NO_LIST = ~0ull;
+__device__ __forceinline__ uint64_t list_index(bool by_track, uint64_t n_lists, uint32_t m, uint32_t t, uint64_t elem0)
+{
+    if (!by_track) return (uint64_t)m * MEMBER_TILES + t;
+    if (elem0 % TILE) return NO_LIST;
+    const uint64_t i = elem0 / TILE + t;
+    return i < n_lists ? i : NO_LIST;
+}
 
 __global__ __launch_bounds__(BLOCK) void k_depth_runs(const int32_t* __restrict__ depth, const uint64_t* __restrict__ member_elem,
                                                       const uint32_t* __restrict__ member_n, uint32_t n_members,
-                                                      uint32_t* __restrict__ tile_nruns, int2* __restrict__ tile_runs)
+                                                      uint32_t* __restrict__ tile_nruns, int2* __restrict__ tile_runs,
+                                                      bool by_track, uint64_t n_lists)
 {
     __shared__ uint32_t starts[BLOCK / 64][RUN_MAX + 1];
     __shared__ int32_t vals[BLOCK / 64][RUN_MAX];
@@ -205,7 +225,11 @@ __global__ __launch_bounds__(BLOCK) void k_depth_runs(const int32_t* __restrict_
     if (m >= n_members) return;
     const uint32_t n_all = member_n[m], first = t * TILE;
     const uint32_t n = n_all > first ? min((uint32_t)TILE, n_all - first) : 0u;
-    if (n == 0) { if (lane == 0) tile_nruns[g] = 0u; return; }
+    const uint64_t li = list_index(by_track, n_lists, m, t, member_elem[m]);
+    if (li == NO_LIST) return;
+    // behind a build that kept its lists only the tiles it left out (dense ones: more events than a wave has lanes) are looked at
+    if (by_track && (n == 0 || tile_nruns[li] != RUNS_WALK)) return;
+    if (n == 0) { if (lane == 0) tile_nruns[li] = 0u; return; }
     const int4* __restrict__ src = reinterpret_cast<const int4*>(depth + member_elem[m] + first);
     uint32_t total = 0;
     int32_t carry = 0;
@@ -230,12 +254,12 @@ __global__ __launch_bounds__(BLOCK) void k_depth_runs(const int32_t* __restrict_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (total > RUN_MAX) { if (lane == 0) tile_nruns[g] = RUNS_WALK; return; }
+    if (total > RUN_MAX) { if (lane == 0) tile_nruns[li] = RUNS_WALK; return; }
     if ((uint32_t)lane < total) {
         const uint32_t a = starts[wave][lane], b = (uint32_t)lane + 1 < total ? starts[wave][lane + 1] : n;
-        tile_runs[g * RUN_MAX + lane] = make_int2(vals[wave][lane], (int)(b - a));
+        tile_runs[li * RUN_MAX + lane] = make_int2(vals[wave][lane], (int)(b - a));
     }
-    if (lane == 0) tile_nruns[g] = total;
+    if (lane == 0) tile_nruns[li] = total;
 }
 
 // One wave = one member of up to 64 tiles; lane t = tile t.  PASS 1: tile_bytes[], member totals + CRC; PASS 2: bytes.
@@ -245,7 +269,8 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
                                                       uint32_t* __restrict__ tile_bytes, uint32_t* __restrict__ member_bytes,
                                                       uint32_t* __restrict__ member_crc, uint32_t* __restrict__ member_isize,
                                                       const uint64_t* __restrict__ member_out, uint8_t* __restrict__ out, uint64_t cap,
-                                                      const uint32_t* __restrict__ tile_nruns, const int2* __restrict__ tile_runs)
+                                                      const uint32_t* __restrict__ tile_nruns, const int2* __restrict__ tile_runs,
+                                                      bool by_track, uint64_t n_lists, const uint32_t* __restrict__ crc_tab)
 {
     __shared__ int32_t run_v[RUNS][64];
     __shared__ uint32_t run_n[RUNS][64];
@@ -279,7 +304,8 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
             t[6] = (uint8_t)z; t[7] = (uint8_t)(z >> 8); t[8] = (uint8_t)(z >> 16); t[9] = (uint8_t)(z >> 24);
         }
     }
-    CrcPair tile{0u, GF_ONE};
+    const CrcTab ct{reinterpret_cast<const uint2*>(crc_tab + TAB_REP), crc_tab + TAB_LINE, crc_tab + TAB_POW};
+    uint32_t tile_c = 0u;                                                             // CRC of the tile's text so far
     uint32_t text_len = 0;
     if (n) o.put(2u, 3u);                                                             // BFINAL = 0, BTYPE = 01 (fixed codes)
 
@@ -289,18 +315,27 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
     uint32_t cnt = 0;                                                                 // the open run
     bool done = n == 0;
     // the tile's runs from the list k_depth_runs made (the usual case), else the walk below
-    const uint64_t g = (uint64_t)m * MEMBER_TILES + lane;
-    const uint32_t listed = tile_nruns ? tile_nruns[g] : RUNS_WALK;
-    const int2* __restrict__ my_runs = tile_runs + g * RUN_MAX;
+    const uint64_t li = tile_nruns ? list_index(by_track, n_lists, m, (uint32_t)lane, e0) : NO_LIST;
+    const uint32_t listed = li != NO_LIST && n ? tile_nruns[li] : RUNS_WALK;
+    const int2* __restrict__ my_runs = tile_runs + (li != NO_LIST ? li : 0ull) * RUN_MAX;
+    uint32_t taken = 0;                                                               // elements the listed runs read so far cover
     while (__any(!done)) {
         int k = 0;
         if (listed != RUNS_WALK) {
-            while (!done && k < RUNS) {
-                if (pos == listed) { done = true; break; }
+            // a build's list may hold empty segments and neighbours of one depth (an interval ending where another begins): they
+            // are put together here, so that either kind of list gives the same runs -- and the same bytes -- as the walk
+            while (!done && k < RUNS) {                                               // (k < RUNS: the slot a closing run needs)
+                if (pos == listed || taken == n) {
+                    if (cnt) { run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0; }
+                    done = true;
+                    break;
+                }
                 const int2 rr = my_runs[pos++];
-                run_v[k][lane] = rr.x; run_n[k][lane] = (uint32_t)rr.y; k++;
+                const uint32_t len = min((uint32_t)rr.y, n - taken);                  // (a member that ends inside the tile)
+                if (len == 0u) continue;
+                if (cnt && rr.x != cur) { run_v[k][lane] = cur; run_n[k][lane] = cnt; k++; cnt = 0; }
+                cur = rr.x; cnt += len; taken += len;
             }
-            if (pos == listed) done = true;
         }
         // one element into the open run; false: it would close a run and the buffer is full (the element stays unread)
         auto feed = [&](int32_t x) -> bool {
@@ -347,9 +382,10 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
         for (int r = 0; r < wave_max; r++) {
             if (r < kmax) {
                 const uint32_t rn = run_n[r][lane];
-                const Line l = make_line((uint32_t)run_v[r][lane]);
+                const uint32_t rv = (uint32_t)run_v[r][lane];
+                const Line l = make_line(rv);
                 if (PASS == 1) {
-                    tile = crc_append_lines(tile, crc_line(l).c, l.w, rn);
+                    tile_c = crc_append_lines(tile_c, rv < (uint32_t)LINE_TAB ? ct.line[rv] : crc_line(l).c, l.w, rn, ct);
                     text_len += rn * l.w;
                 }
                 put_run(o, l, rn);
@@ -367,6 +403,7 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
         const uint32_t bytes = (uint32_t)(o.total >> 3);
         tile_bytes[(size_t)m * MEMBER_TILES + lane] = bytes;
         uint32_t sum = bytes, len = text_len;
+        CrcPair tile{tile_c, pow_x8(text_len, ct)};
         // ordered product of the 64 tiles (lane i absorbs lane i + d) and plain sums
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -382,6 +419,56 @@ __global__ __launch_bounds__(64) void k_depth_deflate(const int32_t* __restrict_
     }
 }
 
+// The CRC tables (layout above), made once per process on the host and copied into the context on its first deflate.
+const uint32_t* host_crc_tab()
+{
+    static uint32_t tab[TAB_WORDS];
+    static const bool made = [] {
+        uint32_t xw = GF_ONE;                                                   // x^(8 w)
+        for (int w = 0; w < REP_W; w++) {
+            uint32_t base_x = xw, base_g = GF_ONE;                              // (X^m, G_m), m = 64^k
+            for (int k = 0; k < 2; k++) {
+                uint32_t x = GF_ONE, g = 0u;                                    // (X^(j m), G_(j m)), j = 0
+                for (int j = 0; j < REP_J; j++) {
+                    uint32_t* e = tab + TAB_REP + 2 * (((size_t)w * 2 + k) * REP_J + j);
+                    e[0] = x; e[1] = g;
+                    g = gf_mul_c(g, base_x) ^ base_g;                           // G_(a + m) = G_a X^m + G_m
+                    x = gf_mul_c(x, base_x);
+                }
+                // m -> 64 m: entry j = 64 of this digit
+                const uint32_t* e64 = tab + TAB_REP + 2 * (((size_t)w * 2 + k) * REP_J + 64);
+                base_x = e64[0]; base_g = e64[1];
+            }
+            xw = gf_mul_c(xw, 0x00800000u);                                     // * x^8
+        }
+        for (uint32_t v = 0; v < (uint32_t)LINE_TAB; v++) {
+            char txt[16];
+            const int nc = snprintf(txt, sizeof txt, "%u\n", v);
+            uint32_t c = 0xFFFFFFFFu;
+            for (int i = 0; i < nc; i++) {
+                c ^= (uint8_t)txt[i];
+                for (int b = 0; b < 8; b++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+            }
+            tab[TAB_LINE + v] = c ^ 0xFFFFFFFFu;
+        }
+        uint32_t x = 0x00800000u;                                               // x^8
+        for (int k = 0; k < POW_K; k++) { tab[TAB_POW + k] = x; x = gf_mul_c(x, x); }
+        return true;
+    }();
+    (void)made;
+    return tab;
+}
+
+int ensure_crc_tab(gci_ctx* ctx)
+{
+    if (ctx->deflate_tab_ready) return GCI_OK;
+    GCI_TRY(gci_ensure(ctx, ctx->deflate_tab, TAB_WORDS * sizeof(uint32_t)));
+    if (hipMemcpyAsync(ctx->deflate_tab.p, host_crc_tab(), TAB_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return GCI_E_HIP;
+    ctx->deflate_tab_ready = true;
+    return GCI_OK;
+}
+
 }  // namespace
 
 // PASS 1.  d_member_elem[m]: element offset of member m's first base in the track (a multiple of 4); d_member_n[m]: its
@@ -394,15 +481,25 @@ extern "C" int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, cons
                                !d_member_isize))) return GCI_E_INVALID;
     if (n_members == 0) return GCI_OK;
     const uint64_t n_tiles = (uint64_t)n_members * MEMBER_TILES;
-    GCI_TRY(gci_ensure(ctx, ctx->deflate_nruns, n_tiles * 4));
-    GCI_TRY(gci_ensure(ctx, ctx->deflate_runs, n_tiles * RUN_MAX * sizeof(int2)));
+    // the run lists: those the depth build of this very track kept (gci_build_opts.want_runs -- the track is then not read for
+    // them; k_depth_runs only looks at the tiles the build left out), else made here from the track
+    const bool from_build = ctx->build_runs_track != nullptr && ctx->build_runs_track == d_depth;
+    if (!from_build) {
+        GCI_TRY(gci_ensure(ctx, ctx->deflate_nruns, n_tiles * 4));
+        GCI_TRY(gci_ensure(ctx, ctx->deflate_runs, n_tiles * RUN_MAX * sizeof(int2)));
+    }
+    uint32_t* nruns = (uint32_t*)(from_build ? ctx->build_nruns.p : ctx->deflate_nruns.p);
+    int2* runs = (int2*)(from_build ? ctx->build_runs.p : ctx->deflate_runs.p);
+    const uint64_t n_lists = from_build ? (uint64_t)ctx->n_tiles : n_tiles;
+    GCI_TRY(ensure_crc_tab(ctx));
     ctx->deflate_members = n_members; ctx->deflate_key_depth = d_depth; ctx->deflate_key_elem = d_member_elem;
+    ctx->deflate_from_build = from_build;
     hipLaunchKernelGGL(k_depth_runs, dim3((uint32_t)((n_tiles + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, ctx->stream, d_depth,
-                       d_member_elem, d_member_n, n_members, (uint32_t*)ctx->deflate_nruns.p, (int2*)ctx->deflate_runs.p);
+                       d_member_elem, d_member_n, n_members, nruns, runs, from_build, n_lists);
     LAUNCHCHK("k_depth_runs");
     hipLaunchKernelGGL(k_depth_deflate<1>, dim3(n_members), dim3(64), 0, ctx->stream, d_depth, d_member_elem, d_member_n, n_members,
                        d_tile_bytes, d_member_bytes, d_member_crc, d_member_isize, (const uint64_t*)nullptr, (uint8_t*)nullptr, 0ull,
-                       (const uint32_t*)ctx->deflate_nruns.p, (const int2*)ctx->deflate_runs.p);
+                       (const uint32_t*)nruns, (const int2*)runs, from_build, n_lists, (const uint32_t*)ctx->deflate_tab.p);
     LAUNCHCHK("k_depth_deflate<1>");
     return GCI_OK;
 }
@@ -415,13 +512,17 @@ extern "C" int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* d_depth, con
     if (!ctx || (n_members && (!d_depth || !d_member_elem || !d_member_n || !d_tile_bytes || !d_member_crc || !d_member_isize ||
                                !d_member_out || !d_out))) return GCI_E_INVALID;
     if (n_members == 0) return GCI_OK;
+    GCI_TRY(ensure_crc_tab(ctx));
+    // the run lists of the size call over the same track and members (else: the lanes walk the track)
+    const bool same = ctx->deflate_members == n_members && ctx->deflate_key_depth == d_depth && ctx->deflate_key_elem == d_member_elem;
+    const bool from_build = same && ctx->deflate_from_build && ctx->build_runs_track == d_depth;
+    const bool listed = same && (from_build || !ctx->deflate_from_build);
     hipLaunchKernelGGL(k_depth_deflate<2>, dim3(n_members), dim3(64), 0, ctx->stream, d_depth, d_member_elem, d_member_n, n_members,
                        const_cast<uint32_t*>(d_tile_bytes), (uint32_t*)nullptr, const_cast<uint32_t*>(d_member_crc),
                        const_cast<uint32_t*>(d_member_isize), d_member_out, d_out, cap,
-                       // the run lists of the size call over the same track and members (else: the lanes walk the track)
-                       ctx->deflate_members == n_members && ctx->deflate_key_depth == d_depth && ctx->deflate_key_elem == d_member_elem
-                           ? (const uint32_t*)ctx->deflate_nruns.p : (const uint32_t*)nullptr,
-                       (const int2*)ctx->deflate_runs.p);
+                       listed ? (const uint32_t*)(from_build ? ctx->build_nruns.p : ctx->deflate_nruns.p) : (const uint32_t*)nullptr,
+                       (const int2*)(from_build ? ctx->build_runs.p : ctx->deflate_runs.p), from_build,
+                       from_build ? (uint64_t)ctx->n_tiles : (uint64_t)n_members * MEMBER_TILES, (const uint32_t*)ctx->deflate_tab.p);
     LAUNCHCHK("k_depth_deflate<2>");
     return GCI_OK;
 }

@@ -819,13 +819,17 @@ __device__ __forceinline__ uint32_t cut_dword(uint32_t a, uint32_t b, int32_t cu
 __device__ __forceinline__ bool tile_sparse2(
     int64_t tile, uint32_t e0, uint32_t n_ev, const uint16_t* __restrict__ events, int32_t carry_in, int32_t valid,
     int32_t* __restrict__ depth, uint64_t T0, uint8_t* __restrict__ text, uint64_t text_cap, int lane, uint32_t wi,
-    uint32_t nw TT_PARAM)
+    uint32_t nw, int2* __restrict__ run_list TT_PARAM)
 {
     // wi / nw: this wave is one of nw that share the tile: every one derives the segments, wave 0 writes the groups
     // that hold boundaries, and the whole groups of segment r go to wave r mod nw
     TT(1);
     Seg sg = sparse_segments(e0, n_ev, events, carry_in, valid, lane);
     TT(2);
+    // want_runs: the segments -- {depth, length}, in order, possibly empty, neighbours possibly of equal depth -- are what the
+    // .depth.gz encoder (k_deflate.hip) wants to know about this tile: one coalesced store of 8 bytes per lane instead of a
+    // second read of the tile's 16 KB
+    if (run_list && wi == 0 && (uint32_t)lane <= n_ev) run_list[(size_t)tile * GCI_RUN_MAX + lane] = make_int2(sg.d, sg.len);
     // padding behind the contig end: the first idle lane owns [valid, TILE) at depth 0 and has no text
     const bool pad_lane = (uint32_t)lane == n_ev + 1u && valid < TILE;
     if (pad_lane) { sg.p = valid; sg.p_next = TILE; sg.len = TILE - valid; sg.d = 0; }
@@ -1019,7 +1023,8 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const uint16_t* __restrict__ events, const uint32_t* __restrict__ evt_off, const int32_t* __restrict__ tile_carry,
     const int32_t* __restrict__ tile_valid, int64_t n_tiles, int32_t* __restrict__ depth,
     const uint64_t* __restrict__ tile_text_off, uint8_t* __restrict__ text, uint64_t text_cap,
-    uint8_t* __restrict__ dense_flag, uint32_t* __restrict__ dense_list, int32_t sparse_max, uint32_t* __restrict__ cd_words
+    uint8_t* __restrict__ dense_flag, uint32_t* __restrict__ dense_list, int32_t sparse_max, uint32_t* __restrict__ cd_words,
+    uint32_t* __restrict__ run_n, int2* __restrict__ run_list
 #ifdef GCI_TILE_TRACE
     , unsigned long long* __restrict__ trace
 #endif
@@ -1047,9 +1052,10 @@ __global__ __launch_bounds__(BLOCK) void k_tile_build(
     const uint64_t T0 = text ? tile_text_off[tile] : 0ull;
     bool done = false;
     if ((int64_t)(e1 - e0) <= sparse_max)
-        done = tile_sparse2(tile, e0, e1 - e0, events, carry_in, valid, depth, T0, text, text_cap, lane, wi, SHARE TT_ARG);
+        done = tile_sparse2(tile, e0, e1 - e0, events, carry_in, valid, depth, T0, text, text_cap, lane, wi, SHARE, run_list TT_ARG);
     if (lane == 0 && wi == 0) {
         dense_flag[tile] = done ? 0 : 1;                                     // k_tile_dense takes the rest
+        if (run_n) run_n[tile] = done ? (e1 - e0) + 1u : GCI_RUNS_WALK;      // (a dense tile: the encoder reads the track)
         cd_words[2 * tile + 1] = 0u;                                         // the coarse difference has been consumed: table clean again
     }
     TT(7);
@@ -1126,7 +1132,8 @@ static int launch_tile_build(gci_ctx* ctx, int pass, IssueArgs iss, int32_t* d_d
             ProfScope _ps(ctx, GCI_PROF_DEPTH_SCAN);
             hipLaunchKernelGGL(k_tile_build, grid2, block, 0, ctx->stream, ev, eo, tc, tv, ctx->n_tiles, d_depth,
                                (const uint64_t*)ctx->tile_u64.p, d_text, text_cap, flag, list, ctx->sparse_max,
-                               (uint32_t*)ctx->tile_cd.p TILE_TRACE_ARG);
+                               (uint32_t*)ctx->tile_cd.p, ctx->build_runs_wanted ? (uint32_t*)ctx->build_nruns.p : nullptr,
+                               ctx->build_runs_wanted ? (int2*)ctx->build_runs.p : nullptr TILE_TRACE_ARG);
             LAUNCHCHK("k_tile_build");
         }
         ProfScope _ps(ctx, GCI_PROF_TILE_DENSE);
@@ -1146,6 +1153,8 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     if (o->want_text && !o->d_contig_text_off) return GCI_E_INVALID;
     if (o->d_n_keys && o->key_cap && !o->d_keys) return GCI_E_INVALID;
     ctx->build_pending = false;
+    ctx->build_runs_track = nullptr;                        // whatever lists an earlier build kept describe another track now
+    ctx->build_runs_wanted = false;
     const int64_t nt = ctx->n_tiles;
     if (nt == 0) {
         if (o->d_contig_text_off) HIPCHK(hipMemsetAsync(o->d_contig_text_off, 0, (size_t)(ctx->n_contigs + 1) * 8, ctx->stream));
@@ -1268,6 +1277,11 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
             }
         }
     }
+    if (o->want_runs) {
+        GCI_TRY(gci_ensure(ctx, ctx->build_nruns, (size_t)nt * sizeof(uint32_t)));
+        GCI_TRY(gci_ensure(ctx, ctx->build_runs, (size_t)nt * GCI_RUN_MAX * sizeof(int2)));
+        ctx->build_runs_wanted = true;
+    }
     ctx->build_pending = true;
     ctx->build_text = o->want_text != 0;
     return GCI_OK;
@@ -1283,6 +1297,7 @@ extern "C" int gci_depth_build_finish(gci_ctx* ctx, int32_t* d_depth, uint8_t* d
     IssueArgs none;
     memset(&none, 0, sizeof none);
     GCI_TRY(launch_tile_build(ctx, 2, none, d_depth, d_text, text_cap));
+    if (ctx->build_runs_wanted) ctx->build_runs_track = d_depth;
     ctx->cd_state = 0;                                      // k_evt_scatter returned the counts, k_tile_build the differences
     return GCI_OK;
 }

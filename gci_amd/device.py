@@ -751,10 +751,12 @@ class Engine:
     def depth_build_fused(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
                           want_text: bool = True, want_sums: bool = False,
                           issue: Optional[Tuple[float, float, int]] = None, max_n: Optional[int] = None,
-                          counted: bool = False, key_cap: int = 1 << 16):
+                          counted: bool = False, key_cap: int = 1 << 16, want_runs: bool = False):
         """Depth build that also returns what the reference derives from the fresh depths, computed in
         the same pass (no re-read of the track): decimal text, per-contig sums and -- only valid when
-        no gap mask follows -- the raw issue runs for (lo, hi, flank).
+        no gap mask follows -- the raw issue runs for (lo, hi, flank).  want_runs: the library keeps the constant-depth runs of
+        every tile as the build wrote them, and a depth_deflate() of this track -- before anything else writes it -- takes them
+        from there instead of reading the track (gci_build_opts.want_runs).
 
         -> dict(text=uint8 tensor | None, text_off=int64 ndarray | None, sums=ndarray | None,
                 runs=list of per-contig arrays | None)"""
@@ -764,6 +766,7 @@ class Engine:
         o.flank = int(flank)
         o.counted = 1 if counted else 0
         o.want_text = 1 if want_text else 0
+        o.want_runs = 1 if want_runs else 0
         text_off = torch.zeros(nc + 1, dtype=torch.int64, device=self.device) if want_text else None
         # want_sums: True = per-contig sums returned as a host array; a device tensor (int64 [n_contigs]) = written there, nothing copied
         sums_dev = want_sums if isinstance(want_sums, torch.Tensor) else None

@@ -1010,7 +1010,7 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     text_on_device = bool(write) and DEPTH_GZ != "gpu"
     with phases.wall("depth_build"), phases.gpu("depth build"):
         fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=text_on_device, want_sums=True,
-                                         issue=issue_hint, counted=True)
+                                         issue=issue_hint, counted=True, want_runs=bool(write) and not text_on_device)
     depths = DepthTracks(engine, targets_length, track)
     depths._fresh_sums = fused["sums"]
     if issue_hint is not None:

@@ -289,6 +289,13 @@ typedef struct gci_build_opts {
     double lo, hi;
     int counted;                  /* 1: the intervals are exactly what the last gci_name_join_count emitted (same flank):
                                      the per-tile counting pass has been done there */
+    int want_runs;                /* 1: finish also keeps, in the context, the constant-depth runs of every 4096-base tile as it
+                                     wrote them; gci_depth_deflate_size / _write over the SAME d_depth then take the runs from
+                                     there instead of reading the track (members that start on a tile boundary: every
+                                     contig does).  gci_gap_mask / gci_max2 / gci_two_type_tail, a new build and
+                                     gci_layout_set drop the lists; a caller that writes the track by other means
+                                     between the build and the deflate calls must not set this.  (Occupies what was
+                                     padding: sizeof(gci_build_opts) is unchanged.) */
 } gci_build_opts;
 int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const uint32_t* d_n, uint32_t max_n,
                           const gci_build_opts* h_opts);

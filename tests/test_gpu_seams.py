@@ -768,6 +768,59 @@ def test_depth_text_as_gzip_members_from_the_gpu(engine):
         assert gzip.decompress(members[c]) == whole[int(off_t[c]):int(off_t[c + 1])]
 
 
+def test_gzip_members_from_the_run_lists_the_build_keeps(engine):
+    """gci_build_opts.want_runs: k_tile_build writes down the constant-depth segments it holds in registers and the deflate
+    passes take them instead of reading the track.  Same bytes as from the track itself -- over tiles with empty segments,
+    neighbours of equal depth (an interval ends where another begins), dense tiles (pile-ups: more events than the sparse
+    path takes, left to the walk), contigs that end inside a tile and contigs without any interval; a gap mask between the
+    build and the deflate drops the lists (the members then show the masked track)."""
+    import gzip
+    rng = np.random.default_rng(4242)
+    lens = [5, 4096, 4097, 70_000, 64 * 4096 + 17, 900_000, 12_345]
+    engine.set_layout(lens)
+    rows = []
+    for c, L in enumerate(lens):
+        if c == 6:
+            continue                                         # a contig nothing aligns to
+        n = max(3, L // 400)
+        a = rng.integers(0, max(1, L - 1), n)
+        b = np.minimum(L - 1, a + rng.integers(0, 3000, n))
+        rows += [(c, int(x), int(y), 0) for x, y in zip(a, b)]
+        # abutting intervals (the second begins where the first ended) and a pile-up in one tile
+        for k in range(0, min(L, 60_000) - 200, 997):
+            rows += [(c, k, k + 99, 0), (c, k + 100, k + 180, 0)]
+        if L > 9000:
+            st = rng.integers(4100, 8100, 300)
+            rows += [(c, int(x), int(x) + 7, 0) for x in st]
+    ivl = engine.to_device(np.asarray(rows, dtype=np.int32).reshape(-1, 4))
+    plain = engine.new_track()
+    engine.depth_build(ivl, None, 0, plain)
+    want = [bytes(b) for b in engine.depth_deflate(plain)]          # lists made from the track (k_depth_runs)
+    host = plain.cpu().numpy()
+    for c, (off, L) in enumerate(zip(engine.offsets, lens)):
+        assert gzip.decompress(want[c]) == ("\n".join(map(str, host[off:off + L].tolist())) + "\n").encode()
+    track = engine.new_track()
+    engine.depth_build_fused(ivl, None, 0, track, want_text=False, want_runs=True)
+    assert torch.equal(track, plain)
+    got = [bytes(b) for b in engine.depth_deflate(track)]
+    assert got == want
+    # the same once more (the lists are still those of this track), then with flanks
+    assert [bytes(b) for b in engine.depth_deflate(track)] == want
+    engine.depth_build_fused(ivl, None, 15, track, want_text=False, want_runs=True)
+    engine.depth_build(ivl, None, 15, plain)
+    assert torch.equal(track, plain)
+    assert [bytes(b) for b in engine.depth_deflate(track)] == [bytes(b) for b in engine.depth_deflate(plain)]
+    # a mask between build and deflate: the lists no longer describe the track
+    engine.depth_build_fused(ivl, None, 0, track, want_text=False, want_runs=True)
+    gaps = engine.to_device(np.asarray([(3, 100, 9000, 0), (5, 0, 4096, 0)], dtype=np.int32).reshape(-1, 4))
+    engine.gap_mask(track, gaps)
+    masked = track.cpu().numpy()
+    after = [bytes(b) for b in engine.depth_deflate(track)]
+    for c, (off, L) in enumerate(zip(engine.offsets, lens)):
+        assert gzip.decompress(after[c]) == ("\n".join(map(str, masked[off:off + L].tolist())) + "\n").encode()
+    assert after[3] != want[3]
+
+
 def _forged_input(engine, names, hashes, contig, start, end, qlen, hq):
     """A join input whose name hashes are given instead of computed (collision tests)."""
     n = len(names)
