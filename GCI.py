@@ -53,9 +53,40 @@ if __name__ == "__main__" and _a_run_of_this_process(sys.argv) and os.environ.ge
 
 from gci_amd.cli import main  # noqa: E402
 
+def _leave_at_once() -> bool:
+    """After a run that went through -- every output file written and closed -- the process leaves through os._exit: what an
+    orderly interpreter exit does from there on (the allocator handing 150 GB of device memory back piece by piece, pinned
+    slots unmapped, the HIP runtime and a hundred modules taken down) took 0.3 - 0.4 s of a 6 s command line and changes
+    nothing a caller can see.  Not under a profiler or a tool that collects at exit (they write their results in atexit /
+    library destructors), not as one rank of several (the process group is taken down in order), and GCI_EXIT=clean turns
+    it off."""
+    if os.environ.get("GCI_EXIT", "") == "clean":
+        return False
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        return False
+    tools = ("ROCPROFILER_", "ROCPROF", "ROCP_", "HSA_TOOLS_LIB", "COVERAGE_", "COV_CORE_", "PYTHONFAULTHANDLER")
+    if any(k.startswith(t) for k in os.environ for t in tools):
+        return False
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or sys.gettrace() is not None:
+        return False
+    return True
+
+
 if __name__ == "__main__":
+    done = False
     try:
         main(sys.argv)
+        done = True
     finally:
         if _WAKER is not None:
             _WAKER.join(timeout=10.0)                 # (an early exit -- a refused argument -- does not leave while the runtime is starting)
+    if done and _leave_at_once():
+        try:
+            import threading as _th
+            for t in _th.enumerate():                 # what an interpreter exit waits for as well
+                if t is not _th.main_thread() and not t.daemon:
+                    t.join()
+            sys.stdout.flush()
+            sys.stderr.flush()
+        finally:
+            os._exit(0)

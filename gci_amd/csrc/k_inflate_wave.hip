@@ -346,12 +346,16 @@ using namespace iw;
 // members [m0, m0 + n_batch) of the run; sym: n_batch x SYM_STRIDE entries; n_sym, wstatus: one word per member of the RUN;
 // lists: per workgroup 64 x MAXS entries, entry i of lane k at [i * 64 + k] (a step's stores are one 256-byte row)
 // entry: bit 31 set = literal (low 8 bits); else (length - 3) << 15 | (distance - 1)
-extern "C" __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
+// MEASURE = false (what runs): the phase counters and the cuts do not exist -- they cost registers both kernels are short of.
+template <bool MEASURE>
+__global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ member_pos,
                                                                    const uint64_t* __restrict__ out_off, uint64_t out_cap, uint32_t m0, uint32_t n_batch,
                                                                    uint32_t* __restrict__ sym, uint32_t* __restrict__ n_sym,
                                                                    uint32_t* __restrict__ wstatus, uint32_t* __restrict__ lists, uint32_t* __restrict__ next,
-                                                                   uint32_t cut, unsigned long long* __restrict__ prof)
+                                                                   uint32_t cut_arg, unsigned long long* __restrict__ prof_arg)
 {
+    unsigned long long* const prof = MEASURE ? prof_arg : nullptr;
+    const uint32_t cut = MEASURE ? cut_arg : 0u;
     // (prof: measurements only -- cycles per phase, summed over the waves: GCI_IW_PROF=1, tools/hwtests/inflate_product.py)
     unsigned long long t_hdr = 0, t_stage = 0, t_p1 = 0, t_st = 0, t_ch = 0, t_ga = 0, n_chunks = 0, t_all0 = prof ? __builtin_amdgcn_s_memtime() : 0;
 #define IW_T(acc, t0) do { if (prof) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); acc += _n - t0; t0 = _n; } } while (0)
@@ -667,56 +671,108 @@ constexpr uint32_t CP_UNIT = 256;                               // cells a wave 
 constexpr uint32_t CP_UPW = 256u / (uint32_t)CP_WAVES;          // units per wave (65 536 cells = 256 units)
 static_assert(CP_UPW <= 32u && CP_UPW % 4u == 0u, "a wave's units are a 32-bit mask, written four at a time");
 
-// one member (member mb of the batch) by the whole workgroup
-__device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t (*wsum)[CP_WAVES], uint32_t& s_bad, uint32_t mb,
+// What the workgroup needs to know of a member before it can start on it, and the first tile of its symbols: fetched while the
+// member in front of it is being resolved (IW_CP_PREFETCH; one workgroup per CU means nothing else hides these round trips --
+// status, then count and offsets, then the symbols: three of them in a row at the head of every member).
+#ifndef IW_CP_PREFETCH
+#define IW_CP_PREFETCH 1
+#endif
+#ifndef IW_CP_RES_UNITS
+#define IW_CP_RES_UNITS 1
+#endif
+struct CpMeta { uint32_t status, ns, isize; uint64_t o0; };
+__device__ __forceinline__ CpMeta cp_meta(uint32_t mb, uint32_t n_batch, uint32_t m0, const uint32_t* __restrict__ n_sym,
+                                          const uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off)
+{
+    CpMeta c{0xFFFFFFFFu, 0u, 0u, 0ull};
+    if (mb < n_batch) {
+        const uint32_t m = m0 + mb;
+        c.status = wstatus[m]; c.ns = n_sym[m]; c.o0 = out_off[m]; c.isize = (uint32_t)(out_off[m + 1] - c.o0);
+    }
+    return c;
+}
+// IW_CP_PF tiles of a member's symbols are in registers ahead of the tile being placed (a tile = four symbols per thread): the
+// place phase took a round trip to memory per tile with one tile ahead -- its tiles are too short to hide one.
+#ifndef IW_CP_PF
+#define IW_CP_PF 2
+#endif
+#ifndef IW_CP_FILL_STEPS
+#define IW_CP_FILL_STEPS 4
+#endif
+#ifndef IW_CP_CUT
+#define IW_CP_CUT 0                      // (measurements: 1 = the copy kernel leaves a member behind its place phase, 2 = behind the resolve phase)
+#endif
+struct CpTiles { uint4 t[IW_CP_PF]; };
+__device__ __forceinline__ uint4 cp_load4(const uint32_t* __restrict__ msym, uint32_t i0, uint32_t ns)
+{
+    if (i0 + 4u <= ns) { uint4 v; __builtin_memcpy(&v, msym + i0, 16); return v; }
+    uint4 v = make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
+    if (i0 < ns) v.x = msym[i0];
+    if (i0 + 1u < ns) v.y = msym[i0 + 1u];
+    if (i0 + 2u < ns) v.z = msym[i0 + 2u];
+    return v;
+}
+__device__ __forceinline__ void cp_first_tiles(CpTiles& b, const uint32_t* __restrict__ msym, uint32_t tid, uint32_t ns)
+{
+#pragma unroll
+    for (int k = 0; k < IW_CP_PF; k++) b.t[k] = cp_load4(msym, 4u * tid + (uint32_t)k * 4u * (uint32_t)IW_CP_THREADS, ns);
+}
+
+// one member (member mb of the batch) by the whole workgroup; mb_next: the member this workgroup takes after it
+template <bool MEASURE>
+__device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* __restrict__ SB, uint32_t (*wsum)[CP_WAVES], uint32_t& s_bad, uint32_t mb,
                                             const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
                                             uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off,
-                                            uint32_t m0, uint8_t* __restrict__ out, uint32_t cut,
-                                            unsigned long long* __restrict__ prof)
+                                            uint32_t m0, uint8_t* __restrict__ out, uint32_t cut_arg,
+                                            unsigned long long* __restrict__ prof_arg, CpMeta& meta, CpTiles& first, uint32_t mb_next, uint32_t n_batch)
 {
+    unsigned long long* const prof = MEASURE ? prof_arg : nullptr;
+    const uint32_t cut = MEASURE ? cut_arg : (uint32_t)IW_CP_CUT;
     unsigned long long tb = prof ? __builtin_amdgcn_s_memtime() : 0, t_place = 0, t_res = 0, n_ur = 0, n_rounds = 0;
+    unsigned long long t_scan = 0, t_cells = 0, t_long = 0;
+    const unsigned long long t_begin = tb;
     const uint32_t m = m0 + mb;
-    if (wstatus[m] != ST_OK) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t ns = n_sym[m];
-    const uint64_t o0 = out_off[m];
-    const uint32_t isize = (uint32_t)(out_off[m + 1] - o0);
+    const CpMeta me = meta;
+    CpTiles buf = first;
+    meta = cp_meta(mb_next, n_batch, m0, n_sym, wstatus, out_off);         // (in flight from here on; looked at behind the place phase)
+    if (me.status != ST_OK) {
+        if (meta.status == ST_OK) cp_first_tiles(first, sym + (size_t)mb_next * SYM_STRIDE, (uint32_t)tid, meta.ns);
+        return;
+    }
+    const uint32_t ns = me.ns;
+    const uint64_t o0 = me.o0;
+    const uint32_t isize = me.isize;
     const uint32_t* const msym = sym + (size_t)mb * SYM_STRIDE;
     if (tid == 0) s_bad = 0u;
+    SB[tid] = 0u; SB[tid + CP_THREADS] = 0u;                               // (in front of the first barrier of the place phase)
+    if (tid < 2) SB[2048 + tid] = 0u;                                      // (the word behind the last one: read, never set)
+    static_assert(2 * CP_THREADS == 2048, "two words of the start bitmap per thread");
     // ---- place: every symbol's output offset by a scan (four symbols per thread and tile), its cells ---------------------------------
     uint32_t run = 0;
     bool bad = false;
-    auto load4 = [&](uint32_t i0) -> uint4 {
-        if (i0 + 4u <= ns) { uint4 v; __builtin_memcpy(&v, msym + i0, 16); return v; }
-        uint4 v = make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
-        if (i0 < ns) v.x = msym[i0];
-        if (i0 + 1u < ns) v.y = msym[i0 + 1u];
-        if (i0 + 2u < ns) v.z = msym[i0 + 2u];
-        return v;
-    };
-    uint4 nxt = load4(4u * (uint32_t)tid);
-    uint32_t par = 0;
-    for (uint32_t t0 = 0; t0 < ns; t0 += 4u * CP_THREADS, par ^= 1u) {
-        const uint32_t i0 = t0 + 4u * (uint32_t)tid;
-        const uint4 ev = nxt;
-        if (t0 + 4u * CP_THREADS < ns) nxt = load4(i0 + 4u * CP_THREADS);          // the next tile's entries while this one is placed
+    auto load4 = [&](uint32_t i0) -> uint4 { return cp_load4(msym, i0, ns); };
+    // the lengths of a thread's four symbols of a tile (0 behind the member's last symbol) and their sum
+    auto lengths = [&](const uint4& ev, uint32_t i0, uint32_t (&len)[4]) -> uint32_t {
         const uint32_t e[4] = {ev.x, ev.y, ev.z, ev.w};
-        uint32_t len[4], tl = 0;
+        uint32_t tl = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) { len[k] = i0 + (uint32_t)k < ns ? ((e[k] >> 31) ? 1u : ((e[k] >> 15) & 0xFFu) + 3u) : 0u; tl += len[k]; }
+        return tl;
+    };
+    auto wave_scan = [&](uint32_t tl) -> uint32_t {
         uint32_t inc = tl;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
-        if (lane == 63) wsum[par][wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < CP_WAVES; w++) { const uint32_t v = wsum[par][w]; if (w < wave) woff += v; total += v; }
-        if (run + total > isize) { bad = true; break; }                   // (uniform)
-        uint32_t dst = run + woff + inc - tl;
-        // literals and the first cells of a match by its own lane; what lies behind the eighth cell by the whole wave, match by match
-        // (eight stores without a branch and a hand-over per symbol were tried: 2 % slower -- short matches pay for stores they do not need)
-        uint32_t long_dst = 0, long_len = 0, long_dist = 0;               // (at most one of a thread's four is taken over: the others stay inline)
+        return inc;
+    };
+    // A symbol writes its FIRST cell only -- the byte, or the pointer of a match's first cell -- and sets that cell's bit in the start
+    // bitmap; the other cells of the matches are filled in afterwards, cell by cell (below), from the nearest start at or in front of
+    // them.  (Until round 5's last day every symbol wrote all its cells: per-symbol loops, lanes with matches of every length side by
+    // side, and a serial pass over the long matches of a wave -- 5.2 ms per 1.83 GB where marks + fill take 2.0.)
+    auto mark4 = [&](const uint4& ev, const uint32_t (&len)[4], uint32_t dst) {
+        const uint32_t e[4] = {ev.x, ev.y, ev.z, ev.w};
+        uint32_t word = 0xFFFFFFFFu, bits = 0u;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (len[k] == 0u) continue;
@@ -724,35 +780,94 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t (
             else {
                 const uint32_t dist = (e[k] & 0x7FFFu) + 1u;
                 if (dist > dst) bad = true;
-                else {
-                    // cell x of the match copies cell x - dist; behind the first `dist` cells that is a cell of the match itself:
-                    // point past it, to the cell in front of the match that holds the same byte (x mod dist - dist)
-                    const bool hand_over = len[k] > 8u && dist >= len[k] && long_len == 0u;
-                    const uint32_t n_in = hand_over ? 8u : len[k];
-                    uint32_t r = 0, D = dist;
-                    for (uint32_t x = 0; x < n_in; x++) {
-                        W[dst + x] = (uint16_t)(0x8000u | ((D <= 0x8000u ? D : dist) - 1u));
-                        r++;
-                        if (r == dist) { r = 0; D += dist; }
-                    }
-                    if (hand_over) { long_dst = dst + 8u; long_len = len[k] - 8u; long_dist = dist; }
-                }
+                W[dst] = (uint16_t)(0x8000u | (dist - 1u));
             }
+            if ((dst >> 5) != word) { if (bits) atomicOr(&SB[word], bits); word = dst >> 5; bits = 0u; }
+            bits |= 1u << (dst & 31u);
             dst += len[k];
         }
-        for (unsigned long long todo = __ballot(long_len != 0u); todo; todo &= todo - 1ull) {
-            const int src = __ffsll((long long)todo) - 1;                     // (uniform: the three values come over the scalar path)
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)long_dst, src), n = (uint32_t)__builtin_amdgcn_readlane((int)long_len, src);
-            const uint16_t v = (uint16_t)(0x8000u | ((uint32_t)__builtin_amdgcn_readlane((int)long_dist, src) - 1u));
-            for (uint32_t x = (uint32_t)lane; x < n; x += 64) W[d0 + x] = v;
+        if (bits) atomicOr(&SB[word], bits);
+    };
+    {
+        uint32_t par = 0;
+        for (uint32_t t0 = 0; t0 < ns; t0 += 4u * CP_THREADS, par ^= 1u) {
+            const uint32_t i0 = t0 + 4u * (uint32_t)tid;
+            const uint4 ev = buf.t[0];
+#pragma unroll
+            for (int k = 0; k + 1 < IW_CP_PF; k++) buf.t[k] = buf.t[k + 1];
+            if (t0 + (uint32_t)IW_CP_PF * 4u * CP_THREADS < ns) buf.t[IW_CP_PF - 1] = load4(i0 + (uint32_t)IW_CP_PF * 4u * CP_THREADS);   // (tile t + PF)
+            uint32_t len[4];
+            const uint32_t tl = lengths(ev, i0, len);
+            const uint32_t inc = wave_scan(tl);
+            if (lane == 63) wsum[par][wave] = inc;
+            __syncthreads();
+            uint32_t woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < CP_WAVES; w++) { const uint32_t v = wsum[par][w]; if (w < wave) woff += v; total += v; }
+            if (run + total > isize) { bad = true; break; }               // (uniform)
+            if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_scan += n - tb; tb = n; }
+            if (cut != 4u) mark4(ev, len, run + woff + inc - tl);          // (4: the scans and their barriers alone)
+            run += total;
         }
-        run += total;
+    }
+    __syncthreads();                                                       // (every symbol's first cell and bit are there)
+    if (run == isize && isize && cut != 4u && cut != 5u) {                 // (5: without the fill)
+        // fill_cells: wave w takes cells [4096 w, 4096 (w + 1)), 64 per step, a cell per lane.  The symbol a cell belongs to begins at
+        // the highest set bit at or below it -- in the step's own 64 bits, else where the last step's (or, for the wave's first step,
+        // a look backwards) says; cell x of a match of distance d points d (x / d + 1) back (past the match, to the cell in front
+        // of it that holds the same byte) as long as that fits the cell's 15 bits; a cell whose target holds the same byte as the
+        // cell `dist` back is what makes an overlapping match (distance 1: a run of one byte) resolve in one hop instead of `length`.
+        const unsigned long long le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
+        uint32_t c0 = (uint32_t)wave * 4096u;
+        uint32_t carry = 0u;
+        if (wave && c0 < isize) {
+            uint32_t p = (c0 >> 5) - 1u;
+            while (SB[p] == 0u) p--;                                           // (word 0 holds bit 0: the member's first symbol)
+            carry = 32u * p + 31u - (uint32_t)__clz((int)SB[p]);
+        }
+        const uint32_t c_end = min(isize, c0 + 4096u);
+        constexpr uint32_t FS = IW_CP_FILL_STEPS;                              // steps (64 cells each) in flight: their LDS round trips overlap
+        for (; c0 < c_end; c0 += 64u * FS) {
+            unsigned long long m[FS];
+            uint32_t st[FS], v[FS];
+#pragma unroll
+            for (uint32_t f = 0; f < FS; f++) {
+                const uint32_t w0 = min((c0 >> 5) + 2u * f, 2048u);              // (behind the member's cells: the two zero words)
+                m[f] = ((unsigned long long)SB[w0 + 1u] << 32) | SB[w0];
+            }
+#pragma unroll
+            for (uint32_t f = 0; f < FS; f++) {
+                const unsigned long long mj = m[f] & le;
+                st[f] = mj ? c0 + 64u * f + 63u - (uint32_t)__clzll((long long)mj) : carry;
+                if (m[f]) carry = c0 + 64u * f + 63u - (uint32_t)__clzll((long long)m[f]);
+                v[f] = (uint32_t)W[st[f]];
+            }
+#pragma unroll
+            for (uint32_t f = 0; f < FS; f++) {
+                const uint32_t c = c0 + 64u * f + (uint32_t)lane;
+                const uint32_t x = c - st[f], dist = (v[f] & 0x7FFFu) + 1u;
+                uint32_t out16 = v[f];                                         // (cell x < dist of a match: the first cell's own pointer)
+                if (__any(x >= dist)) {                                        // (some lane inside a match that overlaps itself: one step in four)
+                    // x / dist: dist <= 257 here, and the quotient of two small integers survives the reciprocal's rounding
+                    // ((x + 0.5) / dist is at least 0.5 / 257 away from an integer)
+                    const uint32_t q = x < dist ? 0u : (uint32_t)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)dist));
+                    const uint32_t D = dist * (q + 1u);
+                    out16 = 0x8000u | ((D <= 0x8000u ? D : dist) - 1u);
+                }
+                if (x != 0u && c < isize) {
+                    if (!(v[f] & 0x8000u)) bad = true;                         // (a literal is one cell long)
+                    W[c] = (uint16_t)out16;
+                }
+            }
+        }
     }
     if (bad) atomicOr(&s_bad, 1u);
+    // the next member's first symbols: on their way while this one's cells are resolved and written
+    if (meta.status == ST_OK) cp_first_tiles(first, sym + (size_t)mb_next * SYM_STRIDE, (uint32_t)tid, meta.ns);
     __syncthreads();
     if (s_bad || run != isize) { if (tid == 0) wstatus[m] = s_bad ? 17u : run < isize ? 16u : 18u; return; }
-    if (cut == 1u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
-    if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_place = n - tb; tb = n; }
+    if (cut == 1u || cut == 4u || cut == 5u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
+    if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_place = n - t_begin; tb = n; }
     // ---- resolve: pointer jumping; unit u (256 cells) is wave u % 16's, four cells per lane in flight -----------------------------------
     // (plain LDS accesses; the compiler may keep nothing of W in registers from one look at a unit to the next: the barrier below)
     const uint32_t n_units = (isize + CP_UNIT - 1u) / CP_UNIT;
@@ -761,31 +876,46 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t (
     while (pending) {
         uint32_t next = 0;
         n_rounds++;
-        for (uint32_t rest = pending; rest; rest &= rest - 1u) {
-            n_ur++;
-            const uint32_t j = (uint32_t)__ffs((int)rest) - 1u;
-            const uint32_t i0 = ((uint32_t)wave + (uint32_t)CP_WAVES * j) * CP_UNIT + (uint32_t)lane;
+        for (uint32_t rest = pending; rest;) {
+            constexpr int NU = IW_CP_RES_UNITS;                          // units a wave has in flight (4 cells per lane each)
+            uint32_t jj[NU], i0[NU], lim[NU];
+#pragma unroll
+            for (int q = 0; q < NU; q++) {
+                const bool has = rest != 0u;
+                jj[q] = has ? (uint32_t)__ffs((int)rest) - 1u : 0u;
+                rest &= rest - (has ? 1u : 0u);
+                i0[q] = ((uint32_t)wave + (uint32_t)CP_WAVES * jj[q]) * CP_UNIT + (uint32_t)lane;
+                lim[q] = has ? isize : 0u;
+                n_ur += has ? 1u : 0u;
+            }
             __asm__ volatile("" ::: "memory");
-            uint32_t v[4], u[4];
+            uint32_t v[NU][4], u[NU][4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; v[k] = i < isize ? (uint32_t)W[i] : 0u; }
+            for (int q = 0; q < NU; q++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {                                // (a cell that holds a byte reads itself: no branch around the look-up)
-                const uint32_t i = i0 + 64u * (uint32_t)k;
-                const uint32_t src = (v[k] & 0x8000u) ? i - (v[k] & 0x7FFFu) - 1u : (i < isize ? i : 0u);
-                u[k] = (uint32_t)W[src];
+                for (int k = 0; k < 4; k++) { const uint32_t i = i0[q] + 64u * (uint32_t)k; v[q][k] = i < lim[q] ? (uint32_t)W[i] : 0u; }
+#pragma unroll
+            for (int q = 0; q < NU; q++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {                            // (a cell that holds a byte reads itself: no branch around the look-up)
+                    const uint32_t i = i0[q] + 64u * (uint32_t)k;
+                    const uint32_t src = (v[q][k] & 0x8000u) ? i - (v[q][k] & 0x7FFFu) - 1u : (i < lim[q] ? i : 0u);
+                    u[q][k] = (uint32_t)W[src];
+                }
+#pragma unroll
+            for (int q = 0; q < NU; q++) {
+                bool open = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0[q] + 64u * (uint32_t)k;
+                    const bool ptr = (v[q][k] & 0x8000u) != 0u, to_ptr = (u[q][k] & 0x8000u) != 0u;
+                    const uint32_t d2 = (v[q][k] & 0x7FFFu) + (u[q][k] & 0x7FFFu) + 2u;
+                    const uint32_t nv = !to_ptr ? u[q][k] : d2 <= 0x8000u ? 0x8000u | (d2 - 1u) : v[q][k];
+                    if (ptr && nv != v[q][k]) W[i] = (uint16_t)nv;
+                    open = open || (ptr && to_ptr);
+                }
+                if (__ballot(open)) next |= 1u << jj[q];
             }
-            bool open = false;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t i = i0 + 64u * (uint32_t)k;
-                const bool ptr = (v[k] & 0x8000u) != 0u, to_ptr = (u[k] & 0x8000u) != 0u;
-                const uint32_t d2 = (v[k] & 0x7FFFu) + (u[k] & 0x7FFFu) + 2u;
-                const uint32_t nv = !to_ptr ? u[k] : d2 <= 0x8000u ? 0x8000u | (d2 - 1u) : v[k];
-                if (ptr && nv != v[k]) W[i] = (uint16_t)nv;
-                open = open || (ptr && to_ptr);
-            }
-            if (__ballot(open)) next |= 1u << j;
         }
         pending = next;
     }
@@ -805,29 +935,43 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t (
         v.z = __builtin_amdgcn_perm(b.y, b.x, 0x06040200u);
         v.w = __builtin_amdgcn_perm(b.w, b.z, 0x06040200u);
         if (i + 16u <= isize) __builtin_memcpy(dst + i, &v, 16);
-        else {
-            const unsigned long long lo = ((unsigned long long)v.y << 32) | v.x, hi = ((unsigned long long)v.w << 32) | v.z;
-            for (uint32_t x = 0; x < 16u && i + x < isize; x++) dst[i + x] = (uint8_t)(x < 8u ? lo >> (8u * x) : hi >> (8u * (x - 8u)));
+        else {                                                             // (the member's last bytes: a loop the compiler leaves alone -- sixteen
+#pragma clang loop unroll(disable)                                         //  predicated byte stores, four times over, kept 60 registers busy)
+            for (uint32_t x = i; x < isize; x++) dst[x] = (uint8_t)W[x];
         }
     }
     if (prof && lane == 0) {
         atomicAdd(&prof[8], t_place); atomicAdd(&prof[9], t_res); atomicAdd(&prof[10], __builtin_amdgcn_s_memtime() - tb); atomicAdd(&prof[11], n_ur);
         atomicAdd(&prof[12], n_rounds); atomicMax(&prof[13], n_rounds); atomicAdd(&prof[14], 1ull);
+        atomicAdd(&prof[15], t_scan); atomicAdd(&prof[16], t_cells); atomicAdd(&prof[17], t_long);
     }
 }
 
 // One workgroup per CU for the whole batch (the member's cells take the CU's LDS anyway): the members in strides of the grid, so that
 // no CU waits for a workgroup to be dispatched between two members.
-extern "C" __global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
+template <bool MEASURE>
+__global__ __launch_bounds__(CP_THREADS) void k_inflate_copy(const uint32_t* __restrict__ sym, const uint32_t* __restrict__ n_sym,
                                                                         uint32_t* __restrict__ wstatus, const uint64_t* __restrict__ out_off,
                                                                         uint32_t m0, uint32_t n_batch, uint8_t* __restrict__ out, uint32_t cut,
                                                                         unsigned long long* __restrict__ prof)
 {
     __shared__ uint16_t W[65536];
     __shared__ uint32_t wsum[2][CP_WAVES];
+    __shared__ uint32_t SB[2048 + 2];                                      // one bit per cell, set where a symbol begins (+ two words that stay zero)
     __shared__ uint32_t s_bad;
+    CpMeta meta = cp_meta(blockIdx.x, n_batch, m0, n_sym, wstatus, out_off);
+    CpTiles first;
+#pragma unroll
+    for (int k = 0; k < IW_CP_PF; k++) first.t[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (meta.status == ST_OK) cp_first_tiles(first, sym + (size_t)blockIdx.x * SYM_STRIDE, threadIdx.x, meta.ns);
     for (uint32_t mb = blockIdx.x; mb < n_batch; mb += gridDim.x) {
-        copy_member(W, wsum, s_bad, mb, sym, n_sym, wstatus, out_off, m0, out, cut, prof);
+#if IW_CP_PREFETCH
+        copy_member<MEASURE>(W, SB, wsum, s_bad, mb, sym, n_sym, wstatus, out_off, m0, out, cut, prof, meta, first, mb + gridDim.x, n_batch);
+#else
+        meta = cp_meta(mb, n_batch, m0, n_sym, wstatus, out_off);
+        if (meta.status == ST_OK) cp_first_tiles(first, sym + (size_t)mb * SYM_STRIDE, threadIdx.x, meta.ns);
+        copy_member<MEASURE>(W, SB, wsum, s_bad, mb, sym, n_sym, wstatus, out_off, m0, out, cut, prof, meta, first, n_batch, n_batch);
+#endif
         __syncthreads();                                                  // (every wave has written its bytes: the cells are the next member's)
     }
 }
@@ -845,10 +989,10 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     static const bool want_prof = [] { const char* e = getenv("GCI_IW_PROF"); return e && atoi(e) != 0; }();
     unsigned long long* d_prof = nullptr;
     if (want_prof) {
-        const int stp = gci_ensure(ctx, ctx->inflate_prof, 16 * sizeof(unsigned long long));
+        const int stp = gci_ensure(ctx, ctx->inflate_prof, 24 * sizeof(unsigned long long));
         if (stp) return stp;
         d_prof = (unsigned long long*)ctx->inflate_prof.p;
-        HIPCHK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(d_prof, 0, 24 * sizeof(unsigned long long), ctx->stream));
     }
     // The members in batches (the symbol streams of a batch: batch x 256 KB of scratch), every other batch on a second stream with
     // scratch of its own: a wave takes a millisecond per member, so the last members of a batch leave most of the chip idle -- the
@@ -878,7 +1022,8 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     if (st) return st;
     int cus = 0, per_cu = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_symbols, 64, 0));
+    const bool measure = want_prof || cut_a || cut_b;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_symbols<false>, 64, 0));
     if (waves_per_cu > 0 && waves_per_cu < per_cu) per_cu = waves_per_cu;
     const uint32_t resident = (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu : 1024);
     st = gci_ensure(ctx, ctx->inflate_lists, (size_t)resident * 64u * (MAXS + 1u) * sizeof(uint32_t));
@@ -906,11 +1051,12 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
         hipStream_t sm = second ? ctx->inflate_stream2 : ctx->stream;
         uint32_t* const symk = (uint32_t*)(second ? ctx->inflate_sym2.p : ctx->inflate_sym.p);
         uint32_t* const listk = (uint32_t*)(second ? ctx->inflate_lists2.p : ctx->inflate_lists.p);
-        hipLaunchKernelGGL(k_inflate_symbols, dim3(nb < resident ? nb : resident), dim3(64), 0, sm, d_raw, d_member_pos, d_out_off, out_cap, m0, nb,
-                           symk, (uint32_t*)ctx->inflate_nsym.p, d_wstatus, listk, (uint32_t*)ctx->inflate_next.p + k, cut_a, d_prof);
+        hipLaunchKernelGGL(measure ? k_inflate_symbols<true> : k_inflate_symbols<false>, dim3(nb < resident ? nb : resident), dim3(64), 0, sm, d_raw,
+                           d_member_pos, d_out_off, out_cap, m0, nb, symk, (uint32_t*)ctx->inflate_nsym.p, d_wstatus, listk,
+                           (uint32_t*)ctx->inflate_next.p + k, cut_a, d_prof);
         LAUNCHCHK("k_inflate_symbols");
         const uint32_t copy_grid = copy_persistent && cus > 0 ? (nb < (uint32_t)cus ? nb : (uint32_t)cus) : nb;
-        hipLaunchKernelGGL(k_inflate_copy, dim3(copy_grid), dim3(CP_THREADS), 0, sm, (const uint32_t*)symk,
+        hipLaunchKernelGGL(measure ? k_inflate_copy<true> : k_inflate_copy<false>, dim3(copy_grid), dim3(CP_THREADS), 0, sm, (const uint32_t*)symk,
                            (const uint32_t*)ctx->inflate_nsym.p, d_wstatus, d_out_off, m0, nb, d_out, cut_b, d_prof);
         LAUNCHCHK("k_inflate_copy");
     }
@@ -919,13 +1065,13 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->inflate_ev_out, 0));       // (the lane decoder and the CRC check behind this: after both)
     }
     if (want_prof) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         HIPCHK(hipMemcpyAsync(h, d_prof, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         const double a = (double)h[6] > 0 ? 100.0 / (double)h[6] : 0.0, b = (double)(h[8] + h[9] + h[10]) > 0 ? 100.0 / (double)(h[8] + h[9] + h[10]) : 0.0;
         fprintf(stderr, "iw prof: A %% of wave time: header %.1f stage %.1f pass1 %.1f stitch %.1f chain %.1f gather %.1f; chunks %llu (%.0f cycles each); "
-                        "B %%: place %.1f resolve %.1f write %.1f; unit-rounds per member %.1f, rounds per wave %.2f (max %llu)\n",
-                a * h[0], a * h[1], a * h[2], a * h[3], a * h[4], a * h[5], h[7], h[7] ? (double)h[6] / (double)h[7] : 0.0, b * h[8], b * h[9], b * h[10],
+                        "B %%: place %.1f (scan + barrier %.1f, cells %.1f, long matches %.1f) resolve %.1f write %.1f; unit-rounds per member %.1f, rounds per wave %.2f (max %llu)\n",
+                a * h[0], a * h[1], a * h[2], a * h[3], a * h[4], a * h[5], h[7], h[7] ? (double)h[6] / (double)h[7] : 0.0, b * h[8], b * h[15], b * h[16], b * h[17], b * h[9], b * h[10],
                 h[14] ? (double)h[11] / ((double)h[14] / 16.0) : 0.0, h[14] ? (double)h[12] / (double)h[14] : 0.0, h[13]);
     }
     return GCI_OK;
