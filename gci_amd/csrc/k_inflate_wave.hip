@@ -868,6 +868,8 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* 
     if (s_bad || run != isize) { if (tid == 0) wstatus[m] = s_bad ? 17u : run < isize ? 16u : 18u; return; }
     if (cut == 1u || cut == 4u || cut == 5u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
     if (prof) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_place = n - t_begin; tb = n; }
+    // ---- resolve: pointer jumping; unit u (256 cells) is wave u % 16's, four stretches of 64 cells in flight per step ------------------------
+    // (plain LDS accesses; the compiler may keep nothing of W in registers from one look at a cell to the next: the barrier below)
     // ---- resolve: pointer jumping; unit u (256 cells) is wave u % 16's, four cells per lane in flight -----------------------------------
     // (plain LDS accesses; the compiler may keep nothing of W in registers from one look at a unit to the next: the barrier below)
     const uint32_t n_units = (isize + CP_UNIT - 1u) / CP_UNIT;
@@ -918,6 +920,9 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* 
             }
         }
         pending = next;
+        // (tried: what is open kept per stretch of 64 cells instead of per unit -- 2.4 x the sweeps, 1.8 x the time: a wave with little
+        //  left sweeps it over and over while it waits for cells of other waves; a sleep behind a sweep that changed nothing -- 4 % slower
+        //  whatever its length; two units per step in flight -- 6 - 10 % slower.  profiles/r05h_inflate_copy_place_ab.txt)
     }
     __asm__ volatile("" ::: "memory");
     if (cut == 2u) { if (W[tid] == 0xFFFFu) wstatus[m] = ST_LANES; return; }
