@@ -1923,6 +1923,14 @@ def main():
                 out["cpu_baseline"] = None
             if not args.no_e2e and not args.no_cli_genome and args.reads == "hifi":
                 inp, orc = w.inp, w.oracle_on_chosen
+                # The command line is a process of its own and wants most of the device for itself (150 GB at its peak): what this
+                # process's allocator still caches from the legs above (a second workload, fill buffers, members) goes back to the
+                # driver first -- with it held here the child's inflate ran 40 % longer (5.5 s of device time where the same command
+                # line alone on the box takes 3.3: tools/hwtests/cli_trace.sh, profiles/r05i2_cli_genome_trace.txt).
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
                 survey["3_command_line_genome"] = cli_genome_number(inp, orc)
                 if survey["3_command_line_genome"].get("parity") is False:
                     out["survey_8d"] = survey

@@ -3,7 +3,7 @@
 mkdir -p /root/repo/gpurun_out/$1
 cd /root/repo
 AB=${GCI_TRACE_AB:-'[["traced", {}]]'}
-GCI_EXP_PROFILE=1 GCI_EXP_NO_ROCPROF=1 GCI_PHASES_TRACE=1 GCI_EXP_SAVE=/tmp/ph GCI_EXP_AB="$AB" timeout 560 python tools/exp_cli_genome.py ${2:-0.3} 2>&1 | grep -E "rc [0-9]+ wall" | cut -c1-330
+GCI_EXP_PROFILE=1 GCI_EXP_NO_ROCPROF=1 GCI_PHASES_TRACE=1 GCI_EXP_SAVE=/tmp/ph GCI_EXP_AB="$AB" timeout ${CLI_TRACE_TIMEOUT:-560} python tools/exp_cli_genome.py ${2:-0.3} 2>&1 | grep -E "rc [0-9]+ wall" | cut -c1-330
 python - <<'PY'
 import json,glob,statistics
 for f in sorted(glob.glob("/tmp/ph/phases_*.json")):
