@@ -41,7 +41,8 @@ if os.environ.get("GCI_EXP_PROFILE"):
         if os.environ.get("GCI_EXP_AB"):                   # e.g. '[["16 GiB runs", {"GCI_BAM_CHUNK_BYTES": "17179869184"}]]'
             variants = [("product", {})] + [(a, b) for a, b in json.loads(os.environ["GCI_EXP_AB"])] + [("product again", {})]
         for label, extra in variants:
-            env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, GCI_STUCK_TRACE="15", **extra)
+            env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, GCI_STUCK_TRACE="15")
+            env.update(extra)
             od = os.path.join(tmp, "out_ab")
             shutil.rmtree(od, ignore_errors=True)
             t0 = time.perf_counter()
@@ -55,6 +56,7 @@ if os.environ.get("GCI_EXP_PROFILE"):
                 os.makedirs(os.environ["GCI_EXP_SAVE"], exist_ok=True)
                 ph2 = dict(ph, notes={k: v for k, v in ph["notes"].items() if not k.startswith("depth_gz_layout")})
                 json.dump(ph2, open(os.path.join(os.environ["GCI_EXP_SAVE"], "phases_%s.json" % label.replace(" ", "_")), "w"))
+                open(os.path.join(os.environ["GCI_EXP_SAVE"], "stderr_%s.txt" % label.replace(" ", "_")), "w").write(r.stderr)
             keep = ("bam_ingest", "name_join", "filter[", "fasta", "bgzf_member", "wait")
             if os.environ.get("GCI_EXP_MEMINFO"):            # what the page cache looks like behind the run (huge pages of tmpfs?)
                 mi = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/meminfo")}
