@@ -370,19 +370,17 @@ class _Members:
 
     def group(self, k: int) -> Optional[Tuple[int, int]]:
         """Run k as (first member, one past its last), None behind the last run; self.pos / self.isz cover it afterwards."""
-        # (the wait for the next piece of the table is NOT under the lock: the thread that uploads run k + 1 waits here for a piece
-        #  while the main thread asks for run k -- which is known -- and stood behind it for the quarter of a second the piece took)
-        while True:
-            with self.lock:
-                if k < len(self.groups):
-                    return self.groups[k]
-                rest = self._rest
-                if rest is None:
-                    return None
-            got = rest.result()
-            with self.lock:
-                if self._rest is rest:
-                    self._extend(*got)
+        # (The wait for the next piece IS under the lock, and the main thread, asking for run k while the uploader of run k + 1 waits
+        #  here for a piece, stands behind it -- 0.25 s at the head of a whole-genome file.  Waiting outside the lock was built and
+        #  measured on the round's last day: run 0's inflate then starts beside the assembly's upload and the walk through the second
+        #  piece, and on two boxes of four that first inflate and the upload beside it took 0.9 - 2.3 s instead of 0.1 (the command
+        #  line 7.0 s instead of 5.1: profiles/r05i6_cli_genome_trace_lock_fix_slow_head.txt); on the others nothing was gained --
+        #  the first inflate's allocations took what the wait had taken.  What collides there is not understood yet: DESIGN.md
+        #  section 8.)
+        with self.lock:
+            while k >= len(self.groups) and self._rest is not None:
+                self._extend(*self._rest.result())
+            return self.groups[k] if k < len(self.groups) else None
 
     def is_last(self, k: int) -> bool:
         """Run k is known to be the last one (False while more of the table is to come)."""
@@ -395,15 +393,10 @@ class _Members:
             return [int(self.pos[hi]) - int(self.pos[lo]) for lo, hi in self.groups]
 
     def whole(self) -> Tuple[np.ndarray, np.ndarray]:
-        while True:
-            with self.lock:
-                rest = self._rest
-                if rest is None:
-                    return self.pos, self.isz
-            got = rest.result()
-            with self.lock:
-                if self._rest is rest:
-                    self._extend(*got)
+        with self.lock:
+            while self._rest is not None:
+                self._extend(*self._rest.result())
+            return self.pos, self.isz
 
     def lazy(self) -> bool:
         return self._rest is not None
@@ -676,11 +669,9 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
                     # (more bytes than a whole-file ingestion may inflate to: run by run for certain.)  The table of the beginning of
                     # the file, the first run on its way, and only then the walk through the rest of the file's members
                     engine = default_engine()
-                    # (5/8 of a run's inflated size in file bytes holds a whole first run at the usual 2.4 - 4 : 1; then pieces that
-                    # double -- the walk covers ~120 GB of file per second, the device takes ~45: a piece is there before the runs of
-                    # the one in front of it are used up, where ONE second piece of four run sizes left the device idle for the
-                    # quarter of a second its walk took)
-                    limits = [x for x in (BAM_CHUNK_BYTES * 5 // 8, BAM_CHUNK_BYTES, BAM_CHUNK_BYTES * 2, BAM_CHUNK_BYTES * 4) if x < n_raw]
+                    # (5/8 of a run's inflated size in file bytes holds a whole first run at the usual 2.4 - 4 : 1; four times a
+                    # run's size holds eight more: a second of inflate, which covers the walk through the rest)
+                    limits = [x for x in (BAM_CHUNK_BYTES * 5 // 8, BAM_CHUNK_BYTES * 4) if x < n_raw]
                     rests = [Future() for _ in limits]
                     first = table(path, raw, threads, limit=limits[0]) if limits else table(path, raw, threads)
                     members = _Members(engine, BAM_CHUNK_BYTES, first[0], first[1], rests[0] if rests else None)
