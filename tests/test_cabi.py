@@ -79,3 +79,45 @@ def test_product_does_not_import_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src and "gci_oracle" not in src, fn
     for fn in ("GCI.py",):
         assert "oracle" not in open(os.path.join(ROOT, fn)).read()
+
+
+def test_struct_layouts_agree_with_the_header_as_a_c_compiler_sees_it(tmp_path):
+    """The ctypes mirrors of the header's structs (gci_amd/_lib.py) field by field against offsetof / sizeof from gcc over
+    include/gci_hip.h: a field added on one side only (gci_build_opts.want_runs took what was padding) shows here, off the GPU."""
+    import shutil, subprocess
+    from gci_amd import _lib
+    from gci_amd.device import REC_DTYPE, IVL_DTYPE
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {
+        "gci_join_file": (_lib.JoinFile, [f for f, _ in _lib.JoinFile._fields_]),
+        "gci_window": (_lib.Window, [f for f, _ in _lib.Window._fields_]),
+        "gci_build_opts": (_lib.BuildOpts, [f for f, _ in _lib.BuildOpts._fields_]),
+    }
+    dtypes = {"gci_rec": (REC_DTYPE, ["name_hash", "contig", "start", "end", "qlen", "rec_idx", "mapq", "flags", "name_len"]),
+              "gci_ivl": (IVL_DTYPE, ["contig", "start", "end"])}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gci_hip.h"', 'int main(void) {']
+    for name, (_, fields) in list(structs.items()) + list(dtypes.items()):
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fields:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n"):
+        if ln:
+            a, b, c = ln.split()
+            got[(a, b)] = int(c)
+    for name, (cls, fields) in structs.items():
+        assert ctypes.sizeof(cls) == got[(name, "size")], name
+        for f in fields:
+            assert getattr(cls, f).offset == got[(name, f)], (name, f)
+    for name, (dt, fields) in dtypes.items():
+        assert dt.itemsize == got[(name, "size")], name
+        for f in fields:
+            assert dt.fields[f][1] == got[(name, f)], (name, f)
