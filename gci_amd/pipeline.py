@@ -371,12 +371,10 @@ class _Members:
     def group(self, k: int) -> Optional[Tuple[int, int]]:
         """Run k as (first member, one past its last), None behind the last run; self.pos / self.isz cover it afterwards."""
         # (The wait for the next piece IS under the lock, and the main thread, asking for run k while the uploader of run k + 1 waits
-        #  here for a piece, stands behind it -- 0.25 s at the head of a whole-genome file.  Waiting outside the lock was built and
-        #  measured on the round's last day: run 0's inflate then starts beside the assembly's upload and the walk through the second
-        #  piece, and on two boxes of four that first inflate and the upload beside it took 0.9 - 2.3 s instead of 0.1 (the command
-        #  line 7.0 s instead of 5.1: profiles/r05i6_cli_genome_trace_lock_fix_slow_head.txt); on the others nothing was gained --
-        #  the first inflate's allocations took what the wait had taken.  What collides there is not understood yet: DESIGN.md
-        #  section 8.)
+        #  here for a piece, stands behind it -- 0.25 s at the head of a whole-genome file.  Waiting outside the lock, with pieces of 1,
+        #  2 and 4 run sizes, was built and measured on the round's last day and gained nothing: 5.08 s against 5.10 for the command
+        #  line at genome size -- the first inflate, now beside the walk through the next piece and the assembly's upload, took what the
+        #  wait had taken.  DESIGN.md section 8 "The head of the ingestion".)
         with self.lock:
             while k >= len(self.groups) and self._rest is not None:
                 self._extend(*self._rest.result())
