@@ -51,3 +51,28 @@ def test_warning_and_overwrite_guards(engine, tmp_path, monkeypatch):
             run_scenario(sc, str(tmp_path / "out"), monkeypatch)
             ran += 1
     assert ran == len(NEEDS_GPU)
+
+
+def test_the_quick_exit_is_not_taken_under_a_profiler_or_as_a_rank(monkeypatch):
+    """GCI.py leaves through os._exit after a run that went through (_leave_at_once): not when a tool collects at exit, not as one
+    rank of several, not when GCI_EXIT=clean says so."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gci_launcher_under_test", os.path.join(root, "GCI.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                              # (not __main__: nothing runs)
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS_LIB", "COVERAGE_", "COV_CORE_", "PYTHONFAULTHANDLER")) or k in ("GCI_EXIT", "WORLD_SIZE", "LD_PRELOAD"):
+            monkeypatch.delenv(k, raising=False)
+    assert mod._leave_at_once() is (sys.gettrace() is None)
+    monkeypatch.setenv("GCI_EXIT", "clean")
+    assert mod._leave_at_once() is False
+    monkeypatch.delenv("GCI_EXIT")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert mod._leave_at_once() is False
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("ROCPROFILER_REGISTER_ROOT", "/opt/rocm")
+    assert mod._leave_at_once() is False
+    monkeypatch.delenv("ROCPROFILER_REGISTER_ROOT")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert mod._leave_at_once() is False
