@@ -56,7 +56,7 @@ def test_warning_and_overwrite_guards(engine, tmp_path, monkeypatch):
 def test_the_quick_exit_is_not_taken_under_a_profiler_or_as_a_rank(monkeypatch):
     """GCI.py leaves through os._exit after a run that went through (_leave_at_once): not when a tool collects at exit, not as one
     rank of several, not when GCI_EXIT=clean says so."""
-    import importlib.util, os
+    import importlib.util, os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("gci_launcher_under_test", os.path.join(root, "GCI.py"))
     mod = importlib.util.module_from_spec(spec)
