@@ -33,3 +33,16 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("8 GB torch.empty beside a 4 GB pinned H2D copy: the allocation returned after %.1f ms, the copy was over after %.1f ms (alone: ~75 ms)" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+# first touch: is a fresh allocation slower to write than one that has been written before?  (demand paging -- XNACK / retry faults --
+# would make the FIRST kernel that touches a buffer pay for its pages; the boxes of the pool may differ in that)
+print("xnack / retry:", subprocess.run("(rocminfo 2>/dev/null | grep -i -m2 xnack); echo HSA_XNACK=$HSA_XNACK; cat /sys/module/amdgpu/parameters/noretry 2>/dev/null",
+                                       shell=True, capture_output=True, text=True).stdout.replace("\n", " | "))
+del a, dst
+torch.cuda.empty_cache()
+for gb in (8, 8):
+    b = torch.empty(gb << 30, dtype=torch.uint8, device="cuda")
+    _, f1 = t(lambda: b.fill_(1))
+    _, f2 = t(lambda: b.fill_(2))
+    print("%d GB fresh buffer: first fill %.1f ms (%.0f GB/s), second fill %.1f ms (%.0f GB/s)" % (gb, f1, gb * 1.074 / f1 * 1e3, f2, gb * 1.074 / f2 * 1e3), flush=True)
+    del b
+    torch.cuda.empty_cache()
