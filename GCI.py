@@ -3,9 +3,7 @@
 the work is done by the gfx950 HIP path in gci_amd/ -- see gci_amd/cli.py."""
 import os
 import sys
-import time as _time
 
-_T_START = _time.monotonic()
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (gci_amd/__init__.py says why; here as well: the runtime is woken below, before that import)
 
 
@@ -23,39 +21,6 @@ def _wake_the_gpu():
         hip = ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL)
         if hip.hipInit(0) == 0 and hip.hipSetDevice(int(os.environ.get("LOCAL_RANK", "0") or 0)) == 0:
             hip.hipFree(None)
-            _keep_the_gpu_busy(hip, ctypes)
-    except Exception:                                 # noqa: BLE001
-        pass
-
-
-def _keep_the_gpu_busy(hip, ctypes):
-    """Fills of a 1 GiB buffer, one after the other, from the moment the runtime is up until about when the first run of the first
-    file reaches the device (GCI_WARM_S seconds of process age, default 1.1; 0: off).  On some boxes of the pool the FIRST heavy
-    kernels of a process -- the first inflate: 0.9 - 2.3 s between its events instead of 0.1 -- ran an order of magnitude slower than
-    every later launch of the same kernels; a device that has been idle since the process before clocks up
-    at its own pace, and this gives it the second the interpreter spends importing to do so.  Costs nothing that is waited for: the
-    fills run while nothing else wants the device, and the buffer is gone before the ingestion allocates."""
-    import time
-    until = float(os.environ.get("GCI_WARM_S", "1.1") or 0)
-    if until <= 0:
-        return
-    try:
-        p, st = ctypes.c_void_p(), ctypes.c_void_p()
-        n = 1 << 30
-        if hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) != 0:          # (non-blocking: no ties to the streams of the run)
-            return
-        try:
-            if hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n)) != 0:
-                return
-            while time.monotonic() - _T_START < until:
-                for _ in range(4):
-                    hip.hipMemsetAsync(p, 0, ctypes.c_size_t(n), st)
-                if hip.hipStreamSynchronize(st) != 0:
-                    break
-        finally:
-            if p:
-                hip.hipFree(p)
-            hip.hipStreamDestroy(st)
     except Exception:                                 # noqa: BLE001
         pass
 
