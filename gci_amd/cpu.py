@@ -70,6 +70,8 @@ EXPORTS = [
     ("gci_depth_sum", c_int, [c_void_p, c_void_p, c_void_p]),
     ("gci_range_sums", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     ("gci_cpu_option", c_int, [c_void_p, c_char_p, c_int]),
+    ("gci_depth_deflate_size", c_int, [c_void_p] * 4 + [c_uint32] + [c_void_p] * 4),
+    ("gci_depth_deflate_write", c_int, [c_void_p] * 4 + [c_uint32] + [c_void_p] * 5 + [c_uint64]),
 ]
 
 
@@ -251,6 +253,31 @@ class CpuEngine:
         out = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
         self._chk(self.lib.gci_depth_text_write(self.ctx, _p(track), _p(out), out.shape[0]), "gci_depth_text_write")
         return out[:int(off[-1])], off
+
+    MEMBER_BASES = 64 * 4096
+
+    def depth_deflate(self, track: np.ndarray) -> List[bytes]:
+        """-> per contig the bytes of the gzip members whose payload is its depth lines (device.Engine.depth_deflate's twin)."""
+        elem, cnt, first = [], [], [0]
+        for off, length in zip(self.offsets.tolist(), self.lengths):
+            for g in range(0, int(length), self.MEMBER_BASES):
+                elem.append(int(off) + g)
+                cnt.append(min(self.MEMBER_BASES, int(length) - g))
+            first.append(len(elem))
+        nm = len(elem)
+        if nm == 0:
+            return [b"" for _ in self.lengths]
+        d_elem, d_cnt = np.asarray(elem, dtype=np.uint64), np.asarray(cnt, dtype=np.uint32)
+        tile_bytes = np.zeros(nm * 64, dtype=np.uint32)
+        mb, crc, isz = (np.zeros(nm, dtype=np.uint32) for _ in range(3))
+        self._chk(self.lib.gci_depth_deflate_size(self.ctx, _p(track), _p(d_elem), _p(d_cnt), nm, _p(tile_bytes), _p(mb), _p(crc), _p(isz)),
+                  "gci_depth_deflate_size")
+        offs = np.zeros(nm + 1, dtype=np.uint64)
+        np.cumsum(mb.astype(np.uint64), out=offs[1:])
+        out = np.zeros(int(offs[nm]), dtype=np.uint8)
+        self._chk(self.lib.gci_depth_deflate_write(self.ctx, _p(track), _p(d_elem), _p(d_cnt), nm, _p(tile_bytes), _p(crc), _p(isz), _p(offs),
+                                                   _p(out), out.shape[0]), "gci_depth_deflate_write")
+        return [out[int(offs[first[c]]):int(offs[first[c + 1]])].tobytes() for c in range(len(self.lengths))]
 
     def depth_sum(self, track: np.ndarray) -> np.ndarray:
         s = np.zeros(len(self.lengths), dtype=np.int64)

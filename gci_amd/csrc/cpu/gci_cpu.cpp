@@ -628,3 +628,146 @@ int gci_range_sums(gci_ctx* ctx, const int32_t* depth, const int64_t* ranges, ui
 }
 
 }  // extern "C"
+
+/* ---- N2: the depth text as gzip members (write_depth incl. its gzip, GCI.py:99-143) ------------------------------------------------------
+ * The format libgci_hip.so writes (k_deflate.hip), token for token: a tile of 4096 bases is one fixed-Huffman block -- per run of n
+ * equal depths the line's literals and matches of distance = line width over the other (n - 1) lines, never leaving one or two
+ * bytes behind a match -- closed by an empty stored block (byte alignment); 64 tiles are one member:
+ *     1f 8b 08 00 00000000 00 ff | tile 0 | ... | tile 63 | 03 00 | CRC-32 | ISIZE
+ * Here the text of a tile is written out (12 KB) and its CRC taken byte by byte: no GF(2) algebra to agree with. */
+namespace {
+struct BitW {
+    uint8_t* out = nullptr;          // nullptr: count only
+    uint64_t acc = 0, total = 0;
+    uint32_t nb = 0;
+    void put(uint32_t bits, uint32_t n)
+    {
+        acc |= (uint64_t)bits << nb;
+        nb += n;
+        total += n;
+        while (nb >= 8u) { if (out) *out++ = (uint8_t)acc; acc >>= 8; nb -= 8u; }
+    }
+    void align() { if (nb) put(0u, 8u - nb); }
+};
+inline uint32_t rev(uint32_t v, int bits) { uint32_t r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i); return r; }
+inline void put_literal(BitW& o, uint32_t byte) { o.put(rev(0x30u + byte, 8), 8u); }                     // bytes < 144
+inline void put_match(BitW& o, uint32_t len, uint32_t dist)                                              // 3 <= len <= 258, 2 <= dist <= 12
+{
+    if (len == 258u) o.put(rev(0xC5u, 8), 8u);
+    else {
+        const uint32_t t = len - 3u;
+        uint32_t e = 0;
+        if (t >= 8u) { uint32_t lg = 0; while ((t >> (lg + 1u)) != 0u) lg++; e = lg - 2u; }
+        const uint32_t sym = 257u + 4u * e + (e ? (t >> e) : t);
+        if (sym <= 279u) o.put(rev(sym - 256u, 7), 7u); else o.put(rev(0xC0u + (sym - 280u), 8), 8u);
+        if (e) o.put(t & ((1u << e) - 1u), e);
+    }
+    uint32_t code, eb, ev;
+    if (dist <= 4u) { code = dist - 1u; eb = 0; ev = 0; }
+    else if (dist <= 8u) { code = 4u + ((dist - 5u) >> 1); eb = 1; ev = (dist - 5u) & 1u; }
+    else { code = 6u + ((dist - 9u) >> 2); eb = 2; ev = (dist - 9u) & 3u; }
+    o.put(rev(code, 5), 5u);
+    if (eb) o.put(ev, eb);
+}
+const uint32_t* crc_table()
+{
+    static uint32_t T[256];
+    static const bool made = [] {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u); T[i] = c; }
+        return true;
+    }();
+    (void)made;
+    return T;
+}
+// one tile: its block into o, its text's bytes into the running CRC register / length
+void deflate_tile(const int32_t* d, uint32_t n, BitW& o, uint32_t& crc_reg, uint32_t& text_len)
+{
+    if (n == 0) return;
+    const uint32_t* T = crc_table();
+    o.put(2u, 3u);                                                          // BFINAL = 0, BTYPE = 01
+    for (uint32_t i = 0; i < n;) {
+        uint32_t j = i + 1;
+        while (j < n && d[j] == d[i]) j++;
+        const uint32_t reps = j - i;
+        char line[16];
+        const int w = snprintf(line, sizeof line, "%u\n", (uint32_t)d[i]);
+        for (uint32_t r = 0; r < reps; r++)
+            for (int k = 0; k < w; k++) crc_reg = T[(crc_reg ^ (uint8_t)line[k]) & 0xFFu] ^ (crc_reg >> 8);
+        text_len += reps * (uint32_t)w;
+        for (int k = 0; k < w; k++) put_literal(o, (uint8_t)line[k]);
+        uint32_t rest = (reps - 1u) * (uint32_t)w;
+        while (rest >= 3u) {
+            uint32_t len = rest < 258u ? rest : 258u;
+            if (rest - len != 0u && rest - len < 3u) len = rest - 3u;       // never leave 1 or 2 bytes behind
+            put_match(o, len, (uint32_t)w);
+            rest -= len;
+        }
+        for (uint32_t k = 0; k < rest; k++) put_literal(o, (uint8_t)line[k]);   // (two lines of two bytes: the second as literals)
+        i = j;
+    }
+    o.put(0u, 7u);                                                          // end of block
+    o.put(0u, 3u);                                                          // empty stored block
+    o.align();
+    o.put(0x0000u, 16u);
+    o.put(0xFFFFu, 16u);
+}
+constexpr uint32_t DEF_TILE = 4096, DEF_MEMBER_TILES = 64;
+}  // namespace
+
+extern "C" {
+
+int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* depth, const uint64_t* member_elem, const uint32_t* member_n, uint32_t n_members,
+                           uint32_t* tile_bytes, uint32_t* member_bytes, uint32_t* member_crc, uint32_t* member_isize)
+{
+    if (!ctx || (n_members && (!depth || !member_elem || !member_n || !tile_bytes || !member_bytes || !member_crc || !member_isize)))
+        return GCI_E_INVALID;
+    parallel_blocks(ctx->threads, n_members, 1, [&](uint64_t m, uint64_t) {
+        uint32_t reg = 0xFFFFFFFFu, len = 0, sum = 0;
+        for (uint32_t t = 0; t < DEF_MEMBER_TILES; t++) {
+            const uint32_t first = t * DEF_TILE, n_all = member_n[m];
+            const uint32_t n = n_all > first ? std::min(DEF_TILE, n_all - first) : 0u;
+            BitW o;
+            deflate_tile(depth + member_elem[m] + first, n, o, reg, len);
+            tile_bytes[m * DEF_MEMBER_TILES + t] = (uint32_t)(o.total >> 3);
+            sum += (uint32_t)(o.total >> 3);
+        }
+        member_bytes[m] = sum + 20u;
+        member_crc[m] = reg ^ 0xFFFFFFFFu;
+        member_isize[m] = len;
+    });
+    return GCI_OK;
+}
+
+int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* depth, const uint64_t* member_elem, const uint32_t* member_n, uint32_t n_members,
+                            const uint32_t* tile_bytes, const uint32_t* member_crc, const uint32_t* member_isize, const uint64_t* member_out,
+                            uint8_t* out, uint64_t cap)
+{
+    if (!ctx || (n_members && (!depth || !member_elem || !member_n || !tile_bytes || !member_crc || !member_isize || !member_out || !out)))
+        return GCI_E_INVALID;
+    std::atomic<int> bad{0};
+    parallel_blocks(ctx->threads, n_members, 1, [&](uint64_t m, uint64_t) {
+        uint32_t total = 20u;
+        for (uint32_t t = 0; t < DEF_MEMBER_TILES; t++) total += tile_bytes[m * DEF_MEMBER_TILES + t];
+        if (member_out[m] + total > cap) { bad = 1; return; }
+        uint8_t* h = out + member_out[m];
+        const uint8_t head[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 0xFF};
+        memcpy(h, head, 10);
+        uint8_t* w = h + 10;
+        for (uint32_t t = 0; t < DEF_MEMBER_TILES; t++) {
+            const uint32_t first = t * DEF_TILE, n_all = member_n[m];
+            const uint32_t n = n_all > first ? std::min(DEF_TILE, n_all - first) : 0u;
+            BitW o;
+            o.out = w;
+            uint32_t reg = 0, len = 0;
+            deflate_tile(depth + member_elem[m] + first, n, o, reg, len);
+            w += tile_bytes[m * DEF_MEMBER_TILES + t];
+        }
+        const uint32_t c = member_crc[m], z = member_isize[m];
+        const uint8_t tail[10] = {0x03, 0x00, (uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24),
+                                  (uint8_t)z, (uint8_t)(z >> 8), (uint8_t)(z >> 16), (uint8_t)(z >> 24)};
+        memcpy(w, tail, 10);
+    });
+    return bad ? GCI_E_CAPACITY : GCI_OK;
+}
+
+}  // extern "C"

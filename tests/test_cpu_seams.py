@@ -349,3 +349,47 @@ def test_results_do_not_depend_on_the_threads():
     ta, tb = a.depth_build(ia, 15), b.depth_build(ib, 15)
     assert np.array_equal(ta, tb) and a.depth_text(ta)[0].tobytes() == b.depth_text(tb)[0].tobytes()
     assert np.array_equal(a.issue_keys(ta, -1, 0, 15), b.issue_keys(tb, -1, 0, 15))
+
+
+def test_depth_text_as_gzip_members(eng):
+    """gci_depth_deflate_size / _write behind the same header on the host (N2): the members decompress -- CRC and length checked by
+    Python's gzip -- to exactly f'{depth}\\n' per base: runs of every length and line width, contigs that end inside a tile / a member,
+    depths up to 2^31 - 1; the same cases as tests/test_gpu_seams.py::test_depth_text_as_gzip_members_from_the_gpu."""
+    import gzip
+    rng = np.random.default_rng(77)
+    lens = [1, 3, 4095, 4096, 4097, 64 * 4096 - 1, 64 * 4096, 64 * 4096 + 5, 300_001, 1_000_003]
+    eng.set_layout(lens)
+    host = np.zeros(eng.total, dtype=np.int32)
+    want = []
+    for c, (off, L) in enumerate(zip(eng.offsets.tolist(), lens)):
+        if c % 3 == 0:        # long runs of small depths, like a real track
+            edges = np.sort(rng.choice(np.arange(1, max(L, 2)), size=min(L - 1, max(1, L // 900)), replace=False)) if L > 1 else np.zeros(0, int)
+            vals = rng.integers(0, 130, edges.shape[0] + 1)
+            d = np.repeat(vals, np.diff(np.concatenate(([0], edges, [L]))))
+        elif c % 3 == 1:      # every run length from 1 up, every line width
+            widths = rng.choice([0, 7, 42, 999, 1000, 65_536, 9_999_999, 123_456_789, 2_147_483_647], size=L)
+            rl = rng.integers(1, 6, size=L)
+            d = np.repeat(widths, rl)[:L]
+        else:                 # no two neighbours equal
+            d = (np.arange(L) * 7919 + c) % 1013
+        host[off:off + L] = d
+        want.append(("\n".join(map(str, d.tolist())) + "\n").encode())
+    members = eng.depth_deflate(host)
+    assert len(members) == len(lens)
+    for c, blob in enumerate(members):
+        assert blob[:4] == b"\x1f\x8b\x08\x00"
+        assert gzip.decompress(blob) == want[c], c
+        assert blob.count(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff") >= -(-lens[c] // (64 * 4096))
+    assert len(members[9]) * 40 < len(want[9])
+    text, off_t = eng.depth_text(host)
+    whole = text.tobytes()
+    for c in range(len(lens)):
+        assert gzip.decompress(members[c]) == whole[int(off_t[c]):int(off_t[c + 1])]
+    # two lines of two bytes (the second goes out as literals), three of them, and a run of 4096
+    eng.set_layout([2, 3, 4096])
+    t = np.concatenate([np.full(2, 7), np.full(3, 7), np.full(4096, 5)]).astype(np.int32)
+    tr = np.zeros(eng.total, dtype=np.int32)
+    for c, (off, L) in enumerate(zip(eng.offsets.tolist(), [2, 3, 4096])):
+        tr[off:off + L] = [7, 7, 5][c]
+    got = eng.depth_deflate(tr)
+    assert [gzip.decompress(b) for b in got] == [b"7\n" * 2, b"7\n" * 3, b"5\n" * 4096]

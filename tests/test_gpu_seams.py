@@ -766,6 +766,13 @@ def test_depth_text_as_gzip_members_from_the_gpu(engine):
     whole = text.cpu().numpy().tobytes()
     for c in range(len(lens)):
         assert gzip.decompress(members[c]) == whole[int(off_t[c]):int(off_t[c + 1])]
+    # byte for byte what libgci_cpu.so -- the same header through g++, the text written out and its CRC taken byte by byte -- makes
+    # of the same track: the token rules and the GF(2) arithmetic of the device's CRC against an implementation without either trick
+    from gci_amd import cpu
+    ce = cpu.CpuEngine(threads=8)
+    ce.set_layout(lens)
+    assert [bytes(b) for b in ce.depth_deflate(host)] == members
+    ce.close()
 
 
 def test_gzip_members_from_the_run_lists_the_build_keeps(engine):
