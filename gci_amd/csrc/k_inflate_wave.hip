@@ -718,6 +718,33 @@ __device__ __forceinline__ void cp_first_tiles(CpTiles& b, const uint32_t* __res
     for (int k = 0; k < IW_CP_PF; k++) b.t[k] = cp_load4(msym, 4u * tid + (uint32_t)k * 4u * (uint32_t)IW_CP_THREADS, ns);
 }
 
+// One sweep over a unit of 256 cells, four per lane (cells i0 + 64 k): a cell whose target holds a byte takes it, one whose target is a
+// pointer adds the two distances when the sum still fits.  -> some cell of this lane still points at a pointer.
+template <bool WHOLE>
+__device__ __forceinline__ bool resolve_unit(uint16_t* __restrict__ W, uint32_t i0, uint32_t isize)
+{
+    uint32_t v[4], u[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; v[k] = WHOLE || i < isize ? (uint32_t)W[i] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                                        // (a cell that holds a byte reads itself: no branch around the look-up)
+        const uint32_t i = i0 + 64u * (uint32_t)k;
+        const uint32_t src = (v[k] & 0x8000u) ? i - (v[k] & 0x7FFFu) - 1u : (WHOLE || i < isize ? i : 0u);
+        u[k] = (uint32_t)W[src];
+    }
+    bool open = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = i0 + 64u * (uint32_t)k;
+        const bool ptr = (v[k] & 0x8000u) != 0u, to_ptr = (u[k] & 0x8000u) != 0u;
+        const uint32_t d2 = (v[k] & 0x7FFFu) + (u[k] & 0x7FFFu) + 2u;
+        const uint32_t nv = !to_ptr ? u[k] : d2 <= 0x8000u ? 0x8000u | (d2 - 1u) : v[k];
+        if (ptr && nv != v[k]) W[i] = (uint16_t)nv;
+        open = open || (ptr && to_ptr);
+    }
+    return open;
+}
+
 // one member (member mb of the batch) by the whole workgroup; mb_next: the member this workgroup takes after it
 template <bool MEASURE>
 __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* __restrict__ SB, uint32_t (*wsum)[CP_WAVES], uint32_t& s_bad, uint32_t mb,
@@ -732,7 +759,8 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* 
     unsigned long long t_scan = 0, t_cells = 0, t_long = 0;
     const unsigned long long t_begin = tb;
     const uint32_t m = m0 + mb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (uniform: the loops over a wave's units and tiles are scalar code)
     const CpMeta me = meta;
     CpTiles buf = first;
     meta = cp_meta(mb_next, n_batch, m0, n_sym, wstatus, out_off);         // (in flight from here on; looked at behind the place phase)
@@ -878,46 +906,15 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* 
     while (pending) {
         uint32_t next = 0;
         n_rounds++;
-        for (uint32_t rest = pending; rest;) {
-            constexpr int NU = IW_CP_RES_UNITS;                          // units a wave has in flight (4 cells per lane each)
-            uint32_t jj[NU], i0[NU], lim[NU];
-#pragma unroll
-            for (int q = 0; q < NU; q++) {
-                const bool has = rest != 0u;
-                jj[q] = has ? (uint32_t)__ffs((int)rest) - 1u : 0u;
-                rest &= rest - (has ? 1u : 0u);
-                i0[q] = ((uint32_t)wave + (uint32_t)CP_WAVES * jj[q]) * CP_UNIT + (uint32_t)lane;
-                lim[q] = has ? isize : 0u;
-                n_ur += has ? 1u : 0u;
-            }
+        for (uint32_t rest = pending; rest; rest &= rest - 1u) {
+            const uint32_t j = (uint32_t)__ffs((int)rest) - 1u;
+            const uint32_t base = ((uint32_t)wave + (uint32_t)CP_WAVES * j) * CP_UNIT;
+            n_ur++;
             __asm__ volatile("" ::: "memory");
-            uint32_t v[NU][4], u[NU][4];
-#pragma unroll
-            for (int q = 0; q < NU; q++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const uint32_t i = i0[q] + 64u * (uint32_t)k; v[q][k] = i < lim[q] ? (uint32_t)W[i] : 0u; }
-#pragma unroll
-            for (int q = 0; q < NU; q++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {                            // (a cell that holds a byte reads itself: no branch around the look-up)
-                    const uint32_t i = i0[q] + 64u * (uint32_t)k;
-                    const uint32_t src = (v[q][k] & 0x8000u) ? i - (v[q][k] & 0x7FFFu) - 1u : (i < lim[q] ? i : 0u);
-                    u[q][k] = (uint32_t)W[src];
-                }
-#pragma unroll
-            for (int q = 0; q < NU; q++) {
-                bool open = false;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = i0[q] + 64u * (uint32_t)k;
-                    const bool ptr = (v[q][k] & 0x8000u) != 0u, to_ptr = (u[q][k] & 0x8000u) != 0u;
-                    const uint32_t d2 = (v[q][k] & 0x7FFFu) + (u[q][k] & 0x7FFFu) + 2u;
-                    const uint32_t nv = !to_ptr ? u[q][k] : d2 <= 0x8000u ? 0x8000u | (d2 - 1u) : v[q][k];
-                    if (ptr && nv != v[q][k]) W[i] = (uint16_t)nv;
-                    open = open || (ptr && to_ptr);
-                }
-                if (__ballot(open)) next |= 1u << jj[q];
-            }
+            // (a member of 0xFF00 bytes is 255 whole units: the bounds of a cell are looked at for the member's last, partial unit only)
+            const bool open = base + CP_UNIT <= isize ? resolve_unit<true>(W, base + (uint32_t)lane, isize)
+                                                      : resolve_unit<false>(W, base + (uint32_t)lane, isize);
+            if (__ballot(open)) next |= 1u << j;
         }
         pending = next;
         // (tried: what is open kept per stretch of 64 cells instead of per unit -- 2.4 x the sweeps, 1.8 x the time: a wave with little
