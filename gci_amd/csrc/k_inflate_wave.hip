@@ -723,26 +723,27 @@ __device__ __forceinline__ void cp_first_tiles(CpTiles& b, const uint32_t* __res
 template <bool WHOLE>
 __device__ __forceinline__ bool resolve_unit(uint16_t* __restrict__ W, uint32_t i0, uint32_t isize)
 {
+    // (written for the instruction count -- the kernel is bound by it: a pointer is 0x8000 | (distance - 1), so its distance is
+    //  max(v, 0x7FFF) - 0x7FFF, which is 0 for a byte; two pointers in a row add up to v + u - 0x7FFF, which fits while it is <= 0xFFFF)
     uint32_t v[4], u[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; v[k] = WHOLE || i < isize ? (uint32_t)W[i] : 0u; }
 #pragma unroll
     for (int k = 0; k < 4; k++) {                                        // (a cell that holds a byte reads itself: no branch around the look-up)
         const uint32_t i = i0 + 64u * (uint32_t)k;
-        const uint32_t src = (v[k] & 0x8000u) ? i - (v[k] & 0x7FFFu) - 1u : (WHOLE || i < isize ? i : 0u);
-        u[k] = (uint32_t)W[src];
+        const uint32_t back = max(v[k], 0x7FFFu) - 0x7FFFu;
+        u[k] = (uint32_t)W[WHOLE || i < isize ? i - back : 0u];
     }
-    bool open = false;
+    uint32_t both = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t i = i0 + 64u * (uint32_t)k;
-        const bool ptr = (v[k] & 0x8000u) != 0u, to_ptr = (u[k] & 0x8000u) != 0u;
-        const uint32_t d2 = (v[k] & 0x7FFFu) + (u[k] & 0x7FFFu) + 2u;
-        const uint32_t nv = !to_ptr ? u[k] : d2 <= 0x8000u ? 0x8000u | (d2 - 1u) : v[k];
-        if (ptr && nv != v[k]) W[i] = (uint16_t)nv;
-        open = open || (ptr && to_ptr);
+        const uint32_t sum = v[k] + u[k] - 0x7FFFu;
+        const uint32_t nv = u[k] < 0x8000u ? u[k] : sum <= 0xFFFFu ? sum : v[k];
+        if (v[k] >= 0x8000u && nv != v[k]) W[i] = (uint16_t)nv;
+        both |= v[k] & u[k];
     }
-    return open;
+    return (both & 0x8000u) != 0u;
 }
 
 // one member (member mb of the batch) by the whole workgroup; mb_next: the member this workgroup takes after it
