@@ -696,6 +696,9 @@ __device__ __forceinline__ CpMeta cp_meta(uint32_t mb, uint32_t n_batch, uint32_
 #ifndef IW_CP_PF
 #define IW_CP_PF 2
 #endif
+#ifndef IW_CP_FILL_LEAN
+#define IW_CP_FILL_LEAN 0                // (see the fill loop: a variant waiting for its measurement)
+#endif
 #ifndef IW_CP_FILL_STEPS
 #define IW_CP_FILL_STEPS 4
 #endif
@@ -854,6 +857,9 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* 
             while (SB[p] == 0u) p--;                                           // (word 0 holds bit 0: the member's first symbol)
             carry = 32u * p + 31u - (uint32_t)__clz((int)SB[p]);
         }
+#if IW_CP_FILL_LEAN
+        carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)carry);
+#endif
         const uint32_t c_end = min(isize, c0 + 4096u);
         constexpr uint32_t FS = IW_CP_FILL_STEPS;                              // steps (64 cells each) in flight: their LDS round trips overlap
         for (; c0 < c_end; c0 += 64u * FS) {
@@ -862,7 +868,15 @@ __device__ __forceinline__ void copy_member(uint16_t* __restrict__ W, uint32_t* 
 #pragma unroll
             for (uint32_t f = 0; f < FS; f++) {
                 const uint32_t w0 = min((c0 >> 5) + 2u * f, 2048u);              // (behind the member's cells: the two zero words)
+#if IW_CP_FILL_LEAN
+                // (NOT MEASURED YET -- built on the round's last day without a device to run it on; tools/hwtests/build_iw_variants.sh
+                //  lean="-DIW_CP_FILL_LEAN=1": the step's start bits as scalars, so that what depends on them alone -- the start
+                //  carried into the next step -- is scalar code)
+                m[f] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)SB[w0 + 1u]) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)SB[w0]);
+#else
                 m[f] = ((unsigned long long)SB[w0 + 1u] << 32) | SB[w0];
+#endif
             }
 #pragma unroll
             for (uint32_t f = 0; f < FS; f++) {
