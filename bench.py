@@ -1408,6 +1408,11 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
                 "startup_seconds_outside_the_phase_log": wall - rep["total_s"],
                 "phases_wall_s": {k: round(v, 4) for k, v in rep["wall_s"].items()},
                 "phases_device_s": {k: round(v, 4) for k, v in rep["gpu_s"].items()},
+                # (the first and the longest call of every device stage, and how many there were: on some boxes the first inflate of the
+                #  first file takes 1 - 2 s instead of 0.1 -- DESIGN.md section 8 -- and this is where a run says whether it met one)
+                "phases_device_first_call_s": {k: round(v, 4) for k, v in rep.get("gpu_first_s", {}).items()},
+                "phases_device_longest_call_s": {k: round(v, 4) for k, v in rep.get("gpu_max_s", {}).items()},
+                "phases_device_calls": rep.get("gpu_calls", {}),
                 "bgzf_bytes": rep["notes"].get("bgzf_bytes"), "inflated_bytes": rep["notes"].get("inflated_bytes"),
                 "bgzf_members": rep["notes"].get("bgzf_members"),
                 "deflate_ratio": rep["notes"].get("inflated_bytes", 0) / max(1, rep["notes"].get("bgzf_bytes", 1)),

@@ -126,8 +126,15 @@ def report(path: Optional[str] = None) -> dict:
     if _GPU:
         import torch
         torch.cuda.synchronize()
+        # per stage also its FIRST occurrence, its longest one and their number: a first call that takes ten times the later ones (the
+        # first inflate of a file on some boxes: DESIGN.md section 8) shows in every phase log, traced or not
+        out["gpu_first_s"], out["gpu_max_s"], out["gpu_calls"] = {}, {}, {}
         for name, a, b in _GPU:
-            out["gpu_s"][name] = out["gpu_s"].get(name, 0.0) + a.elapsed_time(b) * 1e-3
+            dt = a.elapsed_time(b) * 1e-3
+            out["gpu_s"][name] = out["gpu_s"].get(name, 0.0) + dt
+            out["gpu_first_s"].setdefault(name, dt)
+            out["gpu_max_s"][name] = max(out["gpu_max_s"].get(name, 0.0), dt)
+            out["gpu_calls"][name] = out["gpu_calls"].get(name, 0) + 1
         if _TRACE and _BASE is not None:                  # every stage on the host's clock: [name, begin, end]
             e0, t0 = _BASE
             out["gpu_trace"] = [[name, round(t0 + e0.elapsed_time(a) * 1e-3, 4), round(t0 + e0.elapsed_time(b) * 1e-3, 4)] for name, a, b in _GPU]
