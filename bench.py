@@ -1958,6 +1958,7 @@ def main():
                 "3_command_line_genome_s": g3.get("seconds"), "3_first_pass_s": g3.get("seconds_first_pass_over_freshly_written_files"),
                 "3_command_line_genome_gbases_per_s": g3.get("gbases_per_s"),
                 "3_inflate_crc_device_s": (g3.get("phases_device_s") or {}).get("bgzf_inflate + crc"),
+                "3_first_inflate_call_s": (g3.get("phases_device_first_call_s") or {}).get("bgzf_inflate + crc"),
                 "3_parity": g3.get("parity")}
         elif not args.no_cpu_baseline:
             cdt, depths, bed, text, mean = cpu_baseline_chr19(w)
