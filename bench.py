@@ -1130,7 +1130,7 @@ def cli_shaped_step(eng, w, steps):
             w.step_records()
             chk(lib.gci_depth_build_begin(ctx, _p(w.ivl), _p(w.count), int(w.ivl.shape[0]), ctypes.byref(o)), "gci_depth_build_begin")
             chk(lib.gci_depth_build_finish(ctx, _p(w.track), None, 0), "gci_depth_build_finish")
-            return eng.depth_deflate(w.track)
+            return eng.depth_deflate(w.track, from_build=True)
         blobs = one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -59,6 +59,28 @@ EXPORTS = [
     ("gci_memcpy_h2d", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     ("gci_memcpy_d2h", c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     ("gci_memset", c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    ("gci_dev_last_error", c_char_p, []),
+    ("gci_dev_count", c_int, [POINTER(c_int)]),
+    ("gci_dev_malloc", c_int, [c_int, c_size_t, POINTER(c_void_p)]),
+    ("gci_dev_free", c_int, [c_int, c_void_p]),
+    ("gci_dev_mem_info", c_int, [c_int, POINTER(c_uint64), POINTER(c_uint64)]),
+    ("gci_dev_sync", c_int, [c_int]),
+    ("gci_dev_host_alloc", c_int, [c_int, c_size_t, POINTER(c_void_p)]),
+    ("gci_dev_host_free", c_int, [c_int, c_void_p]),
+    ("gci_dev_stream_create", c_int, [c_int, POINTER(c_void_p)]),
+    ("gci_dev_stream_destroy", c_int, [c_int, c_void_p]),
+    ("gci_dev_stream_sync", c_int, [c_int, c_void_p]),
+    ("gci_dev_event_create", c_int, [c_int, c_int, POINTER(c_void_p)]),
+    ("gci_dev_event_destroy", c_int, [c_int, c_void_p]),
+    ("gci_dev_event_record", c_int, [c_int, c_void_p, c_void_p]),
+    ("gci_dev_event_sync", c_int, [c_int, c_void_p]),
+    ("gci_dev_event_elapsed_ms", c_int, [c_int, c_void_p, c_void_p, POINTER(c_double)]),
+    ("gci_dev_stream_wait_event", c_int, [c_int, c_void_p, c_void_p]),
+    ("gci_dev_memcpy_async", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    ("gci_dev_memset_async", c_int, [c_int, c_void_p, c_int, c_size_t, c_void_p]),
+    ("gci_dev_i64_add", c_int, [c_int, c_void_p, c_uint64, c_int64, c_void_p, c_void_p]),
+    ("gci_dev_rec_flags_and", c_int, [c_int, c_void_p, c_uint64, c_uint32, c_void_p]),
+    ("gci_dev_u32_scan_u64", c_int, [c_int, c_void_p, c_uint32, c_void_p, c_void_p]),
     ("gci_profile_enable", c_int, [c_void_p, c_int]),
     ("gci_profile_read", c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_uint64), c_int]),
     ("gci_profile_name", c_char_p, [c_int]),
@@ -79,6 +101,7 @@ EXPORTS = [
     ("gci_join_mode", c_int, [c_void_p, c_int]),
     ("gci_name_join_count", c_int, [c_void_p, POINTER(JoinFile), c_int, c_double, c_void_p, c_void_p, c_uint32, c_void_p,
                               c_void_p, c_int]),
+    ("gci_depth_deflate_from_build", c_int, [c_void_p, c_void_p]),
     ("gci_depth_deflate_size", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("gci_depth_deflate_write", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_uint64]),
@@ -126,6 +149,7 @@ EXPORTS = [
     ("gci_stage_send_fd", c_int, [c_void_p, c_void_p, c_int, c_uint64, c_uint64, c_void_p, c_void_p, c_int]),
     ("gci_stage_free", c_int, [c_void_p]),
     ("gci_bgzf_inflate_device", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
+    ("gci_bgzf_inflate_streams", c_int, [c_void_p, c_int]),
     ("gci_bgzf_inflate_last_stats", c_int, [c_void_p, c_void_p]),
     ("gci_bgzf_inflate_round", c_uint32, [c_void_p]),
     ("gci_bam_record_offsets_device", c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_int32, c_void_p, c_uint64, c_void_p]),

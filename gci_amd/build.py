@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libgci_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("api_ctx.hip", "k_filter.hip", "k_join.hip", "k_depth.hip", "k_track.hip", "k_deflate.hip", "k_paf.hip", "k_inflate.hip", "k_inflate_wave.hip", "k_pages.hip", "k_shard.hip", "host_io.cpp", "staging.cpp")]
+SOURCES = [os.path.join(CSRC, f) for f in ("api_ctx.hip", "k_filter.hip", "k_join.hip", "k_depth.hip", "k_track.hip", "k_deflate.hip", "k_paf.hip", "k_inflate.hip", "k_inflate_wave.hip", "k_pages.hip", "k_shard.hip", "k_hbm.hip", "host_io.cpp", "staging.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "gci_common.h"), os.path.join(CSRC, "gci_ctx.hpp"),
                   os.path.join(_HERE, "..", "include", "gci_hip.h")]
 

@@ -341,6 +341,8 @@ def _run(args, ctx):
                 dist.destroy_process_group()
         return
     GCI(**args)
+    if os.environ.get("GCI_ASSERT_NO_TORCH") == "1" and "torch" in sys.modules:      # (tests/test_gpu_native.py: a single-GPU run holds its buffers itself)
+        sys.exit("ERROR!!! internal: a single-GPU run imported torch")
 
 
 if __name__ == "__main__":

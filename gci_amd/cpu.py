@@ -70,6 +70,7 @@ EXPORTS = [
     ("gci_depth_sum", c_int, [c_void_p, c_void_p, c_void_p]),
     ("gci_range_sums", c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     ("gci_cpu_option", c_int, [c_void_p, c_char_p, c_int]),
+    ("gci_depth_deflate_from_build", c_int, [c_void_p, c_void_p]),
     ("gci_depth_deflate_size", c_int, [c_void_p] * 4 + [c_uint32] + [c_void_p] * 4),
     ("gci_depth_deflate_write", c_int, [c_void_p] * 4 + [c_uint32] + [c_void_p] * 5 + [c_uint64]),
 ]

@@ -235,7 +235,7 @@ extern "C" int gci_layout_set(gci_ctx* ctx, int32_t n, const int64_t* h_len)
     HIPCHK(hipMemsetAsync(ctx->tile_cd.p, 0, (size_t)(tiles + 1) * 8, ctx->stream));
     ctx->cd_state = 0;
     ctx->build_pending = false;
-    ctx->build_runs_track = nullptr;
+    ctx->build_runs_track = nullptr; ctx->build_runs_armed = false;
     return GCI_OK;
 }
 

@@ -716,6 +716,12 @@ constexpr uint32_t DEF_TILE = 4096, DEF_MEMBER_TILES = 64;
 
 extern "C" {
 
+int gci_depth_deflate_from_build(gci_ctx* ctx, const int32_t* depth)
+{
+    (void)ctx; (void)depth;
+    return GCI_E_INVALID;                              // this library's build keeps no run lists: the pair always walks the track
+}
+
 int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* depth, const uint64_t* member_elem, const uint32_t* member_n, uint32_t n_members,
                            uint32_t* tile_bytes, uint32_t* member_bytes, uint32_t* member_crc, uint32_t* member_isize)
 {

@@ -66,6 +66,7 @@ struct gci_ctx {
     bool build_runs_wanted = false;         // gci_build_opts.want_runs of the pending build
     DevBuf build_nruns, build_runs;         // ... per tile of the layout its constant-depth runs, as k_tile_build saw them
     const void* build_runs_track = nullptr; // ... and the track they describe (nullptr: none; cleared by whatever writes a track)
+    bool build_runs_armed = false;          // ... gci_depth_deflate_from_build() has said that track is untouched: the next size / write pair may use them
     // join scratch
     DevBuf join_table, join_last, join_hq;
     DevBuf join_bucket;                     // partitioned join: per bucket its survivor count, first slot and output offset
@@ -93,6 +94,7 @@ struct gci_ctx {
     uint32_t inflate_last_n = 0;            // members of the last gci_bgzf_inflate_device call (0: the wave decoder was not used)
     DevBuf inflate_sym, inflate_nsym, inflate_wstatus, inflate_lists, inflate_prof, inflate_next;
     DevBuf inflate_sym2, inflate_lists2;    // ... of the batches that run on the second stream
+    int inflate_streams = 1;                // gci_bgzf_inflate_streams(): 2 = every other batch of members on inflate_stream2
     hipStream_t inflate_stream2 = nullptr;  // k_inflate_wave.hip: every other batch of members on a stream of its own (made on first use)
     hipEvent_t inflate_ev_in = nullptr, inflate_ev_out = nullptr;   // k_inflate_wave.hip: a batch's symbol streams, per member its symbols and how it fared
     DevBuf tail_sums;                       // gci_two_type_tail: per-tile sums of the three tracks

@@ -483,7 +483,8 @@ extern "C" int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, cons
     const uint64_t n_tiles = (uint64_t)n_members * MEMBER_TILES;
     // the run lists: those the depth build of this very track kept (gci_build_opts.want_runs -- the track is then not read for
     // them; k_depth_runs only looks at the tiles the build left out), else made here from the track
-    const bool from_build = ctx->build_runs_track != nullptr && ctx->build_runs_track == d_depth;
+    const bool from_build = ctx->build_runs_armed && ctx->build_runs_track != nullptr && ctx->build_runs_track == d_depth;
+    ctx->build_runs_armed = false;                           // (said for one size call)
     if (!from_build) {
         GCI_TRY(gci_ensure(ctx, ctx->deflate_nruns, n_tiles * 4));
         GCI_TRY(gci_ensure(ctx, ctx->deflate_runs, n_tiles * RUN_MAX * sizeof(int2)));
@@ -524,5 +525,13 @@ extern "C" int gci_depth_deflate_write(gci_ctx* ctx, const int32_t* d_depth, con
                        (const int2*)(from_build ? ctx->build_runs.p : ctx->deflate_runs.p), from_build,
                        from_build ? (uint64_t)ctx->n_tiles : (uint64_t)n_members * MEMBER_TILES, (const uint32_t*)ctx->deflate_tab.p);
     LAUNCHCHK("k_depth_deflate<2>");
+    if (from_build) { ctx->build_runs_track = nullptr; ctx->deflate_from_build = false; ctx->deflate_members = 0; }   // one shot
+    return GCI_OK;
+}
+
+extern "C" int gci_depth_deflate_from_build(gci_ctx* ctx, const int32_t* d_depth)
+{
+    if (!ctx || !d_depth || ctx->build_runs_track == nullptr || ctx->build_runs_track != d_depth) return GCI_E_INVALID;
+    ctx->build_runs_armed = true;
     return GCI_OK;
 }

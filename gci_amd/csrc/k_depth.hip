@@ -1153,7 +1153,7 @@ extern "C" int gci_depth_build_begin(gci_ctx* ctx, const gci_ivl* d_ivl, const u
     if (o->want_text && !o->d_contig_text_off) return GCI_E_INVALID;
     if (o->d_n_keys && o->key_cap && !o->d_keys) return GCI_E_INVALID;
     ctx->build_pending = false;
-    ctx->build_runs_track = nullptr;                        // whatever lists an earlier build kept describe another track now
+    ctx->build_runs_track = nullptr; ctx->build_runs_armed = false;                        // whatever lists an earlier build kept describe another track now
     ctx->build_runs_wanted = false;
     const int64_t nt = ctx->n_tiles;
     if (nt == 0) {

@@ -1015,14 +1015,12 @@ int gci_inflate_wave_run(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_m
     // scratch of its own: a wave takes a millisecond per member, so the last members of a batch leave most of the chip idle -- the
     // other stream's kernels move in as CUs fall free (and the copy kernel of one batch runs beside the decode of the next).
     static const bool copy_persistent = [] { const char* e = getenv("GCI_INFLATE_COPY_GRID"); return !(e && !strcmp(e, "members")); }();   // (A/B)
-    // (two streams only in a process whose runtime has hardware queues to spare -- GPU_MAX_HW_QUEUES >= 8, which gci_amd sets --: with the
-    // default four, the second stream came to share a queue with the host's copy stream and every upload waited for an inflate)
-    static const int n_streams = [] {
-        const char* e = getenv("GCI_INFLATE_STREAMS");
-        const char* q = getenv("GPU_MAX_HW_QUEUES");
-        const int v = e ? atoi(e) : (q && atoi(q) >= 8 ? 2 : 1);
-        return v < 1 ? 1 : v > 2 ? 2 : v;
-    }();
+    // (two streams only when the HOST says its runtime has hardware queues to spare -- gci_bgzf_inflate_streams(ctx, 2), which
+    // gci_amd calls when it placed GPU_MAX_HW_QUEUES=8 in the environment BEFORE the runtime started --: with the default four, the
+    // second stream came to share a queue with the host's copy stream and every upload waited for an inflate.  The environment
+    // string alone proves nothing: a runtime that was already running when the variable was set has four queues all the same.)
+    static const int env_streams = [] { const char* e = getenv("GCI_INFLATE_STREAMS"); return e ? atoi(e) : 0; }();   // (A/B)
+    const int n_streams = env_streams >= 1 ? (env_streams > 2 ? 2 : env_streams) : ctx->inflate_streams;
     const uint32_t batch = n_members < batch_max ? n_members : batch_max;
     const uint32_t n_batches = (n_members + batch - 1u) / batch;
     const bool two = n_streams == 2 && n_batches > 1u && !want_prof;
@@ -1104,5 +1102,12 @@ extern "C" int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[32])
     HIPCHK(hipMemcpyAsync(h.data(), ctx->inflate_wstatus.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (uint32_t v : h) h_counts[v < 31u ? v : 31u]++;
+    return GCI_OK;
+}
+
+extern "C" int gci_bgzf_inflate_streams(gci_ctx* ctx, int n)
+{
+    if (!ctx || n < 1 || n > 2) return GCI_E_INVALID;
+    ctx->inflate_streams = n;
     return GCI_OK;
 }

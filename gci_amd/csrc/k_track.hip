@@ -27,7 +27,7 @@ extern "C" int gci_gap_mask(gci_ctx* ctx, int32_t* d_depth, const gci_ivl* d_gap
 {
     if (!ctx || !d_depth || (n_gaps && !d_gaps)) return GCI_E_INVALID;
     if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
-    ctx->build_runs_track = nullptr;                       // (a build's run lists, gci_build_opts.want_runs, describe no track any more)
+    ctx->build_runs_track = nullptr; ctx->build_runs_armed = false;                       // (a build's run lists, gci_build_opts.want_runs, describe no track any more)
     ProfScope _ps(ctx, GCI_PROF_GAP_MASK);
     for (uint32_t done = 0; done < n_gaps; done += 65535) {
         const uint32_t n = n_gaps - done < 65535 ? n_gaps - done : 65535;
@@ -53,7 +53,7 @@ extern "C" int gci_max2(gci_ctx* ctx, const int32_t* a, const int32_t* b, int32_
 {
     if (!ctx || !a || !b || !o) return GCI_E_INVALID;
     if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
-    ctx->build_runs_track = nullptr;
+    ctx->build_runs_track = nullptr; ctx->build_runs_armed = false;
     const int64_t n4 = ctx->total / 4;
     if (n4 == 0) return GCI_OK;
     const int64_t want = (n4 + BLOCK * 4 - 1) / (BLOCK * 4);
@@ -356,7 +356,7 @@ extern "C" int gci_two_type_tail(gci_ctx* ctx, int32_t* d_a, int32_t* d_b, int32
 {
     if (!ctx || !d_a || !d_b || !d_out || !d_n_keys || (cap && !d_keys) || (n_gaps && !h_gaps)) return GCI_E_INVALID;
     if (!ctx->n_contigs) return GCI_E_NO_LAYOUT;
-    ctx->build_runs_track = nullptr;
+    ctx->build_runs_track = nullptr; ctx->build_runs_armed = false;
     HIPCHK(hipMemsetAsync(d_n_keys, 0, 12, ctx->stream));
     if (d_sums) HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)3 * ctx->n_contigs * 8, ctx->stream));
     if (ctx->n_tiles == 0) return GCI_OK;

@@ -1,7 +1,8 @@
 """Device side of the path: one `Engine` per GPU wrapping a gci_ctx (include/gci_hip.h).
 
-torch is plumbing only: it owns the HBM buffers and the stream; every per-record and per-base
-operation is a hand-written gfx950 kernel reached through the C ABI.  Nothing here computes on
+HBM buffers, streams and events come from a provider (gci_amd/hbm.py): the library's own `gci_dev_*` exports for the single-GPU
+command line (no `import torch` in that process), or torch for contig-sharded runs and the test fixtures -- plumbing either way:
+every per-record and per-base operation is a hand-written gfx950 kernel reached through the C ABI.  Nothing here computes on
 the CPU; a missing library or GPU raises.
 """
 from __future__ import annotations
@@ -12,12 +13,11 @@ import threading
 from concurrent.futures import ThreadPoolExecutor
 import warnings
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
-import torch
 
-from . import _lib
+from . import _lib, hbm
 from ._lib import BuildOpts, GciError, JoinFile, Window
 
 REC_DTYPE = np.dtype([("name_hash", "<u8"), ("contig", "<i4"), ("start", "<i4"), ("end", "<i4"), ("qlen", "<i4"),
@@ -26,6 +26,7 @@ assert REC_DTYPE.itemsize == 32
 IVL_DTYPE = np.dtype([("contig", "<i4"), ("start", "<i4"), ("end", "<i4"), ("pad", "<i4")])
 
 _M64 = (1 << 64) - 1
+Buffer = Any                  # a device buffer of the engine's provider: hbm.Buf or Buffer
 
 
 def name_hash_np(names: Sequence[bytes]) -> np.ndarray:
@@ -102,17 +103,24 @@ class _Staging:
         self.urgent = 0
 
         def pin(k):                             # page-locking 64 MB takes ~20 ms: the slots side by side, the first piece waits for one
-            self.slots[k] = torch.empty(self.SLOT, dtype=torch.uint8).pin_memory()
+            self.slots[k] = engine.T.pinned(self.SLOT)
             self.views[k] = self.slots[k].numpy()
 
         self.pinned = [self.pool.submit(pin, k) for k in range(self.SLOTS)]
 
     def close(self):
+        """The ring's threads, pinned slots and events (gci_stage_free), and the descriptors the pread path kept open."""
         if self.native is not None:
             self.engine.lib.gci_stage_free(self.native)
             self.native = None
+        for fd in self._fds.values():
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        self._fds.clear()
 
-    def send(self, raw, p0: int, p1: int, dst: torch.Tensor, stream, urgent: bool = True) -> None:
+    def send(self, raw, p0: int, p1: int, dst: Buffer, stream, urgent: bool = True) -> None:
         """raw[p0:p1] -> dst[:p1 - p0] (device), enqueued on `stream`; returns when the last piece is enqueued.  A sender that is not
         urgent (the assembly, whose N runs nobody waits for) lets the urgent ones (the runs of a BAM file: the device inflates them
         as they arrive) go first, piece by piece."""
@@ -125,7 +133,12 @@ class _Staging:
                 fd = self._fds.get(path)
                 if fd is None:
                     fd = self._fds[path] = os.open(path, os.O_RDONLY)
-                base = int(getattr(raw, "offset", 0))
+                # where raw[0] lies in the file: a SLICE of a memmap keeps its parent's .offset (numpy: m[50:].offset == 0), so the
+                # position comes from the addresses -- first byte of this array minus first byte of the mapping's own array
+                whole = raw
+                while isinstance(getattr(whole, "base", None), np.ndarray):
+                    whole = whole.base
+                base = int(getattr(whole, "offset", 0)) + (raw.ctypes.data - whole.ctypes.data)
                 self.engine._chk(self.engine.lib.gci_stage_send_fd(self.engine.ctx, self.native, fd, base + p0, p1 - p0, ctypes.c_void_p(dst.data_ptr()),
                                                                    ctypes.c_void_p(stream.cuda_stream), 1 if urgent else 0), "gci_stage_send_fd")
                 return
@@ -163,9 +176,10 @@ class _Staging:
                 for j in jobs:
                     j.result()
                 _forget_pages(raw, a, b)
-                with torch.cuda.stream(stream):
+                T = self.engine.T
+                with T.stream(stream):
                     dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
-                    ev = torch.cuda.Event()
+                    ev = T.Event()
                     ev.record(stream)
                 self.free_at[k] = ev
 
@@ -174,16 +188,16 @@ class _Staging:
 @dataclass
 class JoinInput:
     """One file of the join: compact records on the device + where its name bytes are."""
-    recs: torch.Tensor            # uint8 [n, 32]
-    name_base: torch.Tensor       # uint8 blob (BAM: the inflated stream)
-    name_off: torch.Tensor        # int64 [*], indexed by rec_idx
+    recs: Buffer            # uint8 [n, 32]
+    name_base: Buffer       # uint8 blob (BAM: the inflated stream)
+    name_off: Buffer        # int64 [*], indexed by rec_idx
     name_delta: int               # 36 for BAM records, 0 for a names blob
 
 
 @dataclass
 class Pages:
     """Record pages of one alignment file on the device (gci_bam_pages_write)."""
-    buf: torch.Tensor             # uint8: pages | blob | 16 zero bytes
+    buf: Buffer             # uint8: pages | blob | 16 zero bytes
     n_pages: int
     page_bytes: int
     blob_off: int
@@ -191,26 +205,33 @@ class Pages:
 
 
 class Engine:
-    """A gci_ctx bound to torch's current stream on `device`."""
+    """A gci_ctx bound to a stream of its provider (hbm.py) on `device`."""
 
-    def __init__(self, device: int = 0, stream: Optional["torch.cuda.Stream"] = None):
-        """`stream`: the torch stream this context enqueues on (default: the device's current stream)."""
+    def __init__(self, device: int = 0, stream: Optional[Any] = None, backend: Optional[str] = None):
+        """`stream`: the provider's stream this context enqueues on (default: the device's current stream).  `backend`: "native"
+        (the library's own gci_dev_* exports: no torch in the process) or "torch"; default hbm.provider()'s rule."""
         self.lib = _lib.load()
-        if not torch.cuda.is_available():
+        self.T = T = hbm.provider_of(stream) if (stream is not None and backend is None) else hbm.provider(backend)
+        if not T.is_available():
             raise GciError(_lib.GCI_E_HIP, "no MI355X visible: the HIP path has no CPU fallback")
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
-        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.device = T.device(device)
+        T.set_device(self.device)
+        self.stream = stream if stream is not None else T.current_stream(self.device)
+        from . import phases
+        phases.set_provider(T)
         h = ctypes.c_void_p()
         st = self.lib.gci_ctx_create(device, ctypes.c_void_p(self.stream.cuda_stream), 0, ctypes.byref(h))
         if st != 0:
             raise GciError(st, "gci_ctx_create: %s" % self.lib.gci_strerror(st).decode())
         self.ctx = h
+        from . import HW_QUEUES_OK
+        if HW_QUEUES_OK:                          # (the runtime has hardware queues to spare: the inflate may take a second stream)
+            self.lib.gci_bgzf_inflate_streams(h, 2)
         self.lengths: List[int] = []
         self.offsets: List[int] = []
         self.total = 0
-        self._status = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._status = self.T.zeros(1, self.T.int64, self.device)
+        self._count = self.T.zeros(1, self.T.int32, self.device)
         self._members_host = None                 # pinned staging buffer of depth_deflate()
         self._staging = None
         self._copy_stream = None
@@ -220,6 +241,9 @@ class Engine:
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
+            st, self._staging = getattr(self, "_staging", None), None
+            if st is not None and getattr(st, "engine", None) is self:     # (a side engine borrows the main engine's ring)
+                st.close()                                # before the context it was made with goes
             self.lib.gci_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -239,27 +263,27 @@ class Engine:
         self._chk(self.lib.gci_sync(self.ctx), "gci_sync")
 
     @staticmethod
-    def _p(t: Optional[torch.Tensor]):
+    def _p(t: Optional[Buffer]):
         return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
-    def to_device(self, a: np.ndarray) -> torch.Tensor:
-        a = np.ascontiguousarray(a)
-        if not a.flags.writeable:
-            a = a.copy()
-        if a.dtype == np.uint64:
-            a = a.view(np.int64)
-        elif a.dtype == np.uint32:
-            a = a.view(np.int32)
-        return torch.from_numpy(a).to(self.device)
+    def to_device(self, a: np.ndarray) -> Buffer:
+        return self.T.from_numpy(a, self.device)
 
-    def upload_staged(self, a: np.ndarray) -> torch.Tensor:
+    def _host_src(self, a) -> Any:
+        """A host array as the source of a buffer's copy_(): numpy for the native provider, a tensor over the same memory for torch."""
+        a = np.asarray(a)
+        if self.T.name == "torch":
+            return self.T.t.from_numpy(a)
+        return a
+
+    def upload_staged(self, a: np.ndarray) -> Buffer:
         """A large host array (the 3 GB assembly) to the device through the ring of pinned buffers (`_Staging`) instead of one
         pageable copy: host threads fill a slot while the one before it crosses PCIe.  Ordered before what this engine's stream
         does next."""
         a = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
         n = int(a.shape[0])
         staging, copy = self.staging(), self.copy_stream()
-        dst = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+        dst = self.T.empty(max(n, 1), self.T.uint8, self.device)
         copy.wait_stream(self.stream)
         staging.send(a, 0, n, dst, copy, urgent=os.environ.get("GCI_FASTA_URGENT", "0") == "1")
         self.stream.wait_stream(copy)
@@ -272,10 +296,10 @@ class Engine:
                 self._staging = _Staging(self)
             return self._staging
 
-    def copy_stream(self) -> "torch.cuda.Stream":
+    def copy_stream(self) -> Any:
         with self._lock:
             if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream(device=self.device)
+                self._copy_stream = self.T.Stream(self.device)
             return self._copy_stream
 
     # ---- per-kernel HIP-event timing (library side, on the ctx stream) -------------------------
@@ -304,18 +328,18 @@ class Engine:
         self.total = int(self.lib.gci_layout_total(self.ctx))
         return self.offsets
 
-    def new_track(self) -> torch.Tensor:
-        return torch.empty(max(self.total, 1), dtype=torch.int32, device=self.device)
+    def new_track(self) -> Buffer:
+        return self.T.empty(max(self.total, 1), self.T.int32, self.device)
 
     # ---- R1 ----------------------------------------------------------------------------------
-    def bam_filter(self, d_bam: torch.Tensor, d_rec_off: torch.Tensor, d_ref_sel: torch.Tensor, map_qual: int,
-                   mq_cutoff: int, clip_percent: float, iden_percent: float, out: Optional[torch.Tensor] = None,
-                   check: bool = True, rec_idx_base: int = 0) -> torch.Tensor:
+    def bam_filter(self, d_bam: Buffer, d_rec_off: Buffer, d_ref_sel: Buffer, map_qual: int,
+                   mq_cutoff: int, clip_percent: float, iden_percent: float, out: Optional[Buffer] = None,
+                   check: bool = True, rec_idx_base: int = 0) -> Buffer:
         """K1 over the whole inflated stream (the round-1 / 2 kernel, GCI_K1=stream; the product runs bam_pages +
         bam_filter_pages)."""
         n = int(d_rec_off.shape[0])
         if out is None:
-            out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+            out = self.T.empty((max(n, 1), 32), self.T.uint8, self.device)
         st = self.lib.gci_bam_filter(self.ctx, self._p(d_bam), int(d_bam.shape[0]), self._p(d_rec_off), n, self._p(d_ref_sel),
                 int(d_ref_sel.shape[0]), int(map_qual), int(mq_cutoff), float(clip_percent), float(iden_percent),
                 int(rec_idx_base), self._p(out), self._p(self._status))
@@ -325,7 +349,7 @@ class Engine:
         return out[:n]
 
     # ---- R1 over record pages (include/gci_hip.h: gci_bam_pages_*, gci_bam_filter_pages) -------------------------------
-    def bam_pages(self, d_stream: torch.Tensor, d_rec_off: torch.Tensor, has_seq: bool, page_bytes: int = 0) -> "Pages":
+    def bam_pages(self, d_stream: Buffer, d_rec_off: Buffer, has_seq: bool, page_bytes: int = 0) -> "Pages":
         """The records of an inflated BAM stream (has_seq) or of a heads stream laid out as record pages: the bytes read_sam
         looks at, 16-byte aligned, no offset table -- what the record filter is fastest on."""
         page_bytes = int(page_bytes or os.environ.get("GCI_PAGE_BYTES", 0) or _lib.PAGE_BYTES_DEFAULT)
@@ -333,20 +357,20 @@ class Engine:
         h = (ctypes.c_uint64 * 3)()
         self._chk(self.lib.gci_bam_pages_size(self.ctx, self._p(d_stream), int(d_stream.shape[0]), self._p(d_rec_off), n, int(has_seq),
                                               page_bytes, h), "gci_bam_pages_size")
-        buf = torch.empty(int(h[1]), dtype=torch.uint8, device=self.device)
+        buf = self.T.empty(int(h[1]), self.T.uint8, self.device)
         self._chk(self.lib.gci_bam_pages_write(self.ctx, self._p(d_stream), int(d_stream.shape[0]), self._p(d_rec_off), n, int(has_seq),
                                                self._p(buf), int(h[1])), "gci_bam_pages_write")
         return Pages(buf, int(h[0]), page_bytes, int(h[2]), n)
 
-    def bam_filter_pages(self, pages: "Pages", d_ref_sel: torch.Tensor, map_qual: int, mq_cutoff: int, clip_percent: float,
-                         iden_percent: float, out: Optional[torch.Tensor] = None, name_off: Optional[torch.Tensor] = None,
-                         check: bool = True, rec_idx_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    def bam_filter_pages(self, pages: "Pages", d_ref_sel: Buffer, map_qual: int, mq_cutoff: int, clip_percent: float,
+                         iden_percent: float, out: Optional[Buffer] = None, name_off: Optional[Buffer] = None,
+                         check: bool = True, rec_idx_base: int = 0) -> Tuple[Buffer, Buffer]:
         """-> (records uint8 [n, 32], name offsets int64 [n] into pages.buf)."""
         n = pages.n_rec
         if out is None:
-            out = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
+            out = self.T.empty((max(n, 1), 32), self.T.uint8, self.device)
         if name_off is None:
-            name_off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            name_off = self.T.empty(max(n, 1), self.T.int64, self.device)
         st = self.lib.gci_bam_filter_pages(self.ctx, self._p(pages.buf), int(pages.buf.shape[0]), pages.page_bytes, pages.n_pages, n,
                                            self._p(d_ref_sel), int(d_ref_sel.shape[0]), int(map_qual), int(mq_cutoff),
                                            float(clip_percent), float(iden_percent), int(rec_idx_base), self._p(out),
@@ -380,10 +404,10 @@ class Engine:
             arr[i].d_name_off = f.name_off.data_ptr()
         return arr
 
-    def name_join(self, files: Sequence[JoinInput], ovlp_percent: float, contig_map: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None, check: bool = True,
+    def name_join(self, files: Sequence[JoinInput], ovlp_percent: float, contig_map: Optional[Buffer] = None,
+                  out: Optional[Buffer] = None, count: Optional[Buffer] = None, check: bool = True,
                   count_flank: Optional[int] = None, fallback: bool = True,
-                  status: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  status: Optional[Buffer] = None) -> Tuple[Buffer, Buffer]:
         """-> (intervals int32 [cap, 4], device count).  With check=True the count is read back,
         capacity is grown if needed and the record-level status is raised.
 
@@ -391,9 +415,9 @@ class Engine:
         pass inside the join (pass counted=True to depth_build_fused / depth_build)."""
         total = sum(int(f.recs.shape[0]) for f in files)
         if out is None:
-            out = torch.empty((max(total, 1), 4), dtype=torch.int32, device=self.device)
+            out = self.T.empty((max(total, 1), 4), self.T.int32, self.device)
         if count is None:
-            count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            count = self.T.zeros(1, self.T.int32, self.device)
         arr = self._join_files(files)
         st_word = self._status if status is None else status          # status: the caller reads the word later (check=False)
         while True:
@@ -422,15 +446,18 @@ class Engine:
             n = int(count.item())
             if n <= out.shape[0]:
                 return out, count
-            out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+            out = self.T.empty((n, 4), self.T.int32, self.device)
 
     # ---- R7 / N2: gzip members of the depth text, written on the device ----------------------------------------
     MEMBER_BASES = 64 * 4096
 
-    def depth_deflate(self, track: torch.Tensor) -> List[bytes]:
+    def depth_deflate(self, track: Buffer, from_build: bool = False) -> List[bytes]:
         """-> per contig of the layout, the bytes of the gzip members whose payload is that contig's depth lines
         (f'{depth}\\n' per base, GCI.py:115-117; no '>' line), as memoryviews of a pinned buffer the engine reuses: valid until
-        the next call.  gci_depth_deflate_size / _write."""
+        the next call.  gci_depth_deflate_size / _write.  from_build: the caller states that `track` is exactly what the last
+        depth_build_fused(want_runs=True) of THIS engine wrote and that nothing has written it since (no other engine, no torch
+        operation): the members are then encoded from the run lists that build kept and the track is not read
+        (gci_depth_deflate_from_build; the lists serve one call)."""
         elem, cnt, first = [], [], [0]
         for off, length in zip(self.offsets, self.lengths):
             for g in range(0, int(length), self.MEMBER_BASES):
@@ -443,22 +470,23 @@ class Engine:
         d_elem = self.to_device(np.asarray(elem, dtype=np.uint64))
         d_cnt = self.to_device(np.asarray(cnt, dtype=np.uint32))
         dev = self.device
-        tile_bytes = torch.empty(nm * 64, dtype=torch.int32, device=dev)
-        mb, crc, isz = (torch.empty(nm, dtype=torch.int32, device=dev) for _ in range(3))
+        tile_bytes = self.T.empty(nm * 64, self.T.int32, dev)
+        mb, crc, isz = (self.T.empty(nm, self.T.int32, dev) for _ in range(3))
+        if from_build:
+            self._chk(self.lib.gci_depth_deflate_from_build(self.ctx, self._p(track)), "gci_depth_deflate_from_build")
         self._chk(self.lib.gci_depth_deflate_size(self.ctx, self._p(track), self._p(d_elem), self._p(d_cnt), nm, self._p(tile_bytes),
                                                   self._p(mb), self._p(crc), self._p(isz)), "gci_depth_deflate_size")
         # member offsets on the device (no round trip through the host for them); one sync for the total
-        d_off64 = torch.zeros(nm + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(mb.view(torch.int32).to(torch.int64) & 0xFFFFFFFF, 0, out=d_off64[1:])
+        d_off64 = self.T.scan_u32_u64(mb)
         total = int(d_off64[nm].item())
-        out = torch.empty(total, dtype=torch.uint8, device=dev)
+        out = self.T.empty(total, self.T.uint8, dev)
         self._chk(self.lib.gci_depth_deflate_write(self.ctx, self._p(track), self._p(d_elem), self._p(d_cnt), nm, self._p(tile_bytes),
                                                    self._p(crc), self._p(isz), self._p(d_off64), self._p(out), total),
                   "gci_depth_deflate_write")
         # the members leave through a pinned staging buffer of the engine (a pageable destination halves the D2H rate and
         # .tobytes() per contig copied everything once more): the caller gets views of it, valid until the next call
         if self._members_host is None or int(self._members_host.shape[0]) < total:
-            self._members_host = torch.empty(max(total + (total >> 3), 1 << 20), dtype=torch.uint8).pin_memory()
+            self._members_host = self.T.pinned(max(total + (total >> 3), 1 << 20))
         host = self._members_host[:total]
         host.copy_(out, non_blocking=True)
         offs = d_off64.cpu().numpy()
@@ -466,64 +494,64 @@ class Engine:
         blob = host.numpy()
         return [memoryview(blob[int(offs[first[c]]):int(offs[first[c + 1]])]) for c in range(len(self.lengths))]
 
-    def hash_bucket(self, recs: torch.Tensor, n_parts: int, part_cap: int, out: torch.Tensor,
-                    next_out: Optional[torch.Tensor] = None) -> None:
+    def hash_bucket(self, recs: Buffer, n_parts: int, part_cap: int, out: Buffer,
+                    next_out: Optional[Buffer] = None) -> None:
         """out: int64 [n_parts * (part_cap + 1)]; word 0 of each bucket = its count.  next_out: the array the caller
         alternates with `out` (its count words are zeroed for the next call; `out`'s must be zero on entry)."""
         self._chk(self.lib.gci_hash_bucket(self.ctx, self._p(recs), int(recs.shape[0]), int(n_parts), int(part_cap),
                                            self._p(out), self._p(next_out)), "gci_hash_bucket")
 
-    def hash_conflicts(self, buckets: torch.Tensor, n_parts: int, part_cap: int, n_conflicts: torch.Tensor) -> None:
+    def hash_conflicts(self, buckets: Buffer, n_parts: int, part_cap: int, n_conflicts: Buffer) -> None:
         """Adds to n_conflicts (int32 [1])."""
         self._chk(self.lib.gci_hash_conflicts(self.ctx, self._p(buckets), int(n_parts), int(part_cap),
                                               self._p(n_conflicts)), "gci_hash_conflicts")
 
     # ---- multi-GPU: buckets of the name-hash-sharded join (gci_route_*; the collectives are shard.ShardedJoin's) ----------
-    def route_records(self, f: JoinInput, n_parts: int, cap: int, out_recs: torch.Tensor, out_names: torch.Tensor,
-                      name_slot: int, status: torch.Tensor) -> None:
+    def route_records(self, f: JoinInput, n_parts: int, cap: int, out_recs: Buffer, out_names: Buffer,
+                      name_slot: int, status: Buffer) -> None:
         """out_recs uint8 [n_parts * (cap + 1), 32], out_names uint8 [n_parts * cap * name_slot], status int64 [1]."""
         self._chk(self.lib.gci_route_records(self.ctx, self._join_files([f]), int(n_parts), int(cap), self._p(out_recs),
                                              self._p(out_names), int(name_slot), self._p(status)), "gci_route_records")
 
-    def route_seal_records(self, recs: torch.Tensor, n_parts: int, cap: int, status: torch.Tensor) -> None:
+    def route_seal_records(self, recs: Buffer, n_parts: int, cap: int, status: Buffer) -> None:
         self._chk(self.lib.gci_route_seal_records(self.ctx, self._p(recs), int(n_parts), int(cap), self._p(status)),
                   "gci_route_seal_records")
 
-    def route_intervals(self, ivl: torch.Tensor, count: torch.Tensor, owner: torch.Tensor, n_parts: int, cap: int,
-                        out: torch.Tensor, status: torch.Tensor) -> None:
+    def route_intervals(self, ivl: Buffer, count: Buffer, owner: Buffer, n_parts: int, cap: int,
+                        out: Buffer, status: Buffer) -> None:
         """owner int32 [n_contigs]: rank of every contig; out int32 [n_parts * (cap + 1), 4]."""
         self._chk(self.lib.gci_route_intervals(self.ctx, self._p(ivl), self._p(count), int(ivl.shape[0]), self._p(owner),
                                                int(owner.shape[0]), int(n_parts), int(cap), self._p(out), self._p(status)),
                   "gci_route_intervals")
 
-    def route_seal_intervals(self, ivl: torch.Tensor, n_parts: int, cap: int, cmap: torch.Tensor, status: torch.Tensor) -> None:
+    def route_seal_intervals(self, ivl: Buffer, n_parts: int, cap: int, cmap: Buffer, status: Buffer) -> None:
         self._chk(self.lib.gci_route_seal_intervals(self.ctx, self._p(ivl), int(n_parts), int(cap), self._p(cmap),
                                                     int(cmap.shape[0]), self._p(status)), "gci_route_seal_intervals")
 
-    def pack_names(self, f: JoinInput) -> Tuple[torch.Tensor, torch.Tensor]:
+    def pack_names(self, f: JoinInput) -> Tuple[Buffer, Buffer]:
         n = int(f.recs.shape[0])
-        off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        off = self.T.zeros(n + 1, self.T.int64, self.device)
         arr = self._join_files([f])
         self._chk(self.lib.gci_pack_names(self.ctx, arr, None, 0, self._p(off)), "gci_pack_names(size)")
         total = int(off[n].item())
-        blob = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        blob = self.T.empty(max(total, 1), self.T.uint8, self.device)
         self._chk(self.lib.gci_pack_names(self.ctx, arr, self._p(blob), total, self._p(off)), "gci_pack_names")
         return blob[:total], off
 
     # ---- N1: BGZF inflate + record walk on the device (k_inflate.hip) ---------------------------------------------------
-    def upload_padded(self, raw: np.ndarray) -> torch.Tensor:
+    def upload_padded(self, raw: np.ndarray) -> Buffer:
         """The bytes of a BGZF file on the device with 16 readable bytes behind them (gci_bgzf_inflate_device takes its
         input as whole aligned 16-byte blocks)."""
         n_raw = int(raw.shape[0])
-        with torch.cuda.stream(self.stream), warnings.catch_warnings():      # (may be called from a helper thread)
+        with self.T.stream(self.stream), warnings.catch_warnings():      # (may be called from a helper thread)
             warnings.simplefilter("ignore", UserWarning)                     # a read-only memmap is only read
-            d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
+            d_raw = self.T.empty(n_raw + 16, self.T.uint8, self.device)
             d_raw[n_raw:].zero_()
-            d_raw[:n_raw].copy_(torch.from_numpy(np.asarray(raw)))
+            d_raw[:n_raw].copy_(self._host_src(raw))
         return d_raw
 
     def bgzf_inflate(self, raw: Optional[np.ndarray], pos: np.ndarray, isize: np.ndarray, check_crc: bool = True,
-                     prefix: Optional[torch.Tensor] = None, d_raw: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     prefix: Optional[Buffer] = None, d_raw: Optional[Buffer] = None) -> Buffer:
         """raw: the bytes of a BGZF file (or of a run of its members) -- or d_raw, the same already on the device
         (upload_padded); pos (uint64, n + 1) / isize (uint64, n): its member table (hostio.bgzf_blocks), pos relative to
         raw.  -> the inflated bytes on the device, behind the bytes of `prefix` (the partial record a previous run of
@@ -539,7 +567,7 @@ class Engine:
         # (sizes in steps of 256 MiB: the runs of a file differ by a few MB, and a request a little larger than the block the run before
         #  gave back is a new device allocation -- 44 ms beside a copy in flight -- where the same step finds that block again)
         want = max(n_pre + total, 1)
-        out = torch.empty(((want + (1 << 28) - 1) >> 28) << 28 if want > (1 << 28) else want, dtype=torch.uint8, device=self.device)
+        out = self.T.empty(((want + (1 << 28) - 1) >> 28) << 28 if want > (1 << 28) else want, self.T.uint8, self.device)
         if n_pre:
             out[:n_pre].copy_(prefix)
         self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(d_raw), self._p(d_pos), self._p(d_off), n, ctypes.c_void_p(out.data_ptr() + n_pre), total,
@@ -565,20 +593,20 @@ class Engine:
         from concurrent.futures import ThreadPoolExecutor
         n_raw = int(raw.shape[0])
         cuts = sorted({min(n_raw, (n_raw * (k + 1) // parts + 15) & ~15) for k in range(parts)} | {n_raw})
-        d_raw = torch.empty(n_raw + 16, dtype=torch.uint8, device=self.device)
+        d_raw = self.T.empty(n_raw + 16, self.T.uint8, self.device)
         copy_stream = self.copy_stream()                         # (creating a stream costs milliseconds: one per engine)
         copy_stream.wait_stream(self.stream)                     # (the allocation may recycle memory still in use on the main stream)
-        events = [torch.cuda.Event() for _ in cuts]
+        events = [self.T.Event() for _ in cuts]
         queued = [threading.Event() for _ in cuts]               # (a CUDA event that was never recorded counts as complete)
 
         def run():
-            with torch.cuda.stream(copy_stream), warnings.catch_warnings():
+            with self.T.stream(copy_stream), warnings.catch_warnings():
                 warnings.simplefilter("ignore", UserWarning)     # a read-only memmap is only read
                 d_raw[n_raw:].zero_()
                 lo = 0
                 for k, hi in enumerate(cuts):
                     if hi > lo:
-                        d_raw[lo:hi].copy_(torch.from_numpy(np.asarray(raw[lo:hi])))
+                        d_raw[lo:hi].copy_(self._host_src(raw[lo:hi]))
                     events[k].record(copy_stream)
                     queued[k].set()
                     lo = hi
@@ -587,7 +615,7 @@ class Engine:
         pool = ThreadPoolExecutor(1)
         return dict(d_raw=d_raw, cuts=cuts, events=events, queued=queued, future=pool.submit(run), pool=pool, stream=copy_stream)
 
-    def bgzf_inflate_uploaded(self, up, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True) -> torch.Tensor:
+    def bgzf_inflate_uploaded(self, up, pos: np.ndarray, isize: np.ndarray, check_crc: bool = True) -> Buffer:
         """bgzf_inflate over a file whose upload start_upload began: one launch per uploaded piece, over the members that lie
         wholly inside what has arrived (and the 16 bytes the decoder may read behind a member)."""
         n = int(isize.shape[0])
@@ -595,10 +623,10 @@ class Engine:
         np.cumsum(isize, out=off[1:])
         total = int(off[n])
         d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
-        out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+        out = self.T.empty(max(total, 1), self.T.uint8, self.device)
         ends = np.asarray(pos[1:n + 1], dtype=np.uint64)
         n_raw = int(up["d_raw"].shape[0]) - 16
-        status = torch.zeros(len(up["cuts"]), dtype=torch.int64, device=self.device)
+        status = self.T.zeros(len(up["cuts"]), self.T.int64, self.device)
         m_lo, bases = 0, []
         try:
             for k, (cut, ev) in enumerate(zip(up["cuts"], up["events"])):
@@ -629,14 +657,14 @@ class Engine:
         self.stream.wait_stream(up["stream"])
         return out[:total]
 
-    def bam_record_offsets(self, d_stream: torch.Tensor, first_record: int, n_ref: int) -> Tuple[torch.Tensor, int, bool]:
+    def bam_record_offsets(self, d_stream: Buffer, first_record: int, n_ref: int) -> Tuple[Buffer, int, bool]:
         """-> (int64 offsets of every record on the device, bytes consumed, chain_ok).  chain_ok False: a record the strict
         format test rejects sits on the chain -- the caller walks the chain on the host instead."""
         n = int(d_stream.shape[0])
-        res = torch.zeros(3, dtype=torch.int64, device=self.device)
+        res = self.T.zeros(3, self.T.int64, self.device)
         cap = max(1024, n // 256)
         while True:
-            offs = torch.empty(cap, dtype=torch.int64, device=self.device)
+            offs = self.T.empty(cap, self.T.int64, self.device)
             self._chk(self.lib.gci_bam_record_offsets_device(self.ctx, self._p(d_stream), n, int(first_record), int(n_ref), self._p(offs), cap,
                                                              self._p(res)), "gci_bam_record_offsets_device")
             n_rec, used, broken = (int(x) for x in res.cpu().tolist())
@@ -656,7 +684,7 @@ class Engine:
         text = np.concatenate(bufs) if bufs and int(ends[-1]) else np.zeros(1, np.uint8)
         return self.paf_filter_text(self.to_device(text), ends, targets, map_qual, mq_cutoff, iden_percent)
 
-    def paf_filter_text(self, d_text: torch.Tensor, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
+    def paf_filter_text(self, d_text: Buffer, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
                         iden_percent: float) -> List[JoinInput]:
         """paf_filter() over PAF text that is on the device already: the bytes of all files back to back, ends[i] = end offset
         of file i."""
@@ -680,19 +708,19 @@ class Engine:
     # ---- the PAF filter in two halves (runs that shard a PAF file by byte range: shard.paf_by_byte_range) ----
     PAF_HIT_BYTES = 80
 
-    def _paf_dev_inputs(self, handle, n_files: int, d_names: torch.Tensor) -> List[JoinInput]:
+    def _paf_dev_inputs(self, handle, n_files: int, d_names: Buffer) -> List[JoinInput]:
         out = []
         for f in range(n_files):
             n = int(self.lib.gci_paf_dev_count(handle, f))
-            recs = torch.empty((max(n, 1), 32), dtype=torch.uint8, device=self.device)
-            off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            recs = self.T.empty((max(n, 1), 32), self.T.uint8, self.device)
+            off = self.T.empty(max(n, 1), self.T.int64, self.device)
             self._chk(self.lib.gci_paf_dev_export(handle, f, self._p(recs), self._p(off)), "gci_paf_dev_export")
             out.append(JoinInput(recs[:n], d_names, off[:n], 0))
         self.sync()
         return out
 
-    def paf_hits_text(self, d_text: torch.Tensor, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
-                      iden_percent: float) -> List[torch.Tensor]:
+    def paf_hits_text(self, d_text: Buffer, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
+                      iden_percent: float) -> List[Buffer]:
         """Stage A (gci_paf_hits_device) over the byte ranges in d_text (ends[i] = end of file i's range): per file the lines
         that pass, as a uint8 tensor [n, 80] of gci_paf_hit in line order (qn_off points into d_text)."""
         ends = np.ascontiguousarray(ends, dtype=np.uint64)
@@ -709,7 +737,7 @@ class Engine:
             out = []
             for f in range(n_files):
                 n = int(self.lib.gci_paf_hits_count(handle, f))
-                h = torch.empty((max(n, 1), self.PAF_HIT_BYTES), dtype=torch.uint8, device=self.device)
+                h = self.T.empty((max(n, 1), self.PAF_HIT_BYTES), self.T.uint8, self.device)
                 self._chk(self.lib.gci_paf_hits_export(handle, f, self._p(h)), "gci_paf_hits_export")
                 out.append(h[:n])
             self.sync()
@@ -717,15 +745,15 @@ class Engine:
         finally:
             self.lib.gci_paf_hits_free(handle)
 
-    def route_hits(self, hits: torch.Tensor, d_name_base: torch.Tensor, n_parts: int, cap: int, out_hits: torch.Tensor,
-                   out_names: torch.Tensor, name_slot: int, status: torch.Tensor) -> None:
+    def route_hits(self, hits: Buffer, d_name_base: Buffer, n_parts: int, cap: int, out_hits: Buffer,
+                   out_names: Buffer, name_slot: int, status: Buffer) -> None:
         """gci_route_hits: hits [n, 80] -> out_hits [n_parts * (cap + 1), 80] (slot 0 of a bucket: header, qhash = count), their
         query names into out_names [n_parts * cap * name_slot]."""
         n = int(hits.shape[0])
         self._chk(self.lib.gci_route_hits(self.ctx, self._p(hits) if n else None, n, self._p(d_name_base), int(n_parts), int(cap),
                                           self._p(out_hits), self._p(out_names), int(name_slot), self._p(status)), "gci_route_hits")
 
-    def paf_score_hits(self, d_names: torch.Tensor, d_hits: torch.Tensor, upto: Sequence[int], targets: Sequence[str]) -> List[JoinInput]:
+    def paf_score_hits(self, d_names: Buffer, d_hits: Buffer, upto: Sequence[int], targets: Sequence[str]) -> List[JoinInput]:
         """Stage B (gci_paf_score_device): d_hits [total, 80] = the hits of the queries this rank owns, file after file
         (upto[f] = first hit of file f, upto[-1] = total), qn_off relative to d_names -> one JoinInput per file."""
         n_files = len(upto) - 1
@@ -743,15 +771,15 @@ class Engine:
             self.lib.gci_paf_dev_free(handle)
 
     # ---- R6 / R8 / R9 / R15 --------------------------------------------------------------------
-    def depth_build(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
-                    max_n: Optional[int] = None) -> torch.Tensor:
+    def depth_build(self, ivl: Buffer, count: Optional[Buffer], flank: int, track: Buffer,
+                    max_n: Optional[int] = None) -> Buffer:
         n = int(ivl.shape[0]) if max_n is None else int(max_n)
         st = self.lib.gci_depth_build(self.ctx, self._p(ivl) if n else None, self._p(count), n, int(flank),
                                       self._p(track))
         self._chk(st, "gci_depth_build")
         return track
 
-    def depth_build_fused(self, ivl: torch.Tensor, count: Optional[torch.Tensor], flank: int, track: torch.Tensor,
+    def depth_build_fused(self, ivl: Buffer, count: Optional[Buffer], flank: int, track: Buffer,
                           want_text: bool = True, want_sums: bool = False,
                           issue: Optional[Tuple[float, float, int]] = None, max_n: Optional[int] = None,
                           counted: bool = False, key_cap: int = 1 << 16, want_runs: bool = False):
@@ -770,18 +798,18 @@ class Engine:
         o.counted = 1 if counted else 0
         o.want_text = 1 if want_text else 0
         o.want_runs = 1 if want_runs else 0
-        text_off = torch.zeros(nc + 1, dtype=torch.int64, device=self.device) if want_text else None
+        text_off = self.T.zeros(nc + 1, self.T.int64, self.device) if want_text else None
         # want_sums: True = per-contig sums returned as a host array; a device tensor (int64 [n_contigs]) = written there, nothing copied
-        sums_dev = want_sums if isinstance(want_sums, torch.Tensor) else None
+        sums_dev = want_sums if self.T.is_buffer(want_sums) else None
         want_sums = bool(sums_dev is not None or want_sums is True)
-        sums = sums_dev if sums_dev is not None else (torch.zeros(max(nc, 1), dtype=torch.int64, device=self.device) if want_sums else None)
+        sums = sums_dev if sums_dev is not None else (self.T.zeros(max(nc, 1), self.T.int64, self.device) if want_sums else None)
         o.d_contig_text_off = text_off.data_ptr() if want_text else None
         o.d_sums = sums.data_ptr() if want_sums else None
         cap = int(key_cap)                                 # grown (and the first pass repeated) when more run boundaries turn up
         keys = None
         while True:
             if issue is not None:
-                keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+                keys = self.T.empty(cap, self.T.int64, self.device)
                 o.d_n_keys, o.d_keys, o.key_cap = self._count.data_ptr(), keys.data_ptr(), cap
                 o.lo, o.hi, o.issue_flank = float(issue[0]), float(issue[1]), int(issue[2])
             self._chk(self.lib.gci_depth_build_begin(self.ctx, self._p(ivl) if n else None, self._p(count), n,
@@ -798,7 +826,7 @@ class Engine:
         if want_text:
             h = text_off.cpu().numpy()
             total = int(h[nc])
-            text = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+            text = self.T.empty(max(total, 1), self.T.uint8, self.device)
             out["text_off"] = h
         self._chk(self.lib.gci_depth_build_finish(self.ctx, self._p(track), self._p(text), int(text.shape[0]) if want_text else 0),
                   "gci_depth_build_finish")
@@ -810,21 +838,21 @@ class Engine:
             out["runs"] = self._keys_to_runs(keys[:nk].cpu().numpy().view(np.uint64), nc)
         return out
 
-    def gap_mask(self, track: torch.Tensor, gaps: torch.Tensor) -> torch.Tensor:
+    def gap_mask(self, track: Buffer, gaps: Buffer) -> Buffer:
         n = int(gaps.shape[0])
         if n:
             self._chk(self.lib.gci_gap_mask(self.ctx, self._p(track), self._p(gaps), n), "gci_gap_mask")
         return track
 
-    def max2(self, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def max2(self, a: Buffer, b: Buffer, out: Optional[Buffer] = None) -> Buffer:
         if out is None:
             out = self.new_track()
         self._chk(self.lib.gci_max2(self.ctx, self._p(a), self._p(b), self._p(out)), "gci_max2")
         return out
 
-    def two_type_tail(self, a: torch.Tensor, b: torch.Tensor, gaps: Optional[np.ndarray], lo: float, hi: float, flank: int,
-                      out: Optional[torch.Tensor] = None, keys: Optional[torch.Tensor] = None, n_keys: Optional[torch.Tensor] = None,
-                      read: bool = True, sums: Optional[torch.Tensor] = None):
+    def two_type_tail(self, a: Buffer, b: Buffer, gaps: Optional[np.ndarray], lo: float, hi: float, flank: int,
+                      out: Optional[Buffer] = None, keys: Optional[Buffer] = None, n_keys: Optional[Buffer] = None,
+                      read: bool = True, sums: Optional[Buffer] = None):
         """gci_two_type_tail: N-run masks of both tracks (in place; gaps = int32 [n, 4] rows (contig, start, end, 0) on the HOST, or
         None), their maximum and the issue runs of all three in one pass.  -> (maximum track, [runs of a, of b, of the maximum]);
         read=False: (maximum track, keys int64 [3, cap] on the device, n_keys int32 [3]) with nothing copied to the host.
@@ -835,9 +863,9 @@ class Engine:
         cap = int(keys.shape[1]) if keys is not None else 1 << 16
         while True:
             if keys is None:
-                keys = torch.empty((3, cap), dtype=torch.int64, device=self.device)
+                keys = self.T.empty((3, cap), self.T.int64, self.device)
             if n_keys is None:
-                n_keys = torch.zeros(3, dtype=torch.int32, device=self.device)
+                n_keys = self.T.zeros(3, self.T.int32, self.device)
             self._chk(self.lib.gci_two_type_tail(self.ctx, self._p(a), self._p(b), self._p(out),
                                                  ctypes.c_void_p(g.ctypes.data) if g is not None else None, 0 if g is None else int(g.shape[0]),
                                                  float(lo), float(hi), int(flank), self._p(keys), cap, self._p(n_keys), self._p(sums)),
@@ -851,8 +879,8 @@ class Engine:
         hk = keys.cpu().numpy().view(np.uint64)
         return out, [self._keys_to_runs(hk[x, :int(n[x])], len(self.lengths)) for x in range(3)]
 
-    def depth_sum(self, track: torch.Tensor) -> np.ndarray:
-        sums = torch.zeros(max(len(self.lengths), 1), dtype=torch.int64, device=self.device)
+    def depth_sum(self, track: Buffer) -> np.ndarray:
+        sums = self.T.zeros(max(len(self.lengths), 1), self.T.int64, self.device)
         self._chk(self.lib.gci_depth_sum(self.ctx, self._p(track), self._p(sums)), "gci_depth_sum")
         return sums.cpu().numpy()[:len(self.lengths)]
 
@@ -863,10 +891,10 @@ class Engine:
         d_text = self.upload_staged(text) if n >= (256 << 20) else self.to_device(text)
         d_body = self.to_device(np.ascontiguousarray(bodies, dtype=np.int64).reshape(-1, 2))
         tiles = (n + 4095) // 4096
-        kept = torch.zeros(max(tiles, 1), dtype=torch.int32, device=self.device)
+        kept = self.T.zeros(max(tiles, 1), self.T.int32, self.device)
         cap = 1 << 16
         while True:
-            keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            keys = self.T.empty(cap, self.T.int64, self.device)
             self._chk(self.lib.gci_fasta_n_scan(self.ctx, self._p(d_text), n, self._p(d_body), int(bodies.shape[0]), self._p(kept),
                                                 self._p(keys), cap, self._p(self._count)), "gci_fasta_n_scan")
             nk = int(self._count.item())
@@ -875,14 +903,14 @@ class Engine:
             cap = nk
         return kept.cpu().numpy().view(np.uint32)[:tiles], np.sort(keys[:nk].cpu().numpy().view(np.uint64))
 
-    def range_sums(self, track: torch.Tensor, ranges: np.ndarray) -> np.ndarray:
+    def range_sums(self, track: Buffer, ranges: np.ndarray) -> np.ndarray:
         """Sum of the depths in each [begin, end) of track element indices (int64 [n, 2]) -> int64 [n]."""
         ranges = np.ascontiguousarray(ranges, dtype=np.int64).reshape(-1, 2)
         n = int(ranges.shape[0])
         if n == 0:
             return np.zeros(0, dtype=np.int64)
         d_r = self.to_device(ranges)
-        sums = torch.empty(n, dtype=torch.int64, device=self.device)
+        sums = self.T.empty(n, self.T.int64, self.device)
         self._chk(self.lib.gci_range_sums(self.ctx, self._p(track), self._p(d_r), n, self._p(sums)), "gci_range_sums")
         return sums.cpu().numpy()
 
@@ -907,14 +935,14 @@ class Engine:
     def _scan(self, call, n_windows: int) -> List[np.ndarray]:
         cap = 1 << 16
         while True:
-            keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            keys = self.T.empty(cap, self.T.int64, self.device)
             call(keys, cap)
             n = int(self._count.item())
             if n <= cap:
                 return self._keys_to_runs(keys[:n].cpu().numpy().view(np.uint64), n_windows)
             cap = n
 
-    def issue_scan(self, track: torch.Tensor, lo: float, hi: float, flank: int) -> List[np.ndarray]:
+    def issue_scan(self, track: Buffer, lo: float, hi: float, flank: int) -> List[np.ndarray]:
         """Raw maximal runs of lo < depth <= hi inside [flank, L - flank) of every contig, as
         positions relative to the window start (add `flank` for contig coordinates)."""
         def call(keys, cap):
@@ -922,7 +950,7 @@ class Engine:
                                               self._p(keys), cap, self._p(self._count)), "gci_issue_scan")
         return self._scan(call, len(self.lengths))
 
-    def issue_scan_windows(self, track: torch.Tensor, windows: Sequence[Tuple[int, int]], lo: float, hi: float
+    def issue_scan_windows(self, track: Buffer, windows: Sequence[Tuple[int, int]], lo: float, hi: float
                            ) -> List[np.ndarray]:
         arr = (Window * max(len(windows), 1))()
         for i, (a, b) in enumerate(windows):
@@ -935,14 +963,14 @@ class Engine:
         return self._scan(call, len(windows))
 
     # ---- R7 ----------------------------------------------------------------------------------
-    def depth_text(self, track: torch.Tensor, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, np.ndarray]:
+    def depth_text(self, track: Buffer, out: Optional[Buffer] = None) -> Tuple[Buffer, np.ndarray]:
         """-> (uint8 text of all contigs back to back, int64 [n_contigs + 1] byte offsets)."""
         n = len(self.lengths)
-        offs = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        offs = self.T.zeros(n + 1, self.T.int64, self.device)
         self._chk(self.lib.gci_depth_text_size(self.ctx, self._p(track), self._p(offs)), "gci_depth_text_size")
         h = offs.cpu().numpy()
         total = int(h[n])
         if out is None or out.shape[0] < total:
-            out = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+            out = self.T.empty(max(total, 1), self.T.uint8, self.device)
         self._chk(self.lib.gci_depth_text_write(self.ctx, self._p(track), self._p(out), total), "gci_depth_text_write")
         return out[:total], h

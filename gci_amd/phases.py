@@ -1,6 +1,6 @@
 """Where a run of the command line spends its time (number 3): wall-clock phases of the host and, inside the
 ingestion, device time per stage from HIP events on the engine's stream (recorded without synchronising: the uploads, the
-inflate and the record filter of consecutive runs overlap, and a `torch.cuda.synchronize()` per stage would undo exactly that).
+inflate and the record filter of consecutive runs overlap, and a device synchronisation per stage would undo exactly that).
 
 Off by default -- the command line prints and writes what the reference does and nothing else.  `GCI_PHASES=<file.json>` (or
 `phases.start()` from a harness such as bench.py) switches it on; `phases.report()` returns / writes the split."""
@@ -73,21 +73,37 @@ def wall(name: str):
         _WALL.append((name, time.perf_counter() - t))
 
 
+_PROVIDER = None
+
+
+def set_provider(T) -> None:
+    """The buffer / stream provider (gci_amd/hbm.py) whose events time the device stages: an Engine says which when it is made."""
+    global _PROVIDER
+    _PROVIDER = T
+
+
+def _provider():
+    if _PROVIDER is not None:
+        return _PROVIDER
+    from . import hbm
+    return hbm.provider()
+
+
 @contextlib.contextmanager
 def gpu(name: str, stream=None):
     """Device time of what is enqueued inside, between two events on the current (= the engine's) stream."""
     if not _ON:
         yield
         return
-    import torch
+    T = _provider()
     global _BASE
     if _TRACE and _BASE is None:                          # a common clock: an event right behind a synchronisation + the host's time then
-        torch.cuda.synchronize()
-        e = torch.cuda.Event(enable_timing=True)
+        T.synchronize()
+        e = T.Event(enable_timing=True)
         e.record(stream)
         e.synchronize()
         _BASE = (e, now())
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a, b = T.Event(enable_timing=True), T.Event(enable_timing=True)
     a.record(stream)
     try:
         yield
@@ -124,8 +140,7 @@ def report(path: Optional[str] = None) -> dict:
     for name, s in _WALL:
         out["wall_s"][name] = out["wall_s"].get(name, 0.0) + s
     if _GPU:
-        import torch
-        torch.cuda.synchronize()
+        _provider().synchronize()
         # per stage also its FIRST occurrence, its longest one and their number: a first call that takes ten times the later ones (the
         # first inflate of a file on some boxes: DESIGN.md section 8) shows in every phase log, traced or not
         out["gpu_first_s"], out["gpu_max_s"], out["gpu_calls"] = {}, {}, {}

@@ -25,10 +25,9 @@ from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
-import torch
 
-from . import phases, score
-from .device import Engine, JoinInput, REC_DTYPE, name_hash_np
+from . import hbm, phases, score
+from .device import Buffer, Engine, JoinInput, REC_DTYPE, name_hash_np
 from . import _lib
 from ._lib import GciError, REC_HQ, REC_PASS
 from .formats import bam as bamfmt
@@ -46,7 +45,9 @@ def default_engine() -> Engine:
     global _ENGINE
     with _ENGINE_LOCK:                                    # (the helper thread of prefetch_member_tables may be the first to ask)
         if _ENGINE is None:
-            _ENGINE = Engine(SHARD.device_index if SHARD is not None else 0)
+            # (a contig-sharded run exchanges tensors through torch.distributed: its buffers are torch's; a single process holds its
+            # own -- hbm.py -- unless GCI_HBM or an already imported torch says otherwise)
+            _ENGINE = Engine(SHARD.device_index if SHARD is not None else 0, backend="torch" if SHARD is not None else None)
         return _ENGINE
 
 
@@ -59,7 +60,7 @@ def _slice_bound(v: int, L: int) -> int:
 class DepthTracks:
     """The reference's `depths` dict (contig -> per-base array), resident in HBM."""
 
-    def __init__(self, engine: Engine, targets_length: Dict[str, int], track: torch.Tensor):
+    def __init__(self, engine: Engine, targets_length: Dict[str, int], track: Buffer):
         self.engine = engine
         self.targets_length = dict(targets_length)
         self.targets = list(targets_length.keys())
@@ -151,7 +152,7 @@ def refuse_overwrite(path: str, force) -> None:
 def get_Ns_ref(reference=None, prefix="GCI", directory=".", force=False):
     if _INGEST_AHEAD:                                                     # (a helper thread owns the default context just now)
         side = _side_engine()
-        with torch.cuda.stream(side.stream):
+        with side.T.stream(side.stream):
             _, ns_bed = fasta.n_runs_device(side, reference)
     else:
         _, ns_bed = fasta.n_runs_device(default_engine(), reference)      # N4: the scan itself runs on the GPU
@@ -275,7 +276,7 @@ BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(8 << 30)))
 K1_MODE = os.environ.get("GCI_K1", "pages")
 
 
-def _filter_stream(engine: Engine, d_stream: torch.Tensor, d_off: torch.Tensor, has_seq: bool, ref_sel: torch.Tensor, filt,
+def _filter_stream(engine: Engine, d_stream: Buffer, d_off: Buffer, has_seq: bool, ref_sel: Buffer, filt,
                    rec_idx_base: int = 0) -> JoinInput:
     """K1 over the records of an inflated BAM stream (has_seq) or a heads stream -> join input (records + where their names are)."""
     map_qual, mq_cutoff, clip_percent, iden_percent = filt
@@ -301,27 +302,26 @@ def _keep_part(engine: Engine, ji: JoinInput) -> JoinInput:
     names, noff = engine.pack_names(ji)
     recs = ji.recs.clone()
     if ji.name_delta == 0:
-        recs[:, 29] &= 3                                  # packed names no longer lie at 16 k + 4: not GCI_REC_NAME16
+        engine.T.rec_flags_and(recs, 3)                   # packed names no longer lie at 16 k + 4: not GCI_REC_NAME16
     return JoinInput(recs, names.clone(), noff[:-1].clone(), 0)
 
 
 def _concat_parts(engine: Engine, parts: List[JoinInput]) -> JoinInput:
-    dev = engine.device
+    dev, T = engine.device, engine.T
     if not parts:
-        return JoinInput(torch.zeros((0, 32), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.uint8, device=dev),
-                         torch.zeros(1, dtype=torch.int64, device=dev), 0)
+        return JoinInput(T.zeros((0, 32), T.uint8, dev), T.zeros(1, T.uint8, dev), T.zeros(1, T.int64, dev), 0)
     if len(parts) == 1:
         return parts[0]
     offs, base = [], 0
     for p in parts:
-        offs.append(p.name_off + base)
+        offs.append(T.add_i64(p.name_off, base))
         base += (int(p.name_base.shape[0]) + 15) // 16 * 16            # (pages keep their 16-byte phase: GCI_REC_NAME16)
-    names = torch.zeros(max(base, 1), dtype=torch.uint8, device=dev)
+    names = T.zeros(max(base, 1), T.uint8, dev)
     at = 0
     for p in parts:
         names[at:at + int(p.name_base.shape[0])] = p.name_base
         at += (int(p.name_base.shape[0]) + 15) // 16 * 16
-    return JoinInput(torch.cat([p.recs for p in parts]), names, torch.cat(offs), 0)
+    return JoinInput(T.cat([p.recs for p in parts]), names, T.cat(offs), 0)
 
 
 def _runs_of_members(engine: Engine, isz: np.ndarray, chunk_bytes: int) -> List[Tuple[int, int]]:
@@ -429,8 +429,9 @@ class _RunUploads:
             # from the COPY stream's pool: a block recycled there was last used in that stream's order, so the upload need not wait
             # for whatever the main stream is busy with (the file in front is still being inflated when the next file's first
             # run leaves); the main stream's use of it is told to the allocator instead
-            with torch.cuda.stream(self.copy):
-                self.bufs[i] = torch.empty(want, dtype=torch.uint8, device=self.engine.device)
+            T = self.engine.T
+            with T.stream(self.copy):
+                self.bufs[i] = T.empty(want, T.uint8, self.engine.device)
             self.bufs[i].record_stream(self.engine.stream)
         return self.bufs[i]
 
@@ -447,16 +448,17 @@ class _RunUploads:
             n = p1 - p0
             buf = self._buffer(k, n + 16)
             t_send = phases.now()
-            with torch.cuda.stream(self.copy), warnings.catch_warnings():
+            T = self.engine.T
+            with T.stream(self.copy), warnings.catch_warnings():
                 warnings.simplefilter("ignore", UserWarning)     # a read-only memmap is only read
                 if freed is not None:
                     self.copy.wait_event(freed)
                 if self.staged:
                     self.staging.send(self.raw, p0, p1, buf, self.copy)
                 else:
-                    buf[:n].copy_(torch.from_numpy(np.asarray(self.raw[p0:p1])))
+                    buf[:n].copy_(self.engine._host_src(self.raw[p0:p1]))
                 buf[n:n + 16].zero_()
-                ev = torch.cuda.Event()
+                ev = T.Event()
                 ev.record(self.copy)
             phases.trace("upload", k, t_send, phases.now(), n)
             if self.m.is_last(k):
@@ -477,7 +479,7 @@ class _RunUploads:
 
     def release(self, k: int):
         """Everything that reads run k's buffer has been enqueued on the main stream: the run after next may overwrite it."""
-        ev = torch.cuda.Event()
+        ev = self.engine.T.Event()
         ev.record(self.engine.stream)
         self.freed[k & 1] = ev
 
@@ -725,7 +727,7 @@ def start_ingest_ahead(bam_files: Sequence[str], chrs_list, filt: Tuple[int, int
     ingestion raises is raised by filter() where bam_join_input() would have raised it."""
     from concurrent.futures import Future
     if (os.environ.get("GCI_INGEST_AHEAD", "1") == "0" or os.environ.get("GCI_BAM_INGEST", "gpu") != "gpu" or _sharded()
-            or not bam_files or bam_files[0] in _INGEST_AHEAD or not torch.cuda.is_available()):
+            or not bam_files or bam_files[0] in _INGEST_AHEAD):
         return
     path = bam_files[0]
     try:
@@ -771,7 +773,7 @@ def _side_engine() -> Engine:
     global _SIDE_ENGINE
     if _SIDE_ENGINE is None:
         main = default_engine()
-        _SIDE_ENGINE = Engine(main.device.index, stream=torch.cuda.Stream(device=main.device))
+        _SIDE_ENGINE = Engine(main.device.index, stream=main.T.Stream(main.device))
         _SIDE_ENGINE._staging = main.staging()
     return _SIDE_ENGINE
 
@@ -858,7 +860,7 @@ def bam_join_input(engine: Engine, path: str, targets: Sequence[str], filt: Tupl
                     if uploads is not None:
                         uploads.close()                       # (idempotent: a failure in front of the run loop leaves it open)
                 if phases.on():
-                    torch.cuda.synchronize()
+                    engine.T.synchronize()
             if phases.on():
                 pos, isz = members.whole()
                 phases.add("bgzf_bytes", int(raw.shape[0]))
@@ -1028,7 +1030,7 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
             if text_on_device:
                 _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
             else:
-                _write_depth_members(directory, prefix, depths)
+                _write_depth_members(directory, prefix, depths, from_build=True)     # (the build just above kept its run lists)
         print("Writing depths done!!!\n\n")
     return depths, targets_length
 
@@ -1137,7 +1139,7 @@ def _replicate(engine: Engine, ji: JoinInput) -> JoinInput:
     if n:
         blob, off = engine.pack_names(ji)
     else:
-        blob, off = torch.zeros(0, dtype=torch.uint8, device=engine.device), torch.zeros(1, dtype=torch.int64, device=engine.device)
+        blob, off = engine.T.zeros(0, engine.T.uint8, engine.device), engine.T.zeros(1, engine.T.int64, engine.device)
     ex = shard.RecordExchange(n, int(blob.shape[0]), engine.device, via_host=SHARD.backend != "nccl")
     ex.send_recs[:n] = ji.recs
     ex.send_recs[:n, 29] &= 3                          # the names travel packed: no longer GCI_REC_NAME16
@@ -1152,6 +1154,7 @@ def _own_names_only(engine: Engine, ji: JoinInput, world: int, rank: int) -> Joi
     (hash >> 33) % world, the rule of gci_route_records -- so that they meet the routed BAM records of the same names."""
     if int(ji.recs.shape[0]) == 0:
         return ji
+    import torch                                       # (a contig-sharded run: the torch provider)
     h = ji.recs[:, 0:8].contiguous().view(torch.int64).reshape(-1)
     dest = ((h >> 33) & 0x7FFFFFFF) % world
     recs = ji.recs.clone()
@@ -1217,6 +1220,7 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
         err, err_contig = e, getattr(e, "contig", 0)
     _agree_on_error(err, err_contig)
     # routed name slots: as long as the longest query name of the run (a multiple of 16, the same on every rank)
+    import torch                                       # (a contig-sharded run: the torch provider)
     longest = max([int(ji.recs[:, 30:32].contiguous().view(torch.int16).max().item()) if int(ji.recs.shape[0]) else 0 for ji in local] + [1])
     slot = (SHARD.all_reduce_max([longest])[0] + 15) // 16 * 16
     sj = shard.ShardedJoin(engine, [int(ji.recs.shape[0]) for ji in local], SHARD.owner, engine.device,
@@ -1327,11 +1331,12 @@ def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads
     _write_depth_text(directory, prefix, depths, text, offs, threads)
 
 
-def _write_depth_members(directory, prefix, depths: DepthTracks) -> None:
+def _write_depth_members(directory, prefix, depths: DepthTracks, from_build: bool = False) -> None:
     """'>contig' member (host), then the contig's lines as the members the device wrote.  Contig-sharded run: every rank
-    deflates the contigs it owns, rank 0 gathers the members and writes them in header order."""
+    deflates the contigs it owns, rank 0 gathers the members and writes them in header order.  from_build: only filter() says
+    so, for the track its own build has just written (Engine.depth_deflate)."""
     from . import hostio
-    blobs = depths.engine.depth_deflate(depths.track)               # views of the engine's pinned staging buffer
+    blobs = depths.engine.depth_deflate(depths.track, from_build=from_build)               # views of the engine's pinned staging buffer
     items = list(zip(depths.targets, depths.lengths, blobs))
     if _sharded():
         # to rank 0 only (the members of a genome are GBs), as bytes: a sized gather of one uint8 tensor per rank -- which contigs a
@@ -1398,7 +1403,7 @@ def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTrac
     if issue_hint is not None and nano_depths.engine is engine and same_pending:
         hifi_depths._bind_layout()
         lo, hi, fl = float(issue_hint[0]), float(issue_hint[1]), int(issue_hint[2])
-        d_sums = torch.zeros((3, max(len(hifi_depths.targets), 1)), dtype=torch.int64, device=engine.device)
+        d_sums = engine.T.zeros((3, max(len(hifi_depths.targets), 1)), engine.T.int64, engine.device)
         two, runs = engine.two_type_tail(hifi_depths.track, nano_depths.track, pend[0], lo, hi, fl, sums=d_sums)
         merged = DepthTracks(engine, hifi_depths.targets_length, two)
         h_sums = d_sums.cpu().numpy()[:, :len(hifi_depths.targets)]

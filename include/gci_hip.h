@@ -127,6 +127,40 @@ int gci_memcpy_h2d(gci_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); 
 int gci_memcpy_d2h(gci_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
 int gci_memset(gci_ctx* ctx, void* d_dst, int byte, size_t bytes);                /* async */
 
+/* ---- device memory, streams and events for a host without a tensor library (k_hbm.hip; round 6) -------------------------------
+ * What the single-GPU command line holds its HBM buffers with (gci_amd/hbm.py: a caching allocator, stream-ordered like the
+ * one it replaces, over gci_dev_malloc) -- `import torch` costs half a second of a 4 s run and is needed only for
+ * torch.distributed (--gpus N).  Not tied to a context: `device` is the HIP device index, `stream` / `event` are hipStream_t /
+ * hipEvent_t handles (a stream made here can be handed to gci_ctx_create with own_stream = 0).  Every call returns a gci_status;
+ * gci_dev_last_error() is the calling thread's last HIP message.  gci_dev_malloc returns GCI_E_NOMEM when the device is full
+ * (the caller frees what it caches and tries again).
+ * gci_dev_memcpy_async: kind 1 = host -> device, 2 = device -> host, 3 = device -> device.
+ * The three element-wise helpers are what the host side does to buffers it cannot touch: out[i] = in[i] + delta (name offsets
+ * of the runs of a file put behind one another), recs[i].flags &= mask (GCI_REC_NAME16 dropped when names are packed), and the
+ * exclusive prefix sum of the .depth.gz member sizes (uint32 in, uint64 out, n + 1 entries; one workgroup). */
+const char* gci_dev_last_error(void);
+int gci_dev_count(int* n_out);
+int gci_dev_malloc(int device, size_t bytes, void** d_out);
+int gci_dev_free(int device, void* d_ptr);
+int gci_dev_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+int gci_dev_sync(int device);
+int gci_dev_host_alloc(int device, size_t bytes, void** h_out);      /* pinned */
+int gci_dev_host_free(int device, void* h_ptr);
+int gci_dev_stream_create(int device, void** out);                   /* non-blocking */
+int gci_dev_stream_destroy(int device, void* stream);
+int gci_dev_stream_sync(int device, void* stream);
+int gci_dev_event_create(int device, int timing, void** out);
+int gci_dev_event_destroy(int device, void* event);
+int gci_dev_event_record(int device, void* event, void* stream);
+int gci_dev_event_sync(int device, void* event);
+int gci_dev_event_elapsed_ms(int device, void* event_a, void* event_b, double* ms);
+int gci_dev_stream_wait_event(int device, void* stream, void* event);
+int gci_dev_memcpy_async(int device, void* dst, const void* src, size_t bytes, int kind, void* stream);
+int gci_dev_memset_async(int device, void* d_dst, int byte, size_t bytes, void* stream);
+int gci_dev_i64_add(int device, const int64_t* d_in, uint64_t n, int64_t delta, int64_t* d_out, void* stream);
+int gci_dev_rec_flags_and(int device, gci_rec* d_recs, uint64_t n, uint32_t mask, void* stream);
+int gci_dev_u32_scan_u64(int device, const uint32_t* d_in, uint32_t n, uint64_t* d_out, void* stream);
+
 /* ---- optional per-kernel timing with HIP events on the ctx stream ------------------------------
  * gci_profile_enable(mask): bit k enables an event pair around every launch of kernel id k.
  * gci_profile_read(): synchronises, folds finished event pairs in and returns the accumulated
@@ -290,9 +324,9 @@ typedef struct gci_build_opts {
     int counted;                  /* 1: the intervals are exactly what the last gci_name_join_count emitted (same flank):
                                      the per-tile counting pass has been done there */
     int want_runs;                /* 1: finish also keeps, in the context, the constant-depth runs of every 4096-base tile as it
-                                     wrote them; gci_depth_deflate_size / _write over the SAME d_depth then take the runs from
-                                     there instead of reading the track (members that start on a tile boundary: every
-                                     contig does).  gci_gap_mask / gci_max2 / gci_two_type_tail, a new build and
+                                     wrote them; a gci_depth_deflate_size / _write pair over the SAME d_depth, announced by
+                                     gci_depth_deflate_from_build(), then takes the runs from there instead of reading
+                                     the track (members that start on a tile boundary: every contig does), once.  gci_gap_mask / gci_max2 / gci_two_type_tail, a new build and
                                      gci_layout_set drop the lists; a caller that writes the track by other means
                                      between the build and the deflate calls must not set this.  (Occupies what was
                                      padding: sizeof(gci_build_opts) is unchanged.) */
@@ -343,6 +377,12 @@ int gci_depth_text_write(gci_ctx* ctx, const int32_t* d_depth, uint8_t* d_out, u
  * of 4; the caller cuts members so that none spans two contigs and writes the '>contig' lines as members of its own).
  *   size:  d_tile_bytes[64 m + t], d_member_bytes[m] (header and trailer included), d_member_crc[m], d_member_isize[m]
  *   write: d_member_out[m] = byte offset of member m in d_out (exclusive scan of d_member_bytes by the caller). */
+/* The run lists a build kept (gci_build_opts.want_runs) are used by the NEXT size / write pair only when the caller says so, here:
+ * "d_depth is the track that build wrote, and nothing -- no call of this library through any context, no other code -- has
+ * written it since".  The library cannot see writes that go around this context (another context's gci_gap_mask, the caller's
+ * own kernels, an allocator handing the address to a new buffer), so a pointer match alone is never taken as that statement.
+ * Returns GCI_E_INVALID when this context holds no lists for d_depth; the pair that follows consumes the lists (one shot). */
+int gci_depth_deflate_from_build(gci_ctx* ctx, const int32_t* d_depth);
 int gci_depth_deflate_size(gci_ctx* ctx, const int32_t* d_depth, const uint64_t* d_member_elem, const uint32_t* d_member_n,
                            uint32_t n_members, uint32_t* d_tile_bytes, uint32_t* d_member_bytes, uint32_t* d_member_crc,
                            uint32_t* d_member_isize);
@@ -522,9 +562,11 @@ int gci_stage_free(gci_stage* stage);
  * buffer is the window).  Every member's length and -- check_crc != 0, by a further kernel, one wave per member -- CRC-32 are
  * verified.  d_raw must be readable for 8 bytes past its last member (the decoders fetch whole aligned words).
  * *d_status: min over failing members of (member << 8 | -status), UINT64_MAX if none (decode with gci_decode_status).
- * Every other batch of members runs on a second stream of the context's own when the process's HIP runtime has hardware queues to
- * spare (GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the runtime starts; the default four are shared by all streams of a process,
- * and a copy stream that shares one with the inflate waits for it); GCI_INFLATE_STREAMS=1|2 overrides.
+ * gci_bgzf_inflate_streams(ctx, 2): every other batch of members runs on a second stream of the context's own.  For a host
+ * whose HIP runtime has hardware queues to spare -- GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the runtime started; the
+ * default four are shared by all streams of a process, and a copy stream that shares one with the inflate waits for it (uploads
+ * at 26 instead of 58 GB/s) -- and only the host knows whether the variable was there in time: the default is 1.
+ * GCI_INFLATE_STREAMS=1|2 in the environment overrides (measurements).
  * gci_bgzf_inflate_last_stats (synchronises): how the members of the context's LAST gci_bgzf_inflate_device call fared with the
  * wave decoder -- h_counts[0] decoded, [1] header not taken, [2] no meeting point, [3] end-of-block codes on wrong paths,
  * [4] undecodable / copies, [5] length, [6] lanes, [7] not tried (GCI_INFLATE=lane); [1 .. 6] went to the lane decoder.
@@ -537,6 +579,7 @@ int gci_stage_free(gci_stage* stage);
  * The call synchronises. */
 int gci_bgzf_inflate_device(gci_ctx* ctx, const uint8_t* d_raw, const uint64_t* d_member_pos, const uint64_t* d_out_off,
                             uint32_t n_members, uint8_t* d_out, uint64_t out_cap, int check_crc, uint64_t* d_status);
+int gci_bgzf_inflate_streams(gci_ctx* ctx, int n);
 int gci_bgzf_inflate_last_stats(gci_ctx* ctx, uint32_t h_counts[32]);
 /* Members the device decodes at a time (a launch takes a whole number of such rounds: size runs of a large file accordingly); 0 = unknown. */
 uint32_t gci_bgzf_inflate_round(gci_ctx* ctx);

@@ -809,19 +809,36 @@ def test_gzip_members_from_the_run_lists_the_build_keeps(engine):
     track = engine.new_track()
     engine.depth_build_fused(ivl, None, 0, track, want_text=False, want_runs=True)
     assert torch.equal(track, plain)
-    got = [bytes(b) for b in engine.depth_deflate(track)]
+    got = [bytes(b) for b in engine.depth_deflate(track, from_build=True)]
     assert got == want
-    # the same once more (the lists are still those of this track), then with flanks
+    # the lists serve ONE size / write pair: a second statement "from the build" is refused, the plain call walks the track
+    with pytest.raises(GciErr):
+        engine.depth_deflate(track, from_build=True)
     assert [bytes(b) for b in engine.depth_deflate(track)] == want
+    # ... then with flanks
     engine.depth_build_fused(ivl, None, 15, track, want_text=False, want_runs=True)
     engine.depth_build(ivl, None, 15, plain)
     assert torch.equal(track, plain)
-    assert [bytes(b) for b in engine.depth_deflate(track)] == [bytes(b) for b in engine.depth_deflate(plain)]
-    # a mask between build and deflate: the lists no longer describe the track
+    assert [bytes(b) for b in engine.depth_deflate(track, from_build=True)] == [bytes(b) for b in engine.depth_deflate(plain)]
+    # the lists are never taken on a pointer match alone: a write the context cannot see -- another context's gap
+    # mask, here -- between the build and a deflate that does NOT claim "from the build" shows in the members
     engine.depth_build_fused(ivl, None, 0, track, want_text=False, want_runs=True)
-    gaps = engine.to_device(np.asarray([(3, 100, 9000, 0), (5, 0, 4096, 0)], dtype=np.int32).reshape(-1, 4))
+    from gci_amd.device import Engine
+    other = Engine(0)
+    other.set_layout(lens)
+    gaps_rows = np.asarray([(3, 100, 9000, 0), (5, 0, 4096, 0)], dtype=np.int32).reshape(-1, 4)
+    other.gap_mask(track, other.to_device(gaps_rows))
+    other.sync()
+    unseen = [bytes(b) for b in engine.depth_deflate(track)]
+    assert gzip.decompress(unseen[3]) == ("\n".join(map(str, track.cpu().numpy()[engine.offsets[3]:engine.offsets[3] + lens[3]].tolist())) + "\n").encode()
+    other.close()
+    # a mask through this context between build and deflate: the lists are dropped, claiming them is refused
+    engine.depth_build_fused(ivl, None, 0, track, want_text=False, want_runs=True)
+    gaps = engine.to_device(gaps_rows)
     engine.gap_mask(track, gaps)
     masked = track.cpu().numpy()
+    with pytest.raises(GciErr):
+        engine.depth_deflate(track, from_build=True)
     after = [bytes(b) for b in engine.depth_deflate(track)]
     for c, (off, L) in enumerate(zip(engine.offsets, lens)):
         assert gzip.decompress(after[c]) == ("\n".join(map(str, masked[off:off + L].tolist())) + "\n").encode()
@@ -1036,3 +1053,135 @@ def test_two_type_tail_in_one_pass_equals_the_seams(engine, oracle, flank, thres
         assert tr._fresh_sums is not None and [int(x) for x in tr.sums()] == [int(want[k].sum()) for k in shapes]
         assert tr.mean() == oracle.mean_depth(want)
         assert [int(x) for x in engine.depth_sum(tr.track)] == [int(want[k].sum()) for k in shapes]
+
+
+# ---- the two divisions of GCI.py:165 at their thresholds, through the kernel the product runs (round 6) -------------------------
+def _threshold_records():
+    """Records whose clip quotient S / (M + I + S) and identity quotient (M - mm) / (M + I + D) cover what single precision can
+    and cannot tell apart: small exact fractions, denominators beyond 2^24 (inexact as f32), beyond 2^30 (the 32-bit path of the
+    kernel is left), one-operation and many-operation CIGARs, quotients of 0 and 1."""
+    from test_bam_decode import op, rec_bytes
+    import struct
+    shapes = [  # (S, M, I, D, mismatches under M)
+        (10, 90, 0, 0, 0), (10, 90, 0, 0, 9), (11, 89, 0, 0, 10), (1, 9, 0, 0, 1), (0, 100, 0, 0, 10), (0, 100, 0, 0, 0),
+        (100, 900, 0, 0, 100), (333, 2667, 30, 0, 270), (1000, 9000, 100, 100, 720), (1801, 16203, 7, 9, 1620),
+        (1 << 20, 9 << 20, 0, 0, 1 << 20), ((1 << 20) + 1, 9 << 20, 0, 0, (1 << 20) - 1), (1677722, 15099494, 3, 5, 1509949),
+        (16777217, 150994943, 11, 13, 15099494), (26843546, 241591910, 0, 1, 24159191),
+        (100, 0, 0, 0, 0), (0, 1, 0, 0, 0), (0, 1, 0, 0, 1), (5, 45, 0, 0, 5), (7, 63, 1, 1, 5), (12345, 111105, 17, 19, 11112),
+        (99999, 900001, 0, 0, 90000), (50000, 450000, 0, 0, 45001), (3, 30, 0, 0, 3), (2, 17, 1, 0, 2), (214748364, 1932735283, 0, 0, 193273528),
+    ]
+    out = []
+    for k, (S, M, I, D, mm) in enumerate(shapes):
+        ops = []
+        if S:
+            for piece in _pieces(S):
+                ops.append(op(piece, "S"))
+        left = M
+        parts = _pieces(M) if M else []
+        for j, piece in enumerate(parts):
+            ops.append(op(piece, "M" if (k + j) % 2 else "="))
+            if j == 0 and I:
+                ops.append(op(I, "I"))
+            if j == 0 and D:
+                ops.append(op(D, "D"))
+        if not parts:
+            if I:
+                ops.append(op(I, "I"))
+            if D:
+                ops.append(op(D, "D"))
+        nm = I + D + mm
+        aux = (b"NMC" + bytes([nm])) if nm < 256 else (b"NMI" + struct.pack("<I", nm))
+        out.append((rec_bytes(0, 100 + k, b"thr/%d/ccs" % k, 60, 0, ops, 50, aux), (S, M + I + S, M + I + D - nm, M + I + D)))
+    return out
+
+
+def _pieces(n, cap=(1 << 28) - 1):
+    """n as operation lengths (an operation holds 28 bits): one, or a few."""
+    out = []
+    while n > cap:
+        out.append(cap)
+        n -= cap
+    if n > (1 << 24) + 5:                      # (two operations where one would do: the lean path sums, the full path sums)
+        out += [n - (1 << 24) - 3, (1 << 24) + 3]
+    elif n:
+        out.append(n)
+    return out
+
+
+def test_hand_assembled_records_through_the_paged_filter(engine):
+    """tests/test_bam_decode.py's hand-assembled records -- the pysam-independent anchors of R1, "10 % clip passes exactly" and
+    "identity 0.9 exactly" among them -- through the kernel the command line and bench.py run (gci_bam_pages_* +
+    gci_bam_filter_pages), from the whole stream and from the heads stream."""
+    from test_bam_decode import HAND, stream_of
+    from gci_amd.formats import bam
+    s, offs, h = stream_of([r for _, r, _ in HAND])
+    h_bytes, h_offs = heads_expected(s, offs, bam.parse_header(s).first_record)
+    sel = engine.to_device(np.array([0, 1], np.int32))
+    for stream, o, has_seq in ((s, offs, True), (np.frombuffer(h_bytes, dtype=np.uint8), h_offs, False)):
+        for pb in (0, 8192):
+            pages = engine.bam_pages(engine.to_device(stream), engine.to_device(o), has_seq, pb)
+            recs = _recs_np(engine.bam_filter_pages(pages, sel, 30, 50, 0.1, 0.9)[0])
+            for i, (desc, _, want) in enumerate(HAND):
+                if want is None:
+                    continue
+                f = int(recs["flags"][i])
+                got = (f & 1, (f >> 1) & 1, int(recs["start"][i]), int(recs["end"][i]), int(recs["qlen"][i])) if f & 1 else (0, 0, 0, 0, 0)
+                assert got == want, (desc, has_seq, pb)
+
+
+@pytest.mark.parametrize("which", ["clip", "identity"])
+def test_filter_thresholds_at_and_around_every_quotient(engine, oracle, which):
+    """GCI.py:165 compares two f64 quotients with -cp / -ip.  The paged filter decides them in single precision unless the quotient
+    lies within 1e-4 of the threshold (k_filter.hip: ratio_cmp and the lean path's copy): here every record's f64 quotient q is
+    taken as the threshold itself, one ulp either side of it, and q +- 1e-7, 1e-6, 1e-5, 9.9e-5, 1.01e-4, 1e-3 -- i.e. exactly
+    on, just inside and just outside the band in which the kernel must fall back to the f64 division -- through the stream
+    kernel, the pages of the whole stream and the pages of the heads stream, against the oracle's division, all records each time."""
+    from test_bam_decode import stream_of
+    from gci_amd.formats import bam
+    items = _threshold_records()
+    s, offs, h = stream_of([r for r, _ in items], refs=(("chr1", 2_000_000_000),))
+    ref_sel = np.array([0], np.int32)
+    sel = engine.to_device(ref_sel)
+    h_bytes, h_offs = heads_expected(s, offs, bam.parse_header(s).first_record)
+    d_s, d_o = engine.to_device(s), engine.to_device(offs)
+    pages = [engine.bam_pages(d_s, d_o, True), engine.bam_pages(engine.to_device(np.frombuffer(h_bytes, dtype=np.uint8)), engine.to_device(h_offs), False, 8192)]
+    seen, n_flips, n_errors = set(), 0, 0
+    for _, (a1, b1, a2, b2) in items:
+        a, b = (a1, b1) if which == "clip" else (a2, b2)
+        if b == 0:
+            continue
+        q = a / b
+        cands = [q, np.nextafter(q, np.inf), np.nextafter(q, -np.inf)]
+        for d in (1e-7, 1e-6, 1e-5, 9.9e-5, 1.01e-4, 1e-3):
+            cands += [q + d, q - d, q * (1 + d), q * (1 - d)]
+        for c in cands:
+            c = float(c)
+            if c in seen:
+                continue
+            seen.add(c)
+            cp, ip = (c, 0.5) if which == "clip" else (0.75, c)
+            try:
+                want = oracle.bam_filter_arrays(s, offs, ref_sel, 30, 50, cp, ip)["passed"].astype(bool)
+            except oracle.OracleRecordError as e:          # (the all-clipped record passes the clip test: ZeroDivisionError behind it)
+                for call in ([lambda: engine.bam_filter(d_s, d_o, sel, 30, 50, cp, ip)] +
+                             [lambda pg=pg: engine.bam_filter_pages(pg, sel, 30, 50, cp, ip) for pg in pages]):
+                    with pytest.raises(GciErr) as g:
+                        call()
+                    assert (g.value.status, g.value.rec) == (e.status, e.rec), (which, c)
+                n_errors += 1
+                continue
+            got_stream = (_recs_np(engine.bam_filter(d_s, d_o, sel, 30, 50, cp, ip))["flags"] & 1).astype(bool)
+            assert np.array_equal(got_stream, want), ("stream", which, c)
+            for k, pg in enumerate(pages):
+                got = (_recs_np(engine.bam_filter_pages(pg, sel, 30, 50, cp, ip)[0])["flags"] & 1).astype(bool)
+                assert np.array_equal(got, want), ("pages", k, which, c, np.flatnonzero(got != want))
+            n_flips += int(want.sum())
+    assert len(seen) > 300 and n_flips > 1000 and (n_errors > 0) == (which == "clip")
+    # the twin in pure Python (the reference's own expression, GCI.py:165) on the thresholds that sit exactly on a quotient
+    for i, (_, (a1, b1, a2, b2)) in enumerate(items):
+        if b1 and b2:
+            rec = bam.decode_record(s, int(offs[i]))
+            for cp, ip in ((a1 / b1, a2 / b2), (np.nextafter(a1 / b1, -np.inf), a2 / b2), (a1 / b1, np.nextafter(a2 / b2, np.inf))):
+                want = oracle.bam_filter_record_py(rec, h.references, list(h.references), 30, 50, float(cp), float(ip)) is not None
+                got = bool(_recs_np(engine.bam_filter_pages(pages[0], sel, 30, 50, float(cp), float(ip))[0])["flags"][i] & 1)
+                assert got == want, (i, cp, ip)
