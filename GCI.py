@@ -27,6 +27,12 @@ def _wake_the_gpu():
         lib.gci_dev_mem_info.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         if lib.gci_dev_count(ctypes.byref(n)) == 0 and n.value > 0:
             lib.gci_dev_mem_info(0, None, None)       # (the device's primary context)
+            # a run over tens of GB of input says so to the library's arena now: its slabs are made here, beside the imports, not
+            # one driver call at a time in the middle of the first file's ingestion (include/gci_hip.h: gci_dev_reserve)
+            given = sum(os.path.getsize(a) for a in sys.argv[1:] if not a.startswith("-") and os.path.isfile(a))
+            if given >= (4 << 30) and os.environ.get("GCI_RESERVE", "1") != "0":
+                lib.gci_dev_reserve.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
+                lib.gci_dev_reserve(0, min(64 << 30, given // 2), None)
     except Exception:                                 # noqa: BLE001
         pass
 
@@ -43,7 +49,7 @@ def _a_single_gpu_run(argv) -> bool:
     copy of the runtime and must be the one to load it)."""
     if len(argv) < 2 or any(a in ("-h", "--help", "-v", "--version") for a in argv[1:]):
         return False
-    if all(k in os.environ for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR")):
+    if all(k in os.environ for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR")) or os.environ.get("GCI_HBM") == "torch":
         return False
     for k, a in enumerate(argv[1:], 1):
         if a == "--gpus" or a.startswith("--gpus="):

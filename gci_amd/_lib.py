@@ -63,6 +63,8 @@ EXPORTS = [
     ("gci_dev_count", c_int, [POINTER(c_int)]),
     ("gci_dev_malloc", c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     ("gci_dev_free", c_int, [c_int, c_void_p]),
+    ("gci_dev_reserve", c_int, [c_int, c_uint64, POINTER(c_uint64)]),
+    ("gci_dev_arena_info", c_int, [c_int, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint32)]),
     ("gci_dev_mem_info", c_int, [c_int, POINTER(c_uint64), POINTER(c_uint64)]),
     ("gci_dev_sync", c_int, [c_int]),
     ("gci_dev_host_alloc", c_int, [c_int, c_size_t, POINTER(c_void_p)]),

@@ -13,9 +13,9 @@ int gci_fail(gci_ctx* c, hipError_t e, const char* what)
 int gci_ensure(gci_ctx* ctx, DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap) return GCI_OK;
-    if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(gci_dfree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 4 + 256;
-    HIPCHK(hipMalloc(&b.p, want));
+    HIPCHK(gci_dmalloc(ctx->device, &b.p, want));
     b.cap = want;
     return GCI_OK;
 }
@@ -58,7 +58,7 @@ extern "C" int gci_ctx_create(int device, void* stream, int own_stream, gci_ctx*
     {
         uint32_t lut[TEXT_LUT];
         gci_text_lut_host(lut);
-        if (hipMalloc(&ctx->text_lut.p, sizeof lut) != hipSuccess ||
+        if (gci_dmalloc(device, &ctx->text_lut.p, sizeof lut) != hipSuccess ||
             hipMemcpy(ctx->text_lut.p, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
             gci_ctx_destroy(ctx);
             return GCI_E_HIP;
@@ -78,8 +78,8 @@ extern "C" int gci_ctx_destroy(gci_ctx* ctx)
                       &ctx->evt_off, &ctx->events, &ctx->blk_a, &ctx->blk_b, &ctx->tile_sum, &ctx->tile_u32,
                       &ctx->tile_u64, &ctx->blk_u64, &ctx->join_table, &ctx->join_last, &ctx->join_hq, &ctx->part_a, &ctx->part_b, &ctx->part_hist, &ctx->part_blk, &ctx->conflict_table, &ctx->win,
                       &ctx->win_tile_first, &ctx->text_lut, &ctx->long_items, &ctx->pg_cost, &ctx->pg_scan, &ctx->pg_first, &ctx->route_tab, &ctx->deflate_nruns, &ctx->deflate_runs, &ctx->deflate_tab, &ctx->build_nruns, &ctx->build_runs, &ctx->join_bucket, &ctx->tail_gaps, &ctx->tail_sums, &ctx->crc_tabs, &ctx->inflate_sym, &ctx->inflate_nsym, &ctx->inflate_wstatus, &ctx->inflate_lists, &ctx->inflate_prof, &ctx->inflate_next, &ctx->inflate_sym2, &ctx->inflate_lists2};
-    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
-    for (DevBuf& b : ctx->paf_pool) if (b.p) (void)hipFree(b.p);
+    for (DevBuf* b : bufs) if (b->p) (void)gci_dfree(b->p);
+    for (DevBuf& b : ctx->paf_pool) if (b.p) (void)gci_dfree(b.p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto* v : {&ctx->prof_live, &ctx->prof_free}) for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->inflate_stream2) { (void)hipStreamSynchronize(ctx->inflate_stream2); (void)hipStreamDestroy(ctx->inflate_stream2); }
@@ -154,13 +154,13 @@ extern "C" int gci_malloc(gci_ctx* ctx, size_t bytes, void** d_out)
 {
     if (!ctx || !d_out) return GCI_E_INVALID;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMalloc(d_out, bytes ? bytes : 16));
+    HIPCHK(gci_dmalloc(ctx->device, d_out, bytes ? bytes : 16));
     return GCI_OK;
 }
 extern "C" int gci_free(gci_ctx* ctx, void* p)
 {
     if (!ctx) return GCI_E_INVALID;
-    if (p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(p)); }
+    if (p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(gci_dfree(p)); }
     return GCI_OK;
 }
 extern "C" int gci_memcpy_h2d(gci_ctx* ctx, void* d, const void* h, size_t n)

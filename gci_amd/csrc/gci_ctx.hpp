@@ -137,6 +137,10 @@ int gci_fail(gci_ctx* c, hipError_t e, const char* what);
 int gci_ensure(gci_ctx* ctx, DevBuf& b, size_t bytes);
 int gci_upload_small(gci_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 
+// every device allocation of the library comes from the arena of k_hbm.hip (slabs of GBs, cut up here: no driver call per buffer)
+hipError_t gci_dmalloc(int device, void** out, size_t bytes);
+hipError_t gci_dfree(void* p);
+
 #define HIPCHK(call)                                      \
     do {                                                  \
         hipError_t _e = (call);                           \

@@ -3,6 +3,125 @@
 // status-returning wrappers over the HIP runtime, plus three element-wise helpers the host side needs on buffers it cannot touch.
 #include "gci_ctx.hpp"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+// ---- the arena: every device allocation of this library (its contexts' scratch, gci_malloc, gci_dev_malloc) is cut from a few large
+// slabs, so that a run makes a handful of hipMalloc calls -- all of them before or between its phases -- instead of forty in the
+// middle of its first inflate.  hipMalloc is a driver call that takes the process's address-space locks: 0.3 ms on an idle process,
+// 44 ms each beside a pinned copy with a dozen threads faulting a file mapping in (round 5: the 1 - 2 s "stall at the head of the
+// first file" on a third of the boxes, profiles/r05j2).  A slab is never given back while the process lives (hipFree synchronises
+// the device); blocks are 4 KiB granular, best fit, neighbours coalesced.  GCI_ARENA=0: straight hipMalloc / hipFree.
+// GCI_ARENA_SLAB_GB (default 16): the size of a slab; a larger request gets a slab of its own size.
+namespace {
+struct Arena {
+    std::mutex mu;
+    struct Slab { uintptr_t base; size_t size; };
+    std::vector<Slab> slabs;
+    std::map<uintptr_t, size_t> free_by_addr;
+    std::multimap<size_t, uintptr_t> free_by_size;
+    std::unordered_map<uintptr_t, size_t> live;
+    size_t reserved = 0, in_use = 0;
+};
+Arena g_arena[16];
+const bool g_arena_on = [] { const char* e = getenv("GCI_ARENA"); return !(e && e[0] == '0'); }();
+const size_t g_slab_bytes = [] { const char* e = getenv("GCI_ARENA_SLAB_GB"); const long v = e ? atol(e) : 16; return (size_t)(v < 1 ? 1 : v) << 30; }();
+constexpr size_t ARENA_GRAIN = 4096;
+
+void arena_erase_free(Arena& a, uintptr_t addr, size_t size)
+{
+    a.free_by_addr.erase(addr);
+    auto r = a.free_by_size.equal_range(size);
+    for (auto it = r.first; it != r.second; ++it) if (it->second == addr) { a.free_by_size.erase(it); break; }
+}
+void arena_insert_free(Arena& a, uintptr_t addr, size_t size)
+{
+    a.free_by_addr[addr] = size;
+    a.free_by_size.emplace(size, addr);
+}
+const Arena::Slab* arena_slab_of(const Arena& a, uintptr_t addr)
+{
+    for (const auto& s : a.slabs) if (addr >= s.base && addr < s.base + s.size) return &s;
+    return nullptr;
+}
+hipError_t arena_add_slab(Arena& a, int device, size_t at_least)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
+    // slabs grow geometrically -- 256 MiB, 1 GiB, 4 GiB, ... up to GCI_ARENA_SLAB_GB -- so that a small run (a test, chr19) holds
+    // little; a run that knows it will need tens of GB says so up front (gci_dev_reserve)
+    size_t step = a.slabs.empty() ? ((size_t)256 << 20) : a.slabs.back().size * 4;
+    if (step > g_slab_bytes) step = g_slab_bytes;
+    if (step < ((size_t)256 << 20)) step = (size_t)256 << 20;
+    size_t want = at_least > step ? (at_least + ((size_t)256 << 20) - 1) / ((size_t)256 << 20) * ((size_t)256 << 20) : step;
+    void* p = nullptr;
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess && want > at_least) {              // the device is filling up: exactly what is asked for
+        (void)hipGetLastError();
+        want = (at_least + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    a.slabs.push_back({(uintptr_t)p, want});
+    a.reserved += want;
+    arena_insert_free(a, (uintptr_t)p, want);
+    return hipSuccess;
+}
+}  // namespace
+
+hipError_t gci_dmalloc(int device, void** out, size_t bytes)
+{
+    if (!out || device < 0 || device >= 16) return hipErrorInvalidValue;
+    if (!g_arena_on) { hipError_t e = hipSetDevice(device); return e != hipSuccess ? e : hipMalloc(out, bytes ? bytes : 16); }
+    const size_t need = (bytes + ARENA_GRAIN - 1) / ARENA_GRAIN * ARENA_GRAIN + (bytes ? 0 : ARENA_GRAIN);
+    Arena& a = g_arena[device];
+    std::lock_guard<std::mutex> lock(a.mu);
+    auto it = a.free_by_size.lower_bound(need);
+    if (it == a.free_by_size.end()) {
+        hipError_t e = arena_add_slab(a, device, need);
+        if (e != hipSuccess) return e;
+        it = a.free_by_size.lower_bound(need);
+        if (it == a.free_by_size.end()) return hipErrorOutOfMemory;
+    }
+    const size_t have = it->first;
+    const uintptr_t addr = it->second;
+    a.free_by_size.erase(it);
+    a.free_by_addr.erase(addr);
+    if (have > need) arena_insert_free(a, addr + need, have - need);
+    a.live[addr] = need;
+    a.in_use += need;
+    *out = (void*)addr;
+    return hipSuccess;
+}
+
+hipError_t gci_dfree(void* p)
+{
+    if (!p) return hipSuccess;
+    if (!g_arena_on) return hipFree(p);
+    const uintptr_t addr = (uintptr_t)p;
+    for (Arena& a : g_arena) {
+        std::lock_guard<std::mutex> lock(a.mu);
+        auto lv = a.live.find(addr);
+        if (lv == a.live.end()) continue;
+        size_t size = lv->second;
+        a.live.erase(lv);
+        a.in_use -= size;
+        const Arena::Slab* slab = arena_slab_of(a, addr);
+        uintptr_t lo = addr;
+        auto nx = a.free_by_addr.find(addr + size);                       // the free neighbour behind, inside the same slab
+        if (nx != a.free_by_addr.end() && slab && nx->first < slab->base + slab->size) { const size_t ns = nx->second; arena_erase_free(a, addr + size, ns); size += ns; }
+        auto pv = a.free_by_addr.lower_bound(addr);                       // ... and the one in front
+        if (pv != a.free_by_addr.begin()) {
+            --pv;
+            if (pv->first + pv->second == addr && slab && pv->first >= slab->base) { lo = pv->first; const size_t ps = pv->second; arena_erase_free(a, lo, ps); size += ps; }
+        }
+        arena_insert_free(a, lo, size);
+        return hipSuccess;
+    }
+    return hipFree(p);                                     // (not the arena's: a pointer from before GCI_ARENA, or a caller's mistake the runtime reports)
+}
+
 namespace {
 thread_local std::string g_dev_err;
 int dev_fail(hipError_t e, const char* what) { g_dev_err = std::string(what) + ": " + hipGetErrorString(e); return GCI_E_HIP; }
@@ -56,16 +175,44 @@ int gci_dev_count(int* n_out)
 int gci_dev_malloc(int device, size_t bytes, void** d_out)
 {
     if (!d_out) return GCI_E_INVALID;
-    DEVCHK(hipSetDevice(device));
-    hipError_t e = hipMalloc(d_out, bytes ? bytes : 16);
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); g_dev_err = "hipMalloc: out of memory"; return GCI_E_NOMEM; }
-    if (e != hipSuccess) return dev_fail(e, "hipMalloc");
+    hipError_t e = gci_dmalloc(device, d_out, bytes);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); g_dev_err = "device memory: out of memory"; return GCI_E_NOMEM; }
+    if (e != hipSuccess) return dev_fail(e, "gci_dmalloc");
     return GCI_OK;
 }
 int gci_dev_free(int device, void* d_ptr)
 {
-    DEVCHK(hipSetDevice(device));
-    if (d_ptr) DEVCHK(hipFree(d_ptr));
+    (void)device;
+    if (d_ptr) DEVCHK(gci_dfree(d_ptr));
+    return GCI_OK;
+}
+// Slabs for at least `bytes` in all (what a run expects to hold at once), made now -- by the command line's waker thread, beside the
+// interpreter's imports -- rather than piece by piece when the buffers are first asked for.  *reserved_out: the arena's slabs after it.
+int gci_dev_reserve(int device, uint64_t bytes, uint64_t* reserved_out)
+{
+    if (device < 0 || device >= 16) return GCI_E_INVALID;
+    Arena& a = g_arena[device];
+    if (g_arena_on) {
+        std::lock_guard<std::mutex> lock(a.mu);
+        while (a.reserved < bytes) {
+            const size_t before = a.reserved;
+            hipError_t e = arena_add_slab(a, device, (size_t)(bytes - a.reserved));
+            if (e == hipErrorOutOfMemory) { g_dev_err = "gci_dev_reserve: out of memory"; break; }
+            if (e != hipSuccess) return dev_fail(e, "gci_dev_reserve");
+            if (a.reserved == before) break;
+        }
+    }
+    if (reserved_out) *reserved_out = a.reserved;
+    return GCI_OK;
+}
+int gci_dev_arena_info(int device, uint64_t* reserved, uint64_t* in_use, uint32_t* n_slabs)
+{
+    if (device < 0 || device >= 16) return GCI_E_INVALID;
+    Arena& a = g_arena[device];
+    std::lock_guard<std::mutex> lock(a.mu);
+    if (reserved) *reserved = a.reserved;
+    if (in_use) *in_use = a.in_use;
+    if (n_slabs) *n_slabs = (uint32_t)a.slabs.size();
     return GCI_OK;
 }
 int gci_dev_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes)

@@ -521,14 +521,14 @@ struct gci_paf_hits {
 
 static void paf_dev_release(gci_paf_dev* h)
 {
-    for (void* p : h->recs) if (p) (void)hipFree(p);
-    for (void* p : h->name_off) if (p) (void)hipFree(p);
+    for (void* p : h->recs) if (p) (void)gci_dfree(p);
+    for (void* p : h->name_off) if (p) (void)gci_dfree(p);
     delete h;
 }
 
 static void paf_hits_release(gci_paf_hits* h)
 {
-    for (void* p : h->hits) if (p) (void)hipFree(p);
+    for (void* p : h->hits) if (p) (void)gci_dfree(p);
     delete h;
 }
 
@@ -552,7 +552,7 @@ struct PafScratch {
         static const size_t keep = [] { const char* e = getenv("GCI_PAF_POOL_KEEP_GB"); return e ? (size_t)atoll(e) << 30 : (size_t)PAF_POOL_KEEP; }();
         if (held <= keep) return;
         (void)hipStreamSynchronize(ctx->stream);
-        for (DevBuf& b : ctx->paf_pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        for (DevBuf& b : ctx->paf_pool) { if (b.p) (void)gci_dfree(b.p); b.p = nullptr; b.cap = 0; }
     }
     void* alloc(size_t bytes)
     {
@@ -575,7 +575,7 @@ extern "C" int gci_paf_pool_release(gci_ctx* ctx)
     for (const DevBuf& b : ctx->paf_pool) any = any || b.p;
     if (!any) return GCI_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (DevBuf& b : ctx->paf_pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    for (DevBuf& b : ctx->paf_pool) { if (b.p) (void)gci_dfree(b.p); b.p = nullptr; b.cap = 0; }
     return GCI_OK;
 }
 
@@ -746,9 +746,9 @@ int paf_stage_b(gci_ctx* ctx, PafScratch& S, const uint8_t* d_names, PafHitD* d_
         const uint32_t limit = hits_upto[f + 1];
         if (limit == 0) continue;
         void *p_recs = nullptr, *p_off = nullptr;
-        if (hipMalloc(&p_recs, sizeof(gci_rec) * (size_t)limit) != hipSuccess) return GCI_E_NOMEM;
+        if (gci_dmalloc(ctx->device, &p_recs, sizeof(gci_rec) * (size_t)limit) != hipSuccess) return GCI_E_NOMEM;
         H->recs[f] = p_recs;
-        if (hipMalloc(&p_off, 8ull * limit) != hipSuccess) return GCI_E_NOMEM;
+        if (gci_dmalloc(ctx->device, &p_off, 8ull * limit) != hipSuccess) return GCI_E_NOMEM;
         H->name_off[f] = p_off;
         HIPCHK(hipMemsetAsync(d_n, 0, 4, st));
         hipLaunchKernelGGL(k_paf_score, dim3((n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, (const PafHitD*)d_hits, (const uint32_t*)d_table,

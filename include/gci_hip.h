@@ -142,6 +142,14 @@ const char* gci_dev_last_error(void);
 int gci_dev_count(int* n_out);
 int gci_dev_malloc(int device, size_t bytes, void** d_out);
 int gci_dev_free(int device, void* d_ptr);
+/* Device memory of this library -- gci_dev_malloc, gci_malloc and every context's scratch -- is cut from an ARENA of large slabs
+ * (k_hbm.hip): a run makes a handful of hipMalloc calls instead of one per buffer, none of them in the middle of its ingestion
+ * (a driver allocation beside a pinned copy and a dozen threads faulting a file in was measured at 44 ms instead of 0.3).  Slabs
+ * grow 256 MiB, 1 GiB, 4 GiB ... up to GCI_ARENA_SLAB_GB (16) and stay until the process ends; GCI_ARENA=0 turns the arena off.
+ * gci_dev_reserve: slabs for at least `bytes` in all, now (a host that knows its inputs are tens of GB calls this before it starts).
+ * gci_dev_arena_info: bytes in slabs, bytes handed out, number of slabs. */
+int gci_dev_reserve(int device, uint64_t bytes, uint64_t* reserved_out);
+int gci_dev_arena_info(int device, uint64_t* reserved, uint64_t* in_use, uint32_t* n_slabs);
 int gci_dev_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int gci_dev_sync(int device);
 int gci_dev_host_alloc(int device, size_t bytes, void** h_out);      /* pinned */

@@ -96,6 +96,60 @@ def test_provider_buffers_streams_and_the_allocator():
     assert hbm.memory_held(0) < held
 
 
+def test_arena_cuts_blocks_from_slabs_and_coalesces():
+    """gci_dev_malloc / gci_dev_free (the arena of k_hbm.hip): blocks come out of slabs without a driver call each, a freed block
+    merges with its free neighbours (the slab's space is whole again after any order of frees), a request beyond every slab makes a
+    slab of its own, and the library's contexts draw from the same arena."""
+    import ctypes
+    from gci_amd import _lib
+    lib = _lib.load()
+
+    def info():
+        r, u, n = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        assert lib.gci_dev_arena_info(0, ctypes.byref(r), ctypes.byref(u), ctypes.byref(n)) == 0
+        return r.value, u.value, n.value
+
+    def alloc(nbytes):
+        p = ctypes.c_void_p()
+        assert lib.gci_dev_malloc(0, nbytes, ctypes.byref(p)) == 0
+        return p.value
+
+    if os.environ.get("GCI_ARENA", "1") == "0":
+        pytest.skip("arena off")
+    first = alloc(1)                                           # (at least one slab exists from here on)
+    r0, u0, n0 = info()
+    sizes = [4096, 100_000, 3 << 20, 1, 40 << 20, 12_345_678, 65_536, 2 << 20]
+    ptrs = [alloc(s) for s in sizes]
+    r1, u1, n1 = info()
+    assert len(set(ptrs)) == len(ptrs) and all(p % 4096 == 0 for p in ptrs)
+    assert u1 - u0 == sum((s + 4095) // 4096 * 4096 for s in sizes)
+    spans = sorted((p, (s + 4095) // 4096 * 4096) for p, s in zip(ptrs, sizes))
+    assert all(a + n <= b for (a, n), (b, _) in zip(spans, spans[1:]))          # no two blocks overlap
+    for k in (3, 0, 7, 5, 1, 6, 2, 4):                                           # freed in a scrambled order
+        assert lib.gci_dev_free(0, ctypes.c_void_p(ptrs[k])) == 0
+    r2, u2, n2 = info()
+    assert u2 == u0 and r2 == r1
+    again = alloc(sum(sizes))                                                    # fits only where the freed blocks have merged
+    r3, _, n3 = info()
+    assert (r3, n3) == (r2, n2) or n3 == n2 + 1                                  # (a small first slab may have been outgrown: then one more)
+    assert lib.gci_dev_free(0, ctypes.c_void_p(again)) == 0
+    big = alloc(r3 + (1 << 20))                                                  # larger than everything reserved: a slab of its own
+    r4, _, n4 = info()
+    assert n4 == n3 + 1 and r4 >= 2 * r3
+    assert lib.gci_dev_free(0, ctypes.c_void_p(big)) == 0 and lib.gci_dev_free(0, ctypes.c_void_p(first)) == 0
+    got = ctypes.c_uint64(0)
+    assert lib.gci_dev_reserve(0, r4 // 2, ctypes.byref(got)) == 0 and got.value == r4      # already there: nothing new
+    # a context's scratch comes from the arena too
+    from gci_amd.device import Engine
+    _, ua, _ = info()
+    e = Engine(0, backend="native")
+    e.set_layout([5_000_000])
+    _, ub, _ = info()
+    e.close()
+    _, uc, _ = info()
+    assert ub > ua and uc <= ua + (64 << 20)
+
+
 def test_native_engine_against_the_oracle_and_the_torch_engine(native_engine, engine, oracle, tmp_path):
     """The smoke path -- pages, paged filter, join, depth build, issue scan, text, .depth.gz members, BGZF inflate -- through an
     Engine whose buffers are the library's own: equal to the oracle, and byte-equal to the torch-backed Engine's outputs."""

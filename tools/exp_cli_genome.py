@@ -40,6 +40,14 @@ if os.environ.get("GCI_EXP_PROFILE"):
                     ("product again", {}))
         if os.environ.get("GCI_EXP_AB"):                   # e.g. '[["16 GiB runs", {"GCI_BAM_CHUNK_BYTES": "17179869184"}]]'
             variants = [("product", {})] + [(a, b) for a, b in json.loads(os.environ["GCI_EXP_AB"])] + [("product again", {})]
+        if os.environ.get("GCI_EXP_FIRST"):                # the FIRST pass over the freshly written files under another environment
+            lab, extra0 = json.loads(os.environ["GCI_EXP_FIRST"])
+            variants = [("first pass: " + lab, extra0)] + list(variants)
+        if os.environ.get("GCI_EXP_PRETOUCH") == "cat":    # the files read once by another process before the first pass
+            t0 = time.perf_counter()
+            for b in bams + [fa]:
+                subprocess.run(["cat", b], stdout=subprocess.DEVNULL)
+            print("pretouch: cat of %d files took %.2f s" % (len(bams) + 1, time.perf_counter() - t0), flush=True)
         for label, extra in variants:
             env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph_ab.json"), PYTHONPATH=ROOT, GCI_STUCK_TRACE="15")
             env.update(extra)
