@@ -12,26 +12,20 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (gci_amd/__init__.py says
 
 def _wake_the_gpu():
     """The HIP runtime's own start (driver, device, primary context: a few tenths of a second) on a thread of its own while the
-    interpreter imports numpy and the package -- through libgci_hip.so itself, the library every later call goes through (ctypes
-    releases the interpreter lock for the duration of a call).  Anything that goes wrong here is left for the ordinary path to
+    interpreter imports numpy and the rest of the package -- through libgci_hip.so itself, the library every later call goes through
+    (ctypes releases the interpreter lock for the duration of a call).  Anything that goes wrong here is left for the ordinary path to
     report."""
     try:
         import ctypes
-        here = os.path.dirname(os.path.abspath(__file__))
-        path = os.environ.get("GCI_LIB_PATH") or os.path.join(here, "gci_amd", "csrc", "libgci_hip.so")
-        if not os.path.isfile(path):
-            return
-        lib = ctypes.CDLL(path)
+        from gci_amd import _lib
+        lib = _lib.load()
         n = ctypes.c_int(0)
-        lib.gci_dev_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
-        lib.gci_dev_mem_info.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         if lib.gci_dev_count(ctypes.byref(n)) == 0 and n.value > 0:
             lib.gci_dev_mem_info(0, None, None)       # (the device's primary context)
             # a run over tens of GB of input says so to the library's arena now: its slabs are made here, beside the imports, not
             # one driver call at a time in the middle of the first file's ingestion (include/gci_hip.h: gci_dev_reserve)
             given = sum(os.path.getsize(a) for a in sys.argv[1:] if not a.startswith("-") and os.path.isfile(a))
             if given >= (4 << 30) and os.environ.get("GCI_RESERVE", "1") != "0":
-                lib.gci_dev_reserve.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
                 lib.gci_dev_reserve(0, min(64 << 30, given // 2), None)
     except Exception:                                 # noqa: BLE001
         pass
@@ -67,9 +61,24 @@ if __name__ == "__main__" and _a_single_gpu_run(sys.argv) and os.environ.get("GC
 
 from gci_amd.cli import main  # noqa: E402
 
+def _exit_trace():
+    """GCI_EXIT_TRACE=1 (tools/hwtests/exit_cost.py): wall-clock stamps on stderr when main() has returned, when the interpreter's
+    atexit handlers run and when the C library's do -- what the process does between its last output file and its end."""
+    import atexit
+    import ctypes
+    import time
+    sys.stderr.write("exit-trace main_returned %.6f\n" % time.time())
+    atexit.register(lambda: sys.stderr.write("exit-trace python_atexit %.6f\n" % time.time()))
+    cb = ctypes.CFUNCTYPE(None)(lambda: os.write(2, b"exit-trace libc_atexit %.6f\n" % time.time()))
+    _exit_trace.keep = cb
+    ctypes.CDLL(None).atexit(cb)
+
+
 if __name__ == "__main__":
     try:
         main(sys.argv)
+        if os.environ.get("GCI_EXIT_TRACE") == "1":
+            _exit_trace()
     finally:
         if _WAKER is not None:
             _WAKER.join(timeout=10.0)                 # (an early exit -- a refused argument -- does not leave while the runtime is starting)

@@ -164,11 +164,22 @@ class Workload:
                      "read through its record pages")
         self.k1 = k1
         self.pages = None
+        # The inflated record bytes (the heads stream, or the whole stream) and the record offsets STAY resident: they are the
+        # step's input ("inflated record bytes resident"), and laying them out as record pages -- the last step of the
+        # record walk, gci_bam_pages_size / _write -- is done INSIDE every step (round 6; rounds 3 - 5 made the pages once, in front
+        # of the clock).  pages_in_step = False keeps that older window (`n1_*` in the bench line: kernels over resident pages).
+        self.pages_in_step = False
+        self.keys_to_host = False
+        self.keys_host = None
+        self.in_stream, self.in_off, self.in_bytes = list(self.d_bam), list(self.d_off), list(self.stream_bytes)
         if k1 == "pages":
             self.pages = [eng.bam_pages(b, o, not heads) for b, o in zip(self.d_bam, self.d_off)]
             self.d_bam = [p.buf for p in self.pages]
             self.d_off = [torch.empty(max(n, 1), dtype=torch.int64, device=dev) for n in self.n_rec]   # K1 writes the name offsets
             self.stream_bytes = [int(p.buf.shape[0]) for p in self.pages]
+            self.pages_in_step = True
+        else:
+            self.in_stream = self.in_off = None
         self.name_delta = 0 if k1 == "pages" else 36
 
     def layout(self, own):
@@ -242,6 +253,15 @@ class Workload:
         for f in range(F):
             if self.pages is not None:
                 pg = self.pages[f]
+                if self.pages_in_step:
+                    # record pages from the resident record bytes, into the buffer the first build sized (the same input: the same size)
+                    h = (ctypes.c_uint64 * 3)()
+                    chk(lib.gci_bam_pages_size(ctx, _p(self.in_stream[f]), self.in_bytes[f], _p(self.in_off[f]), self.n_rec[f], int(not self.heads),
+                                               pg.page_bytes, h), "gci_bam_pages_size")
+                    if int(h[1]) != self.stream_bytes[f] or int(h[0]) != pg.n_pages:
+                        raise RuntimeError("bench: the record pages of file %d changed size between steps" % f)
+                    chk(lib.gci_bam_pages_write(ctx, _p(self.in_stream[f]), self.in_bytes[f], _p(self.in_off[f]), self.n_rec[f], int(not self.heads),
+                                                _p(pg.buf), int(h[1])), "gci_bam_pages_write")
                 chk(lib.gci_bam_filter_pages(ctx, _p(pg.buf), self.stream_bytes[f], pg.page_bytes, pg.n_pages, self.n_rec[f],
                                              _p(self.ref_sel), len(self.contigs), FILTER[0], FILTER[1], FILTER[2], FILTER[3],
                                              self.rec_base[f], _p(self.recs[f]), _p(self.d_off[f]), _p(self.status[f:f + 1])),
@@ -300,6 +320,13 @@ class Workload:
             import torch.distributed as dist
             # ONE integer all-reduce per step, in place: the sums of depth (global mean depth = their total / bases)
             all_reduce(self.sums, dist.ReduceOp.SUM)
+        self._keys_home()
+
+    def _keys_home(self):
+        """The issue-run boundaries of the step on the HOST ("... and issue intervals on host"): count, then the keys."""
+        if self.keys_to_host:
+            n = int(self.nkeys.item())
+            self.keys_host = self.keys[:min(n, int(self.keys.shape[0]))].cpu()
 
     def _step_sharded(self):
         """Strong scaling: records of this rank's contigs -> by name hash to the rank that owns the name (two all-to-alls per
@@ -319,6 +346,7 @@ class Workload:
         chk(lib.gci_depth_build_finish(ctx, _p(self.track), _p(self.text), int(self.text.shape[0])), "gci_depth_build_finish")
         self.torch.sum(self.sums, dim=0, keepdim=True, out=self.sum_total)
         all_reduce(self.sum_total, dist.ReduceOp.SUM)      # the genome-wide sum of depth: ONE integer all-reduce per step
+        self._keys_home()
 
     def check(self):
         """Record-level status of the last step + output capacities; False when a name is shared between ranks."""
@@ -358,7 +386,9 @@ class Workload:
         k1 = int(self.algo.get("k1_bytes", 0)) + 32 * self.total_rec
         join = 16 * self.n_rec[0] + 48 * sum(self.n_rec[1:]) + 16 * K
         build = 28 * K + 4 * L + T
-        return {"k1_record_filter": k1, "name_join": join, "depth_build_text": build, "total": k1 + join + build,
+        # record pages inside the step: the record bytes read once, the pages written once
+        pages = (int(sum(self.in_bytes)) + int(sum(self.stream_bytes))) if (self.pages_in_step and self.pages is not None) else 0
+        return {"record_pages": pages, "k1_record_filter": k1, "name_join": join, "depth_build_text": build, "total": pages + k1 + join + build,
                 "intervals": K, "bases": L, "text_bytes": T}
 
 
@@ -1341,9 +1371,12 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
         od, ph = os.path.join(tmp, "out"), os.path.join(tmp, "phases.json")
         env = dict(os.environ, GCI_PHASES=ph, PYTHONPATH=ROOT)
         cmd = [sys.executable, os.path.join(ROOT, "GCI.py"), "-r", fa, "--hifi"] + bams + ["-d", od, "-t", str(hostio.default_threads())]
-        # Twice: the files have just been written (by sixteen processes, into tmpfs), and the first pass of anything over freshly
-        # written page-cache pages is slower than every later one (the staging threads get 13 GB/s out of them instead of 30: the
-        # kernel's first-access bookkeeping per page, nothing of this program's) -- both are reported, the second is `seconds`.
+        # Twice: the files have just been written (by sixteen processes, into tmpfs), and the first pass of ANY process over freshly
+        # written tmpfs pages is slower than every later one -- measured in round 6 (profiles/r06b_first_pass_experiments.txt): `cat`
+        # of the fresh files to /dev/null runs at 13 GB/s, and a command line started behind that `cat` is as fast as a second pass
+        # (1.59 s against 3.8 s at 0.3 of the genome); pread() instead of the mapping changes nothing (3.9 s).  The kernel's first
+        # read access to a page it has only ever written, nothing of this program's.  Both are reported, the second is `seconds`;
+        # a user whose BAM has just been written by samtools onto tmpfs sees the first.
         # (a pass gets three minutes: on a host whose other tenants keep its cores and its page cache busy a pass has been seen to
         # take a quarter of an hour, nearly all of it in front of and behind this program's own phases -- such a pass is given up,
         # said so, and the next one measured)
@@ -1394,7 +1427,7 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
             ok = ok and got_rows.get(c) == want_rows[c] and len(want_rows[c]) == 1
         outputs = {fn: os.path.getsize(os.path.join(od, fn)) for fn in sorted(os.listdir(od))}
         aligned = inp.aligned_bases
-        serial = ("process start (interpreter, import torch; the HIP runtime starts beside it); the table of the beginning of the first "
+        serial = ("process start (interpreter, numpy; the HIP runtime starts beside it -- no torch in this process); the table of the beginning of the first "
                   "file and the upload of its first run; after the last byte of the last file: join -> depth build -> .depth.gz "
                   "members -> D2H -> file writes.  Everything else -- the assembly's N scan, the rest of the member tables, every "
                   "later upload, the record walk, pages and filter of a run -- runs beside the inflate kernel")
@@ -1403,8 +1436,8 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
                 "seconds_in_front_of_the_phase_log": rep["notes"].get("process_age_s_when_the_phase_clock_started"),
                 "seconds_behind_the_phase_report": (wall - rep["notes"]["process_age_s_at_the_report"]) if "process_age_s_at_the_report" in rep["notes"] else None,
                 "first_pass_phases_wall_s": {k: round(v, 4) for k, v in reps[0]["wall_s"].items() if v >= 0.05},
-                "process": "python GCI.py (a process of its own: interpreter, "
-                "import torch, HIP context and library load are inside the wall time)",
+                "process": "python GCI.py (a process of its own: interpreter, imports, HIP context and library load are inside the wall "
+                           "time; it holds its HBM buffers itself -- gci_amd/hbm.py -- and ends through the interpreter's ordinary exit)",
                 "startup_seconds_outside_the_phase_log": wall - rep["total_s"],
                 "phases_wall_s": {k: round(v, 4) for k, v in rep["wall_s"].items()},
                 "phases_device_s": {k: round(v, 4) for k, v in rep["gpu_s"].items()},
@@ -1724,6 +1757,10 @@ def main():
                 with torch.cuda.stream(st):
                     w_k.step()
 
+    # The window of `value` (with the inputs in HBM as the bench contract wants them): inflated record bytes resident
+    # on the device -> record pages -> K1 -> join -> depth build (+ decimal text) -> the issue-run boundaries on the host.
+    for _, w_k, _ in [(eng, w, None)]:
+        w_k.keys_to_host = not two_type
     for _ in range(max(1, args.warmup)):
         w.step()
     fence()
@@ -1798,6 +1835,19 @@ def main():
         w.step()
     breakdown = {k: round(ms / n * 1e3, 2) for k, (ms, n) in eng.profile_read(reset=True).items()}   # us / launch
     eng.profile_enable(0)
+    # number (1) of SURVEY 8(d) as rounds 3 - 5 reported it as `value`: the kernels alone over record pages made in front of the clock,
+    # nothing copied to the host inside the step
+    n1_ms = None
+    if world == 1 and not two_type and getattr(w, "pages_in_step", False):
+        w.pages_in_step, w.keys_to_host = False, False
+        w.step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            w.step()
+        fence()
+        n1_ms = (time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3
+        w.pages_in_step, w.keys_to_host = True, True
     fill_gbs = None
     if world == 1 and rank == 0 and algo_bytes > 0:
         try:
@@ -1827,7 +1877,14 @@ def main():
                                 + ("heads stream (records without SEQ / QUAL)" if w.heads else "whole inflated stream") + (")" if w.pages else ""),
                    "input_bytes_per_gpu": w.stream_bytes, "parallelism": "contig-sharded x%d" % world,
                    "steps_in_flight": len(lanes),
-                   "value_is": "SURVEY 8(d) number (1): kernels only, record pages already resident in HBM; numbers (2) and (3) in survey_8d",
+                   "value_is": ("SURVEY 8(d)'s window with the inputs resident in HBM: inflated record bytes (heads streams + record offsets) on the "
+                                "device -> record pages (gci_bam_pages_*) -> K1 -> join -> depth build + decimal text -> issue-run boundaries "
+                                "copied to the host, all inside every timed step; n1_* = the kernels alone over pages made in front of the "
+                                "clock (what rounds 3 - 5 reported as value), n2_* = the same window with the record bytes coming from pinned "
+                                "host memory (PCIe inside), n3_* = the command line on BGZF files" if getattr(w, "pages_in_step", False) else
+                                "kernels only over resident inputs"),
+                   "n1_kernels_only_ms_per_step": n1_ms,
+                   "n1_kernels_only_gbases_per_s": (aligned_total / (n1_ms * 1e-3) / 1e9) if n1_ms else None,
                    "workload_generated": "once, by rank 0" if (world > 1 and os.environ.get("GCI_BENCH_SHARED")) else "by every rank" if world > 1 else "in this process",
                    "join": ("sharded by name hash: per file one all-to-all of 32-byte records and one of 48-byte name slots, then one of "
                             "16-byte intervals to the owners of their contigs; %d bytes leave this rank per step" % w.sj.bytes_per_step()
@@ -1891,7 +1948,7 @@ def main():
             if not ok:
                 print(json.dumps(out))
                 sys.exit("PARITY FAILURE: GPU result differs from the oracle at full size")
-            survey = {"1_kernels_only_gbases_per_s": out["value"]}
+            survey = {"1_kernels_only_gbases_per_s": out["config"]["n1_kernels_only_gbases_per_s"], "value_window_gbases_per_s": out["value"]}
             if not args.no_e2e and args.inflight == 1:
                 out["two_steps_in_flight"] = two_in_flight(eng, w, args, device_index)
             if not args.only_step:
@@ -1915,7 +1972,8 @@ def main():
                     "value": aligned_total / c["seconds"] / 1e9, "unit": "Gbases/s", "cores": c["cores"], "kind": "port", "port": "libgci_cpu",
                     "sample": "100 %%: the whole workload (both files, all %d contigs) through libgci_cpu.so -- include/gci_hip.h compiled by g++ "
                               "for host memory and host threads -- on %d threads (os.cpu_count() = %s), %.2f s wall: %s; its depth track equals "
-                              "the GPU's base for base" % (len(w.inp.names), c["cores"], c["os_cpu_count"], c["seconds"],
+                              "the GPU's base for base.  It starts from the inflated record bytes in host memory (NO BGZF inflate): comparable with "
+                              "`value`, n1 and n2 -- not with n3, the command line, which also inflates the files" % (len(w.inp.names), c["cores"], c["os_cpu_count"], c["seconds"],
                                                            ", ".join("%s %.2f" % kv for kv in c["stages_s"].items())),
                     "equal_to_the_gpu_track": c.get("equal_to_the_gpu_track"),
                     "oracle_port_on_a_sample": {
@@ -1949,17 +2007,22 @@ def main():
                     torch.cuda.empty_cache()
                     survey["3b_ingest_genome"] = ingest_number(args.coverage, args.ingest_gb)
             out["survey_8d"] = survey
-            # the three numbers of SURVEY 8(d) where the driver's record keeps them (it stores `config` whole)
+            # the numbers of SURVEY 8(d) as FLAT SCALARS of `config` (the driver's record keeps scalars of config, not nested objects)
             g3 = survey.get("3_command_line_genome") or {}
             p2 = survey.get("2_device_pipeline_incl_h2d_d2h") or {}
-            out["config"]["survey_8d"] = {
-                "1_kernels_only_gbases_per_s": out["value"],
-                "2_device_pipeline_gbases_per_s": p2.get("gbases_per_s"), "2_device_pipeline_s": p2.get("seconds"),
-                "3_command_line_genome_s": g3.get("seconds"), "3_first_pass_s": g3.get("seconds_first_pass_over_freshly_written_files"),
-                "3_command_line_genome_gbases_per_s": g3.get("gbases_per_s"),
-                "3_inflate_crc_device_s": (g3.get("phases_device_s") or {}).get("bgzf_inflate + crc"),
-                "3_first_inflate_call_s": (g3.get("phases_device_first_call_s") or {}).get("bgzf_inflate + crc"),
-                "3_parity": g3.get("parity")}
+            cfg = out["config"]
+            cfg["n2_device_pipeline_gbases_per_s"] = p2.get("gbases_per_s")
+            cfg["n2_device_pipeline_s"] = p2.get("seconds")
+            cfg["n3_cli_genome_s"] = g3.get("seconds")
+            cfg["n3_cli_genome_gbases_per_s"] = g3.get("gbases_per_s")
+            cfg["n3_cli_first_pass_s"] = g3.get("seconds_first_pass_over_freshly_written_files")
+            cfg["n3_inflate_device_s"] = (g3.get("phases_device_s") or {}).get("bgzf_inflate + crc")
+            cfg["n3_first_inflate_call_s"] = (g3.get("phases_device_first_call_s") or {}).get("bgzf_inflate + crc")
+            cfg["n3_start_s"] = g3.get("startup_seconds_outside_the_phase_log")
+            cfg["n3_exit_s"] = g3.get("seconds_behind_the_phase_report")
+            cfg["n3_bgzf_gb"] = (g3.get("bgzf_bytes") or 0) / 1e9 if g3 else None
+            cfg["n3_parity"] = g3.get("parity")
+            cfg["cpu_baseline_excludes"] = "BGZF inflate: libgci_cpu.so starts from the inflated record bytes in host memory, as n1 / value / n2 do -- not comparable with n3"
         elif not args.no_cpu_baseline:
             cdt, depths, bed, text, mean = cpu_baseline_chr19(w)
             out["cpu_baseline"] = {"value": w.aligned_bases / cdt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",

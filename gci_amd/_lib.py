@@ -181,13 +181,44 @@ EXPORTS = [
 _lib = None
 
 
+def _one_hip_runtime() -> None:
+    """libgci_hip.so is linked against the system's libamdhip64; a torch wheel brings a copy of its own and loads THAT one by path.
+    A process that ends up with both (this library first, `import torch` later: a test session, GCI_HBM=torch, an embedding
+    application) has two runtimes, and the second finds no device.  So when a torch installation is present, its copy of the
+    runtime is mapped first -- found through the module spec, torch itself is NOT imported (a few ms) -- and this library's
+    DT_NEEDED entry resolves to it by soname: one runtime whoever comes first.  GCI_HIP_RUNTIME=system skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("GCI_HIP_RUNTIME") == "system" or os.environ.get("GCI_HOST_ONLY") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        path = spec and spec.origin and os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if path and os.path.isfile(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:                                      # noqa: BLE001  (no torch, an unusual layout: the system's runtime)
+        pass
+
+
+_load_lock = __import__("threading").Lock()
+
+
 def load() -> ctypes.CDLL:
     """Load the library and bind every export; raises if the .so or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        return _load_locked()
+
+
+def _load_locked() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise GciError(GCI_E_INVALID, "libgci_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        _one_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         # GCI_HOST_ONLY=1: a build of the host-side entry points alone (host_io.cpp through g++ with the sanitizers,
         # tools/asan_host.sh): the device exports are absent, nothing that needs them can run

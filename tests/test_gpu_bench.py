@@ -36,8 +36,17 @@ def test_bench_line_contract():
     assert cb["unit"] == "Gbases/s" and cb["sample"].startswith("100 %") and cb["equal_to_the_gpu_track"] is True
     assert cb["oracle_port_on_a_sample"]["value"] > 0
     assert d["parity_vs_oracle_full_size"] is True
-    s8 = d["survey_8d"]
-    assert s8["1_kernels_only_gbases_per_s"] == d["value"]
+    s8, cfg = d["survey_8d"], d["config"]
+    # `value` is SURVEY 8(d)'s window with the inputs resident in HBM (record pages made, keys copied home inside every step); the
+    # kernels-only figure of rounds 3 - 5 and the numbers (2) / (3) are FLAT SCALARS of config (the driver's record keeps those)
+    assert "record pages" in cfg["value_is"] and cfg["n1_kernels_only_gbases_per_s"] >= d["value"] > 0
+    assert s8["1_kernels_only_gbases_per_s"] == cfg["n1_kernels_only_gbases_per_s"] and s8["value_window_gbases_per_s"] == d["value"]
+    for k in ("n1_kernels_only_ms_per_step", "n2_device_pipeline_gbases_per_s", "n2_device_pipeline_s", "n3_cli_genome_s", "n3_cli_genome_gbases_per_s",
+              "n3_cli_first_pass_s", "n3_inflate_device_s", "n3_first_inflate_call_s", "n3_start_s", "n3_exit_s", "n3_bgzf_gb"):
+        assert isinstance(cfg[k], (int, float)) and cfg[k] > 0, k
+    assert cfg["n3_parity"] is True and "inflate" in cfg["cpu_baseline_excludes"] and "NO BGZF inflate" in d["cpu_baseline"]["sample"]
+    assert d["step_roofline"]["algorithmic_bytes_per_step"]["record_pages"] > 0
+    assert cfg["n3_start_s"] < 1.0                 # (a process that does not import torch)
     assert s8["2_device_pipeline_incl_h2d_d2h"]["seconds"] > 0 and s8["3_command_line_chr19_realistic_bam"]["seconds"] > 0
     g = s8["3_command_line_genome"]              # the command line as a process of its own on the two BGZF files of the workload
     assert g["parity"] is True and len(g["parity_vs_oracle_on_contigs"]) >= 3 and g["seconds"] > 0
