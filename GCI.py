@@ -22,11 +22,6 @@ def _wake_the_gpu():
         n = ctypes.c_int(0)
         if lib.gci_dev_count(ctypes.byref(n)) == 0 and n.value > 0:
             lib.gci_dev_mem_info(0, None, None)       # (the device's primary context)
-            # a run over tens of GB of input says so to the library's arena now: its slabs are made here, beside the imports, not
-            # one driver call at a time in the middle of the first file's ingestion (include/gci_hip.h: gci_dev_reserve)
-            given = sum(os.path.getsize(a) for a in sys.argv[1:] if not a.startswith("-") and os.path.isfile(a))
-            if given >= (4 << 30) and os.environ.get("GCI_RESERVE", "1") != "0":
-                lib.gci_dev_reserve(0, min(64 << 30, given // 2), None)
     except Exception:                                 # noqa: BLE001
         pass
 

@@ -323,6 +323,7 @@ def _main_single(argv, ctx):
         _run(args, ctx)
     finally:
         if phase_file and (ctx is None or ctx.root):
+            pipeline.note_device_memory()
             phases.report(phase_file)
             phases.stop()
 

@@ -7,13 +7,17 @@
 #include <mutex>
 #include <unordered_map>
 
-// ---- the arena: every device allocation of this library (its contexts' scratch, gci_malloc, gci_dev_malloc) is cut from a few large
-// slabs, so that a run makes a handful of hipMalloc calls -- all of them before or between its phases -- instead of forty in the
-// middle of its first inflate.  hipMalloc is a driver call that takes the process's address-space locks: 0.3 ms on an idle process,
-// 44 ms each beside a pinned copy with a dozen threads faulting a file mapping in (round 5: the 1 - 2 s "stall at the head of the
-// first file" on a third of the boxes, profiles/r05j2).  A slab is never given back while the process lives (hipFree synchronises
-// the device); blocks are 4 KiB granular, best fit, neighbours coalesced.  GCI_ARENA=0: straight hipMalloc / hipFree.
-// GCI_ARENA_SLAB_GB (default 16): the size of a slab; a larger request gets a slab of its own size.
+// ---- the arena: the many small and medium device allocations of this library (its contexts' scratch tables, status words, record
+// buffers; gci_malloc, gci_dev_malloc) are cut from slabs, so that a run makes tens of driver calls instead of hundreds.  What a
+// driver allocation costs on this chip is not the call but the MEMORY: the kernel driver hands out VRAM it knows to be clean, and
+// clears what it does not -- measured 35 - 45 ms per GB (tools/hwtests/reserve_timing.py: 16 GB 0.56 s, 64 GB 2.8 s; ~0 when the
+// blocks were wiped when a previous process released them).  So nothing is reserved ahead of need (a 64 GB reservation at the start
+// of the genome-size command line cost it 2.8 s: profiles/r06c), slabs stay small (256 MiB growing to GCI_ARENA_SLAB_MB, 1024: at
+// most ~40 ms under the arena's lock), a request of ARENA_DIRECT (64 MiB) or more that no free block fits becomes a slab of exactly
+// its size, made OUTSIDE the lock, and -- the point of the arena at genome size -- memory that one phase of a run gives back is
+// what the next phase is cut from: blocks coalesce, the ingestion's 8 GB buffers become the depth track without the driver (and its
+// clearing) being asked again.  A slab is never returned while the process lives.  Blocks are 4 KiB granular, best fit.
+// GCI_ARENA=0: straight hipMalloc / hipFree.
 namespace {
 struct Arena {
     std::mutex mu;
@@ -26,8 +30,9 @@ struct Arena {
 };
 Arena g_arena[16];
 const bool g_arena_on = [] { const char* e = getenv("GCI_ARENA"); return !(e && e[0] == '0'); }();
-const size_t g_slab_bytes = [] { const char* e = getenv("GCI_ARENA_SLAB_GB"); const long v = e ? atol(e) : 16; return (size_t)(v < 1 ? 1 : v) << 30; }();
+const size_t g_slab_bytes = [] { const char* e = getenv("GCI_ARENA_SLAB_MB"); const long v = e ? atol(e) : 1024; return (size_t)(v < 256 ? 256 : v) << 20; }();
 constexpr size_t ARENA_GRAIN = 4096;
+constexpr size_t ARENA_DIRECT = (size_t)64 << 20;
 
 void arena_erase_free(Arena& a, uintptr_t addr, size_t size)
 {
@@ -49,8 +54,7 @@ hipError_t arena_add_slab(Arena& a, int device, size_t at_least)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return e;
-    // slabs grow geometrically -- 256 MiB, 1 GiB, 4 GiB, ... up to GCI_ARENA_SLAB_GB -- so that a small run (a test, chr19) holds
-    // little; a run that knows it will need tens of GB says so up front (gci_dev_reserve)
+    // slabs for the small and medium blocks: 256 MiB, then GCI_ARENA_SLAB_MB (1 GiB)
     size_t step = a.slabs.empty() ? ((size_t)256 << 20) : a.slabs.back().size * 4;
     if (step > g_slab_bytes) step = g_slab_bytes;
     if (step < ((size_t)256 << 20)) step = (size_t)256 << 20;
@@ -76,8 +80,24 @@ hipError_t gci_dmalloc(int device, void** out, size_t bytes)
     if (!g_arena_on) { hipError_t e = hipSetDevice(device); return e != hipSuccess ? e : hipMalloc(out, bytes ? bytes : 16); }
     const size_t need = (bytes + ARENA_GRAIN - 1) / ARENA_GRAIN * ARENA_GRAIN + (bytes ? 0 : ARENA_GRAIN);
     Arena& a = g_arena[device];
-    std::lock_guard<std::mutex> lock(a.mu);
+    std::unique_lock<std::mutex> lock(a.mu);
     auto it = a.free_by_size.lower_bound(need);
+    if (it == a.free_by_size.end() && need >= ARENA_DIRECT) {
+        // a large block nothing free can hold: a slab of exactly its size, made without the lock (the driver may take 40 ms per GB)
+        lock.unlock();
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        void* p = nullptr;
+        e = hipMalloc(&p, need);
+        if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+        lock.lock();
+        a.slabs.push_back({(uintptr_t)p, need});
+        a.reserved += need;
+        a.live[(uintptr_t)p] = need;
+        a.in_use += need;
+        *out = p;
+        return hipSuccess;
+    }
     if (it == a.free_by_size.end()) {
         hipError_t e = arena_add_slab(a, device, need);
         if (e != hipSuccess) return e;
@@ -186,8 +206,9 @@ int gci_dev_free(int device, void* d_ptr)
     if (d_ptr) DEVCHK(gci_dfree(d_ptr));
     return GCI_OK;
 }
-// Slabs for at least `bytes` in all (what a run expects to hold at once), made now -- by the command line's waker thread, beside the
-// interpreter's imports -- rather than piece by piece when the buffers are first asked for.  *reserved_out: the arena's slabs after it.
+// Slabs for at least `bytes` in all, made now (one driver allocation for what is missing -- at the driver's 35 - 45 ms per GB of
+// memory it has to clear).  For a host that wants the cost in a place of its choosing; the command line does not use it.
+// *reserved_out: the arena's slabs after it.
 int gci_dev_reserve(int device, uint64_t bytes, uint64_t* reserved_out)
 {
     if (device < 0 || device >= 16) return GCI_E_INVALID;

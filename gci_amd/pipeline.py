@@ -51,6 +51,20 @@ def default_engine() -> Engine:
         return _ENGINE
 
 
+def note_device_memory() -> None:
+    """Into the phase log: what the process took from the driver (the arena's slabs: include/gci_hip.h gci_dev_arena_info) and what of it
+    is handed out at the end of the run -- a driver allocation costs by the GB on this chip, so this is a number to keep small."""
+    if _ENGINE is None or not phases.on():
+        return
+    try:
+        r, u, n = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        _ENGINE.lib.gci_dev_arena_info(_ENGINE.device.index or 0, ctypes.byref(r), ctypes.byref(u), ctypes.byref(n))
+        phases.note("device_memory", {"provider": _ENGINE.T.name, "arena_slab_bytes": int(r.value), "arena_bytes_handed_out": int(u.value),
+                                      "arena_slabs": int(n.value), "pool_bytes_held": int(hbm.memory_held(_ENGINE.device.index or 0)) if _ENGINE.T.name == "native" else None})
+    except Exception:                                      # noqa: BLE001  (a note, not a result)
+        pass
+
+
 def _slice_bound(v: int, L: int) -> int:
     if v < 0:
         return max(v + L, 0)
@@ -968,6 +982,14 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     targets = list(targets_length.keys())
     tindex = {t: i for i, t in enumerate(targets)}
     filt = (map_qual, mq_cutoff, clip_percent, iden_percent)
+    # The depth track is asked for NOW, while the first file is still being ingested on its helper thread (this thread would only
+    # wait for it): a driver allocation costs by the GB on this chip -- the kernel driver clears VRAM it does not know to be clean,
+    # 35 - 45 ms per GB (tools/hwtests/reserve_timing.py) -- and the 12.5 GB of a human genome's track, asked for behind the last
+    # file's last byte, were half a second of the command line with nothing beside them.
+    early_track = None
+    total_elems = sum((int(targets_length[t]) + _lib.GCI_TILE - 1) // _lib.GCI_TILE * _lib.GCI_TILE for t in targets)
+    if total_elems >= (1 << 26) and os.environ.get("GCI_EARLY_TRACK", "1") != "0":
+        early_track = engine.T.empty(max(total_elems, 1), engine.T.int32, engine.device)
     # the first file may have been started on already (start_ingest_ahead): its helper thread owns this context until it is done
     first_ahead = None
     for path in [p for p in _INGEST_AHEAD if p != bam_files[0]] + ([bam_files[0]] if bam_files[0] in _INGEST_AHEAD else []):
@@ -1013,7 +1035,7 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
             ivl, count = engine.name_join(inputs, ovlp_percent, count_flank=flank_len)     # + the build's counting pass
     except GciError as e:
         _reraise_like_reference(e)
-    track = engine.new_track()
+    track = early_track if (early_track is not None and int(early_track.shape[0]) == max(engine.total, 1)) else engine.new_track()
     text_on_device = bool(write) and DEPTH_GZ != "gpu"
     with phases.wall("depth_build"), phases.gpu("depth build"):
         fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=text_on_device, want_sums=True,

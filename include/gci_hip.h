@@ -142,11 +142,13 @@ const char* gci_dev_last_error(void);
 int gci_dev_count(int* n_out);
 int gci_dev_malloc(int device, size_t bytes, void** d_out);
 int gci_dev_free(int device, void* d_ptr);
-/* Device memory of this library -- gci_dev_malloc, gci_malloc and every context's scratch -- is cut from an ARENA of large slabs
- * (k_hbm.hip): a run makes a handful of hipMalloc calls instead of one per buffer, none of them in the middle of its ingestion
- * (a driver allocation beside a pinned copy and a dozen threads faulting a file in was measured at 44 ms instead of 0.3).  Slabs
- * grow 256 MiB, 1 GiB, 4 GiB ... up to GCI_ARENA_SLAB_GB (16) and stay until the process ends; GCI_ARENA=0 turns the arena off.
- * gci_dev_reserve: slabs for at least `bytes` in all, now (a host that knows its inputs are tens of GB calls this before it starts).
+/* Device memory of this library -- gci_dev_malloc, gci_malloc and every context's scratch -- comes from an ARENA (k_hbm.hip): small
+ * and medium blocks are cut from slabs (256 MiB, then GCI_ARENA_SLAB_MB = 1024 each), a block of 64 MiB or more that nothing free
+ * can hold is a driver allocation of its own, and whatever is given back coalesces and serves later requests -- the memory of one
+ * phase of a run becomes the next phase's without the driver being asked again.  That matters because a driver allocation costs by
+ * the GB on this chip (the kernel driver clears VRAM it does not know to be clean: 35 - 45 ms per GB measured).  Slabs stay until
+ * the process ends; GCI_ARENA=0 turns the arena off.
+ * gci_dev_reserve: slabs for at least `bytes` in all, now (for a host that wants that cost in a place of its choosing).
  * gci_dev_arena_info: bytes in slabs, bytes handed out, number of slabs. */
 int gci_dev_reserve(int device, uint64_t bytes, uint64_t* reserved_out);
 int gci_dev_arena_info(int device, uint64_t* reserved, uint64_t* in_use, uint32_t* n_slabs);

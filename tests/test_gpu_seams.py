@@ -816,8 +816,8 @@ def test_gzip_members_from_the_run_lists_the_build_keeps(engine):
         engine.depth_deflate(track, from_build=True)
     assert [bytes(b) for b in engine.depth_deflate(track)] == want
     # ... then with flanks
+    engine.depth_build(ivl, None, 15, plain)                        # (first: any build through this context drops the lists of the one before)
     engine.depth_build_fused(ivl, None, 15, track, want_text=False, want_runs=True)
-    engine.depth_build(ivl, None, 15, plain)
     assert torch.equal(track, plain)
     assert [bytes(b) for b in engine.depth_deflate(track, from_build=True)] == [bytes(b) for b in engine.depth_deflate(plain)]
     # the lists are never taken on a pointer match alone: a write the context cannot see -- another context's gap
