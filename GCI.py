@@ -57,22 +57,21 @@ if __name__ == "__main__" and _a_single_gpu_run(sys.argv) and os.environ.get("GC
 from gci_amd.cli import main  # noqa: E402
 
 def _exit_trace():
-    """GCI_EXIT_TRACE=1 (tools/hwtests/exit_cost.py): wall-clock stamps on stderr when main() has returned, when the interpreter's
-    atexit handlers run and when the C library's do -- what the process does between its last output file and its end."""
+    """GCI_EXIT_TRACE=<path of tools/hwtests/exit_stamp.c built as a shared library> (tools/hwtests/exit_cost.py): wall-clock stamps on
+    stderr when main() has returned, when the interpreter's atexit handlers run and -- from that library, loaded here, i.e. behind the
+    HIP runtime -- when the C library's handlers start: what the process does between its last output file and its end."""
     import atexit
     import ctypes
     import time
     sys.stderr.write("exit-trace main_returned %.6f\n" % time.time())
     atexit.register(lambda: sys.stderr.write("exit-trace python_atexit %.6f\n" % time.time()))
-    cb = ctypes.CFUNCTYPE(None)(lambda: os.write(2, b"exit-trace libc_atexit %.6f\n" % time.time()))
-    _exit_trace.keep = cb
-    ctypes.CDLL(None).atexit(cb)
+    ctypes.CDLL(os.environ["GCI_EXIT_TRACE"])
 
 
 if __name__ == "__main__":
     try:
         main(sys.argv)
-        if os.environ.get("GCI_EXIT_TRACE") == "1":
+        if os.environ.get("GCI_EXIT_TRACE"):
             _exit_trace()
     finally:
         if _WAKER is not None:

@@ -334,8 +334,8 @@ class Workload:
         import torch.distributed as dist
         from gci_amd.device import JoinInput
         eng, lib, ctx, chk, sj = self.eng, self.eng.lib, self.eng.ctx, self.eng._chk, self.sj
-        inputs = [sj.exchange_file(f, JoinInput(self.recs[f][:self.n_rec[f]], self.d_bam[f], self.d_off[f], self.name_delta))
-                  for f in range(self.n_files)]
+        inputs = sj.exchange_files([JoinInput(self.recs[f][:self.n_rec[f]], self.d_bam[f], self.d_off[f], self.name_delta)
+                                    for f in range(self.n_files)])
         ivl, n_slots = sj.join(inputs, OVLP)
         self.ivl_in_build, self.count_in_build = ivl, None
         o = self.opts
@@ -1886,8 +1886,10 @@ def main():
                    "n1_kernels_only_ms_per_step": n1_ms,
                    "n1_kernels_only_gbases_per_s": (aligned_total / (n1_ms * 1e-3) / 1e9) if n1_ms else None,
                    "workload_generated": "once, by rank 0" if (world > 1 and os.environ.get("GCI_BENCH_SHARED")) else "by every rank" if world > 1 else "in this process",
-                   "join": ("sharded by name hash: per file one all-to-all of 32-byte records and one of 48-byte name slots, then one of "
-                            "16-byte intervals to the owners of their contigs; %d bytes leave this rank per step" % w.sj.bytes_per_step()
+                   "collectives_per_step": (3 if w.sharded else None),
+                   "join": ("sharded by name hash: ONE all-to-all of the 32-byte records and 48-byte name slots of every file, one of the "
+                            "16-byte intervals to the owners of their contigs, one all-reduce of the sum of depth (3 collectives per step, "
+                            "whatever the number of files); %d bytes leave this rank per step" % w.sj.bytes_per_step()
                             if w.sharded else "local" if not w.exchange else
                             "local, validated by the exact cross-rank name check (hash all-to-all)" if not w.replicated_steps else
                             "replicated (all-gather of records + names)")},
@@ -1912,7 +1914,7 @@ def main():
                 sys.exit("PARITY FAILURE: the multi-rank result differs from the oracle over all ranks' files")
     if forced:
         out["config"]["collectives"] = {"backend": args.backend, "world": 1, "executed_per_step": (
-            "all_to_all_single x %d (records + name slots per file, intervals) + all_reduce of the sum of depth" % (2 * w.n_files + 1)
+            "all_to_all_single x 2 (records + name slots of all files in one, intervals) + all_reduce of the sum of depth"
             if w.sharded else "all_to_all_single (name-check hashes) + all_reduce of the per-contig sums"
             + (" + all_gather_into_tensor x 3 per file (replicated join)" if w.replicated_steps else ""))}
         out["cpu_baseline"] = None

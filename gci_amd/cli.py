@@ -266,22 +266,65 @@ def _split_gpus(argv: Sequence[str]) -> Tuple[List[str], int]:
     return out, n
 
 
+def _spawn_ranks(n: int, entry: str, args: Sequence[str]) -> int:
+    """`GCI.py --gpus N`: N copies of the command line, one per GPU, started directly with the environment torch.distributed's
+    env:// rendezvous reads (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) -- what `python -m torch.distributed.run` sets up,
+    without its launcher process importing torch and its elastic agent standing between the shell and the ranks (round 5 re-executed
+    itself under it: one more `import torch` + rendezvous store in front of every rank's own).  This process imports nothing heavy,
+    waits for the ranks, ends the others when one fails, and leaves with rank 0's status.  GCI_LAUNCHER=torchrun keeps the old way."""
+    import subprocess
+    import time
+    port = int(os.environ.get("MASTER_PORT", str(29600 + os.getpid() % 2000)))
+    if os.environ.get("GCI_LAUNCHER") == "torchrun":
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), entry] + list(args))
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                GCI_LAUNCHED_AT="%.6f" % time.time())
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # (the host driver shares device memory between processes by dmabuf only)
+    base.setdefault("OMP_NUM_THREADS", "1")                          # (as torch.distributed.run: N ranks do not each take every core)
+    procs = [subprocess.Popen([sys.executable, entry] + list(args), env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    status = [None] * n
+    try:
+        while any(s is None for s in status):
+            for r, p in enumerate(procs):
+                if status[r] is None:
+                    status[r] = p.poll()
+            bad = [s for s in status if s not in (None, 0)]
+            if bad:                                                  # one rank failed: the others would wait in a collective for ever
+                for r, p in enumerate(procs):
+                    if status[r] is None:
+                        p.terminate()
+                for r, p in enumerate(procs):
+                    if status[r] is None:
+                        try:
+                            status[r] = p.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            status[r] = p.wait()
+                return status[0] if status[0] not in (None, 0) and status[0] > 0 else (bad[0] if bad[0] > 0 else 1)
+            time.sleep(0.005)
+    except KeyboardInterrupt:
+        for p in procs:
+            p.terminate()
+        raise
+    return status[0] or 0
+
+
 def main(argv=None):
-    """`python GCI.py ...` as the reference; `--gpus N` (or a launch under torch.distributed.run) shards the contigs over
-    N GPUs of one node, one process per GPU: rank 0 prints and writes what a single process would."""
+    """`python GCI.py ...` as the reference; `--gpus N` (this process then starts N ranks of itself: _spawn_ranks) or a launch under
+    torch.distributed.run shards the contigs over N GPUs of one node, one process per GPU: rank 0 prints and writes what a single
+    process would."""
     argv = sys.argv if argv is None else argv
     argv, gpus = _split_gpus(list(argv))
     # A contig-sharded run is opted into: by --gpus, or by a launch under torch.distributed.run (which sets RANK, LOCAL_RANK and
     # MASTER_ADDR for every process) -- a WORLD_SIZE left in the environment by a scheduler does not make one.
     launched = all(k in os.environ for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR"))
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
-    if gpus > 1 and world == 1:                                      # re-launch, one process per GPU
-        port = 29600 + os.getpid() % 2000
+    if gpus > 1 and world == 1:                                      # start the ranks, one process per GPU
         entry = os.path.abspath(argv[0])
         if not os.path.isfile(entry) or os.path.basename(entry) == "cli.py":     # (started as `python -m gci_amd.cli`)
             entry = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "GCI.py")
-        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-                                   "--master-addr", "127.0.0.1", "--master-port", str(port), entry] + argv[1:])
+        sys.exit(_spawn_ranks(gpus, entry, argv[1:]))
     if world > 1 or (launched and os.environ.get("GCI_FORCE_SHARDED", "0") == "1"):
         from . import shard
         ctx = shard.Context()
@@ -330,8 +373,15 @@ def _main_single(argv, ctx):
 
 def _run(args, ctx):
     if ctx is not None:
+        import time
         import torch.distributed as dist
+        t0 = time.perf_counter()
         ctx.init()
+        # what a rank spends before its first kernel (VERDICT r05 "next" 4b): into the phase log of rank 0
+        phases.note("rank_start", {"process_age_s_before_init_process_group": round(phases.process_age() - (time.perf_counter() - t0), 3),
+                                   "init_process_group_s": round(time.perf_counter() - t0, 3), "backend": ctx.backend, "world": ctx.world,
+                                   "s_since_the_launcher_started_the_ranks": (round(time.time() - float(os.environ["GCI_LAUNCHED_AT"]), 3)
+                                                                               if os.environ.get("GCI_LAUNCHED_AT") else None)})
         pipeline.SHARD = ctx
         try:
             GCI(**args)

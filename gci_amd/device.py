@@ -82,7 +82,9 @@ class _Staging:
     the slot leaves by DMA on the copy stream, and is reused once that copy's event has passed.  One per engine, made once."""
     SLOT = int(os.environ.get("GCI_STAGING_SLOT_MB", "64")) << 20    # (page-locking costs ~0.3 s per GB on these hosts: a ring of 256 MB, not of 1.2 GB)
     SLOTS = int(os.environ.get("GCI_STAGING_SLOTS", "4"))
-    THREADS = int(os.environ.get("GCI_STAGING_THREADS", "12"))
+    # (copying threads: 6, 12 and 24 bring a tmpfs file to the device at 46 - 47 GB/s inside the command line, 48 at 57 GB/s -- the
+    #  link's own rate -- on the 256-thread hosts of the pool: profiles/r06e_staging_threads.txt; a quarter of the host's threads, at most 48)
+    THREADS = int(os.environ.get("GCI_STAGING_THREADS", str(min(48, max(6, (os.cpu_count() or 24) // 4)))))
 
     def __init__(self, engine=None):
         # the loop over the slots is the library's (staging.cpp: gci_stage_send) -- the Python one below stays behind GCI_STAGING=python

@@ -1251,7 +1251,7 @@ def _filter_sharded(paf_files, bam_files, prefix, map_qual, mq_cutoff, iden_perc
     classic = False
     try:
         while True:
-            inputs = paf_inputs + [sj.exchange_file(f, ji) for f, ji in enumerate(local)]
+            inputs = paf_inputs + sj.exchange_files(local)          # (ONE all-to-all for the records and names of every file)
             ivl, n_slots = sj.join(inputs, ovlp_percent)
             err = None
             try:

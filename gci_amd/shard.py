@@ -316,8 +316,9 @@ def gather_interval_lists(local: List[Tuple[int, int, int]], group=None) -> List
 class ShardedJoin:
     """The name-hash-sharded join of a contig-sharded run (gci_route_* in include/gci_hip.h, k_shard.hip).
 
-    Per step, with F input files:  F x [route the rank's passing records by (name hash >> 33) % world -> all-to-all of the
-    record buckets -> all-to-all of the name slots -> seal]  ->  gci_name_join over what arrived (the names this rank owns,
+    Per step, with F input files:  F x [route the rank's passing records by (name hash >> 33) % world into record buckets and name
+    slots]  ->  ONE all-to-all of all of them (exchange_files; exchange_file, the per-file form with two all-to-alls each, stays for
+    callers that take the files one at a time)  ->  F x seal  ->  gci_name_join over what arrived (the names this rank owns,
     from every contig)  ->  route the intervals by the owner of their contig -> all-to-all -> seal (global contig -> index in
     this rank's track layout).  Bucket capacities are fixed at construction (1.3 x the even share + slack): the collectives
     have one shape for every step and nothing is sized on the host per step; an overflow or a name longer than a routed
@@ -373,6 +374,7 @@ class ShardedJoin:
         self.status = torch.full((2 * self.n_files + 3,), -1, dtype=torch.int64, device=dev)   # route / seal per file, join, route, seal
 
     def grow(self, factor: float = 2.0) -> None:
+        self.send_all = self.recv_all = None
         self._alloc([int(c * factor) for c in self.rec_cap], int(self.ivl_cap * factor))
 
     def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
@@ -387,6 +389,44 @@ class ShardedJoin:
         self._all_to_all(self.recv_names[f], self.send_names[f])
         self.ops.route_seal_records(self.recv_recs[f], W, cap, self.status[2 * f + 1:2 * f + 2])
         return JoinInput(self.recv_recs[f], self.recv_names[f], self.name_off[f], 0)
+
+    def exchange_files(self, jis: Sequence["object"]) -> List["object"]:
+        """exchange_file() for ALL files of the step in ONE collective (round 6: a step was 2 F + 1 all-to-alls + 1 all-reduce
+        around ~1 ms of kernels per rank at 8 GPUs -- latency, not bytes; it is 3 collectives now whatever F is).  Every file's
+        record buckets and name slots are routed into their own arrays as before (the kernels keep their contiguous bucket
+        layout), packed side by side into one send buffer -- per destination rank [records of file 0 | ... | names of file 0 | ...],
+        2 F strided copies --, exchanged, and unpacked into the per-file arrays the seal step and the join read."""
+        from .device import JoinInput
+        W, F = self.world, self.n_files
+        if len(jis) != F:
+            raise ValueError("ShardedJoin.exchange_files: %d inputs for %d files" % (len(jis), F))
+        if getattr(self, "send_all", None) is None or int(self.send_all.shape[1]) != self._per_dest():
+            self.send_all = torch.zeros((W, self._per_dest()), dtype=torch.uint8, device=self.device)
+            self.recv_all = torch.zeros_like(self.send_all)
+        at = 0
+        spans = []
+        for f, ji in enumerate(jis):
+            cap = self.rec_cap[f]
+            self.ops.route_records(ji, W, cap, self.send_recs[f], self.send_names[f], self.ROUTE_NAME, self.status[2 * f:2 * f + 1])
+            nr, nn = (cap + 1) * 32, cap * self.ROUTE_NAME
+            self.send_all[:, at:at + nr] = self.send_recs[f].view(W, nr)
+            self.send_all[:, at + nr:at + nr + nn] = self.send_names[f].view(W, nn)
+            spans.append((at, nr, nn))
+            at += nr + nn
+        self._all_to_all(self.recv_all, self.send_all)
+        out = []
+        for f, (a, nr, nn) in enumerate(spans):
+            cap = self.rec_cap[f]
+            self.recv_recs[f].view(W, nr).copy_(self.recv_all[:, a:a + nr])
+            self.recv_names[f].view(W, nn).copy_(self.recv_all[:, a + nr:a + nr + nn])
+            self.ops.route_seal_records(self.recv_recs[f], W, cap, self.status[2 * f + 1:2 * f + 2])
+            out.append(JoinInput(self.recv_recs[f], self.recv_names[f], self.name_off[f], 0))
+        return out
+
+    def _per_dest(self) -> int:
+        return sum((c + 1) * 32 + c * self.ROUTE_NAME for c in self.rec_cap)
+
+    COLLECTIVES_PER_STEP = 3          # exchange_files (records + names of every file), the intervals, the all-reduce of the sums
 
     def join(self, inputs: Sequence["object"], ovlp_percent: float) -> Tuple[torch.Tensor, int]:
         """inputs: what exchange_file returned for every file, in the reference's file order (a PAF input whose records already

@@ -255,8 +255,25 @@ def _worker_sharded_join(rank, world, port, q):
             local.append(JoinInput(torch.from_numpy(recs.view(np.uint8).reshape(n, 32).copy()), torch.from_numpy(stream.copy()),
                                    torch.from_numpy(a["name_off"][mine].astype(np.int64)), 0))
         sj = shard.ShardedJoin(ops, [int(ji.recs.shape[0]) for ji in local], owner, torch.device("cpu"))
-        inputs = [sj.exchange_file(f, ji) for f, ji in enumerate(local)]
-        ivl, n_slots = sj.join(inputs, 0.9)
+        # ONE all-to-all for the records and names of every file (exchange_files) -- and the per-file form gives the same arrays
+        counted = {"n": 0}
+        real = shard.all_to_all_bytes
+
+        def counting(*a, **kw):
+            counted["n"] += 1
+            return real(*a, **kw)
+        shard.all_to_all_bytes = counting
+        try:
+            inputs = sj.exchange_files(local)
+            assert counted["n"] == 1
+            ivl, n_slots = sj.join(inputs, 0.9)
+            assert counted["n"] == 2 and shard.ShardedJoin.COLLECTIVES_PER_STEP == 3      # (+ the all-reduce of the sums)
+        finally:
+            shard.all_to_all_bytes = real
+        one_by_one = shard.ShardedJoin(ops, [int(ji.recs.shape[0]) for ji in local], owner, torch.device("cpu"))
+        for f, ji in enumerate(local):
+            x = one_by_one.exchange_file(f, ji)
+            assert torch.equal(x.recs, inputs[f].recs) and torch.equal(x.name_base, inputs[f].name_base)
         assert n_slots == ivl.shape[0] and sj.bytes_per_step() > 0
         sj.check(lambda w, what: None if w == (1 << 64) - 1 else (_ for _ in ()).throw(AssertionError((what, w))))
         cmap, mine_c = shard.contig_map_for(owner, rank)

@@ -50,19 +50,37 @@ def test_two_ranks_reproduce_the_reference(k, case, tmp_path):
     assert rest.replace(out, "{OUT}").replace(inp, "{IN}") == manifest(case)["stdout"]
 
 
-def test_gpus_switch_relaunches_itself(tmp_path):
-    """`python GCI.py --gpus 2 ...` (this implementation's own switch): the process re-launches itself under
-    torch.distributed.run, one process per GPU, and writes the reference's files."""
+@pytest.mark.parametrize("launcher", ["direct", "torchrun"])
+def test_gpus_switch_starts_the_ranks_itself(launcher, tmp_path):
+    """`python GCI.py --gpus 2 ...` (this implementation's own switch): the process starts two ranks of itself -- directly, with the
+    env:// rendezvous variables (cli._spawn_ranks; round 5 re-executed itself under torch.distributed.run, kept as
+    GCI_LAUNCHER=torchrun) -- and they write the reference's files; what rank 0 spent before its first kernel is in its phase log."""
+    import json
     case = "c3_two_bam"
-    out = str(tmp_path / "out")
+    out, ph = str(tmp_path / "out"), str(tmp_path / "phases.json")
     argv = cli_args(case, out)
-    env = dict(os.environ, GCI_DIST_BACKEND="gloo", GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    env = dict(os.environ, GCI_DIST_BACKEND="gloo", GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, GCI_PHASES=ph)
+    if launcher == "torchrun":
+        env["GCI_LAUNCHER"] = "torchrun"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "GCI.py"), "--gpus", "2"] + argv[1:], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got, want = read_outputs(out), expected(case)
     assert sorted(got) == sorted(want)
     for fn in want:
         assert got[fn] == want[fn], fn
+    start = json.load(open(ph))["notes"]["rank_start"]
+    assert start["world"] == 2 and start["init_process_group_s"] > 0
+    assert (start["s_since_the_launcher_started_the_ranks"] is not None) == (launcher == "direct")
+
+
+def test_a_failing_rank_ends_the_run(tmp_path):
+    """One rank of a directly started run dies (an unreadable input on every rank here: both exit with the reference's message): the
+    launcher leaves with a non-zero status instead of waiting for ever."""
+    argv = cli_args("c3_two_bam", str(tmp_path / "out"))
+    argv[argv.index("-r") + 1] = str(tmp_path / "no_such_reference.fa")
+    env = dict(os.environ, GCI_DIST_BACKEND="gloo", GCI_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "GCI.py"), "--gpus", "2"] + argv[1:], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "is not an available file" in r.stderr
 
 
 def test_two_ranks_fragmented_assembly(tmp_path):

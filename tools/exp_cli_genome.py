@@ -72,7 +72,8 @@ if os.environ.get("GCI_EXP_PROFILE"):
             print("%-26s rc %d wall %.2f s (in front of the phase log %.2f, behind its report %.2f) | " % (
                   label, r.returncode, wall, ph["notes"].get("process_age_s_when_the_phase_clock_started", -1),
                   wall - ph["notes"].get("process_age_s_at_the_report", wall)) + ", ".join("%s %.2f" % (k.strip()[:28], v) for k, v in ph["wall_s"].items() if k.strip().startswith(keep))
-                  + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0), flush=True)
+                  + " | gpu inflate %.2f" % ph["gpu_s"].get("bgzf_inflate + crc", 0)
+                  + " | mem %s" % ", ".join("%s %.1f GB" % (k[:12], v / 1e9) for k, v in (ph["notes"].get("device_memory") or {}).items() if isinstance(v, int) and v > 1e6), flush=True)
         if os.environ.get("GCI_EXP_NO_ROCPROF"):
             raise SystemExit(0)
         env = dict(os.environ, GCI_PHASES=os.path.join(tmp, "ph.json"), PYTHONPATH=ROOT, TMPDIR="/tmp")

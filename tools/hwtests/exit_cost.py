@@ -18,20 +18,28 @@ try:
         bams.append(p)
     fa = os.path.join(tmp, "ref.fa")
     synth.write_reference_fasta(fa, inp.contigs)
-    for label, extra in (("ordinary exit", {}), ("ordinary exit", {}), ("arena off", {"GCI_ARENA": "0"}), ("no reserve", {"GCI_RESERVE": "0"})):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sodir = tempfile.mkdtemp(prefix="gci_exit_so_", dir="/tmp")          # (/dev/shm is mounted noexec on the GPU boxes)
+    late, first = os.path.join(sodir, "libstamp_late.so"), os.path.join(sodir, "libstamp_first.so")
+    for out, name in ((late, "late"), (first, "preloaded")):
+        subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-DSTAMP_NAME=\"%s\"" % name, os.path.join(here, "exit_stamp.c"), "-o", out], check=True)
+    for label, extra in (("ordinary exit", {}), ("ordinary exit", {}), ("arena off", {"GCI_ARENA": "0"}), ("torch buffers", {"GCI_HBM": "torch"})):
         od = os.path.join(tmp, "out")
         shutil.rmtree(od, ignore_errors=True)
-        env = dict(os.environ, GCI_EXIT_TRACE="1", PYTHONPATH=ROOT)
+        env = dict(os.environ, GCI_EXIT_TRACE=late, LD_PRELOAD=first, PYTHONPATH=ROOT)
         env.update(extra)
         t0 = time.time()
         r = subprocess.run([sys.executable, os.path.join(ROOT, "GCI.py"), "-r", fa, "--hifi"] + bams + ["-d", od, "-t", str(hostio.default_threads())],
                            env=env, capture_output=True, text=True)
         t1 = time.time()
         st = {l.split()[1]: float(l.split()[2]) for l in r.stderr.splitlines() if l.startswith("exit-trace")}
-        if r.returncode or len(st) < 3:
-            print(label, "rc", r.returncode, r.stderr[-800:])
+        need = ("main_returned", "python_atexit", "late_atexit", "preloaded_destructor")
+        if r.returncode or any(k not in st for k in need):
+            print(label, "rc", r.returncode, sorted(st), r.stderr[-600:])
             continue
-        print("%-14s wall %.3f s | main() returned at %.3f | -> python atexit +%.3f | -> libc atexit (interpreter finalised) +%.3f | -> process gone +%.3f" % (
-            label, t1 - t0, st["main_returned"] - t0, st["python_atexit"] - st["main_returned"], st["libc_atexit"] - st["python_atexit"], t1 - st["libc_atexit"]), flush=True)
+        print("%-14s wall %.3f s | main() returned at %.3f | -> interpreter's atexit +%.3f | -> interpreter finalised, C handlers start +%.3f | -> "
+              "the preloaded library's destructor (HIP's teardown is over) +%.3f | -> process gone +%.3f" % (
+                  label, t1 - t0, st["main_returned"] - t0, st["python_atexit"] - st["main_returned"], st["late_atexit"] - st["python_atexit"],
+                  st["preloaded_destructor"] - st["late_atexit"], t1 - st["preloaded_destructor"]), flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
