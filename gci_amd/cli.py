@@ -291,6 +291,12 @@ def _spawn_ranks(n: int, entry: str, args: Sequence[str]) -> int:
                     status[r] = p.poll()
             bad = [s for s in status if s not in (None, 0)]
             if bad:                                                  # one rank failed: the others would wait in a collective for ever
+                deadline = time.time() + 3.0                         # (a failure every rank meets -- a bad argument -- ends them all by itself:
+                while time.time() < deadline and any(p.poll() is None for p in procs):       #  rank 0 gets to say why)
+                    time.sleep(0.01)
+                for r, p in enumerate(procs):
+                    if status[r] is None:
+                        status[r] = p.poll()
                 for r, p in enumerate(procs):
                     if status[r] is None:
                         p.terminate()
