@@ -124,12 +124,82 @@ __device__ __forceinline__ uint32_t pg_src_dword(const uint8_t* __restrict__ bam
     return w;
 }
 
-#define PG_LANES 16                    // lanes that copy one record into the page
+#define PG_LANES 8                     // lanes that copy one record into the page (16: half as many records in flight, +25 %)
 struct PgArgs {
     const uint8_t* bam; uint64_t n_bytes; const uint64_t* rec_off; uint32_t n_rec; int has_seq;
     const unsigned long long* S; const unsigned long long* B; const uint32_t* page_first;
     uint32_t page_bytes; uint64_t blob_off; uint8_t* out;
 };
+
+// What the copy phase needs of a record, left in LDS by the thread that measured it: where its three runs of bytes lie in the stream
+// (name + CIGAR directly behind the core, aux behind SEQ / QUAL) and where they go in the page.
+struct PgMeta {
+    uint64_t off, aux_off;
+    uint16_t n_cig, aux_len, at;       // (aux_len <= 1024 for the kinds that are copied, n_cig is 16 bits in BAM, at < page_bytes <= 32768)
+    uint8_t lrn, kind;
+};
+static_assert(sizeof(PgMeta) == 24, "PgMeta");
+#define PG_META_MAX 128                // records measured at a time (a page of 24 KiB holds ~58 HiFi records; tiny records: several passes)
+
+// pg_measure() from naturally aligned dword loads (the byte loads of the generic form are a dozen memory instructions per record):
+// the 36 core bytes as 10 aligned dwords re-aligned in registers.
+__device__ __forceinline__ PgRec pg_measure_fast(const uint8_t* __restrict__ bam, uint64_t n_bytes, uint64_t off, bool has_seq, uint32_t core[9])
+{
+    PgRec r;
+    r.kind = PG_MALFORMED; r.size = 48; r.blob = 0; r.lrn = r.n_cig = r.aux_len = 0; r.aux_off = 0; r.short_core = false;
+#pragma unroll
+    for (int d = 0; d < 9; d++) core[d] = 0u;
+    if (off + 36 > n_bytes) { r.short_core = true; return r; }
+    const uint8_t* p = bam + off;
+    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+    const uint8_t* end = bam + n_bytes;
+    uint32_t w[10];
+#pragma unroll
+    for (int d = 0; d < 10; d++) w[d] = (d < 9 || sh) ? pg_ldw(p - sh + 4 * d, end) : 0u;
+#pragma unroll
+    for (int d = 0; d < 9; d++) core[d] = __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh);
+    const int32_t block_size = (int32_t)core[0];
+    const uint32_t lrn = core[3] & 0xFFu, n_cig = core[4] & 0xFFFFu;
+    const int32_t l_seq = (int32_t)core[5];
+    const uint64_t rec_end = off + 4 + (uint64_t)(uint32_t)block_size;
+    const uint64_t aux_off = off + 36 + lrn + 4ull * n_cig + (has_seq ? (((uint64_t)(uint32_t)l_seq + 1) >> 1) + (uint64_t)(uint32_t)l_seq : 0ull);
+    if (block_size < 32 || rec_end > n_bytes || l_seq < 0 || aux_off > rec_end) return r;
+    r.lrn = lrn; r.n_cig = n_cig; r.aux_off = aux_off;
+    const uint64_t aux_len = rec_end - aux_off;
+    const uint32_t cig_at = a16(36 + lrn);
+    if (aux_len <= PG_MAX_REC && 4ull * n_cig <= PG_MAX_REC && a16(cig_at + a16(4 * n_cig) + (uint32_t)aux_len) <= PG_MAX_REC) {
+        r.kind = 0; r.size = a16(cig_at + a16(4 * n_cig) + (uint32_t)aux_len); r.aux_len = (uint32_t)aux_len;
+    } else if (aux_len <= PG_MAX_REC && a16(cig_at + 16 + (uint32_t)aux_len) <= PG_MAX_REC) {
+        r.kind = PG_EXT; r.size = a16(cig_at + 16 + (uint32_t)aux_len); r.blob = a16(4 * n_cig); r.aux_len = (uint32_t)aux_len;
+    } else {
+        r.kind = PG_OVERSIZE; r.size = 48; r.aux_len = (uint32_t)aux_len;
+        r.blob = (uint32_t)((36 + lrn + 4ull * n_cig + aux_len + 15ull) & ~15ull);
+    }
+    return r;
+}
+
+// `n` dwords of the `len` bytes at stream offset `src` into LDS at dst (4-byte aligned), by the PG_LANES lanes of a group: every lane
+// loads ONE naturally aligned dword per step and takes the dword behind it from its neighbour lane (the group's last lane loads that
+// one itself) -- half the memory instructions of two aligned loads per output dword.
+__device__ __forceinline__ void pg_copy_run(const uint8_t* __restrict__ bam, const uint8_t* end, uint64_t src, uint32_t len, uint8_t* dst, uint32_t gl)
+{
+    const uint32_t n = (len + 3u) >> 2;
+    const uint8_t* p = bam + src;
+    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+    const uint8_t* base = p - sh;
+    for (uint32_t d0 = 0; d0 < n; d0 += PG_LANES) {              // (n is uniform over the group: no lane leaves the shuffles)
+        const uint32_t d = d0 + gl;
+        const uint32_t lo = pg_ldw(base + 4ull * d, end);
+        uint32_t hi = (uint32_t)__shfl_down((int)lo, 1, PG_LANES);
+        if (gl == PG_LANES - 1) hi = sh ? pg_ldw(base + 4ull * d + 4, end) : 0u;
+        if (d < n) {
+            uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            const uint32_t left = len - 4u * d;
+            if (left < 4u) w &= (1u << (8u * left)) - 1u;
+            *reinterpret_cast<uint32_t*>(dst + 4 * d) = w;
+        }
+    }
+}
 
 __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
 {
@@ -139,6 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
     // to memory per page and most of this kernel's time
     __shared__ uint16_t s_blob_rec[GCI_PAGE_MAX_BYTES / 48];
     __shared__ uint32_t s_n_blob;
+    __shared__ PgMeta s_meta[PG_META_MAX];
     const uint32_t t = threadIdx.x, k = blockIdx.x;
     const uint32_t P = A.page_bytes;
     for (uint32_t i = t; i < P / 16; i += BLOCK) reinterpret_cast<uint4*>(page)[i] = make_uint4(0, 0, 0, 0);
@@ -146,45 +217,57 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
     const uint32_t first = A.page_first[k], cnt = A.page_first[k + 1] - first;
     const unsigned long long S0 = cnt ? A.S[first] : 0ull;
     const uint32_t rec0 = 16u + a16(2u * cnt);
+    const uint8_t* end = A.bam + A.n_bytes;
     __syncthreads();
     const uint32_t gl = t % PG_LANES, grp = t / PG_LANES;
     uint32_t used = rec0;
-    for (uint32_t j0 = 0; j0 < cnt; j0 += BLOCK / PG_LANES) {
-        const uint32_t j = j0 + grp;
-        if (j >= cnt) continue;
-        const uint32_t i = first + j;
-        const uint64_t off = A.rec_off[i];
-        const PgRec r = pg_measure(A.bam, A.n_bytes, off, A.has_seq != 0);
-        const uint32_t at = rec0 + (uint32_t)(A.S[i] - S0) - 2u * j;
-        uint8_t* dst = page + at;
-        if (gl == 0) *reinterpret_cast<uint16_t*>(page + 16 + 2 * j) = (uint16_t)(at >> 4);
-        const uint64_t blob_at = r.blob ? A.blob_off + A.B[i] : 0ull;
-        if (r.blob && gl == 0) s_blob_rec[atomicAdd(&s_n_blob, 1u)] = (uint16_t)j;
-        // the 36-byte core: dwords 1, 2, 4, 5 and the low half of 3 as in the stream; size, kind, aux_len, blob offset patched in
-        if (gl < 9) {
-            uint32_t w = r.short_core ? 0u : pg_src_dword(A.bam, A.n_bytes, off, 36, gl);
-            if (gl == 0) w = r.size;
-            if (gl == 3) w = (w & 0xFFFFu) | (r.kind << 16);
-            if (gl == 6) w = r.aux_len;
-            if (gl == 7) w = (uint32_t)blob_at;
-            if (gl == 8) w = (uint32_t)(blob_at >> 32);
-            if (r.kind == PG_MALFORMED && gl >= 6) w = 0u;
-            *reinterpret_cast<uint32_t*>(dst + 4 * gl) = w;
+    for (uint32_t m0 = 0; m0 < cnt; m0 += PG_META_MAX) {
+        const uint32_t mc = cnt - m0 < PG_META_MAX ? cnt - m0 : PG_META_MAX;
+        // ---- phase A: one thread per record measures it (offset -> 10 aligned dwords: the only dependent trips to memory of the
+        // page), leaves what the copy needs in LDS and writes the patched 36-byte core and the directory entry
+        if (t < mc) {
+            const uint32_t j = m0 + t, i = first + j;
+            const uint64_t off = A.rec_off[i];
+            const unsigned long long Si = A.S[i];
+            uint32_t core[9];
+            const PgRec r = pg_measure_fast(A.bam, A.n_bytes, off, A.has_seq != 0, core);
+            const uint32_t at = rec0 + (uint32_t)(Si - S0) - 2u * j;
+            const uint64_t blob_at = r.blob ? A.blob_off + A.B[i] : 0ull;
+            if (r.blob) s_blob_rec[atomicAdd(&s_n_blob, 1u)] = (uint16_t)j;
+            *reinterpret_cast<uint16_t*>(page + 16 + 2 * j) = (uint16_t)(at >> 4);
+            core[0] = r.size;
+            core[3] = (core[3] & 0xFFFFu) | (r.kind << 16);
+            core[6] = r.aux_len; core[7] = (uint32_t)blob_at; core[8] = (uint32_t)(blob_at >> 32);
+            if (r.kind == PG_MALFORMED) core[6] = core[7] = core[8] = 0u;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(page + at);
+#pragma unroll
+            for (int d = 0; d < 9; d++) dst[d] = core[d];
+            PgMeta mt;
+            mt.off = off; mt.aux_off = r.aux_off; mt.lrn = (uint8_t)r.lrn; mt.n_cig = (uint16_t)r.n_cig;
+            mt.aux_len = (uint16_t)(r.aux_len <= PG_MAX_REC ? r.aux_len : 0u);
+            mt.at = (uint16_t)at; mt.kind = (uint8_t)r.kind;
+            s_meta[t] = mt;
         }
-        if (r.kind == PG_MALFORMED || r.kind == PG_OVERSIZE) continue;
-        for (uint32_t d = gl; 4u * d < r.lrn; d += PG_LANES)
-            *reinterpret_cast<uint32_t*>(dst + 36 + 4 * d) = pg_src_dword(A.bam, A.n_bytes, off + 36, r.lrn, d);
-        uint32_t c = a16(36 + r.lrn);
-        if (r.kind == 0) {
-            for (uint32_t d = gl; d < r.n_cig; d += PG_LANES)
-                *reinterpret_cast<uint32_t*>(dst + c + 4 * d) = pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, d);
-            c += a16(4 * r.n_cig);
-        } else {                                                   // kind 1: the first operation stays visible in the page
-            if (gl == 0) *reinterpret_cast<uint32_t*>(dst + c) = pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, 0);
-            c += 16;
+        __syncthreads();
+        // ---- phase B: PG_LANES lanes per record copy its name, CIGAR and aux bytes; nothing here waits for anything but its own loads
+        for (uint32_t j0 = 0; j0 < mc; j0 += BLOCK / PG_LANES) {
+            const uint32_t jj = j0 + grp;
+            if (jj >= mc) continue;
+            const PgMeta mt = s_meta[jj];
+            if (mt.kind == PG_MALFORMED || mt.kind == PG_OVERSIZE) continue;
+            uint8_t* dst = page + mt.at;
+            pg_copy_run(A.bam, end, mt.off + 36, mt.lrn, dst + 36, gl);
+            uint32_t c = a16(36 + mt.lrn);
+            if (mt.kind == 0) {
+                pg_copy_run(A.bam, end, mt.off + 36 + mt.lrn, 4u * mt.n_cig, dst + c, gl);
+                c += a16(4u * mt.n_cig);
+            } else {                                               // kind 1: the first operation stays visible in the page
+                if (gl == 0) *reinterpret_cast<uint32_t*>(dst + c) = pg_src_dword(A.bam, A.n_bytes, mt.off + 36 + mt.lrn, 4u * mt.n_cig, 0);
+                c += 16;
+            }
+            pg_copy_run(A.bam, end, mt.aux_off, mt.aux_len, dst + c, gl);
         }
-        for (uint32_t d = gl; 4u * d < r.aux_len; d += PG_LANES)
-            *reinterpret_cast<uint32_t*>(dst + c + 4 * d) = pg_src_dword(A.bam, A.n_bytes, r.aux_off, r.aux_len, d);
+        __syncthreads();                                           // (s_meta is reused by the next pass)
     }
     if (cnt) used = rec0 + (uint32_t)(A.S[first + cnt] - S0) - 2u * cnt;
     if (t == 0) {

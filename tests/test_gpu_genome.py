@@ -88,10 +88,11 @@ def test_two_read_types_bam_and_paf_match_oracle(engine, oracle, config):
     gap masks, per-base max, three issue scans, region scans -- against the oracle's exact restriction to whole contigs
     (oracle.file1_on_contigs_mixed), tracks, issue lists and region lists.
 
-    GCI_TEST_TWO_TYPE_SCALE (default 0.1) scales every contig; `python bench.py --workload genome4 | diploid` runs the same at
-    full size (profiles/)."""
+    configs[3] runs at FULL size (25 contigs of CHM13, 3.1 Gb, HiFi + ONT with their PAFs: ~150 s, most of it the host-side
+    generation); configs[4] at 0.1 of every contig (GCI_TEST_TWO_TYPE_SCALE overrides both; at 1.0 it takes ~170 s and passes:
+    profiles/r06f_two_type_full_size_tests.txt; `python bench.py --workload diploid` runs it at full size)."""
     import bench
-    scale = float(os.environ.get("GCI_TEST_TWO_TYPE_SCALE", "0.1"))
+    scale = float(os.environ.get("GCI_TEST_TWO_TYPE_SCALE", "1.0" if config == 4 else "0.1"))
     inp = workloads.genome_two_type(config, scale, 40.0 if config == 4 else 100.0, 40.0 if config == 4 else 20.0)
     assert len(inp.contigs) == (25 if config == 4 else 46) and (inp.hifi.paf is not None) == (config == 4)
     w = bench.TwoTypeWorkload(engine, inp, "test")
