@@ -77,16 +77,6 @@ __device__ __forceinline__ PgRec pg_measure(const uint8_t* __restrict__ bam, uin
     return r;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pg_measure(const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
-                                                      uint32_t n_rec, int has_seq, uint32_t* __restrict__ cost, uint32_t* __restrict__ blob)
-{
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_rec) return;
-    const PgRec r = pg_measure(bam, n_bytes, rec_off[i], has_seq != 0);
-    cost[i] = r.size + 2u;
-    blob[i] = r.blob;
-}
-
 // page_first[k] = first record whose cost offset is >= k * Q (k = n_pages: n_rec)
 __global__ __launch_bounds__(BLOCK) void k_pg_first(const unsigned long long* __restrict__ S, uint32_t n_rec, uint32_t n_pages, uint32_t Q,
                                                     uint32_t* __restrict__ page_first)
@@ -124,7 +114,9 @@ __device__ __forceinline__ uint32_t pg_src_dword(const uint8_t* __restrict__ bam
     return w;
 }
 
-#define PG_LANES 8                     // lanes that copy one record into the page (16: half as many records in flight, +25 %)
+#ifndef PG_LANES
+#define PG_LANES 8                     // lanes that copy one record into the page
+#endif
 struct PgArgs {
     const uint8_t* bam; uint64_t n_bytes; const uint64_t* rec_off; uint32_t n_rec; int has_seq;
     const unsigned long long* S; const unsigned long long* B; const uint32_t* page_first;
@@ -178,25 +170,57 @@ __device__ __forceinline__ PgRec pg_measure_fast(const uint8_t* __restrict__ bam
     return r;
 }
 
-// `n` dwords of the `len` bytes at stream offset `src` into LDS at dst (4-byte aligned), by the PG_LANES lanes of a group: every lane
-// loads ONE naturally aligned dword per step and takes the dword behind it from its neighbour lane (the group's last lane loads that
-// one itself) -- half the memory instructions of two aligned loads per output dword.
-__device__ __forceinline__ void pg_copy_run(const uint8_t* __restrict__ bam, const uint8_t* end, uint64_t src, uint32_t len, uint8_t* dst, uint32_t gl)
+__global__ __launch_bounds__(BLOCK) void k_pg_measure(const uint8_t* __restrict__ bam, uint64_t n_bytes, const uint64_t* __restrict__ rec_off,
+                                                      uint32_t n_rec, int has_seq, uint32_t* __restrict__ cost, uint32_t* __restrict__ blob)
 {
-    const uint32_t n = (len + 3u) >> 2;
-    const uint8_t* p = bam + src;
-    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
-    const uint8_t* base = p - sh;
-    for (uint32_t d0 = 0; d0 < n; d0 += PG_LANES) {              // (n is uniform over the group: no lane leaves the shuffles)
-        const uint32_t d = d0 + gl;
-        const uint32_t lo = pg_ldw(base + 4ull * d, end);
-        uint32_t hi = (uint32_t)__shfl_down((int)lo, 1, PG_LANES);
-        if (gl == PG_LANES - 1) hi = sh ? pg_ldw(base + 4ull * d + 4, end) : 0u;
-        if (d < n) {
-            uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-            const uint32_t left = len - 4u * d;
-            if (left < 4u) w &= (1u << (8u * left)) - 1u;
-            *reinterpret_cast<uint32_t*>(dst + 4 * d) = w;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_rec) return;
+    uint32_t core[9];
+    const PgRec r = pg_measure_fast(bam, n_bytes, rec_off[i], has_seq != 0, core);      // (ten aligned dwords instead of a dozen byte loads)
+    cost[i] = r.size + 2u;
+    blob[i] = r.blob;
+}
+
+// A record's three runs of bytes -- name, CIGAR (kind 0 only), aux -- into the page in LDS, by the PG_LANES lanes of a group.  The
+// kernel is bound by the LATENCY of these loads (tools/hwtests/pages_ab.py: 0.60 of its 0.80 ms per quarter genome were this copy,
+// and neither fewer load instructions -- one aligned dword per lane, the one behind it from the neighbour lane -- nor 4 / 16 lanes
+// per record changed that: every step of the loop waited for its own loads before the next step's were issued).  So the three runs are
+// ONE flat sequence of output dwords, and a lane asks for PG_UNROLL of them -- two aligned dwords each: the one that holds the first
+// byte and the one behind it -- BEFORE it uses any: sixteen loads in flight per lane where there were two, a typical HiFi record
+// (9 + 70 + 10 dwords) in two steps instead of thirteen (0.74 -> 0.44 ms).
+#ifndef PG_UNROLL
+#define PG_UNROLL 8
+#endif
+struct PgRun { uint64_t src; uint32_t len, n, at; };     // stream offset, bytes, dwords, offset in the record's page image
+
+__device__ __forceinline__ void pg_copy_runs(const uint8_t* __restrict__ bam, const uint8_t* end, const PgRun r0, const PgRun r1, const PgRun r2,
+                                             uint8_t* dst, uint32_t gl)
+{
+    const uint32_t total = r0.n + r1.n + r2.n;
+    for (uint32_t f0 = 0; f0 < total; f0 += PG_UNROLL * PG_LANES) {
+        uint32_t lo[PG_UNROLL], hi[PG_UNROLL], sh[PG_UNROLL], left[PG_UNROLL], where[PG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PG_UNROLL; u++) {
+            const uint32_t f = f0 + u * PG_LANES + gl;
+            const bool in0 = f < r0.n, in1 = f < r0.n + r1.n;
+            const uint64_t src = in0 ? r0.src : in1 ? r1.src : r2.src;
+            const uint32_t len = in0 ? r0.len : in1 ? r1.len : r2.len;
+            const uint32_t d = in0 ? f : in1 ? f - r0.n : f - r0.n - r1.n;
+            const uint32_t at = in0 ? r0.at : in1 ? r1.at : r2.at;
+            const uint8_t* p = bam + src + 4ull * d;
+            sh[u] = (uint32_t)((uintptr_t)p & 3u);
+            left[u] = f < total ? len - 4u * d : 0u;
+            where[u] = at + 4u * d;
+            lo[u] = f < total ? pg_ldw(p - sh[u], end) : 0u;
+            hi[u] = (f < total && sh[u]) ? pg_ldw(p - sh[u] + 4, end) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PG_UNROLL; u++) {
+            if (left[u]) {
+                uint32_t w = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh[u]);
+                if (left[u] < 4u) w &= (1u << (8u * left[u])) - 1u;
+                *reinterpret_cast<uint32_t*>(dst + where[u]) = w;
+            }
         }
     }
 }
@@ -221,7 +245,11 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
     __syncthreads();
     const uint32_t gl = t % PG_LANES, grp = t / PG_LANES;
     uint32_t used = rec0;
+#ifdef PG_CUT_RECORDS                  // (measurement builds: zero fill + write-out only)
+    for (uint32_t m0 = 0; m0 < 0; m0 += PG_META_MAX) {
+#else
     for (uint32_t m0 = 0; m0 < cnt; m0 += PG_META_MAX) {
+#endif
         const uint32_t mc = cnt - m0 < PG_META_MAX ? cnt - m0 : PG_META_MAX;
         // ---- phase A: one thread per record measures it (offset -> 10 aligned dwords: the only dependent trips to memory of the
         // page), leaves what the copy needs in LDS and writes the patched 36-byte core and the directory entry
@@ -250,23 +278,24 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
         }
         __syncthreads();
         // ---- phase B: PG_LANES lanes per record copy its name, CIGAR and aux bytes; nothing here waits for anything but its own loads
+#ifndef PG_CUT_COPY                    // (measurement builds, tools/hwtests/pages_ab.py: the kernel without its copy phase)
         for (uint32_t j0 = 0; j0 < mc; j0 += BLOCK / PG_LANES) {
             const uint32_t jj = j0 + grp;
             if (jj >= mc) continue;
             const PgMeta mt = s_meta[jj];
             if (mt.kind == PG_MALFORMED || mt.kind == PG_OVERSIZE) continue;
             uint8_t* dst = page + mt.at;
-            pg_copy_run(A.bam, end, mt.off + 36, mt.lrn, dst + 36, gl);
-            uint32_t c = a16(36 + mt.lrn);
-            if (mt.kind == 0) {
-                pg_copy_run(A.bam, end, mt.off + 36 + mt.lrn, 4u * mt.n_cig, dst + c, gl);
-                c += a16(4u * mt.n_cig);
-            } else {                                               // kind 1: the first operation stays visible in the page
-                if (gl == 0) *reinterpret_cast<uint32_t*>(dst + c) = pg_src_dword(A.bam, A.n_bytes, mt.off + 36 + mt.lrn, 4u * mt.n_cig, 0);
-                c += 16;
-            }
-            pg_copy_run(A.bam, end, mt.aux_off, mt.aux_len, dst + c, gl);
+            const uint32_t c = a16(36u + mt.lrn);
+            PgRun r0, r1, r2;
+            r0.src = mt.off + 36; r0.len = mt.lrn; r0.n = (mt.lrn + 3u) >> 2; r0.at = 36;
+            r1.src = mt.off + 36 + mt.lrn; r1.at = c;
+            if (mt.kind == 0) { r1.len = 4u * mt.n_cig; r1.n = mt.n_cig; }
+            else { r1.len = mt.n_cig ? 4u : 0u; r1.n = mt.n_cig ? 1u : 0u; }       // kind 1: the first operation stays visible in the page
+            r2.src = mt.aux_off; r2.len = mt.aux_len; r2.n = (mt.aux_len + 3u) >> 2;
+            r2.at = c + (mt.kind == 0 ? a16(4u * mt.n_cig) : 16u);
+            pg_copy_runs(A.bam, end, r0, r1, r2, dst, gl);
         }
+#endif
         __syncthreads();                                           // (s_meta is reused by the next pass)
     }
     if (cnt) used = rec0 + (uint32_t)(A.S[first + cnt] - S0) - 2u * cnt;
