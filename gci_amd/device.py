@@ -577,6 +577,33 @@ class Engine:
         self.check_status("gci_bgzf_inflate_device")
         return out[:n_pre + total]
 
+    def bgzf_inflate_ahead(self, d_raw: Buffer, pos: np.ndarray, isize: np.ndarray, headroom: int, check_crc: bool = True
+                           ) -> Tuple[Buffer, Buffer, int]:
+        """bgzf_inflate() for a run of members of a file that goes through the device run by run, ENQUEUED and not waited for: the
+        inflated bytes go `headroom` bytes into a fresh buffer (in front of them the caller later puts the partial record the run
+        before ended in -- which it knows only when that run has been walked, while this run is already being inflated) and the
+        status word into a buffer of its own, which the caller checks (check_status_word) once it has made its stream wait for this
+        one.  -> (buffer of headroom + total bytes, status word, total)."""
+        n = int(isize.shape[0])
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(isize, out=off[1:])
+        total = int(off[n])
+        d_pos, d_off = self.to_device(np.ascontiguousarray(pos[:n + 1], dtype=np.uint64)), self.to_device(off)
+        want = max(int(headroom) + total, 1)
+        out = self.T.empty(((want + (1 << 28) - 1) >> 28) << 28 if want > (1 << 28) else want, self.T.uint8, self.device)
+        status = self.T.empty(1, self.T.int64, self.device)
+        self._chk(self.lib.gci_bgzf_inflate_device(self.ctx, self._p(d_raw), self._p(d_pos), self._p(d_off), n, ctypes.c_void_p(out.data_ptr() + int(headroom)),
+                                                   total, int(check_crc), self._p(status)), "gci_bgzf_inflate_device")
+        return out[:int(headroom) + total], status, total
+
+    def check_status_word(self, status: Buffer, what: str) -> None:
+        """check_status() over a status word of the caller's (read on the calling thread's current stream)."""
+        w = int(status.item()) & _M64
+        rec = ctypes.c_uint32(0)
+        st = self.lib.gci_decode_status(w, ctypes.byref(rec))
+        if st != 0:
+            raise GciError(st, "%s: %s (record %d)" % (what, self.lib.gci_strerror(st).decode(), rec.value), rec=int(rec.value))
+
     def inflate_stats(self) -> dict:
         """How the members of the last bgzf_inflate fared with the wave decoder (gci_bgzf_inflate_last_stats; synchronises)."""
         c = (ctypes.c_uint32 * 32)()

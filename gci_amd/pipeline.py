@@ -280,7 +280,7 @@ GPU_INFLATE_MAX = int(os.environ.get("GCI_GPU_INFLATE_MAX", str(32 << 30)))
 
 # A BAM whose inflated stream exceeds this many bytes is streamed through the GPU chunk by chunk (K1 per chunk,
 # compact records + packed names kept, SEQ/QUAL bytes dropped): real 40x whole-genome BAMs inflate to hundreds of GB.
-BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(8 << 30)))
+BAM_CHUNK_BYTES = int(os.environ.get("GCI_BAM_CHUNK_BYTES", str(4 << 30)))     # (8 GiB until round 6: the same wall time, 10 GB more device memory)
 
 
 # What the record filter runs over.  "pages" (default): the records are laid out as RECORD PAGES on the device first
@@ -542,58 +542,116 @@ def _bam_join_input_gpu(engine: Engine, path: str, raw, members: _Members, ref_s
         upload["pool"].shutdown()
         upload = None
     # the bytes of run k + 1 travel while run k is inflated and filtered (the first run may be on its way already:
-    # prefetch_member_tables)
+    # prefetch_member_tables); and (round 6) run k + 1 is INFLATED while run k is walked, paged and filtered: the inflate stays on this
+    # engine's stream, everything behind it runs on a second context with a stream of its own (_walk_engine), two output buffers in
+    # turns.  The partial record run k ends in is known only when run k has been walked -- by then run k + 1 is being inflated --, so
+    # every run is inflated INGEST_HEADROOM bytes into its buffer and the carried bytes are put in front of it afterwards.
     ahead = uploads if uploads is not None else _RunUploads(engine, raw, members)
+    T = engine.T
+    walk = _walk_engine(engine) if INGEST_OVERLAP else engine
     parts: List[JoinInput] = []
     carry, start, n_done = None, hdr.first_record, 0
+
+    def launch(k: int):
+        """Run k's inflate on the engine's stream, as soon as its bytes are on the device; None behind the last run."""
+        t_take = phases.now()
+        with phases.wall("  wait for the upload of a run (host blocked)"):
+            d_raw = ahead.take(k)
+        if d_raw is None:
+            return None
+        t_got = phases.now()
+        lo, hi = members.group(k)
+        pos, isz = members.pos, members.isz
+        p0 = int(pos[lo])
+        with phases.gpu("bgzf_inflate + crc"):
+            buf, status, total = engine.bgzf_inflate_ahead(d_raw, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], INGEST_HEADROOM, check_crc=BGZF_CRC)
+        ahead.release(k)
+        ev = T.Event()
+        ev.record(engine.stream)
+        if walk is not engine:
+            buf.record_stream(walk.stream)                   # (read over there: not handed out again before that is through)
+            status.record_stream(walk.stream)
+        phases.trace("run", k, t_take, t_got, phases.now())
+        return dict(buf=buf, status=status, lo=lo, ev=ev)
+
     try:
-        k = -1
-        while True:
-            k += 1
-            t_take = phases.now()
-            with phases.wall("  wait for the upload of a run (host blocked)"):
-                d_raw = ahead.take(k)
-            if d_raw is None:
-                break
-            t_got = phases.now()
-            lo, hi = members.group(k)
-            pos, isz = members.pos, members.isz
-            p0 = int(pos[lo])
-            try:
-                with phases.gpu("bgzf_inflate + crc"):
-                    d_buf = engine.bgzf_inflate(None, pos[lo:hi + 1] - np.uint64(p0), isz[lo:hi], check_crc=BGZF_CRC, prefix=carry, d_raw=d_raw)
-            except GciError as e:
-                if e.rec >= 0:
-                    e.rec += lo
-                raise
-            ahead.release(k)
-            del d_raw
-            phases.trace("run", k, t_take, t_got, phases.now())
-            if int(d_buf.shape[0]) <= start:                  # still inside the header
-                carry, start = None, start - int(d_buf.shape[0])
-                continue
-            with phases.gpu("record walk"):
-                d_off, used, ok = engine.bam_record_offsets(d_buf, start, n_ref)
-            if not ok:
-                return None
-            carry, start = (d_buf[used:].clone() if used < int(d_buf.shape[0]) else None), 0
-            if int(d_off.shape[0]) == 0:
-                continue
-            try:
-                ji = _filter_stream(engine, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
-            except GciError as e:
-                if e.rec >= 0:
-                    e.rec += n_done
-                raise
-            parts.append(_keep_part(engine, ji))
-            n_done += int(d_off.shape[0])
-            del d_buf, d_off, ji
+        k = 0
+        cur = launch(0)
+        while cur is not None:
+            nxt = launch(k + 1)                              # enqueued BEFORE run k is walked: the two overlap on the device
+            with T.stream(walk.stream):
+                walk.stream.wait_event(cur["ev"])
+                try:
+                    walk.check_status_word(cur["status"], "gci_bgzf_inflate_device")
+                except GciError as e:
+                    if e.rec >= 0:
+                        e.rec += cur["lo"]
+                    raise
+                buf = cur["buf"]
+                n_carry = int(carry.shape[0]) if carry is not None else 0
+                if n_carry > INGEST_HEADROOM:                 # (a record of more than the headroom: put together in a buffer of its own)
+                    whole = T.empty(n_carry + int(buf.shape[0]) - INGEST_HEADROOM, T.uint8, engine.device)
+                    whole[:n_carry].copy_(carry)
+                    whole[n_carry:].copy_(buf[INGEST_HEADROOM:])
+                    d_buf = whole
+                else:
+                    if n_carry:
+                        buf[INGEST_HEADROOM - n_carry:INGEST_HEADROOM].copy_(carry)
+                    d_buf = buf[INGEST_HEADROOM - n_carry:]
+                del buf
+                cur = None
+                if int(d_buf.shape[0]) <= start:              # still inside the header
+                    carry, start = None, start - int(d_buf.shape[0])
+                else:
+                    with phases.gpu("record walk"):
+                        d_off, used, ok = walk.bam_record_offsets(d_buf, start, n_ref)
+                    if not ok:
+                        return None
+                    carry, start = (d_buf[used:].clone() if used < int(d_buf.shape[0]) else None), 0
+                    if int(d_off.shape[0]):
+                        try:
+                            ji = _filter_stream(walk, d_buf, d_off, True, ref_sel, filt, rec_idx_base=n_done)
+                        except GciError as e:
+                            if e.rec >= 0:
+                                e.rec += n_done
+                            raise
+                        kept = _keep_part(walk, ji)
+                        if walk is not engine:                # (made in the walk stream's order, joined in the engine's)
+                            for t in (kept.recs, kept.name_base, kept.name_off):
+                                t.record_stream(engine.stream)
+                        parts.append(kept)
+                        n_done += int(d_off.shape[0])
+                        del ji
+                    del d_off
+                del d_buf
             phases.trace("run_done", k, phases.now())
+            cur, nxt = nxt, None
+            k += 1
     finally:
         ahead.close()
+        if walk is not engine:
+            engine.stream.wait_stream(walk.stream)           # (what the join reads was written over there)
     if carry is not None:
         raise bamfmt.BAMError("truncated BAM: %d trailing bytes do not form a record" % int(carry.shape[0]))
     return _concat_parts(engine, parts)
+
+
+# A large file's runs: run k + 1 is inflated while run k is walked, paged and filtered on a second context (GCI_INGEST_OVERLAP=0: one
+# after the other on one stream, as in rounds 3 - 5); the bytes kept free in front of every run's inflated bytes for the record the run
+# before it ended in (a longer one -- an ONT read of megabases -- is put together in a buffer of its own).
+INGEST_OVERLAP = os.environ.get("GCI_INGEST_OVERLAP", "1") != "0"
+INGEST_HEADROOM = int(os.environ.get("GCI_INGEST_HEADROOM", str(8 << 20)))
+_WALK_ENGINES: Dict[int, Engine] = {}
+
+
+def _walk_engine(engine: Engine) -> Engine:
+    """The context that walks, pages and filters a run while `engine` inflates the next one: a stream and scratch of its own (a gci_ctx is
+    one stream and is not shared between streams), the same provider and device."""
+    with _ENGINE_LOCK:
+        w = _WALK_ENGINES.get(id(engine))
+        if w is None:
+            w = _WALK_ENGINES[id(engine)] = Engine(engine.device.index or 0, stream=engine.T.Stream(engine.device))
+        return w
 
 
 _DROP_QUEUE = None
