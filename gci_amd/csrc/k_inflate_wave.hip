@@ -486,6 +486,10 @@ __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __rest
                 // End-of-block codes the lane passes: on a wrong path they mean nothing (a fixed code has one in 128 symbols), so the lane
                 // goes on; the first four with the symbols listed in front of them (position << 16 | count).
                 uint32_t eb0 = NONE, eb1 = NONE, eb2 = NONE, eb3 = NONE, n_eb = 0;
+                // The first step of the piece that met bits no code matches (kind 3: it moves on by one bit and lists nothing).  On a wrong
+                // path that means nothing; on the lane's TRUE path -- decided below -- the member is damaged, and is handed to the lane
+                // decoder, which says so (with the CRC check off, such a member whose lengths still added up was accepted).
+                uint32_t bad_rel = NONE;
                 Reader R;
                 R.seek(S, active ? start : 0u);
                 if (active) {
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __rest
                         S.ckpt[((g != grain ? g : NCK) << 6) | (uint32_t)lane] = (rel << 16) | os;     // (no branch: a step in a grain it has noted writes the spare row)
                         grain = g;
                         const Sym s = step(S, C, R, nb);
+                        if (__ballot(s.kind == 3u)) { if (s.kind == 3u && bad_rel == NONE) bad_rel = rel; }      // (rare: the whole wave skips this)
                         if (__ballot(s.kind == 2u)) {                      // (rare: the whole wave skips this)
                             if (s.kind == 2u) {
                                 const uint32_t v = (rel << 16) | os;
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __rest
                 // front of it found, and all of it is decided side by side; a lane that took a piece over (or has more end-of-block codes
                 // than it lists) sends the wave down the chain one lane at a time.
                 uint32_t ss = 0, cs = 0;                                                     // the lane's share of its list: [ss, ss + cs)
-                bool live = false, own_eob = false, block_ends = false, chain_bad = false;
+                bool live = false, own_eob = false, block_ends = false, chain_bad = false, undecodable = false;
                 uint32_t own_end = 0;                                                        // behind the lane's own end-of-block code, if it ends the block
                 int E = 0;
                 const uint32_t base = (uint32_t)lane * PIECE;
@@ -583,6 +588,9 @@ __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __rest
                                 const Sym y = step(S, C, R, nb);
                                 own_end = base + (own >> 16) + y.used;
                             } else cs = os + xs - ss;
+                            // an undecodable step inside what this lane contributes: from where its true path enters the piece to its
+                            // end-of-block code (the last lane) or the end of the piece
+                            undecodable = bad_rel != NONE && bad_rel >= from_f - base && (!own_eob || bad_rel < (own >> 16));
                         }
                         block_ends = (bool)__shfl((int)(own != NONE || x_eob), e, 64);
                     }
@@ -614,6 +622,7 @@ __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __rest
                                 const Sym y = step(S, C, R, nb);
                                 own_end = base + (own >> 16) + y.used;
                             } else cs = os + xs - ss;
+                            undecodable = bad_rel != NONE && bad_rel >= from_cur - base && (!own_eob || bad_rel < (own >> 16));
                         }
                         if (!(bool)__shfl((int)active, (int)cur, 64)) { chain_bad = true; st = 10u; break; }
                         if ((bool)__shfl((int)own_eob, (int)cur, 64)) { E = (int)cur; block_ends = true; break; }
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(64, 4) void k_inflate_symbols(const uint8_t* __rest
                     }
                 }
                 if (chain_bad) break;
+                if (__ballot(live && undecodable)) { st = ST_UNDECODABLE; break; }
                 if (cut == 3u) { st = __ballot(ss == NONE - 3u) ? ST_LANES : ST_LENGTH; break; }
                 if (__ballot(live && (ss + cs > MAXS || ss + cs < ss))) { st = 9u; break; }   // (a share the list did not hold)
                 IW_T(t_ch, tt);

@@ -86,29 +86,13 @@ class _Staging:
     #  link's own rate -- on the 256-thread hosts of the pool: profiles/r06e_staging_threads.txt; a quarter of the host's threads, at most 48)
     THREADS = int(os.environ.get("GCI_STAGING_THREADS", str(min(48, max(6, (os.cpu_count() or 24) // 4)))))
 
-    def __init__(self, engine=None):
-        # the loop over the slots is the library's (staging.cpp: gci_stage_send) -- the Python one below stays behind GCI_STAGING=python
-        self.native = None
+    def __init__(self, engine):
+        # the loop over the slots is the library's (staging.cpp: gci_stage_send)
         self.engine = engine
         self._fds = {}
-        if engine is not None and os.environ.get("GCI_STAGING", "native") != "python":
-            h = ctypes.c_void_p()
-            engine._chk(engine.lib.gci_stage_create(engine.ctx, self.SLOT, self.SLOTS, self.THREADS, ctypes.byref(h)), "gci_stage_create")
-            self.native = h
-            return
-        self.slots = [None] * self.SLOTS
-        self.views = [None] * self.SLOTS
-        self.free_at = [None] * self.SLOTS
-        self.next = 0
-        self.pool = ThreadPoolExecutor(self.THREADS)
-        self.lock = threading.Lock()            # (two senders -- the assembly and the first run of a BAM file -- take slots in turns)
-        self.urgent = 0
-
-        def pin(k):                             # page-locking 64 MB takes ~20 ms: the slots side by side, the first piece waits for one
-            self.slots[k] = engine.T.pinned(self.SLOT)
-            self.views[k] = self.slots[k].numpy()
-
-        self.pinned = [self.pool.submit(pin, k) for k in range(self.SLOTS)]
+        h = ctypes.c_void_p()
+        engine._chk(engine.lib.gci_stage_create(engine.ctx, self.SLOT, self.SLOTS, self.THREADS, ctypes.byref(h)), "gci_stage_create")
+        self.native = h
 
     def close(self):
         """The ring's threads, pinned slots and events (gci_stage_free), and the descriptors the pread path kept open."""
@@ -149,42 +133,7 @@ class _Staging:
             self.engine._chk(self.engine.lib.gci_stage_send(self.engine.ctx, self.native, ctypes.c_void_p(src), p1 - p0, ctypes.c_void_p(dst.data_ptr()),
                                                             ctypes.c_void_p(stream.cuda_stream), forget, 1 if urgent else 0), "gci_stage_send")
             return
-        if urgent:
-            with self.lock:
-                self.urgent += 1
-        try:
-            self._send(raw, p0, p1, dst, stream, urgent)
-        finally:
-            if urgent:
-                with self.lock:
-                    self.urgent -= 1
-
-    def _send(self, raw, p0, p1, dst, stream, urgent) -> None:
-        import time
-        for a in range(p0, p1, self.SLOT):
-            b = min(p1, a + self.SLOT)
-            while not urgent and self.urgent > 0:
-                time.sleep(0.0005)
-            with self.lock:
-                k = self.next
-                self.next = (k + 1) % self.SLOTS
-                if self.free_at[k] is not None:
-                    self.free_at[k].synchronize()              # (the helper thread waits; the device and the main thread do not)
-                self.pinned[k].result()
-                view = self.views[k]
-                step = -(-(b - a) // self.THREADS)
-                step = (step + 4095) // 4096 * 4096
-                jobs = [self.pool.submit(np.copyto, view[x - a:min(b, x + step) - a], raw[x:min(b, x + step)]) for x in range(a, b, step)]
-                for j in jobs:
-                    j.result()
-                _forget_pages(raw, a, b)
-                T = self.engine.T
-                with T.stream(stream):
-                    dst[a - p0:b - p0].copy_(self.slots[k][:b - a], non_blocking=True)
-                    ev = T.Event()
-                    ev.record(stream)
-                self.free_at[k] = ev
-
+        raise GciError(_lib.GCI_E_INVALID, "the staging ring of this engine has been closed")
 
 
 @dataclass

@@ -425,7 +425,7 @@ class _RunUploads:
         self.bufs = [None, None]
         self.copy = engine.copy_stream()
         self.freed = [None, None]                            # main-stream event behind the last kernel that read the buffer
-        self.staged = isinstance(raw, np.memmap) and os.environ.get("GCI_UPLOAD", "staged") == "staged"
+        self.staged = isinstance(raw, np.memmap)               # (a mapped file goes through the ring of pinned slots; an array in memory as it is)
         self.staging = engine.staging() if self.staged else None
         self.last_sent = threading.Event()                   # the last run's bytes are all enqueued: the ring is the next file's
         self.pool = ThreadPoolExecutor(1)
@@ -710,7 +710,7 @@ def prefetch_member_tables(paths: Sequence[str]) -> None:
     # them takes on the device, and their threads would compete with the ones that stage that file's bytes: a quarter as many)
     many = hostio.default_threads()
     by_fd = os.environ.get("GCI_BGZF_TABLE", "mmap") == "pread"     # (measured at genome size on tmpfs: pread 1.7 - 2.2 s, the mapping 1.2 - 1.4 s)
-    first_run = os.environ.get("GCI_FIRST_RUN_AHEAD", "1") != "0" and os.environ.get("GCI_UPLOAD", "staged") == "staged"
+    first_run = os.environ.get("GCI_FIRST_RUN_AHEAD", "1") != "0"
 
     def table(path, raw, threads, limit=None, known=None):
         """The member table up to byte `limit` (None: all of the file); known = the table of a beginning of the file: only what lies
@@ -1094,10 +1094,9 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     except GciError as e:
         _reraise_like_reference(e)
     track = early_track if (early_track is not None and int(early_track.shape[0]) == max(engine.total, 1)) else engine.new_track()
-    text_on_device = bool(write) and DEPTH_GZ != "gpu"
     with phases.wall("depth_build"), phases.gpu("depth build"):
-        fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=text_on_device, want_sums=True,
-                                         issue=issue_hint, counted=True, want_runs=bool(write) and not text_on_device)
+        fused = engine.depth_build_fused(ivl, count, flank_len, track, want_text=False, want_sums=True,
+                                         issue=issue_hint, counted=True, want_runs=bool(write))
     depths = DepthTracks(engine, targets_length, track)
     depths._fresh_sums = fused["sums"]
     if issue_hint is not None:
@@ -1107,10 +1106,7 @@ def filter(paf_files=[], bam_files=[], prefix="GCI", map_qual=30, mq_cutoff=50, 
     if write:
         print(f'Writing depths into "{directory}/{prefix}.depth.gz" ...')
         with phases.wall("write_depth_gz (deflate on the device, D2H, file)"):
-            if text_on_device:
-                _write_depth_text(directory, prefix, depths, fused["text"], fused["text_off"], threads)
-            else:
-                _write_depth_members(directory, prefix, depths, from_build=True)     # (the build just above kept its run lists)
+            _write_depth_members(directory, prefix, depths, from_build=True)         # (the build just above kept its run lists)
         print("Writing depths done!!!\n\n")
     return depths, targets_length
 
@@ -1395,20 +1391,16 @@ def _reraise_like_reference(e: GciError):
 # Contig-sharded runs: "range" (default) = PAF files by byte range, "whole" = every rank the whole files.
 PAF_SHARDING = os.environ.get("GCI_PAF_SHARDING", "range")
 
-# How `{prefix}.depth.gz` is produced.  "gpu" (default): the device writes the gzip members straight from the track
-# (gci_depth_deflate_*: no text buffer, a few MB cross PCIe).  "host": the device renders the text, host threads gzip it.
-DEPTH_GZ = os.environ.get("GCI_DEPTH_GZ", "gpu")
+# `{prefix}.depth.gz` is written by the device: gzip members straight from the track or from the run lists the build kept
+# (gci_depth_deflate_*: no text buffer, a few MB cross PCIe).  (Rounds 1 - 5 kept the older way -- text rendered on the device, gzip on
+# host threads -- behind GCI_DEPTH_GZ=host; the text seam itself, gci_depth_text_*, stays in the library and in bench.py's step.)
 
 
 def write_depth(directory=".", prefix="GCI", depths: DepthTracks = None, threads=1) -> None:
     """`{directory}/{prefix}.depth.gz`: '>contig' line then one decimal per line (GCI.py:99-143), as a multi-member
     gzip (any gzip whose payload equals the reference's text is a valid .depth.gz)."""
     depths._bind()
-    if DEPTH_GZ == "gpu" or _sharded():
-        _write_depth_members(directory, prefix, depths)
-        return
-    text, offs = depths.engine.depth_text(depths.track)
-    _write_depth_text(directory, prefix, depths, text, offs, threads)
+    _write_depth_members(directory, prefix, depths)
 
 
 def _write_depth_members(directory, prefix, depths: DepthTracks, from_build: bool = False) -> None:
@@ -1446,23 +1438,6 @@ def _write_depth_members(directory, prefix, depths: DepthTracks, from_build: boo
             f.write(blob)
             layout[t] = (at, f.tell())
     phases.note("depth_gz_layout:" + path, layout)    # (a harness that checks single contigs of a genome-size file reads this)
-
-
-def _write_depth_text(directory, prefix, depths: DepthTracks, text, offs, threads) -> None:
-    """Frame the GPU-rendered text as a multi-member gzip: '>contig' member, then the contig's lines compressed in
-    parallel by the native host helper (any gzip whose payload equals the text is a valid .depth.gz)."""
-    from . import hostio
-    host = text.cpu().numpy()
-    path = f"{directory}/{prefix}.depth.gz"
-    if os.path.exists(path):
-        os.remove(path)
-    nthreads = hostio.pick_threads(threads)
-    with open(path, "wb") as f:
-        for c, t in enumerate(depths.targets):
-            if depths.lengths[c] == 0:
-                continue              # (as above)
-            f.write(hostio.gzip_members((">%s\n" % t).encode(), threads=1))
-            f.write(hostio.gzip_members(host[int(offs[c]):int(offs[c + 1])], threads=nthreads))
 
 
 def merge_two_type_depth(hifi_depths: DepthTracks = None, nano_depths: DepthTracks = None, prefix="GCI_two_type",

@@ -36,7 +36,7 @@ if os.environ.get("GCI_EXP_PROFILE"):
         fa = os.path.join(tmp, "ref.fa")
         synth.write_reference_fasta(fa, inp.contigs)
         # A/B of host-side switches on the same files and the same box, unprofiled: wall time and the phase log
-        variants = (("product (staged upload)", {}), ("GCI_UPLOAD=pageable", {"GCI_UPLOAD": "pageable"}), ("staged, pages kept", {"GCI_FORGET_PAGES": "0"}),
+        variants = (("product (staged upload)", {}), ("staged, pages kept", {"GCI_FORGET_PAGES": "0"}),
                     ("product again", {}))
         if os.environ.get("GCI_EXP_AB"):                   # e.g. '[["16 GiB runs", {"GCI_BAM_CHUNK_BYTES": "17179869184"}]]'
             variants = [("product", {})] + [(a, b) for a, b in json.loads(os.environ["GCI_EXP_AB"])] + [("product again", {})]
