@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paf-published-gb", default="",
+                    help="--workload genome4 --cli: write the two PAF files at these sizes in GB, 'HIFI,ONT' (the reference's published CHM13 "
+                         "run: '3.6,48'), by a cg:Z: tag behind every line; default: the PAF texts as generated (0.7 GB together)")
     ap.add_argument("--paf-gb", type=float, default=20.0,
                     help="--workload paf: size of the PAF text (the reference's CHM13 run reads a 48 GB ONT PAF and a 3.6 GB HiFi PAF)")
     ap.add_argument("--workload", choices=("genome", "chr19", "genome4", "diploid", "paf"), default="genome",
@@ -1457,6 +1460,9 @@ def cli_genome_number(inp, oracle_on_chosen, verbose=True):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+PAF_PUBLISHED_GB = {}      # bench.py --paf-published-gb H,N -> {"hifi": H, "nano": N}
+
+
 def cli_two_type_number(inp, chosen, verbose=True):
     """SURVEY.md 8(d) number (3) for the two-read-type command line (GCI.py:1007-1026 -- the run the reference's only published timing,
     images/RAM_t32.png, is about: per read type one BAM and one PAF): the inputs as real files on tmpfs -- BGZF BAMs with SEQ / QUAL of
@@ -1484,7 +1490,13 @@ def cli_two_type_number(inp, chosen, verbose=True):
             files[kind] = [p]
             if t.paf is not None:
                 q = os.path.join(tmp, "%s.paf" % kind)
-                t.paf.tofile(q)
+                # --paf-published-gb "3.6,48": the PAF files at the sizes of the reference's published CHM13 run (README.md:321,
+                # images/RAM_t32.png) -- the same lines, every one with a cg:Z: tag of the length that makes up the size
+                want = PAF_PUBLISHED_GB.get(kind)
+                if want:
+                    workloads.write_paf_at_size(q, t.paf, int(want * 1e9))
+                else:
+                    t.paf.tofile(q)
                 files[kind].append(q)
             files[kind + "_made"] = made
         fa = os.path.join(tmp, "assembly.fa")
@@ -1648,6 +1660,9 @@ def paf_number(args):
 
 def main():
     args = parse_args()
+    if args.paf_published_gb:
+        h, n = (float(x) for x in args.paf_published_gb.split(","))
+        PAF_PUBLISHED_GB.update({"hifi": h, "nano": n})
     if args.only_step:
         args.no_e2e = args.no_cpu_baseline = args.no_cli_genome = True
     if args.workload == "paf":

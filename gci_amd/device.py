@@ -657,10 +657,29 @@ class Engine:
         compact record per query seen so far (files < i included: the reference never resets its block table) and
         pointing at the names inside the uploaded text.  Raises GciError with .rec = the 1-based line the reference
         would have raised on (GCI_E_MALFORMED: IndexError / ValueError, GCI_E_ZERO_DIV: ZeroDivisionError)."""
-        bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
-        ends = np.cumsum([b.shape[0] for b in bufs], dtype=np.uint64) if bufs else np.zeros(0, np.uint64)
-        text = np.concatenate(bufs) if bufs and int(ends[-1]) else np.zeros(1, np.uint8)
-        return self.paf_filter_text(self.to_device(text), ends, targets, map_qual, mq_cutoff, iden_percent)
+        sizes = [int(os.path.getsize(p)) for p in paths]
+        ends = np.cumsum(sizes, dtype=np.uint64) if sizes else np.zeros(0, np.uint64)
+        total = int(ends[-1]) if sizes else 0
+        if total < (256 << 20):
+            bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
+            text = np.concatenate(bufs) if bufs and total else np.zeros(1, np.uint8)
+            return self.paf_filter_text(self.to_device(text), ends, targets, map_qual, mq_cutoff, iden_percent)
+        # Files of GBs (the reference's published CHM13 run reads a 3.6 GB HiFi and a 48 GB ONT PAF, README.md:321): their bytes go
+        # from the mapped files through the ring of pinned slots straight to their places in ONE device buffer -- round 5 read every
+        # file into host memory, concatenated the arrays and handed the result to a pageable copy: three passes over 52 GB of host
+        # memory and 104 GB of it held, before the first byte moved
+        d_text = self.T.empty(total, self.T.uint8, self.device)
+        staging, copy = self.staging(), self.copy_stream()
+        copy.wait_stream(self.stream)
+        at = 0
+        for p, n in zip(paths, sizes):
+            if n:
+                raw = np.memmap(p, dtype=np.uint8, mode="r")
+                staging.send(raw, 0, n, d_text[at:at + n], copy)
+                del raw
+            at += n
+        self.stream.wait_stream(copy)
+        return self.paf_filter_text(d_text, ends, targets, map_qual, mq_cutoff, iden_percent)
 
     def paf_filter_text(self, d_text: Buffer, ends: np.ndarray, targets: Sequence[str], map_qual: int, mq_cutoff: int,
                         iden_percent: float) -> List[JoinInput]:

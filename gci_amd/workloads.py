@@ -495,3 +495,37 @@ def write_bgzf_from_heads(path: str, heads: np.ndarray, offsets: np.ndarray, see
         f.seek(nbytes)
         f.write(bgzf.BGZF_EOF)
     return {"bytes": nbytes + len(bgzf.BGZF_EOF), "inflated_bytes": inflated, "members": members, "seconds": time.time() - t0}
+
+
+def write_paf_at_size(path: str, paf_text: np.ndarray, target_bytes: int, chunk_lines: int = 4096) -> int:
+    """The PAF text `paf_text` (its lines end in '\\n') written with a `cg:Z:` tag behind every line so that the file is about
+    `target_bytes` long -- the shape of the PAFs the reference's published CHM13 run read (3.6 GB for HiFi, 48 GB for ONT: minimap2 -c
+    writes every alignment's CIGAR as text, tens of KB per ONT line).  The twelve mandatory columns, the only ones GCI.py:218-229 reads,
+    are untouched; the tag's text is a repeating CIGAR-like pattern (its content is never looked at).  Written chunk by chunk: the
+    file never exists in this process's memory.  -> bytes written."""
+    text = np.ascontiguousarray(paf_text, dtype=np.uint8)
+    ends = np.flatnonzero(text == 10) + 1
+    n = int(ends.shape[0])
+    if n == 0:
+        text.tofile(path)
+        return int(text.shape[0])
+    starts = np.concatenate([[0], ends[:-1]])
+    extra = max(0, (int(target_bytes) - int(text.shape[0])) // n - 6)
+    pattern = np.frombuffer((b"1234=1X56=2I789=1D" * (extra // 18 + 2))[:max(extra, 0)], dtype=np.uint8)
+    tag = np.concatenate([np.frombuffer(b"\tcg:Z:", dtype=np.uint8), pattern, np.frombuffer(b"\n", dtype=np.uint8)]) if extra > 0 else None
+    written = 0
+    with open(path, "wb") as f:
+        if tag is None:
+            f.write(text.tobytes())
+            return int(text.shape[0])
+        ends_l, starts_l = ends.tolist(), starts.tolist()
+        for a in range(0, n, chunk_lines):
+            b = min(n, a + chunk_lines)
+            parts = []
+            for i in range(a, b):                                    # the line without its newline, then the tag (which brings one)
+                parts.append(text[starts_l[i]:ends_l[i] - 1])
+                parts.append(tag)
+            buf = np.concatenate(parts)
+            f.write(buf.data)
+            written += int(buf.shape[0])
+    return written
