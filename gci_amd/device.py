@@ -84,7 +84,9 @@ class _Staging:
     SLOTS = int(os.environ.get("GCI_STAGING_SLOTS", "4"))
     # (copying threads: 6, 12 and 24 bring a tmpfs file to the device at 46 - 47 GB/s inside the command line, 48 at 57 GB/s -- the
     #  link's own rate -- on the 256-thread hosts of the pool: profiles/r06e_staging_threads.txt; a quarter of the host's threads, at most 48)
-    THREADS = int(os.environ.get("GCI_STAGING_THREADS", str(min(48, max(6, (os.cpu_count() or 24) // 4)))))
+    # As one rank of N on a node (LOCAL_WORLD_SIZE, set by `GCI.py --gpus N` and by torch.distributed.run) a ring takes its share of that.
+    _RANKS = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)) if "RANK" in os.environ else 1
+    THREADS = int(os.environ.get("GCI_STAGING_THREADS", str(min(48, max(4, (os.cpu_count() or 24) // (4 * _RANKS))))))
 
     def __init__(self, engine):
         # the loop over the slots is the library's (staging.cpp: gci_stage_send)
@@ -660,7 +662,7 @@ class Engine:
         sizes = [int(os.path.getsize(p)) for p in paths]
         ends = np.cumsum(sizes, dtype=np.uint64) if sizes else np.zeros(0, np.uint64)
         total = int(ends[-1]) if sizes else 0
-        if total < (256 << 20):
+        if total < int(os.environ.get("GCI_PAF_STAGE_MIN", str(256 << 20))):          # (small files: read, put together, one copy)
             bufs = [np.fromfile(p, dtype=np.uint8) for p in paths]
             text = np.concatenate(bufs) if bufs and total else np.zeros(1, np.uint8)
             return self.paf_filter_text(self.to_device(text), ends, targets, map_qual, mq_cutoff, iden_percent)

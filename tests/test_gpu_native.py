@@ -251,3 +251,16 @@ def test_command_line_provider_switch_and_streamed_ingestion(tmp_path):
         r, _ = _run_cli(cli_args(case, out), env)
         assert r.returncode == 0, r.stderr[-2000:]
         assert read_outputs(out) == want, env
+
+
+def test_paf_files_through_the_staging_ring(tmp_path):
+    """PAF files of GBs travel from their mappings through the ring of pinned slots to their places in one device buffer
+    (Engine.paf_filter; GCI_PAF_STAGE_MIN makes the golden cases' small files go that way): the same files as the small-file way."""
+    for case in ("c4_two_paf", "c5_two_type"):
+        out = str(tmp_path / case)
+        r, _ = _run_cli(cli_args(case, out), dict(GCI_PAF_STAGE_MIN="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        got, want = read_outputs(out), expected(case)
+        assert sorted(got) == sorted(want)
+        for fn in want:
+            assert got[fn] == want[fn], (case, fn)

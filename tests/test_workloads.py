@@ -114,3 +114,23 @@ def test_phase_log_is_off_unless_asked_for(tmp_path):
     assert set(rep["wall_s"]) == {"a", "b"} and rep["gpu_s"] == {} and rep["total_s"] >= rep["wall_s"]["a"]
     import json
     assert json.load(open(tmp_path / "p.json"))["notes"] == rep["notes"]
+
+
+def test_paf_written_at_a_given_size_keeps_its_twelve_columns(tmp_path):
+    """workloads.write_paf_at_size: the PAF text with a cg:Z: tag behind every line so that the file has the size asked for (the
+    reference's published run read a 3.6 GB and a 48 GB PAF): the same lines in the same order, their first twelve columns untouched,
+    one tag per line, the size within a line's worth of the target -- and the oracle's PAF filter sees the same file."""
+    from gci_amd import workloads
+    rs = synth.simulate_reads((("a", 400_000), ("b", 90_000)), 12, "ont", seed=5)
+    text = synth.to_paf_text(rs, seed=9)
+    p = str(tmp_path / "big.paf")
+    target = 40 * int(text.shape[0])
+    n = workloads.write_paf_at_size(p, text, target, chunk_lines=37)
+    out = open(p, "rb").read()
+    assert n == len(out) and abs(len(out) - target) < 2 * target // max(1, out.count(b"\n")) + 64
+    a, b = text.tobytes().split(b"\n")[:-1], out.split(b"\n")[:-1]
+    assert len(a) == len(b) > 100
+    for x, y in zip(a, b):
+        assert y.startswith(x + b"\tcg:Z:") and y.split(b"\t")[:12] == x.split(b"\t")[:12]
+    small = str(tmp_path / "small.paf")
+    assert workloads.write_paf_at_size(small, text, 10) == text.shape[0] and open(small, "rb").read() == text.tobytes()
