@@ -12,7 +12,8 @@ from gci_amd.formats import bam as bamfmt
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-rs = synth.simulate_reads((("chr19", int(61_707_364 * scale)),), 40, "hifi", seed=synth.seed_for(2, 0))
+kind = os.environ.get("READS", "hifi")                    # READS=ont: ONT reads (longer, noisier qualities: members that deflate less)
+rs = synth.simulate_reads((("chr19", int(61_707_364 * scale)),), 40, kind, seed=synth.seed_for(2, 0))
 stream, _ = synth.to_bam_stream(rs, seq_qual="random", seed=7)
 p = os.path.join(tempfile.mkdtemp(), "x.bam")
 bamfmt.write_bam_stream(p, stream, level=int(os.environ.get("BAM_LEVEL", "1")), threads=hostio.default_threads())
@@ -31,8 +32,8 @@ for _ in range(reps):
     torch.cuda.synchronize()
     ms.append(a.elapsed_time(b))
 ok = np.array_equal(out.cpu().numpy(), stream)
-print("mode %s: %d members, %.1f MB -> %.1f MB; calls (tables up + inflate + crc) %s ms -> %.1f GB/s out; equal to the stream: %s; %s" % (
-    os.environ.get("GCI_INFLATE", "wave"), isz.shape[0], raw.shape[0] / 1e6, stream.shape[0] / 1e6, ["%.2f" % x for x in ms],
+print("reads %s, level %s, mode %s: %d members, %.1f MB -> %.1f MB; calls (tables up + inflate + crc) %s ms -> %.1f GB/s out; equal to the stream: %s; %s" % (
+    kind, os.environ.get("BAM_LEVEL", "1"), os.environ.get("GCI_INFLATE", "wave"), isz.shape[0], raw.shape[0] / 1e6, stream.shape[0] / 1e6, ["%.2f" % x for x in ms],
     stream.shape[0] / 1e6 / min(ms), ok, e.inflate_stats()), flush=True)
 if not ok:
     got = out.cpu().numpy()
