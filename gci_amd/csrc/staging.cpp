@@ -8,8 +8,6 @@
 // the uploads are what the command line waits for: the loop is native.
 #include "gci_ctx.hpp"
 
-#include <sched.h>
-#include <stdio.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -46,56 +44,12 @@ struct gci_stage {
     std::atomic<int> io_error{0};
     int forget = 0;                         // the parts' pages are dropped from the page table as they have been read
     long page = 4096;
-    bool bind = false;                      // the copying threads run on the CPUs of the device's NUMA node (cpus)
-    cpu_set_t cpus;
 };
 
 namespace {
 
-// The CPUs of the NUMA node the device hangs off (empty set: unknown, one node, or GCI_STAGING_NUMA=0).  The copying threads write
-// the pinned slots -- which the runtime places on the device's node -- and read page cache that lies on either socket of a two-socket
-// host: bound to the device's node their writes are local and half their reads remote; left to the scheduler, half of them write
-// across the sockets.
-bool device_node_cpus(int device, cpu_set_t* set)
-{
-    CPU_ZERO(set);
-    const char* e = getenv("GCI_STAGING_NUMA");
-    if (e && e[0] == '0') return false;
-    char bdf[64] = {0}, path[256];
-    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return false; }
-    for (char* c = bdf; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
-    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
-    FILE* f = fopen(path, "r");
-    if (!f) return false;
-    int node = -1;
-    if (fscanf(f, "%d", &node) != 1) node = -1;
-    fclose(f);
-    if (node < 0) return false;
-    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    f = fopen(path, "r");
-    if (!f) return false;
-    int n = 0, a = 0, b = 0;
-    char sep = 0;
-    while (fscanf(f, "%d", &a) == 1) {                                     // "0-63,128-191"
-        b = a;
-        if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b) != 1) b = a; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, set); n++; }
-        if (sep != ',') break;
-    }
-    fclose(f);
-    // (only a subset of the host's CPUs, and one this process may run on at all)
-    cpu_set_t mine;
-    if (sched_getaffinity(0, sizeof mine, &mine) == 0) {
-        int both = 0;
-        for (int c = 0; c < CPU_SETSIZE; c++) { if (CPU_ISSET(c, set) && !CPU_ISSET(c, &mine)) CPU_CLR(c, set); if (CPU_ISSET(c, set)) both++; }
-        n = both;
-    }
-    return n >= 4 && n < (int)sysconf(_SC_NPROCESSORS_ONLN);
-}
-
 void worker(gci_stage* s)
 {
-    if (s->bind) (void)sched_setaffinity(0, sizeof s->cpus, &s->cpus);    // (this thread only)
     uint64_t seen = 0;
     for (;;) {
         {
@@ -155,7 +109,6 @@ extern "C" int gci_stage_create(gci_ctx* ctx, uint64_t slot_bytes, int n_slots, 
         // (page-locking 64 MB takes ~20 ms: the slots are locked when they are first needed, not all of them in front of the first byte)
         if (hipEventCreateWithFlags(&s->ev[(size_t)k], hipEventDisableTiming) != hipSuccess) { delete s; return GCI_E_HIP; }
     }
-    s->bind = device_node_cpus(ctx->device, &s->cpus);
     for (int t = 0; t < threads; t++) s->workers.emplace_back(worker, s);
     *out = s;
     return GCI_OK;
