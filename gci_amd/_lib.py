@@ -19,7 +19,7 @@ GCI_TILE = 4096
 GCI_MAX_JOIN_FILES = 16
 PAGE_MAX_REC, PAGE_MAX_BYTES, PAGE_BYTES_DEFAULT = 1024, 32768, 24576
 REC_PASS, REC_HQ = 1, 2
-PROF_COUNT = 17
+PROF_COUNT = 19
 PROF_DEPTH_SCAN = 5          # k_tile_build: the pass that writes the depth track (+ text)
 PROF_TILE_PASS1 = 13
 PROF_TILE_DENSE = 14         # k_tile_dense<1>, <2>: the tiles the event-list kernels left over

@@ -120,7 +120,7 @@ extern "C" const char* gci_last_error(gci_ctx* ctx) { return ctx ? ctx->err.c_st
 static const char* const PROF_NAMES[GCI_PROF_COUNT] = {
     "k_bam_filter", "k_join_insert", "k_join_fold", "k_evt_count+scatter", "k_scan2", "k_tile_build", "k_gap_mask",
     "k_max2", "k_issue_scan", "k_text_count", "k_text_write", "k_depth_sum", "memset", "k_tile_pass1", "k_tile_dense",
-    "k_part1+k_part2 (radix partition of the join)", "k_join_part"};
+    "k_part1+k_part2 (radix partition of the join)", "k_join_part", "k_pg_measure+scans+k_pg_first (record pages: sizes)", "k_pg_write (record pages)"};
 
 extern "C" int gci_profile_enable(gci_ctx* ctx, int mask)
 {

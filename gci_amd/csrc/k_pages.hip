@@ -354,13 +354,17 @@ extern "C" int gci_bam_pages_size(gci_ctx* ctx, const uint8_t* d_stream, uint64_
     uint32_t* blob = cost + n_rec + 1;
     unsigned long long* S = (unsigned long long*)ctx->pg_scan.p;
     unsigned long long* B = S + n_rec + 1;
-    hipLaunchKernelGGL(k_pg_measure, dim3((n_rec + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_stream, n_bytes, d_rec_off, n_rec,
-                       has_seq, cost, blob);
-    LAUNCHCHK("k_pg_measure");
-    int r = device_exclusive_scan<uint32_t, unsigned long long>(ctx, cost, S, (unsigned long long*)ctx->blk_u64.p, n_rec, true);
-    if (r) return r;
-    r = device_exclusive_scan<uint32_t, unsigned long long>(ctx, blob, B, (unsigned long long*)ctx->blk_u64.p, n_rec, true);
-    if (r) return r;
+    int r;
+    {
+        ProfScope _ps(ctx, GCI_PROF_PAGES_SIZE);
+        hipLaunchKernelGGL(k_pg_measure, dim3((n_rec + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, d_stream, n_bytes, d_rec_off, n_rec,
+                           has_seq, cost, blob);
+        LAUNCHCHK("k_pg_measure");
+        r = device_exclusive_scan<uint32_t, unsigned long long>(ctx, cost, S, (unsigned long long*)ctx->blk_u64.p, n_rec, true);
+        if (r) return r;
+        r = device_exclusive_scan<uint32_t, unsigned long long>(ctx, blob, B, (unsigned long long*)ctx->blk_u64.p, n_rec, true);
+        if (r) return r;
+    }
     unsigned long long tail[2], b_total;
     HIPCHK(hipMemcpyAsync(tail, S + n_rec - 1, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&b_total, B + n_rec, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -395,8 +399,11 @@ extern "C" int gci_bam_pages_write(gci_ctx* ctx, const uint8_t* d_stream, uint64
     A.blob_off = ctx->pg_blob_off; A.out = d_out;
     const uint64_t need = ctx->pg_blob_off + ctx->pg_blob_bytes + 16;        // = h_out[1] of the size call
     if (cap < need) return GCI_E_CAPACITY;
-    hipLaunchKernelGGL(k_pg_write, dim3(ctx->pg_n_pages), dim3(BLOCK), ctx->pg_page_bytes, ctx->stream, A);
-    LAUNCHCHK("k_pg_write");
+    {
+        ProfScope _ps(ctx, GCI_PROF_PAGES_WRITE);
+        hipLaunchKernelGGL(k_pg_write, dim3(ctx->pg_n_pages), dim3(BLOCK), ctx->pg_page_bytes, ctx->stream, A);
+        LAUNCHCHK("k_pg_write");
+    }
     // the 16 zero bytes directly behind the blob (k_cigar_chunks fetches whole 16-byte pieces)
     HIPCHK(hipMemsetAsync(d_out + need - 16, 0, 16, ctx->stream));
     return GCI_OK;

@@ -179,7 +179,7 @@ enum {
     GCI_PROF_BAM_FILTER = 0, GCI_PROF_JOIN_INSERT, GCI_PROF_JOIN_FOLD, GCI_PROF_DEPTH_DIFF, GCI_PROF_SCAN_TILES,
     GCI_PROF_DEPTH_SCAN, GCI_PROF_GAP_MASK, GCI_PROF_MAX2, GCI_PROF_ISSUE_SCAN, GCI_PROF_TEXT_COUNT,
     GCI_PROF_TEXT_WRITE, GCI_PROF_DEPTH_SUM, GCI_PROF_MEMSET, GCI_PROF_TILE_PASS1, GCI_PROF_TILE_DENSE, GCI_PROF_PARTITION,
-    GCI_PROF_JOIN_PART, GCI_PROF_COUNT
+    GCI_PROF_JOIN_PART, GCI_PROF_PAGES_SIZE, GCI_PROF_PAGES_WRITE, GCI_PROF_COUNT
 };
 int gci_profile_enable(gci_ctx* ctx, int mask);
 int gci_profile_read(gci_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches, int reset);
