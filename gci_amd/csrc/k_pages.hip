@@ -175,8 +175,9 @@ __global__ __launch_bounds__(BLOCK) void k_pg_measure(const uint8_t* __restrict_
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_rec) return;
-    uint32_t core[9];
-    const PgRec r = pg_measure_fast(bam, n_bytes, rec_off[i], has_seq != 0, core);      // (ten aligned dwords instead of a dozen byte loads)
+    // (byte loads: pg_measure_fast's ten aligned dwords were measured SLOWER here -- 0.181 against 0.155 ms per quarter genome for the size
+    //  pass: one lane per record, every lane its own cache line, and the dozen byte loads of a lane hit that one line)
+    const PgRec r = pg_measure(bam, n_bytes, rec_off[i], has_seq != 0);
     cost[i] = r.size + 2u;
     blob[i] = r.blob;
 }
@@ -225,7 +226,10 @@ __device__ __forceinline__ void pg_copy_runs(const uint8_t* __restrict__ bam, co
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
+#ifndef PG_BLOCK
+#define PG_BLOCK BLOCK                 // threads of a k_pg_write workgroup
+#endif
+__global__ __launch_bounds__(PG_BLOCK) void k_pg_write(const PgArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t page[];
     // which records of the page leave something in the blob (nearly none of a HiFi file): the pass over the blob below looks
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
     __shared__ PgMeta s_meta[PG_META_MAX];
     const uint32_t t = threadIdx.x, k = blockIdx.x;
     const uint32_t P = A.page_bytes;
-    for (uint32_t i = t; i < P / 16; i += BLOCK) reinterpret_cast<uint4*>(page)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = t; i < P / 16; i += PG_BLOCK) reinterpret_cast<uint4*>(page)[i] = make_uint4(0, 0, 0, 0);
     if (t == 0) s_n_blob = 0;
     const uint32_t first = A.page_first[k], cnt = A.page_first[k + 1] - first;
     const unsigned long long S0 = cnt ? A.S[first] : 0ull;
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
         __syncthreads();
         // ---- phase B: PG_LANES lanes per record copy its name, CIGAR and aux bytes; nothing here waits for anything but its own loads
 #ifndef PG_CUT_COPY                    // (measurement builds, tools/hwtests/pages_ab.py: the kernel without its copy phase)
-        for (uint32_t j0 = 0; j0 < mc; j0 += BLOCK / PG_LANES) {
+        for (uint32_t j0 = 0; j0 < mc; j0 += PG_BLOCK / PG_LANES) {
             const uint32_t jj = j0 + grp;
             if (jj >= mc) continue;
             const PgMeta mt = s_meta[jj];
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
     }
     __syncthreads();
     uint4* g = reinterpret_cast<uint4*>(A.out + (uint64_t)k * P);
-    for (uint32_t i = t; i < P / 16; i += BLOCK) g[i] = reinterpret_cast<const uint4*>(page)[i];
+    for (uint32_t i = t; i < P / 16; i += PG_BLOCK) g[i] = reinterpret_cast<const uint4*>(page)[i];
     // what the page leaves in the blob: CIGAR words (kind 1) or heads-form records (kind 2), record after record, all threads
     const uint32_t n_blob = s_n_blob;                            // (written before the barrier above)
     for (uint32_t b = 0; b < n_blob; b++) {
@@ -315,12 +319,12 @@ __global__ __launch_bounds__(BLOCK) void k_pg_write(const PgArgs A)
         if (!r.blob) continue;
         uint32_t* o = reinterpret_cast<uint32_t*>(A.out + A.blob_off + A.B[i]);
         if (r.kind == PG_EXT) {
-            for (uint32_t d = t; d < r.blob / 4; d += BLOCK)
+            for (uint32_t d = t; d < r.blob / 4; d += PG_BLOCK)
                 o[d] = d < r.n_cig ? pg_src_dword(A.bam, A.n_bytes, off + 36 + r.lrn, 4 * r.n_cig, d) : 0u;
         } else {
             // heads form: core (block_size shortened), name + CIGAR (contiguous in the stream), aux (behind SEQ / QUAL there)
             const uint32_t head = 36 + r.lrn + 4 * r.n_cig, total = head + r.aux_len;
-            for (uint32_t d = t; d < r.blob / 4; d += BLOCK) {
+            for (uint32_t d = t; d < r.blob / 4; d += PG_BLOCK) {
                 uint32_t w = 0;
                 const uint32_t b0 = 4 * d;
                 if (b0 + 4 <= head) w = pg_src_dword(A.bam, A.n_bytes, off, head, d);
@@ -401,7 +405,7 @@ extern "C" int gci_bam_pages_write(gci_ctx* ctx, const uint8_t* d_stream, uint64
     if (cap < need) return GCI_E_CAPACITY;
     {
         ProfScope _ps(ctx, GCI_PROF_PAGES_WRITE);
-        hipLaunchKernelGGL(k_pg_write, dim3(ctx->pg_n_pages), dim3(BLOCK), ctx->pg_page_bytes, ctx->stream, A);
+        hipLaunchKernelGGL(k_pg_write, dim3(ctx->pg_n_pages), dim3(PG_BLOCK), ctx->pg_page_bytes, ctx->stream, A);
         LAUNCHCHK("k_pg_write");
     }
     // the 16 zero bytes directly behind the blob (k_cigar_chunks fetches whole 16-byte pieces)
